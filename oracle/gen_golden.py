@@ -1,0 +1,576 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the UNMODIFIED reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container (where /root/reference
+exists); the GPU box never runs this.  Output: small .npz fixtures under
+tests/golden/ that pin (a) the CPU oracle in oracle/jorldy_oracle.py and
+(b) the HIP path, because the reference's own tests hold no golden vectors
+(SURVEY.md §4 / §8c).
+
+How the reference is exercised without editing it:
+  * the tree is copied (minus Unity binaries) to a scratch dir and imported
+    from there with PYTHONDONTWRITEBYTECODE (importing `core` rewrites
+    `_*_dict.txt` files, SURVEY.md §8c "import trap");
+  * intermediate values inside `learn()` are captured with a `sys.settrace`
+    line tap that snapshots named locals, and with forward hooks on the
+    output `nn.Linear`s so d(loss)/d(logits) is retained;
+  * numpy / torch global RNGs are seeded explicitly before every call so the
+    HIP mirror can re-draw the identical sample indices.
+
+Usage:  python oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import inspect
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+
+def _to_np(v):
+    import torch
+
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy().copy()
+    if isinstance(v, np.ndarray):
+        return v.copy()
+    if isinstance(v, (list, tuple)) and v and isinstance(v[0], (int, float, np.integer, np.floating)):
+        return np.asarray(v)
+    if isinstance(v, (int, float, bool, np.integer, np.floating)):
+        return np.asarray(v)
+    return None
+
+
+class LineTap:
+    """Snapshot named locals of `func` each time execution reaches a source line
+    containing one of the given marker substrings (BEFORE that line executes),
+    and once more at return (key '<return>')."""
+
+    def __init__(self, func, markers):
+        self.code = func.__code__
+        src, first = inspect.getsourcelines(func)
+        self.line_to_key = {}
+        for key, (needle, names) in markers.items():
+            hits = [i for i, s in enumerate(src) if needle in s]
+            assert hits, f"marker {needle!r} not found in {func.__qualname__}"
+            self.line_to_key[first + hits[0]] = (key, names)
+        self.ret_names = markers.get("<return>", (None, ()))[1] if "<return>" in markers else ()
+        self.records = {}  # key -> list of dict
+        self.on_line = {}  # key -> callback(frame)
+
+    def _local(self, frame, event, arg):
+        if event == "line" and frame.f_lineno in self.line_to_key:
+            key, names = self.line_to_key[frame.f_lineno]
+            if key in self.on_line:
+                self.on_line[key](frame)
+            snap = {}
+            for n in names:
+                if n in frame.f_locals:
+                    a = _to_np(frame.f_locals[n])
+                    if a is not None:
+                        snap[n] = a
+            self.records.setdefault(key, []).append(snap)
+        return self._local
+
+    def _global(self, frame, event, arg):
+        if event == "call" and frame.f_code is self.code:
+            return self._local
+        return None
+
+    def __enter__(self):
+        sys.settrace(self._global)
+        return self
+
+    def __exit__(self, *a):
+        sys.settrace(None)
+
+
+def flat(prefix, d, out):
+    for k, v in d.items():
+        out[f"{prefix}{k}"] = v
+
+
+def sd_to_np(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------
+# buffers
+# ----------------------------------------------------------------------------
+def gen_buffers(out_dir):
+    from core.buffer import ReplayBuffer, RolloutBuffer, PERBuffer
+
+    rng = np.random.RandomState(1234)
+
+    def mk(n, S=4):
+        trs = []
+        for _ in range(n):
+            trs.append(
+                {
+                    "state": rng.randn(1, S).astype(np.float32),
+                    "action": rng.randint(0, 3, size=(1, 1)),
+                    "reward": rng.randn(1, 1),
+                    "next_state": rng.randn(1, S).astype(np.float32),
+                    "done": rng.rand(1, 1) < 0.2,
+                }
+            )
+        return trs
+
+    # --- ReplayBuffer: ring wrap + seeded sample ---------------------------------
+    out = {}
+    buf = ReplayBuffer(16)
+    buf.first_store = False
+    trs = mk(23)
+    buf.store(trs[:10])
+    buf.store(trs[10:])
+    out["n_store"] = np.asarray([10, 13])
+    for k in trs[0]:
+        out[f"in_{k}"] = np.concatenate([t[k] for t in trs], 0)
+    np.random.seed(7)
+    s = buf.sample(8)
+    for k, v in s.items():
+        out[f"sample_{k}"] = v
+    out["buffer_index"] = np.asarray(buf.buffer_index)
+    out["buffer_counter"] = np.asarray(buf.buffer_counter)
+    np.savez(os.path.join(out_dir, "replay_buffer.npz"), **out)
+
+    # --- RolloutBuffer ---------------------------------------------------------------
+    out = {}
+    rb = RolloutBuffer()
+    rb.first_store = False
+    trs = mk(12)
+    rb.store(trs[:5])
+    rb.store(trs[5:])
+    s = rb.sample()
+    for k in trs[0]:
+        out[f"in_{k}"] = np.concatenate([t[k] for t in trs], 0)
+    for k, v in s.items():
+        out[f"sample_{k}"] = v
+    out["size_after"] = np.asarray(rb.size)
+    np.savez(os.path.join(out_dir, "rollout_buffer.npz"), **out)
+
+    # --- PERBuffer scenario: N=64, wrap, sample, write-back, actor priorities ------
+    # (every transition of one buffer carries "priority" or none does: the key is stacked on sample)
+    for name, N, n_ops, B, with_prio in (
+        ("per_n64", 64, 6, 16, False),
+        ("per_n1000", 1000, 8, 32, False),
+        ("per_n1000_prio", 1000, 6, 32, True),
+    ):
+        out = {}
+        per = PERBuffer(N, uniform_sample_prob=0.05 if N == 64 else 1e-3)
+        per.first_store = False
+        prng = np.random.RandomState(99 + N)
+        ops = []
+        step = 0
+        for op in range(n_ops):
+            # store a chunk (some ops carry explicit actor-side priorities)
+            n_st = int(prng.randint(N // 3, N // 2 + 5))
+            trs = mk(n_st)
+            if with_prio:
+                pr = prng.rand(n_st) * 3.0
+                for t, p in zip(trs, pr):
+                    t["priority"] = np.asarray([[p]])  # (1,1) like ape_x.py:174-199
+                out[f"op{op}_store_prio"] = pr
+            for k in ("state", "reward"):
+                out[f"op{op}_store_{k}"] = np.concatenate([t[k] for t in trs], 0)
+            out[f"op{op}_n_store"] = np.asarray(n_st)
+            per.store(trs)
+            out[f"op{op}_tree_after_store"] = per.sum_tree.copy()
+            out[f"op{op}_maxp_after_store"] = np.asarray(per.max_priority)
+            out[f"op{op}_tree_index"] = np.asarray(per.tree_index)
+            # sample
+            seed = 1000 + op
+            np.random.seed(seed)
+            beta = 0.4 + 0.1 * op
+            tr, w, idx, sp, mp = per.sample(beta, B)
+            out[f"op{op}_seed"] = np.asarray(seed)
+            out[f"op{op}_beta"] = np.asarray(beta)
+            out[f"op{op}_weights"] = w
+            out[f"op{op}_indices"] = idx
+            out[f"op{op}_sampled_p"] = np.asarray(sp)
+            out[f"op{op}_mean_p"] = np.asarray(mp)
+            out[f"op{op}_sample_state"] = tr["state"]
+            out[f"op{op}_sample_reward"] = tr["reward"]
+            # priority write-back the way the agents do it: fp32 tensor -> .item()
+            newp = (prng.rand(B).astype(np.float32) ** 2 * 2.0).astype(np.float32)
+            if op == 1:  # force duplicate indices in one batch (last write wins)
+                idx = idx.copy()
+                idx[1] = idx[0]
+                idx[5] = idx[0]
+            for i, p in zip(idx, newp):
+                per.update_priority(float(p), int(i))
+            out[f"op{op}_upd_idx"] = idx
+            out[f"op{op}_upd_p"] = newp
+            out[f"op{op}_tree_after_update"] = per.sum_tree.copy()
+            out[f"op{op}_maxp_after_update"] = np.asarray(per.max_priority)
+        out["N"] = np.asarray(N)
+        out["B"] = np.asarray(B)
+        out["usp"] = np.asarray(per.uniform_sample_prob)
+        out["n_ops"] = np.asarray(n_ops)
+        out["with_prio"] = np.asarray(with_prio)
+        np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **out)
+
+
+# ----------------------------------------------------------------------------
+# PPO
+# ----------------------------------------------------------------------------
+def gen_ppo(out_dir):
+    import torch
+    from core.agent.ppo import PPO
+
+    cases = [
+        # name, S, A, hidden, W, T, batch, n_epoch, continuous
+        ("ppo_disc_small", 4, 3, 32, 4, 16, 16, 2, False),
+        ("ppo_disc_cartpole", 4, 2, 64, 8, 128, 256, 3, False),
+        ("ppo_cont_small", 5, 3, 32, 4, 16, 32, 2, True),
+        ("ppo_cont_hopper", 11, 3, 64, 4, 64, 64, 2, True),
+    ]
+    for name, S, A, H, W, T, B, E, cont in cases:
+        torch.manual_seed(11)
+        np.random.seed(11)
+        agent = PPO(
+            state_size=S,
+            action_size=A,
+            hidden_size=H,
+            network="continuous_policy_value" if cont else "discrete_policy_value",
+            optim_config={"name": "adam", "lr": 2.5e-4},
+            batch_size=B,
+            n_step=T,
+            n_epoch=E,
+            _lambda=0.95,
+            epsilon_clip=0.1,
+            vf_coef=1.0,
+            ent_coef=0.01,
+            clip_grad_norm=1.0,
+            gamma=0.99,
+            run_step=100000,
+            num_workers=W,
+            device="cpu",
+        )
+        # perturb the heads so pi is not ~uniform / value not ~0 (policy gain is 0.01)
+        with torch.no_grad():
+            for p in agent.network.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        sd0 = sd_to_np(agent.network.state_dict())
+
+        rng = np.random.RandomState(5)
+        M = W * T
+        trs = []
+        for i in range(M):
+            t = {
+                "state": rng.randn(1, S).astype(np.float32),
+                "next_state": rng.randn(1, S).astype(np.float32),
+                "reward": rng.randn(1, 1) * 0.5,
+                "done": np.asarray([[rng.rand() < 0.05]]),
+            }
+            if cont:
+                t["action"] = np.tanh(rng.randn(1, A)).astype(np.float32)
+                if i % 17 == 0:
+                    t["action"][0, 0] = 1.0  # hits the atanh clamp
+            else:
+                t["action"] = rng.randint(0, A, size=(1, 1))
+            trs.append(t)
+        agent.memory.first_store = False
+
+        # capture pre-softmax / pre-clamp head outputs with grads
+        head_out = {}
+
+        def mk_hook(tag):
+            def hook(mod, inp, outp):
+                if outp.requires_grad:
+                    outp.retain_grad()
+                head_out.setdefault(tag, []).append(outp)
+
+            return hook
+
+        hooks = []
+        if cont:
+            hooks.append(agent.network.mu.register_forward_hook(mk_hook("mu_raw")))
+            hooks.append(agent.network.log_std.register_forward_hook(mk_hook("log_std_raw")))
+        else:
+            hooks.append(agent.network.pi.register_forward_hook(mk_hook("logits")))
+        hooks.append(agent.network.v.register_forward_hook(mk_hook("v")))
+
+        markers = {
+            "gae_done": ("mean_ret = ret.mean().item()", ["value", "next_value", "delta", "adv", "ret", "log_prob_old", "reward", "done"]),
+            "mb_loss": ("self.optimizer.zero_grad", ["idx", "ratio", "actor_loss", "critic_loss", "critic_loss1", "critic_loss2", "entropy_loss", "loss", "value_pred", "log_prob"]),
+            "mb_grad": ("torch.nn.utils.clip_grad_norm_", []),
+            "mb_step": ("self.optimizer.step()", []),
+        }
+        tap = LineTap(PPO.learn, markers)
+        # keyed by minibatch index: a multi-line statement fires its first line more than once
+        grads_raw, grads_clip, head_grads = {}, {}, {}
+
+        def on_grad(frame):
+            mbi = len(tap.records["mb_loss"]) - 1
+            grads_raw[mbi] = {k: p.grad.detach().numpy().copy() for k, p in agent.network.named_parameters()}
+            # the LAST two/three forward outputs are this minibatch's heads
+            hg = {}
+            for tag, lst in head_out.items():
+                hg[tag] = lst[-1].detach().numpy().copy()
+                hg["d_" + tag] = lst[-1].grad.detach().numpy().copy()
+            head_grads[mbi] = hg
+
+        def on_step(frame):
+            mbi = len(tap.records["mb_loss"]) - 1
+            grads_clip[mbi] = {k: p.grad.detach().numpy().copy() for k, p in agent.network.named_parameters()}
+
+        tap.on_line["mb_grad"] = on_grad
+        tap.on_line["mb_step"] = on_step
+
+        np.random.seed(21)
+        torch.manual_seed(21)
+        with tap:
+            result = agent.process(trs, T)
+        for h in hooks:
+            h.remove()
+        assert result, "learn did not run"
+
+        out = {}
+        out["cfg"] = np.asarray([S, A, H, W, T, B, E, int(cont)])
+        out["hyper"] = np.asarray([0.99, 0.95, 0.1, 1.0, 0.01, 1.0, 2.5e-4])  # gamma, lambda, eps, vf, ent, clip, lr
+        out["np_seed"] = np.asarray(21)
+        for k in ("state", "next_state", "reward", "done", "action"):
+            out[f"in_{k}"] = np.concatenate([t[k] for t in trs], 0)
+        flat("sd0/", sd0, out)
+        flat("sd1/", sd_to_np(agent.network.state_dict()), out)
+        flat("gae/", tap.records["gae_done"][0], out)
+        nmb = len(tap.records["mb_loss"])
+        out["n_minibatch"] = np.asarray(nmb)
+        for i in range(nmb):
+            flat(f"mb{i}/", tap.records["mb_loss"][i], out)
+            flat(f"mb{i}/head/", head_grads[i], out)
+            if i in (0, nmb - 1):  # param grads are big; keep first and last only
+                flat(f"mb{i}/grad_raw/", grads_raw[i], out)
+                flat(f"mb{i}/grad_clip/", grads_clip[i], out)
+        for k, v in result.items():
+            out[f"result/{k}"] = np.asarray(v)
+        out["lr_after"] = np.asarray(agent.optimizer.param_groups[0]["lr"])
+        np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **out)
+        print(name, {k: float(v) for k, v in result.items()})
+
+
+# ----------------------------------------------------------------------------
+# DQN family
+# ----------------------------------------------------------------------------
+def _fill(agent, n, S, A, rng, n_step=None, with_q=False):
+    """Drive interact_callback + memory.store the way Actor.run / run_mode do."""
+    for i in range(n):
+        t = {
+            "state": rng.randn(1, S).astype(np.float32),
+            "action": rng.randint(0, A, size=(1, 1)),
+            "reward": rng.choice([-1.0, 0.0, 1.0, 0.5], size=(1, 1)),
+            "next_state": rng.randn(1, S).astype(np.float32),
+            "done": np.asarray([[rng.rand() < 0.1]]),
+        }
+        if with_q:
+            t["q"] = rng.randn(1, 1).astype(np.float32)
+        t = agent.interact_callback(t)
+        if t:
+            agent.memory.store([t])
+
+
+def gen_dqn_family(out_dir):
+    import torch
+    from core.agent.dqn import DQN
+    from core.agent.double import Double
+    from core.agent.per import PER
+    from core.agent.multistep import Multistep
+    from core.agent.ape_x import ApeX
+    from core.agent.c51 import C51
+    from core.agent.rainbow import Rainbow
+
+    S, A, H, B = 4, 3, 32, 32
+    common = dict(
+        state_size=S,
+        action_size=A,
+        hidden_size=H,
+        optim_config={"name": "adam", "lr": 1e-3},
+        gamma=0.99,
+        buffer_size=256,
+        batch_size=B,
+        start_train_step=0,
+        target_update_period=10000,
+        run_step=100000,
+        device="cpu",
+    )
+    specs = [
+        ("dqn", DQN, {}, dict(markers=["q", "target_q", "next_q", "loss"])),
+        ("double", Double, {}, dict(markers=["q", "target_q", "next_q", "next_target_q", "max_a", "loss"])),
+        ("per", PER, dict(alpha=0.6, beta=0.4, learn_period=1, uniform_sample_prob=0.05), dict(markers=["q", "target_q", "next_q", "next_target_q", "max_a", "td_error", "p_j", "loss", "weights", "indices"])),
+        ("multistep", Multistep, dict(n_step=3), dict(markers=["q", "target_q", "next_q", "loss", "reward", "done"])),
+        ("ape_x", ApeX, dict(n_step=3, alpha=0.6, beta=0.4, learn_period=1, uniform_sample_prob=0.05, num_workers=4, clip_grad_norm=40.0), dict(markers=["q", "target_q", "next_q", "next_target_q", "max_a", "td_error", "p_j", "loss", "weights", "indices", "reward", "done"], with_q=True)),
+        ("c51", C51, dict(v_min=-2, v_max=5, num_support=21), dict(markers=["logit", "p_logit", "q_action", "p_action", "target_p_logit", "target_q_action", "target_action", "target_p_action", "Tz", "b", "l", "u", "target_dist", "loss"])),
+        ("rainbow", Rainbow, dict(n_step=3, alpha=0.5, beta=0.4, learn_period=1, uniform_sample_prob=0.05, v_min=-1, v_max=10, num_support=51), dict(markers=["logit", "p_logit", "q_action", "p_action", "next_q_action", "target_p_logit", "target_action", "target_p_action", "Tz", "b", "l", "u", "target_dist", "KL", "p_j", "loss", "weights", "indices", "reward", "done"])),
+    ]
+    for name, cls, extra, opt in specs:
+        torch.manual_seed(3)
+        np.random.seed(3)
+        kw = dict(common)
+        kw.update(extra)
+        agent = cls(**kw)
+        with torch.no_grad():
+            for p in agent.network.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+            # target differs from online so double-Q is not degenerate
+            for p in agent.target_network.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        agent.memory.first_store = False
+        rng = np.random.RandomState(17)
+        _fill(agent, 200, S, A, rng, with_q=opt.get("with_q", False))
+        is_per = hasattr(agent.memory, "sum_tree")
+        if is_per:
+            # non-trivial priorities before the sampled learn
+            for leaf in range(agent.memory.size):
+                agent.memory.update_priority(float(np.float32(rng.rand() ** 2 + 0.01)), leaf + agent.memory.first_leaf_index)
+        sd0 = sd_to_np(agent.network.state_dict())
+        sdt = sd_to_np(agent.target_network.state_dict())
+
+        out = {}
+        # buffer contents in slot order (so the mirror can be loaded identically)
+        n = agent.memory.size
+        keys = list(agent.memory.buffer[0].keys())
+        for k in keys:
+            if k == "priority":
+                continue
+            out[f"buf_{k}"] = np.concatenate([agent.memory.buffer[i][k] for i in range(n)], 0)
+        if is_per:
+            out["tree0"] = agent.memory.sum_tree.copy()
+            out["maxp0"] = np.asarray(agent.memory.max_priority)
+            out["tree_index0"] = np.asarray(agent.memory.tree_index)
+
+        is_dist = name in ("c51", "rainbow")
+        loss_line = "self.optimizer.zero_grad"
+        markers = {
+            "pre_step": (loss_line, opt["markers"] + ["state", "action", "next_state"]),
+            "step": ("self.optimizer.step()", []),
+        }
+        tap = LineTap(cls.learn, markers)
+        graw = {}
+        head = {}
+
+        def on_step(frame):
+            graw.update({k: p.grad.detach().numpy().copy() for k, p in agent.network.named_parameters()})
+            for nm in ("q", "logit"):
+                if nm in frame.f_locals and frame.f_locals[nm].grad is not None:
+                    head["d_" + nm] = frame.f_locals[nm].grad.detach().numpy().copy()
+
+        def on_pre(frame):
+            for nm in ("q", "logit"):
+                if nm in frame.f_locals and frame.f_locals[nm].requires_grad:
+                    frame.f_locals[nm].retain_grad()
+
+        tap.on_line["step"] = on_step
+        tap.on_line["pre_step"] = on_pre
+
+        np.random.seed(42)
+        torch.manual_seed(42)
+        with tap:
+            result = agent.learn()
+        rec = tap.records["pre_step"][0]
+        flat("learn/", rec, out)
+        flat("learn/", head, out)
+        flat("grad/", graw, out)
+        flat("sd0/", sd0, out)
+        flat("sdt/", sdt, out)
+        flat("sd1/", sd_to_np(agent.network.state_dict()), out)
+        for k, v in result.items():
+            out[f"result/{k}"] = np.asarray(v)
+        if is_per:
+            out["tree1"] = agent.memory.sum_tree.copy()
+            out["maxp1"] = np.asarray(agent.memory.max_priority)
+        hyper = dict(gamma=0.99, lr=1e-3, B=B, S=S, A=A, H=H, np_seed=42, torch_seed=42)
+        hyper.update({k: v for k, v in extra.items() if isinstance(v, (int, float))})
+        for k, v in hyper.items():
+            out[f"hyper/{k}"] = np.asarray(v)
+        np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **out)
+        print(name, {k: float(v) for k, v in result.items()})
+
+
+def gen_nstep(out_dir):
+    """n-step assemblers (rainbow.py:294-308, multistep.py:90-104, ape_x.py:174-199)."""
+    from core.agent.rainbow import Rainbow
+    from core.agent.ape_x import ApeX
+
+    S, A = 3, 2
+    out = {}
+    rng = np.random.RandomState(8)
+    raw = []
+    for i in range(12):
+        raw.append(
+            {
+                "state": rng.randn(1, S).astype(np.float32),
+                "action": rng.randint(0, A, size=(1, 1)),
+                "reward": rng.randn(1, 1),
+                "next_state": rng.randn(1, S).astype(np.float32),
+                "done": np.asarray([[i in (4, 9)]]),
+                "q": rng.randn(1, 1).astype(np.float32),
+            }
+        )
+    for k in raw[0]:
+        out[f"in_{k}"] = np.concatenate([t[k] for t in raw], 0)
+    rb = Rainbow(state_size=S, action_size=A, hidden_size=8, n_step=3, buffer_size=16, device="cpu")
+    emitted = []
+    for t in raw:
+        t2 = {k: v for k, v in t.items() if k != "q"}
+        e = rb.interact_callback(t2)
+        emitted.append(bool(e))
+        if e:
+            for k, v in e.items():
+                out.setdefault(f"rainbow_{k}", []).append(v)
+    out["rainbow_emitted"] = np.asarray(emitted)
+    ax = ApeX(state_size=S, action_size=A, hidden_size=8, n_step=3, buffer_size=16, num_workers=4, device="cpu")
+    emitted = []
+    for t in raw:
+        e = ax.interact_callback(dict(t))
+        emitted.append(bool(e))
+        if e:
+            for k, v in e.items():
+                out.setdefault(f"apex_{k}", []).append(np.asarray(v))
+    out["apex_emitted"] = np.asarray(emitted)
+    for k in list(out):
+        if isinstance(out[k], list):
+            out[k] = np.concatenate(out[k], 0)
+    np.savez(os.path.join(out_dir, "nstep.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    os.makedirs(out_dir, exist_ok=True)
+
+    scratch = tempfile.mkdtemp(prefix="jref_")
+    subprocess.check_call(
+        f"cd {args.ref} && tar --exclude='jorldy/core/env/mlagents' -cf - jorldy | (cd {scratch} && tar xf -)",
+        shell=True,
+    )
+    os.chdir(os.path.join(scratch, "jorldy"))
+    sys.path.insert(0, os.getcwd())
+    sys.dont_write_bytecode = True
+    import torch
+
+    torch.set_num_threads(1)  # deterministic reductions in the fixtures
+    try:
+        todo = args.only.split(",") if args.only else ["buffers", "ppo", "dqn", "nstep"]
+        if "buffers" in todo:
+            gen_buffers(out_dir)
+        if "ppo" in todo:
+            gen_ppo(out_dir)
+        if "dqn" in todo:
+            gen_dqn_family(out_dir)
+        if "nstep" in todo:
+            gen_nstep(out_dir)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    print("golden fixtures written to", out_dir)
+
+
+if __name__ == "__main__":
+    main()
