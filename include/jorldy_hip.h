@@ -1,0 +1,198 @@
+/*
+ * jorldy_hip.h -- C ABI of libjorldy_hip.so, the MI355X (gfx950) native RL hot path
+ * that sits behind JORLDY's core/agent + core/buffer API.
+ *
+ * The reference (kakaoenterprise/JORLDY, all paths below relative to
+ * /root/reference/jorldy/) has NO native code and NO FFI: every function here
+ * replaces a piece of pure-Python/numpy/torch-CPU code.  Each entry point cites
+ * the reference file:line it stands in for.  INTEGRATION.md shows the ctypes
+ * binding a JORLDY maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative jh_status otherwise;
+ *     jh_last_error() returns a thread-local, human readable message.
+ *   - `d_*` parameters are DEVICE pointers (e.g. torch `tensor.data_ptr()`),
+ *     borrowed for the duration of the enqueued work; `h_*` are HOST pointers,
+ *     consumed before the call returns (copied into the library's pinned staging).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     work is enqueued on it; no call synchronises unless its comment says so.
+ *   - one jh_ctx per GPU; a ctx (and objects created from it) is not thread-safe.
+ *   - plain C types only; no torch / C++ types cross this boundary.
+ */
+#ifndef JORLDY_HIP_H
+#define JORLDY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JH_ABI_VERSION 1
+
+typedef enum {
+  JH_OK = 0,
+  JH_ERR_HIP = -1,      /* a HIP runtime call failed (message has hipGetErrorString) */
+  JH_ERR_ARG = -2,      /* invalid argument */
+  JH_ERR_STATE = -3,    /* object in the wrong state (e.g. sampling an empty tree) */
+  JH_ERR_NOMEM = -4,
+  JH_ERR_NODEVICE = -5  /* no usable gfx950 device */
+} jh_status;
+
+typedef enum { JH_U8 = 0, JH_F32 = 1, JH_I64 = 2, JH_F64 = 3, JH_I32 = 4 } jh_dtype;
+
+typedef struct jh_ctx jh_ctx;
+typedef struct jh_store jh_store;
+typedef struct jh_per jh_per;
+typedef struct jh_cartpole jh_cartpole;
+typedef void* jh_stream;
+
+/* ------------------------------------------------------------------ library / context */
+int jh_abi_version(void);
+const char* jh_last_error(void);
+int jh_device_count(void);                       /* 0 when no GPU is visible (never an error) */
+int jh_ctx_create(int device, jh_ctx** out);     /* binds the device, allocates pinned staging */
+void jh_ctx_destroy(jh_ctx* ctx);
+int jh_ctx_sync(jh_ctx* ctx, jh_stream stream);  /* hipStreamSynchronize */
+
+/* ------------------------------------------------------------------ transition store
+ * GPU-resident struct-of-arrays ring that replaces the list-of-dicts storage of
+ *   ReplayBuffer   core/buffer/replay_buffer.py:8-35   (ring + uniform gather)
+ *   RolloutBuffer  core/buffer/rollout_buffer.py:6-24  (append, take all, clear)
+ * and BaseBuffer.stack_transition core/buffer/base.py:42-56 (AoS->SoA, done once at
+ * push time on the host side instead of at every sample).
+ * Column c is a device array [capacity][elems[c]] of dtype[c].                      */
+typedef struct {
+  int32_t dtype;  /* jh_dtype of the stored column */
+  int64_t elems;  /* elements per transition */
+} jh_col_desc;
+
+int jh_store_create(jh_ctx* ctx, int64_t capacity, int32_t n_cols, const jh_col_desc* cols, jh_store** out);
+void jh_store_destroy(jh_store* s);
+/* Append n transitions (ring write at buffer_index, wraps; replay_buffer.py:16-23).
+ * h_cols[c] points at n*elems[c] contiguous elements of dtype[c].  The data is copied into
+ * pinned staging before returning, then moved with hipMemcpyAsync on `stream`.          */
+int jh_store_push(jh_store* s, int64_t n, const void* const* h_cols, jh_stream stream);
+/* Zero-copy variant for native collectors: get pinned slab pointers for n rows, fill them,
+ * then commit (enqueues the async H2D copies).  begin/commit must alternate.             */
+int jh_store_stage_begin(jh_store* s, int64_t n, void** h_cols_out);
+int jh_store_stage_commit(jh_store* s, jh_stream stream);
+/* out[c][b][:] = convert(col[c][idx[b] - idx_offset][:]) for the selected columns
+ * (replay_buffer.py:25-31 + base.py:42-56 + the fp32 cast of BaseAgent.as_tensor,
+ * core/agent/base.py:61-73).  out_dtype[c] is JH_F32 (as_tensor semantics) or the stored
+ * dtype (keeps uint8 frames 4x smaller).  d_idx: int64[B]; idx_offset lets PER pass
+ * tree-space indices (leaf = idx - (N-1), per_buffer.py:95).                             */
+int jh_store_gather(jh_store* s, int64_t B, const int64_t* d_idx, int64_t idx_offset, int32_t n_sel,
+                    const int32_t* sel_cols, void* const* d_out, const int32_t* out_dtype, jh_stream stream);
+void* jh_store_col_ptr(jh_store* s, int32_t col);  /* device base of a column (rollout "sample" is a view) */
+int64_t jh_store_size(const jh_store* s);          /* buffer_counter */
+int64_t jh_store_index(const jh_store* s);         /* buffer_index   */
+int64_t jh_store_capacity(const jh_store* s);
+void jh_store_clear(jh_store* s);                  /* rollout_buffer.py:19 */
+
+/* ------------------------------------------------------------------ prioritized replay
+ * Device-resident float64 sum tree, array-heap layout identical to
+ * core/buffer/per_buffer.py:7-105: 2N-1 nodes, leaves at [N-1, 2N-2].  All updates
+ * are the reference's incremental `+= delta` climbs applied in batch order per node,
+ * so the tree stays BIT-IDENTICAL to the reference's numpy tree.                        */
+int jh_per_create(jh_ctx* ctx, int64_t capacity, double uniform_sample_prob, jh_per** out);
+void jh_per_destroy(jh_per* p);
+/* per_buffer.py:19-40: n x add_tree_data at tree_index (wraps independently).
+ * h_prio == NULL -> every new leaf gets the current max_priority (per_buffer.py:27-31). */
+int jh_per_push(jh_per* p, int64_t n, const double* h_prio, jh_stream stream);
+/* per_buffer.py:42-54 applied for b = 0..B-1 in order: d_idx int64[B] TREE-space indices,
+ * d_prio float32[B] (prio_dtype JH_F32: the `.item()` of an fp32 tensor, per.py:68-70,
+ * rainbow.py:230-231) or float64[B].  Duplicated indices behave sequentially.          */
+int jh_per_update(jh_per* p, int64_t B, const int64_t* d_idx, const void* d_prio, int32_t prio_dtype, jh_stream stream);
+/* per_buffer.py:70-101.  The three numpy global-RNG draws stay on the host so indices are
+ * bit-exact: n_uniform = sum(uniform(B) < usp); h_uniform_slot = randint(counter, n_uniform);
+ * h_u = uniform(B - n_uniform) (NOT yet multiplied by the root).  Outputs (device):
+ * d_idx int64[B] tree-space, uniform first; d_w64 float64[B] and/or d_w32 float32[B]
+ * (either may be NULL) = ((1/counter)/P)^beta / max; d_stats float64[4] =
+ * {sampled_p, mean_p, root, max_w_unnormalised}.                                        */
+int jh_per_sample(jh_per* p, int64_t B, double beta, int64_t n_uniform, const int64_t* h_uniform_slot,
+                  const double* h_u, int64_t* d_idx, double* d_w64, float* d_w32, double* d_stats, jh_stream stream);
+/* Blocking read-back of the scalar state (synchronises `stream`). */
+int jh_per_state(jh_per* p, double* max_priority, double* root, int64_t* tree_index, int64_t* counter, jh_stream stream);
+double* jh_per_tree_ptr(jh_per* p);  /* device float64[2N-1] */
+int64_t jh_per_tree_size(const jh_per* p);
+/* Checkpoint / restore of the whole tree state (blocking; the reference cannot resume its buffer,
+ * SURVEY.md §5 -- this is what a complete checkpoint needs).  h_tree: float64[2N-1].   */
+int jh_per_load(jh_per* p, const double* h_tree, double max_priority, int64_t tree_index, int64_t counter);
+int jh_per_dump(jh_per* p, double* h_tree, jh_stream stream);
+
+/* ------------------------------------------------------------------ PPO math
+ * jh_gae: core/agent/ppo.py:95-110.  Inputs float32[W*T], worker-major (row w = one
+ * worker's T steps).  delta = r + (1-d)*gamma*V' - V; reverse scan per row that does not
+ * bootstrap across the row end; ret = adv + V; if standardize: per-row
+ * (adv-mean)/(std_unbiased+1e-7).  One wave per row, wave-shuffle segmented scan.       */
+int jh_gae(jh_ctx* ctx, int32_t W, int32_t T, float gamma, float lambda, const float* d_reward, const float* d_done,
+           const float* d_value, const float* d_next_value, float* d_adv, float* d_ret, int32_t standardize,
+           jh_stream stream);
+/* log pi_old(a|s): ppo.py:90-92 `pi.gather(1, action).log()` with pi = exp(log_softmax(logits)). */
+int jh_logp_discrete(jh_ctx* ctx, int64_t M, int32_t A, const float* d_logits, const float* d_action, float* d_logp,
+                     jh_stream stream);
+/* ppo.py:85-88 continuous: per-dimension Normal log-prob of atanh(clamp(a)); takes RAW heads
+ * (mu before clamp(+-5), log_std before tanh; core/network/policy_value.py:52-56).      */
+int jh_logp_continuous(jh_ctx* ctx, int64_t M, int32_t A, const float* d_mu_raw, const float* d_log_std_raw,
+                       const float* d_action, float* d_logp, jh_stream stream);
+/* Clipped surrogate + clipped value + entropy, forward AND backward to the head outputs
+ * (ppo.py:131-165).  Row i of the minibatch reads the rollout-sized arrays at
+ * r = d_idx ? d_idx[i] : i  (the `x[idx]` gathers of ppo.py:122-125 are fused away);
+ * d_logits / d_value_pred are minibatch-sized [B][A] / [B].
+ * d_stats float32[8] = {loss, actor_loss, critic_loss, entropy_loss, max_ratio, min_prob, c1, c2}. */
+int jh_ppo_loss_discrete(jh_ctx* ctx, int32_t B, int32_t A, const float* d_logits, const float* d_value_pred,
+                         const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
+                         const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef,
+                         float ent_coef, float* d_grad_logits, float* d_grad_value, float* d_stats,
+                         jh_stream stream);
+int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const float* d_mu_raw, const float* d_log_std_raw,
+                           const float* d_value_pred, const int64_t* d_idx, const float* d_action, const float* d_adv,
+                           const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip,
+                           float vf_coef, float ent_coef, float* d_grad_mu_raw, float* d_grad_log_std_raw,
+                           float* d_grad_value, float* d_stats, jh_stream stream);
+
+/* ------------------------------------------------------------------ TD losses (DQN family)
+ * One kernel for dqn.py:128-141, double.py:28-39, multistep.py:41-50, per.py:54-74,
+ * ape_x.py:96-116.  flags: */
+#define JH_TD_DOUBLE 1   /* a* = argmax Q_online(s'); bootstrap Q_target(s')[a*]           */
+#define JH_TD_PER 2      /* loss = mean(w*td^2), priorities td^alpha; else Huber (beta=1)  */
+/* d_q [B][A] online Q(s); d_q_next_online [B][A] (DOUBLE only); d_q_next_target [B][A];
+ * d_action float32[B]; d_reward/d_done float32 [B][n] (n = max(n_step,1); n_step==0 is the
+ * 1-step form); d_weights float32[B] (PER only).  Outputs: d_grad_q [B][A] (d loss/d Q(s)),
+ * d_prio float32[B] (= td^alpha, or |td| when not PER; may be NULL),
+ * d_stats float32[4] = {loss, max_Q, mean_td, 0}.                                        */
+int jh_td_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t n_step, int32_t flags, const float* d_q,
+               const float* d_q_next_online, const float* d_q_next_target, const float* d_action,
+               const float* d_reward, const float* d_done, const float* d_weights, float gamma, float alpha,
+               float* d_grad_q, float* d_prio, float* d_stats, jh_stream stream);
+
+/* ------------------------------------------------------------------ C51 / Rainbow
+ * Categorical n-step projection + cross-entropy, forward and backward to the online
+ * logits (rainbow.py:167-239, c51.py:68-109, logits2Q rainbow.py:285-292).  flags: */
+#define JH_C51_DOUBLE 1     /* rainbow: action from argmax Q_online(s'); else target net's own */
+#define JH_C51_PER 2        /* rainbow: prio = KL^alpha, loss = mean(w)*mean(KL) (shape-broadcast quirk) */
+#define JH_C51_SHIFT_MAX 4  /* c51.py:126-128 subtracts the row max before log_softmax        */
+/* d_logit / d_next_logit_online / d_target_logit: [B][A][K]; d_reward/d_done [B][n];
+ * outputs d_grad_logit [B][A][K], d_prio float32[B] (NULL ok), d_kl float32[B] (NULL ok),
+ * d_stats float32[8] = {loss, max_Q, max_logit, min_logit, mean_kl, 0,0,0}.              */
+int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t n_step, int32_t flags, const float* d_logit,
+                const float* d_next_logit_online, const float* d_target_logit, const float* d_action,
+                const float* d_reward, const float* d_done, const float* d_weights, float v_min, float v_max,
+                float gamma, float alpha, float* d_grad_logit, float* d_prio, float* d_kl, float* d_stats,
+                jh_stream stream);
+
+/* ------------------------------------------------------------------ vectorised host collector
+ * Synthetic CartPole-v1 (gym is not installable in the build image): W envs stepped in one
+ * call on the host, float64 dynamics, reward shaping of core/env/gym_env.py:78, auto-reset
+ * like Actor.run (manager/distributed_manager.py:76-92).  Pure host code.               */
+int jh_cartpole_create(int32_t W, uint64_t seed, jh_cartpole** out);
+void jh_cartpole_destroy(jh_cartpole* e);
+int jh_cartpole_obs(const jh_cartpole* e, float* h_obs /* [W][4] */);
+int jh_cartpole_step(jh_cartpole* e, const int64_t* h_action /* [W] */, float* h_next_obs /* [W][4] */,
+                     float* h_reward /* [W] */, uint8_t* h_done /* [W] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JORLDY_HIP_H */

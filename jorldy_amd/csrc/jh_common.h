@@ -1,0 +1,120 @@
+// Shared internals of libjorldy_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/jorldy_hip.h"
+
+#define JH_EXPORT extern "C" __attribute__((visibility("default")))
+
+std::string& jh_err_slot();
+int jh_fail(int code, const char* fmt, ...);
+
+#define JH_HIP(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return jh_fail(JH_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define JH_ARG(cond)                                                                    \
+  do {                                                                                  \
+    if (!(cond)) return jh_fail(JH_ERR_ARG, "%s:%d bad argument: %s", __FILE__, __LINE__, #cond); \
+  } while (0)
+
+#define JH_LAUNCH_CHECK()                                                                      \
+  do {                                                                                         \
+    hipError_t _e = hipGetLastError();                                                         \
+    if (_e != hipSuccess)                                                                      \
+      return jh_fail(JH_ERR_HIP, "%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+  } while (0)
+
+static inline hipStream_t jh_s(jh_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline size_t jh_dtype_size(int dt) {
+  switch (dt) {
+    case JH_U8: return 1;
+    case JH_F32: return 4;
+    case JH_I64: return 8;
+    case JH_F64: return 8;
+    case JH_I32: return 4;
+    default: return 0;
+  }
+}
+
+// A pinned (host-coherent, device-mapped) slab that is reused round-robin; the event guards
+// reuse while an async copy / kernel that reads it may still be in flight.
+struct jh_pinned_slab {
+  void* host = nullptr;
+  void* dev = nullptr;  // device-visible alias of `host`
+  size_t bytes = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+};
+
+struct jh_ctx {
+  int device = 0;
+  static constexpr int kSlabs = 8;
+  jh_pinned_slab slabs[kSlabs];
+  int next_slab = 0;
+  // small device scratch for reductions (partials) -- grows on demand
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+// Get a pinned slab of at least `bytes` (waits for its previous use to drain).
+int jh_ctx_slab(jh_ctx* ctx, size_t bytes, jh_pinned_slab** out);
+// Mark the slab busy until everything enqueued on `stream` so far has executed.
+int jh_ctx_slab_release(jh_ctx* ctx, jh_pinned_slab* slab, hipStream_t stream);
+int jh_ctx_scratch(jh_ctx* ctx, size_t bytes, void** out);
+
+// ---------------------------------------------------------------- device helpers (wave = 64)
+#ifdef __HIPCC__
+__device__ __forceinline__ float jh_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double jh_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float jh_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float jh_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double jh_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Block-wide reductions for blockDim.x <= 1024 (<= 16 waves).  `red` is 16 floats of LDS.
+// Deterministic: fixed shuffle tree inside a wave, then wave partials summed in wave order.
+template <typename T, typename Op>
+__device__ __forceinline__ T jh_block_reduce(T v, T* red, Op op, T ident) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+  __syncthreads();  // protect `red` from a previous use
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  T r = ident;
+  for (int w = 0; w < nw; ++w) r = op(r, red[w]);
+  return r;
+}
+struct JhAdd { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
+struct JhMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
+struct JhMin { template <typename T> __device__ T operator()(T a, T b) const { return a < b ? a : b; } };
+#endif

@@ -1,0 +1,114 @@
+// Context, error slot, pinned staging slabs.
+#include <stdarg.h>
+
+#include "jh_common.h"
+
+std::string& jh_err_slot() {
+  static thread_local std::string s;
+  return s;
+}
+
+int jh_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  jh_err_slot() = buf;
+  return code;
+}
+
+JH_EXPORT int jh_abi_version(void) { return JH_ABI_VERSION; }
+JH_EXPORT const char* jh_last_error(void) { return jh_err_slot().c_str(); }
+
+JH_EXPORT int jh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+JH_EXPORT int jh_ctx_create(int device, jh_ctx** out) {
+  JH_ARG(out != nullptr);
+  int n = jh_device_count();
+  if (n <= 0) return jh_fail(JH_ERR_NODEVICE, "no HIP device visible: libjorldy_hip needs an MI355X (gfx950)");
+  JH_ARG(device >= 0 && device < n);
+  JH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  JH_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return jh_fail(JH_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  jh_ctx* c = new jh_ctx();
+  c->device = device;
+  *out = c;
+  return JH_OK;
+}
+
+JH_EXPORT void jh_ctx_destroy(jh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (auto& s : ctx->slabs) {
+    if (s.ev) {
+      (void)hipEventSynchronize(s.ev);
+      (void)hipEventDestroy(s.ev);
+    }
+    if (s.host) (void)hipHostFree(s.host);
+  }
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  delete ctx;
+}
+
+JH_EXPORT int jh_ctx_sync(jh_ctx* ctx, jh_stream stream) {
+  JH_ARG(ctx != nullptr);
+  JH_HIP(hipStreamSynchronize(jh_s(stream)));
+  return JH_OK;
+}
+
+int jh_ctx_slab(jh_ctx* ctx, size_t bytes, jh_pinned_slab** out) {
+  jh_pinned_slab& s = ctx->slabs[ctx->next_slab];
+  ctx->next_slab = (ctx->next_slab + 1) % jh_ctx::kSlabs;
+  if (s.pending) {
+    JH_HIP(hipEventSynchronize(s.ev));
+    s.pending = false;
+  }
+  if (s.bytes < bytes) {
+    if (s.host) JH_HIP(hipHostFree(s.host));
+    size_t want = 1 << 16;
+    while (want < bytes) want <<= 1;
+    s.host = nullptr;
+    s.bytes = 0;
+    // coherent, device-mapped pinned memory: kernels may read small inputs in place,
+    // hipMemcpyAsync from it is a true async DMA.
+    JH_HIP(hipHostMalloc(&s.host, want, hipHostMallocMapped));
+    JH_HIP(hipHostGetDevicePointer(&s.dev, s.host, 0));
+    s.bytes = want;
+  }
+  if (!s.ev) JH_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  *out = &s;
+  return JH_OK;
+}
+
+int jh_ctx_slab_release(jh_ctx* ctx, jh_pinned_slab* slab, hipStream_t stream) {
+  (void)ctx;
+  JH_HIP(hipEventRecord(slab->ev, stream));
+  slab->pending = true;
+  return JH_OK;
+}
+
+int jh_ctx_scratch(jh_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->scratch_bytes < bytes) {
+    // growing is rare (first calls); the old block may still be in use by enqueued work
+    JH_HIP(hipDeviceSynchronize());
+    if (ctx->scratch) JH_HIP(hipFree(ctx->scratch));
+    size_t want = 1 << 16;
+    while (want < bytes) want <<= 1;
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    JH_HIP(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return JH_OK;
+}

@@ -1,0 +1,392 @@
+// Prioritized replay on the GPU: float64 sum tree in the reference's array-heap layout
+// (core/buffer/per_buffer.py:7-105), bit-identical to the reference's numpy tree.
+//
+// Why it can be bit-identical: the reference never rebuilds the tree; every priority change is
+//   delta = new - tree[leaf]; tree[leaf] = new; for every ancestor a: tree[a] += delta
+// (per_buffer.py:42-54).  A node's value therefore depends only on the ORDER in which deltas reach
+// it.  The batch kernels below keep that order per node:
+//   * jh_per_delta_kernel resolves duplicate leaves sequentially (the 2nd write of a leaf in one
+//     batch sees the 1st as its old value) and writes the leaves;
+//   * jh_per_climb_kernel runs one workgroup per tree DEPTH (a node has exactly one depth, so no
+//     two workgroups ever touch the same node) and, for every node hit by the batch, adds the
+//     deltas in ascending batch order, in float64, one rounding per add -- exactly numpy's `+=`.
+// The descent (per_buffer.py:56-68) is a dependent chain of ~log2(N) 8-byte loads per sample:
+// latency-bound, one lane per sample, `num <= left` goes left.
+#include "jh_common.h"
+
+namespace {
+constexpr int kChunk = 2048;  // items per kernel pass (LDS: 2048 * (8+8) B = 32 KiB)
+
+struct PerWs {
+  double* delta = nullptr;   // [kChunk]
+  double* prio = nullptr;    // [ws_cap] sampled priorities
+  double* w = nullptr;       // [ws_cap] unnormalised weights
+  double* partial = nullptr; // [2 * kMaxBlocks]
+  int64_t ws_cap = 0;
+};
+constexpr int kMaxBlocks = 1024;
+}  // namespace
+
+struct jh_per {
+  jh_ctx* ctx = nullptr;
+  int64_t N = 0, tree_size = 0;
+  double usp = 0;
+  double* tree = nullptr;
+  double* maxp = nullptr;  // device scalar, starts at 1.0 (per_buffer.py:16)
+  PerWs ws;
+  int64_t tree_index = 0;  // per_buffer.py:14, wraps independently of the store's buffer_index
+  int64_t counter = 0;
+  int depth_max = 0;        // depth of the deepest leaf = floor(log2(2N-1))
+  int64_t deep_first = 0;   // first tree index at depth_max (= 2^depth_max - 1)
+};
+
+// ----------------------------------------------------------------------------- kernels
+__device__ __forceinline__ int node_depth(int64_t i) { return 63 - __clzll((unsigned long long)(i + 1)); }
+
+// mode bits
+#define PER_DISTINCT 1  // caller guarantees all leaves distinct (push of consecutive leaves)
+#define PER_CONTIG 2    // caller guarantees each node's items are contiguous in batch order
+
+__global__ void __launch_bounds__(256) jh_per_delta_kernel(double* __restrict__ tree, double* __restrict__ maxp, int B,
+                                                           const int64_t* __restrict__ idx, int64_t push_start,
+                                                           const void* __restrict__ prio, int prio_dt, int mode,
+                                                           int64_t tree_size, int64_t first_leaf,
+                                                           double* __restrict__ delta_out) {
+  __shared__ int64_t s_idx[kChunk];
+  __shared__ double s_new[kChunk];
+  __shared__ double s_red[16];
+  const double cur_max = *maxp;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    int64_t ix = idx ? idx[i] : push_start + i;
+    // a bad index must not corrupt internal nodes: clamp into the leaf range
+    ix = ix < first_leaf ? first_leaf : (ix >= tree_size ? tree_size - 1 : ix);
+    double p;
+    if (!prio) p = cur_max;
+    else if (prio_dt == JH_F32) p = (double)((const float*)prio)[i];  // fp32 tensor .item() -> python float
+    else p = ((const double*)prio)[i];
+    s_idx[i] = ix;
+    s_new[i] = p;
+  }
+  __syncthreads();
+  double my_max = cur_max;
+  // every thread owns items i = t, t+256, ...: at most kChunk/256 = 8 of them
+  double old_v[kChunk / 256];
+  bool last_v[kChunk / 256];
+#pragma unroll
+  for (int k = 0; k < kChunk / 256; ++k) {  // fully unrolled: old_v/last_v stay in registers
+    const int i = threadIdx.x + k * 256;
+    old_v[k] = 0.0;
+    last_v[k] = false;
+    if (i < B) {
+      const int64_t ix = s_idx[i];
+      double oldp;
+      bool has_later = false;
+      if (mode & PER_DISTINCT) {
+        oldp = tree[ix];
+      } else {
+        int j = i - 1;
+        while (j >= 0 && s_idx[j] != ix) --j;
+        oldp = j >= 0 ? s_new[j] : tree[ix];
+        for (int q = i + 1; q < B; ++q)
+          if (s_idx[q] == ix) { has_later = true; break; }
+      }
+      old_v[k] = oldp;
+      last_v[k] = !has_later;
+      my_max = fmax(my_max, s_new[i]);
+    }
+  }
+  __syncthreads();  // all leaf reads are done before any leaf is overwritten
+#pragma unroll
+  for (int k = 0; k < kChunk / 256; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < B) {
+      delta_out[i] = s_new[i] - old_v[k];
+      if (last_v[k]) tree[s_idx[i]] = s_new[i];
+    }
+  }
+  const double m = jh_block_reduce(my_max, s_red, JhMax(), 0.0);
+  if (threadIdx.x == 0) *maxp = m;  // max(max_priority, new...) per_buffer.py:48
+}
+
+__global__ void __launch_bounds__(256) jh_per_climb_kernel(double* __restrict__ tree, int B,
+                                                           const int64_t* __restrict__ idx, int64_t push_start,
+                                                           const double* __restrict__ delta, int mode,
+                                                           int64_t tree_size, int64_t first_leaf) {
+  __shared__ int64_t s_node[kChunk];
+  __shared__ double s_delta[kChunk];
+  const int d = blockIdx.x;  // this workgroup owns every node at depth d
+  for (int i = threadIdx.x; i < B; i += 256) {
+    int64_t ix = idx ? idx[i] : push_start + i;
+    ix = ix < first_leaf ? first_leaf : (ix >= tree_size ? tree_size - 1 : ix);
+    const int dep = node_depth(ix);
+    s_node[i] = dep > d ? (((ix + 1) >> (dep - d)) - 1) : -1;
+    s_delta[i] = delta[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const int64_t node = s_node[i];
+    if (node < 0) continue;
+    if (mode & PER_CONTIG) {
+      if (i > 0 && s_node[i - 1] == node) continue;  // not the head of this node's run
+      double v = tree[node];
+      for (int j = i; j < B && s_node[j] == node; ++j) v += s_delta[j];
+      tree[node] = v;
+    } else {
+      int j = i - 1;
+      while (j >= 0 && s_node[j] != node) --j;
+      if (j >= 0) continue;  // an earlier item owns this node
+      double v = tree[node];
+      for (int q = i; q < B; ++q)
+        if (s_node[q] == node) v += s_delta[q];
+      tree[node] = v;
+    }
+  }
+}
+
+// one lane per sample: descent + importance weight (unnormalised) + per-block partials
+__global__ void __launch_bounds__(256) jh_per_sample_kernel(const double* __restrict__ tree, int64_t first_leaf,
+                                                            int64_t B, int64_t n_uniform,
+                                                            const int64_t* __restrict__ uni_slot,
+                                                            const double* __restrict__ u, int64_t counter, double usp,
+                                                            double beta, int64_t* __restrict__ idx_out,
+                                                            double* __restrict__ prio_ws, double* __restrict__ w_ws,
+                                                            double* __restrict__ partial) {
+  __shared__ double s_red[16];
+  const double root = tree[0];
+  const double uniform_probs = 1.0 / (double)counter;
+  double my_w = 0.0, my_p = 0.0;
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+    int64_t index;
+    if (b < n_uniform) {
+      index = uni_slot[b] + first_leaf;  // per_buffer.py:75-78
+    } else {
+      double num = u[b - n_uniform] * root;  // per_buffer.py:81
+      index = 0;
+      while (index < first_leaf) {  // per_buffer.py:56-68
+        const int64_t left = 2 * index + 1;
+        const double l = tree[left];
+        if (num <= l) index = left;
+        else { num -= l; index = left + 1; }
+      }
+    }
+    const double p = tree[index];
+    const double prioritized = p / root;
+    const double sample_prob = (1.0 - usp) * prioritized + usp * uniform_probs;  // per_buffer.py:91-92
+    const double w = pow(uniform_probs / sample_prob, beta);
+    idx_out[b] = index;
+    prio_ws[b] = p;
+    w_ws[b] = w;
+    my_w = fmax(my_w, w);
+    my_p += p;
+  }
+  const double bw = jh_block_reduce(my_w, s_red, JhMax(), 0.0);
+  const double bp = jh_block_reduce(my_p, s_red, JhAdd(), 0.0);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = bw;
+    partial[2 * blockIdx.x + 1] = bp;
+  }
+}
+
+__global__ void __launch_bounds__(256) jh_per_norm_kernel(const double* __restrict__ tree, int64_t B, int nb_partial,
+                                                          const double* __restrict__ partial,
+                                                          const double* __restrict__ w_ws, int64_t counter,
+                                                          double* __restrict__ w64, float* __restrict__ w32,
+                                                          double* __restrict__ stats) {
+  __shared__ double s_red[16];
+  double mw = 0.0, sp = 0.0;
+  for (int i = threadIdx.x; i < nb_partial; i += 256) {
+    mw = fmax(mw, partial[2 * i]);
+    sp += partial[2 * i + 1];
+  }
+  mw = jh_block_reduce(mw, s_red, JhMax(), 0.0);
+  sp = jh_block_reduce(sp, s_red, JhAdd(), 0.0);
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+    const double w = w_ws[b] / mw;  // per_buffer.py:94
+    if (w64) w64[b] = w;
+    if (w32) w32[b] = (float)w;  // torch.FloatTensor(weights)
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
+    const double root = tree[0];
+    stats[0] = sp / (double)B;           // sampled_p  per_buffer.py:99
+    stats[1] = root / (double)counter;   // mean_p     per_buffer.py:100
+    stats[2] = root;
+    stats[3] = mw;
+  }
+}
+
+__global__ void jh_per_init_kernel(double* maxp) { *maxp = 1.0; }
+
+// ----------------------------------------------------------------------------- host API
+JH_EXPORT int jh_per_create(jh_ctx* ctx, int64_t capacity, double usp, jh_per** out) {
+  JH_ARG(ctx && out);
+  JH_ARG(capacity > 0 && capacity < ((int64_t)1 << 40));
+  JH_HIP(hipSetDevice(ctx->device));
+  jh_per* p = new jh_per();
+  p->ctx = ctx;
+  p->N = capacity;
+  p->tree_size = 2 * capacity - 1;
+  p->usp = usp;
+  p->tree_index = capacity - 1;
+  p->depth_max = 63 - __builtin_clzll((unsigned long long)(p->tree_size));  // depth(2N-2) = floor(log2(2N-1))
+  p->deep_first = ((int64_t)1 << p->depth_max) - 1;
+  hipError_t e = hipMalloc((void**)&p->tree, sizeof(double) * (size_t)p->tree_size);
+  if (e != hipSuccess) {
+    delete p;
+    return jh_fail(JH_ERR_NOMEM, "hipMalloc of the sum tree (%lld doubles) failed: %s", (long long)p->tree_size,
+                   hipGetErrorString(e));
+  }
+  JH_HIP(hipMemset(p->tree, 0, sizeof(double) * (size_t)p->tree_size));
+  JH_HIP(hipMalloc((void**)&p->maxp, sizeof(double)));
+  JH_HIP(hipMalloc((void**)&p->ws.delta, sizeof(double) * kChunk));
+  JH_HIP(hipMalloc((void**)&p->ws.partial, sizeof(double) * 2 * kMaxBlocks));
+  hipLaunchKernelGGL(jh_per_init_kernel, dim3(1), dim3(1), 0, 0, p->maxp);
+  JH_LAUNCH_CHECK();
+  JH_HIP(hipDeviceSynchronize());
+  *out = p;
+  return JH_OK;
+}
+
+JH_EXPORT void jh_per_destroy(jh_per* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(p->tree);
+  (void)hipFree(p->maxp);
+  (void)hipFree(p->ws.delta);
+  (void)hipFree(p->ws.partial);
+  if (p->ws.prio) (void)hipFree(p->ws.prio);
+  if (p->ws.w) (void)hipFree(p->ws.w);
+  delete p;
+}
+
+static int per_apply(jh_per* p, int B, const int64_t* d_idx, int64_t push_start, const void* prio, int prio_dt, int mode,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(jh_per_delta_kernel, dim3(1), dim3(256), 0, st, p->tree, p->maxp, B, d_idx, push_start, prio,
+                     prio_dt, mode, p->tree_size, p->N - 1, p->ws.delta);
+  JH_LAUNCH_CHECK();
+  if (p->depth_max > 0) {
+    hipLaunchKernelGGL(jh_per_climb_kernel, dim3(p->depth_max), dim3(256), 0, st, p->tree, B, d_idx, push_start,
+                       p->ws.delta, mode, p->tree_size, p->N - 1);
+    JH_LAUNCH_CHECK();
+  }
+  return JH_OK;
+}
+
+JH_EXPORT int jh_per_push(jh_per* p, int64_t n, const double* h_prio, jh_stream stream) {
+  JH_ARG(p != nullptr && n >= 0);
+  hipStream_t st = jh_s(stream);
+  int64_t done = 0;
+  while (done < n) {
+    // a segment never wraps (2N-2 -> N-1), never crosses the depth boundary (2^D-2 -> 2^D-1)
+    // and holds at most kChunk leaves: inside it every node's items are contiguous.
+    int64_t seg = n - done;
+    if (seg > kChunk) seg = kChunk;
+    if (p->tree_index + seg > p->tree_size) seg = p->tree_size - p->tree_index;
+    if (p->tree_index < p->deep_first && p->tree_index + seg > p->deep_first) seg = p->deep_first - p->tree_index;
+    const void* prio_dev = nullptr;
+    jh_pinned_slab* slab = nullptr;
+    if (h_prio) {
+      int rc = jh_ctx_slab(p->ctx, sizeof(double) * (size_t)seg, &slab);
+      if (rc) return rc;
+      memcpy(slab->host, h_prio + done, sizeof(double) * (size_t)seg);
+      prio_dev = slab->dev;
+    }
+    int rc = per_apply(p, (int)seg, nullptr, p->tree_index, prio_dev, JH_F64, PER_DISTINCT | PER_CONTIG, st);
+    if (rc) return rc;
+    if (slab) {
+      rc = jh_ctx_slab_release(p->ctx, slab, st);
+      if (rc) return rc;
+    }
+    p->tree_index += seg;
+    if (p->tree_index == p->tree_size) p->tree_index = p->N - 1;  // per_buffer.py:38-40
+    p->counter = p->counter + seg < p->N ? p->counter + seg : p->N;
+    done += seg;
+  }
+  return JH_OK;
+}
+
+JH_EXPORT int jh_per_update(jh_per* p, int64_t B, const int64_t* d_idx, const void* d_prio, int32_t prio_dtype,
+                            jh_stream stream) {
+  JH_ARG(p && d_idx && d_prio);
+  JH_ARG(B >= 0);
+  JH_ARG(prio_dtype == JH_F32 || prio_dtype == JH_F64);
+  const size_t es = prio_dtype == JH_F32 ? 4 : 8;
+  for (int64_t done = 0; done < B; done += kChunk) {
+    const int seg = (int)(B - done < kChunk ? B - done : kChunk);
+    int rc = per_apply(p, seg, d_idx + done, 0, (const char*)d_prio + es * (size_t)done, prio_dtype, 0, jh_s(stream));
+    if (rc) return rc;
+  }
+  return JH_OK;
+}
+
+JH_EXPORT int jh_per_sample(jh_per* p, int64_t B, double beta, int64_t n_uniform, const int64_t* h_uniform_slot,
+                            const double* h_u, int64_t* d_idx, double* d_w64, float* d_w32, double* d_stats,
+                            jh_stream stream) {
+  JH_ARG(p && d_idx);
+  JH_ARG(B > 0 && n_uniform >= 0 && n_uniform <= B);
+  JH_ARG(n_uniform == 0 || h_uniform_slot);
+  JH_ARG(n_uniform == B || h_u);
+  if (p->counter <= 0) return jh_fail(JH_ERR_STATE, "jh_per_sample on an empty buffer (per_buffer.py:71 asserts root > 0)");
+  hipStream_t st = jh_s(stream);
+  if (p->ws.ws_cap < B) {
+    JH_HIP(hipStreamSynchronize(st));
+    if (p->ws.prio) JH_HIP(hipFree(p->ws.prio));
+    if (p->ws.w) JH_HIP(hipFree(p->ws.w));
+    int64_t cap = 1024;
+    while (cap < B) cap <<= 1;
+    JH_HIP(hipMalloc((void**)&p->ws.prio, sizeof(double) * (size_t)cap));
+    JH_HIP(hipMalloc((void**)&p->ws.w, sizeof(double) * (size_t)cap));
+    p->ws.ws_cap = cap;
+  }
+  // RNG draws: written into a pinned, device-mapped slab that the kernel reads in place
+  // (B*8 bytes: one PCIe read burst, cheaper than a separate DMA for B = 32..512)
+  jh_pinned_slab* slab = nullptr;
+  const size_t off_u = (sizeof(int64_t) * (size_t)n_uniform + 255) & ~(size_t)255;
+  int rc = jh_ctx_slab(p->ctx, off_u + sizeof(double) * (size_t)(B - n_uniform) + 256, &slab);
+  if (rc) return rc;
+  if (n_uniform) memcpy(slab->host, h_uniform_slot, sizeof(int64_t) * (size_t)n_uniform);
+  if (B - n_uniform) memcpy((char*)slab->host + off_u, h_u, sizeof(double) * (size_t)(B - n_uniform));
+  int64_t nbl = (B + 255) / 256;
+  const int nb = (int)(nbl < kMaxBlocks ? nbl : kMaxBlocks);
+  hipLaunchKernelGGL(jh_per_sample_kernel, dim3(nb), dim3(256), 0, st, p->tree, p->N - 1, B, n_uniform,
+                     (const int64_t*)slab->dev, (const double*)((char*)slab->dev + off_u), p->counter, p->usp, beta,
+                     d_idx, p->ws.prio, p->ws.w, p->ws.partial);
+  JH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(jh_per_norm_kernel, dim3(nb), dim3(256), 0, st, p->tree, B, nb, p->ws.partial, p->ws.w,
+                     p->counter, d_w64, d_w32, d_stats);
+  JH_LAUNCH_CHECK();
+  return jh_ctx_slab_release(p->ctx, slab, st);
+}
+
+JH_EXPORT int jh_per_state(jh_per* p, double* max_priority, double* root, int64_t* tree_index, int64_t* counter,
+                           jh_stream stream) {
+  JH_ARG(p != nullptr);
+  hipStream_t st = jh_s(stream);
+  if (max_priority) JH_HIP(hipMemcpyAsync(max_priority, p->maxp, sizeof(double), hipMemcpyDeviceToHost, st));
+  if (root) JH_HIP(hipMemcpyAsync(root, p->tree, sizeof(double), hipMemcpyDeviceToHost, st));
+  JH_HIP(hipStreamSynchronize(st));
+  if (tree_index) *tree_index = p->tree_index;
+  if (counter) *counter = p->counter;
+  return JH_OK;
+}
+
+JH_EXPORT int jh_per_load(jh_per* p, const double* h_tree, double max_priority, int64_t tree_index, int64_t counter) {
+  JH_ARG(p && h_tree);
+  JH_ARG(tree_index >= p->N - 1 && tree_index < p->tree_size && counter >= 0 && counter <= p->N);
+  JH_HIP(hipDeviceSynchronize());
+  JH_HIP(hipMemcpy(p->tree, h_tree, sizeof(double) * (size_t)p->tree_size, hipMemcpyHostToDevice));
+  JH_HIP(hipMemcpy(p->maxp, &max_priority, sizeof(double), hipMemcpyHostToDevice));
+  p->tree_index = tree_index;
+  p->counter = counter;
+  return JH_OK;
+}
+
+JH_EXPORT int jh_per_dump(jh_per* p, double* h_tree, jh_stream stream) {
+  JH_ARG(p && h_tree);
+  JH_HIP(hipStreamSynchronize(jh_s(stream)));
+  JH_HIP(hipMemcpy(h_tree, p->tree, sizeof(double) * (size_t)p->tree_size, hipMemcpyDeviceToHost));
+  return JH_OK;
+}
+
+JH_EXPORT double* jh_per_tree_ptr(jh_per* p) { return p ? p->tree : nullptr; }
+JH_EXPORT int64_t jh_per_tree_size(const jh_per* p) { return p ? p->tree_size : -1; }

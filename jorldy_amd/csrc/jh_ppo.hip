@@ -1,0 +1,487 @@
+// PPO hot-path math for gfx950 (core/agent/ppo.py:83-165):
+//   jh_gae                 GAE reverse scan + return + per-row standardisation (ppo.py:95-110)
+//   jh_logp_*              log pi_old(a|s)                                      (ppo.py:84-93)
+//   jh_ppo_loss_*          clipped surrogate + clipped value + entropy, fwd + bwd to the heads
+// All of it is HBM/latency-bound elementwise + reduction work: SoA float32 columns, coalesced
+// loads, wave-shuffle scans/reductions, no GEMM.  Compiled with -ffp-contract=off so products and
+// sums round separately like the torch ops they replace.
+#include "jh_common.h"
+
+// ============================================================================ GAE
+// One wave (64 lanes) per rollout row.  The recurrence adv[t] = delta[t] + c[t]*adv[t+1],
+// c[t] = (1-d[t])*gamma*lambda, is a first-order linear recurrence: with f_t(x) = b_t + a_t*x the
+// suffix composition F_t = f_t o f_{t+1} o ... is associative, so a 64-wide tile is scanned with
+// 6 shuffle steps; tiles are walked from the row end carrying adv of the next tile's first lane.
+// Algorithmic traffic: 4 reads + 2 writes = 24 B per transition (+ L2-resident re-reads for the
+// standardisation passes).
+__global__ void __launch_bounds__(256) jh_gae_kernel(int W, int T, float gamma, float lambda,
+                                                     const float* __restrict__ reward,
+                                                     const float* __restrict__ done,
+                                                     const float* __restrict__ value,
+                                                     const float* __restrict__ next_value,
+                                                     float* __restrict__ adv, float* __restrict__ ret,
+                                                     int standardize) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= W) return;  // whole wave exits together
+  const size_t base = (size_t)row * (size_t)T;
+  const int ntiles = (T + 63) >> 6;
+  float carry = 0.f;  // adv[t+1] for the last lane of the current tile
+  float sum = 0.f;
+  for (int k = ntiles - 1; k >= 0; --k) {
+    const int t = k * 64 + lane;
+    float a = 1.f, b = 0.f, v = 0.f;
+    if (t < T) {
+      const float r = reward[base + t], d = done[base + t], vn = next_value[base + t];
+      v = value[base + t];
+      const float nd_g = (1.f - d) * gamma;  // ((1-done)*gamma) first, as in ppo.py:95,99-100
+      b = r + nd_g * vn - v;                 // delta
+      a = (t == T - 1) ? 0.f : nd_g * lambda;  // no bootstrap across the row end (ppo.py:98)
+    }
+    // inclusive suffix scan of (a,b) over the 64 lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float a2 = __shfl_down(a, off, 64);
+      const float b2 = __shfl_down(b, off, 64);
+      if (lane + off < 64) {
+        b = b + a * b2;
+        a = a * a2;
+      }
+    }
+    const float x = b + a * carry;
+    carry = __shfl(x, 0, 64);
+    if (t < T) {
+      adv[base + t] = x;
+      ret[base + t] = x + v;  // ppo.py:103
+      sum += x;
+    }
+  }
+  if (!standardize) return;
+  // per-row (adv - mean) / (std_unbiased + 1e-7)   ppo.py:105-108.  Each lane re-reads only the
+  // elements it wrote itself, so no cross-lane visibility is needed.
+  const float mean = jh_wave_sum(sum) / (float)T;
+  float ssq = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const float c = adv[base + t] - mean;
+    ssq += c * c;
+  }
+  const float var = jh_wave_sum(ssq) / (float)(T - 1);
+  const float inv = 1.f / (sqrtf(var) + 1e-7f);
+  for (int t = lane; t < T; t += 64) adv[base + t] = (adv[base + t] - mean) * inv;
+}
+
+JH_EXPORT int jh_gae(jh_ctx* ctx, int32_t W, int32_t T, float gamma, float lambda, const float* d_reward,
+                     const float* d_done, const float* d_value, const float* d_next_value, float* d_adv, float* d_ret,
+                     int32_t standardize, jh_stream stream) {
+  JH_ARG(ctx && d_reward && d_done && d_value && d_next_value && d_adv && d_ret);
+  JH_ARG(W > 0 && T > 0);
+  hipLaunchKernelGGL(jh_gae_kernel, dim3((W + 3) / 4), dim3(256), 0, jh_s(stream), W, T, gamma, lambda, d_reward, d_done,
+                     d_value, d_next_value, d_adv, d_ret, standardize);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// ============================================================================ shared row math
+#define JH_EPS32 1.1920929e-07f        // torch.finfo(float32).eps used by Categorical's clamp
+#define JH_HALF_LOG_2PI 0.9189385332f  // log(sqrt(2*pi))
+#define JH_ATANH_HI 0.99999988f        // fp32(1 - 1e-7)   ppo.py:87
+#define JH_ATANH_LO -0.99999988f
+
+struct PpoParams {
+  float eps, vf, ent;
+};
+
+struct RowFwd {
+  float ratio, surr1, surr2, smin, v, vclip, ret, adv, e1, e2, ent, minp, d_logp_scale;
+};
+
+// ---- discrete head -----------------------------------------------------------------------------
+struct DiscRow {
+  float m, lse, s;  // row max, log-sum-exp of (z-m), sum of p (re-normalisation by Categorical)
+};
+
+__device__ __forceinline__ DiscRow disc_prepare(const float* __restrict__ z, int A) {
+  DiscRow r;
+  float m = z[0];
+  for (int k = 1; k < A; ++k) m = fmaxf(m, z[k]);
+  float se = 0.f;
+  for (int k = 0; k < A; ++k) se += expf(z[k] - m);
+  r.m = m;
+  r.lse = logf(se);
+  float s = 0.f;
+  for (int k = 0; k < A; ++k) s += expf((z[k] - m) - r.lse);
+  r.s = s;
+  return r;
+}
+
+// Categorical(probs=pi): pn = pi/sum(pi); logits = log(clamp(pn, eps, 1-eps))
+__device__ __forceinline__ void disc_terms(const float* __restrict__ z, int k, const DiscRow& r, float& p, float& pn,
+                                           float& c, float& lg, bool& inr) {
+  p = expf((z[k] - r.m) - r.lse);
+  pn = p / r.s;
+  inr = (pn >= JH_EPS32) && (pn <= 1.f - JH_EPS32);
+  c = fminf(fmaxf(pn, JH_EPS32), 1.f - JH_EPS32);
+  lg = logf(c);
+}
+
+// ============================================================================ log pi_old
+__global__ void __launch_bounds__(256) jh_logp_discrete_kernel(int64_t M, int A, const float* __restrict__ logits,
+                                                               const float* __restrict__ action,
+                                                               float* __restrict__ logp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const float* z = logits + i * A;
+  float m = z[0];
+  for (int k = 1; k < A; ++k) m = fmaxf(m, z[k]);
+  float se = 0.f;
+  for (int k = 0; k < A; ++k) se += expf(z[k] - m);
+  int a = (int)action[i];
+  a = a < 0 ? 0 : (a >= A ? A - 1 : a);
+  const float pi = expf((z[a] - m) - logf(se));  // exp(log_softmax)  policy_value.py:22
+  logp[i] = logf(pi);                            // pi.gather(1, a).log()  ppo.py:92
+}
+
+__device__ __forceinline__ float normal_logp(float mu_raw, float ls_raw, float act, float& mu, float& std, float& z) {
+  mu = fminf(fmaxf(mu_raw, -5.f), 5.f);  // policy_value.py:54
+  std = expf(tanhf(ls_raw));             // policy_value.py:55-56
+  const float a = fminf(fmaxf(act, JH_ATANH_LO), JH_ATANH_HI);
+  z = atanhf(a);
+  const float var = std * std;
+  const float dm = z - mu;
+  return -(dm * dm) / (2.f * var) - logf(std) - JH_HALF_LOG_2PI;  // Normal.log_prob
+}
+
+__global__ void __launch_bounds__(256) jh_logp_continuous_kernel(int64_t MA, const float* __restrict__ mu_raw,
+                                                                 const float* __restrict__ ls_raw,
+                                                                 const float* __restrict__ action,
+                                                                 float* __restrict__ logp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= MA) return;
+  float mu, std, z;
+  logp[i] = normal_logp(mu_raw[i], ls_raw[i], action[i], mu, std, z);
+}
+
+JH_EXPORT int jh_logp_discrete(jh_ctx* ctx, int64_t M, int32_t A, const float* d_logits, const float* d_action,
+                               float* d_logp, jh_stream stream) {
+  JH_ARG(ctx && d_logits && d_action && d_logp);
+  JH_ARG(M > 0 && A > 0);
+  hipLaunchKernelGGL(jh_logp_discrete_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, jh_s(stream), M, A,
+                     d_logits, d_action, d_logp);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+JH_EXPORT int jh_logp_continuous(jh_ctx* ctx, int64_t M, int32_t A, const float* d_mu_raw, const float* d_log_std_raw,
+                                 const float* d_action, float* d_logp, jh_stream stream) {
+  JH_ARG(ctx && d_mu_raw && d_log_std_raw && d_action && d_logp);
+  JH_ARG(M > 0 && A > 0);
+  const int64_t MA = M * A;
+  hipLaunchKernelGGL(jh_logp_continuous_kernel, dim3((unsigned)((MA + 255) / 256)), dim3(256), 0, jh_s(stream), MA,
+                     d_mu_raw, d_log_std_raw, d_action, d_logp);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// ============================================================================ PPO loss
+// Per-row forward terms shared by both heads once logp-sum is known.
+struct RowCommon {
+  float ratio, adv, v, vold, ret, vclip, smin;
+  float g1, g2;  // sub-gradients of min(surr1, surr2) (ties split 1/2 like torch.min)
+  bool in_clip, in_v;
+};
+
+__device__ __forceinline__ RowCommon row_common(float logp_diff_sum, float adv, float v, float vold, float ret,
+                                                float eps) {
+  RowCommon c;
+  c.ratio = expf(logp_diff_sum);
+  c.adv = adv;
+  c.v = v;
+  c.vold = vold;
+  c.ret = ret;
+  const float surr1 = c.ratio * adv;
+  const float rc = fminf(fmaxf(c.ratio, 1.f - eps), 1.f + eps);
+  const float surr2 = rc * adv;
+  c.smin = fminf(surr1, surr2);
+  c.g1 = surr1 < surr2 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);
+  c.g2 = surr2 < surr1 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);
+  c.in_clip = (c.ratio >= 1.f - eps) && (c.ratio <= 1.f + eps);
+  const float dv = v - vold;
+  c.in_v = (dv >= -eps) && (dv <= eps);
+  c.vclip = vold + fminf(fmaxf(dv, -eps), eps);
+  return c;
+}
+
+// partial layout per block: {sum_smin, sum_e1, sum_e2, sum_ent, max_ratio, min_prob}
+#define PPO_NPART 6
+
+template <bool CONT>
+struct PpoArgs {
+  int B, A;
+  const float* h0;  // logits | mu_raw           [B][A]
+  const float* h1;  // unused | log_std_raw      [B][A]
+  const float* value_pred;  // [B]
+  const int64_t* idx;       // [B] or null
+  const float* action;      // [M] (disc) | [M][A] (cont)
+  const float* adv;         // [M]
+  const float* ret;         // [M]
+  const float* value_old;   // [M]
+  const float* logp_old;    // [M] (disc) | [M][A] (cont)
+  float eps, vf, ent;
+  float* g0;  // d logits | d mu_raw
+  float* g1;  // unused   | d log_std_raw
+  float* gv;  // d value_pred
+  float* partial;
+  float* stats;
+  int nb;
+};
+
+template <bool CONT>
+__device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, RowCommon& rc, float& ent_row,
+                                            float& minp_row, DiscRow& dr, int& act_k) {
+  const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
+  const float adv = a.adv[r], ret = a.ret[r], vold = a.value_old[r], v = a.value_pred[i];
+  if (!CONT) {
+    const float* z = a.h0 + (size_t)i * a.A;
+    dr = disc_prepare(z, a.A);
+    int ak = (int)a.action[r];
+    ak = ak < 0 ? 0 : (ak >= a.A ? a.A - 1 : ak);
+    act_k = ak;
+    float ent = 0.f, logp = 0.f;
+    for (int k = 0; k < a.A; ++k) {
+      float p, pn, c, lg;
+      bool inr;
+      disc_terms(z, k, dr, p, pn, c, lg, inr);
+      ent += pn * lg;
+      if (k == ak) logp = lg;
+    }
+    ent_row = -ent;  // Categorical.entropy
+    rc = row_common(logp - a.logp_old[r], adv, v, vold, ret, a.eps);
+    minp_row = expf(logp);
+  } else {
+    float lsum = 0.f, ent = 0.f, minp = 3.4e38f;
+    for (int k = 0; k < a.A; ++k) {
+      float mu, std, z;
+      const float lp = normal_logp(a.h0[(size_t)i * a.A + k], a.h1[(size_t)i * a.A + k], a.action[r * a.A + k], mu, std, z);
+      lsum += lp - a.logp_old[r * a.A + k];
+      ent += 0.5f + JH_HALF_LOG_2PI + logf(std);  // Normal.entropy
+      minp = fminf(minp, expf(lp));
+    }
+    ent_row = ent;  // summed over dims; the mean is over B*A elements (ppo.py:156)
+    rc = row_common(lsum, adv, v, vold, ret, a.eps);
+    minp_row = minp;
+  }
+}
+
+template <bool CONT>
+__device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const RowCommon& rc, const DiscRow& dr,
+                                            int act_k, float w1, float w2) {
+  const float invB = 1.f / (float)a.B;
+  const float d_ratio = -invB * (rc.g1 * rc.adv + (rc.in_clip ? rc.g2 * rc.adv : 0.f));
+  const float d_logp = d_ratio * rc.ratio;
+  // critic = max(c1, c2): weights w1/w2 (ties split); clamp passes grad inside [-eps, eps]
+  const float dv = a.vf * (w1 * 2.f * (rc.v - rc.ret) * invB + (rc.in_v ? w2 * 2.f * (rc.vclip - rc.ret) * invB : 0.f));
+  a.gv[i] = dv;
+  if (!CONT) {
+    const float* z = a.h0 + (size_t)i * a.A;
+    const float ce = a.ent * invB;  // loss += ent_coef * (-mean(H)) = ent_coef/B * sum pn*lg
+    float T1 = 0.f;
+    for (int k = 0; k < a.A; ++k) {
+      float p, pn, c, lg;
+      bool inr;
+      disc_terms(z, k, dr, p, pn, c, lg, inr);
+      const float g_lg = (k == act_k ? d_logp : 0.f) + ce * pn;
+      const float g_pn = ce * lg + (inr ? g_lg / c : 0.f);
+      T1 += g_pn * p;
+    }
+    float T2 = 0.f;
+    const float s = dr.s;
+    for (int k = 0; k < a.A; ++k) {
+      float p, pn, c, lg;
+      bool inr;
+      disc_terms(z, k, dr, p, pn, c, lg, inr);
+      const float g_lg = (k == act_k ? d_logp : 0.f) + ce * pn;
+      const float g_pn = ce * lg + (inr ? g_lg / c : 0.f);
+      const float g_p = g_pn / s - T1 / (s * s);
+      T2 += g_p * p;
+    }
+    for (int k = 0; k < a.A; ++k) {
+      float p, pn, c, lg;
+      bool inr;
+      disc_terms(z, k, dr, p, pn, c, lg, inr);
+      const float g_lg = (k == act_k ? d_logp : 0.f) + ce * pn;
+      const float g_pn = ce * lg + (inr ? g_lg / c : 0.f);
+      const float g_p = g_pn / s - T1 / (s * s);
+      a.g0[(size_t)i * a.A + k] = g_p * p - p * T2;  // log_softmax backward
+    }
+  } else {
+    const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
+    const float ce = -a.ent / (float)(a.B * a.A);  // d(ent_coef * -mean(H)) / d log(std)
+    for (int k = 0; k < a.A; ++k) {
+      const float mr = a.h0[(size_t)i * a.A + k], lr = a.h1[(size_t)i * a.A + k];
+      float mu, std, z;
+      (void)normal_logp(mr, lr, a.action[r * a.A + k], mu, std, z);
+      const float var = std * std, dm = z - mu;
+      const float d_mu = d_logp * dm / var;
+      float d_std = d_logp * ((dm * dm) / (var * std) - 1.f / std);
+      d_std += ce / std;
+      const float th = tanhf(lr);
+      a.g0[(size_t)i * a.A + k] = (mr >= -5.f && mr <= 5.f) ? d_mu : 0.f;
+      a.g1[(size_t)i * a.A + k] = d_std * std * (1.f - th * th);
+    }
+  }
+}
+
+__device__ __forceinline__ void ppo_finish_stats(float s_smin, float s_e1, float s_e2, float s_ent, float max_ratio,
+                                                 float min_prob, int B, int ent_count, float vf, float ent, float& w1,
+                                                 float& w2, float* stats) {
+  const float actor = -(s_smin / (float)B);
+  const float c1 = s_e1 / (float)B, c2 = s_e2 / (float)B;
+  const float critic = fmaxf(c1, c2);
+  w1 = c1 > c2 ? 1.f : (c1 == c2 ? 0.5f : 0.f);
+  w2 = 1.f - w1;
+  const float entropy_loss = -(s_ent / (float)ent_count);
+  if (stats) {
+    stats[0] = actor + vf * critic + ent * entropy_loss;  // ppo.py:158-162
+    stats[1] = actor;
+    stats[2] = critic;
+    stats[3] = entropy_loss;
+    stats[4] = max_ratio;
+    stats[5] = min_prob;
+    stats[6] = c1;
+    stats[7] = c2;
+  }
+}
+
+// B <= 1024: one workgroup does forward, the 6 block reductions and backward with the row terms
+// still in registers (one launch per minibatch instead of two).
+template <bool CONT>
+__global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
+  __shared__ float s_red[16];
+  const int i = threadIdx.x;
+  const bool on = i < a.B;
+  RowCommon rc{};
+  DiscRow dr{};
+  int act_k = 0;
+  float ent_row = 0.f, minp = 3.4e38f;
+  if (on) ppo_row_fwd<CONT>(a, i, rc, ent_row, minp, dr, act_k);
+  const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
+  const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
+  const float s_smin = jh_block_reduce(on ? rc.smin : 0.f, s_red, JhAdd(), 0.f);
+  const float s_e1 = jh_block_reduce(e1, s_red, JhAdd(), 0.f);
+  const float s_e2 = jh_block_reduce(e2, s_red, JhAdd(), 0.f);
+  const float s_ent = jh_block_reduce(on ? ent_row : 0.f, s_red, JhAdd(), 0.f);
+  const float mx = jh_block_reduce(on ? rc.ratio : -3.4e38f, s_red, JhMax(), -3.4e38f);
+  const float mn = jh_block_reduce(on ? minp : 3.4e38f, s_red, JhMin(), 3.4e38f);
+  float w1, w2;
+  ppo_finish_stats(s_smin, s_e1, s_e2, s_ent, mx, mn, a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
+                   threadIdx.x == 0 ? a.stats : nullptr);
+  if (on) ppo_row_bwd<CONT>(a, i, rc, dr, act_k, w1, w2);
+}
+
+// B > 1024: pass 1 writes per-block partials, pass 2 re-reduces them in every block (deterministic,
+// no atomics) and recomputes the cheap row terms instead of spilling them to HBM.
+template <bool CONT>
+__global__ void __launch_bounds__(256) jh_ppo_fwd_kernel(PpoArgs<CONT> a) {
+  __shared__ float s_red[16];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < a.B;
+  RowCommon rc{};
+  DiscRow dr{};
+  int act_k = 0;
+  float ent_row = 0.f, minp = 3.4e38f;
+  if (on) ppo_row_fwd<CONT>(a, i, rc, ent_row, minp, dr, act_k);
+  const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
+  const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
+  const float s_smin = jh_block_reduce(on ? rc.smin : 0.f, s_red, JhAdd(), 0.f);
+  const float s_e1 = jh_block_reduce(e1, s_red, JhAdd(), 0.f);
+  const float s_e2 = jh_block_reduce(e2, s_red, JhAdd(), 0.f);
+  const float s_ent = jh_block_reduce(on ? ent_row : 0.f, s_red, JhAdd(), 0.f);
+  const float mx = jh_block_reduce(on ? rc.ratio : -3.4e38f, s_red, JhMax(), -3.4e38f);
+  const float mn = jh_block_reduce(on ? minp : 3.4e38f, s_red, JhMin(), 3.4e38f);
+  if (threadIdx.x == 0) {
+    float* p = a.partial + (size_t)blockIdx.x * PPO_NPART;
+    p[0] = s_smin; p[1] = s_e1; p[2] = s_e2; p[3] = s_ent; p[4] = mx; p[5] = mn;
+  }
+}
+
+template <bool CONT>
+__global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
+  __shared__ float s_red[16];
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = -3.4e38f, t5 = 3.4e38f;
+  for (int b = threadIdx.x; b < a.nb; b += 256) {
+    const float* p = a.partial + (size_t)b * PPO_NPART;
+    t0 += p[0]; t1 += p[1]; t2 += p[2]; t3 += p[3];
+    t4 = fmaxf(t4, p[4]); t5 = fminf(t5, p[5]);
+  }
+  t0 = jh_block_reduce(t0, s_red, JhAdd(), 0.f);
+  t1 = jh_block_reduce(t1, s_red, JhAdd(), 0.f);
+  t2 = jh_block_reduce(t2, s_red, JhAdd(), 0.f);
+  t3 = jh_block_reduce(t3, s_red, JhAdd(), 0.f);
+  t4 = jh_block_reduce(t4, s_red, JhMax(), -3.4e38f);
+  t5 = jh_block_reduce(t5, s_red, JhMin(), 3.4e38f);
+  float w1, w2;
+  ppo_finish_stats(t0, t1, t2, t3, t4, t5, a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
+                   (blockIdx.x == 0 && threadIdx.x == 0) ? a.stats : nullptr);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.B) return;
+  RowCommon rc;
+  DiscRow dr{};
+  int act_k = 0;
+  float ent_row, minp;
+  ppo_row_fwd<CONT>(a, i, rc, ent_row, minp, dr, act_k);
+  ppo_row_bwd<CONT>(a, i, rc, dr, act_k, w1, w2);
+}
+
+template <bool CONT>
+static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
+  if (a.B <= 1024) {
+    const int threads = ((a.B + 63) / 64) * 64;
+    a.nb = 1;
+    hipLaunchKernelGGL(jh_ppo_fused_kernel<CONT>, dim3(1), dim3(threads), 0, st, a);
+    JH_LAUNCH_CHECK();
+    return JH_OK;
+  }
+  a.nb = (a.B + 255) / 256;
+  void* scratch = nullptr;
+  int rc = jh_ctx_scratch(ctx, sizeof(float) * PPO_NPART * (size_t)a.nb, &scratch);
+  if (rc) return rc;
+  a.partial = (float*)scratch;
+  hipLaunchKernelGGL(jh_ppo_fwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
+  JH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(jh_ppo_bwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+JH_EXPORT int jh_ppo_loss_discrete(jh_ctx* ctx, int32_t B, int32_t A, const float* d_logits, const float* d_value_pred,
+                                   const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
+                                   const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef,
+                                   float ent_coef, float* d_grad_logits, float* d_grad_value, float* d_stats,
+                                   jh_stream stream) {
+  JH_ARG(ctx && d_logits && d_value_pred && d_action && d_adv && d_ret && d_value_old && d_logp_old);
+  JH_ARG(d_grad_logits && d_grad_value);
+  JH_ARG(B > 0 && A > 0);
+  PpoArgs<false> a{};
+  a.B = B; a.A = A; a.h0 = d_logits; a.h1 = nullptr; a.value_pred = d_value_pred; a.idx = d_idx;
+  a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+  a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_logits; a.g1 = nullptr; a.gv = d_grad_value;
+  a.stats = d_stats;
+  return ppo_launch<false>(ctx, a, jh_s(stream));
+}
+
+JH_EXPORT int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const float* d_mu_raw,
+                                     const float* d_log_std_raw, const float* d_value_pred, const int64_t* d_idx,
+                                     const float* d_action, const float* d_adv, const float* d_ret,
+                                     const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef,
+                                     float ent_coef, float* d_grad_mu_raw, float* d_grad_log_std_raw,
+                                     float* d_grad_value, float* d_stats, jh_stream stream) {
+  JH_ARG(ctx && d_mu_raw && d_log_std_raw && d_value_pred && d_action && d_adv && d_ret && d_value_old && d_logp_old);
+  JH_ARG(d_grad_mu_raw && d_grad_log_std_raw && d_grad_value);
+  JH_ARG(B > 0 && A > 0);
+  PpoArgs<true> a{};
+  a.B = B; a.A = A; a.h0 = d_mu_raw; a.h1 = d_log_std_raw; a.value_pred = d_value_pred; a.idx = d_idx;
+  a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+  a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_mu_raw; a.g1 = d_grad_log_std_raw; a.gv = d_grad_value;
+  a.stats = d_stats;
+  return ppo_launch<true>(ctx, a, jh_s(stream));
+}

@@ -1,0 +1,243 @@
+// GPU-resident SoA transition store: ring push via pinned staging + async H2D, and a fused
+// multi-column gather that also performs the fp32 cast of BaseAgent.as_tensor.
+// Replaces core/buffer/replay_buffer.py:8-35, rollout_buffer.py:6-24, base.py:42-56.
+#include "jh_common.h"
+
+struct jh_store {
+  jh_ctx* ctx = nullptr;
+  int64_t capacity = 0;
+  int n_cols = 0;
+  std::vector<jh_col_desc> cols;
+  std::vector<void*> dev;         // device column bases
+  std::vector<size_t> row_bytes;  // bytes per transition per column
+  int64_t index = 0;              // buffer_index
+  int64_t counter = 0;            // buffer_counter
+  // staged push state
+  jh_pinned_slab* staged = nullptr;
+  int64_t staged_n = 0;
+  std::vector<size_t> staged_off;
+};
+
+JH_EXPORT int jh_store_create(jh_ctx* ctx, int64_t capacity, int32_t n_cols, const jh_col_desc* cols, jh_store** out) {
+  JH_ARG(ctx && out && cols);
+  JH_ARG(capacity > 0 && n_cols > 0 && n_cols <= 16);
+  JH_HIP(hipSetDevice(ctx->device));
+  jh_store* s = new jh_store();
+  s->ctx = ctx;
+  s->capacity = capacity;
+  s->n_cols = n_cols;
+  for (int c = 0; c < n_cols; ++c) {
+    size_t es = jh_dtype_size(cols[c].dtype);
+    if (es == 0 || cols[c].elems <= 0) {
+      delete s;
+      return jh_fail(JH_ERR_ARG, "column %d: bad dtype %d / elems %lld", c, cols[c].dtype, (long long)cols[c].elems);
+    }
+    s->cols.push_back(cols[c]);
+    s->row_bytes.push_back(es * (size_t)cols[c].elems);
+  }
+  for (int c = 0; c < n_cols; ++c) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, s->row_bytes[c] * (size_t)capacity);
+    if (e != hipSuccess) {
+      for (void* q : s->dev) (void)hipFree(q);
+      delete s;
+      return jh_fail(JH_ERR_NOMEM, "hipMalloc of column %d (%zu bytes) failed: %s", c, s->row_bytes[c] * (size_t)capacity,
+                     hipGetErrorString(e));
+    }
+    s->dev.push_back(p);
+  }
+  s->staged_off.resize(n_cols);
+  *out = s;
+  return JH_OK;
+}
+
+JH_EXPORT void jh_store_destroy(jh_store* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : s->dev) (void)hipFree(p);
+  delete s;
+}
+
+JH_EXPORT int jh_store_stage_begin(jh_store* s, int64_t n, void** h_cols_out) {
+  JH_ARG(s && h_cols_out);
+  JH_ARG(n > 0 && n <= s->capacity);
+  if (s->staged) return jh_fail(JH_ERR_STATE, "jh_store_stage_begin called twice without commit");
+  size_t total = 0;
+  for (int c = 0; c < s->n_cols; ++c) {
+    s->staged_off[c] = total;
+    total += (s->row_bytes[c] * (size_t)n + 255) & ~(size_t)255;
+  }
+  jh_pinned_slab* slab = nullptr;
+  int rc = jh_ctx_slab(s->ctx, total, &slab);
+  if (rc) return rc;
+  s->staged = slab;
+  s->staged_n = n;
+  for (int c = 0; c < s->n_cols; ++c) h_cols_out[c] = (char*)slab->host + s->staged_off[c];
+  return JH_OK;
+}
+
+JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) {
+  JH_ARG(s != nullptr);
+  if (!s->staged) return jh_fail(JH_ERR_STATE, "jh_store_stage_commit without begin");
+  hipStream_t st = jh_s(stream);
+  const int64_t n = s->staged_n;
+  const int64_t first = s->capacity - s->index < n ? s->capacity - s->index : n;  // rows before the wrap
+  for (int c = 0; c < s->n_cols; ++c) {
+    const size_t rb = s->row_bytes[c];
+    const char* src = (const char*)s->staged->host + s->staged_off[c];
+    JH_HIP(hipMemcpyAsync((char*)s->dev[c] + rb * (size_t)s->index, src, rb * (size_t)first, hipMemcpyHostToDevice, st));
+    if (first < n)
+      JH_HIP(hipMemcpyAsync(s->dev[c], src + rb * (size_t)first, rb * (size_t)(n - first), hipMemcpyHostToDevice, st));
+  }
+  int rc = jh_ctx_slab_release(s->ctx, s->staged, st);
+  s->staged = nullptr;
+  if (rc) return rc;
+  s->index = (s->index + n) % s->capacity;
+  s->counter = s->counter + n < s->capacity ? s->counter + n : s->capacity;
+  return JH_OK;
+}
+
+JH_EXPORT int jh_store_push(jh_store* s, int64_t n, const void* const* h_cols, jh_stream stream) {
+  JH_ARG(s && h_cols);
+  if (n == 0) return JH_OK;
+  // a push longer than the ring keeps only the last `capacity` rows, like the reference's loop
+  if (n > s->capacity) {
+    // advance the ring as the reference would, then store the surviving tail
+    const int64_t skip = n - s->capacity;
+    std::vector<const void*> tail(s->n_cols);
+    for (int c = 0; c < s->n_cols; ++c) tail[c] = (const char*)h_cols[c] + s->row_bytes[c] * (size_t)skip;
+    s->index = (s->index + skip) % s->capacity;
+    s->counter = s->capacity;
+    return jh_store_push(s, s->capacity, tail.data(), stream);
+  }
+  std::vector<void*> dst(s->n_cols);
+  int rc = jh_store_stage_begin(s, n, dst.data());
+  if (rc) return rc;
+  for (int c = 0; c < s->n_cols; ++c) memcpy(dst[c], h_cols[c], s->row_bytes[c] * (size_t)n);
+  return jh_store_stage_commit(s, stream);
+}
+
+// ------------------------------------------------------------------------------ gather
+struct GatherCol {
+  const void* src;
+  void* dst;
+  int64_t elems;
+  int32_t src_dt;
+  int32_t dst_dt;
+};
+struct GatherArgs {
+  GatherCol col[16];
+};
+
+template <typename S>
+__device__ __forceinline__ float to_f32(S v) { return (float)v; }
+
+// Generic element-wise path over the flattened [B*elems] output: consecutive lanes write
+// consecutive output elements (fully coalesced stores; loads are coalesced within a row).
+template <typename S, typename D>
+__device__ __forceinline__ void gather_rows(const S* __restrict__ src, D* __restrict__ dst, int64_t elems, int64_t B,
+                                            const int64_t* __restrict__ idx, int64_t idx_off, int64_t cap) {
+  const int64_t total = B * elems;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / elems, e = i - b * elems;
+    int64_t r = idx[b] - idx_off;
+    r = r < 0 ? 0 : (r >= cap ? cap - 1 : r);  // never read out of bounds on a bad index
+    dst[i] = (D)src[r * elems + e];
+  }
+}
+
+// uint8 rows whose byte length is a multiple of 16 (Atari frame stacks: 4*84*84 = 28224 = 16*1764):
+// 16 B per lane loads; uint8 out -> one 16 B store, fp32 out -> four 16 B stores.
+template <bool TO_F32>
+__device__ __forceinline__ void gather_u8_vec(const uint8_t* __restrict__ src, void* __restrict__ dstv, int64_t elems,
+                                              int64_t B, const int64_t* __restrict__ idx, int64_t idx_off, int64_t cap) {
+  const int64_t vecs = elems / 16;
+  const int64_t total = B * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / vecs, v = i - b * vecs;
+    int64_t r = idx[b] - idx_off;
+    r = r < 0 ? 0 : (r >= cap ? cap - 1 : r);
+    const uint4 x = *reinterpret_cast<const uint4*>(src + r * elems + v * 16);
+    if (!TO_F32) {
+      *reinterpret_cast<uint4*>((uint8_t*)dstv + b * elems + v * 16) = x;
+    } else {
+      float* d = (float*)dstv + b * elems + v * 16;
+      const unsigned wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float4 f;
+        f.x = (float)(wds[k] & 0xff);
+        f.y = (float)((wds[k] >> 8) & 0xff);
+        f.z = (float)((wds[k] >> 16) & 0xff);
+        f.w = (float)(wds[k] >> 24);
+        *reinterpret_cast<float4*>(d + 4 * k) = f;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) jh_gather_kernel(GatherArgs a, int64_t B, const int64_t* __restrict__ idx,
+                                                        int64_t idx_off, int64_t cap) {
+  const GatherCol c = a.col[blockIdx.y];
+  const int64_t elems = c.elems;
+  if (c.src_dt == JH_U8) {
+    const bool vec = (elems % 16) == 0;
+    if (c.dst_dt == JH_U8) {
+      if (vec) gather_u8_vec<false>((const uint8_t*)c.src, c.dst, elems, B, idx, idx_off, cap);
+      else gather_rows((const uint8_t*)c.src, (uint8_t*)c.dst, elems, B, idx, idx_off, cap);
+    } else {
+      if (vec) gather_u8_vec<true>((const uint8_t*)c.src, c.dst, elems, B, idx, idx_off, cap);
+      else gather_rows((const uint8_t*)c.src, (float*)c.dst, elems, B, idx, idx_off, cap);
+    }
+  } else if (c.src_dt == JH_F32) {
+    gather_rows((const float*)c.src, (float*)c.dst, elems, B, idx, idx_off, cap);
+  } else if (c.src_dt == JH_I64) {
+    if (c.dst_dt == JH_I64) gather_rows((const int64_t*)c.src, (int64_t*)c.dst, elems, B, idx, idx_off, cap);
+    else gather_rows((const int64_t*)c.src, (float*)c.dst, elems, B, idx, idx_off, cap);
+  } else if (c.src_dt == JH_F64) {
+    if (c.dst_dt == JH_F64) gather_rows((const double*)c.src, (double*)c.dst, elems, B, idx, idx_off, cap);
+    else gather_rows((const double*)c.src, (float*)c.dst, elems, B, idx, idx_off, cap);
+  } else if (c.src_dt == JH_I32) {
+    if (c.dst_dt == JH_I32) gather_rows((const int32_t*)c.src, (int32_t*)c.dst, elems, B, idx, idx_off, cap);
+    else gather_rows((const int32_t*)c.src, (float*)c.dst, elems, B, idx, idx_off, cap);
+  }
+}
+
+JH_EXPORT int jh_store_gather(jh_store* s, int64_t B, const int64_t* d_idx, int64_t idx_offset, int32_t n_sel,
+                              const int32_t* sel_cols, void* const* d_out, const int32_t* out_dtype, jh_stream stream) {
+  JH_ARG(s && d_idx && sel_cols && d_out && out_dtype);
+  JH_ARG(n_sel > 0 && n_sel <= 16);
+  if (B == 0) return JH_OK;
+  JH_ARG(B > 0);
+  GatherArgs a;
+  int64_t max_items = 1;
+  for (int i = 0; i < n_sel; ++i) {
+    const int c = sel_cols[i];
+    JH_ARG(c >= 0 && c < s->n_cols);
+    const int sdt = s->cols[c].dtype, ddt = out_dtype[i];
+    if (!(ddt == sdt || ddt == JH_F32)) return jh_fail(JH_ERR_ARG, "gather: column %d out dtype %d unsupported (stored %d)", c, ddt, sdt);
+    a.col[i] = GatherCol{s->dev[c], d_out[i], s->cols[c].elems, sdt, ddt};
+    const int64_t per = (sdt == JH_U8 && s->cols[c].elems % 16 == 0) ? s->cols[c].elems / 16 : s->cols[c].elems;
+    const int64_t items = (B * per + 255) / 256;
+    if (items > max_items) max_items = items;
+  }
+  // memory-bound: cap at 256 CUs x 8 blocks and grid-stride (guide G11)
+  const unsigned gx = (unsigned)(max_items < 2048 ? max_items : 2048);
+  hipLaunchKernelGGL(jh_gather_kernel, dim3(gx, n_sel), dim3(256), 0, jh_s(stream), a, B, d_idx, idx_offset, s->capacity);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+JH_EXPORT void* jh_store_col_ptr(jh_store* s, int32_t col) {
+  if (!s || col < 0 || col >= s->n_cols) return nullptr;
+  return s->dev[col];
+}
+JH_EXPORT int64_t jh_store_size(const jh_store* s) { return s ? s->counter : -1; }
+JH_EXPORT int64_t jh_store_index(const jh_store* s) { return s ? s->index : -1; }
+JH_EXPORT int64_t jh_store_capacity(const jh_store* s) { return s ? s->capacity : -1; }
+JH_EXPORT void jh_store_clear(jh_store* s) {
+  if (!s) return;
+  s->index = 0;
+  s->counter = 0;
+}

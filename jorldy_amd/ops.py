@@ -1,0 +1,321 @@
+"""Torch-facing wrappers over the C ABI (device memory, streams: plumbing only).
+
+Every function enqueues HIP kernels from libjorldy_hip.so on torch's current stream and
+returns torch tensors that alias the outputs.  Nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_DT = {torch.uint8: L.JH_U8, torch.float32: L.JH_F32, torch.int64: L.JH_I64, torch.float64: L.JH_F64, torch.int32: L.JH_I32, torch.bool: L.JH_U8}
+_NP_DT = {np.dtype("uint8"): L.JH_U8, np.dtype("float32"): L.JH_F32, np.dtype("int64"): L.JH_I64, np.dtype("float64"): L.JH_F64, np.dtype("int32"): L.JH_I32, np.dtype("bool"): L.JH_U8}
+_TORCH_OF = {L.JH_U8: torch.uint8, L.JH_F32: torch.float32, L.JH_I64: torch.int64, L.JH_F64: torch.float64, L.JH_I32: torch.int32}
+_NP_OF = {L.JH_U8: np.uint8, L.JH_F32: np.float32, L.JH_I64: np.int64, L.JH_F64: np.float64, L.JH_I32: np.int32}
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda, "expected a float32 CUDA tensor"
+    return t.contiguous()
+
+
+def _dev(t):
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+# ============================================================================= store
+class DeviceStore:
+    """GPU-resident SoA ring of transitions (jh_store_*)."""
+
+    def __init__(self, capacity, columns, device=None):
+        """columns: list of (name, jh_dtype, elems, shape_without_batch)."""
+        self.lib = L.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ctx = L.ctx(self.device.index)
+        self.capacity = int(capacity)
+        self.columns = list(columns)
+        self.names = [c[0] for c in columns]
+        descs = (L.ColDesc * len(columns))(*[L.ColDesc(int(c[1]), int(c[2])) for c in columns])
+        self.h = C.c_void_p()
+        L.check(self.lib.jh_store_create(self.ctx, self.capacity, len(columns), descs, C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jh_store_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return int(self.lib.jh_store_size(self.h))
+
+    @property
+    def index(self):
+        return int(self.lib.jh_store_index(self.h))
+
+    def clear(self):
+        self.lib.jh_store_clear(self.h)
+
+    def push(self, cols):
+        """cols: dict name -> numpy array [n, ...] (any float/int dtype; converted to the stored dtype)."""
+        n = None
+        arrs = []
+        for name, dt, elems, _ in self.columns:
+            a = np.ascontiguousarray(np.asarray(cols[name]).reshape(len(cols[name]), -1), dtype=_NP_OF[dt])
+            assert a.shape[1] == elems, f"column {name}: expected {elems} elems, got {a.shape[1]}"
+            n = a.shape[0] if n is None else n
+            assert a.shape[0] == n
+            arrs.append(a)
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        L.check(self.lib.jh_store_push(self.h, n, ptrs, L.stream_ptr()))
+        return n
+
+    def stage(self, n):
+        """Zero-copy push: returns dict name -> numpy view [n, elems] of PINNED memory; call commit() after filling."""
+        ptrs = (C.c_void_p * len(self.columns))()
+        L.check(self.lib.jh_store_stage_begin(self.h, n, ptrs))
+        out = {}
+        for (name, dt, elems, _), p in zip(self.columns, ptrs):
+            buf = (C.c_char * (n * elems * np.dtype(_NP_OF[dt]).itemsize)).from_address(p)
+            out[name] = np.frombuffer(buf, dtype=_NP_OF[dt]).reshape(n, elems)
+        return out
+
+    def commit(self):
+        L.check(self.lib.jh_store_stage_commit(self.h, L.stream_ptr()))
+
+    def column(self, name):
+        """Zero-copy torch view of a whole device column [capacity, *shape] (the lib owns the memory)."""
+        i = self.names.index(name)
+        _, dt, elems, shape = self.columns[i]
+        p = self.lib.jh_store_col_ptr(self.h, i)
+        return _wrap_device(p, (self.capacity,) + tuple(shape), _TORCH_OF[dt], self.device, owner=self)
+
+    def gather(self, idx, names=None, as_float=True, idx_offset=0):
+        """idx: int64 CUDA tensor [B] -> dict name -> tensor [B, *shape]; float32 (as_tensor semantics)
+        unless as_float=False (stored dtype, e.g. uint8 frames)."""
+        names = self.names if names is None else names
+        B = int(idx.numel())
+        sel, outs, odt = [], [], []
+        for nm in names:
+            i = self.names.index(nm)
+            _, dt, elems, shape = self.columns[i]
+            keep = (not as_float) if not isinstance(as_float, dict) else (not as_float.get(nm, True))
+            tdt = _TORCH_OF[dt] if keep else torch.float32
+            outs.append(torch.empty((B,) + tuple(shape), dtype=tdt, device=self.device))
+            sel.append(i)
+            odt.append(_DT[tdt])
+        selc = (C.c_int32 * len(sel))(*sel)
+        odtc = (C.c_int32 * len(sel))(*odt)
+        ptrs = (C.c_void_p * len(sel))(*[o.data_ptr() for o in outs])
+        assert idx.dtype == torch.int64 and idx.is_cuda
+        L.check(self.lib.jh_store_gather(self.h, B, L.ptr(idx.contiguous()), int(idx_offset), len(sel), selc, ptrs, odtc, L.stream_ptr()))
+        return dict(zip(names, outs))
+
+
+class _Owner:
+    pass
+
+
+def _wrap_device(ptr_value, shape, dtype, device, owner=None):
+    """torch tensor aliasing raw device memory owned by the library (via __cuda_array_interface__)."""
+    typestr = {torch.uint8: "|u1", torch.float32: "<f4", torch.int64: "<i8", torch.float64: "<f8", torch.int32: "<i4"}[dtype]
+    holder = _Owner()
+    holder.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr_value), False), "version": 2}
+    holder._owner = owner
+    with torch.cuda.device(device):
+        return torch.as_tensor(holder, device=device)
+
+
+# ============================================================================= PER sum tree
+class SumTree:
+    """Device float64 sum tree (jh_per_*), bit-identical to per_buffer.py's numpy tree."""
+
+    def __init__(self, capacity, uniform_sample_prob=1e-3, device=None):
+        self.lib = L.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ctx = L.ctx(self.device.index)
+        self.capacity = int(capacity)
+        self.usp = float(uniform_sample_prob)
+        self.h = C.c_void_p()
+        L.check(self.lib.jh_per_create(self.ctx, self.capacity, self.usp, C.byref(self.h)))
+        self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jh_per_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def tree_size(self):
+        return 2 * self.capacity - 1
+
+    def push(self, n, priorities=None):
+        p = None if priorities is None else np.ascontiguousarray(priorities, dtype=np.float64).reshape(-1)
+        if p is not None:
+            assert p.size == n
+        L.check(self.lib.jh_per_push(self.h, int(n), L.ptr(p), L.stream_ptr()))
+
+    def update(self, idx, prio):
+        assert idx.dtype == torch.int64 and idx.is_cuda and prio.is_cuda
+        dt = L.JH_F32 if prio.dtype == torch.float32 else L.JH_F64
+        assert prio.dtype in (torch.float32, torch.float64)
+        L.check(self.lib.jh_per_update(self.h, int(idx.numel()), L.ptr(idx.contiguous()), L.ptr(prio.contiguous()), dt, L.stream_ptr()))
+
+    def sample(self, beta, uniform_slot, u, want_w64=True):
+        """uniform_slot int64[n_uni] (numpy), u float64[B-n_uni] (numpy).  Returns (idx i64[B], w64|None, w32, stats f64[4]) on device."""
+        uniform_slot = np.ascontiguousarray(uniform_slot, dtype=np.int64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        B = uniform_slot.size + u.size
+        idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        w64 = torch.empty(B, dtype=torch.float64, device=self.device) if want_w64 else None
+        w32 = torch.empty(B, dtype=torch.float32, device=self.device)
+        L.check(self.lib.jh_per_sample(self.h, B, float(beta), int(uniform_slot.size), L.ptr(uniform_slot), L.ptr(u), L.ptr(idx), L.ptr(w64), L.ptr(w32), L.ptr(self._stats), L.stream_ptr()))
+        return idx, w64, w32, self._stats
+
+    def state(self):
+        mp, root, ti, cnt = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
+        L.check(self.lib.jh_per_state(self.h, C.byref(mp), C.byref(root), C.byref(ti), C.byref(cnt), L.stream_ptr()))
+        return dict(max_priority=mp.value, root=root.value, tree_index=ti.value, counter=cnt.value)
+
+    def dump(self):
+        out = np.empty(self.tree_size, dtype=np.float64)
+        L.check(self.lib.jh_per_dump(self.h, L.ptr(out), L.stream_ptr()))
+        return out
+
+    def load(self, tree, max_priority, tree_index, counter):
+        t = np.ascontiguousarray(tree, dtype=np.float64)
+        assert t.size == self.tree_size
+        L.check(self.lib.jh_per_load(self.h, L.ptr(t), float(max_priority), int(tree_index), int(counter)))
+
+
+# ============================================================================= PPO math
+def gae(reward, done, value, next_value, n_step, gamma, lam, standardize=True):
+    """ppo.py:95-110.  Inputs float32 CUDA [M,1] (or [M]), M = W*n_step, worker-major.
+    Returns (adv [M,1], ret [M,1])."""
+    lib = L.load()
+    r, d, v, vn = (_f32(x).reshape(-1) for x in (reward, done, value, next_value))
+    M = r.numel()
+    assert M % n_step == 0
+    adv = torch.empty(M, dtype=torch.float32, device=r.device)
+    ret = torch.empty(M, dtype=torch.float32, device=r.device)
+    L.check(lib.jh_gae(L.ctx(_dev(r)), M // n_step, int(n_step), float(gamma), float(lam), L.ptr(r), L.ptr(d), L.ptr(v), L.ptr(vn), L.ptr(adv), L.ptr(ret), int(bool(standardize)), L.stream_ptr()))
+    return adv.view(-1, 1), ret.view(-1, 1)
+
+
+def logp_discrete(logits, action):
+    lib = L.load()
+    z = _f32(logits)
+    M, A = z.shape
+    a = _f32(action).reshape(-1)
+    out = torch.empty(M, dtype=torch.float32, device=z.device)
+    L.check(lib.jh_logp_discrete(L.ctx(_dev(z)), M, A, L.ptr(z), L.ptr(a), L.ptr(out), L.stream_ptr()))
+    return out.view(-1, 1)
+
+
+def logp_continuous(mu_raw, log_std_raw, action):
+    lib = L.load()
+    mu, ls, a = _f32(mu_raw), _f32(log_std_raw), _f32(action)
+    M, A = mu.shape
+    out = torch.empty(M, A, dtype=torch.float32, device=mu.device)
+    L.check(lib.jh_logp_continuous(L.ctx(_dev(mu)), M, A, L.ptr(mu), L.ptr(ls), L.ptr(a), L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def ppo_loss_discrete(logits, value_pred, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, stats=None):
+    """Returns (grad_logits [B,A], grad_value [B,1], stats f32[8])."""
+    lib = L.load()
+    z, v = _f32(logits), _f32(value_pred).reshape(-1)
+    B, A = z.shape
+    g_z = torch.empty_like(z)
+    g_v = torch.empty(B, dtype=torch.float32, device=z.device)
+    if stats is None:
+        stats = torch.empty(8, dtype=torch.float32, device=z.device)
+    L.check(lib.jh_ppo_loss_discrete(L.ctx(_dev(z)), B, A, L.ptr(z), L.ptr(v), L.ptr(idx), L.ptr(_f32(action).reshape(-1)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)), L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old).reshape(-1)), float(eps_clip), float(vf_coef), float(ent_coef), L.ptr(g_z), L.ptr(g_v), L.ptr(stats), L.stream_ptr()))
+    return g_z, g_v.view(-1, 1), stats
+
+
+def ppo_loss_continuous(mu_raw, log_std_raw, value_pred, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, stats=None):
+    lib = L.load()
+    mu, ls, v = _f32(mu_raw), _f32(log_std_raw), _f32(value_pred).reshape(-1)
+    B, A = mu.shape
+    g_mu, g_ls = torch.empty_like(mu), torch.empty_like(ls)
+    g_v = torch.empty(B, dtype=torch.float32, device=mu.device)
+    if stats is None:
+        stats = torch.empty(8, dtype=torch.float32, device=mu.device)
+    L.check(lib.jh_ppo_loss_continuous(L.ctx(_dev(mu)), B, A, L.ptr(mu), L.ptr(ls), L.ptr(v), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)), L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef), L.ptr(g_mu), L.ptr(g_ls), L.ptr(g_v), L.ptr(stats), L.stream_ptr()))
+    return g_mu, g_ls, g_v.view(-1, 1), stats
+
+
+# ============================================================================= TD / C51
+def td_loss(q, q_next_target, action, reward, done, gamma, q_next_online=None, weights=None, alpha=0.0, n_step=0, stats=None):
+    """Returns (grad_q [B,A], prio [B], stats f32[4] = {loss, max_Q, mean_td, 0})."""
+    lib = L.load()
+    q = _f32(q)
+    B, A = q.shape
+    flags = (L.JH_TD_DOUBLE if q_next_online is not None else 0) | (L.JH_TD_PER if weights is not None else 0)
+    g = torch.empty_like(q)
+    prio = torch.empty(B, dtype=torch.float32, device=q.device)
+    if stats is None:
+        stats = torch.empty(4, dtype=torch.float32, device=q.device)
+    r, d = _f32(reward).reshape(B, -1), _f32(done).reshape(B, -1)
+    assert r.shape[1] == max(n_step, 1) and d.shape == r.shape
+    L.check(lib.jh_td_loss(L.ctx(_dev(q)), B, A, int(n_step), flags, L.ptr(q), L.ptr(None if q_next_online is None else _f32(q_next_online)), L.ptr(_f32(q_next_target)), L.ptr(_f32(action).reshape(-1)), L.ptr(r), L.ptr(d), L.ptr(None if weights is None else _f32(weights).reshape(-1)), float(gamma), float(alpha), L.ptr(g), L.ptr(prio), L.ptr(stats), L.stream_ptr()))
+    return g, prio, stats
+
+
+def c51_loss(logit, target_logit, action, reward, done, v_min, v_max, gamma, next_logit_online=None, weights=None, alpha=0.0, n_step=0, shift_max=False, stats=None):
+    """logit/target_logit/next_logit_online [B,A,K].  Returns (grad_logit, prio [B], kl [B], stats f32[8])."""
+    lib = L.load()
+    z = _f32(logit)
+    B, A, K = z.shape
+    flags = (L.JH_C51_DOUBLE if next_logit_online is not None else 0) | (L.JH_C51_PER if weights is not None else 0) | (L.JH_C51_SHIFT_MAX if shift_max else 0)
+    g = torch.empty_like(z)
+    prio = torch.empty(B, dtype=torch.float32, device=z.device)
+    kl = torch.empty(B, dtype=torch.float32, device=z.device)
+    if stats is None:
+        stats = torch.empty(8, dtype=torch.float32, device=z.device)
+    r, d = _f32(reward).reshape(B, -1), _f32(done).reshape(B, -1)
+    assert r.shape[1] == max(n_step, 1) and d.shape == r.shape
+    L.check(lib.jh_c51_loss(L.ctx(_dev(z)), B, A, K, int(n_step), flags, L.ptr(z), L.ptr(None if next_logit_online is None else _f32(next_logit_online)), L.ptr(_f32(target_logit)), L.ptr(_f32(action).reshape(-1)), L.ptr(r), L.ptr(d), L.ptr(None if weights is None else _f32(weights).reshape(-1)), float(v_min), float(v_max), float(gamma), float(alpha), L.ptr(g), L.ptr(prio), L.ptr(kl), L.ptr(stats), L.stream_ptr()))
+    return g, prio, kl, stats
+
+
+# ============================================================================= host collector
+class CartPoleVec:
+    """W synthetic CartPole-v1 envs stepped in one native call (jh_cartpole_*)."""
+
+    def __init__(self, W, seed=0):
+        self.lib = L.load()
+        self.W = int(W)
+        self.h = C.c_void_p()
+        L.check(self.lib.jh_cartpole_create(self.W, C.c_uint64(int(seed)), C.byref(self.h)))
+        self.state_size, self.action_size, self.action_type = 4, 2, "discrete"
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jh_cartpole_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def obs(self, out=None):
+        out = np.empty((self.W, 4), np.float32) if out is None else out
+        L.check(self.lib.jh_cartpole_obs(self.h, L.ptr(out)))
+        return out
+
+    def step(self, action, next_obs=None, reward=None, done=None):
+        a = np.ascontiguousarray(action, dtype=np.int64).reshape(-1)
+        assert a.size == self.W
+        next_obs = np.empty((self.W, 4), np.float32) if next_obs is None else next_obs
+        reward = np.empty(self.W, np.float32) if reward is None else reward
+        done = np.empty(self.W, np.uint8) if done is None else done
+        L.check(self.lib.jh_cartpole_step(self.h, L.ptr(a), L.ptr(next_obs), L.ptr(reward), L.ptr(done)))
+        return next_obs, reward, done

@@ -1,0 +1,494 @@
+"""GPU parity tests: HIP kernels (through the C ABI) vs the golden fixtures generated from the
+reference and vs the CPU oracle on seeded inputs.  Integer indexing / the float64 sum tree are
+compared bit-exactly; fp32 losses/advantages within 1e-5 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from tests.util import cu, f32, load, npy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+
+    assert torch.cuda.is_available()
+    from jorldy_amd import ops as _ops
+
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import jorldy_oracle
+
+    return jorldy_oracle
+
+
+# ============================================================================= store
+def _std_columns(L, S):
+    return [("state", L.JH_F32, S, (S,)), ("action", L.JH_I64, 1, (1,)), ("reward", L.JH_F32, 1, (1,)),
+            ("next_state", L.JH_F32, S, (S,)), ("done", L.JH_U8, 1, (1,))]
+
+
+def test_store_ring_wrap_and_gather_matches_reference_sample(ops):
+    from jorldy_amd import _lib as L
+
+    z = load("replay_buffer")
+    st = ops.DeviceStore(16, _std_columns(L, 4))
+    keys = ["state", "action", "reward", "next_state", "done"]
+    n0, n1 = [int(x) for x in z["n_store"]]
+    st.push({k: z[f"in_{k}"][:n0] for k in keys})
+    st.push({k: z[f"in_{k}"][n0:n0 + n1] for k in keys})
+    assert st.index == int(z["buffer_index"]) and st.size == int(z["buffer_counter"])
+    np.random.seed(7)
+    idx = np.random.randint(st.size, size=8)  # replay_buffer.py:26
+    out = st.gather(cu(idx))
+    for k in keys:
+        np.testing.assert_array_equal(npy(out[k]), z[f"sample_{k}"].astype(np.float32))
+    raw = st.gather(cu(idx), as_float=False)
+    np.testing.assert_array_equal(npy(raw["action"]), z["sample_action"])
+    assert raw["done"].dtype.__str__() == "torch.uint8"
+
+
+def test_store_gather_uint8_frames_vectorised_and_scalar(ops):
+    from jorldy_amd import _lib as L
+
+    rng = np.random.RandomState(0)
+    for shape in ((4, 84, 84), (3, 5, 7)):  # 28224 B rows (16 B vector path) and 105 B rows (scalar path)
+        elems = int(np.prod(shape))
+        st = ops.DeviceStore(50, [("state", L.JH_U8, elems, shape), ("reward", L.JH_F32, 3, (3, 1))])
+        frames = rng.randint(0, 256, size=(70,) + shape).astype(np.uint8)
+        rew = rng.randn(70, 3, 1).astype(np.float32)
+        st.push({"state": frames[:33], "reward": rew[:33]})
+        st.push({"state": frames[33:], "reward": rew[33:]})  # wraps: slots hold rows 20..69
+        slot_to_row = {(i % 50): i for i in range(70)}
+        idx = rng.randint(0, 50, size=37)
+        want = np.stack([frames[slot_to_row[int(i)]] for i in idx])
+        got_u8 = st.gather(cu(idx), names=["state"], as_float=False)["state"]
+        got_f = st.gather(cu(idx))
+        np.testing.assert_array_equal(npy(got_u8), want)
+        np.testing.assert_array_equal(npy(got_f["state"]), want.astype(np.float32))
+        np.testing.assert_array_equal(npy(got_f["reward"]), np.stack([rew[slot_to_row[int(i)]] for i in idx]))
+
+
+def test_store_column_view_is_rollout_sample(ops):
+    from jorldy_amd import _lib as L
+
+    z = load("rollout_buffer")
+    st = ops.DeviceStore(32, _std_columns(L, 4))
+    keys = ["state", "action", "reward", "next_state", "done"]
+    st.push({k: z[f"in_{k}"][:5] for k in keys})
+    st.push({k: z[f"in_{k}"][5:12] for k in keys})
+    n = st.size
+    assert n == 12
+    for k in keys:
+        np.testing.assert_array_equal(npy(st.column(k)[:n]).astype(np.float32), z[f"sample_{k}"].astype(np.float32))
+    st.clear()
+    assert st.size == 0 and st.index == 0
+
+
+def test_store_staged_zero_copy_push(ops):
+    from jorldy_amd import _lib as L
+
+    st = ops.DeviceStore(8, [("x", L.JH_F32, 3, (3,)), ("y", L.JH_I64, 1, (1,))])
+    for rep in range(5):  # cycles through all pinned slabs and the ring wrap
+        v = st.stage(3)
+        v["x"][:] = np.arange(9, dtype=np.float32).reshape(3, 3) + 100 * rep
+        v["y"][:] = np.arange(3).reshape(3, 1) + 10 * rep
+        st.commit()
+    import torch
+
+    torch.cuda.synchronize()
+    x = npy(st.column("x"))
+    # 15 rows written into 8 slots: slot s holds row r = last r with r % 8 == s
+    for s in range(8):
+        r = max(r for r in range(15) if r % 8 == s)
+        rep, j = divmod(r, 3)
+        np.testing.assert_array_equal(x[s], np.arange(9, dtype=np.float32).reshape(3, 3)[j] + 100 * rep)
+
+
+# ============================================================================= PER
+@pytest.mark.parametrize("name", ["per_n64", "per_n1000", "per_n1000_prio"])
+def test_per_scenario_tree_bit_exact(ops, name):
+    z = load(name)
+    N, B = int(z["N"]), int(z["B"])
+    tree = ops.SumTree(N, float(z["usp"]))
+    counter = 0
+    for op in range(int(z["n_ops"])):
+        n = int(z[f"op{op}_n_store"])
+        tree.push(n, z[f"op{op}_store_prio"] if bool(z["with_prio"]) else None)
+        counter = min(counter + n, N)
+        np.testing.assert_array_equal(tree.dump(), z[f"op{op}_tree_after_store"])
+        s = tree.state()
+        assert s["max_priority"] == float(np.asarray(z[f"op{op}_maxp_after_store"]).reshape(-1)[0])
+        assert s["tree_index"] == int(z[f"op{op}_tree_index"]) and s["counter"] == counter
+        # the reference's three global-RNG draws, in order (per_buffer.py:72-81)
+        np.random.seed(int(z[f"op{op}_seed"]))
+        mask = np.random.uniform(size=B) < float(z["usp"])
+        n_uni = int(mask.sum())
+        uni = np.random.randint(counter, size=n_uni)
+        u = np.random.uniform(size=B - n_uni)
+        idx, w64, w32, stats = tree.sample(float(z[f"op{op}_beta"]), uni, u)
+        np.testing.assert_array_equal(npy(idx), z[f"op{op}_indices"])  # bit-exact integer indexing
+        np.testing.assert_allclose(npy(w64), z[f"op{op}_weights"], rtol=1e-13, atol=0)
+        np.testing.assert_array_equal(npy(w32), z[f"op{op}_weights"].astype(np.float32))
+        st = npy(stats)
+        np.testing.assert_allclose(st[0], float(z[f"op{op}_sampled_p"]), rtol=1e-13)
+        assert st[1] == float(z[f"op{op}_mean_p"])
+        tree.update(cu(z[f"op{op}_upd_idx"]), cu(z[f"op{op}_upd_p"]))
+        np.testing.assert_array_equal(tree.dump(), z[f"op{op}_tree_after_update"])
+        assert tree.state()["max_priority"] == float(np.asarray(z[f"op{op}_maxp_after_update"]).reshape(-1)[0])
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 1000, 4096, 100003])
+def test_per_random_ops_vs_oracle_bit_exact(ops, O, N):
+    """Odd / power-of-two / large capacities, pushes longer than a chunk and longer than the ring,
+    heavy duplicate write-backs: tree, indices and max_priority identical to the oracle's."""
+    rng = np.random.RandomState(N)
+    tree = ops.SumTree(N, 0.01)
+    orc = O.PEROracle(N, 0.01)
+    for it in range(6):
+        n = int(rng.randint(1, min(3 * N, 7000) + 1))
+        with_p = it % 2 == 1
+        pr = rng.rand(n) * 2 if with_p else None
+        tree.push(n, pr)
+        orc.store([({"priority": np.asarray([[p]])} if with_p else {}) for p in (pr if with_p else range(n))])
+        np.testing.assert_array_equal(tree.dump(), orc.sum_tree)
+        B = int(rng.randint(1, 700))
+        seed = int(rng.randint(1 << 30))
+        np.random.seed(seed)
+        n_uni, uni, u = orc.draw(B)
+        np.random.seed(seed)
+        w_o, idx_o, sp_o, mp_o = orc.sample_indices(0.5, B)
+        idx, w64, w32, stats = tree.sample(0.5, uni, u)
+        np.testing.assert_array_equal(npy(idx), idx_o)
+        np.testing.assert_allclose(npy(w64), w_o, rtol=1e-13)
+        # write back with many duplicates
+        k = max(1, B // 3)
+        upd_idx = idx_o[rng.randint(0, B, size=B)] if N > 1 else idx_o
+        upd_idx[:k] = upd_idx[0]
+        newp = (rng.rand(B) ** 2).astype(np.float32)
+        tree.update(cu(upd_idx), cu(newp))
+        for i, p in zip(upd_idx, newp):
+            orc.update_priority(float(p), int(i))
+        np.testing.assert_array_equal(tree.dump(), orc.sum_tree)
+        s = tree.state()
+        assert s["max_priority"] == orc.max_priority and s["tree_index"] == orc.tree_index and s["counter"] == orc.buffer_counter
+
+
+def test_per_load_dump_roundtrip(ops):
+    rng = np.random.RandomState(1)
+    t = ops.SumTree(100, 1e-3)
+    arr = rng.rand(199)
+    t.load(arr, 3.5, 120, 77)
+    np.testing.assert_array_equal(t.dump(), arr)
+    s = t.state()
+    assert s == dict(max_priority=3.5, root=arr[0], tree_index=120, counter=77)
+
+
+# ============================================================================= GAE
+PPO_CASES = ["ppo_disc_small", "ppo_disc_cartpole", "ppo_cont_small", "ppo_cont_hopper"]
+
+
+@pytest.mark.parametrize("name", PPO_CASES)
+def test_gae_vs_reference_fixture(ops, name):
+    z = load(name)
+    T = int(z["cfg"][4])
+    gamma, lam = z["hyper"][:2]
+    adv, ret = ops.gae(f32(z["gae/reward"]), f32(z["gae/done"].reshape(-1, 1)), f32(z["gae/value"]), f32(z["gae/next_value"]), T, gamma, lam, True)
+    np.testing.assert_allclose(npy(ret), z["gae/ret"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(npy(adv), z["gae/adv"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("W,T", [(1, 1), (3, 2), (5, 63), (4, 64), (7, 65), (8, 128), (32, 2048), (1000, 130)])
+def test_gae_shapes_vs_oracle(ops, O, W, T):
+    rng = np.random.RandomState(W * 1000 + T)
+    M = W * T
+    r = rng.randn(M, 1).astype(np.float32)
+    d = (rng.rand(M, 1) < 0.03).astype(np.float32)
+    v = rng.randn(M, 1).astype(np.float32)
+    vn = rng.randn(M, 1).astype(np.float32)
+    adv_o, ret_o = O.gae(r, d, v, vn, 0.99, 0.95, T)
+    adv, ret = ops.gae(f32(r), f32(d), f32(v), f32(vn), T, 0.99, 0.95, False)
+    scale = max(1.0, np.abs(adv_o).max())
+    np.testing.assert_allclose(npy(adv).reshape(W, T), adv_o, rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(npy(ret), ret_o, rtol=0, atol=1e-5 * scale)
+    if T > 1:
+        adv_s, _ = ops.gae(f32(r), f32(d), f32(v), f32(vn), T, 0.99, 0.95, True)
+        np.testing.assert_allclose(npy(adv_s).reshape(W, T), O.standardize_rows(adv_o), rtol=0, atol=2e-5)
+
+
+def test_gae_linearity_full_size(ops):
+    """Size-independent property at a scaled shape (W=8192 rows x T=128): the scan is linear in
+    (reward, value, next_value) for fixed dones."""
+    import torch
+
+    W, T = 8192, 128
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M = W * T
+    mk = lambda: torch.randn(M, 1, device="cuda", generator=g)
+    d = (torch.rand(M, 1, device="cuda", generator=g) < 0.02).float()
+    r1, v1, n1, r2, v2, n2 = mk(), mk(), mk(), mk(), mk(), mk()
+    a1, _ = ops.gae(r1, d, v1, n1, T, 0.99, 0.95, False)
+    a2, _ = ops.gae(r2, d, v2, n2, T, 0.99, 0.95, False)
+    a3, _ = ops.gae(r1 + 2 * r2, d, v1 + 2 * v2, n1 + 2 * n2, T, 0.99, 0.95, False)
+    torch.testing.assert_close(a3, a1 + 2 * a2, rtol=0, atol=2e-4)
+
+
+# ============================================================================= PPO loss
+@pytest.mark.parametrize("name", PPO_CASES)
+def test_ppo_loss_vs_reference_fixture(ops, name):
+    z = load(name)
+    S, A, H, W, T, B, E, cont = z["cfg"]
+    gamma, lam, eps, vf, ent, clip, lr = z["hyper"]
+    adv, ret, vold, lpo = f32(z["gae/adv"]), f32(z["gae/ret"]), f32(z["gae/value"]), f32(z["gae/log_prob_old"])
+    act = f32(z["in_action"])
+    # log pi_old through the HIP path too
+    for i in range(int(z["n_minibatch"])):
+        idx = cu(z[f"mb{i}/idx"])
+        vp = f32(z[f"mb{i}/head/v"])
+        if cont:
+            g_mu, g_ls, g_v, st = ops.ppo_loss_continuous(f32(z[f"mb{i}/head/mu_raw"]), f32(z[f"mb{i}/head/log_std_raw"]), vp, idx, act, adv, ret, vold, lpo, eps, vf, ent)
+            for got, key in ((g_mu, "mu_raw"), (g_ls, "log_std_raw")):
+                gold = z[f"mb{i}/head/d_{key}"]
+                # clamped actions (|a| = 1-1e-7) have O(-100) log-probs: tolerance relative to the largest gradient
+                np.testing.assert_allclose(npy(got), gold, rtol=1e-3, atol=2e-4 * np.abs(gold).max())
+        else:
+            g_z, g_v, st = ops.ppo_loss_discrete(f32(z[f"mb{i}/head/logits"]), vp, idx, act, adv, ret, vold, lpo, eps, vf, ent)
+            np.testing.assert_allclose(npy(g_z), z[f"mb{i}/head/d_logits"], rtol=1e-4, atol=1e-7)
+        st = npy(st)
+        for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")):
+            np.testing.assert_allclose(st[j], z[f"mb{i}/{k}"], rtol=1e-5, atol=1e-5, err_msg=f"{name} mb{i} {k}")
+        np.testing.assert_allclose(npy(g_v), z[f"mb{i}/head/d_v"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(st[4], z[f"mb{i}/ratio"].max(), rtol=1e-4 if cont else 1e-5)
+
+
+@pytest.mark.parametrize("name", PPO_CASES)
+def test_logp_old_vs_reference_fixture(ops, O, name):
+    z = load(name)
+    cont = int(z["cfg"][7])
+    # head outputs of the no-grad pass are not in the fixture; minibatch 0 of epoch 0 uses the same
+    # weights, so its logp equals logp_old on those rows
+    idx = z["mb0/idx"]
+    if cont:
+        lp = ops.logp_continuous(f32(z["mb0/head/mu_raw"]), f32(z["mb0/head/log_std_raw"]), f32(z["in_action"][idx]))
+        np.testing.assert_allclose(npy(lp), z["gae/log_prob_old"][idx], rtol=1e-4, atol=1e-4)
+    else:
+        lp = ops.logp_discrete(f32(z["mb0/head/logits"]), f32(z["in_action"][idx]))
+        np.testing.assert_allclose(npy(lp), z["gae/log_prob_old"][idx], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("cont", [False, True])
+@pytest.mark.parametrize("B", [1, 64, 200, 1024, 1025, 5000])
+def test_ppo_loss_sizes_vs_oracle(ops, O, cont, B):
+    """Fused single-workgroup path (B<=1024) and the two-pass path (B>1024) against the oracle,
+    with and without the minibatch index indirection."""
+    rng = np.random.RandomState(B + 7 * cont)
+    A, M = (3, B + 50)
+    idx = rng.permutation(M)[:B]
+    adv = rng.randn(M, 1).astype(np.float32)
+    ret = rng.randn(M, 1).astype(np.float32)
+    vold = rng.randn(M, 1).astype(np.float32)
+    vp = (vold[idx] + 0.2 * rng.randn(B, 1)).astype(np.float32)
+    if cont:
+        act = np.tanh(rng.randn(M, A)).astype(np.float32)
+        mu, ls = rng.randn(B, A).astype(np.float32), rng.randn(B, A).astype(np.float32)
+        mu0, std0 = O.normal_head(mu + 0.05 * rng.randn(B, A).astype(np.float32), ls)
+        lpo_rows, _ = O.normal_logp_of_action(mu0, std0, act[idx])
+        lpo = np.zeros((M, A), np.float32)
+        lpo[idx] = lpo_rows
+        ro = O.ppo_loss_continuous(mu, ls, vp, act[idx], adv[idx], ret[idx], vold[idx], lpo[idx], 0.2, 0.5, 0.01)
+        g_mu, g_ls, g_v, st = ops.ppo_loss_continuous(f32(mu), f32(ls), f32(vp), cu(idx), f32(act), f32(adv), f32(ret), f32(vold), f32(lpo), 0.2, 0.5, 0.01)
+        # the surrogate gradient is discontinuous where ratio crosses 1 +- eps: rows whose ratio sits within
+        # rounding distance of the clip edge may legitimately fall on either side -> excluded
+        ok = (np.abs(ro["ratio"] - 1.2) > 1e-3) & (np.abs(ro["ratio"] - 0.8) > 1e-3)
+        ok = ok.reshape(-1)
+        assert ok.mean() > 0.99
+        np.testing.assert_allclose(npy(g_mu)[ok], ro["d_mu_raw"][ok], rtol=1e-3, atol=1e-4 * np.abs(ro["d_mu_raw"]).max())
+        np.testing.assert_allclose(npy(g_ls)[ok], ro["d_log_std_raw"][ok], rtol=1e-3, atol=1e-4 * np.abs(ro["d_log_std_raw"]).max())
+    else:
+        act = rng.randint(0, A, size=(M, 1)).astype(np.float32)
+        logits = (2 * rng.randn(B, A)).astype(np.float32)
+        lpo = np.zeros((M, 1), np.float32)
+        lsm = O._log_softmax(logits + 0.1 * rng.randn(B, A).astype(np.float32))
+        lpo[idx, 0] = lsm[np.arange(B), act[idx].astype(int).reshape(-1)]
+        ro = O.ppo_loss_discrete(logits, vp, act[idx], adv[idx], ret[idx], vold[idx], lpo[idx], 0.2, 0.5, 0.01)
+        g_z, g_v, st = ops.ppo_loss_discrete(f32(logits), f32(vp), cu(idx), f32(act), f32(adv), f32(ret), f32(vold), f32(lpo), 0.2, 0.5, 0.01)
+        ok = ((np.abs(ro["ratio"] - 1.2) > 1e-3) & (np.abs(ro["ratio"] - 0.8) > 1e-3)).reshape(-1)
+        np.testing.assert_allclose(npy(g_z)[ok], ro["d_logits"][ok], rtol=1e-4, atol=1e-7)
+    st = npy(st)
+    for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob")):
+        np.testing.assert_allclose(st[j], ro[k], rtol=2e-5, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(npy(g_v), ro["d_value"], rtol=1e-4, atol=1e-8)
+
+
+# ============================================================================= TD losses
+def _h(z, k):
+    return z[f"hyper/{k}"].item()
+
+
+def _qall(z):
+    B, A = int(_h(z, "B")), int(_h(z, "A"))
+    a = z["learn/action"].astype(np.int64).reshape(B)
+    q_all = np.zeros((B, A), np.float32)
+    q_all[np.arange(B), a] = z["learn/q"].reshape(B)
+    return q_all, a
+
+
+def _sampled_rows(z):
+    np.random.seed(int(_h(z, "np_seed")))
+    return np.random.randint(z["buf_state"].shape[0], size=int(_h(z, "B")))
+
+
+def _check_td(z, g, st, a, per=False, prio=None):
+    B = len(a)
+    np.testing.assert_allclose(npy(st)[0], z["learn/loss"], rtol=1e-5)
+    np.testing.assert_allclose(npy(st)[1], z["result/max_Q"], rtol=1e-6)
+    np.testing.assert_allclose(npy(g)[np.arange(B), a].reshape(B, 1), z["learn/d_q"], rtol=1e-5, atol=1e-8)
+    mask = np.ones_like(npy(g), bool)
+    mask[np.arange(B), a] = False
+    assert np.all(npy(g)[mask] == 0)
+    if per:
+        np.testing.assert_allclose(npy(prio).reshape(B, 1), z["learn/p_j"], rtol=1e-5, atol=1e-7)
+
+
+def test_td_dqn_fixture(ops):
+    z = load("dqn")
+    q, a = _qall(z)
+    rows = _sampled_rows(z)
+    g, prio, st = ops.td_loss(f32(q), f32(z["learn/next_q"]), f32(a), f32(z["buf_reward"][rows]), f32(z["buf_done"][rows]), _h(z, "gamma"))
+    _check_td(z, g, st, a)
+    np.testing.assert_allclose(npy(prio).reshape(-1, 1), np.abs(z["learn/target_q"] - z["learn/q"]), atol=1e-6)
+
+
+def test_td_double_fixture(ops):
+    z = load("double")
+    q, a = _qall(z)
+    rows = _sampled_rows(z)
+    g, prio, st = ops.td_loss(f32(q), f32(z["learn/next_target_q"]), f32(a), f32(z["buf_reward"][rows]), f32(z["buf_done"][rows]), _h(z, "gamma"), q_next_online=f32(z["learn/next_q"]))
+    _check_td(z, g, st, a)
+
+
+def test_td_multistep_fixture(ops):
+    z = load("multistep")
+    q, a = _qall(z)
+    g, prio, st = ops.td_loss(f32(q), f32(z["learn/next_q"]), f32(a), f32(z["learn/reward"]), f32(z["learn/done"]), _h(z, "gamma"), n_step=int(_h(z, "n_step")))
+    _check_td(z, g, st, a)
+
+
+@pytest.mark.parametrize("name", ["per", "ape_x"])
+def test_td_per_fixture_with_tree_writeback(ops, name):
+    """The whole PER learn step on device: sample (bit-exact indices) -> loss -> priorities -> tree."""
+    z = load(name)
+    q, a = _qall(z)
+    B = len(a)
+    N = (z["tree0"].shape[0] + 1) // 2
+    n = z["buf_state"].shape[0]
+    tree = ops.SumTree(N, _h(z, "uniform_sample_prob"))
+    tree.load(z["tree0"], float(np.asarray(z["maxp0"]).reshape(-1)[0]), int(z["tree_index0"]), n)
+    np.random.seed(int(_h(z, "np_seed")))
+    mask = np.random.uniform(size=B) < _h(z, "uniform_sample_prob")
+    n_uni = int(mask.sum())
+    uni = np.random.randint(n, size=n_uni)
+    u = np.random.uniform(size=B - n_uni)
+    idx, w64, w32, stats = tree.sample(_h(z, "beta"), uni, u)
+    np.testing.assert_array_equal(npy(idx), z["learn/indices"])
+    np.testing.assert_array_equal(npy(w32).reshape(B, 1), z["learn/weights"])
+    leaf = z["learn/indices"] - (N - 1)
+    if name == "per":
+        r, d, ns = z["buf_reward"][leaf], z["buf_done"][leaf], 0
+    else:
+        r, d, ns = z["learn/reward"], z["learn/done"], int(_h(z, "n_step"))
+    g, prio, st = ops.td_loss(f32(q), f32(z["learn/next_target_q"]), f32(a), f32(r), f32(d), _h(z, "gamma"), q_next_online=f32(z["learn/next_q"]), weights=w32, alpha=_h(z, "alpha"), n_step=ns)
+    _check_td(z, g, st, a, per=True, prio=prio)
+    st64 = npy(stats)
+    np.testing.assert_allclose(st64[0], z["result/sampled_p"], rtol=1e-13)
+    assert st64[1] == z["result/mean_p"].item()
+    # tree after writing back the REFERENCE's fp32 priorities must be bit-identical
+    tree.update(idx, f32(z["learn/p_j"].reshape(B)))
+    np.testing.assert_array_equal(tree.dump(), z["tree1"])
+    assert tree.state()["max_priority"] == float(np.asarray(z["maxp1"]).reshape(-1)[0])
+
+
+@pytest.mark.parametrize("B", [1, 255, 256, 257, 3000])
+def test_td_sizes_vs_oracle(ops, O, B):
+    rng = np.random.RandomState(B)
+    A, n = 6, 3
+    q = rng.randn(B, A).astype(np.float32) * 2
+    qno, qnt = rng.randn(B, A).astype(np.float32), rng.randn(B, A).astype(np.float32)
+    a = rng.randint(0, A, size=B)
+    r = rng.randn(B, n, 1).astype(np.float32)
+    d = (rng.rand(B, n, 1) < 0.2).astype(np.float32)
+    w = rng.rand(B).astype(np.float32)
+    ro = O.dqn_loss(q, a, r, d, qnt, 0.99, next_q_online=qno, weights=w, alpha=0.6, n_step=n)
+    g, prio, st = ops.td_loss(f32(q), f32(qnt), f32(a), f32(r), f32(d), 0.99, q_next_online=f32(qno), weights=f32(w), alpha=0.6, n_step=n)
+    np.testing.assert_allclose(npy(g), ro["d_q_all"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(npy(prio).reshape(B, 1), ro["p_j"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(npy(st)[0], ro["loss"], rtol=1e-5)
+    ro = O.dqn_loss(q, a, r[:, 0], d[:, 0], qnt, 0.99)
+    g, prio, st = ops.td_loss(f32(q), f32(qnt), f32(a), f32(r[:, 0]), f32(d[:, 0]), 0.99)
+    np.testing.assert_allclose(npy(g), ro["d_q_all"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(npy(st)[0], ro["loss"], rtol=1e-5)
+
+
+# ============================================================================= C51 / Rainbow
+def _target_logit_from_p(p):
+    return np.log(np.maximum(p, 1e-30)).astype(np.float32)
+
+
+def _logit_with_q_order(q, K):
+    B, A = q.shape
+    out = np.full((B, A, K), -30.0, np.float32)
+    order = np.argsort(np.argsort(q, axis=1), axis=1)
+    for b in range(B):
+        for a in range(A):
+            out[b, a, order[b, a]] = 30.0
+    return out
+
+
+def test_c51_fixture(ops):
+    z = load("c51")
+    B, A, K = int(_h(z, "B")), int(_h(z, "A")), int(_h(z, "num_support"))
+    rows = _sampled_rows(z)
+    g, prio, kl, st = ops.c51_loss(f32(z["learn/logit"].reshape(B, A, K)), f32(_target_logit_from_p(z["learn/target_p_logit"])), f32(z["learn/action"]), f32(z["buf_reward"][rows]), f32(z["buf_done"][rows]), _h(z, "v_min"), _h(z, "v_max"), _h(z, "gamma"), shift_max=True)
+    st = npy(st)
+    np.testing.assert_allclose(st[0], z["learn/loss"], rtol=1e-5)
+    np.testing.assert_allclose(st[1], z["result/max_Q"], rtol=1e-5)
+    np.testing.assert_allclose(st[2], z["result/max_logit"], rtol=1e-6)
+    np.testing.assert_allclose(st[3], z["result/min_logit"], rtol=1e-6)
+    np.testing.assert_allclose(npy(g).reshape(B, -1), z["learn/d_logit"], rtol=1e-4, atol=1e-8)
+
+
+def test_rainbow_fixture(ops):
+    z = load("rainbow")
+    B, A, K = int(_h(z, "B")), int(_h(z, "A")), int(_h(z, "num_support"))
+    g, prio, kl, st = ops.c51_loss(f32(z["learn/logit"]), f32(_target_logit_from_p(z["learn/target_p_logit"])), f32(z["learn/action"]), f32(z["learn/reward"]), f32(z["learn/done"]), _h(z, "v_min"), _h(z, "v_max"), _h(z, "gamma"),
+                                   next_logit_online=f32(_logit_with_q_order(z["learn/next_q_action"], K)), weights=f32(z["learn/weights"]), alpha=_h(z, "alpha"), n_step=int(_h(z, "n_step")))
+    np.testing.assert_allclose(npy(kl), z["learn/KL"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(npy(prio), z["learn/p_j"], rtol=1e-5, atol=1e-6)
+    st = npy(st)
+    np.testing.assert_allclose(st[0], z["learn/loss"], rtol=1e-5)
+    np.testing.assert_allclose(st[1], z["result/max_Q"], rtol=1e-5)
+    np.testing.assert_allclose(npy(g), z["learn/d_logit"], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("B,A,K,n", [(1, 2, 11, 1), (7, 4, 51, 3), (33, 6, 51, 3), (64, 3, 200, 2)])
+def test_c51_sizes_vs_oracle(ops, O, B, A, K, n):
+    """Includes K > 64 (several atoms per lane), terminal rows, and rewards that push Tz onto exact
+    atoms / outside the support."""
+    rng = np.random.RandomState(B * 100 + K)
+    logit = rng.randn(B, A, K).astype(np.float32)
+    nlo, tl = rng.randn(B, A, K).astype(np.float32), rng.randn(B, A, K).astype(np.float32)
+    a = rng.randint(0, A, size=(B, 1))
+    r = rng.choice([-1.0, 0.0, 1.0, 20.0, -20.0], size=(B, n, 1)).astype(np.float32)
+    d = (rng.rand(B, n, 1) < 0.3).astype(np.float32)
+    w = rng.rand(B, 1).astype(np.float32)
+    ro = O.c51_project_kl(logit, a, r, d, tl, -1, 10, K, 0.99, next_logit_online=nlo, weights=w, alpha=0.5)
+    g, prio, kl, st = ops.c51_loss(f32(logit), f32(tl), f32(a), f32(r), f32(d), -1, 10, 0.99, next_logit_online=f32(nlo), weights=f32(w), alpha=0.5, n_step=n)
+    np.testing.assert_allclose(npy(kl), ro["KL"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(npy(prio), ro["p_j"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(npy(st)[0], ro["loss"], rtol=2e-5)
+    np.testing.assert_allclose(npy(g), ro["d_logit"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(npy(st)[1], ro["max_Q"], rtol=1e-5)
