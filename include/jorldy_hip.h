@@ -77,6 +77,9 @@ int jh_store_push(jh_store* s, int64_t n, const void* const* h_cols, jh_stream s
  * then commit (enqueues the async H2D copies).  begin/commit must alternate.             */
 int jh_store_stage_begin(jh_store* s, int64_t n, void** h_cols_out);
 int jh_store_stage_commit(jh_store* s, jh_stream stream);
+/* Same ring append from DEVICE-resident rows already in the stored dtypes (on-device collectors,
+ * growing a rollout store): d_cols[c] -> n*elems[c] elements, device-to-device async copies.   */
+int jh_store_push_device(jh_store* s, int64_t n, const void* const* d_cols, jh_stream stream);
 /* out[c][b][:] = convert(col[c][idx[b] - idx_offset][:]) for the selected columns
  * (replay_buffer.py:25-31 + base.py:42-56 + the fp32 cast of BaseAgent.as_tensor,
  * core/agent/base.py:61-73).  out_dtype[c] is JH_F32 (as_tensor semantics) or the stored

@@ -37,6 +37,7 @@ _PROTOS = {
     "jh_store_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _pp]),
     "jh_store_destroy": (None, [_vp]),
     "jh_store_push": (C.c_int, [_vp, _i64, _pp, _vp]),
+    "jh_store_push_device": (C.c_int, [_vp, _i64, _pp, _vp]),
     "jh_store_stage_begin": (C.c_int, [_vp, _i64, _pp]),
     "jh_store_stage_commit": (C.c_int, [_vp, _vp]),
     "jh_store_gather": (C.c_int, [_vp, _i64, _vp, _i64, _i32, C.POINTER(_i32), _pp, C.POINTER(_i32), _vp]),

@@ -1,0 +1,300 @@
+import os
+from collections import deque
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..buffer import PERBuffer, ReplayBuffer
+from ..network import Network
+from ..optimizer import Optimizer
+from .base import BaseAgent
+
+
+class DQN(BaseAgent):
+    """core/agent/dqn.py:14-203.  learn(): uniform sample (same numpy draw as the reference) ->
+    fused gather -> Q(s), Q_target(s') -> jh_td_loss (target, Huber, dQ) -> backward -> Adam.
+    One host sync per learn (loss/max_Q read-back), not three."""
+
+    action_type = "discrete"
+    _td = dict(double=False, per=False, n_step=0)
+
+    def __init__(self, state_size, action_size, hidden_size=512, optim_config={"name": "adam"},
+                 network="discrete_q_network", head="mlp", gamma=0.99, epsilon_init=1.0, epsilon_min=0.1,
+                 epsilon_eval=0.0, explore_ratio=0.1, buffer_size=50000, batch_size=64, start_train_step=2000,
+                 target_update_period=500, device=None, run_step=1e6, num_workers=1, lr_decay=True, **kwargs):
+        self.device = self._require_gpu(device)
+        self.action_size = action_size
+        self.action_type = "discrete"
+        self.network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
+        self.target_network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
+        self.target_network.load_state_dict(self.network.state_dict())
+        self.optimizer = Optimizer(**optim_config, params=self.network.parameters())
+        self.gamma = gamma
+        self.epsilon = epsilon_init
+        self.epsilon_init = epsilon_init
+        self.epsilon_min = epsilon_min
+        self.epsilon_eval = epsilon_eval
+        self.explore_step = run_step * explore_ratio
+        self.epsilon_delta = (epsilon_init - epsilon_min) / self.explore_step
+        self.buffer_size = buffer_size
+        self.memory = ReplayBuffer(buffer_size, device=self.device)
+        self.batch_size = batch_size
+        self.start_train_step = start_train_step
+        self.target_update_stamp = 0
+        self.target_update_period = target_update_period
+        self.num_learn = 0
+        self.time_t = 0
+        self.num_workers = num_workers
+        self.run_step = run_step
+        self.lr_decay = lr_decay
+        self.clip_grad_norm = None
+        self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    @torch.no_grad()
+    def act(self, state, training=True):
+        self.network.train(training)
+        epsilon = self.epsilon if training else self.epsilon_eval
+        if np.random.random() < epsilon:
+            batch_size = state[0].shape[0] if isinstance(state, list) else state.shape[0]
+            action = np.random.randint(0, self.action_size, size=(batch_size, 1))
+        else:
+            action = torch.argmax(self.network(self.as_tensor(state)), -1, keepdim=True).cpu().numpy()
+        return {"action": action}
+
+    # ------------------------------------------------------------------------------------------
+    def _sample(self):
+        """-> (transitions, weights|None, indices|None, sampled_p, mean_p)"""
+        return self.memory.sample(self.batch_size), None, None, None, None
+
+    def learn(self):
+        tr, weights, indices, sampled_p, mean_p = self._sample()
+        state, action, reward = tr["state"], tr["action"], tr["reward"]
+        next_state, done = tr["next_state"], tr["done"]
+        q = self.network(state)
+        with torch.no_grad():
+            next_target_q = self.target_network(next_state)
+            next_q = self.network(next_state) if self._td["double"] else None
+        g, prio, st = ops.td_loss(q.detach(), next_target_q, action, reward, done, self.gamma, q_next_online=next_q,
+                                  weights=weights, alpha=getattr(self, "alpha", 0.0), n_step=self._td["n_step"] and self.n_step,
+                                  stats=self._stats)
+        if self._td["per"]:
+            self.memory.update_priorities(indices, prio)  # per.py:67-70 without the B `.item()` syncs
+        self.optimizer.zero_grad(set_to_none=True)
+        q.backward(g)
+        if self.clip_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.clip_grad_norm)
+        self.optimizer.step()
+        self.num_learn += 1
+        s = st.cpu().numpy()
+        result = {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1])}
+        if self._td["per"]:
+            result.update({"sampled_p": float(sampled_p.item()), "mean_p": float(mean_p.item())})
+        return result
+
+    def update_target(self):
+        self.target_network.load_state_dict(self.network.state_dict())
+
+    def _store(self, transitions):
+        if isinstance(transitions, dict):
+            self.memory.store_soa(transitions)
+        else:
+            self.memory.store(transitions)
+
+    def process(self, transitions, step):
+        """dqn.py:156-178."""
+        result = {}
+        self._store(transitions)
+        delta_t = step - self.time_t
+        self.time_t = step
+        self.target_update_stamp += delta_t
+        if self.memory.size >= self.batch_size and self.time_t >= self.start_train_step:
+            result = self.learn()
+            if self.lr_decay:
+                self.learning_rate_decay(step)
+        if self.num_learn > 0:
+            self.epsilon_decay(delta_t)
+            if self.target_update_stamp >= self.target_update_period:
+                self.update_target()
+                self.target_update_stamp -= self.target_update_period
+        return result
+
+    def epsilon_decay(self, delta_t):
+        self.epsilon = max(self.epsilon_min, self.epsilon - delta_t * self.epsilon_delta)
+
+    def save(self, path):
+        print(f"...Save model to {path}...")
+        torch.save({"network": self.network.state_dict(), "optimizer": self.optimizer.state_dict()}, os.path.join(path, "ckpt"))
+
+    def load(self, path):
+        print(f"...Load model from {path}...")
+        checkpoint = torch.load(os.path.join(path, "ckpt"), map_location=self.device, weights_only=False)
+        self.network.load_state_dict(checkpoint["network"])
+        self.target_network.load_state_dict(checkpoint["network"])
+        self.optimizer.load_state_dict(checkpoint["optimizer"])
+
+    def set_distributed(self, id):
+        self.epsilon = id / self.num_workers
+        return self
+
+
+class Double(DQN):
+    """core/agent/double.py:9-52."""
+
+    _td = dict(double=True, per=False, n_step=0)
+
+
+class Multistep(DQN):
+    """core/agent/multistep.py:12-104."""
+
+    _td = dict(double=False, per=False, n_step=1)
+
+    def __init__(self, n_step=5, **kwargs):
+        super().__init__(**kwargs)
+        self.n_step = n_step
+        self.tmp_buffer = deque(maxlen=n_step)
+
+    def interact_callback(self, transition):
+        """multistep.py:90-104: sliding window that is NOT reset at episode ends."""
+        _transition = {}
+        self.tmp_buffer.append(transition)
+        if len(self.tmp_buffer) == self.n_step:
+            _transition["state"] = self.tmp_buffer[0]["state"]
+            _transition["action"] = self.tmp_buffer[0]["action"]
+            _transition["next_state"] = self.tmp_buffer[-1]["next_state"]
+            for key in self.tmp_buffer[0].keys():
+                if key not in ["state", "action", "next_state"]:
+                    _transition[key] = np.stack([t[key] for t in self.tmp_buffer], axis=1)
+        return _transition
+
+
+class PER(DQN):
+    """core/agent/per.py:9-122: double-Q target, |td|^alpha priorities, IS-weighted MSE."""
+
+    _td = dict(double=True, per=True, n_step=0)
+
+    def __init__(self, alpha=0.6, beta=0.4, learn_period=16, uniform_sample_prob=1e-3, run_step=1e6, **kwargs):
+        super().__init__(run_step=run_step, **kwargs)
+        self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device)
+        self.alpha = alpha
+        self.beta = beta
+        self.beta_add = (1 - beta) / run_step
+        self.learn_period = learn_period
+        self.learn_period_stamp = 0
+
+    def _sample(self):
+        return self.memory.sample(self.beta, self.batch_size)
+
+    def learn(self):
+        result = super().learn()
+        result["beta"] = self.beta
+        return result
+
+    def process(self, transitions, step):
+        """per.py:89-122."""
+        result = {}
+        self._store(transitions)
+        delta_t = step - self.time_t
+        self.time_t = step
+        self.target_update_stamp += delta_t
+        self.learn_period_stamp += delta_t
+        self.beta = min(1.0, self.beta + (self.beta_add * delta_t))
+        if self.learn_period_stamp >= self.learn_period and self.memory.size >= self.batch_size and self.time_t >= self.start_train_step:
+            result = self.learn()
+            if self.lr_decay:
+                self.learning_rate_decay(step)
+            self.learn_period_stamp -= self.learn_period
+        if self.num_learn > 0:
+            self.epsilon_decay(delta_t)
+            if self.target_update_stamp >= self.target_update_period:
+                self.update_target()
+                self.target_update_stamp -= self.target_update_period
+        return result
+
+
+class ApeX(DQN):
+    """core/agent/ape_x.py:11-199: n-step double-Q, PER, grad clipping, per-actor epsilon and
+    actor-side initial priorities |G_n - q_t|."""
+
+    _td = dict(double=True, per=True, n_step=1)
+
+    def __init__(self, epsilon=0.4, epsilon_alpha=7.0, clip_grad_norm=40.0, alpha=0.6, beta=0.4, learn_period=4,
+                 uniform_sample_prob=1e-3, n_step=4, **kwargs):
+        super().__init__(**kwargs)
+        self.epsilon = epsilon
+        self.epsilon_alpha = epsilon_alpha
+        self.clip_grad_norm = clip_grad_norm
+        self.num_transitions = 0
+        self.alpha = alpha
+        self.beta = beta
+        self.learn_period = learn_period
+        self.learn_period_stamp = 0
+        self.uniform_sample_prob = uniform_sample_prob
+        self.beta_add = (1 - beta) / self.run_step
+        self.n_step = n_step
+        self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device)
+        self.tmp_buffer = deque(maxlen=n_step + 1)
+
+    @torch.no_grad()
+    def act(self, state, training=True):
+        self.network.train(training)
+        epsilon = self.epsilon if training else self.epsilon_eval
+        q = self.network(self.as_tensor(state))
+        if np.random.random() < epsilon:
+            batch_size = state[0].shape[0] if isinstance(state, list) else state.shape[0]
+            action = np.random.randint(0, self.action_size, size=(batch_size, 1))
+        else:
+            action = torch.argmax(q, -1, keepdim=True).cpu().numpy()
+        q = np.take(q.cpu().numpy(), action)
+        return {"action": action, "q": q}
+
+    def _sample(self):
+        return self.memory.sample(self.beta, self.batch_size)
+
+    def learn(self):
+        r = super().learn()
+        return {"loss": r["loss"], "max_Q": r["max_Q"], "sampled_p": r["sampled_p"], "mean_p": r["mean_p"],
+                "num_learn": self.num_learn, "num_transitions": self.num_transitions}
+
+    def process(self, transitions, step):
+        """ape_x.py:135-164."""
+        result = {}
+        self.num_transitions += len(next(iter(transitions.values()))) if isinstance(transitions, dict) else len(transitions)
+        delta_t = step - self.time_t
+        self._store(transitions)
+        self.time_t = step
+        self.target_update_stamp += delta_t
+        self.learn_period_stamp += delta_t
+        self.beta = min(1.0, self.beta + (self.beta_add * delta_t))
+        if self.learn_period_stamp >= self.learn_period and self.memory.buffer_counter >= self.batch_size and self.time_t >= self.start_train_step:
+            result = self.learn()
+            if self.lr_decay:
+                self.learning_rate_decay(step)
+            self.learn_period_stamp -= self.learn_period
+        if self.num_learn > 0 and self.target_update_stamp >= self.target_update_period:
+            self.update_target()
+            self.target_update_stamp -= self.target_update_period
+        return result
+
+    def set_distributed(self, id):
+        assert self.num_workers > 1
+        self.epsilon = self.epsilon ** (1 + (id / (self.num_workers - 1)) * self.epsilon_alpha)
+        return self
+
+    def interact_callback(self, transition):
+        """ape_x.py:174-199."""
+        _transition = {}
+        self.tmp_buffer.append(transition)
+        if len(self.tmp_buffer) == self.tmp_buffer.maxlen:
+            _transition["state"] = self.tmp_buffer[0]["state"]
+            _transition["action"] = self.tmp_buffer[0]["action"]
+            _transition["next_state"] = self.tmp_buffer[-1]["state"]
+            for key in self.tmp_buffer[0].keys():
+                if key not in ["state", "action", "next_state"]:
+                    _transition[key] = np.stack([t[key] for t in self.tmp_buffer][:-1], axis=1)
+            target_q = self.tmp_buffer[-1]["q"]
+            for i in reversed(range(self.n_step)):
+                target_q = self.tmp_buffer[i]["reward"] + (1 - self.tmp_buffer[i]["done"]) * self.gamma * target_q
+            _transition["priority"] = abs(target_q - self.tmp_buffer[0]["q"])
+            del _transition["q"]
+        return _transition

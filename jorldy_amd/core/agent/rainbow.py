@@ -1,0 +1,166 @@
+from collections import deque
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..buffer import PERBuffer
+from ..network import Network
+from ..optimizer import Optimizer
+from .dqn import DQN
+
+
+class C51(DQN):
+    """core/agent/c51.py:11-135: categorical DQN; the target net selects its own greedy action,
+    1-step projection, plain mean cross-entropy."""
+
+    def __init__(self, state_size, action_size, v_min=-10, v_max=10, num_support=51, **kwargs):
+        super().__init__(state_size, action_size * num_support, **kwargs)
+        self.action_size = action_size
+        self.v_min, self.v_max, self.num_support = v_min, v_max, num_support
+        self.delta_z = (v_max - v_min) / (num_support - 1)
+        self.z = torch.linspace(v_min, v_max, num_support, device=self.device).view(1, -1)
+        self._stats8 = torch.zeros(8, dtype=torch.float32, device=self.device)
+
+    def logits2Q(self, logits):
+        _logits = logits.view(logits.shape[0], self.action_size, self.num_support)
+        _logits = _logits - torch.max(_logits, -1, keepdim=True).values
+        p_logit = torch.exp(torch.log_softmax(_logits, dim=-1))
+        return p_logit, torch.sum(self.z.view(1, 1, -1) * p_logit, dim=-1)
+
+    @torch.no_grad()
+    def act(self, state, training=True):
+        self.network.train(training)
+        epsilon = self.epsilon if training else self.epsilon_eval
+        if np.random.random() < epsilon:
+            batch_size = state[0].shape[0] if isinstance(state, list) else state.shape[0]
+            action = np.random.randint(0, self.action_size, size=(batch_size, 1))
+        else:
+            _, q_action = self.logits2Q(self.network(self.as_tensor(state)))
+            action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
+        return {"action": action}
+
+    def learn(self):
+        tr = self.memory.sample(self.batch_size)
+        B, A, K = self.batch_size, self.action_size, self.num_support
+        logit = self.network(tr["state"])
+        with torch.no_grad():
+            target_logit = self.target_network(tr["next_state"])
+        g, _, _, st = ops.c51_loss(logit.detach().view(B, A, K), target_logit.view(B, A, K), tr["action"], tr["reward"], tr["done"],
+                                   self.v_min, self.v_max, self.gamma, shift_max=True, stats=self._stats8)
+        self.optimizer.zero_grad(set_to_none=True)
+        logit.backward(g.view_as(logit))
+        self.optimizer.step()
+        self.num_learn += 1
+        s = st.cpu().numpy()
+        return {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3])}
+
+
+class Rainbow(DQN):
+    """core/agent/rainbow.py:14-308: noisy dueling categorical net, n-step double-Q projection, PER
+    with priorities KL^alpha.  The projection + KL + backward-to-logits + priorities are one HIP
+    kernel (jh_c51_loss); priorities go straight into the device sum tree (no B `.item()` syncs)."""
+
+    def __init__(self, state_size, action_size, hidden_size=512, network="rainbow", head="mlp",
+                 optim_config={"name": "adam"}, gamma=0.99, buffer_size=50000, batch_size=64, start_train_step=2000,
+                 target_update_period=500, run_step=1e6, lr_decay=True, n_step=4, alpha=0.6, beta=0.4, learn_period=4,
+                 uniform_sample_prob=1e-3, noise_type="factorized", v_min=-10, v_max=10, num_support=51, device=None,
+                 **kwargs):
+        self.device = self._require_gpu(device)
+        self.action_size = action_size
+        self.action_type = "discrete"
+        mk = lambda: Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head).to(self.device)
+        self.network, self.target_network = mk(), mk()
+        self.target_network.load_state_dict(self.network.state_dict())
+        self.optimizer = Optimizer(**optim_config, params=self.network.parameters())
+        self.gamma = gamma
+        self.batch_size = batch_size
+        self.start_train_step = start_train_step
+        self.target_update_stamp = 0
+        self.target_update_period = target_update_period
+        self.num_learn = 0
+        self.time_t = 0
+        self.run_step = run_step
+        self.lr_decay = lr_decay
+        self.n_step = n_step
+        self.tmp_buffer = deque(maxlen=n_step)
+        self.alpha = alpha
+        self.beta = beta
+        self.learn_period = learn_period
+        self.learn_period_stamp = 0
+        self.uniform_sample_prob = uniform_sample_prob
+        self.beta_add = (1 - beta) / run_step
+        self.v_min, self.v_max, self.num_support = v_min, v_max, num_support
+        self.memory = PERBuffer(buffer_size, uniform_sample_prob, device=self.device)
+        self.delta_z = (v_max - v_min) / (num_support - 1)
+        self.z = torch.linspace(v_min, v_max, num_support, device=self.device).view(1, -1)
+        self.epsilon = 0.0
+        self._stats8 = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._noise = None  # parity tests inject the Gaussian draws here
+
+    def logits2Q(self, logits):
+        _logits = logits.view(logits.shape[0], self.action_size, self.num_support)
+        p_logit = torch.exp(torch.log_softmax(_logits, dim=-1))
+        return p_logit, torch.sum(self.z.view(1, 1, -1) * p_logit, dim=-1)
+
+    @torch.no_grad()
+    def act(self, state, training=True):
+        self.network.train(training)
+        if training and self.memory.size < max(self.batch_size, self.start_train_step):
+            batch_size = state[0].shape[0] if isinstance(state, list) else state.shape[0]
+            action = np.random.randint(0, self.action_size, size=(batch_size, 1))
+        else:
+            _, q_action = self.logits2Q(self.network(self.as_tensor(state), training))
+            action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
+        return {"action": action}
+
+    def learn(self):
+        tr, weights, indices, sampled_p, mean_p = self.memory.sample(self.beta, self.batch_size)
+        nz = self._noise or [None, None, None]
+        logit = self.network(tr["state"], True, nz[0])  # [B, A, K]
+        with torch.no_grad():
+            next_logit = self.network(tr["next_state"], True, nz[1])
+            target_logit = self.target_network(tr["next_state"], True, nz[2])
+        g, prio, kl, st = ops.c51_loss(logit.detach(), target_logit, tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max,
+                                       self.gamma, next_logit_online=next_logit, weights=weights, alpha=self.alpha,
+                                       n_step=self.n_step, stats=self._stats8)
+        self.memory.update_priorities(indices, prio)  # rainbow.py:230-231
+        self.optimizer.zero_grad(set_to_none=True)
+        logit.backward(g)
+        self.optimizer.step()
+        self.num_learn += 1
+        s = st.cpu().numpy()
+        return {"loss": float(s[0]), "beta": self.beta, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3]),
+                "sampled_p": float(sampled_p.item()), "mean_p": float(mean_p.item())}
+
+    def process(self, transitions, step):
+        """rainbow.py:255-283."""
+        result = {}
+        delta_t = step - self.time_t
+        self._store(transitions)
+        self.time_t = step
+        self.target_update_stamp += delta_t
+        self.learn_period_stamp += delta_t
+        self.beta = min(1.0, self.beta + (self.beta_add * delta_t))
+        if self.learn_period_stamp >= self.learn_period and self.memory.buffer_counter >= self.batch_size and self.time_t >= self.start_train_step:
+            result = self.learn()
+            if self.lr_decay:
+                self.learning_rate_decay(step)
+            self.learn_period_stamp -= self.learn_period
+        if self.num_learn > 0 and self.target_update_stamp >= self.target_update_period:
+            self.update_target()
+            self.target_update_stamp -= self.target_update_period
+        return result
+
+    def interact_callback(self, transition):
+        """rainbow.py:294-308."""
+        _transition = {}
+        self.tmp_buffer.append(transition)
+        if len(self.tmp_buffer) == self.n_step:
+            _transition["state"] = self.tmp_buffer[0]["state"]
+            _transition["action"] = self.tmp_buffer[0]["action"]
+            _transition["next_state"] = self.tmp_buffer[-1]["next_state"]
+            for key in self.tmp_buffer[0].keys():
+                if key not in ["state", "action", "next_state"]:
+                    _transition[key] = np.stack([t[key] for t in self.tmp_buffer], axis=1)
+        return _transition

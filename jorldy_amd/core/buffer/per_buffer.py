@@ -1,0 +1,86 @@
+import numpy as np
+import torch
+
+from ... import ops
+from .base import h2d_small
+from .replay_buffer import ReplayBuffer
+
+
+class PERBuffer(ReplayBuffer):
+    """core/buffer/per_buffer.py:7-105 on the GPU.
+
+    The float64 sum tree lives in HBM (array-heap layout, 2N-1 nodes, leaves at [N-1, 2N-2]); store,
+    priority write-back and sampling are batch kernels that reproduce the reference's sequential
+    `+= delta` arithmetic per node, so tree contents and sampled indices are bit-identical.  The
+    three numpy global-RNG draws of `sample` stay on the host, in the reference's order.
+    """
+
+    def __init__(self, buffer_size, uniform_sample_prob=1e-3, device=None):
+        super().__init__(buffer_size, device)
+        self.tree_size = self.buffer_size * 2 - 1
+        self.first_leaf_index = self.buffer_size - 1
+        self.uniform_sample_prob = uniform_sample_prob
+        self._tree = ops.SumTree(self.buffer_size, uniform_sample_prob, device=self.device)
+
+    # -- store ------------------------------------------------------------------------------------
+    def store_soa(self, cols, priorities=None):
+        cols = {k: v for k, v in cols.items() if k != "priority"}
+        n = super().store_soa(cols)
+        self._tree.push(n, priorities)  # per_buffer.py:27-33 (max_priority when no actor-side priority)
+        return n
+
+    def store(self, transitions):
+        if self.first_store:
+            self.check_dim(transitions[0])
+        if not transitions:
+            return
+        prio = None
+        if "priority" in transitions[0]:  # Ape-X actor-side priorities (ape_x.py:188-196), (1,1) arrays
+            prio = np.asarray([np.asarray(t["priority"]).reshape(-1)[0] for t in transitions], dtype=np.float64)
+        self.store_soa(self.stack_transition(transitions, skip=("priority",)), prio)
+
+    # -- priorities -------------------------------------------------------------------------------
+    def update_priorities(self, indices, priorities):
+        """Batched write-back: indices int64 device tensor (tree space), priorities float32/float64
+        device tensor; equivalent to `for i, p in zip(indices, p_j): update_priority(p.item(), i)`
+        (per.py:69-70, rainbow.py:230-231) without the B host syncs."""
+        self._tree.update(indices.reshape(-1), priorities.reshape(-1))
+
+    def update_priority(self, new_priority, index):
+        """Scalar compatibility path (per_buffer.py:42-48)."""
+        idx = h2d_small(np.asarray([index], dtype=np.int64), self.device)
+        p = h2d_small(np.asarray([float(np.asarray(new_priority).reshape(-1)[0])], dtype=np.float64), self.device)
+        self._tree.update(idx, p)
+
+    # -- sample -----------------------------------------------------------------------------------
+    def draw(self, batch_size):
+        """per_buffer.py:72-81: the three global-RNG draws, in reference order."""
+        mask = np.random.uniform(size=batch_size) < self.uniform_sample_prob
+        n_uni = int(np.sum(mask))
+        uni = np.random.randint(self.buffer_counter, size=n_uni)
+        u = np.random.uniform(size=batch_size - n_uni)
+        return uni, u
+
+    def sample(self, beta, batch_size, as_float=True):
+        """-> (transitions, weights f32[B] device, indices i64[B] device (tree space, uniform first),
+               sampled_p, mean_p) ; sampled_p/mean_p are 0-dim device float64 tensors (call .item()
+               when logging)."""
+        assert self.buffer_counter > 0
+        uni, u = self.draw(batch_size)
+        idx, w64, w32, stats = self._tree.sample(beta, uni, u, want_w64=False)
+        transitions = self.gather(idx, idx_offset=self.first_leaf_index, as_float=as_float)
+        stats = stats.clone()
+        return transitions, w32, idx, stats[0], stats[1]
+
+    # -- state the reference exposes ----------------------------------------------------------------
+    @property
+    def sum_tree(self):
+        return self._tree.dump()
+
+    @property
+    def max_priority(self):
+        return self._tree.state()["max_priority"]
+
+    @property
+    def tree_index(self):
+        return self._tree.state()["tree_index"]

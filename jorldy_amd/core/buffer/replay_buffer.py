@@ -1,0 +1,50 @@
+import numpy as np
+
+from .base import BaseBuffer, h2d_small
+
+
+class ReplayBuffer(BaseBuffer):
+    """core/buffer/replay_buffer.py:8-35 on the GPU.
+
+    store():   ring write (buffer_index wraps, buffer_counter saturates) through pinned staging +
+               hipMemcpyAsync.
+    sample():  `np.random.randint(buffer_counter, size=B)` on the host -- the SAME global-RNG draw as
+               the reference, so sampled indices are bit-identical -- then one fused gather kernel.
+    """
+
+    def __init__(self, buffer_size, device=None):
+        super().__init__(device)
+        self.buffer_size = int(buffer_size)
+        self.buffer_index = 0
+        self.buffer_counter = 0
+
+    # fast path: already-SoA numpy columns [n, ...]
+    def store_soa(self, cols, n=None):
+        if self._store is None:
+            self._make_store(cols, self.buffer_size)
+        flat = self._flat_cols(cols)
+        n = self._store.push(flat)
+        self.buffer_index = (self.buffer_index + n) % self.buffer_size
+        self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
+        return n
+
+    def store(self, transitions):
+        if self.first_store:
+            self.check_dim(transitions[0])
+        if not transitions:
+            return
+        self.store_soa(self.stack_transition(transitions))
+
+    def sample_indices(self, batch_size):
+        return np.random.randint(self.buffer_counter, size=batch_size)  # replay_buffer.py:26
+
+    def gather(self, idx_device, idx_offset=0, as_float=True):
+        return self._unflatten(self._store.gather(idx_device, as_float=as_float, idx_offset=idx_offset))
+
+    def sample(self, batch_size, as_float=True):
+        idx = h2d_small(self.sample_indices(batch_size).astype(np.int64), self.device)
+        return self.gather(idx, as_float=as_float)
+
+    @property
+    def size(self):
+        return self.buffer_counter

@@ -74,6 +74,16 @@ class DeviceStore:
         L.check(self.lib.jh_store_push(self.h, n, ptrs, L.stream_ptr()))
         return n
 
+    def push_device(self, cols, n):
+        """cols: dict name -> CUDA tensor [n, ...] already in the stored dtype (device-to-device ring append)."""
+        ts = []
+        for name, dt, elems, _ in self.columns:
+            t = cols[name].contiguous()
+            assert t.is_cuda and t.dtype == _TORCH_OF[dt] and t.numel() >= n * elems
+            ts.append(t)
+        ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        L.check(self.lib.jh_store_push_device(self.h, int(n), ptrs, L.stream_ptr()))
+
     def stage(self, n):
         """Zero-copy push: returns dict name -> numpy view [n, elems] of PINNED memory; call commit() after filling."""
         ptrs = (C.c_void_p * len(self.columns))()
