@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the PPO sync hot path (BASELINE.json configs[1]: config.ppo.cartpole --sync
+--train.num_workers 8 on 1 x MI355X).
+
+One "step" = one loop body of sync_distributed_train (run_mode.py:180-186):
+    collect W x T transitions (batched GPU acting + native host CartPole)  -> GPU rollout store
+    agent.process: log pi_old, GAE, n_epoch x minibatch clipped-loss updates (HIP kernels)
+`value` = env transitions per second over the whole job (W*T*K*N / wall), measured between
+barrier + torch.cuda.synchronize() brackets, max over ranks.
+
+    python bench.py --gpus N --steps K --warmup W
+(for N>1 the driver launches it with torch.distributed.run, one rank per GPU; ranks are
+data-parallel learners: own envs, own minibatches, one RCCL all-reduce of the flat gradient per
+minibatch -> "weak" scaling, global batch = N x 256.)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workers", type=int, default=8, help="sync workers per GPU (config: train.num_workers 8)")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(iters, W, T):
+    """The reference's CPU path (port: oracle/ppo_port.py, pinned bit-for-bit against the reference)
+    timed on this box's host cores: W in-process workers doing B=1 acting on the synthetic CartPole,
+    then PPO.learn with torch CPU using all cores."""
+    from oracle import ppo_port as P
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    agent = P.PPOPort(4, 2, 512, False, 2.5e-4, 0.99, 256, T, 3, 0.95, 0.1, 1.0, 0.01, 1.0, run_step=100000)
+    envs = [P._OneEnv(seed=w) for w in range(W)]
+    states = [e.reset_obs() for e in envs]
+    step = 0
+    for _ in range(2):  # warm-up
+        trs = P.sync_iteration(agent, envs, states, T)
+        step += T
+        agent.process(trs, step)
+    t0 = time.perf_counter()
+    n_tr = 0
+    t_collect = 0.0
+    for _ in range(iters):
+        c0 = time.perf_counter()
+        trs = P.sync_iteration(agent, envs, states, T)
+        t_collect += time.perf_counter() - c0
+        step += T
+        agent.process(trs, step)
+        n_tr += len(trs)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_tr / dt,
+        "unit": "env_transitions/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{iters} sync iterations of config.ppo.cartpole (W={W}, T={T}, 3 epochs x 4 minibatches of 256), "
+                  f"workers run sequentially in-process (no Ray), learner on {cores} torch threads; "
+                  f"collect {t_collect / iters * 1e3:.1f} ms + learn {(dt - t_collect) / iters * 1e3:.1f} ms per iteration",
+        "learner_updates_per_s": iters * 12 / (dt - t_collect),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import VecCollector
+    from jorldy_amd.parallel import make_grad_sync
+
+    W, T = args.workers, 128
+    np.random.seed(1234 + rank)
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    agent = Agent("ppo", state_size=4, action_size=2, hidden_size=512, network="discrete_policy_value",
+                  optim_config={"name": "adam", "lr": 2.5e-4}, gamma=0.99, batch_size=256, n_step=T, n_epoch=3, _lambda=0.95,
+                  epsilon_clip=0.1, vf_coef=1.0, ent_coef=0.01, clip_grad_norm=1.0, use_standardization=True, lr_decay=True,
+                  run_step=10_000_000, num_workers=W, device=f"cuda:{local_rank}")
+    agent.memory.first_store = False
+    if world > 1:
+        agent.grad_sync = make_grad_sync(agent.network, dist)
+    env = ops.CartPoleVec(W, seed=100 + rank)
+    collector = VecCollector(env, agent, W)
+
+    step = 0
+
+    def one_iteration():
+        nonlocal step
+        transitions, _ = collector.run(T)
+        step += T
+        result = agent.process(transitions, step)
+        collector.sync(None)
+        return result
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_iteration()
+    ops.profile_reset(enable=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = one_iteration()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_collect()
+    ops.profile_reset(enable=False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_updates = 3 * ((W * T + 255) // 256)
+    out = {
+        "metric": "env_steps_per_s (PPO CartPole sync, W=8 workers/GPU, T=128)",
+        "value": world * W * T * args.steps / dt,
+        "unit": "env_transitions/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "config.ppo.cartpole --sync --train.num_workers 8 (BASELINE.json configs[1]): synthetic CartPole-v1, "
+                               "W=8 x T=128 = 1024 transitions/iteration/GPU, MLP 4-512-512-{2,1}, 3 epochs x 4 minibatches of 256",
+                   "workers_per_gpu": W, "n_step": T, "batch_size": 256, "n_epoch": 3, "parallelism": f"dp{world}"},
+        "learner_updates_per_s": world * n_updates * args.steps / dt,
+        "last_result": {k: float(v) for k, v in result.items()},
+    }
+    # ---- roofline of the dominant hand-written kernel, from HIP events recorded in the timed region
+    if prof:
+        name, (n_launch, ms_total, bytes_per_launch, bound) = max(prof.items(), key=lambda kv: kv[1][1])
+        avg_s = ms_total / n_launch * 1e-3
+        achieved = bytes_per_launch / avg_s / 1e9
+        out["roofline"] = {"kernel": name, "bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": n_launch, "avg_us": avg_s * 1e6,
+                           "algorithmic_bytes_per_launch": bytes_per_launch}
+        out["kernel_times_us"] = {k: v[1] / v[0] * 1e3 for k, v in prof.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters, W, T)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

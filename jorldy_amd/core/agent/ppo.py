@@ -51,6 +51,7 @@ class PPO(BaseAgent):
         self.time_t = 0
         self.learn_stamp = 0
         self._stats = None
+        self.grad_sync = None  # data-parallel hook: jorldy_amd.parallel.FlatGradSync (RCCL all-reduce)
 
     @torch.no_grad()
     def act(self, state, training=True):
@@ -106,6 +107,8 @@ class PPO(BaseAgent):
                     outs, grads = [logits, value_pred], [g_z, g_v]
                 self.optimizer.zero_grad(set_to_none=True)
                 torch.autograd.backward(outs, grads)
+                if self.grad_sync is not None:
+                    self.grad_sync()
                 torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.clip_grad_norm)
                 self.optimizer.step()
                 k += 1

@@ -16,6 +16,44 @@ _TORCH_OF = {L.JH_U8: torch.uint8, L.JH_F32: torch.float32, L.JH_I64: torch.int6
 _NP_OF = {L.JH_U8: np.uint8, L.JH_F32: np.float32, L.JH_I64: np.int64, L.JH_F64: np.float64, L.JH_I32: np.int32}
 
 
+# ----------------------------------------------------------------------------- kernel timing
+# bench.py measures the hand-written kernels live with HIP events recorded on the stream they are
+# launched on (torch's current stream).  Off by default: zero overhead in the product path.
+_PROF = {"on": False, "ev": {}}
+
+
+class _timed:
+    def __init__(self, name, nbytes, bound="hbm"):
+        self.name, self.nbytes, self.bound = name, nbytes, bound
+
+    def __enter__(self):
+        if _PROF["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _PROF["on"]:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _PROF["ev"].setdefault(self.name, []).append((self.e0, e1, self.nbytes, self.bound))
+
+
+def profile_reset(enable):
+    _PROF["on"] = bool(enable)
+    _PROF["ev"] = {}
+
+
+def profile_collect():
+    """-> {kernel: (n_launches, total_ms, algorithmic_bytes_per_launch, bound)}"""
+    torch.cuda.synchronize()
+    out = {}
+    for name, lst in _PROF["ev"].items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in lst)
+        out[name] = (len(lst), ms, sum(x[2] for x in lst) / len(lst), lst[0][3])
+    return out
+
+
 def _f32(t):
     assert t.dtype == torch.float32 and t.is_cuda, "expected a float32 CUDA tensor"
     return t.contiguous()
@@ -122,7 +160,9 @@ class DeviceStore:
         odtc = (C.c_int32 * len(sel))(*odt)
         ptrs = (C.c_void_p * len(sel))(*[o.data_ptr() for o in outs])
         assert idx.dtype == torch.int64 and idx.is_cuda
-        L.check(self.lib.jh_store_gather(self.h, B, L.ptr(idx.contiguous()), int(idx_offset), len(sel), selc, ptrs, odtc, L.stream_ptr()))
+        nbytes = sum(B * self.columns[i][2] * np.dtype(_NP_OF[self.columns[i][1]]).itemsize + o.numel() * o.element_size() for i, o in zip(sel, outs)) + 8 * B
+        with _timed("jh_gather_kernel", nbytes):
+            L.check(self.lib.jh_store_gather(self.h, B, L.ptr(idx.contiguous()), int(idx_offset), len(sel), selc, ptrs, odtc, L.stream_ptr()))
         return dict(zip(names, outs))
 
 
@@ -215,7 +255,8 @@ def gae(reward, done, value, next_value, n_step, gamma, lam, standardize=True):
     assert M % n_step == 0
     adv = torch.empty(M, dtype=torch.float32, device=r.device)
     ret = torch.empty(M, dtype=torch.float32, device=r.device)
-    L.check(lib.jh_gae(L.ctx(_dev(r)), M // n_step, int(n_step), float(gamma), float(lam), L.ptr(r), L.ptr(d), L.ptr(v), L.ptr(vn), L.ptr(adv), L.ptr(ret), int(bool(standardize)), L.stream_ptr()))
+    with _timed("jh_gae_kernel", 24 * M):  # 4 reads + 2 writes of fp32 per transition
+      L.check(lib.jh_gae(L.ctx(_dev(r)), M // n_step, int(n_step), float(gamma), float(lam), L.ptr(r), L.ptr(d), L.ptr(v), L.ptr(vn), L.ptr(adv), L.ptr(ret), int(bool(standardize)), L.stream_ptr()))
     return adv.view(-1, 1), ret.view(-1, 1)
 
 
@@ -247,7 +288,8 @@ def ppo_loss_discrete(logits, value_pred, idx, action, adv, ret, value_old, logp
     g_v = torch.empty(B, dtype=torch.float32, device=z.device)
     if stats is None:
         stats = torch.empty(8, dtype=torch.float32, device=z.device)
-    L.check(lib.jh_ppo_loss_discrete(L.ctx(_dev(z)), B, A, L.ptr(z), L.ptr(v), L.ptr(idx), L.ptr(_f32(action).reshape(-1)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)), L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old).reshape(-1)), float(eps_clip), float(vf_coef), float(ent_coef), L.ptr(g_z), L.ptr(g_v), L.ptr(stats), L.stream_ptr()))
+    with _timed("jh_ppo_fused_kernel" if B <= 1024 else "jh_ppo_fwd+bwd", 4 * B * (2 * A + 7) + 8 * B):  # (A+6) reads + (A+1) writes + idx
+      L.check(lib.jh_ppo_loss_discrete(L.ctx(_dev(z)), B, A, L.ptr(z), L.ptr(v), L.ptr(idx), L.ptr(_f32(action).reshape(-1)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)), L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old).reshape(-1)), float(eps_clip), float(vf_coef), float(ent_coef), L.ptr(g_z), L.ptr(g_v), L.ptr(stats), L.stream_ptr()))
     return g_z, g_v.view(-1, 1), stats
 
 
