@@ -54,6 +54,11 @@ int jh_device_count(void);                       /* 0 when no GPU is visible (ne
 int jh_ctx_create(int device, jh_ctx** out);     /* binds the device, allocates pinned staging */
 void jh_ctx_destroy(jh_ctx* ctx);
 int jh_ctx_sync(jh_ctx* ctx, jh_stream stream);  /* hipStreamSynchronize */
+/* Pinned host memory mapped into the device address space (the pinned staging of the collector:
+ * observations written by the host are read in place by the acting kernels, actions come back
+ * the same way).  *dev_out is the address kernels must use.                                 */
+int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void** dev_out);
+void jh_pinned_free(void* host);
 
 /* ------------------------------------------------------------------ transition store
  * GPU-resident struct-of-arrays ring that replaces the list-of-dicts storage of
@@ -184,6 +189,43 @@ int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t n_step, in
                 const float* d_reward, const float* d_done, const float* d_weights, float v_min, float v_max,
                 float gamma, float alpha, float* d_grad_logit, float* d_prio, float* d_kl, float* d_stats,
                 jh_stream stream);
+
+/* ------------------------------------------------------------------ native policy-value MLP
+ * The encoder of the PPO configs (core/network/head.py:6-18 MLP head + policy_value.py:8-57):
+ * S -> H relu -> H relu -> {A logits | A mu, A log_std} + value, as hand-written kernels
+ * (fp32-input MFMA for the H x H contractions).  Parameters, gradients and Adam moments are FLAT
+ * fp32 device buckets borrowed from the caller, laid out in the reference's state_dict order:
+ *   head.l.weight [H][S], head.l.bias [H], l.weight [H][H], l.bias [H],
+ *   pi.weight [A][H], pi.bias [A]                              (discrete)
+ *   mu.weight, mu.bias, log_std.weight [A][H], log_std.bias    (continuous)
+ *   v.weight [1][H], v.bias [1]
+ * so one RCCL all-reduce covers the whole gradient and torch views give state_dict()/ckpt compat. */
+typedef struct jh_pponet jh_pponet;
+int64_t jh_pponet_param_count(int32_t S, int32_t H, int32_t A, int32_t continuous);
+int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int32_t continuous, int32_t max_rows,
+                     float* d_params, float* d_grads, float* d_m, float* d_v, uint64_t seed, jh_pponet** out);
+void jh_pponet_destroy(jh_pponet* n);
+/* Adam hyper-parameters live in device memory (a captured graph can be replayed while the host
+ * anneals lr, core/agent/base.py:93-111).  step >= 0 sets Adam's step counter (checkpoint restore),
+ * step < 0 keeps it.                                                                            */
+int jh_pponet_set_hyper(jh_pponet* n, float lr, float beta1, float beta2, float eps, float step, jh_stream stream);
+int jh_pponet_set_lr(jh_pponet* n, float lr, jh_stream stream);
+/* Forward of B rows of d_x [*, S] (gathered through d_idx int64[B] when non-NULL: the `state[idx]`
+ * of ppo.py:122).  Writes the RAW heads: d_head0 = logits | mu_raw [B][A], d_head1 = log_std_raw
+ * (continuous only), d_value [B].  Activations stay in the net for a following backward.     */
+int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, float* d_head0,
+                      float* d_head1, float* d_value, jh_stream stream);
+/* Backward of the last forward given d(loss)/d(raw heads); OVERWRITES the flat gradient bucket
+ * (== optimizer.zero_grad + loss.backward, ppo.py:164-165).                                    */
+int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0,
+                       const float* d_g_head1, const float* d_g_value, jh_stream stream);
+/* torch.nn.utils.clip_grad_norm_(max_norm) (skipped if max_norm <= 0) + torch.optim.Adam.step
+ * on the flat buckets (ppo.py:166-169).  d_norm_out: optional device float, pre-clip norm.      */
+int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_out, jh_stream stream);
+/* PPO.act for W envs in one shot (ppo.py:55-69, discrete): forward + softmax + multinomial
+ * (argmax when training == 0).  d_obs / d_action may be device-mapped pinned host memory.       */
+int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_ws,
+                           float* d_value_ws, int32_t training, jh_stream stream);
 
 /* ------------------------------------------------------------------ vectorised host collector
  * Synthetic CartPole-v1 (gym is not installable in the build image): W envs stepped in one

@@ -34,6 +34,8 @@ _PROTOS = {
     "jh_ctx_create": (C.c_int, [C.c_int, _pp]),
     "jh_ctx_destroy": (None, [_vp]),
     "jh_ctx_sync": (C.c_int, [_vp, _vp]),
+    "jh_pinned_alloc": (C.c_int, [_vp, _i64, _pp, _pp]),
+    "jh_pinned_free": (None, [_vp]),
     "jh_store_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _pp]),
     "jh_store_destroy": (None, [_vp]),
     "jh_store_push": (C.c_int, [_vp, _i64, _pp, _vp]),
@@ -63,6 +65,15 @@ _PROTOS = {
     "jh_ppo_loss_continuous": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "jh_td_loss": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "jh_c51_loss": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "jh_pponet_param_count": (_i64, [_i32, _i32, _i32, _i32]),
+    "jh_pponet_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.c_uint64, _pp]),
+    "jh_pponet_destroy": (None, [_vp]),
+    "jh_pponet_set_hyper": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "jh_pponet_set_lr": (C.c_int, [_vp, _f32, _vp]),
+    "jh_pponet_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "jh_pponet_backward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "jh_pponet_adam_step": (C.c_int, [_vp, _f32, _vp, _vp]),
+    "jh_pponet_act_discrete": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),
     "jh_cartpole_destroy": (None, [_vp]),
     "jh_cartpole_obs": (C.c_int, [_vp, _vp]),

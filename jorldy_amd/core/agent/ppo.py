@@ -19,16 +19,23 @@ class PPO(BaseAgent):
       log pi_old, GAE scan, per-row standardisation        jh_logp_*, jh_gae    ppo.py:83-110
       minibatch gathers x[idx] + clipped surrogate +       jh_ppo_loss_*        ppo.py:122-165
         clipped value + entropy, forward AND backward
+      MLP encoder fwd/bwd (fp32 MFMA), clip_grad_norm_,    jh_pponet_*          ppo.py:127-169
+        Adam on flat buckets            [backend "native"]
       the 5 `.item()` syncs per minibatch                  one D2H of a [n_updates, 8] stats array
 
-    The encoder fwd/bwd, clip_grad_norm_ and Adam stay torch ops on the same stream in this layer.
+    backend = "native": everything above is hand-written kernels; the whole learn() is captured in
+              one hipGraph after the first call (single-GPU).  Needs head="mlp", an int state_size
+              and the Adam optimizer (what configs ppo.cartpole / ppo.mujoco use).
+    backend = "torch":  encoder fwd/bwd, clip and the optimizer are torch ops on the same stream
+              (any head / optimizer); losses, GAE and buffers are still the HIP kernels.
+    backend = "auto" (default): native when eligible.
     Constructor arguments, `act`, `process`, result keys, checkpoint format are the reference's.
     """
 
     def __init__(self, state_size, action_size, hidden_size=512, network="discrete_policy_value", head="mlp",
                  optim_config={"name": "adam"}, gamma=0.99, use_standardization=True, run_step=1e6, lr_decay=True,
                  device=None, batch_size=32, n_step=128, n_epoch=3, _lambda=0.95, epsilon_clip=0.1, vf_coef=1.0,
-                 ent_coef=0.01, clip_grad_norm=1.0, num_workers=1, **kwargs):
+                 ent_coef=0.01, clip_grad_norm=1.0, num_workers=1, backend="auto", use_graph=True, seed=0, **kwargs):
         self.device = self._require_gpu(device)
         self.action_type = network.split("_")[0]
         assert self.action_type in ["continuous", "discrete"]
@@ -53,8 +60,72 @@ class PPO(BaseAgent):
         self._stats = None
         self.grad_sync = None  # data-parallel hook: jorldy_amd.parallel.FlatGradSync (RCCL all-reduce)
 
+        eligible = (
+            head == "mlp" and isinstance(state_size, (int, np.integer)) and optim_config.get("name", "adam").lower() == "adam"
+            and network in ("discrete_policy_value", "continuous_policy_value") and hidden_size % 16 == 0
+            and not self.optimizer.defaults.get("amsgrad", False) and self.optimizer.defaults.get("weight_decay", 0) == 0
+            and (2 * action_size + 1 if self.action_type == "continuous" else action_size + 1) <= 8
+        )
+        assert backend in ("auto", "native", "torch")
+        if backend == "native" and not eligible:
+            raise ValueError("backend='native' needs head='mlp', an int state_size, Adam without weight decay and <= 8 head outputs")
+        self.backend = "native" if (eligible and backend != "torch") else "torch"
+        self.use_graph = use_graph
+        self._net = None
+        self._graph = None
+        self._static = None
+        self._adam_steps = 0
+        if self.backend == "native":
+            self._init_native(int(state_size), int(action_size), int(hidden_size), seed)
+
+    # ---------------------------------------------------------------------------------- native engine
+    def _init_native(self, S, A, H, seed, max_rows=4096):
+        cont = self.action_type == "continuous"
+        net = ops.PPONet(S, H, A, cont, max_rows, self.device, seed=seed)
+        params = list(self.network.parameters())
+        assert sum(p.numel() for p in params) == net.n_params, "state_dict layout mismatch with libjorldy_hip"
+        o = 0
+        with torch.no_grad():
+            for p in params:  # registration order == the reference's state_dict order == the flat layout
+                n = p.numel()
+                net.params[o : o + n].copy_(p.reshape(-1))
+                p.data = net.params[o : o + n].view_as(p)       # nn.Parameters become views of the bucket
+                p.grad = net.grads[o : o + n].view_as(p)
+                o += n
+        self._views = [(p, net.m[a : a + p.numel()].view_as(p), net.v[a : a + p.numel()].view_as(p))
+                       for p, a in zip(params, np.cumsum([0] + [q.numel() for q in params[:-1]]))]
+        d = self.optimizer.defaults
+        net.set_hyper(d["lr"], d["betas"][0], d["betas"][1], d["eps"], step=0.0)
+        self._net = net
+
+    def _grow_native(self, rows):
+        if rows <= self._net.max_rows:
+            return
+        old = self._net
+        S, H, A = old.S, old.H, old.A
+        net = ops.PPONet(S, H, A, old.cont, max(rows, 2 * old.max_rows), self.device)
+        for dst, src in ((net.params, old.params), (net.grads, old.grads), (net.m, old.m), (net.v, old.v)):
+            dst.copy_(src)
+        o = 0
+        for p in self.network.parameters():
+            n = p.numel()
+            p.data = net.params[o : o + n].view_as(p)
+            p.grad = net.grads[o : o + n].view_as(p)
+            o += n
+        params = list(self.network.parameters())
+        self._views = [(p, net.m[a : a + p.numel()].view_as(p), net.v[a : a + p.numel()].view_as(p))
+                       for p, a in zip(params, np.cumsum([0] + [q.numel() for q in params[:-1]]))]
+        d = self.optimizer.defaults
+        net.set_hyper(self.optimizer.param_groups[0]["lr"], d["betas"][0], d["betas"][1], d["eps"], step=float(self._adam_steps))
+        torch.cuda.synchronize()
+        self._net, self._graph, self._static = net, None, None
+
+    # ---------------------------------------------------------------------------------- act
     @torch.no_grad()
     def act(self, state, training=True):
+        if self._net is not None and self.action_type == "discrete" and not isinstance(state, list):
+            self._grow_native(len(state))
+            return {"action": self._net.act_discrete(np.asarray(state, dtype=np.float32), training)}
         self.network.train(training)
         if self.action_type == "continuous":
             mu, std, _ = self.network(self.as_tensor(state))
@@ -65,13 +136,28 @@ class PPO(BaseAgent):
             action = torch.multinomial(pi, 1) if training else torch.argmax(pi, dim=-1, keepdim=True)
         return {"action": action.cpu().numpy()}
 
+    # ---------------------------------------------------------------------------------- learn
     def learn(self):
+        if self._net is not None:
+            return self._learn_native()
+        return self._learn_torch()
+
+    def _result(self, s, n_upd):
+        return {
+            "actor_loss": np.mean(s[:n_upd, 1]),
+            "critic_loss": np.mean(s[:n_upd, 2]),
+            "entropy_loss": np.mean(s[:n_upd, 3]),
+            "max_ratio": float(s[:n_upd, 4].max()),
+            "min_prob": float(s[:n_upd, 5].min()),
+            "mean_ret": float(s[n_upd, 0]),
+        }
+
+    def _learn_torch(self):
         tr = self.memory.sample()  # float32 device tensors, arrival (worker-major) order
         state, action, reward = tr["state"], tr["action"], tr["reward"]
         next_state, done = tr["next_state"], tr["done"]
         M = reward.shape[0]
         cont = self.action_type == "continuous"
-
         with torch.no_grad():  # ppo.py:83-110
             if cont:
                 mu_raw, ls_raw, value = self.network.raw(state)
@@ -83,7 +169,6 @@ class PPO(BaseAgent):
             adv, ret = ops.gae(reward, done, value, next_value, self.n_step, self.gamma, self._lambda, self.use_standardization)
             value = value.contiguous()
             mean_ret_t = ret.mean()
-
         n_mb = (M + self.batch_size - 1) // self.batch_size
         n_upd = self.n_epoch * n_mb
         if self._stats is None or self._stats.shape[0] < n_upd + 1:
@@ -114,14 +199,96 @@ class PPO(BaseAgent):
                 k += 1
         stats[n_upd, 0] = mean_ret_t
         s = stats[: n_upd + 1].cpu().numpy().astype(np.float64)  # the only host sync of learn()
-        return {
-            "actor_loss": np.mean(s[:n_upd, 1]),
-            "critic_loss": np.mean(s[:n_upd, 2]),
-            "entropy_loss": np.mean(s[:n_upd, 3]),
-            "max_ratio": float(s[:n_upd, 4].max()),
-            "min_prob": float(s[:n_upd, 5].min()),
-            "mean_ret": float(s[n_upd, 0]),
-        }
+        return self._result(s, n_upd)
+
+    # -- native: static buffers so that the whole update sequence can be replayed as one hipGraph ----
+    def _alloc_static(self, M):
+        S, A = self._net.S, self._net.A
+        cont = self._net.cont
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=self.device)
+        n_mb = (M + self.batch_size - 1) // self.batch_size
+        n_upd = self.n_epoch * n_mb
+        B = self.batch_size
+        st = dict(
+            M=M, n_upd=n_upd,
+            tr={"state": f(M, S), "action": f(M, A if cont else 1), "reward": f(M, 1), "next_state": f(M, S), "done": f(M, 1)},
+            arange=torch.arange(M, dtype=torch.int64, device=self.device),
+            idx=torch.zeros(self.n_epoch * M, dtype=torch.int64, device=self.device),
+            h0=f(M, A), h1=f(M, A) if cont else None, value=f(M, 1), nh0=f(M, A), nh1=f(M, A) if cont else None, next_value=f(M, 1),
+            logp_old=f(M, A if cont else 1), adv=None, ret=None,
+            mb_h0=f(B, A), mb_h1=f(B, A) if cont else None, mb_v=f(B, 1),
+            stats=torch.zeros(n_upd + 1, 8, dtype=torch.float32, device=self.device),
+        )
+        self._stats = st["stats"]
+        return st
+
+    def _enqueue_learn(self, st):
+        """Everything between `memory.sample()` and the result read-back, as stream work only (no host
+        sync, no allocation outside torch's graph-private pool): capturable."""
+        net, M, B = self._net, st["M"], self.batch_size
+        cont = net.cont
+        tr = st["tr"]
+        self.memory._store.gather(st["arange"], as_float=True, out={k: tr[k] for k in tr})
+        net.forward(tr["next_state"], out=(st["nh0"], st["nh1"], st["next_value"]))
+        net.forward(tr["state"], out=(st["h0"], st["h1"], st["value"]))
+        if cont:
+            logp_old = ops.logp_continuous(st["h0"], st["h1"], tr["action"])
+        else:
+            logp_old = ops.logp_discrete(st["h0"], tr["action"])
+        adv, ret = ops.gae(tr["reward"], tr["done"], st["value"], st["next_value"], self.n_step, self.gamma, self._lambda, self.use_standardization)
+        st["stats"][st["n_upd"], 0:1].copy_(ret.mean().reshape(1))
+        k = 0
+        for e in range(self.n_epoch):
+            for offset in range(0, M, B):
+                b = min(B, M - offset)
+                idx = st["idx"][e * M + offset : e * M + offset + b]
+                if cont:
+                    mu, ls, vp = net.forward(tr["state"], idx=idx, out=(st["mb_h0"][:b], st["mb_h1"][:b], st["mb_v"][:b]))
+                    g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu, ls, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])
+                    net.backward(tr["state"], idx, g_mu, g_ls, g_v)
+                else:
+                    z, vp = net.forward(tr["state"], idx=idx, out=(st["mb_h0"][:b], None, st["mb_v"][:b]))
+                    g_z, g_v, _ = ops.ppo_loss_discrete(z, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])
+                    net.backward(tr["state"], idx, g_z, None, g_v)
+                if self.grad_sync is not None:
+                    self.grad_sync.reduce_flat(net.grads)
+                net.adam_step(self.clip_grad_norm)
+                k += 1
+
+    def _learn_native(self):
+        M = self.memory.size
+        self._grow_native(M)
+        if self._static is None or self._static["M"] != M:
+            self._static, self._graph = self._alloc_static(M), None
+        st = self._static
+        # the reference's global-RNG shuffles (ppo.py:118), all epochs uploaded at once
+        idxs = np.arange(M)
+        perm = np.empty(self.n_epoch * M, np.int64)
+        for e in range(self.n_epoch):
+            np.random.shuffle(idxs)
+            perm[e * M : (e + 1) * M] = idxs
+        st["idx"].copy_(h2d_small(perm, self.device))
+        graphable = self.use_graph and self.grad_sync is None and not ops._PROF["on"]
+        if graphable and self._graph is None and getattr(self, "_warm", False):
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self._enqueue_learn(st)
+            self._graph = g  # capture does not execute: replay below runs this iteration's update
+        if graphable and self._graph is not None:
+            self._graph.replay()
+        else:
+            self._enqueue_learn(st)
+            self._warm = True
+        self.memory._store.clear()
+        self._adam_steps += st["n_upd"]
+        s = st["stats"].cpu().numpy().astype(np.float64)  # the only host sync of learn()
+        return self._result(s, st["n_upd"])
+
+    def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
+        super().learning_rate_decay(step, optimizers, mode)
+        if self._net is not None:
+            self._net.set_lr(self.optimizer.param_groups[0]["lr"])
 
     def process(self, transitions, step):
         """ppo.py:187-202.  `transitions` is the reference's List[Dict] or an SoA dict of arrays."""
@@ -140,8 +307,32 @@ class PPO(BaseAgent):
             self.learn_stamp = 0
         return result
 
+    # ---------------------------------------------------------------------------------- checkpoint
+    def _export_optim_state(self):
+        """Native Adam moments -> torch.optim.Adam state, so `ckpt` keeps the reference's format
+        ({"network": state_dict, "optimizer": state_dict}, reinforce.py:128-136)."""
+        if self._net is None:
+            return
+        for p, m, v in self._views:
+            self.optimizer.state[p] = {"step": torch.tensor(float(self._adam_steps)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+
+    def _import_optim_state(self):
+        if self._net is None:
+            return
+        steps = 0
+        for p, m, v in self._views:
+            stt = self.optimizer.state.get(p)
+            if stt:
+                m.copy_(stt["exp_avg"])
+                v.copy_(stt["exp_avg_sq"])
+                steps = int(float(stt["step"]))
+        self._adam_steps = steps
+        d = self.optimizer.defaults
+        self._net.set_hyper(self.optimizer.param_groups[0]["lr"], d["betas"][0], d["betas"][1], d["eps"], step=float(steps))
+
     def save(self, path):
         print(f"...Save model to {path}...")
+        self._export_optim_state()
         torch.save({"network": self.network.state_dict(), "optimizer": self.optimizer.state_dict()}, os.path.join(path, "ckpt"))
 
     def load(self, path):
@@ -149,3 +340,4 @@ class PPO(BaseAgent):
         checkpoint = torch.load(os.path.join(path, "ckpt"), map_location=self.device, weights_only=False)
         self.network.load_state_dict(checkpoint["network"])
         self.optimizer.load_state_dict(checkpoint["optimizer"])
+        self._import_optim_state()

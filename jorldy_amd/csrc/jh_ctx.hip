@@ -112,3 +112,22 @@ int jh_ctx_scratch(jh_ctx* ctx, size_t bytes, void** out) {
   *out = ctx->scratch;
   return JH_OK;
 }
+
+// Pinned, device-mapped host memory for callers that exchange small per-step data with kernels
+// (observations in, actions out) without a memcpy node.
+JH_EXPORT int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void** dev_out) {
+  JH_ARG(ctx && host_out && dev_out && bytes > 0);
+  JH_HIP(hipSetDevice(ctx->device));
+  void* h = nullptr;
+  JH_HIP(hipHostMalloc(&h, (size_t)bytes, hipHostMallocMapped));
+  void* d = nullptr;
+  JH_HIP(hipHostGetDevicePointer(&d, h, 0));
+  memset(h, 0, (size_t)bytes);
+  *host_out = h;
+  *dev_out = d;
+  return JH_OK;
+}
+
+JH_EXPORT void jh_pinned_free(void* host) {
+  if (host) (void)hipHostFree(host);
+}

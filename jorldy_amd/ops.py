@@ -142,7 +142,7 @@ class DeviceStore:
         p = self.lib.jh_store_col_ptr(self.h, i)
         return _wrap_device(p, (self.capacity,) + tuple(shape), _TORCH_OF[dt], self.device, owner=self)
 
-    def gather(self, idx, names=None, as_float=True, idx_offset=0):
+    def gather(self, idx, names=None, as_float=True, idx_offset=0, out=None):
         """idx: int64 CUDA tensor [B] -> dict name -> tensor [B, *shape]; float32 (as_tensor semantics)
         unless as_float=False (stored dtype, e.g. uint8 frames)."""
         names = self.names if names is None else names
@@ -153,7 +153,12 @@ class DeviceStore:
             _, dt, elems, shape = self.columns[i]
             keep = (not as_float) if not isinstance(as_float, dict) else (not as_float.get(nm, True))
             tdt = _TORCH_OF[dt] if keep else torch.float32
-            outs.append(torch.empty((B,) + tuple(shape), dtype=tdt, device=self.device))
+            if out is not None:  # static output buffers (graph capture / no allocator traffic)
+                o_t = out[nm]
+                assert o_t.dtype == tdt and o_t.is_contiguous() and o_t.numel() == B * elems
+                outs.append(o_t)
+            else:
+                outs.append(torch.empty((B,) + tuple(shape), dtype=tdt, device=self.device))
             sel.append(i)
             odt.append(_DT[tdt])
         selc = (C.c_int32 * len(sel))(*sel)
@@ -303,6 +308,102 @@ def ppo_loss_continuous(mu_raw, log_std_raw, value_pred, idx, action, adv, ret, 
         stats = torch.empty(8, dtype=torch.float32, device=mu.device)
     L.check(lib.jh_ppo_loss_continuous(L.ctx(_dev(mu)), B, A, L.ptr(mu), L.ptr(ls), L.ptr(v), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)), L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef), L.ptr(g_mu), L.ptr(g_ls), L.ptr(g_v), L.ptr(stats), L.stream_ptr()))
     return g_mu, g_ls, g_v.view(-1, 1), stats
+
+
+# ============================================================================= native policy-value MLP
+class PinnedBuffer:
+    """Pinned host memory mapped into the device address space (jh_pinned_alloc): `.np` is the host
+    view, `.dev_ptr` the address kernels use."""
+
+    def __init__(self, shape, dtype, device_index=None):
+        self.lib = L.load()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        h, d = C.c_void_p(), C.c_void_p()
+        L.check(self.lib.jh_pinned_alloc(L.ctx(device_index), max(n, 8), C.byref(h), C.byref(d)))
+        self._h = h
+        self.dev_ptr = C.c_void_p(d.value)
+        buf = (C.c_char * max(n, 8)).from_address(h.value)
+        self.np = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.np = None
+                self.lib.jh_pinned_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class PPONet:
+    """jh_pponet_*: S -> H relu -> H relu -> heads, fwd / bwd / clip + Adam on flat fp32 buckets."""
+
+    def __init__(self, S, H, A, continuous, max_rows, device, seed=0):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.ctx = L.ctx(self.device.index)
+        self.S, self.H, self.A, self.cont, self.max_rows = int(S), int(H), int(A), bool(continuous), int(max_rows)
+        self.n_params = int(self.lib.jh_pponet_param_count(self.S, self.H, self.A, int(self.cont)))
+        mk = lambda: torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.params, self.grads, self.m, self.v = mk(), mk(), mk(), mk()
+        self.h = C.c_void_p()
+        L.check(self.lib.jh_pponet_create(self.ctx, self.S, self.H, self.A, int(self.cont), self.max_rows, L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), C.c_uint64(int(seed)), C.byref(self.h)))
+        self._act = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jh_pponet_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_hyper(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=-1.0):
+        """step >= 0 sets Adam's step counter (0 = fresh optimizer), step < 0 keeps it."""
+        L.check(self.lib.jh_pponet_set_hyper(self.h, float(lr), float(beta1), float(beta2), float(eps), float(step), L.stream_ptr()))
+
+    def set_lr(self, lr):
+        L.check(self.lib.jh_pponet_set_lr(self.h, float(lr), L.stream_ptr()))
+
+    def forward(self, x, idx=None, B=None, out=None):
+        """x float32 [*, S]; rows gathered by idx (int64 [B]) when given.  Returns raw heads
+        (logits, value) or (mu_raw, log_std_raw, value); `out` = preallocated tuple."""
+        B = int(idx.numel()) if idx is not None else (int(x.shape[0]) if B is None else int(B))
+        if out is None:
+            h0 = torch.empty(B, self.A, dtype=torch.float32, device=self.device)
+            h1 = torch.empty(B, self.A, dtype=torch.float32, device=self.device) if self.cont else None
+            val = torch.empty(B, 1, dtype=torch.float32, device=self.device)
+        else:
+            h0, h1, val = out
+        flops = 2.0 * B * self.H * (self.S + self.H + (2 * self.A + 1 if self.cont else self.A + 1))
+        with _timed("jh_pponet_forward", flops, "mfma"):
+            L.check(self.lib.jh_pponet_forward(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(h0), L.ptr(h1), L.ptr(val), L.stream_ptr()))
+        return (h0, h1, val) if self.cont else (h0, val)
+
+    def backward(self, x, idx, g_head0, g_head1, g_value, B=None):
+        B = int(idx.numel()) if idx is not None else (int(x.shape[0]) if B is None else int(B))
+        flops = 4.0 * B * self.H * (self.S + self.H + (2 * self.A + 1 if self.cont else self.A + 1))
+        with _timed("jh_pponet_backward", flops, "mfma"):
+            L.check(self.lib.jh_pponet_backward(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(g_head0), L.ptr(g_head1), L.ptr(g_value), L.stream_ptr()))
+
+    def adam_step(self, max_norm, norm_out=None):
+        with _timed("jh_gradnorm+adam", 4.0 * self.n_params * 8):  # g (r twice, w) + p,m,v (r+w)
+            L.check(self.lib.jh_pponet_adam_step(self.h, float(max_norm if max_norm else 0.0), L.ptr(norm_out), L.stream_ptr()))
+
+    # ---- acting through device-mapped pinned memory ------------------------------------------------
+    def act_discrete(self, obs, training=True):
+        """obs: numpy float32 [W, S] -> numpy int64 [W, 1].  One forward + sampling launch for all W
+        envs; observations / actions cross PCIe through pinned memory the kernels access in place."""
+        W = int(obs.shape[0])
+        if self._act is None or self._act["W"] != W:
+            self._act = dict(W=W, obs=PinnedBuffer((W, self.S), np.float32, self.device.index), act=PinnedBuffer((W, 1), np.int64, self.device.index),
+                             logits=torch.empty(W, self.A, dtype=torch.float32, device=self.device), val=torch.empty(W, 1, dtype=torch.float32, device=self.device))
+        a = self._act
+        a["obs"].np[:] = obs
+        st = L.stream_ptr()
+        L.check(self.lib.jh_pponet_act_discrete(self.h, W, a["obs"].dev_ptr, a["act"].dev_ptr, L.ptr(a["logits"]), L.ptr(a["val"]), int(bool(training)), st))
+        L.check(self.lib.jh_ctx_sync(self.ctx, st))
+        return a["act"].np.copy()
 
 
 # ============================================================================= TD / C51

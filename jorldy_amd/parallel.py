@@ -29,6 +29,12 @@ class FlatGradSync:
         self.flat.div_(self.world)
         torch._foreach_copy_([p.grad for p in self.params], self.views)
 
+    def reduce_flat(self, flat):
+        """Native-backend form: the gradient already IS one flat bucket (jh_pponet_* writes it in
+        state_dict order) -> one in-place all-reduce, no packing copies."""
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+
     def broadcast_weights(self, src=0):
         for p in self.params:
             self.dist.broadcast(p.data, src=src, group=self.group)

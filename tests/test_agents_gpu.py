@@ -224,3 +224,139 @@ def test_reference_bookkeeping_asserts(name, extra, check, tmp_path):
     item = agent.sync_out()
     assert all(v.device.type == "cpu" for v in item["weights"].values())
     agent.sync_in(**item)
+
+
+# ---- native backend (hand-written MLP fwd/bwd + clip + Adam) ---------------------------------------
+def test_pponet_forward_backward_adam_vs_torch():
+    """jh_pponet_* against torch autograd + torch.optim.Adam on the same flat parameters."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.network import Network
+
+    for cont, S, H, A, B in ((False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8)):
+        torch.manual_seed(0)
+        ref = Network("continuous_policy_value" if cont else "discrete_policy_value", S, A, D_hidden=H).cuda()
+        with torch.no_grad():
+            for p in ref.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        net = ops.PPONet(S, H, A, cont, 1024, "cuda:0")
+        flat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+        assert flat.numel() == net.n_params
+        net.params.copy_(flat)
+        lr = 1e-3
+        net.set_hyper(lr, 0.9, 0.999, 1e-8, step=0.0)
+        opt = torch.optim.Adam(ref.parameters(), lr=lr)
+        x_all = torch.randn(300, S, device="cuda")
+        for it in range(3):
+            idx = torch.randperm(300, device="cuda")[:B]
+            outs = net.forward(x_all, idx=idx)
+            routs = ref.raw(x_all[idx])
+            for a, b in zip(outs, routs):
+                torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+            gs = [torch.randn_like(o) / B for o in routs]
+            opt.zero_grad(set_to_none=True)
+            torch.autograd.backward(list(routs), gs)
+            if cont:
+                net.backward(x_all, idx, gs[0], gs[1], gs[2])
+            else:
+                net.backward(x_all, idx, gs[0], None, gs[1])
+            gref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+            torch.testing.assert_close(net.grads, gref, rtol=1e-3, atol=1e-6)
+            norm_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+            opt.step()
+            norm = torch.zeros(1, device="cuda")
+            net.adam_step(0.5, norm)
+            torch.testing.assert_close(norm[0], norm_ref, rtol=1e-4, atol=1e-7)
+            pref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+            # Adam normalises the update: weights with ~0 gradient may differ by a step
+            d = (net.params - pref).abs()
+            assert float((d > 2e-5).float().mean()) < 0.005 and float(d.max()) <= 2.1 * lr * (it + 1)
+            net.params.copy_(pref)  # keep both trajectories aligned for the next iteration
+            net.m.copy_(torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref.parameters()]))
+            net.v.copy_(torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ref.parameters()]))
+
+
+@pytest.mark.parametrize("name", PPO_CASES)
+@pytest.mark.parametrize("graph", [False, True])
+def test_ppo_native_backend_matches_reference(name, graph):
+    """Whole learn() on hand-written kernels (and replayed from a hipGraph) vs the reference run."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load(name)
+    S, A, H, W, T, B, E, cont = [int(x) for x in z["cfg"]]
+    gamma, lam, eps, vf, ent, clip, lr = z["hyper"]
+    agent = Agent("ppo", state_size=S, action_size=A, hidden_size=H, network="continuous_policy_value" if cont else "discrete_policy_value",
+                  optim_config={"name": "adam", "lr": lr}, batch_size=B, n_step=T, n_epoch=E, _lambda=lam, epsilon_clip=eps, vf_coef=vf,
+                  ent_coef=ent, clip_grad_norm=clip, gamma=gamma, run_step=100000, num_workers=W, device="cuda", backend="native", use_graph=graph)
+    assert agent.backend == "native"
+    keys = ["state", "next_state", "reward", "done", "action"]
+    cols = {k: z[f"in_{k}"] for k in keys}
+    agent.memory.first_store = False
+    n_rep = 3 if graph else 1  # graph: eager warm-up, capture+replay, replay -- each from the same start
+    for rep in range(n_rep):
+        agent.network.load_state_dict(_sd(z, "sd0/"))
+        agent._net.m.zero_()
+        agent._net.v.zero_()
+        agent._adam_steps = 0
+        agent._net.set_hyper(lr, 0.9, 0.999, 1e-8, step=0.0)
+        agent.time_t, agent.learn_stamp = 0, 0
+        np.random.seed(int(z["np_seed"]))
+        result = agent.process(cols, T)
+        if graph and rep >= 1:
+            assert agent._graph is not None
+        n_upd = int(z["n_minibatch"])
+        s = npy(agent._stats[:n_upd])
+        for i in range(n_upd):
+            for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")):
+                tol = 1e-4 if cont else 3e-5
+                np.testing.assert_allclose(s[i, j], z[f"mb{i}/{k}"], rtol=tol, atol=tol, err_msg=f"{name} rep {rep} update {i} {k}")
+        for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
+            np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-4, atol=3e-5, err_msg=k)
+        np.testing.assert_allclose(agent.optimizer.param_groups[0]["lr"], z["lr_after"], rtol=1e-12)
+        _cmp_sd(agent.network, _sd(z, "sd1/"), lr, n_upd, atol=3e-5)
+
+
+def test_ppo_native_checkpoint_roundtrip(tmp_path):
+    """ckpt keeps the reference's {"network", "optimizer"} format and restores the native Adam state."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load("ppo_disc_small")
+    S, A, H, W, T, B, E, cont = [int(x) for x in z["cfg"]]
+    mk = lambda: Agent("ppo", state_size=S, action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": 1e-3}, batch_size=B, n_step=T, n_epoch=E, run_step=1000, device="cuda", backend="native", use_graph=False)
+    cols = {k: z[f"in_{k}"] for k in ["state", "next_state", "reward", "done", "action"]}
+    a1 = mk()
+    a1.memory.first_store = False
+    np.random.seed(1)
+    a1.process(cols, T)
+    a1.save(str(tmp_path))
+    ck = torch.load(str(tmp_path / "ckpt"), weights_only=False)
+    assert set(ck) == {"network", "optimizer"} and set(ck["network"]) == {"head.l.weight", "head.l.bias", "l.weight", "l.bias", "pi.weight", "pi.bias", "v.weight", "v.bias"}
+    assert int(ck["optimizer"]["state"][0]["step"]) == a1._adam_steps
+    a2 = mk()
+    a2.memory.first_store = False
+    a2.load(str(tmp_path))
+    a2.time_t = a1.time_t
+    for ag in (a1, a2):
+        np.random.seed(2)
+        ag.process(cols, 2 * T)
+    torch.testing.assert_close(a1._net.params, a2._net.params, rtol=0, atol=0)
+    torch.testing.assert_close(a1._net.m, a2._net.m, rtol=0, atol=0)
+
+
+def test_native_act_discrete_distribution():
+    """On-device multinomial acting: empirical action frequencies match softmax(logits)."""
+    from jorldy_amd.core.agent import Agent
+
+    agent = Agent("ppo", state_size=4, action_size=3, hidden_size=32, device="cuda", backend="native")
+    with torch.no_grad():
+        agent.network.pi.bias.copy_(torch.tensor([0.0, 1.0, -0.5], device="cuda"))
+    obs = np.zeros((64, 4), np.float32)
+    counts = np.zeros(3)
+    for _ in range(200):
+        a = agent.act(obs, training=True)["action"]
+        assert a.shape == (64, 1) and a.dtype == np.int64
+        counts += np.bincount(a.reshape(-1), minlength=3)
+    pi, _ = agent.network(torch.zeros(1, 4, device="cuda"))
+    p = npy(pi)[0]
+    np.testing.assert_allclose(counts / counts.sum(), p, atol=0.015)
+    g = agent.act(obs, training=False)["action"]
+    assert np.all(g == int(np.argmax(p)))
