@@ -60,6 +60,12 @@ int jh_ctx_sync(jh_ctx* ctx, jh_stream stream);  /* hipStreamSynchronize */
 int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void** dev_out);
 void jh_pinned_free(void* host);
 
+/* Per-kernel timing with HIP events recorded on the launch stream around every kernel of this
+ * library (measurement only; off by default).  jh_prof_report synchronises the device and writes
+ * "<kernel>\t<launches>\t<total_ms>\n" lines into buf.                                          */
+int jh_prof_enable(int32_t on);
+int jh_prof_report(char* buf, int64_t cap);
+
 /* ------------------------------------------------------------------ transition store
  * GPU-resident struct-of-arrays ring that replaces the list-of-dicts storage of
  *   ReplayBuffer   core/buffer/replay_buffer.py:8-35   (ring + uniform gather)

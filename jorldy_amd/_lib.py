@@ -34,6 +34,8 @@ _PROTOS = {
     "jh_ctx_create": (C.c_int, [C.c_int, _pp]),
     "jh_ctx_destroy": (None, [_vp]),
     "jh_ctx_sync": (C.c_int, [_vp, _vp]),
+    "jh_prof_enable": (C.c_int, [_i32]),
+    "jh_prof_report": (C.c_int, [C.c_char_p, _i64]),
     "jh_pinned_alloc": (C.c_int, [_vp, _i64, _pp, _pp]),
     "jh_pinned_free": (None, [_vp]),
     "jh_store_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _pp]),

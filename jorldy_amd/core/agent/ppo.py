@@ -268,7 +268,7 @@ class PPO(BaseAgent):
             np.random.shuffle(idxs)
             perm[e * M : (e + 1) * M] = idxs
         st["idx"].copy_(h2d_small(perm, self.device))
-        graphable = self.use_graph and self.grad_sync is None and not ops._PROF["on"]
+        graphable = self.use_graph and self.grad_sync is None and not ops._PROF["on"] and not ops._PROF["lib"]
         if graphable and self._graph is None and getattr(self, "_warm", False):
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()

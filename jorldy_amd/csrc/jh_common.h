@@ -34,6 +34,19 @@ int jh_fail(int code, const char* fmt, ...);
       return jh_fail(JH_ERR_HIP, "%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
   } while (0)
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+// Disabled by default: JH_LAUNCH is then exactly hipLaunchKernelGGL.
+extern bool g_jh_prof_on;
+void jh_prof_begin(const char* name, hipStream_t st);
+void jh_prof_end(hipStream_t st);
+#define JH_LAUNCH_NAMED(NAME, KERNEL, GRID, BLOCK, LDS, ST, ...)       \
+  do {                                                                 \
+    if (g_jh_prof_on) jh_prof_begin(NAME, ST);                         \
+    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__);     \
+    if (g_jh_prof_on) jh_prof_end(ST);                                 \
+  } while (0)
+#define JH_LAUNCH(KERNEL, GRID, BLOCK, LDS, ST, ...) JH_LAUNCH_NAMED(#KERNEL, KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__)
+
 static inline hipStream_t jh_s(jh_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t jh_dtype_size(int dt) {

@@ -131,3 +131,58 @@ JH_EXPORT int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void*
 JH_EXPORT void jh_pinned_free(void* host) {
   if (host) (void)hipHostFree(host);
 }
+
+// ------------------------------------------------------------------------------ kernel profiler
+#include <map>
+bool g_jh_prof_on = false;
+namespace {
+struct ProfRec {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+void jh_prof_begin(const char* name, hipStream_t st) {
+  ProfRec r{name, nullptr, nullptr};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  (void)hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+}
+
+void jh_prof_end(hipStream_t st) {
+  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, st);
+}
+
+JH_EXPORT int jh_prof_enable(int32_t on) {
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  g_jh_prof_on = on != 0;
+  return JH_OK;
+}
+
+// Writes one line per kernel: "<name>\t<launches>\t<total_ms>\n" (synchronises the device).
+JH_EXPORT int jh_prof_report(char* buf, int64_t cap) {
+  JH_ARG(buf && cap > 0);
+  JH_HIP(hipDeviceSynchronize());
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    auto& a = agg[r.name];
+    a.first += 1;
+    a.second += ms;
+  }
+  std::string out;
+  char line[512];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if ((int64_t)out.size() + 1 > cap) return jh_fail(JH_ERR_ARG, "jh_prof_report: buffer too small (%zu needed)", out.size() + 1);
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return JH_OK;
+}

@@ -128,10 +128,10 @@ JH_EXPORT int jh_td_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t n_step, int3
     if (rc) return rc;
     a.partial = (float*)scratch;
   }
-  hipLaunchKernelGGL(jh_td_loss_kernel, dim3(nb), dim3(256), 0, jh_s(stream), a);
+  JH_LAUNCH(jh_td_loss_kernel, dim3(nb), dim3(256), 0, jh_s(stream), a);
   JH_LAUNCH_CHECK();
   if (nb > 1 && d_stats) {
-    hipLaunchKernelGGL(jh_td_finish_kernel, dim3(1), dim3(256), 0, jh_s(stream), nb, B, a.partial, d_stats);
+    JH_LAUNCH(jh_td_finish_kernel, dim3(1), dim3(256), 0, jh_s(stream), nb, B, a.partial, d_stats);
     JH_LAUNCH_CHECK();
   }
   return JH_OK;
@@ -369,9 +369,9 @@ JH_EXPORT int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t 
   if (rc) return rc;
   a.partial = (float*)scratch;
   const size_t lds = sizeof(float) * 4 * 5 * (size_t)K;
-  hipLaunchKernelGGL(jh_c51_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);
+  JH_LAUNCH(jh_c51_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);
   JH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(jh_c51_finish_kernel, dim3(1), dim3(256), 0, jh_s(stream), nb, a);
+  JH_LAUNCH(jh_c51_finish_kernel, dim3(1), dim3(256), 0, jh_s(stream), nb, a);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }

@@ -134,10 +134,10 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(int M, int N, int K, con
 }
 
 template <bool A_KCONT, bool B_KCONT, int TN, int EPI>
-static int launch_gemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+static int launch_gemm(const char* name, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                        const float* aux, int ldaux, hipStream_t st) {
   const int tiles = ((M + 15) / 16) * ((N + 16 * TN - 1) / (16 * TN));
-  hipLaunchKernelGGL((jh_gemm16_kernel<A_KCONT, B_KCONT, TN, EPI>), dim3((tiles + 3) / 4), dim3(256), 0, st, M, N, K, A,
+  JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_KCONT, B_KCONT, TN, EPI>), dim3((tiles + 3) / 4), dim3(256), 0, st, M, N, K, A,
                      lda, B, ldb, C, ldc, aux, ldaux);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -476,14 +476,14 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   hipStream_t st = jh_s(stream);
   const int H = n->H;
   const int64_t bh = (int64_t)B * H;
-  hipLaunchKernelGGL(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, H, d_x, d_idx,
+  JH_LAUNCH(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, H, d_x, d_idx,
                      n->params + n->o_w1, n->params + n->o_b1, n->h1);
   JH_LAUNCH_CHECK();
-  int rc = launch_gemm<true, true, 1, EPI_BIAS_RELU>(B, H, H, n->h1, H, n->params + n->o_w2, H, n->h2, H,
+  int rc = launch_gemm<true, true, 1, EPI_BIAS_RELU>("jh_gemm16_fwd_h2", B, H, H, n->h1, H, n->params + n->o_w2, H, n->h2, H,
                                                      n->params + n->o_b2, 0, st);
   if (rc) return rc;
   HeadPtrs hp = head_ptrs(n, d_head0, d_head1, d_value, nullptr, nullptr, nullptr);
-  hipLaunchKernelGGL(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp);
+  JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
@@ -499,19 +499,19 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
   const int H = n->H, S = n->S;
   const int64_t bh = (int64_t)B * H;
   HeadPtrs hp = head_ptrs(n, nullptr, nullptr, nullptr, d_g_head0, d_g_head1, d_g_value);
-  hipLaunchKernelGGL(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, H, n->h2,
+  JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, H, n->h2,
                      n->dh2, hp);
   JH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(jh_mlp_heads_bwd_dw_kernel, dim3((H + 63) / 64), dim3(256), 0, st, B, H, n->h2, n->dh2,
+  JH_LAUNCH(jh_mlp_heads_bwd_dw_kernel, dim3((H + 63) / 64), dim3(256), 0, st, B, H, n->h2, n->dh2,
                      n->grads + n->o_b2, hp);
   JH_LAUNCH_CHECK();
   // dW2[o][i] = sum_b dh2[b][o] * h1[b][i]     (A = dh2^T: stored [K=B][M=H]; B = h1: stored [K=B][N=H])
-  int rc = launch_gemm<false, false, 2, EPI_NONE>(H, H, B, n->dh2, H, n->h1, H, n->grads + n->o_w2, H, nullptr, 0, st);
+  int rc = launch_gemm<false, false, 2, EPI_NONE>("jh_gemm16_bwd_dW2", H, H, B, n->dh2, H, n->h1, H, n->grads + n->o_w2, H, nullptr, 0, st);
   if (rc) return rc;
   // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] * W2[o][i]   (A = dh2 [M=B][K=H]; B = W2 stored [K=H_out][N=H_in])
-  rc = launch_gemm<true, false, 1, EPI_MASK>(B, H, H, n->dh2, H, n->params + n->o_w2, H, n->dh1, H, n->h1, H, st);
+  rc = launch_gemm<true, false, 1, EPI_MASK>("jh_gemm16_bwd_dh1", B, H, H, n->dh2, H, n->params + n->o_w2, H, n->dh1, H, n->h1, H, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(jh_mlp_l1_bwd_kernel, dim3((H + 63) / 64), dim3(256), sizeof(float) * 4 * 64 * (size_t)(S + 1), st,
+  JH_LAUNCH(jh_mlp_l1_bwd_kernel, dim3((H + 63) / 64), dim3(256), sizeof(float) * 4 * 64 * (size_t)(S + 1), st,
                      B, S, H, d_x, d_idx, n->dh1, n->grads + n->o_w1, n->grads + n->o_b1);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -522,10 +522,10 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
 JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_out, jh_stream stream) {
   JH_ARG(n != nullptr);
   hipStream_t st = jh_s(stream);
-  hipLaunchKernelGGL(jh_gradnorm_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial,
+  JH_LAUNCH(jh_gradnorm_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial,
                      n->hyper);
   JH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
+  JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
                      n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -540,7 +540,7 @@ JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* d_obs
   int rc = jh_pponet_forward(n, W, d_obs, nullptr, d_logits_ws, nullptr, d_value_ws, stream);
   if (rc) return rc;
   const int threads = W >= 1024 ? 1024 : ((W + 63) / 64) * 64;
-  hipLaunchKernelGGL(jh_sample_discrete_kernel, dim3(1), dim3(threads), 0, jh_s(stream), W, n->A, d_logits_ws, n->rng,
+  JH_LAUNCH(jh_sample_discrete_kernel, dim3(1), dim3(threads), 0, jh_s(stream), W, n->A, d_logits_ws, n->rng,
                      d_action, training ? 0 : 1);
   JH_LAUNCH_CHECK();
   return JH_OK;

@@ -239,7 +239,7 @@ JH_EXPORT int jh_per_create(jh_ctx* ctx, int64_t capacity, double usp, jh_per** 
   JH_HIP(hipMalloc((void**)&p->maxp, sizeof(double)));
   JH_HIP(hipMalloc((void**)&p->ws.delta, sizeof(double) * kChunk));
   JH_HIP(hipMalloc((void**)&p->ws.partial, sizeof(double) * 2 * kMaxBlocks));
-  hipLaunchKernelGGL(jh_per_init_kernel, dim3(1), dim3(1), 0, 0, p->maxp);
+  JH_LAUNCH(jh_per_init_kernel, dim3(1), dim3(1), 0, 0, p->maxp);
   JH_LAUNCH_CHECK();
   JH_HIP(hipDeviceSynchronize());
   *out = p;
@@ -261,11 +261,11 @@ JH_EXPORT void jh_per_destroy(jh_per* p) {
 
 static int per_apply(jh_per* p, int B, const int64_t* d_idx, int64_t push_start, const void* prio, int prio_dt, int mode,
                      hipStream_t st) {
-  hipLaunchKernelGGL(jh_per_delta_kernel, dim3(1), dim3(256), 0, st, p->tree, p->maxp, B, d_idx, push_start, prio,
+  JH_LAUNCH(jh_per_delta_kernel, dim3(1), dim3(256), 0, st, p->tree, p->maxp, B, d_idx, push_start, prio,
                      prio_dt, mode, p->tree_size, p->N - 1, p->ws.delta);
   JH_LAUNCH_CHECK();
   if (p->depth_max > 0) {
-    hipLaunchKernelGGL(jh_per_climb_kernel, dim3(p->depth_max), dim3(256), 0, st, p->tree, B, d_idx, push_start,
+    JH_LAUNCH(jh_per_climb_kernel, dim3(p->depth_max), dim3(256), 0, st, p->tree, B, d_idx, push_start,
                        p->ws.delta, mode, p->tree_size, p->N - 1);
     JH_LAUNCH_CHECK();
   }
@@ -348,11 +348,11 @@ JH_EXPORT int jh_per_sample(jh_per* p, int64_t B, double beta, int64_t n_uniform
   if (B - n_uniform) memcpy((char*)slab->host + off_u, h_u, sizeof(double) * (size_t)(B - n_uniform));
   int64_t nbl = (B + 255) / 256;
   const int nb = (int)(nbl < kMaxBlocks ? nbl : kMaxBlocks);
-  hipLaunchKernelGGL(jh_per_sample_kernel, dim3(nb), dim3(256), 0, st, p->tree, p->N - 1, B, n_uniform,
+  JH_LAUNCH(jh_per_sample_kernel, dim3(nb), dim3(256), 0, st, p->tree, p->N - 1, B, n_uniform,
                      (const int64_t*)slab->dev, (const double*)((char*)slab->dev + off_u), p->counter, p->usp, beta,
                      d_idx, p->ws.prio, p->ws.w, p->ws.partial);
   JH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(jh_per_norm_kernel, dim3(nb), dim3(256), 0, st, p->tree, B, nb, p->ws.partial, p->ws.w,
+  JH_LAUNCH(jh_per_norm_kernel, dim3(nb), dim3(256), 0, st, p->tree, B, nb, p->ws.partial, p->ws.w,
                      p->counter, d_w64, d_w32, d_stats);
   JH_LAUNCH_CHECK();
   return jh_ctx_slab_release(p->ctx, slab, st);

@@ -75,7 +75,7 @@ JH_EXPORT int jh_gae(jh_ctx* ctx, int32_t W, int32_t T, float gamma, float lambd
                      int32_t standardize, jh_stream stream) {
   JH_ARG(ctx && d_reward && d_done && d_value && d_next_value && d_adv && d_ret);
   JH_ARG(W > 0 && T > 0);
-  hipLaunchKernelGGL(jh_gae_kernel, dim3((W + 3) / 4), dim3(256), 0, jh_s(stream), W, T, gamma, lambda, d_reward, d_done,
+  JH_LAUNCH(jh_gae_kernel, dim3((W + 3) / 4), dim3(256), 0, jh_s(stream), W, T, gamma, lambda, d_reward, d_done,
                      d_value, d_next_value, d_adv, d_ret, standardize);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -165,7 +165,7 @@ JH_EXPORT int jh_logp_discrete(jh_ctx* ctx, int64_t M, int32_t A, const float* d
                                float* d_logp, jh_stream stream) {
   JH_ARG(ctx && d_logits && d_action && d_logp);
   JH_ARG(M > 0 && A > 0);
-  hipLaunchKernelGGL(jh_logp_discrete_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, jh_s(stream), M, A,
+  JH_LAUNCH(jh_logp_discrete_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, jh_s(stream), M, A,
                      d_logits, d_action, d_logp);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -176,7 +176,7 @@ JH_EXPORT int jh_logp_continuous(jh_ctx* ctx, int64_t M, int32_t A, const float*
   JH_ARG(ctx && d_mu_raw && d_log_std_raw && d_action && d_logp);
   JH_ARG(M > 0 && A > 0);
   const int64_t MA = M * A;
-  hipLaunchKernelGGL(jh_logp_continuous_kernel, dim3((unsigned)((MA + 255) / 256)), dim3(256), 0, jh_s(stream), MA,
+  JH_LAUNCH(jh_logp_continuous_kernel, dim3((unsigned)((MA + 255) / 256)), dim3(256), 0, jh_s(stream), MA,
                      d_mu_raw, d_log_std_raw, d_action, d_logp);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -437,7 +437,7 @@ static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
   if (a.B <= 1024) {
     const int threads = ((a.B + 63) / 64) * 64;
     a.nb = 1;
-    hipLaunchKernelGGL(jh_ppo_fused_kernel<CONT>, dim3(1), dim3(threads), 0, st, a);
+    JH_LAUNCH(jh_ppo_fused_kernel<CONT>, dim3(1), dim3(threads), 0, st, a);
     JH_LAUNCH_CHECK();
     return JH_OK;
   }
@@ -446,9 +446,9 @@ static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
   int rc = jh_ctx_scratch(ctx, sizeof(float) * PPO_NPART * (size_t)a.nb, &scratch);
   if (rc) return rc;
   a.partial = (float*)scratch;
-  hipLaunchKernelGGL(jh_ppo_fwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
+  JH_LAUNCH(jh_ppo_fwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
   JH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(jh_ppo_bwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
+  JH_LAUNCH(jh_ppo_bwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }

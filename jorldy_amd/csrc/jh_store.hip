@@ -242,7 +242,7 @@ JH_EXPORT int jh_store_gather(jh_store* s, int64_t B, const int64_t* d_idx, int6
   }
   // memory-bound: cap at 256 CUs x 8 blocks and grid-stride (guide G11)
   const unsigned gx = (unsigned)(max_items < 2048 ? max_items : 2048);
-  hipLaunchKernelGGL(jh_gather_kernel, dim3(gx, n_sel), dim3(256), 0, jh_s(stream), a, B, d_idx, idx_offset, s->capacity);
+  JH_LAUNCH(jh_gather_kernel, dim3(gx, n_sel), dim3(256), 0, jh_s(stream), a, B, d_idx, idx_offset, s->capacity);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }

@@ -19,7 +19,7 @@ _NP_OF = {L.JH_U8: np.uint8, L.JH_F32: np.float32, L.JH_I64: np.int64, L.JH_F64:
 # ----------------------------------------------------------------------------- kernel timing
 # bench.py measures the hand-written kernels live with HIP events recorded on the stream they are
 # launched on (torch's current stream).  Off by default: zero overhead in the product path.
-_PROF = {"on": False, "ev": {}}
+_PROF = {"on": False, "ev": {}, "lib": False}
 
 
 class _timed:
@@ -51,6 +51,23 @@ def profile_collect():
     for name, lst in _PROF["ev"].items():
         ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in lst)
         out[name] = (len(lst), ms, sum(x[2] for x in lst) / len(lst), lst[0][3])
+    return out
+
+
+def lib_profile(enable):
+    """Bracket every kernel launched by libjorldy_hip with HIP events on its launch stream."""
+    _PROF["lib"] = bool(enable)
+    L.check(L.load().jh_prof_enable(int(bool(enable))))
+
+
+def lib_profile_report():
+    """-> {kernel name: (launches, total_ms)} (synchronises the device)."""
+    buf = C.create_string_buffer(1 << 16)
+    L.check(L.load().jh_prof_report(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms = line.split("\t")
+        out[name] = (int(n), float(ms))
     return out
 
 
