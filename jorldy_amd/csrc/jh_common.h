@@ -86,6 +86,46 @@ int jh_ctx_slab(jh_ctx* ctx, size_t bytes, jh_pinned_slab** out);
 int jh_ctx_slab_release(jh_ctx* ctx, jh_pinned_slab* slab, hipStream_t stream);
 int jh_ctx_scratch(jh_ctx* ctx, size_t bytes, void** out);
 
+// ---------------------------------------------------------------- object layouts (shared between TUs)
+struct jh_store {
+  jh_ctx* ctx = nullptr;
+  int64_t capacity = 0;
+  int n_cols = 0;
+  std::vector<jh_col_desc> cols;
+  std::vector<void*> dev;         // device column bases
+  std::vector<size_t> row_bytes;  // bytes per transition per column
+  int64_t index = 0;              // buffer_index
+  int64_t counter = 0;            // buffer_counter
+  // staged push state
+  jh_pinned_slab* staged = nullptr;
+  int64_t staged_n = 0;
+  std::vector<size_t> staged_off;
+};
+
+struct jh_cartpole {
+  int W = 0;
+  std::vector<double> s;  // [W][4]: x, x_dot, theta, theta_dot
+  std::vector<int64_t> t;
+  std::vector<uint64_t> rng;
+};
+
+struct jh_pponet {
+  jh_ctx* ctx = nullptr;
+  int S = 0, H = 0, A = 0, cont = 0, max_rows = 0;
+  int64_t n_params = 0;
+  float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;  // borrowed flat buckets
+  // offsets into the flat buckets (state_dict order)
+  int64_t o_w1, o_b1, o_w2, o_b2, o_wh0, o_bh0, o_wh1, o_bh1, o_wv, o_bv;
+  // owned workspaces
+  float *h1 = nullptr, *h2 = nullptr, *dh1 = nullptr, *dh2 = nullptr;
+  float* g_all = nullptr;     // [max_rows][8] packed head gradients (A-operand of the dW_heads GEMM)
+  float* act_part = nullptr;  // [H/16][max_act_rows][8] per-column-tile partial head outputs (acting)
+  int max_act_rows = 0;
+  float* norm_partial = nullptr;  // [kNormBlocks]
+  float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
+  unsigned long long* rng = nullptr;  // device: acting RNG counter
+};
+
 // ---------------------------------------------------------------- device helpers (wave = 64)
 #ifdef __HIPCC__
 __device__ __forceinline__ float jh_wave_sum(float v) {

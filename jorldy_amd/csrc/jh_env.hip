@@ -8,12 +8,6 @@
 
 #include "jh_common.h"
 
-struct jh_cartpole {
-  int W = 0;
-  std::vector<double> s;  // [W][4]: x, x_dot, theta, theta_dot
-  std::vector<int64_t> t;
-  std::vector<uint64_t> rng;
-};
 
 namespace {
 constexpr double kGrav = 9.8, kMc = 1.0, kMp = 0.1, kLen = 0.5, kFmag = 10.0, kTau = 0.02;

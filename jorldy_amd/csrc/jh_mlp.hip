@@ -1,37 +1,25 @@
 // Native policy-value MLP encoder for the PPO hot path on gfx950 (a23 in SURVEY.md §8a):
 //   S -> H (relu) -> H (relu) -> {A logits | A mu, A log_std} + 1 value
-// (core/network/head.py:6-18 + policy_value.py:8-57), forward, backward, global-norm clip and Adam,
-// all on flat fp32 parameter / gradient / moment buckets laid out in the reference's state_dict
-// order so one RCCL all-reduce covers the whole gradient.
+// (core/network/head.py:6-18 + policy_value.py:8-57): forward, backward, global-norm clip, Adam and
+// batched acting, on flat fp32 parameter / gradient / moment buckets laid out in the reference's
+// state_dict order so one RCCL all-reduce covers the whole gradient.
 //
-// The two H x H contractions per direction are the only dense work of the path; they run on the
-// fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, 157 TFLOP/s chip peak).  At the BASELINE
-// shape (minibatch 256, H = 512: 0.13 GFLOP per GEMM) a GEMM is ~1 us of math, so the design goal is
-// launch count and latency, not tile efficiency: every wave owns one 16x(16*TN) output tile and
-// streams its operands straight from L2 into MFMA fragments (no LDS round trip, no inter-wave
-// sync), 4 independent waves per workgroup, M/16 * N/(16*TN) waves in flight.
-//
-// K-permutation trick: a lane loads 4 consecutive k of its A row / B column as one 16-byte load
-// and feeds element j of both to MFMA step j.  Step j therefore contracts k = 16t + 4*(lane>>4) + j
-// -- a permutation of the K index that is identical for A and B, so the sum is unchanged and every
-// global load is 16 B wide.
+// Every contraction with a dimension >= 16 runs on the fp32-input MFMA (v_mfma_f32_16x16x4_f32:
+// exact fp32, 157 TFLOP/s chip peak).  At the BASELINE shape (minibatch 256, H = 512) one GEMM is
+// 0.13 GFLOP = ~1 us of math, and its operands were just rewritten by Adam (L2-cold: every access
+// pays ~0.4 us), so the kernel is built for LATENCY, not tile efficiency:
+//   * one workgroup per 16x16 output tile, its 4 waves split K (in-workgroup split-K, LDS combine
+//     in fixed wave order -> deterministic): M/16 * N/16 * 4 waves in flight;
+//   * a wave issues ALL loads of a batch of U k-chunks (2*U 16-byte loads per lane) before its
+//     first MFMA: one memory round trip per batch instead of one per chunk;
+//   * K-permutation: a lane loads 4 consecutive k of its A row / B column with one 16-byte load and
+//     feeds element j of both to MFMA step j, i.e. step j contracts k = 16t + 4*(lane>>4) + j -- the
+//     same permutation of K for A and B, so the sum is unchanged and every load is 16 B wide;
+//   * bias gradients (column sums of the upstream gradient) fall out of the A fragments as row
+//     sums, so they cost no extra pass.
 #include "jh_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct jh_pponet {
-  jh_ctx* ctx = nullptr;
-  int S = 0, H = 0, A = 0, cont = 0, max_rows = 0;
-  int64_t n_params = 0;
-  float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;  // borrowed flat buckets
-  // offsets into the flat buckets (state_dict order)
-  int64_t o_w1, o_b1, o_w2, o_b2, o_wh0, o_bh0, o_wh1, o_bh1, o_wv, o_bv;
-  // owned workspaces
-  float *h1 = nullptr, *h2 = nullptr, *dh1 = nullptr, *dh2 = nullptr;
-  float* norm_partial = nullptr;  // [kNormBlocks]
-  float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
-  unsigned long long* rng = nullptr;  // device: acting RNG counter
-};
 
 namespace {
 constexpr int kNormBlocks = 256;
@@ -55,90 +43,182 @@ __global__ void __launch_bounds__(256) jh_mlp_l1_kernel(int B, int S, int H, con
 }
 
 // ============================================================================ MFMA GEMM
-// C[M][N] = A(m,k) * B(k,n), epilogue EPI.  Layout flags:
-//   A_KCONT: A stored [M][K] (k contiguous)  else stored [K][M] (m contiguous)
-//   B_KCONT: B stored [N][K] (k contiguous)  else stored [K][N] (n contiguous)
-// One wave per 16 x (16*TN) tile, 4 waves per workgroup laid out along N.
-enum { EPI_BIAS_RELU = 0, EPI_MASK = 1, EPI_NONE = 2 };
+// C[M][N] = A(m,k) * B(k,n).
+//   A_MODE 0: A stored [M][K] (k contiguous)           1: A stored [K][M] (m contiguous)
+//          2: A(m,k) = relu(b1[k] + sum_s x[r(m)][s] * W1[k][s])  (layer 1 generated on the fly)
+//   B_KCONT : B stored [N][K] (k contiguous)  else stored [K][N] (n contiguous, optional row gather)
+enum { EPI_BIAS_RELU = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_ROWPTR = 3, EPI_HEADPART = 4 };
 
-template <bool A_KCONT, bool B_KCONT, int TN, int EPI>
-__global__ void __launch_bounds__(256) jh_gemm16_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ Bm, int ldb, float* __restrict__ C,
-                                                        int ldc, const float* __restrict__ aux, int ldaux) {
+struct GemmArgs {
+  int M, N, K;
+  const float* A;
+  int lda;
+  const float* B;
+  int ldb;
+  const int64_t* b_rows;  // !B_KCONT: B(k,n) = B[b_rows[k]*ldb + n] when non-null
+  float* C;
+  int ldc;
+  const float* aux;  // bias[n] (BIAS_RELU / HEADPART) | forward activation for the relu mask (MASK)
+  int ldaux;
+  float* rowptr[8];  // ROWPTR: row m of C lives at rowptr[m] (+ n); M <= 8
+  float* rowsum;     // ROWSUM: rowsum[m] = sum_k A(m,k)   (bias gradients)
+  float* rowsum_ptr[8];
+  // A_MODE 2
+  const float* x;
+  const int64_t* x_rows;
+  const float* W1;
+  const float* b1;
+  int S;
+  // HEADPART: per-tile partial head outputs part[tile_n][row][8] = sum_{n in tile} h2[row][n]*Wh[o][n]
+  const float* wh[8];
+  int n_out;
+  float* part;
+  int part_rows;
+};
+
+template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int U>
+__global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
+  __shared__ float s_acc[4][64][4];
+  __shared__ float s_rs[4][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int tiles_n = (N + 16 * TN - 1) / (16 * TN);
-  const int tile = blockIdx.x * 4 + wid;
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * 16, n0 = tn * 16 * TN;
-  if (m0 >= M) return;
+  const int tiles_n = (g.N + 15) / 16;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * 16, n0 = tn * 16;
   const int r = lane & 15, kq = lane >> 4;
-  f32x4 acc[TN];
+  // this wave's K range (multiple of 16 long)
+  const int kper = ((g.K + 63) / 64) * 16;
+  const int kbeg = wid * kper;
+  const int kend = kbeg + kper < g.K ? kbeg + kper : g.K;
+  const int m = m0 + r, n = n0 + r;
+  const bool m_ok = m < g.M, n_ok = n < g.N;
+  const int mc = m_ok ? m : g.M - 1, nc = n_ok ? n : g.N - 1;  // clamped: loads stay in bounds
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rs = 0.f;
+  int64_t xrow = 0;
+  if (A_MODE == 2) xrow = g.x_rows ? g.x_rows[mc] : (int64_t)mc;
+
+  for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
+    float a[U][4], b[U][4];
+    // ---- issue every load of the batch first
 #pragma unroll
-  for (int t = 0; t < TN; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool m_ok = (m0 + r) < M;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    const int kb = k0 + 4 * kq;
-    float a[4];
-    if (A_KCONT) {
-      if (m_ok && kb + 3 < K) {
-        const float4 v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + kb);
-        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-      } else {
+    for (int u = 0; u < U; ++u) {
+      const int kb = k0 + 16 * u + 4 * kq;
+      if (A_MODE == 0) {
+        const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
+        const float4 v = *reinterpret_cast<const float4*>(g.A + (size_t)mc * g.lda + kc);
+        const bool ok = m_ok && kb < kend;  // K % 4 == 0 for k-contiguous operands
+        a[u][0] = ok ? v.x : 0.f; a[u][1] = ok ? v.y : 0.f; a[u][2] = ok ? v.z : 0.f; a[u][3] = ok ? v.w : 0.f;
+      } else if (A_MODE == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = (m_ok && kb + j < K) ? A[(size_t)(m0 + r) * lda + kb + j] : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = (m_ok && kb + j < K) ? A[(size_t)(kb + j) * lda + m0 + r] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      const int n = n0 + 16 * t + r;
-      const bool n_ok = n < N;
-      float b[4];
-      if (B_KCONT) {
-        if (n_ok && kb + 3 < K) {
-          const float4 v = *reinterpret_cast<const float4*>(Bm + (size_t)n * ldb + kb);
-          b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b[j] = (n_ok && kb + j < K) ? Bm[(size_t)n * ldb + kb + j] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const int k = kb + j;
+          const int kc = k < g.K ? k : g.K - 1;
+          const float v = g.A[(size_t)kc * g.lda + mc];
+          a[u][j] = (m_ok && k < kend) ? v : 0.f;
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = (n_ok && kb + j < K) ? Bm[(size_t)(kb + j) * ldb + n] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const int k = kb + j;
+          const int kc = k < g.K ? k : g.K - 1;
+          float s = g.b1[kc];
+          const float* w = g.W1 + (size_t)kc * g.S;
+          const float* xr = g.x + xrow * g.S;
+          for (int q = 0; q < g.S; ++q) s = fmaf(xr[q], w[q], s);
+          a[u][j] = (m_ok && k < kend && s > 0.f) ? s : 0.f;
+        }
       }
+      if (B_KCONT) {
+        const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
+        const float4 v = *reinterpret_cast<const float4*>(g.B + (size_t)nc * g.ldb + kc);
+        const bool ok = n_ok && kb < kend;
+        b[u][0] = ok ? v.x : 0.f; b[u][1] = ok ? v.y : 0.f; b[u][2] = ok ? v.z : 0.f; b[u][3] = ok ? v.w : 0.f;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[t], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          const int k = kb + j;
+          const int kc = k < g.K ? k : g.K - 1;
+          const int64_t row = g.b_rows ? g.b_rows[kc] : (int64_t)kc;
+          const float v = g.B[(size_t)row * g.ldb + nc];
+          b[u][j] = (n_ok && k < kend) ? v : 0.f;
+        }
+      }
+    }
+    // ---- then the MFMAs
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][j], acc, 0, 0, 0);
+        if (ROWSUM) rs += a[u][j];
+      }
+    }
+  }
+  // ---- in-workgroup split-K combine (fixed order)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s_acc[wid][lane][i] = acc[i];
+  if (ROWSUM) s_rs[wid][lane] = rs;
+  __syncthreads();
+  if (wid != 0) return;
+  float c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = ((s_acc[0][lane][i] + s_acc[1][lane][i]) + s_acc[2][lane][i]) + s_acc[3][lane][i];
+  if (ROWSUM && tn == 0) {
+    float t = ((s_rs[0][lane] + s_rs[1][lane]) + s_rs[2][lane]) + s_rs[3][lane];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (kq == 0 && m_ok) {
+      if (EPI == EPI_ROWPTR) *g.rowsum_ptr[m] = t;
+      else g.rowsum[m] = t;
     }
   }
   // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float hv[4];
 #pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const int n = n0 + 16 * t + r;
-    if (n >= N) continue;
+  for (int i = 0; i < 4; ++i) {
+    const int mm = m0 + kq * 4 + i;
+    float v = c[i];
+    if (EPI == EPI_BIAS_RELU || EPI == EPI_HEADPART) {
+      v += g.aux[nc];
+      v = v > 0.f ? v : 0.f;
+    } else if (EPI == EPI_MASK) {
+      const int mmc = mm < g.M ? mm : g.M - 1;
+      v = g.aux[(size_t)mmc * g.ldaux + nc] > 0.f ? v : 0.f;  // relu'(h) of the forward activation
+    }
+    hv[i] = (n_ok && mm < g.M) ? v : 0.f;
+    if (!n_ok || mm >= g.M) continue;
+    if (EPI == EPI_ROWPTR) g.rowptr[mm][n] = v;
+    else if (EPI != EPI_HEADPART) g.C[(size_t)mm * g.ldc + n] = v;
+  }
+  if (EPI == EPI_HEADPART) {
+    // partial head outputs of this 16-column tile: reduce over the 16 lanes that share kq
+    for (int o = 0; o < g.n_out; ++o) {
+      const float w = n_ok ? g.wh[o][n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + kq * 4 + i;
-      if (m >= M) continue;
-      float v = acc[t][i];
-      if (EPI == EPI_BIAS_RELU) {
-        v += aux[n];
-        v = v > 0.f ? v : 0.f;
-      } else if (EPI == EPI_MASK) {
-        v = aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;  // relu'(h) of the forward activation
+      for (int i = 0; i < 4; ++i) {
+        float p = hv[i] * w;
+        p += __shfl_xor(p, 1, 64);
+        p += __shfl_xor(p, 2, 64);
+        p += __shfl_xor(p, 4, 64);
+        p += __shfl_xor(p, 8, 64);
+        const int mm = m0 + kq * 4 + i;
+        if (r == 0 && mm < g.M) g.part[((size_t)tn * g.part_rows + mm) * 8 + o] = p;
       }
-      C[(size_t)m * ldc + n] = v;
     }
   }
 }
 
-template <bool A_KCONT, bool B_KCONT, int TN, int EPI>
-static int launch_gemm(const char* name, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                       const float* aux, int ldaux, hipStream_t st) {
-  const int tiles = ((M + 15) / 16) * ((N + 16 * TN - 1) / (16 * TN));
-  JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_KCONT, B_KCONT, TN, EPI>), dim3((tiles + 3) / 4), dim3(256), 0, st, M, N, K, A,
-                     lda, B, ldb, C, ldc, aux, ldaux);
+template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM>
+static int launch_gemm(const char* name, const GemmArgs& g, hipStream_t st) {
+  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+  const int kper = ((g.K + 63) / 64) * 16;  // per-wave K range
+  if (kper > 64) {
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 8>), dim3(tiles), dim3(256), 0, st, g);
+  } else if (kper > 32) {
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 4>), dim3(tiles), dim3(256), 0, st, g);
+  } else {
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 2>), dim3(tiles), dim3(256), 0, st, g);
+  }
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
@@ -149,16 +229,8 @@ struct HeadPtrs {
   const float* b[3];
   float* out[3];      // [B][n_i]
   const float* g[3];  // upstream grads (backward)
-  float* dw[3];
-  float* db[3];
   int n[3];
   int groups;
-  // flattened view over all head outputs (<= 8) for kernels that keep one accumulator per output
-  const float* fg[8];  // upstream grad column base (element [b] at fg[o][b * fld[o]])
-  int fld[8];
-  float* fdw[8];       // weight-grad row of output o
-  float* fdb[8];
-  int n_out;
 };
 
 // forward: one wave per row; lanes split H, one shuffle reduction per output
@@ -185,88 +257,25 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, con
   }
 }
 
-// backward part 1: dh2[b][k] = relu'(h2[b][k]) * sum_o g[b][o] * Wh[o][k]
+// backward: dh2[b][k] = relu'(h2[b][k]) * sum_o g[b][o] * Wh[o][k]; lanes k < 8 of each row also pack
+// the head gradients into g_all[b][8] (the A operand of the head-weight-gradient GEMM).
 __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, const float* __restrict__ h2,
-                                                                  float* __restrict__ dh2, HeadPtrs hp) {
+                                                                  float* __restrict__ dh2, float* __restrict__ g_all,
+                                                                  HeadPtrs hp) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)B * H) return;
   const int b = (int)(i / H), k = (int)(i - (int64_t)b * H);
   float acc = 0.f;
+  int o_flat = 0;
+  float mine = 0.f;
   for (int g = 0; g < hp.groups; ++g)
-    for (int o = 0; o < hp.n[g]; ++o) acc = fmaf(hp.g[g][(size_t)b * hp.n[g] + o], hp.w[g][(size_t)o * H + k], acc);
+    for (int o = 0; o < hp.n[g]; ++o, ++o_flat) {
+      const float gv = hp.g[g][(size_t)b * hp.n[g] + o];
+      acc = fmaf(gv, hp.w[g][(size_t)o * H + k], acc);
+      if (o_flat == k) mine = gv;
+    }
   dh2[i] = h2[i] > 0.f ? acc : 0.f;
-}
-
-// backward part 2: head weight/bias grads + the column sums that are the bias grads of layers 1, 2:
-//   dWh[o][k] = sum_b g[b][o] h2[b][k] ; dbh[o] = sum_b g[b][o] ; db2[k] = sum_b dh2[b][k]
-// grid: one workgroup per 64 columns k; 256 threads = 64 columns x 4 batch slices, LDS combine.
-__global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dw_kernel(int B, int H, const float* __restrict__ h2,
-                                                                  const float* __restrict__ dh2, float* __restrict__ db2,
-                                                                  HeadPtrs hp) {
-  __shared__ float s_acc[4][64][9];  // up to 8 head outputs + db2
-  const int kc = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + kc;
-  float acc[9];
-#pragma unroll
-  for (int o = 0; o < 9; ++o) acc[o] = 0.f;
-  if (k < H) {
-    for (int b = sl; b < B; b += 4) {
-      const float hv = h2[(size_t)b * H + k];
-#pragma unroll
-      for (int o = 0; o < 8; ++o)  // static indices: acc[] stays in registers
-        if (o < hp.n_out) acc[o] = fmaf(hp.fg[o][(size_t)b * hp.fld[o]], hv, acc[o]);
-      acc[8] += dh2[(size_t)b * H + k];
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < 9; ++o) s_acc[sl][kc][o] = acc[o];
-  __syncthreads();
-  if (sl == 0 && k < H) {
-#pragma unroll
-    for (int o = 0; o < 8; ++o)
-      if (o < hp.n_out) hp.fdw[o][k] = s_acc[0][kc][o] + s_acc[1][kc][o] + s_acc[2][kc][o] + s_acc[3][kc][o];
-    db2[k] = s_acc[0][kc][8] + s_acc[1][kc][8] + s_acc[2][kc][8] + s_acc[3][kc][8];
-  }
-  // bias grads of the heads: workgroup 0, first wave
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
-    for (int o = 0; o < hp.n_out; ++o) {
-      float sum = 0.f;
-      for (int b = threadIdx.x; b < B; b += 64) sum += hp.fg[o][(size_t)b * hp.fld[o]];
-      sum = jh_wave_sum(sum);
-      if (threadIdx.x == 0) *hp.fdb[o] = sum;
-    }
-  }
-}
-
-// layer-1 backward: dW1[j][s] = sum_b dh1[b][j] x[r(b)][s] ; db1[j] = sum_b dh1[b][j]
-// one workgroup per 64 hidden units j; 4 batch slices combined through LDS.
-__global__ void __launch_bounds__(256) jh_mlp_l1_bwd_kernel(int B, int S, int H, const float* __restrict__ x,
-                                                            const int64_t* __restrict__ idx,
-                                                            const float* __restrict__ dh1, float* __restrict__ dW1,
-                                                            float* __restrict__ db1) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4][64][S+1]
-  const int jc = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + jc;
-  float* mine = smem + ((size_t)sl * 64 + jc) * (S + 1);
-  for (int s = 0; s <= S; ++s) mine[s] = 0.f;
-  if (j < H) {
-    for (int b = sl; b < B; b += 4) {
-      const float d = dh1[(size_t)b * H + j];
-      const int64_t r = idx ? idx[b] : (int64_t)b;
-      const float* xr = x + r * S;
-      for (int s = 0; s < S; ++s) mine[s] = fmaf(d, xr[s], mine[s]);
-      mine[S] += d;
-    }
-  }
-  __syncthreads();
-  if (sl == 0 && j < H) {
-    for (int s = 0; s <= S; ++s) {
-      const float t = smem[((size_t)0 * 64 + jc) * (S + 1) + s] + smem[((size_t)1 * 64 + jc) * (S + 1) + s] +
-                      smem[((size_t)2 * 64 + jc) * (S + 1) + s] + smem[((size_t)3 * 64 + jc) * (S + 1) + s];
-      if (s < S) dW1[(size_t)j * S + s] = t;
-      else db1[j] = t;
-    }
-  }
+  if (k < 8) g_all[(size_t)b * 8 + k] = mine;  // zero for k >= number of head outputs
 }
 
 // ============================================================================ clip_grad_norm_ + Adam
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * coef;
-    g[i] = gi;                                    // clip is in place, like the reference
+    g[i] = gi;                                         // clip is in place, like the reference
     const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // exp_avg.lerp_(grad, 1-beta1)
     const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -314,9 +323,10 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
 }
 
 // ============================================================================ acting
-// softmax + inverse-CDF multinomial on the logits of W rows (W small): one lane per env.
-// Counter-based RNG (splitmix64 of (seed, counter, env)); the counter lives in device memory so a
-// captured graph can be replayed.
+// Stage 2 of the fused acting path: sum the per-column-tile partial head outputs in tile order,
+// add the bias, softmax + inverse-CDF multinomial (argmax when greedy).  Counter-based RNG
+// (splitmix64 of (seed, counter, env)); the counter lives in device memory so a captured graph
+// can be replayed.  ONE workgroup: every lane reads the counter, lane 0 advances it at the end.
 __device__ __forceinline__ float u01_from(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -325,33 +335,68 @@ __device__ __forceinline__ float u01_from(unsigned long long x) {
   return (float)(x >> 40) * (1.0f / 16777216.0f);
 }
 
-__global__ void __launch_bounds__(1024) jh_sample_discrete_kernel(int W, int A, const float* __restrict__ logits,
-                                                                  unsigned long long* __restrict__ rng,
-                                                                  int64_t* __restrict__ action, int greedy) {
-  // ONE workgroup: every lane reads the counter, then lane 0 advances it after the barrier
-  const unsigned long long ctr = rng[0], seed = rng[1];
-  for (int w = threadIdx.x; w < W; w += blockDim.x) {
-    const float* z = logits + (size_t)w * A;
+struct ActArgs {
+  int W, A, tiles_n, part_rows;
+  const float* part;     // [tiles_n][part_rows][8]
+  const float* bias[8];  // bias of flat head output o
+  unsigned long long* rng;
+  int64_t* action;    // [W] (may be device-mapped pinned host memory)
+  float* logits_out;  // optional [W][A]
+  float* value_out;   // optional [W]
+  int greedy;
+};
+
+__global__ void __launch_bounds__(1024) jh_act_sample_kernel(ActArgs a) {
+  const unsigned long long ctr = a.rng[0], seed = a.rng[1];
+  for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
+    float z[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float s = 0.f;
+      if (o <= a.A) {
+        for (int t = 0; t < a.tiles_n; ++t) s += a.part[((size_t)t * a.part_rows + w) * 8 + o];
+        s += *a.bias[o];
+      }
+      z[o] = s;
+    }
     float mx = z[0];
     int arg = 0;
-    for (int k = 1; k < A; ++k)
-      if (z[k] > mx) { mx = z[k]; arg = k; }
-    int a = arg;
-    if (!greedy) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (k < a.A && z[k] > mx) { mx = z[k]; arg = k; }
+    int act = arg;
+    if (!a.greedy) {
       float se = 0.f;
-      for (int k = 0; k < A; ++k) se += expf(z[k] - mx);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) se += k < a.A ? expf(z[k] - mx) : 0.f;
       const float u = u01_from(seed * 0x100000001B3ull + ctr * 0x9E3779B97F4A7C15ull + (unsigned long long)w) * se;
       float c = 0.f;
-      a = A - 1;
-      for (int k = 0; k < A; ++k) {
-        c += expf(z[k] - mx);
-        if (u < c) { a = k; break; }
+      act = a.A - 1;
+      bool found = false;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < a.A && !found) {
+          c += expf(z[k] - mx);
+          if (u < c) { act = k; found = true; }
+        }
       }
     }
-    action[w] = a;
+    a.action[w] = act;
+    if (a.logits_out) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < a.A) a.logits_out[(size_t)w * a.A + k] = z[k];
+    }
+    if (a.value_out) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k == a.A) v = z[k];
+      a.value_out[w] = v;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) rng[0] = ctr + 1;
+  if (threadIdx.x == 0) a.rng[0] = ctr + 1;
 }
 
 // ============================================================================ host API
@@ -398,6 +443,9 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   JH_HIP(hipMalloc((void**)&n->h2, act));
   JH_HIP(hipMalloc((void**)&n->dh1, act));
   JH_HIP(hipMalloc((void**)&n->dh2, act));
+  JH_HIP(hipMalloc((void**)&n->g_all, sizeof(float) * 8 * (size_t)max_rows));
+  n->max_act_rows = max_rows < 1024 ? max_rows : 1024;
+  JH_HIP(hipMalloc((void**)&n->act_part, sizeof(float) * 8 * (size_t)n->max_act_rows * (size_t)(H / 16)));
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
   JH_HIP(hipMalloc((void**)&n->rng, sizeof(unsigned long long) * 2));
@@ -414,6 +462,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipSetDevice(n->ctx->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(n->h1); (void)hipFree(n->h2); (void)hipFree(n->dh1); (void)hipFree(n->dh2);
+  (void)hipFree(n->g_all); (void)hipFree(n->act_part);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper); (void)hipFree(n->rng);
   delete n;
 }
@@ -445,25 +494,29 @@ static HeadPtrs head_ptrs(jh_pponet* n, float* out0, float* out1, float* outv, c
                           const float* gv) {
   HeadPtrs hp{};
   int g = 0;
-  hp.w[g] = n->params + n->o_wh0; hp.b[g] = n->params + n->o_bh0; hp.out[g] = out0; hp.g[g] = g0;
-  hp.dw[g] = n->grads + n->o_wh0; hp.db[g] = n->grads + n->o_bh0; hp.n[g] = n->A; ++g;
+  hp.w[g] = n->params + n->o_wh0; hp.b[g] = n->params + n->o_bh0; hp.out[g] = out0; hp.g[g] = g0; hp.n[g] = n->A; ++g;
   if (n->cont) {
-    hp.w[g] = n->params + n->o_wh1; hp.b[g] = n->params + n->o_bh1; hp.out[g] = out1; hp.g[g] = g1;
-    hp.dw[g] = n->grads + n->o_wh1; hp.db[g] = n->grads + n->o_bh1; hp.n[g] = n->A; ++g;
+    hp.w[g] = n->params + n->o_wh1; hp.b[g] = n->params + n->o_bh1; hp.out[g] = out1; hp.g[g] = g1; hp.n[g] = n->A; ++g;
   }
-  hp.w[g] = n->params + n->o_wv; hp.b[g] = n->params + n->o_bv; hp.out[g] = outv; hp.g[g] = gv;
-  hp.dw[g] = n->grads + n->o_wv; hp.db[g] = n->grads + n->o_bv; hp.n[g] = 1; ++g;
+  hp.w[g] = n->params + n->o_wv; hp.b[g] = n->params + n->o_bv; hp.out[g] = outv; hp.g[g] = gv; hp.n[g] = 1; ++g;
   hp.groups = g;
-  int o = 0;
-  for (int q = 0; q < g; ++q)
-    for (int c = 0; c < hp.n[q]; ++c, ++o) {
-      hp.fg[o] = hp.g[q] ? hp.g[q] + c : nullptr;
-      hp.fld[o] = hp.n[q];
-      hp.fdw[o] = hp.dw[q] + (size_t)c * n->H;
-      hp.fdb[o] = hp.db[q] + c;
-    }
-  hp.n_out = o;
   return hp;
+}
+
+// Flat list of head outputs: weight row / weight-grad row / bias / bias-grad of output o.
+static int head_rows(jh_pponet* n, const float* w[8], float* dw[8], const float* b[8], float* db[8]) {
+  int o = 0;
+  for (int a = 0; a < n->A; ++a, ++o) {
+    w[o] = n->params + n->o_wh0 + (int64_t)a * n->H; dw[o] = n->grads + n->o_wh0 + (int64_t)a * n->H;
+    b[o] = n->params + n->o_bh0 + a; db[o] = n->grads + n->o_bh0 + a;
+  }
+  if (n->cont)
+    for (int a = 0; a < n->A; ++a, ++o) {
+      w[o] = n->params + n->o_wh1 + (int64_t)a * n->H; dw[o] = n->grads + n->o_wh1 + (int64_t)a * n->H;
+      b[o] = n->params + n->o_bh1 + a; db[o] = n->grads + n->o_bh1 + a;
+    }
+  w[o] = n->params + n->o_wv; dw[o] = n->grads + n->o_wv; b[o] = n->params + n->o_bv; db[o] = n->grads + n->o_bv;
+  return o + 1;
 }
 
 // x: [*, S] rows (device, or pinned host memory mapped into the device address space), gathered
@@ -477,10 +530,12 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   const int H = n->H;
   const int64_t bh = (int64_t)B * H;
   JH_LAUNCH(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, H, d_x, d_idx,
-                     n->params + n->o_w1, n->params + n->o_b1, n->h1);
+            n->params + n->o_w1, n->params + n->o_b1, n->h1);
   JH_LAUNCH_CHECK();
-  int rc = launch_gemm<true, true, 1, EPI_BIAS_RELU>("jh_gemm16_fwd_h2", B, H, H, n->h1, H, n->params + n->o_w2, H, n->h2, H,
-                                                     n->params + n->o_b2, 0, st);
+  GemmArgs g{};
+  g.M = B; g.N = H; g.K = H; g.A = n->h1; g.lda = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->h2; g.ldc = H;
+  g.aux = n->params + n->o_b2;
+  int rc = launch_gemm<0, true, EPI_BIAS_RELU, false>("jh_gemm16_fwd_h2", g, st);
   if (rc) return rc;
   HeadPtrs hp = head_ptrs(n, d_head0, d_head1, d_value, nullptr, nullptr, nullptr);
   JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp);
@@ -499,21 +554,40 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
   const int H = n->H, S = n->S;
   const int64_t bh = (int64_t)B * H;
   HeadPtrs hp = head_ptrs(n, nullptr, nullptr, nullptr, d_g_head0, d_g_head1, d_g_value);
-  JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, H, n->h2,
-                     n->dh2, hp);
+  JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
+            n->g_all, hp);
   JH_LAUNCH_CHECK();
-  JH_LAUNCH(jh_mlp_heads_bwd_dw_kernel, dim3((H + 63) / 64), dim3(256), 0, st, B, H, n->h2, n->dh2,
-                     n->grads + n->o_b2, hp);
-  JH_LAUNCH_CHECK();
-  // dW2[o][i] = sum_b dh2[b][o] * h1[b][i]     (A = dh2^T: stored [K=B][M=H]; B = h1: stored [K=B][N=H])
-  int rc = launch_gemm<false, false, 2, EPI_NONE>("jh_gemm16_bwd_dW2", H, H, B, n->dh2, H, n->h1, H, n->grads + n->o_w2, H, nullptr, 0, st);
-  if (rc) return rc;
-  // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] * W2[o][i]   (A = dh2 [M=B][K=H]; B = W2 stored [K=H_out][N=H_in])
-  rc = launch_gemm<true, false, 1, EPI_MASK>("jh_gemm16_bwd_dh1", B, H, H, n->dh2, H, n->params + n->o_w2, H, n->dh1, H, n->h1, H, st);
-  if (rc) return rc;
-  JH_LAUNCH(jh_mlp_l1_bwd_kernel, dim3((H + 63) / 64), dim3(256), sizeof(float) * 4 * 64 * (size_t)(S + 1), st,
-                     B, S, H, d_x, d_idx, n->dh1, n->grads + n->o_w1, n->grads + n->o_b1);
-  JH_LAUNCH_CHECK();
+  const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
+  const int n_out = head_rows(n, w, dw, b, db);
+  int rc;
+  {  // dWh[o][k] = sum_b g[b][o] h2[b][k] ; dbh[o] = sum_b g[b][o]      (A = g_all^T stored [K=B][8])
+    GemmArgs g{};
+    g.M = n_out; g.N = H; g.K = B; g.A = n->g_all; g.lda = 8; g.B = n->h2; g.ldb = H;
+    for (int o = 0; o < n_out; ++o) { g.rowptr[o] = dw[o]; g.rowsum_ptr[o] = db[o]; }
+    rc = launch_gemm<1, false, EPI_ROWPTR, true>("jh_gemm16_bwd_dWheads", g, st);
+    if (rc) return rc;
+  }
+  {  // dW2[o][i] = sum_b dh2[b][o] h1[b][i] ; db2[o] = sum_b dh2[b][o]  (A = dh2^T stored [K=B][M=H])
+    GemmArgs g{};
+    g.M = H; g.N = H; g.K = B; g.A = n->dh2; g.lda = H; g.B = n->h1; g.ldb = H; g.C = n->grads + n->o_w2; g.ldc = H;
+    g.rowsum = n->grads + n->o_b2;
+    rc = launch_gemm<1, false, EPI_NONE, true>("jh_gemm16_bwd_dW2", g, st);
+    if (rc) return rc;
+  }
+  {  // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]                 (B = W2 stored [K=H_out][N=H_in])
+    GemmArgs g{};
+    g.M = B; g.N = H; g.K = H; g.A = n->dh2; g.lda = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->dh1; g.ldc = H;
+    g.aux = n->h1; g.ldaux = H;
+    rc = launch_gemm<0, false, EPI_MASK, false>("jh_gemm16_bwd_dh1", g, st);
+    if (rc) return rc;
+  }
+  {  // dW1[j][s] = sum_b dh1[b][j] x[r(b)][s] ; db1[j] = sum_b dh1[b][j]  (B = gathered x rows [K=B][N=S])
+    GemmArgs g{};
+    g.M = H; g.N = S; g.K = B; g.A = n->dh1; g.lda = H; g.B = d_x; g.ldb = S; g.b_rows = d_idx;
+    g.C = n->grads + n->o_w1; g.ldc = S; g.rowsum = n->grads + n->o_b1;
+    rc = launch_gemm<1, false, EPI_NONE, true>("jh_gemm16_bwd_dW1", g, st);
+    if (rc) return rc;
+  }
   return JH_OK;
 }
 
@@ -522,26 +596,41 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
 JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_out, jh_stream stream) {
   JH_ARG(n != nullptr);
   hipStream_t st = jh_s(stream);
-  JH_LAUNCH(jh_gradnorm_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial,
-                     n->hyper);
+  JH_LAUNCH(jh_gradnorm_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial, n->hyper);
   JH_LAUNCH_CHECK();
   JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
-                     n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out);
+            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
 
-// Batched acting for W envs: forward + softmax + multinomial (greedy when training == 0).
+// Batched acting for W envs (PPO.act, ppo.py:55-69, discrete) in TWO launches:
+//   1. GEMM with layer 1 generated on the fly as the A operand, h2 kept in registers, epilogue
+//      reduces each 16-column tile against the head weights -> partial head outputs;
+//   2. one workgroup sums the partials in tile order, adds the biases, softmax + multinomial.
 // d_obs / d_action may be pinned host memory mapped into the device address space.
 JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action,
-                                     float* d_logits_ws, float* d_value_ws, int32_t training, jh_stream stream) {
-  JH_ARG(n && d_obs && d_action && d_logits_ws && d_value_ws);
+                                     float* d_logits_out, float* d_value_out, int32_t training, jh_stream stream) {
+  JH_ARG(n && d_obs && d_action);
   JH_ARG(!n->cont);
-  int rc = jh_pponet_forward(n, W, d_obs, nullptr, d_logits_ws, nullptr, d_value_ws, stream);
+  JH_ARG(W > 0 && W <= n->max_act_rows);
+  hipStream_t st = jh_s(stream);
+  const int H = n->H;
+  const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
+  const int n_out = head_rows(n, w, dw, b, db);
+  GemmArgs g{};
+  g.M = W; g.N = H; g.K = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = nullptr; g.aux = n->params + n->o_b2;
+  g.x = d_obs; g.x_rows = nullptr; g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.S = n->S;
+  for (int o = 0; o < n_out; ++o) g.wh[o] = w[o];
+  g.n_out = n_out; g.part = n->act_part; g.part_rows = n->max_act_rows;
+  int rc = launch_gemm<2, true, EPI_HEADPART, false>("jh_gemm16_act_fused", g, st);
   if (rc) return rc;
+  ActArgs a{};
+  a.W = W; a.A = n->A; a.tiles_n = H / 16; a.part_rows = n->max_act_rows; a.part = n->act_part;
+  for (int o = 0; o < n_out; ++o) a.bias[o] = b[o];
+  a.rng = n->rng; a.action = d_action; a.logits_out = d_logits_out; a.value_out = d_value_out; a.greedy = training ? 0 : 1;
   const int threads = W >= 1024 ? 1024 : ((W + 63) / 64) * 64;
-  JH_LAUNCH(jh_sample_discrete_kernel, dim3(1), dim3(threads), 0, jh_s(stream), W, n->A, d_logits_ws, n->rng,
-                     d_action, training ? 0 : 1);
+  JH_LAUNCH(jh_act_sample_kernel, dim3(1), dim3(threads), 0, st, a);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }

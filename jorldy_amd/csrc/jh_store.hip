@@ -3,20 +3,6 @@
 // Replaces core/buffer/replay_buffer.py:8-35, rollout_buffer.py:6-24, base.py:42-56.
 #include "jh_common.h"
 
-struct jh_store {
-  jh_ctx* ctx = nullptr;
-  int64_t capacity = 0;
-  int n_cols = 0;
-  std::vector<jh_col_desc> cols;
-  std::vector<void*> dev;         // device column bases
-  std::vector<size_t> row_bytes;  // bytes per transition per column
-  int64_t index = 0;              // buffer_index
-  int64_t counter = 0;            // buffer_counter
-  // staged push state
-  jh_pinned_slab* staged = nullptr;
-  int64_t staged_n = 0;
-  std::vector<size_t> staged_off;
-};
 
 JH_EXPORT int jh_store_create(jh_ctx* ctx, int64_t capacity, int32_t n_cols, const jh_col_desc* cols, jh_store** out) {
   JH_ARG(ctx && out && cols);
