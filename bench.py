@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-baseline-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--python-collector", action="store_true", help="per-timestep Python loop instead of jh_collector_run")
     return ap.parse_args()
 
 
@@ -102,7 +103,7 @@ def main():
 
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
-    from jorldy_amd.manager import VecCollector
+    from jorldy_amd.manager import NativeCollector, VecCollector
     from jorldy_amd.parallel import make_grad_sync
 
     W, T = args.workers, 128
@@ -116,7 +117,7 @@ def main():
     if world > 1:
         agent.grad_sync = make_grad_sync(agent.network, dist)
     env = ops.CartPoleVec(W, seed=100 + rank)
-    collector = VecCollector(env, agent, W)
+    collector = (VecCollector if args.python_collector or agent.backend != "native" else NativeCollector)(env, agent, W)
 
     step = 0
 
@@ -165,7 +166,7 @@ def main():
         "config": {"workload": "config.ppo.cartpole --sync --train.num_workers 8 (BASELINE.json configs[1]): synthetic CartPole-v1, "
                                "W=8 x T=128 = 1024 transitions/iteration/GPU, MLP 4-512-512-{2,1}, 3 epochs x 4 minibatches of 256",
                    "workers_per_gpu": W, "n_step": T, "batch_size": 256, "n_epoch": 3, "parallelism": f"dp{world}",
-                   "backend": agent.backend, "hipgraph": bool(agent._graph is not None)},
+                   "backend": agent.backend, "hipgraph": bool(agent._graph is not None), "collector": type(collector).__name__},
         "learner_updates_per_s": world * n_updates * args.steps / dt,
         "last_result": {k: float(v) for k, v in result.items()},
     }

@@ -243,6 +243,18 @@ int jh_cartpole_obs(const jh_cartpole* e, float* h_obs /* [W][4] */);
 int jh_cartpole_step(jh_cartpole* e, const int64_t* h_action /* [W] */, float* h_next_obs /* [W][4] */,
                      float* h_reward /* [W] */, uint8_t* h_done /* [W] */);
 
+/* ------------------------------------------------------------------ native sync collector
+ * DistributedManager.run + Actor.run (manager/distributed_manager.py:26-31,76-92) for every worker
+ * and T steps in one call: batched on-GPU acting through device-mapped pinned memory, host env
+ * stepping, transitions written worker-major into the rollout store's pinned staging and moved with
+ * one hipMemcpyAsync per column.  cols = store column indices of {state, action, reward,
+ * next_state, done} (f32[4], i64[1], f32[1], f32[4], u8[1]).                                       */
+typedef struct jh_collector jh_collector;
+int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store, const int32_t* cols,
+                        jh_collector** out);
+void jh_collector_destroy(jh_collector* c);
+int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,7 +293,9 @@ class PPO(BaseAgent):
     def process(self, transitions, step):
         """ppo.py:187-202.  `transitions` is the reference's List[Dict] or an SoA dict of arrays."""
         result = {}
-        if isinstance(transitions, dict):
+        if transitions is None:
+            pass  # a native collector already appended them to the rollout store
+        elif isinstance(transitions, dict):
             self.memory.store_soa(transitions)
         else:
             self.memory.store(transitions)

@@ -1,0 +1,96 @@
+// Native sync-mode rollout collection for PPO on CartPole -- the whole of
+// DistributedManager.run + Actor.run (manager/distributed_manager.py:26-31,76-92) for W workers and
+// T steps in ONE call, no Python per step:
+//   for t in 0..T-1:
+//     observations of all W envs  -> device-mapped pinned buffer (read in place by the kernels)
+//     jh_pponet_act_discrete      -> 2 launches: fused MLP forward + multinomial sampling
+//     hipStreamSynchronize        -> actions are in pinned memory
+//     jh_cartpole_step            -> host physics for all W envs, auto-reset
+//     transition (s, a, r, s', d) -> pinned staging slab of the rollout store, worker-major
+//   one hipMemcpyAsync per column moves the W*T transitions into the GPU-resident store.
+// Weights never leave HBM (the acting network IS the learner's), so BaseAgent.sync_out / sync_in
+// (core/agent/base.py:75-85) and the per-iteration state_dict broadcast disappear.
+#include "jh_common.h"
+
+struct jh_collector {
+  jh_ctx* ctx = nullptr;
+  jh_pponet* net = nullptr;
+  jh_cartpole* env = nullptr;
+  jh_store* store = nullptr;
+  int W = 0;
+  int col_state = 0, col_action = 1, col_reward = 2, col_next = 3, col_done = 4;
+  float* obs_h = nullptr;     // pinned [W][4]
+  float* obs_d = nullptr;     // device alias
+  int64_t* act_h = nullptr;   // pinned [W]
+  int64_t* act_d = nullptr;
+  std::vector<float> next_obs, reward;
+  std::vector<uint8_t> done;
+  double t_act = 0, t_env = 0;  // host seconds spent waiting for actions / stepping envs (diagnostics)
+};
+
+JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store,
+                                  const int32_t* cols /* state, action, reward, next_state, done */,
+                                  jh_collector** out) {
+  JH_ARG(ctx && net && env && store && cols && out);
+  JH_ARG(!net->cont && net->S == 4 && net->A == 2);
+  JH_ARG(env->W <= net->max_act_rows);
+  for (int i = 0; i < 5; ++i) JH_ARG(cols[i] >= 0 && cols[i] < store->n_cols);
+  JH_ARG(store->cols[cols[0]].dtype == JH_F32 && store->cols[cols[0]].elems == 4);
+  JH_ARG(store->cols[cols[1]].dtype == JH_I64 && store->cols[cols[1]].elems == 1);
+  JH_ARG(store->cols[cols[2]].dtype == JH_F32 && store->cols[cols[2]].elems == 1);
+  JH_ARG(store->cols[cols[3]].dtype == JH_F32 && store->cols[cols[3]].elems == 4);
+  JH_ARG(store->cols[cols[4]].dtype == JH_U8 && store->cols[cols[4]].elems == 1);
+  JH_HIP(hipSetDevice(ctx->device));
+  jh_collector* c = new jh_collector();
+  c->ctx = ctx; c->net = net; c->env = env; c->store = store; c->W = env->W;
+  c->col_state = cols[0]; c->col_action = cols[1]; c->col_reward = cols[2]; c->col_next = cols[3]; c->col_done = cols[4];
+  JH_HIP(hipHostMalloc((void**)&c->obs_h, sizeof(float) * 4 * (size_t)c->W, hipHostMallocMapped));
+  JH_HIP(hipHostGetDevicePointer((void**)&c->obs_d, c->obs_h, 0));
+  JH_HIP(hipHostMalloc((void**)&c->act_h, sizeof(int64_t) * (size_t)c->W, hipHostMallocMapped));
+  JH_HIP(hipHostGetDevicePointer((void**)&c->act_d, c->act_h, 0));
+  c->next_obs.resize(4 * (size_t)c->W);
+  c->reward.resize(c->W);
+  c->done.resize(c->W);
+  *out = c;
+  return JH_OK;
+}
+
+JH_EXPORT void jh_collector_destroy(jh_collector* c) {
+  if (!c) return;
+  if (c->obs_h) (void)hipHostFree(c->obs_h);
+  if (c->act_h) (void)hipHostFree(c->act_h);
+  delete c;
+}
+
+// Collect T steps from every env and append the W*T transitions (worker-major) to the store.
+JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream) {
+  JH_ARG(c != nullptr && T > 0);
+  const int W = c->W;
+  const int64_t n = (int64_t)W * T;
+  void* cols[16];
+  int rc = jh_store_stage_begin(c->store, n, cols);
+  if (rc) return rc;
+  float* st = (float*)cols[c->col_state];
+  int64_t* ac = (int64_t*)cols[c->col_action];
+  float* rw = (float*)cols[c->col_reward];
+  float* ns = (float*)cols[c->col_next];
+  uint8_t* dn = (uint8_t*)cols[c->col_done];
+  hipStream_t s = jh_s(stream);
+  for (int t = 0; t < T; ++t) {
+    jh_cartpole_obs(c->env, c->obs_h);  // current state of every env (reset state where it just finished)
+    rc = jh_pponet_act_discrete(c->net, W, c->obs_d, c->act_d, nullptr, nullptr, training, stream);
+    if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
+    JH_HIP(hipStreamSynchronize(s));
+    rc = jh_cartpole_step(c->env, c->act_h, c->next_obs.data(), c->reward.data(), c->done.data());
+    if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
+    for (int w = 0; w < W; ++w) {
+      const size_t row = (size_t)w * T + t;  // worker-major: w0 t0..tT-1, w1 ...  (distributed_manager.py:30)
+      memcpy(st + 4 * row, c->obs_h + 4 * w, sizeof(float) * 4);
+      memcpy(ns + 4 * row, c->next_obs.data() + 4 * w, sizeof(float) * 4);
+      ac[row] = c->act_h[w];
+      rw[row] = c->reward[w];
+      dn[row] = c->done[w];
+    }
+  }
+  return jh_store_stage_commit(c->store, stream);
+}

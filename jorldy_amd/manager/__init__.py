@@ -1,3 +1,3 @@
-from .collector import VecCollector
+from .collector import NativeCollector, VecCollector
 
-__all__ = ["VecCollector"]
+__all__ = ["VecCollector", "NativeCollector"]

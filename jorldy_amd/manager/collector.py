@@ -1,4 +1,4 @@
-"""Vectorised sync rollout collector -- replaces DistributedManager + the Ray `Actor`s
+"""Vectorised sync rollout collectors -- replace DistributedManager + the Ray `Actor`s
 (manager/distributed_manager.py:7-95) for sync mode.
 
 Reference: N Ray actors, each with one env and a CPU copy of the agent, run `step` B=1 forwards each;
@@ -7,8 +7,17 @@ Here: ONE batched policy forward on the GPU per timestep for all W envs, the env
 one native call on the host (jh_cartpole_step), transitions are written straight into SoA arrays in
 the reference's worker-major order (w0 t0..tT-1, w1 ...), and `sync()` is a no-op because the
 acting network IS the learner's network (weights never leave HBM; removes base.py:78-85 traffic).
+
+VecCollector     Python loop over timesteps, works with any agent (`agent.act`).
+NativeCollector  the whole T-step loop in one C call (jh_collector_run): acting kernels read the
+                 observations from device-mapped pinned memory and write the actions back the same
+                 way; transitions go directly into the rollout store's pinned staging slab.
 """
+import ctypes as C
+
 import numpy as np
+
+from .. import _lib as L
 
 
 class VecCollector:
@@ -46,3 +55,53 @@ class VecCollector:
 
     def terminate(self):
         return None
+
+
+class NativeCollector:
+    """jh_collector_*: CartPole x native PPO (discrete) only.  `run(step)` appends W*step transitions
+    to the agent's rollout store and returns (None, 1.0); pass None to `agent.process`."""
+
+    def __init__(self, env_vec, agent, num_workers=None, mode="sync"):
+        assert mode == "sync"
+        assert getattr(agent, "_net", None) is not None and agent.action_type == "discrete", "needs the native PPO backend"
+        self.lib = L.load()
+        self.env, self.agent = env_vec, agent
+        self.num_workers = env_vec.W
+        self.h = None
+        self._store_h = None
+        self._net_h = None
+
+    def _bind(self, n_rows):
+        mem, W = self.agent.memory, self.env.W
+        example = {"state": np.zeros((n_rows, 4), np.float32), "action": np.zeros((n_rows, 1), np.int64), "reward": np.zeros((n_rows, 1), np.float32),
+                   "next_state": np.zeros((n_rows, 4), np.float32), "done": np.zeros((n_rows, 1), np.uint8)}
+        mem._ensure(example, n_rows)
+        self.agent._grow_native(W)
+        store, net = mem._store, self.agent._net
+        if self.h is not None and self._store_h == store.h.value and self._net_h == net.h.value:
+            return
+        if self.h is not None:
+            self.lib.jh_collector_destroy(self.h)
+        cols = (C.c_int32 * 5)(*[store.names.index(k) for k in ("state", "action", "reward", "next_state", "done")])
+        h = C.c_void_p()
+        L.check(self.lib.jh_collector_create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
+        self.h, self._store_h, self._net_h = h, store.h.value, net.h.value
+
+    def run(self, step=1):
+        self._bind(self.env.W * step)
+        L.check(self.lib.jh_collector_run(self.h, int(step), 1, L.stream_ptr()))
+        return None, 1.0
+
+    def sync(self, sync_item=None, init=False):
+        return None
+
+    def terminate(self):
+        if self.h is not None:
+            self.lib.jh_collector_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.terminate()
+        except Exception:
+            pass
