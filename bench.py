@@ -170,6 +170,8 @@ def main():
         "learner_updates_per_s": world * n_updates * args.steps / dt,
         "last_result": {k: float(v) for k, v in result.items()},
     }
+    if hasattr(collector, "stats"):
+        out["collector_host_us_per_timestep"] = collector.stats()
 
     # ---- roofline of the dominant hand-written kernel -------------------------------------------------
     # Separate pass after the timed region (the timed region replays one hipGraph per learn(), which

@@ -254,6 +254,9 @@ int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store*
                         jh_collector** out);
 void jh_collector_destroy(jh_collector* c);
 int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream);
+/* Host-side timing of the collection loop (microseconds per timestep): launching + waiting for the
+ * actions, and stepping the envs + writing the transitions.                                        */
+int jh_collector_stats(jh_collector* c, double* act_us_per_step, double* env_us_per_step, int32_t reset);
 
 #ifdef __cplusplus
 }

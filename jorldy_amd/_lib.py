@@ -78,6 +78,7 @@ _PROTOS = {
     "jh_pponet_act_discrete": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jh_collector_create": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
     "jh_collector_destroy": (None, [_vp]),
+    "jh_collector_stats": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), _i32]),
     "jh_collector_run": (C.c_int, [_vp, _i32, _i32, _vp]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),
     "jh_cartpole_destroy": (None, [_vp]),

@@ -10,7 +10,12 @@
 //   one hipMemcpyAsync per column moves the W*T transitions into the GPU-resident store.
 // Weights never leave HBM (the acting network IS the learner's), so BaseAgent.sync_out / sync_in
 // (core/agent/base.py:75-85) and the per-iteration state_dict broadcast disappear.
+#include <chrono>
+
 #include "jh_common.h"
+
+int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_out,
+                                float* d_value_out, int32_t training, unsigned* d_flag, unsigned seq, jh_stream stream);
 
 struct jh_collector {
   jh_ctx* ctx = nullptr;
@@ -25,7 +30,12 @@ struct jh_collector {
   int64_t* act_d = nullptr;
   std::vector<float> next_obs, reward;
   std::vector<uint8_t> done;
-  double t_act = 0, t_env = 0;  // host seconds spent waiting for actions / stepping envs (diagnostics)
+  volatile unsigned* flag_h = nullptr;  // pinned completion word written by the sampling kernel
+  unsigned* flag_d = nullptr;
+  unsigned seq = 0;
+  int wait_mode = 1;  // 0: hipStreamSynchronize per timestep, 1: poll the pinned completion word
+  double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
+  int64_t steps = 0;
 };
 
 JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store,
@@ -48,6 +58,10 @@ JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env,
   JH_HIP(hipHostGetDevicePointer((void**)&c->obs_d, c->obs_h, 0));
   JH_HIP(hipHostMalloc((void**)&c->act_h, sizeof(int64_t) * (size_t)c->W, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&c->act_d, c->act_h, 0));
+  JH_HIP(hipHostMalloc((void**)&c->flag_h, 64, hipHostMallocMapped));
+  JH_HIP(hipHostGetDevicePointer((void**)&c->flag_d, (void*)c->flag_h, 0));
+  *c->flag_h = 0;
+  if (const char* e = getenv("JH_COLLECT_WAIT")) c->wait_mode = atoi(e);
   c->next_obs.resize(4 * (size_t)c->W);
   c->reward.resize(c->W);
   c->done.resize(c->W);
@@ -59,6 +73,7 @@ JH_EXPORT void jh_collector_destroy(jh_collector* c) {
   if (!c) return;
   if (c->obs_h) (void)hipHostFree(c->obs_h);
   if (c->act_h) (void)hipHostFree(c->act_h);
+  if (c->flag_h) (void)hipHostFree((void*)c->flag_h);
   delete c;
 }
 
@@ -78,9 +93,24 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
   hipStream_t s = jh_s(stream);
   for (int t = 0; t < T; ++t) {
     jh_cartpole_obs(c->env, c->obs_h);  // current state of every env (reset state where it just finished)
-    rc = jh_pponet_act_discrete(c->net, W, c->obs_d, c->act_d, nullptr, nullptr, training, stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    const unsigned seq = ++c->seq;
+    rc = jh_pponet_act_discrete_flag(c->net, W, c->obs_d, c->act_d, nullptr, nullptr, training,
+                                     c->wait_mode == 1 ? c->flag_d : nullptr, seq, stream);
     if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
-    JH_HIP(hipStreamSynchronize(s));
+    if (c->wait_mode == 1) {
+      // bounded spin on the pinned word (the kernel release-stores it after the actions); fall back to
+      // a real synchronise if it does not show up, so a lost write can never hang the collector
+      bool seen = false;
+      for (long spin = 0; spin < 20000000L; ++spin) {
+        if (*c->flag_h == seq) { seen = true; break; }
+        __builtin_ia32_pause();
+      }
+      if (!seen) JH_HIP(hipStreamSynchronize(s));
+    } else {
+      JH_HIP(hipStreamSynchronize(s));
+    }
+    const auto t1 = std::chrono::steady_clock::now();
     rc = jh_cartpole_step(c->env, c->act_h, c->next_obs.data(), c->reward.data(), c->done.data());
     if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
     for (int w = 0; w < W; ++w) {
@@ -91,6 +121,21 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
       rw[row] = c->reward[w];
       dn[row] = c->done[w];
     }
+    const auto t2 = std::chrono::steady_clock::now();
+    c->t_act += std::chrono::duration<double>(t1 - t0).count();
+    c->t_env += std::chrono::duration<double>(t2 - t1).count();
+    c->steps += 1;
   }
   return jh_store_stage_commit(c->store, stream);
+}
+
+// Diagnostics: host seconds per timestep spent (a) launching + waiting for the actions, (b) stepping
+// the envs and writing the transitions.
+JH_EXPORT int jh_collector_stats(jh_collector* c, double* act_us_per_step, double* env_us_per_step, int32_t reset) {
+  JH_ARG(c != nullptr);
+  const double n = c->steps > 0 ? (double)c->steps : 1.0;
+  if (act_us_per_step) *act_us_per_step = c->t_act / n * 1e6;
+  if (env_us_per_step) *env_us_per_step = c->t_env / n * 1e6;
+  if (reset) { c->t_act = c->t_env = 0; c->steps = 0; }
+  return JH_OK;
 }

@@ -344,6 +344,8 @@ struct ActArgs {
   float* logits_out;  // optional [W][A]
   float* value_out;   // optional [W]
   int greedy;
+  unsigned* done_flag;  // optional (device-mapped pinned host word): set to done_seq after the actions landed
+  unsigned done_seq;
 };
 
 __global__ void __launch_bounds__(1024) jh_act_sample_kernel(ActArgs a) {
@@ -395,8 +397,13 @@ __global__ void __launch_bounds__(1024) jh_act_sample_kernel(ActArgs a) {
       a.value_out[w] = v;
     }
   }
+  if (a.done_flag) __threadfence_system();  // this lane's action stores are visible to the host ...
   __syncthreads();
-  if (threadIdx.x == 0) a.rng[0] = ctr + 1;
+  if (threadIdx.x == 0) {
+    a.rng[0] = ctr + 1;
+    // ... before the host can see the flag (system-scope release store over PCIe)
+    if (a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ============================================================================ host API
@@ -609,8 +616,18 @@ JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_ou
 //      reduces each 16-column tile against the head weights -> partial head outputs;
 //   2. one workgroup sums the partials in tile order, adds the biases, softmax + multinomial.
 // d_obs / d_action may be pinned host memory mapped into the device address space.
+int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_out,
+                                float* d_value_out, int32_t training, unsigned* d_flag, unsigned seq, jh_stream stream);
+
 JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action,
                                      float* d_logits_out, float* d_value_out, int32_t training, jh_stream stream) {
+  return jh_pponet_act_discrete_flag(n, W, d_obs, d_action, d_logits_out, d_value_out, training, nullptr, 0, stream);
+}
+
+// Same, plus an optional completion word in device-mapped pinned memory that the host can poll
+// instead of calling hipStreamSynchronize (saves the runtime's wake-up latency on every timestep).
+int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_out,
+                                float* d_value_out, int32_t training, unsigned* d_flag, unsigned seq, jh_stream stream) {
   JH_ARG(n && d_obs && d_action);
   JH_ARG(!n->cont);
   JH_ARG(W > 0 && W <= n->max_act_rows);
@@ -629,6 +646,7 @@ JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* d_obs
   a.W = W; a.A = n->A; a.tiles_n = H / 16; a.part_rows = n->max_act_rows; a.part = n->act_part;
   for (int o = 0; o < n_out; ++o) a.bias[o] = b[o];
   a.rng = n->rng; a.action = d_action; a.logits_out = d_logits_out; a.value_out = d_value_out; a.greedy = training ? 0 : 1;
+  a.done_flag = d_flag; a.done_seq = seq;
   const int threads = W >= 1024 ? 1024 : ((W + 63) / 64) * 64;
   JH_LAUNCH(jh_act_sample_kernel, dim3(1), dim3(threads), 0, st, a);
   JH_LAUNCH_CHECK();

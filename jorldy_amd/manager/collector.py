@@ -92,6 +92,11 @@ class NativeCollector:
         L.check(self.lib.jh_collector_run(self.h, int(step), 1, L.stream_ptr()))
         return None, 1.0
 
+    def stats(self, reset=True):
+        a, e = C.c_double(), C.c_double()
+        L.check(self.lib.jh_collector_stats(self.h, C.byref(a), C.byref(e), int(reset)))
+        return {"act_us_per_step": a.value, "env_us_per_step": e.value}
+
     def sync(self, sync_item=None, init=False):
         return None
 
