@@ -80,6 +80,10 @@ template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int U>
 __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
   __shared__ float s_acc[4][64][4];
   __shared__ float s_rs[4][64];
+  // A_MODE 2: the 16 x K slice of layer 1 this tile needs, generated once per workgroup
+  // (dynamic LDS: 16*S floats of observations + 16*(K+4) floats of h1; +4 keeps rows 16 B aligned
+  // and breaks the power-of-two row stride)
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int tiles_n = (g.N + 15) / 16;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
@@ -94,8 +98,35 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
   const int mc = m_ok ? m : g.M - 1, nc = n_ok ? n : g.N - 1;  // clamped: loads stay in bounds
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   float rs = 0.f;
-  int64_t xrow = 0;
-  if (A_MODE == 2) xrow = g.x_rows ? g.x_rows[mc] : (int64_t)mc;
+  if (A_MODE == 2) {
+    float* xs = s_dyn;                    // [16][S]
+    float* h1s = s_dyn + 16 * g.S;        // [16][K + 4]
+    const int ldh = g.K + 4;
+    // observations may live in device-mapped HOST memory (uncached, a PCIe round trip per access):
+    // read every element exactly once per workgroup
+    for (int i = threadIdx.x; i < 16 * g.S; i += 256) {
+      const int rr = i / g.S, q = i - rr * g.S;
+      const int mr = m0 + rr < g.M ? m0 + rr : g.M - 1;
+      const int64_t xrow = g.x_rows ? g.x_rows[mr] : (int64_t)mr;
+      xs[i] = g.x[xrow * g.S + q];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < g.K; k += 256) {  // lane k: W1 row k (coalesced), all 16 rows
+      const float* w = g.W1 + (size_t)k * g.S;
+      const float bk = g.b1[k];
+      float accr[16];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) accr[rr] = bk;
+      for (int q = 0; q < g.S; ++q) {
+        const float wq = w[q];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) accr[rr] = fmaf(xs[rr * g.S + q], wq, accr[rr]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) h1s[rr * ldh + k] = accr[rr] > 0.f ? accr[rr] : 0.f;
+    }
+    __syncthreads();
+  }
 
   for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
     float a[U][4], b[U][4];
@@ -117,16 +148,10 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
           a[u][j] = (m_ok && k < kend) ? v : 0.f;
         }
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = kb + j;
-          const int kc = k < g.K ? k : g.K - 1;
-          float s = g.b1[kc];
-          const float* w = g.W1 + (size_t)kc * g.S;
-          const float* xr = g.x + xrow * g.S;
-          for (int q = 0; q < g.S; ++q) s = fmaf(xr[q], w[q], s);
-          a[u][j] = (m_ok && k < kend && s > 0.f) ? s : 0.f;
-        }
+        const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
+        const float4 v = *reinterpret_cast<const float4*>(s_dyn + 16 * g.S + r * (g.K + 4) + kc);
+        const bool ok = m_ok && kb < kend;
+        a[u][0] = ok ? v.x : 0.f; a[u][1] = ok ? v.y : 0.f; a[u][2] = ok ? v.z : 0.f; a[u][3] = ok ? v.w : 0.f;
       }
       if (B_KCONT) {
         const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
@@ -212,12 +237,13 @@ template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM>
 static int launch_gemm(const char* name, const GemmArgs& g, hipStream_t st) {
   const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
   const int kper = ((g.K + 63) / 64) * 16;  // per-wave K range
+  const size_t lds = A_MODE == 2 ? sizeof(float) * (16 * (size_t)g.S + 16 * (size_t)(g.K + 4)) : 0;
   if (kper > 64) {
-    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 8>), dim3(tiles), dim3(256), 0, st, g);
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 8>), dim3(tiles), dim3(256), lds, st, g);
   } else if (kper > 32) {
-    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 4>), dim3(tiles), dim3(256), 0, st, g);
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 4>), dim3(tiles), dim3(256), lds, st, g);
   } else {
-    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 2>), dim3(tiles), dim3(256), 0, st, g);
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 2>), dim3(tiles), dim3(256), lds, st, g);
   }
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -350,54 +376,61 @@ struct ActArgs {
 
 __global__ void __launch_bounds__(1024) jh_act_sample_kernel(ActArgs a) {
   const unsigned long long ctr = a.rng[0], seed = a.rng[1];
-  for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int w = wid; w < a.W; w += nw) {  // one wave per env row
+    // lane t sums column-tile t (+64, ...) of the partial head outputs, then a butterfly over lanes
     float z[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      float s = 0.f;
-      if (o <= a.A) {
-        for (int t = 0; t < a.tiles_n; ++t) s += a.part[((size_t)t * a.part_rows + w) * 8 + o];
-        s += *a.bias[o];
-      }
-      z[o] = s;
+    for (int o = 0; o < 8; ++o) z[o] = 0.f;
+    for (int t = lane; t < a.tiles_n; t += 64) {
+      const float4* p = reinterpret_cast<const float4*>(a.part + ((size_t)t * a.part_rows + w) * 8);
+      const float4 p0 = p[0], p1 = p[1];
+      z[0] += p0.x; z[1] += p0.y; z[2] += p0.z; z[3] += p0.w;
+      z[4] += p1.x; z[5] += p1.y; z[6] += p1.z; z[7] += p1.w;
     }
-    float mx = z[0];
-    int arg = 0;
 #pragma unroll
-    for (int k = 1; k < 8; ++k)
-      if (k < a.A && z[k] > mx) { mx = z[k]; arg = k; }
-    int act = arg;
-    if (!a.greedy) {
-      float se = 0.f;
+    for (int o = 0; o < 8; ++o) {
+      if (o <= a.A) z[o] = jh_wave_sum(z[o]) + *a.bias[o];
+    }
+    if (lane == 0) {
+      float mx = z[0];
+      int arg = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) se += k < a.A ? expf(z[k] - mx) : 0.f;
-      const float u = u01_from(seed * 0x100000001B3ull + ctr * 0x9E3779B97F4A7C15ull + (unsigned long long)w) * se;
-      float c = 0.f;
-      act = a.A - 1;
-      bool found = false;
+      for (int k = 1; k < 8; ++k)
+        if (k < a.A && z[k] > mx) { mx = z[k]; arg = k; }
+      int act = arg;
+      if (!a.greedy) {
+        float se = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k < a.A && !found) {
-          c += expf(z[k] - mx);
-          if (u < c) { act = k; found = true; }
+        for (int k = 0; k < 8; ++k) se += k < a.A ? expf(z[k] - mx) : 0.f;
+        const float u = u01_from(seed * 0x100000001B3ull + ctr * 0x9E3779B97F4A7C15ull + (unsigned long long)w) * se;
+        float c = 0.f;
+        act = a.A - 1;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (k < a.A && !found) {
+            c += expf(z[k] - mx);
+            if (u < c) { act = k; found = true; }
+          }
         }
       }
-    }
-    a.action[w] = act;
-    if (a.logits_out) {
+      a.action[w] = act;
+      if (a.logits_out) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (k < a.A) a.logits_out[(size_t)w * a.A + k] = z[k];
-    }
-    if (a.value_out) {
-      float v = 0.f;
+        for (int k = 0; k < 8; ++k)
+          if (k < a.A) a.logits_out[(size_t)w * a.A + k] = z[k];
+      }
+      if (a.value_out) {
+        float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (k == a.A) v = z[k];
-      a.value_out[w] = v;
+        for (int k = 0; k < 8; ++k)
+          if (k == a.A) v = z[k];
+        a.value_out[w] = v;
+      }
+      if (a.done_flag) __threadfence_system();  // this lane's action store is visible to the host ...
     }
   }
-  if (a.done_flag) __threadfence_system();  // this lane's action stores are visible to the host ...
   __syncthreads();
   if (threadIdx.x == 0) {
     a.rng[0] = ctr + 1;
@@ -647,7 +680,7 @@ int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int
   for (int o = 0; o < n_out; ++o) a.bias[o] = b[o];
   a.rng = n->rng; a.action = d_action; a.logits_out = d_logits_out; a.value_out = d_value_out; a.greedy = training ? 0 : 1;
   a.done_flag = d_flag; a.done_seq = seq;
-  const int threads = W >= 1024 ? 1024 : ((W + 63) / 64) * 64;
+  const int threads = W >= 16 ? 1024 : W * 64;  // one wave per env row (16 waves loop when W > 16)
   JH_LAUNCH(jh_act_sample_kernel, dim3(1), dim3(threads), 0, st, a);
   JH_LAUNCH_CHECK();
   return JH_OK;
