@@ -124,6 +124,7 @@ struct jh_pponet {
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
   unsigned long long* rng = nullptr;  // device: acting RNG counter
+  unsigned* act_arrive = nullptr;     // device: arrival counter of the fused acting launch
 };
 
 // ---------------------------------------------------------------- device helpers (wave = 64)

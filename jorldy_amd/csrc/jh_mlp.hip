@@ -47,7 +47,25 @@ __global__ void __launch_bounds__(256) jh_mlp_l1_kernel(int B, int S, int H, con
 //   A_MODE 0: A stored [M][K] (k contiguous)           1: A stored [K][M] (m contiguous)
 //          2: A(m,k) = relu(b1[k] + sum_s x[r(m)][s] * W1[k][s])  (layer 1 generated on the fly)
 //   B_KCONT : B stored [N][K] (k contiguous)  else stored [K][N] (n contiguous, optional row gather)
+// Workgroup tile = (16*TM) x (16*TN): operands that are contiguous along m / n are read in
+// 64*TM / 64*TN byte segments, so TM = TN = 2 uses whole 128-byte lines.
 enum { EPI_BIAS_RELU = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_ROWPTR = 3, EPI_HEADPART = 4 };
+
+// Sampling stage of the fused acting path (run by the LAST workgroup of the GEMM to finish).
+struct ActArgs {
+  int W, A, tiles_n, part_rows;
+  const float* part;     // [tiles_n][part_rows][8] per-column-tile partial head outputs
+  const float* bias[8];  // bias of flat head output o
+  unsigned long long* rng;
+  int64_t* action;    // [W] (may be device-mapped pinned host memory)
+  float* logits_out;  // optional [W][A]
+  float* value_out;   // optional [W]
+  int greedy;
+  unsigned* done_flag;  // optional (device-mapped pinned host word): set to done_seq after the actions landed
+  unsigned done_seq;
+  unsigned* arrive;     // device counter of finished GEMM workgroups (self-resetting)
+  int n_blocks;
+};
 
 struct GemmArgs {
   int M, N, K;
@@ -74,33 +92,178 @@ struct GemmArgs {
   int n_out;
   float* part;
   int part_rows;
+  ActArgs act;
 };
 
-template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int U>
+__device__ __forceinline__ float u01_from(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x = x ^ (x >> 31);
+  return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+// One wave: for every env row sum the per-tile partial head outputs (lanes = tiles, butterfly),
+// add the bias, softmax + inverse-CDF multinomial (argmax when greedy), write the action.
+// Counter-based RNG (splitmix64 of (seed, counter, env)); the counter lives in device memory.
+__device__ __forceinline__ void act_sample_wave(const ActArgs& a, int lane) {
+  const unsigned long long ctr = a.rng[0], seed = a.rng[1];
+  for (int w = 0; w < a.W; ++w) {
+    float z[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) z[o] = 0.f;
+    for (int t = lane; t < a.tiles_n; t += 64) {
+      const float4* p = reinterpret_cast<const float4*>(a.part + ((size_t)t * a.part_rows + w) * 8);
+      const float4 p0 = p[0], p1 = p[1];
+      z[0] += p0.x; z[1] += p0.y; z[2] += p0.z; z[3] += p0.w;
+      z[4] += p1.x; z[5] += p1.y; z[6] += p1.z; z[7] += p1.w;
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o <= a.A) z[o] = jh_wave_sum(z[o]) + *a.bias[o];
+    if (lane == 0) {
+      float mx = z[0];
+      int arg = 0;
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (k < a.A && z[k] > mx) { mx = z[k]; arg = k; }
+      int act = arg;
+      if (!a.greedy) {
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) se += k < a.A ? expf(z[k] - mx) : 0.f;
+        const float u = u01_from(seed * 0x100000001B3ull + ctr * 0x9E3779B97F4A7C15ull + (unsigned long long)w) * se;
+        float c = 0.f;
+        act = a.A - 1;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (k < a.A && !found) {
+            c += expf(z[k] - mx);
+            if (u < c) { act = k; found = true; }
+          }
+        }
+      }
+      a.action[w] = act;
+      if (a.logits_out) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < a.A) a.logits_out[(size_t)w * a.A + k] = z[k];
+      }
+      if (a.value_out) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k == a.A) v = z[k];
+        a.value_out[w] = v;
+      }
+    }
+  }
+  if (lane == 0) {
+    a.rng[0] = ctr + 1;
+    if (a.done_flag) {
+      __threadfence_system();  // the action stores are visible to the host before the flag
+      __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int U, int TM, int TN>
 __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
-  __shared__ float s_acc[4][64][4];
-  __shared__ float s_rs[4][64];
+  __shared__ float s_acc[4][TM * TN][64][4];
+  __shared__ float s_rs[4][TM][64];
   // A_MODE 2: the 16 x K slice of layer 1 this tile needs, generated once per workgroup
   // (dynamic LDS: 16*S floats of observations + 16*(K+4) floats of h1; +4 keeps rows 16 B aligned
   // and breaks the power-of-two row stride)
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int tiles_n = (g.N + 15) / 16;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
-  const int m0 = tm * 16, n0 = tn * 16;
+  const int tiles_n = (g.N + 16 * TN - 1) / (16 * TN);
+  const int tm_blk = blockIdx.x / tiles_n, tn_blk = blockIdx.x - tm_blk * tiles_n;
+  const int m0 = tm_blk * 16 * TM, n0 = tn_blk * 16 * TN;
   const int r = lane & 15, kq = lane >> 4;
   // this wave's K range (multiple of 16 long)
   const int kper = ((g.K + 63) / 64) * 16;
   const int kbeg = wid * kper;
   const int kend = kbeg + kper < g.K ? kbeg + kper : g.K;
-  const int m = m0 + r, n = n0 + r;
-  const bool m_ok = m < g.M, n_ok = n < g.N;
-  const int mc = m_ok ? m : g.M - 1, nc = n_ok ? n : g.N - 1;  // clamped: loads stay in bounds
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float rs = 0.f;
+  bool m_ok[TM], n_ok[TN];
+  int mc[TM], nc[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int m = m0 + 16 * t + r;
+    m_ok[t] = m < g.M;
+    mc[t] = m_ok[t] ? m : g.M - 1;  // clamped: loads stay in bounds
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = n0 + 16 * t + r;
+    n_ok[t] = n < g.N;
+    nc[t] = n_ok[t] ? n : g.N - 1;
+  }
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+  float a[U][TM][4], b[U][TN][4];
+
+  auto load_b = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = k0 + 16 * u + 4 * kq;
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        if (B_KCONT) {
+          const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
+          const float4 v = *reinterpret_cast<const float4*>(g.B + (size_t)nc[t] * g.ldb + kc);
+          const bool ok = n_ok[t] && kb < kend;  // K % 4 == 0 for k-contiguous operands
+          b[u][t][0] = ok ? v.x : 0.f; b[u][t][1] = ok ? v.y : 0.f; b[u][t][2] = ok ? v.z : 0.f; b[u][t][3] = ok ? v.w : 0.f;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = kb + j;
+            const int kc = k < g.K ? k : g.K - 1;
+            const int64_t row = g.b_rows ? g.b_rows[kc] : (int64_t)kc;
+            const float v = g.B[(size_t)row * g.ldb + nc[t]];
+            b[u][t][j] = (n_ok[t] && k < kend) ? v : 0.f;
+          }
+        }
+      }
+    }
+  };
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = k0 + 16 * u + 4 * kq;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (A_MODE == 0 || A_MODE == 2) {
+          const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
+          const float4 v = A_MODE == 0 ? *reinterpret_cast<const float4*>(g.A + (size_t)mc[t] * g.lda + kc)
+                                       : *reinterpret_cast<const float4*>(s_dyn + 16 * g.S + r * (g.K + 4) + kc);
+          const bool ok = m_ok[t] && kb < kend;
+          a[u][t][0] = ok ? v.x : 0.f; a[u][t][1] = ok ? v.y : 0.f; a[u][t][2] = ok ? v.z : 0.f; a[u][t][3] = ok ? v.w : 0.f;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = kb + j;
+            const int kc = k < g.K ? k : g.K - 1;
+            const float v = g.A[(size_t)kc * g.lda + mc[t]];
+            a[u][t][j] = (m_ok[t] && k < kend) ? v : 0.f;
+          }
+        }
+      }
+    }
+  };
+
   if (A_MODE == 2) {
-    float* xs = s_dyn;                    // [16][S]
-    float* h1s = s_dyn + 16 * g.S;        // [16][K + 4]
+    // The weight loads of the first (normally only) batch do not depend on the observations: put
+    // them in flight before the PCIe round trip below.
+    load_b(kbeg);
+    float* xs = s_dyn;              // [16][S]
+    float* h1s = s_dyn + 16 * g.S;  // [16][K + 4]
     const int ldh = g.K + 4;
     // observations may live in device-mapped HOST memory (uncached, a PCIe round trip per access):
     // read every element exactly once per workgroup
@@ -129,121 +292,123 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
   }
 
   for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
-    float a[U][4], b[U][4];
     // ---- issue every load of the batch first
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kb = k0 + 16 * u + 4 * kq;
-      if (A_MODE == 0) {
-        const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
-        const float4 v = *reinterpret_cast<const float4*>(g.A + (size_t)mc * g.lda + kc);
-        const bool ok = m_ok && kb < kend;  // K % 4 == 0 for k-contiguous operands
-        a[u][0] = ok ? v.x : 0.f; a[u][1] = ok ? v.y : 0.f; a[u][2] = ok ? v.z : 0.f; a[u][3] = ok ? v.w : 0.f;
-      } else if (A_MODE == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = kb + j;
-          const int kc = k < g.K ? k : g.K - 1;
-          const float v = g.A[(size_t)kc * g.lda + mc];
-          a[u][j] = (m_ok && k < kend) ? v : 0.f;
-        }
-      } else {
-        const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
-        const float4 v = *reinterpret_cast<const float4*>(s_dyn + 16 * g.S + r * (g.K + 4) + kc);
-        const bool ok = m_ok && kb < kend;
-        a[u][0] = ok ? v.x : 0.f; a[u][1] = ok ? v.y : 0.f; a[u][2] = ok ? v.z : 0.f; a[u][3] = ok ? v.w : 0.f;
-      }
-      if (B_KCONT) {
-        const int kc = kb + 3 < g.K ? kb : (g.K >= 4 ? g.K - 4 : 0);
-        const float4 v = *reinterpret_cast<const float4*>(g.B + (size_t)nc * g.ldb + kc);
-        const bool ok = n_ok && kb < kend;
-        b[u][0] = ok ? v.x : 0.f; b[u][1] = ok ? v.y : 0.f; b[u][2] = ok ? v.z : 0.f; b[u][3] = ok ? v.w : 0.f;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = kb + j;
-          const int kc = k < g.K ? k : g.K - 1;
-          const int64_t row = g.b_rows ? g.b_rows[kc] : (int64_t)kc;
-          const float v = g.B[(size_t)row * g.ldb + nc];
-          b[u][j] = (n_ok && k < kend) ? v : 0.f;
-        }
-      }
-    }
+    if (!(A_MODE == 2 && k0 == kbeg)) load_b(k0);
+    load_a(k0);
     // ---- then the MFMAs
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][j], acc, 0, 0, 0);
-        if (ROWSUM) rs += a[u][j];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tm][j], b[u][tn][j], acc[tm][tn], 0, 0, 0);
+          if (ROWSUM) rs[tm] += a[u][tm][j];
+        }
       }
     }
   }
   // ---- in-workgroup split-K combine (fixed order)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s_acc[wid][lane][i] = acc[i];
-  if (ROWSUM) s_rs[wid][lane] = rs;
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s_acc[wid][tm * TN + tn][lane][i] = acc[tm][tn][i];
+    if (ROWSUM) s_rs[wid][tm][lane] = rs[tm];
+  }
   __syncthreads();
   if (wid != 0) return;
-  float c[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) c[i] = ((s_acc[0][lane][i] + s_acc[1][lane][i]) + s_acc[2][lane][i]) + s_acc[3][lane][i];
-  if (ROWSUM && tn == 0) {
-    float t = ((s_rs[0][lane] + s_rs[1][lane]) + s_rs[2][lane]) + s_rs[3][lane];
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
-    if (kq == 0 && m_ok) {
-      if (EPI == EPI_ROWPTR) *g.rowsum_ptr[m] = t;
-      else g.rowsum[m] = t;
+  for (int tm = 0; tm < TM; ++tm) {
+    if (ROWSUM && tn_blk == 0) {
+      float t = ((s_rs[0][tm][lane] + s_rs[1][tm][lane]) + s_rs[2][tm][lane]) + s_rs[3][tm][lane];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (kq == 0 && m_ok[tm]) {
+        const int m = m0 + 16 * tm + r;
+        if (EPI == EPI_ROWPTR) *g.rowsum_ptr[m] = t;
+        else g.rowsum[m] = t;
+      }
     }
-  }
-  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
-  float hv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mm = m0 + kq * 4 + i;
-    float v = c[i];
-    if (EPI == EPI_BIAS_RELU || EPI == EPI_HEADPART) {
-      v += g.aux[nc];
-      v = v > 0.f ? v : 0.f;
-    } else if (EPI == EPI_MASK) {
-      const int mmc = mm < g.M ? mm : g.M - 1;
-      v = g.aux[(size_t)mmc * g.ldaux + nc] > 0.f ? v : 0.f;  // relu'(h) of the forward activation
-    }
-    hv[i] = (n_ok && mm < g.M) ? v : 0.f;
-    if (!n_ok || mm >= g.M) continue;
-    if (EPI == EPI_ROWPTR) g.rowptr[mm][n] = v;
-    else if (EPI != EPI_HEADPART) g.C[(size_t)mm * g.ldc + n] = v;
-  }
-  if (EPI == EPI_HEADPART) {
-    // partial head outputs of this 16-column tile: reduce over the 16 lanes that share kq
-    for (int o = 0; o < g.n_out; ++o) {
-      const float w = n_ok ? g.wh[o][n] : 0.f;
+    for (int tn = 0; tn < TN; ++tn) {
+      const int q = tm * TN + tn;
+      const int n = n0 + 16 * tn + r;
+      // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+      float hv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float p = hv[i] * w;
-        p += __shfl_xor(p, 1, 64);
-        p += __shfl_xor(p, 2, 64);
-        p += __shfl_xor(p, 4, 64);
-        p += __shfl_xor(p, 8, 64);
-        const int mm = m0 + kq * 4 + i;
-        if (r == 0 && mm < g.M) g.part[((size_t)tn * g.part_rows + mm) * 8 + o] = p;
+        const int mm = m0 + 16 * tm + kq * 4 + i;
+        float v = ((s_acc[0][q][lane][i] + s_acc[1][q][lane][i]) + s_acc[2][q][lane][i]) + s_acc[3][q][lane][i];
+        if (EPI == EPI_BIAS_RELU || EPI == EPI_HEADPART) {
+          v += g.aux[nc[tn]];
+          v = v > 0.f ? v : 0.f;
+        } else if (EPI == EPI_MASK) {
+          const int mmc = mm < g.M ? mm : g.M - 1;
+          v = g.aux[(size_t)mmc * g.ldaux + nc[tn]] > 0.f ? v : 0.f;  // relu'(h) of the forward activation
+        }
+        hv[i] = (n_ok[tn] && mm < g.M) ? v : 0.f;
+        if (!n_ok[tn] || mm >= g.M) continue;
+        if (EPI == EPI_ROWPTR) g.rowptr[mm][n] = v;
+        else if (EPI != EPI_HEADPART) g.C[(size_t)mm * g.ldc + n] = v;
       }
+      if (EPI == EPI_HEADPART) {
+        // partial head outputs of this 16-column tile: reduce over the 16 lanes that share kq
+        for (int o = 0; o < g.n_out; ++o) {
+          const float w = n_ok[tn] ? g.wh[o][n] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float p = hv[i] * w;
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 4, 64);
+            p += __shfl_xor(p, 8, 64);
+            const int mm = m0 + 16 * tm + kq * 4 + i;
+            if (r == 0 && mm < g.M) g.part[((size_t)(tn_blk * TN + tn) * g.part_rows + mm) * 8 + o] = p;
+          }
+        }
+      }
+    }
+  }
+  if (EPI == EPI_HEADPART && g.act.arrive) {
+    // Fused acting: the LAST workgroup to publish its partials also samples the actions, so a whole
+    // act() is one launch.  Hand-off = the split-K-seam recipe of the CDNA guide (G16): every writer
+    // drains its stores, ONE agent-scope release, then the arrival ticket; the last arriver does ONE
+    // agent-scope acquire before reading the other workgroups' partials.  Placement-independent.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned ticket = 0;
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ticket = __hip_atomic_fetch_add(g.act.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __shfl(ticket, 0, 64);
+    if (ticket == (unsigned)(g.act.n_blocks - 1)) {
+      if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(g.act.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+      }
+      __builtin_amdgcn_wave_barrier();
+      act_sample_wave(g.act, lane);
     }
   }
 }
 
-template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM>
+template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int TM, int TN>
 static int launch_gemm(const char* name, const GemmArgs& g, hipStream_t st) {
-  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+  const int tiles = ((g.M + 16 * TM - 1) / (16 * TM)) * ((g.N + 16 * TN - 1) / (16 * TN));
   const int kper = ((g.K + 63) / 64) * 16;  // per-wave K range
   const size_t lds = A_MODE == 2 ? sizeof(float) * (16 * (size_t)g.S + 16 * (size_t)(g.K + 4)) : 0;
-  if (kper > 64) {
-    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 8>), dim3(tiles), dim3(256), lds, st, g);
+  constexpr int UMAX = (TM * TN >= 4) ? 4 : 8;  // keep the operand registers of a batch <= 64 + 64
+  if (kper > 64 && UMAX == 8) {
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, UMAX, TM, TN>), dim3(tiles), dim3(256), lds, st, g);
   } else if (kper > 32) {
-    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 4>), dim3(tiles), dim3(256), lds, st, g);
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 4, TM, TN>), dim3(tiles), dim3(256), lds, st, g);
   } else {
-    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 2>), dim3(tiles), dim3(256), lds, st, g);
+    JH_LAUNCH_NAMED(name, (jh_gemm16_kernel<A_MODE, B_KCONT, EPI, ROWSUM, 2, TM, TN>), dim3(tiles), dim3(256), lds, st, g);
   }
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -348,97 +513,6 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
   }
 }
 
-// ============================================================================ acting
-// Stage 2 of the fused acting path: sum the per-column-tile partial head outputs in tile order,
-// add the bias, softmax + inverse-CDF multinomial (argmax when greedy).  Counter-based RNG
-// (splitmix64 of (seed, counter, env)); the counter lives in device memory so a captured graph
-// can be replayed.  ONE workgroup: every lane reads the counter, lane 0 advances it at the end.
-__device__ __forceinline__ float u01_from(unsigned long long x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  x = x ^ (x >> 31);
-  return (float)(x >> 40) * (1.0f / 16777216.0f);
-}
-
-struct ActArgs {
-  int W, A, tiles_n, part_rows;
-  const float* part;     // [tiles_n][part_rows][8]
-  const float* bias[8];  // bias of flat head output o
-  unsigned long long* rng;
-  int64_t* action;    // [W] (may be device-mapped pinned host memory)
-  float* logits_out;  // optional [W][A]
-  float* value_out;   // optional [W]
-  int greedy;
-  unsigned* done_flag;  // optional (device-mapped pinned host word): set to done_seq after the actions landed
-  unsigned done_seq;
-};
-
-__global__ void __launch_bounds__(1024) jh_act_sample_kernel(ActArgs a) {
-  const unsigned long long ctr = a.rng[0], seed = a.rng[1];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int w = wid; w < a.W; w += nw) {  // one wave per env row
-    // lane t sums column-tile t (+64, ...) of the partial head outputs, then a butterfly over lanes
-    float z[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) z[o] = 0.f;
-    for (int t = lane; t < a.tiles_n; t += 64) {
-      const float4* p = reinterpret_cast<const float4*>(a.part + ((size_t)t * a.part_rows + w) * 8);
-      const float4 p0 = p[0], p1 = p[1];
-      z[0] += p0.x; z[1] += p0.y; z[2] += p0.z; z[3] += p0.w;
-      z[4] += p1.x; z[5] += p1.y; z[6] += p1.z; z[7] += p1.w;
-    }
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      if (o <= a.A) z[o] = jh_wave_sum(z[o]) + *a.bias[o];
-    }
-    if (lane == 0) {
-      float mx = z[0];
-      int arg = 0;
-#pragma unroll
-      for (int k = 1; k < 8; ++k)
-        if (k < a.A && z[k] > mx) { mx = z[k]; arg = k; }
-      int act = arg;
-      if (!a.greedy) {
-        float se = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) se += k < a.A ? expf(z[k] - mx) : 0.f;
-        const float u = u01_from(seed * 0x100000001B3ull + ctr * 0x9E3779B97F4A7C15ull + (unsigned long long)w) * se;
-        float c = 0.f;
-        act = a.A - 1;
-        bool found = false;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (k < a.A && !found) {
-            c += expf(z[k] - mx);
-            if (u < c) { act = k; found = true; }
-          }
-        }
-      }
-      a.action[w] = act;
-      if (a.logits_out) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (k < a.A) a.logits_out[(size_t)w * a.A + k] = z[k];
-      }
-      if (a.value_out) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (k == a.A) v = z[k];
-        a.value_out[w] = v;
-      }
-      if (a.done_flag) __threadfence_system();  // this lane's action store is visible to the host ...
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a.rng[0] = ctr + 1;
-    // ... before the host can see the flag (system-scope release store over PCIe)
-    if (a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 // ============================================================================ host API
 static int64_t pponet_layout(jh_pponet* n) {
   const int64_t S = n->S, H = n->H, A = n->A;
@@ -489,6 +563,8 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
   JH_HIP(hipMalloc((void**)&n->rng, sizeof(unsigned long long) * 2));
+  JH_HIP(hipMalloc((void**)&n->act_arrive, 64));
+  JH_HIP(hipMemset(n->act_arrive, 0, 64));
   const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
   JH_HIP(hipMemcpy(n->hyper, hy, sizeof(hy), hipMemcpyHostToDevice));
   const unsigned long long r[2] = {0ull, (unsigned long long)seed};
@@ -503,7 +579,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipDeviceSynchronize();
   (void)hipFree(n->h1); (void)hipFree(n->h2); (void)hipFree(n->dh1); (void)hipFree(n->dh2);
   (void)hipFree(n->g_all); (void)hipFree(n->act_part);
-  (void)hipFree(n->norm_partial); (void)hipFree(n->hyper); (void)hipFree(n->rng);
+  (void)hipFree(n->norm_partial); (void)hipFree(n->hyper); (void)hipFree(n->rng); (void)hipFree(n->act_arrive);
   delete n;
 }
 
@@ -575,7 +651,7 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   GemmArgs g{};
   g.M = B; g.N = H; g.K = H; g.A = n->h1; g.lda = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->h2; g.ldc = H;
   g.aux = n->params + n->o_b2;
-  int rc = launch_gemm<0, true, EPI_BIAS_RELU, false>("jh_gemm16_fwd_h2", g, st);
+  int rc = launch_gemm<0, true, EPI_BIAS_RELU, false, 1, 1>("jh_gemm16_fwd_h2", g, st);
   if (rc) return rc;
   HeadPtrs hp = head_ptrs(n, d_head0, d_head1, d_value, nullptr, nullptr, nullptr);
   JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp);
@@ -604,28 +680,28 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     GemmArgs g{};
     g.M = n_out; g.N = H; g.K = B; g.A = n->g_all; g.lda = 8; g.B = n->h2; g.ldb = H;
     for (int o = 0; o < n_out; ++o) { g.rowptr[o] = dw[o]; g.rowsum_ptr[o] = db[o]; }
-    rc = launch_gemm<1, false, EPI_ROWPTR, true>("jh_gemm16_bwd_dWheads", g, st);
+    rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 2>("jh_gemm16_bwd_dWheads", g, st);
     if (rc) return rc;
   }
   {  // dW2[o][i] = sum_b dh2[b][o] h1[b][i] ; db2[o] = sum_b dh2[b][o]  (A = dh2^T stored [K=B][M=H])
     GemmArgs g{};
     g.M = H; g.N = H; g.K = B; g.A = n->dh2; g.lda = H; g.B = n->h1; g.ldb = H; g.C = n->grads + n->o_w2; g.ldc = H;
     g.rowsum = n->grads + n->o_b2;
-    rc = launch_gemm<1, false, EPI_NONE, true>("jh_gemm16_bwd_dW2", g, st);
+    rc = launch_gemm<1, false, EPI_NONE, true, 2, 2>("jh_gemm16_bwd_dW2", g, st);
     if (rc) return rc;
   }
   {  // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]                 (B = W2 stored [K=H_out][N=H_in])
     GemmArgs g{};
     g.M = B; g.N = H; g.K = H; g.A = n->dh2; g.lda = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->dh1; g.ldc = H;
     g.aux = n->h1; g.ldaux = H;
-    rc = launch_gemm<0, false, EPI_MASK, false>("jh_gemm16_bwd_dh1", g, st);
+    rc = launch_gemm<0, false, EPI_MASK, false, 1, 2>("jh_gemm16_bwd_dh1", g, st);
     if (rc) return rc;
   }
   {  // dW1[j][s] = sum_b dh1[b][j] x[r(b)][s] ; db1[j] = sum_b dh1[b][j]  (B = gathered x rows [K=B][N=S])
     GemmArgs g{};
     g.M = H; g.N = S; g.K = B; g.A = n->dh1; g.lda = H; g.B = d_x; g.ldb = S; g.b_rows = d_idx;
     g.C = n->grads + n->o_w1; g.ldc = S; g.rowsum = n->grads + n->o_b1;
-    rc = launch_gemm<1, false, EPI_NONE, true>("jh_gemm16_bwd_dW1", g, st);
+    rc = launch_gemm<1, false, EPI_NONE, true, 2, 1>("jh_gemm16_bwd_dW1", g, st);
     if (rc) return rc;
   }
   return JH_OK;
@@ -644,10 +720,10 @@ JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_ou
   return JH_OK;
 }
 
-// Batched acting for W envs (PPO.act, ppo.py:55-69, discrete) in TWO launches:
-//   1. GEMM with layer 1 generated on the fly as the A operand, h2 kept in registers, epilogue
-//      reduces each 16-column tile against the head weights -> partial head outputs;
-//   2. one workgroup sums the partials in tile order, adds the biases, softmax + multinomial.
+// Batched acting for W envs (PPO.act, ppo.py:55-69, discrete) in ONE launch:
+//   GEMM with layer 1 generated on the fly as the A operand (LDS), h2 kept in registers, epilogue
+//   reduces each 16-column tile against the head weights -> partial head outputs; the last
+//   workgroup to arrive sums the partials, adds the biases and does softmax + multinomial.
 // d_obs / d_action may be pinned host memory mapped into the device address space.
 int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_out,
                                 float* d_value_out, int32_t training, unsigned* d_flag, unsigned seq, jh_stream stream);
@@ -673,15 +749,13 @@ int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int
   g.x = d_obs; g.x_rows = nullptr; g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.S = n->S;
   for (int o = 0; o < n_out; ++o) g.wh[o] = w[o];
   g.n_out = n_out; g.part = n->act_part; g.part_rows = n->max_act_rows;
-  int rc = launch_gemm<2, true, EPI_HEADPART, false>("jh_gemm16_act_fused", g, st);
-  if (rc) return rc;
-  ActArgs a{};
+  ActArgs& a = g.act;
   a.W = W; a.A = n->A; a.tiles_n = H / 16; a.part_rows = n->max_act_rows; a.part = n->act_part;
   for (int o = 0; o < n_out; ++o) a.bias[o] = b[o];
   a.rng = n->rng; a.action = d_action; a.logits_out = d_logits_out; a.value_out = d_value_out; a.greedy = training ? 0 : 1;
   a.done_flag = d_flag; a.done_seq = seq;
-  const int threads = W >= 16 ? 1024 : W * 64;  // one wave per env row (16 waves loop when W > 16)
-  JH_LAUNCH(jh_act_sample_kernel, dim3(1), dim3(threads), 0, st, a);
-  JH_LAUNCH_CHECK();
+  a.arrive = n->act_arrive; a.n_blocks = ((W + 15) / 16) * (H / 16);
+  int rc = launch_gemm<2, true, EPI_HEADPART, false, 1, 1>("jh_gemm16_act_fused", g, st);
+  if (rc) return rc;
   return JH_OK;
 }
