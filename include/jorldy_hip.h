@@ -228,10 +228,13 @@ int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t*
 /* torch.nn.utils.clip_grad_norm_(max_norm) (skipped if max_norm <= 0) + torch.optim.Adam.step
  * on the flat buckets (ppo.py:166-169).  d_norm_out: optional device float, pre-clip norm.      */
 int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_out, jh_stream stream);
-/* PPO.act for W envs in one shot (ppo.py:55-69, discrete): forward + softmax + multinomial
- * (argmax when training == 0).  d_obs / d_action may be device-mapped pinned host memory.       */
-int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_ws,
-                           float* d_value_ws, int32_t training, jh_stream stream);
+/* PPO.act for W envs in one shot (ppo.py:55-69, discrete): ONE kernel launch computes the fused MLP
+ * forward and writes per-column-tile partial head outputs + sequence words into device-mapped
+ * pinned memory; the host polls them, sums the partials, and does softmax + multinomial (argmax
+ * when training == 0).  h_obs [W][S] / h_action [W] / h_logits_out [W][A] / h_value_out [W] are
+ * ordinary HOST pointers; BLOCKING: returns when the actions are available.                     */
+int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs, int64_t* h_action, float* h_logits_out,
+                           float* h_value_out, int32_t training, jh_stream stream);
 
 /* ------------------------------------------------------------------ vectorised host collector
  * Synthetic CartPole-v1 (gym is not installable in the build image): W envs stepped in one

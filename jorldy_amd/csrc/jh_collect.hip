@@ -2,9 +2,9 @@
 // DistributedManager.run + Actor.run (manager/distributed_manager.py:26-31,76-92) for W workers and
 // T steps in ONE call, no Python per step:
 //   for t in 0..T-1:
-//     observations of all W envs  -> device-mapped pinned buffer (read in place by the kernels)
-//     jh_pponet_act_discrete      -> 2 launches: fused MLP forward + multinomial sampling
-//     hipStreamSynchronize        -> actions are in pinned memory
+//     jh_pponet_act_discrete      -> observations into device-mapped pinned memory, ONE launch (fused
+//                                    MLP forward, partial heads + per-tile flags written back into
+//                                    pinned memory), host polls the flags and samples the actions
 //     jh_cartpole_step            -> host physics for all W envs, auto-reset
 //     transition (s, a, r, s', d) -> pinned staging slab of the rollout store, worker-major
 //   one hipMemcpyAsync per column moves the W*T transitions into the GPU-resident store.
@@ -14,8 +14,6 @@
 
 #include "jh_common.h"
 
-int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_out,
-                                float* d_value_out, int32_t training, unsigned* d_flag, unsigned seq, jh_stream stream);
 
 struct jh_collector {
   jh_ctx* ctx = nullptr;
@@ -24,16 +22,9 @@ struct jh_collector {
   jh_store* store = nullptr;
   int W = 0;
   int col_state = 0, col_action = 1, col_reward = 2, col_next = 3, col_done = 4;
-  float* obs_h = nullptr;     // pinned [W][4]
-  float* obs_d = nullptr;     // device alias
-  int64_t* act_h = nullptr;   // pinned [W]
-  int64_t* act_d = nullptr;
-  std::vector<float> next_obs, reward;
+  std::vector<float> obs, next_obs, reward;
+  std::vector<int64_t> act;
   std::vector<uint8_t> done;
-  volatile unsigned* flag_h = nullptr;  // pinned completion word written by the sampling kernel
-  unsigned* flag_d = nullptr;
-  unsigned seq = 0;
-  int wait_mode = 1;  // 0: hipStreamSynchronize per timestep, 1: poll the pinned completion word
   double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
   int64_t steps = 0;
 };
@@ -54,14 +45,8 @@ JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env,
   jh_collector* c = new jh_collector();
   c->ctx = ctx; c->net = net; c->env = env; c->store = store; c->W = env->W;
   c->col_state = cols[0]; c->col_action = cols[1]; c->col_reward = cols[2]; c->col_next = cols[3]; c->col_done = cols[4];
-  JH_HIP(hipHostMalloc((void**)&c->obs_h, sizeof(float) * 4 * (size_t)c->W, hipHostMallocMapped));
-  JH_HIP(hipHostGetDevicePointer((void**)&c->obs_d, c->obs_h, 0));
-  JH_HIP(hipHostMalloc((void**)&c->act_h, sizeof(int64_t) * (size_t)c->W, hipHostMallocMapped));
-  JH_HIP(hipHostGetDevicePointer((void**)&c->act_d, c->act_h, 0));
-  JH_HIP(hipHostMalloc((void**)&c->flag_h, 64, hipHostMallocMapped));
-  JH_HIP(hipHostGetDevicePointer((void**)&c->flag_d, (void*)c->flag_h, 0));
-  *c->flag_h = 0;
-  if (const char* e = getenv("JH_COLLECT_WAIT")) c->wait_mode = atoi(e);
+  c->obs.resize(4 * (size_t)c->W);
+  c->act.resize(c->W);
   c->next_obs.resize(4 * (size_t)c->W);
   c->reward.resize(c->W);
   c->done.resize(c->W);
@@ -70,10 +55,6 @@ JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env,
 }
 
 JH_EXPORT void jh_collector_destroy(jh_collector* c) {
-  if (!c) return;
-  if (c->obs_h) (void)hipHostFree(c->obs_h);
-  if (c->act_h) (void)hipHostFree(c->act_h);
-  if (c->flag_h) (void)hipHostFree((void*)c->flag_h);
   delete c;
 }
 
@@ -90,34 +71,19 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
   float* rw = (float*)cols[c->col_reward];
   float* ns = (float*)cols[c->col_next];
   uint8_t* dn = (uint8_t*)cols[c->col_done];
-  hipStream_t s = jh_s(stream);
   for (int t = 0; t < T; ++t) {
-    jh_cartpole_obs(c->env, c->obs_h);  // current state of every env (reset state where it just finished)
+    jh_cartpole_obs(c->env, c->obs.data());  // current state of every env (reset state where it just finished)
     const auto t0 = std::chrono::steady_clock::now();
-    const unsigned seq = ++c->seq;
-    rc = jh_pponet_act_discrete_flag(c->net, W, c->obs_d, c->act_d, nullptr, nullptr, training,
-                                     c->wait_mode == 1 ? c->flag_d : nullptr, seq, stream);
+    rc = jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act.data(), nullptr, nullptr, training, stream);
     if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
-    if (c->wait_mode == 1) {
-      // bounded spin on the pinned word (the kernel release-stores it after the actions); fall back to
-      // a real synchronise if it does not show up, so a lost write can never hang the collector
-      bool seen = false;
-      for (long spin = 0; spin < 20000000L; ++spin) {
-        if (*c->flag_h == seq) { seen = true; break; }
-        __builtin_ia32_pause();
-      }
-      if (!seen) JH_HIP(hipStreamSynchronize(s));
-    } else {
-      JH_HIP(hipStreamSynchronize(s));
-    }
     const auto t1 = std::chrono::steady_clock::now();
-    rc = jh_cartpole_step(c->env, c->act_h, c->next_obs.data(), c->reward.data(), c->done.data());
+    rc = jh_cartpole_step(c->env, c->act.data(), c->next_obs.data(), c->reward.data(), c->done.data());
     if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
     for (int w = 0; w < W; ++w) {
       const size_t row = (size_t)w * T + t;  // worker-major: w0 t0..tT-1, w1 ...  (distributed_manager.py:30)
-      memcpy(st + 4 * row, c->obs_h + 4 * w, sizeof(float) * 4);
+      memcpy(st + 4 * row, c->obs.data() + 4 * w, sizeof(float) * 4);
       memcpy(ns + 4 * row, c->next_obs.data() + 4 * w, sizeof(float) * 4);
-      ac[row] = c->act_h[w];
+      ac[row] = c->act[w];
       rw[row] = c->reward[w];
       dn[row] = c->done[w];
     }

@@ -119,12 +119,15 @@ struct jh_pponet {
   // owned workspaces
   float *h1 = nullptr, *h2 = nullptr, *dh1 = nullptr, *dh2 = nullptr;
   float* g_all = nullptr;     // [max_rows][8] packed head gradients (A-operand of the dW_heads GEMM)
-  float* act_part = nullptr;  // [H/16][max_act_rows][8] per-column-tile partial head outputs (acting)
   int max_act_rows = 0;
+  // acting exchange area: pinned host memory mapped into the device address space
+  float *obs_pin_h = nullptr, *obs_pin_d = nullptr;        // [max_act_rows][S] observations (host writes, kernel reads)
+  float *part_pin_h = nullptr, *part_pin_d = nullptr;      // [H/16][max_act_rows][8] partial head outputs (kernel writes)
+  unsigned *flag_pin_h = nullptr, *flag_pin_d = nullptr;   // [tiles] per-tile sequence words
+  unsigned act_seq = 0;
+  uint64_t act_seed = 0, act_ctr = 0;  // host-side counter-based sampling stream
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
-  unsigned long long* rng = nullptr;  // device: acting RNG counter
-  unsigned* act_arrive = nullptr;     // device: arrival counter of the fused acting launch
 };
 
 // ---------------------------------------------------------------- device helpers (wave = 64)

@@ -51,22 +51,6 @@ __global__ void __launch_bounds__(256) jh_mlp_l1_kernel(int B, int S, int H, con
 // 64*TM / 64*TN byte segments, so TM = TN = 2 uses whole 128-byte lines.
 enum { EPI_BIAS_RELU = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_ROWPTR = 3, EPI_HEADPART = 4 };
 
-// Sampling stage of the fused acting path (run by the LAST workgroup of the GEMM to finish).
-struct ActArgs {
-  int W, A, tiles_n, part_rows;
-  const float* part;     // [tiles_n][part_rows][8] per-column-tile partial head outputs
-  const float* bias[8];  // bias of flat head output o
-  unsigned long long* rng;
-  int64_t* action;    // [W] (may be device-mapped pinned host memory)
-  float* logits_out;  // optional [W][A]
-  float* value_out;   // optional [W]
-  int greedy;
-  unsigned* done_flag;  // optional (device-mapped pinned host word): set to done_seq after the actions landed
-  unsigned done_seq;
-  unsigned* arrive;     // device counter of finished GEMM workgroups (self-resetting)
-  int n_blocks;
-};
-
 struct GemmArgs {
   int M, N, K;
   const float* A;
@@ -90,83 +74,12 @@ struct GemmArgs {
   // HEADPART: per-tile partial head outputs part[tile_n][row][8] = sum_{n in tile} h2[row][n]*Wh[o][n]
   const float* wh[8];
   int n_out;
-  float* part;
+  float* part;           // may be device-mapped pinned HOST memory (acting: the host finishes the heads)
   int part_rows;
-  ActArgs act;
+  const float* hbias[8];  // bias of head output o, added by column-tile 0
+  unsigned* tile_flag;   // optional [tiles] (device-mapped pinned host words): set to flag_seq per tile
+  unsigned flag_seq;
 };
-
-__device__ __forceinline__ float u01_from(unsigned long long x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  x = x ^ (x >> 31);
-  return (float)(x >> 40) * (1.0f / 16777216.0f);
-}
-
-// One wave: for every env row sum the per-tile partial head outputs (lanes = tiles, butterfly),
-// add the bias, softmax + inverse-CDF multinomial (argmax when greedy), write the action.
-// Counter-based RNG (splitmix64 of (seed, counter, env)); the counter lives in device memory.
-__device__ __forceinline__ void act_sample_wave(const ActArgs& a, int lane) {
-  const unsigned long long ctr = a.rng[0], seed = a.rng[1];
-  for (int w = 0; w < a.W; ++w) {
-    float z[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) z[o] = 0.f;
-    for (int t = lane; t < a.tiles_n; t += 64) {
-      const float4* p = reinterpret_cast<const float4*>(a.part + ((size_t)t * a.part_rows + w) * 8);
-      const float4 p0 = p[0], p1 = p[1];
-      z[0] += p0.x; z[1] += p0.y; z[2] += p0.z; z[3] += p0.w;
-      z[4] += p1.x; z[5] += p1.y; z[6] += p1.z; z[7] += p1.w;
-    }
-#pragma unroll
-    for (int o = 0; o < 8; ++o)
-      if (o <= a.A) z[o] = jh_wave_sum(z[o]) + *a.bias[o];
-    if (lane == 0) {
-      float mx = z[0];
-      int arg = 0;
-#pragma unroll
-      for (int k = 1; k < 8; ++k)
-        if (k < a.A && z[k] > mx) { mx = z[k]; arg = k; }
-      int act = arg;
-      if (!a.greedy) {
-        float se = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) se += k < a.A ? expf(z[k] - mx) : 0.f;
-        const float u = u01_from(seed * 0x100000001B3ull + ctr * 0x9E3779B97F4A7C15ull + (unsigned long long)w) * se;
-        float c = 0.f;
-        act = a.A - 1;
-        bool found = false;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (k < a.A && !found) {
-            c += expf(z[k] - mx);
-            if (u < c) { act = k; found = true; }
-          }
-        }
-      }
-      a.action[w] = act;
-      if (a.logits_out) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (k < a.A) a.logits_out[(size_t)w * a.A + k] = z[k];
-      }
-      if (a.value_out) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (k == a.A) v = z[k];
-        a.value_out[w] = v;
-      }
-    }
-  }
-  if (lane == 0) {
-    a.rng[0] = ctr + 1;
-    if (a.done_flag) {
-      __threadfence_system();  // the action stores are visible to the host before the flag
-      __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
 
 template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int U, int TM, int TN>
 __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
@@ -367,33 +280,24 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
             p += __shfl_xor(p, 4, 64);
             p += __shfl_xor(p, 8, 64);
             const int mm = m0 + 16 * tm + kq * 4 + i;
-            if (r == 0 && mm < g.M) g.part[((size_t)(tn_blk * TN + tn) * g.part_rows + mm) * 8 + o] = p;
+            if (r == 0 && mm < g.M) {
+              if (tn_blk * TN + tn == 0) p += *g.hbias[o];
+              g.part[((size_t)(tn_blk * TN + tn) * g.part_rows + mm) * 8 + o] = p;
+            }
           }
         }
       }
     }
   }
-  if (EPI == EPI_HEADPART && g.act.arrive) {
-    // Fused acting: the LAST workgroup to publish its partials also samples the actions, so a whole
-    // act() is one launch.  Hand-off = the split-K-seam recipe of the CDNA guide (G16): every writer
-    // drains its stores, ONE agent-scope release, then the arrival ticket; the last arriver does ONE
-    // agent-scope acquire before reading the other workgroups' partials.  Placement-independent.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned ticket = 0;
-    if (lane == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ticket = __hip_atomic_fetch_add(g.act.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ticket = __shfl(ticket, 0, 64);
-    if (ticket == (unsigned)(g.act.n_blocks - 1)) {
-      if (lane == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(g.act.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-      }
-      __builtin_amdgcn_wave_barrier();
-      act_sample_wave(g.act, lane);
-    }
+  if (EPI == EPI_HEADPART && g.tile_flag) {
+    // Acting hand-off to the HOST: the partial head outputs went to device-mapped pinned memory;
+    // make them visible system-wide, then publish this tile's sequence word.  The host polls the
+    // words and finishes the heads (sum over tiles, softmax, sampling): no second launch, no
+    // cross-workgroup synchronisation on the device.
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0)
+      __hip_atomic_store(g.tile_flag + blockIdx.x, g.flag_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -559,16 +463,21 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   JH_HIP(hipMalloc((void**)&n->dh2, act));
   JH_HIP(hipMalloc((void**)&n->g_all, sizeof(float) * 8 * (size_t)max_rows));
   n->max_act_rows = max_rows < 1024 ? max_rows : 1024;
-  JH_HIP(hipMalloc((void**)&n->act_part, sizeof(float) * 8 * (size_t)n->max_act_rows * (size_t)(H / 16)));
+  {
+    const size_t tiles = (size_t)((n->max_act_rows + 15) / 16) * (size_t)(H / 16);
+    JH_HIP(hipHostMalloc((void**)&n->obs_pin_h, sizeof(float) * (size_t)n->max_act_rows * (size_t)S, hipHostMallocMapped));
+    JH_HIP(hipHostGetDevicePointer((void**)&n->obs_pin_d, n->obs_pin_h, 0));
+    JH_HIP(hipHostMalloc((void**)&n->part_pin_h, sizeof(float) * 8 * (size_t)n->max_act_rows * (size_t)(H / 16), hipHostMallocMapped));
+    JH_HIP(hipHostGetDevicePointer((void**)&n->part_pin_d, n->part_pin_h, 0));
+    JH_HIP(hipHostMalloc((void**)&n->flag_pin_h, sizeof(unsigned) * tiles, hipHostMallocMapped));
+    JH_HIP(hipHostGetDevicePointer((void**)&n->flag_pin_d, n->flag_pin_h, 0));
+    memset(n->flag_pin_h, 0, sizeof(unsigned) * tiles);
+    n->act_seed = seed;
+  }
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
-  JH_HIP(hipMalloc((void**)&n->rng, sizeof(unsigned long long) * 2));
-  JH_HIP(hipMalloc((void**)&n->act_arrive, 64));
-  JH_HIP(hipMemset(n->act_arrive, 0, 64));
   const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
   JH_HIP(hipMemcpy(n->hyper, hy, sizeof(hy), hipMemcpyHostToDevice));
-  const unsigned long long r[2] = {0ull, (unsigned long long)seed};
-  JH_HIP(hipMemcpy(n->rng, r, sizeof(r), hipMemcpyHostToDevice));
   *out = n;
   return JH_OK;
 }
@@ -578,8 +487,9 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipSetDevice(n->ctx->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(n->h1); (void)hipFree(n->h2); (void)hipFree(n->dh1); (void)hipFree(n->dh2);
-  (void)hipFree(n->g_all); (void)hipFree(n->act_part);
-  (void)hipFree(n->norm_partial); (void)hipFree(n->hyper); (void)hipFree(n->rng); (void)hipFree(n->act_arrive);
+  (void)hipFree(n->g_all);
+  (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
+  (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
   delete n;
 }
 
@@ -680,28 +590,28 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     GemmArgs g{};
     g.M = n_out; g.N = H; g.K = B; g.A = n->g_all; g.lda = 8; g.B = n->h2; g.ldb = H;
     for (int o = 0; o < n_out; ++o) { g.rowptr[o] = dw[o]; g.rowsum_ptr[o] = db[o]; }
-    rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 2>("jh_gemm16_bwd_dWheads", g, st);
+    rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 1>("jh_gemm16_bwd_dWheads", g, st);
     if (rc) return rc;
   }
   {  // dW2[o][i] = sum_b dh2[b][o] h1[b][i] ; db2[o] = sum_b dh2[b][o]  (A = dh2^T stored [K=B][M=H])
     GemmArgs g{};
     g.M = H; g.N = H; g.K = B; g.A = n->dh2; g.lda = H; g.B = n->h1; g.ldb = H; g.C = n->grads + n->o_w2; g.ldc = H;
     g.rowsum = n->grads + n->o_b2;
-    rc = launch_gemm<1, false, EPI_NONE, true, 2, 2>("jh_gemm16_bwd_dW2", g, st);
+    rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW2", g, st);
     if (rc) return rc;
   }
   {  // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]                 (B = W2 stored [K=H_out][N=H_in])
     GemmArgs g{};
     g.M = B; g.N = H; g.K = H; g.A = n->dh2; g.lda = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->dh1; g.ldc = H;
     g.aux = n->h1; g.ldaux = H;
-    rc = launch_gemm<0, false, EPI_MASK, false, 1, 2>("jh_gemm16_bwd_dh1", g, st);
+    rc = launch_gemm<0, false, EPI_MASK, false, 1, 1>("jh_gemm16_bwd_dh1", g, st);
     if (rc) return rc;
   }
   {  // dW1[j][s] = sum_b dh1[b][j] x[r(b)][s] ; db1[j] = sum_b dh1[b][j]  (B = gathered x rows [K=B][N=S])
     GemmArgs g{};
     g.M = H; g.N = S; g.K = B; g.A = n->dh1; g.lda = H; g.B = d_x; g.ldb = S; g.b_rows = d_idx;
     g.C = n->grads + n->o_w1; g.ldc = S; g.rowsum = n->grads + n->o_b1;
-    rc = launch_gemm<1, false, EPI_NONE, true, 2, 1>("jh_gemm16_bwd_dW1", g, st);
+    rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW1", g, st);
     if (rc) return rc;
   }
   return JH_OK;
@@ -720,42 +630,85 @@ JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_ou
   return JH_OK;
 }
 
-// Batched acting for W envs (PPO.act, ppo.py:55-69, discrete) in ONE launch:
-//   GEMM with layer 1 generated on the fly as the A operand (LDS), h2 kept in registers, epilogue
-//   reduces each 16-column tile against the head weights -> partial head outputs; the last
-//   workgroup to arrive sums the partials, adds the biases and does softmax + multinomial.
-// d_obs / d_action may be pinned host memory mapped into the device address space.
-int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_out,
-                                float* d_value_out, int32_t training, unsigned* d_flag, unsigned seq, jh_stream stream);
-
-JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action,
-                                     float* d_logits_out, float* d_value_out, int32_t training, jh_stream stream) {
-  return jh_pponet_act_discrete_flag(n, W, d_obs, d_action, d_logits_out, d_value_out, training, nullptr, 0, stream);
+// Batched acting for W envs (PPO.act, ppo.py:55-69, discrete): ONE launch + host finish.
+//   device: GEMM with layer 1 generated on the fly as the A operand (LDS), h2 kept in registers,
+//           epilogue reduces each 16-column tile against the head weights and writes the partial
+//           head outputs + a per-tile sequence word straight into device-mapped pinned host memory;
+//   host:   polls the sequence words (bounded spin, falls back to hipStreamSynchronize), sums the
+//           partials in tile order, softmax + inverse-CDF multinomial (argmax when !training) with a
+//           counter-based splitmix64 stream.
+// h_obs [W][S] and h_action [W] are ordinary host pointers; the call returns when the actions are
+// there (acting is synchronous by nature: the envs need them).  h_logits_out / h_value_out optional.
+static inline double jh_u01(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x = x ^ (x >> 31);
+  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// Same, plus an optional completion word in device-mapped pinned memory that the host can poll
-// instead of calling hipStreamSynchronize (saves the runtime's wake-up latency on every timestep).
-int jh_pponet_act_discrete_flag(jh_pponet* n, int32_t W, const float* d_obs, int64_t* d_action, float* d_logits_out,
-                                float* d_value_out, int32_t training, unsigned* d_flag, unsigned seq, jh_stream stream) {
-  JH_ARG(n && d_obs && d_action);
+JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs, int64_t* h_action,
+                                     float* h_logits_out, float* h_value_out, int32_t training, jh_stream stream) {
+  JH_ARG(n && h_obs && h_action);
   JH_ARG(!n->cont);
   JH_ARG(W > 0 && W <= n->max_act_rows);
   hipStream_t st = jh_s(stream);
-  const int H = n->H;
+  const int H = n->H, A = n->A;
+  const int tiles_n = H / 16, tiles = ((W + 15) / 16) * tiles_n;
+  memcpy(n->obs_pin_h, h_obs, sizeof(float) * (size_t)W * n->S);
   const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
   const int n_out = head_rows(n, w, dw, b, db);
   GemmArgs g{};
   g.M = W; g.N = H; g.K = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = nullptr; g.aux = n->params + n->o_b2;
-  g.x = d_obs; g.x_rows = nullptr; g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.S = n->S;
-  for (int o = 0; o < n_out; ++o) g.wh[o] = w[o];
-  g.n_out = n_out; g.part = n->act_part; g.part_rows = n->max_act_rows;
-  ActArgs& a = g.act;
-  a.W = W; a.A = n->A; a.tiles_n = H / 16; a.part_rows = n->max_act_rows; a.part = n->act_part;
-  for (int o = 0; o < n_out; ++o) a.bias[o] = b[o];
-  a.rng = n->rng; a.action = d_action; a.logits_out = d_logits_out; a.value_out = d_value_out; a.greedy = training ? 0 : 1;
-  a.done_flag = d_flag; a.done_seq = seq;
-  a.arrive = n->act_arrive; a.n_blocks = ((W + 15) / 16) * (H / 16);
+  g.x = n->obs_pin_d; g.x_rows = nullptr; g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.S = n->S;
+  for (int o = 0; o < n_out; ++o) { g.wh[o] = w[o]; g.hbias[o] = b[o]; }
+  g.n_out = n_out; g.part = n->part_pin_d; g.part_rows = n->max_act_rows;
+  const unsigned seq = ++n->act_seq;
+  g.tile_flag = n->flag_pin_d; g.flag_seq = seq;
   int rc = launch_gemm<2, true, EPI_HEADPART, false, 1, 1>("jh_gemm16_act_fused", g, st);
   if (rc) return rc;
+  // ---- wait for every tile's sequence word
+  volatile unsigned* flags = n->flag_pin_h;
+  bool all = false;
+  for (long spin = 0; spin < 50000000L && !all; ++spin) {
+    all = true;
+    for (int t = 0; t < tiles; ++t)
+      if (flags[t] != seq) { all = false; break; }
+    if (!all) __builtin_ia32_pause();
+  }
+  if (!all) {
+    JH_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < tiles; ++t)
+      if (flags[t] != seq) return jh_fail(JH_ERR_STATE, "acting kernel finished without publishing tile %d", t);
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // ---- finish the heads on the host
+  const float* part = n->part_pin_h;
+  for (int wq = 0; wq < W; ++wq) {
+    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < tiles_n; ++t) {
+      const float* p = part + ((size_t)t * n->max_act_rows + wq) * 8;
+      for (int o = 0; o < n_out; ++o) z[o] += p[o];
+    }
+    int act = 0;
+    float mx = z[0];
+    for (int k = 1; k < A; ++k)
+      if (z[k] > mx) { mx = z[k]; act = k; }
+    if (training) {
+      float e[8], se = 0.f;
+      for (int k = 0; k < A; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
+      const float u = (float)jh_u01(n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq) * se;
+      float c = 0.f;
+      act = A - 1;
+      for (int k = 0; k < A; ++k) {
+        c += e[k];
+        if (u < c) { act = k; break; }
+      }
+    }
+    h_action[wq] = act;
+    if (h_logits_out) memcpy(h_logits_out + (size_t)wq * A, z, sizeof(float) * A);
+    if (h_value_out) h_value_out[wq] = z[A];
+  }
+  n->act_ctr += 1;
   return JH_OK;
 }

@@ -407,20 +407,16 @@ class PPONet:
         with _timed("jh_gradnorm+adam", 4.0 * self.n_params * 8):  # g (r twice, w) + p,m,v (r+w)
             L.check(self.lib.jh_pponet_adam_step(self.h, float(max_norm if max_norm else 0.0), L.ptr(norm_out), L.stream_ptr()))
 
-    # ---- acting through device-mapped pinned memory ------------------------------------------------
-    def act_discrete(self, obs, training=True):
-        """obs: numpy float32 [W, S] -> numpy int64 [W, 1].  One forward + sampling launch for all W
-        envs; observations / actions cross PCIe through pinned memory the kernels access in place."""
+    # ---- acting (one launch; partial heads come back through device-mapped pinned memory) ---------
+    def act_discrete(self, obs, training=True, want_logits=False):
+        """obs: numpy float32 [W, S] -> numpy int64 [W, 1] (blocking)."""
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
         W = int(obs.shape[0])
-        if self._act is None or self._act["W"] != W:
-            self._act = dict(W=W, obs=PinnedBuffer((W, self.S), np.float32, self.device.index), act=PinnedBuffer((W, 1), np.int64, self.device.index),
-                             logits=torch.empty(W, self.A, dtype=torch.float32, device=self.device), val=torch.empty(W, 1, dtype=torch.float32, device=self.device))
-        a = self._act
-        a["obs"].np[:] = obs
-        st = L.stream_ptr()
-        L.check(self.lib.jh_pponet_act_discrete(self.h, W, a["obs"].dev_ptr, a["act"].dev_ptr, L.ptr(a["logits"]), L.ptr(a["val"]), int(bool(training)), st))
-        L.check(self.lib.jh_ctx_sync(self.ctx, st))
-        return a["act"].np.copy()
+        act = np.empty((W, 1), np.int64)
+        logits = np.empty((W, self.A), np.float32) if want_logits else None
+        val = np.empty((W, 1), np.float32) if want_logits else None
+        L.check(self.lib.jh_pponet_act_discrete(self.h, W, L.ptr(obs), L.ptr(act), L.ptr(logits), L.ptr(val), int(bool(training)), L.stream_ptr()))
+        return (act, logits, val) if want_logits else act
 
 
 # ============================================================================= TD / C51
