@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# kernel arguments (and with them the per-step observations of the acting kernel) are written by the
+# host straight into VRAM instead of being fetched over PCIe at kernel start; must be set before the
+# HIP runtime initialises
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
