@@ -14,6 +14,14 @@
 
 #include "jh_common.h"
 
+// jh_persist.hip: one persistent acting kernel per rollout
+struct jh_persist;
+int jh_persist_create(jh_pponet* n, jh_persist** out);
+void jh_persist_destroy(jh_persist* p);
+int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st);
+int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action, int training);
+void jh_persist_abort(jh_persist* p);
+
 
 struct jh_collector {
   jh_ctx* ctx = nullptr;
@@ -25,6 +33,8 @@ struct jh_collector {
   std::vector<float> obs, next_obs, reward;
   std::vector<int64_t> act;
   std::vector<uint8_t> done;
+  jh_persist* persist = nullptr;  // null: one launch per timestep
+  int mode = 1;                   // 1: persistent acting kernel (default), 0: launch per step
   double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
   int64_t steps = 0;
 };
@@ -45,6 +55,10 @@ JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env,
   jh_collector* c = new jh_collector();
   c->ctx = ctx; c->net = net; c->env = env; c->store = store; c->W = env->W;
   c->col_state = cols[0]; c->col_action = cols[1]; c->col_reward = cols[2]; c->col_next = cols[3]; c->col_done = cols[4];
+  if (const char* e = getenv("JH_COLLECT_PERSISTENT")) c->mode = atoi(e);
+  if (c->mode == 1 && c->W <= 16 && net->H % 64 == 0) {
+    if (jh_persist_create(net, &c->persist) != JH_OK) c->persist = nullptr;  // e.g. LDS too small: fall back
+  }
   c->obs.resize(4 * (size_t)c->W);
   c->act.resize(c->W);
   c->next_obs.resize(4 * (size_t)c->W);
@@ -71,11 +85,26 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
   float* rw = (float*)cols[c->col_reward];
   float* ns = (float*)cols[c->col_next];
   uint8_t* dn = (uint8_t*)cols[c->col_done];
+  bool persistent = c->persist != nullptr;
+  if (persistent) {
+    rc = jh_persist_begin(c->persist, W, T, jh_s(stream));
+    if (rc) persistent = false;
+  }
   for (int t = 0; t < T; ++t) {
     jh_cartpole_obs(c->env, c->obs.data());  // current state of every env (reset state where it just finished)
     const auto t0 = std::chrono::steady_clock::now();
-    rc = jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act.data(), nullptr, nullptr, training, stream);
-    if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
+    if (persistent) {
+      rc = jh_persist_step(c->persist, W, c->obs.data(), c->act.data(), training);
+      if (rc) {  // the kernel gave up (it exits by itself): finish this rollout with per-step launches
+        jh_persist_abort(c->persist);
+        JH_HIP(hipStreamSynchronize(jh_s(stream)));
+        persistent = false;
+      }
+    }
+    if (!persistent) {
+      rc = jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act.data(), nullptr, nullptr, training, stream);
+      if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
+    }
     const auto t1 = std::chrono::steady_clock::now();
     rc = jh_cartpole_step(c->env, c->act.data(), c->next_obs.data(), c->reward.data(), c->done.data());
     if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }

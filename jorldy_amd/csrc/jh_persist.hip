@@ -1,0 +1,276 @@
+// Persistent acting kernel for the native sync collector ("on-GPU batched
+// acting"): ONE launch serves all T timesteps of a rollout.
+//
+// Per-timestep acting is a latency problem, not a throughput problem: W = 8 rows through a
+// 4-512-512-3 MLP is ~4 MFLOP, but a launch costs ~5 us of dispatch latency plus ~4 us of fixed
+// kernel overhead plus PCIe round trips, 128 times per iteration.  This kernel removes all of it:
+//   * grid = H/16 workgroups, each owns 16 hidden-2 columns and keeps ITS slice of every weight
+//     (W2 rows, W1, biases, head-weight columns) resident in LDS for the whole rollout: no global
+//     load on the per-step critical path;
+//   * the host publishes the observations of step t as 8-byte {tag = t, value} granules in
+//     device-mapped pinned memory ("the data IS the flag", CDNA guide G16/R2): one PCIe read round
+//     trip both detects the step and fetches the data;
+//   * every workgroup computes h1 (VALU) and its h2 tile (fp32 MFMA, in-workgroup split-K), reduces
+//     the tile against the head weights and writes its partial head outputs + a sequence word
+//     straight into pinned host memory; the host sums 32 partials, samples, steps the envs;
+//   * no inter-workgroup communication on the device at all -> nothing to deadlock on; every poll
+//     loop is bounded and a timeout makes all workgroups exit (the host then falls back to the
+//     one-launch-per-step path).
+#include "jh_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PersistArgs {
+  int W, S, H, n_out, T;
+  const float *W1, *b1, *W2, *b2;
+  const float* wh[8];
+  const float* hbias[8];
+  const unsigned long long* obs_gran;  // pinned: [W*S] granules {tag << 32 | float bits}
+  float* part;                         // pinned: [tiles][16][8]
+  unsigned* tile_flag;                 // pinned: [tiles]
+  unsigned* abort_flag;                // pinned: set by the kernel on timeout / by the host to stop early
+  unsigned seq0;                       // tag of the first step (tags are seq0+1 .. seq0+T)
+  long max_polls;
+};
+
+__global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = p.H, S = p.S, ldh = H + 4;
+  float* w2s = smem;                 // [16][H+4]  this tile's rows of W2 (B operand, k contiguous)
+  float* h1s = w2s + 16 * ldh;       // [16][H+4]  layer-1 activations of the current step
+  float* w1s = h1s + 16 * ldh;       // [H][S]
+  float* b1s = w1s + H * S;          // [H]
+  float* xs = b1s + H;               // [16][S]
+  float* whs = xs + 16 * S;          // [8][16] head-weight columns of this tile
+  float* misc = whs + 8 * 16;        // [16] b2 slice, [8] head biases
+  float* s_acc = misc + 32;          // [4][64][4] split-K combine
+  __shared__ int s_go;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int tile = blockIdx.x, n0 = tile * 16;
+  const int r = lane & 15, kq = lane >> 4;
+  // ---- one-time: weights into LDS
+  for (int i = threadIdx.x; i < 16 * H; i += 256) {
+    const int rr = i / H, k = i - rr * H;
+    w2s[rr * ldh + k] = p.W2[(size_t)(n0 + rr) * H + k];
+  }
+  for (int i = threadIdx.x; i < H * S; i += 256) w1s[i] = p.W1[i];
+  for (int i = threadIdx.x; i < H; i += 256) b1s[i] = p.b1[i];
+  if (threadIdx.x < 16) misc[threadIdx.x] = p.b2[n0 + threadIdx.x];
+  if (threadIdx.x < 8) misc[16 + threadIdx.x] = threadIdx.x < p.n_out ? *p.hbias[threadIdx.x] : 0.f;
+  for (int i = threadIdx.x; i < 8 * 16; i += 256) {
+    const int o = i >> 4, c = i & 15;
+    whs[i] = o < p.n_out ? p.wh[o][n0 + c] : 0.f;
+  }
+  __syncthreads();
+  const int kper = H / 4;  // H % 64 == 0 is checked on the host
+  const int kbeg = wid * kper;
+  const int n_x = p.W * S;
+
+  for (int t = 1; t <= p.T; ++t) {
+    const unsigned tag = p.seq0 + (unsigned)t;
+    // ---- wait for the host's observations of step t (granule sweep, bounded)
+    if (wid == 0) {
+      bool ok = false;
+      for (long spin = 0; spin < p.max_polls; ++spin) {
+        bool mine = true;
+        for (int i = lane; i < n_x; i += 64) {
+          const unsigned long long gq = __hip_atomic_load(p.obs_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if ((unsigned)(gq >> 32) == tag) xs[i] = __uint_as_float((unsigned)gq);
+          else mine = false;
+        }
+        if (__all(mine)) { ok = true; break; }
+        if ((spin & 63) == 63 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (lane == 0) s_go = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_go) {  // timeout or host abort: tell the host and leave (all workgroups decide alike or time out too)
+      if (threadIdx.x == 0) __hip_atomic_store(p.abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    // ---- layer 1 for the (<=16) env rows: lane k owns hidden unit k
+    for (int k = threadIdx.x; k < H; k += 256) {
+      float accr[16];
+      const float bk = b1s[k];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) accr[rr] = bk;
+      for (int q = 0; q < S; ++q) {
+        const float wq = w1s[k * S + q];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) accr[rr] = fmaf(rr < p.W ? xs[rr * S + q] : 0.f, wq, accr[rr]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) h1s[rr * ldh + k] = accr[rr] > 0.f ? accr[rr] : 0.f;
+    }
+    __syncthreads();
+    // ---- h2 tile = h1 (16 x H) * W2_tile^T (H x 16): fp32 MFMA, this wave's K quarter
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kbeg + kper; k0 += 16) {
+      const int kb = k0 + 4 * kq;
+      const float4 av = *reinterpret_cast<const float4*>(h1s + r * ldh + kb);
+      const float4 bv = *reinterpret_cast<const float4*>(w2s + r * ldh + kb);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_acc[(wid * 64 + lane) * 4 + i] = acc[i];
+    __syncthreads();
+    if (wid == 0) {
+      // C/D fragment: col = lane & 15 (hidden-2 column n0 + r), row = kq * 4 + i (env row)
+      float hv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = ((s_acc[(0 * 64 + lane) * 4 + i] + s_acc[(1 * 64 + lane) * 4 + i]) + s_acc[(2 * 64 + lane) * 4 + i]) +
+                  s_acc[(3 * 64 + lane) * 4 + i];
+        v += misc[r];
+        hv[i] = v > 0.f ? v : 0.f;
+      }
+      for (int o = 0; o < p.n_out; ++o) {
+        const float w = whs[o * 16 + r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float q = hv[i] * w;
+          q += __shfl_xor(q, 1, 64);
+          q += __shfl_xor(q, 2, 64);
+          q += __shfl_xor(q, 4, 64);
+          q += __shfl_xor(q, 8, 64);
+          const int row = kq * 4 + i;
+          if (r == 0 && row < p.W) p.part[((size_t)tile * 16 + row) * 8 + o] = q + (tile == 0 ? misc[16 + o] : 0.f);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(p.tile_flag + tile, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();  // s_acc / h1s are reused by the next step
+  }
+}
+
+// ---------------------------------------------------------------------------------- host side
+struct jh_persist {
+  jh_pponet* net = nullptr;
+  unsigned long long* gran_h = nullptr;
+  unsigned long long* gran_d = nullptr;
+  float *part_h = nullptr, *part_d = nullptr;
+  unsigned *flag_h = nullptr, *flag_d = nullptr;  // [tiles] + abort word at [tiles]
+  unsigned seq = 0;
+  int tiles = 0;
+  size_t lds = 0;
+};
+
+int jh_persist_create(jh_pponet* n, jh_persist** out) {
+  JH_ARG(n && out);
+  JH_ARG(!n->cont && n->H % 64 == 0);
+  jh_persist* p = new jh_persist();
+  p->net = n;
+  p->tiles = n->H / 16;
+  const int H = n->H, S = n->S;
+  p->lds = sizeof(float) * ((size_t)2 * 16 * (H + 4) + (size_t)H * S + H + 16 * (size_t)S + 8 * 16 + 32 + 4 * 64 * 4);
+  if (p->lds > 160 * 1024) {
+    delete p;
+    return jh_fail(JH_ERR_ARG, "persistent acting needs %zu B of LDS (> 160 KiB) for H=%d S=%d", p->lds, H, S);
+  }
+  JH_HIP(hipFuncSetAttribute((const void*)jh_act_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
+  JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 16 * (size_t)S, hipHostMallocMapped));
+  JH_HIP(hipHostGetDevicePointer((void**)&p->gran_d, p->gran_h, 0));
+  JH_HIP(hipHostMalloc((void**)&p->part_h, sizeof(float) * 8 * 16 * (size_t)p->tiles, hipHostMallocMapped));
+  JH_HIP(hipHostGetDevicePointer((void**)&p->part_d, p->part_h, 0));
+  JH_HIP(hipHostMalloc((void**)&p->flag_h, sizeof(unsigned) * (size_t)(p->tiles + 16), hipHostMallocMapped));
+  JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
+  memset(p->gran_h, 0, sizeof(unsigned long long) * 16 * (size_t)S);
+  memset(p->flag_h, 0, sizeof(unsigned) * (size_t)(p->tiles + 16));
+  p->seq = 1000;  // tags never collide with the zero-initialised granules
+  *out = p;
+  return JH_OK;
+}
+
+void jh_persist_destroy(jh_persist* p) {
+  if (!p) return;
+  (void)hipHostFree(p->gran_h);
+  (void)hipHostFree(p->part_h);
+  (void)hipHostFree(p->flag_h);
+  delete p;
+}
+
+// Launch the persistent kernel for T steps of W <= 16 envs.
+int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
+  jh_pponet* n = p->net;
+  JH_ARG(W > 0 && W <= 16 && T > 0);
+  PersistArgs a{};
+  a.W = W; a.S = n->S; a.H = n->H; a.T = T;
+  a.W1 = n->params + n->o_w1; a.b1 = n->params + n->o_b1; a.W2 = n->params + n->o_w2; a.b2 = n->params + n->o_b2;
+  int o = 0;
+  for (int k = 0; k < n->A; ++k, ++o) { a.wh[o] = n->params + n->o_wh0 + (int64_t)k * n->H; a.hbias[o] = n->params + n->o_bh0 + k; }
+  a.wh[o] = n->params + n->o_wv; a.hbias[o] = n->params + n->o_bv; ++o;
+  a.n_out = o;
+  a.obs_gran = p->gran_d; a.part = p->part_d; a.tile_flag = p->flag_d; a.abort_flag = p->flag_d + p->tiles;
+  a.seq0 = p->seq;
+  a.max_polls = 400000;  // x (~0.5 us per poll) = ~0.2 s without observations -> give up
+  p->flag_h[p->tiles] = 0;
+  JH_LAUNCH(jh_act_persist_kernel, dim3(p->tiles), dim3(256), p->lds, st, a);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// One timestep: publish the observations, wait for every tile, finish the heads on the host.
+// Returns JH_ERR_STATE if the kernel gave up (caller falls back to jh_pponet_act_discrete).
+int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action, int training) {
+  jh_pponet* n = p->net;
+  const unsigned tag = ++p->seq;
+  const int n_x = W * n->S;
+  for (int i = 0; i < n_x; ++i) {
+    unsigned bits;
+    memcpy(&bits, h_obs + i, 4);
+    __atomic_store_n(p->gran_h + i, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELEASE);
+  }
+  volatile unsigned* flags = p->flag_h;
+  bool all = false;
+  for (long spin = 0; spin < 40000000L && !all; ++spin) {
+    all = true;
+    for (int t = 0; t < p->tiles; ++t)
+      if (flags[t] != tag) { all = false; break; }
+    if (!all) {
+      if ((spin & 1023) == 1023 && flags[p->tiles] == 2u) break;  // the kernel timed out
+      __builtin_ia32_pause();
+    }
+  }
+  if (!all) return jh_fail(JH_ERR_STATE, "persistent acting kernel did not answer step tag %u", tag);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const int A = n->A, n_out = A + 1;
+  for (int wq = 0; wq < W; ++wq) {
+    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < p->tiles; ++t) {
+      const float* q = p->part_h + ((size_t)t * 16 + wq) * 8;
+      for (int o = 0; o < n_out; ++o) z[o] += q[o];
+    }
+    int act = 0;
+    float mx = z[0];
+    for (int k = 1; k < A; ++k)
+      if (z[k] > mx) { mx = z[k]; act = k; }
+    if (training) {
+      float e[8], se = 0.f;
+      for (int k = 0; k < A; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
+      uint64_t x = n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq;
+      x += 0x9E3779B97F4A7C15ull;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      x = x ^ (x >> 31);
+      const float u = (float)((double)(x >> 11) * (1.0 / 9007199254740992.0)) * se;
+      float c = 0.f;
+      act = A - 1;
+      for (int k = 0; k < A; ++k) {
+        c += e[k];
+        if (u < c) { act = k; break; }
+      }
+    }
+    h_action[wq] = act;
+  }
+  n->act_ctr += 1;
+  return JH_OK;
+}
+
+// Stop a running kernel early (error paths): it sees the word at its next poll and exits.
+void jh_persist_abort(jh_persist* p) { __atomic_store_n(p->flag_h + p->tiles, 1u, __ATOMIC_RELEASE); }
