@@ -11,8 +11,9 @@
 //     device-mapped pinned memory ("the data IS the flag", CDNA guide G16/R2): one PCIe read round
 //     trip both detects the step and fetches the data;
 //   * every workgroup computes h1 (VALU) and its h2 tile (fp32 MFMA, in-workgroup split-K), reduces
-//     the tile against the head weights and writes its partial head outputs + a sequence word
-//     straight into pinned host memory; the host sums 32 partials, samples, steps the envs;
+//     the tile against the head weights and writes its partial head outputs as tagged 8-byte
+//     granules straight into pinned host memory (fire-and-forget posted writes: no fence, no
+//     acknowledgement wait); the host sums the 32 partials per output, samples, steps the envs;
 //   * no inter-workgroup communication on the device at all -> nothing to deadlock on; every poll
 //     loop is bounded and a timeout makes all workgroups exit (the host then falls back to the
 //     one-launch-per-step path).
@@ -26,8 +27,8 @@ struct PersistArgs {
   const float* wh[8];
   const float* hbias[8];
   const unsigned long long* obs_gran;  // pinned: [W*S] granules {tag << 32 | float bits}
-  float* part;                         // pinned: [tiles][16][8]
-  unsigned* tile_flag;                 // pinned: [tiles]
+  unsigned long long* part;            // pinned: [tiles][16][8] granules {tag << 32 | float bits}
+  unsigned* tile_flag;                 // pinned: [tiles] (unused by the granule protocol, kept for debugging)
   unsigned* abort_flag;                // pinned: set by the kernel on timeout / by the host to stop early
   unsigned seq0;                       // tag of the first step (tags are seq0+1 .. seq0+T)
   long max_polls;
@@ -138,12 +139,16 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
           q += __shfl_xor(q, 4, 64);
           q += __shfl_xor(q, 8, 64);
           const int row = kq * 4 + i;
-          if (r == 0 && row < p.W) p.part[((size_t)tile * 16 + row) * 8 + o] = q + (tile == 0 ? misc[16 + o] : 0.f);
+          // the partial IS its own flag: one aligned 8-byte store {tag, value}; fire and forget, no
+          // release fence and no wait for the PCIe write to be acknowledged
+          if (r == 0 && row < p.W) {
+            const float val = q + (tile == 0 ? misc[16 + o] : 0.f);
+            __hip_atomic_store(p.part + ((size_t)tile * 16 + row) * 8 + o,
+                               ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(p.tile_flag + tile, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();  // s_acc / h1s are reused by the next step
   }
@@ -154,7 +159,7 @@ struct jh_persist {
   jh_pponet* net = nullptr;
   unsigned long long* gran_h = nullptr;
   unsigned long long* gran_d = nullptr;
-  float *part_h = nullptr, *part_d = nullptr;
+  unsigned long long *part_h = nullptr, *part_d = nullptr;
   unsigned *flag_h = nullptr, *flag_d = nullptr;  // [tiles] + abort word at [tiles]
   unsigned seq = 0;
   int tiles = 0;
@@ -176,7 +181,8 @@ int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_HIP(hipFuncSetAttribute((const void*)jh_act_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
   JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 16 * (size_t)S, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->gran_d, p->gran_h, 0));
-  JH_HIP(hipHostMalloc((void**)&p->part_h, sizeof(float) * 8 * 16 * (size_t)p->tiles, hipHostMallocMapped));
+  JH_HIP(hipHostMalloc((void**)&p->part_h, sizeof(unsigned long long) * 8 * 16 * (size_t)p->tiles, hipHostMallocMapped));
+  memset(p->part_h, 0, sizeof(unsigned long long) * 8 * 16 * (size_t)p->tiles);
   JH_HIP(hipHostGetDevicePointer((void**)&p->part_d, p->part_h, 0));
   JH_HIP(hipHostMalloc((void**)&p->flag_h, sizeof(unsigned) * (size_t)(p->tiles + 16), hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
@@ -226,25 +232,33 @@ int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action,
     memcpy(&bits, h_obs + i, 4);
     __atomic_store_n(p->gran_h + i, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELEASE);
   }
-  volatile unsigned* flags = p->flag_h;
+  // ---- wait until every partial granule of this step carries the tag, summing as they arrive
+  const int A = n->A, n_out = A + 1;
+  volatile unsigned* abort_w = p->flag_h + p->tiles;
+  volatile unsigned long long* part = p->part_h;
   bool all = false;
   for (long spin = 0; spin < 40000000L && !all; ++spin) {
     all = true;
-    for (int t = 0; t < p->tiles; ++t)
-      if (flags[t] != tag) { all = false; break; }
+    for (int t = 0; t < p->tiles && all; ++t)
+      for (int wq = 0; wq < W && all; ++wq)
+        for (int o = 0; o < n_out; ++o)
+          if ((unsigned)(part[((size_t)t * 16 + wq) * 8 + o] >> 32) != tag) { all = false; break; }
     if (!all) {
-      if ((spin & 1023) == 1023 && flags[p->tiles] == 2u) break;  // the kernel timed out
+      if ((spin & 1023) == 1023 && *abort_w == 2u) break;  // the kernel timed out
       __builtin_ia32_pause();
     }
   }
   if (!all) return jh_fail(JH_ERR_STATE, "persistent acting kernel did not answer step tag %u", tag);
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  const int A = n->A, n_out = A + 1;
   for (int wq = 0; wq < W; ++wq) {
     float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < p->tiles; ++t) {
-      const float* q = p->part_h + ((size_t)t * 16 + wq) * 8;
-      for (int o = 0; o < n_out; ++o) z[o] += q[o];
+      for (int o = 0; o < n_out; ++o) {
+        const unsigned bits = (unsigned)part[((size_t)t * 16 + wq) * 8 + o];
+        float v;
+        memcpy(&v, &bits, 4);
+        z[o] += v;
+      }
     }
     int act = 0;
     float mx = z[0];
