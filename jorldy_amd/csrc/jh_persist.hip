@@ -11,9 +11,10 @@
 //     device-mapped pinned memory ("the data IS the flag", CDNA guide G16/R2): one PCIe read round
 //     trip both detects the step and fetches the data;
 //   * every workgroup computes h1 (VALU) and its h2 tile (fp32 MFMA, in-workgroup split-K), reduces
-//     the tile against the head weights and writes its partial head outputs as tagged 8-byte
-//     granules straight into pinned host memory (fire-and-forget posted writes: no fence, no
-//     acknowledgement wait); the host sums the 32 partials per output, samples, steps the envs;
+//     the tile against the head weights and writes its partial head outputs as 16-byte row granules
+//     {out0, out1, out2, tag} straight into pinned host memory -- W consecutive granules per
+//     workgroup in one store instruction, fire and forget (no fence, no acknowledgement wait); the
+//     host sums the 32 partials per output, samples, steps the envs;
 //   * no inter-workgroup communication on the device at all -> nothing to deadlock on; every poll
 //     loop is bounded and a timeout makes all workgroups exit (the host then falls back to the
 //     one-launch-per-step path).
@@ -27,7 +28,7 @@ struct PersistArgs {
   const float* wh[8];
   const float* hbias[8];
   const unsigned long long* obs_gran;  // pinned: [W*S] granules {tag << 32 | float bits}
-  unsigned long long* part;            // pinned: [tiles][16][8] granules {tag << 32 | float bits}
+  float4* part;                        // pinned: [tiles][16] row granules {out0, out1, out2, tag bits}
   unsigned* tile_flag;                 // pinned: [tiles] (unused by the granule protocol, kept for debugging)
   unsigned* abort_flag;                // pinned: set by the kernel on timeout / by the host to stop early
   unsigned seq0;                       // tag of the first step (tags are seq0+1 .. seq0+T)
@@ -44,7 +45,8 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
   float* xs = b1s + H;               // [16][S]
   float* whs = xs + 16 * S;          // [8][16] head-weight columns of this tile
   float* misc = whs + 8 * 16;        // [16] b2 slice, [8] head biases
-  float* s_acc = misc + 32;          // [4][64][4] split-K combine
+  float* outs_s = misc + 32;         // [16][4] staging of this tile's partial head outputs
+  float* s_acc = outs_s + 64;        // [4][64][4] split-K combine
   __shared__ int s_go;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int tile = blockIdx.x, n0 = tile * 16;
@@ -139,15 +141,19 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
           q += __shfl_xor(q, 4, 64);
           q += __shfl_xor(q, 8, 64);
           const int row = kq * 4 + i;
-          // the partial IS its own flag: one aligned 8-byte store {tag, value}; fire and forget, no
-          // release fence and no wait for the PCIe write to be acknowledged
-          if (r == 0 && row < p.W) {
-            const float val = q + (tile == 0 ? misc[16 + o] : 0.f);
-            __hip_atomic_store(p.part + ((size_t)tile * 16 + row) * 8 + o,
-                               ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
+          if (r == 0) outs_s[row * 4 + o] = q + (tile == 0 ? misc[16 + o] : 0.f);
         }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // One 16-byte row granule {out0, out1, out2, tag}: the partial IS its own flag.  Lanes 0..W-1
+      // store W consecutive granules with ONE instruction (W*16 contiguous bytes -> one or two PCIe
+      // write TLPs per tile instead of dozens of 4-byte ones); fire and forget: no release fence, no
+      // acknowledgement wait on the per-step critical path.
+      if (lane < p.W) {
+        float4 gq = *reinterpret_cast<const float4*>(outs_s + lane * 4);
+        gq.w = __uint_as_float(tag);
+        p.part[(size_t)tile * 16 + lane] = gq;
       }
     }
     __syncthreads();  // s_acc / h1s are reused by the next step
@@ -159,7 +165,7 @@ struct jh_persist {
   jh_pponet* net = nullptr;
   unsigned long long* gran_h = nullptr;
   unsigned long long* gran_d = nullptr;
-  unsigned long long *part_h = nullptr, *part_d = nullptr;
+  float4 *part_h = nullptr, *part_d = nullptr;
   unsigned *flag_h = nullptr, *flag_d = nullptr;  // [tiles] + abort word at [tiles]
   unsigned seq = 0;
   int tiles = 0;
@@ -168,12 +174,12 @@ struct jh_persist {
 
 int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_ARG(n && out);
-  JH_ARG(!n->cont && n->H % 64 == 0);
+  JH_ARG(!n->cont && n->H % 64 == 0 && n->A + 1 <= 3 && (16 * n->S) % 4 == 0);
   jh_persist* p = new jh_persist();
   p->net = n;
   p->tiles = n->H / 16;
   const int H = n->H, S = n->S;
-  p->lds = sizeof(float) * ((size_t)2 * 16 * (H + 4) + (size_t)H * S + H + 16 * (size_t)S + 8 * 16 + 32 + 4 * 64 * 4);
+  p->lds = sizeof(float) * ((size_t)2 * 16 * (H + 4) + (size_t)H * S + H + 16 * (size_t)S + 8 * 16 + 32 + 64 + 4 * 64 * 4);
   if (p->lds > 160 * 1024) {
     delete p;
     return jh_fail(JH_ERR_ARG, "persistent acting needs %zu B of LDS (> 160 KiB) for H=%d S=%d", p->lds, H, S);
@@ -181,8 +187,8 @@ int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_HIP(hipFuncSetAttribute((const void*)jh_act_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
   JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 16 * (size_t)S, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->gran_d, p->gran_h, 0));
-  JH_HIP(hipHostMalloc((void**)&p->part_h, sizeof(unsigned long long) * 8 * 16 * (size_t)p->tiles, hipHostMallocMapped));
-  memset(p->part_h, 0, sizeof(unsigned long long) * 8 * 16 * (size_t)p->tiles);
+  JH_HIP(hipHostMalloc((void**)&p->part_h, sizeof(float4) * 16 * (size_t)p->tiles, hipHostMallocMapped));
+  memset(p->part_h, 0, sizeof(float4) * 16 * (size_t)p->tiles);
   JH_HIP(hipHostGetDevicePointer((void**)&p->part_d, p->part_h, 0));
   JH_HIP(hipHostMalloc((void**)&p->flag_h, sizeof(unsigned) * (size_t)(p->tiles + 16), hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
@@ -235,14 +241,13 @@ int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action,
   // ---- wait until every partial granule of this step carries the tag, summing as they arrive
   const int A = n->A, n_out = A + 1;
   volatile unsigned* abort_w = p->flag_h + p->tiles;
-  volatile unsigned long long* part = p->part_h;
+  const volatile unsigned* part = reinterpret_cast<const volatile unsigned*>(p->part_h);  // [tiles][16][4 words]
   bool all = false;
   for (long spin = 0; spin < 40000000L && !all; ++spin) {
     all = true;
     for (int t = 0; t < p->tiles && all; ++t)
-      for (int wq = 0; wq < W && all; ++wq)
-        for (int o = 0; o < n_out; ++o)
-          if ((unsigned)(part[((size_t)t * 16 + wq) * 8 + o] >> 32) != tag) { all = false; break; }
+      for (int wq = 0; wq < W; ++wq)
+        if (part[((size_t)t * 16 + wq) * 4 + 3] != tag) { all = false; break; }
     if (!all) {
       if ((spin & 1023) == 1023 && *abort_w == 2u) break;  // the kernel timed out
       __builtin_ia32_pause();
@@ -254,7 +259,7 @@ int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action,
     float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < p->tiles; ++t) {
       for (int o = 0; o < n_out; ++o) {
-        const unsigned bits = (unsigned)part[((size_t)t * 16 + wq) * 8 + o];
+        const unsigned bits = part[((size_t)t * 16 + wq) * 4 + o];
         float v;
         memcpy(&v, &bits, 4);
         z[o] += v;
