@@ -151,9 +151,13 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
       // write TLPs per tile instead of dozens of 4-byte ones); fire and forget: no release fence, no
       // acknowledgement wait on the per-step critical path.
       if (lane < p.W) {
-        float4 gq = *reinterpret_cast<const float4*>(outs_s + lane * 4);
-        gq.w = __uint_as_float(tag);
-        p.part[(size_t)tile * 16 + lane] = gq;
+        const float4 o4 = *reinterpret_cast<const float4*>(outs_s + lane * 4);
+        const f32x4 gq = (f32x4){o4.x, o4.y, o4.z, __uint_as_float(tag)};
+        float4* dst = p.part + (size_t)tile * 16 + lane;
+        // write-through system-scope 16-byte store (a plain store lingers in L2 for milliseconds); hipcc
+        // does not track asm stores: nothing here waits for it on purpose, the s_nop keeps the data
+        // registers intact until the store has read them (CDNA guide §5.7)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
       }
     }
     __syncthreads();  // s_acc / h1s are reused by the next step
