@@ -395,3 +395,40 @@ def test_native_collector_matches_python_collector_layout():
     # and the learner consumes it
     res = agent.process(None, T)
     assert set(res) == {"actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob", "mean_ret"} and agent.memory.size == 0
+
+
+def test_ppo_native_data_parallel_path_single_rank_rccl():
+    """The DP code path (eager native kernels + one RCCL all-reduce of the flat gradient bucket per
+    minibatch) on a 1-rank nccl group: must equal the graph-replayed single-learner result."""
+    import socket
+
+    import torch.distributed as dist
+
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.parallel import make_grad_sync
+
+    z = load("ppo_disc_cartpole")
+    S, A, H, W, T, B, E, cont = [int(x) for x in z["cfg"]]
+    gamma, lam, eps, vf, ent, clip, lr = z["hyper"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cols = {k: z[f"in_{k}"] for k in ["state", "next_state", "reward", "done", "action"]}
+        outs = []
+        for dp in (False, True):
+            agent = Agent("ppo", state_size=S, action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": lr}, batch_size=B, n_step=T, n_epoch=E,
+                          _lambda=lam, epsilon_clip=eps, vf_coef=vf, ent_coef=ent, clip_grad_norm=clip, gamma=gamma, run_step=100000, device="cuda", backend="native")
+            agent.network.load_state_dict(_sd(z, "sd0/"))
+            agent.memory.first_store = False
+            if dp:
+                agent.grad_sync = make_grad_sync(agent.network, dist)
+            np.random.seed(int(z["np_seed"]))
+            agent.process(cols, T)
+            outs.append(agent._net.params.clone())
+        torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=0)
+        _cmp_sd(agent.network, _sd(z, "sd1/"), lr, int(z["n_minibatch"]), atol=3e-5)
+    finally:
+        dist.destroy_process_group()
