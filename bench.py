@@ -91,6 +91,30 @@ def cpu_baseline(iters, W, T):
     }
 
 
+# rocprofv3 kernel name of each library-profiler label (template arguments of jh_gemm16_kernel)
+_PMC_NAME = {
+    "jh_gemm16_bwd_dh1": "jh_gemm16_kernel<0, false, 1,", "jh_gemm16_bwd_dW2": "jh_gemm16_kernel<1, false, 2,",
+    "jh_gemm16_bwd_dW1": "jh_gemm16_kernel<1, false, 2,", "jh_gemm16_fwd_h2": "jh_gemm16_kernel<0, true, 0,",
+    "jh_gemm16_bwd_dWheads": "jh_gemm16_kernel<1, false, 3,", "jh_adam_kernel": "jh_adam_kernel", "jh_gae_kernel": "jh_gae_kernel",
+    "jh_ppo_fused_kernel<CONT>": "jh_ppo_fused_kernel<false>", "jh_gather_kernel": "jh_gather_kernel",
+}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_bench_ppo_cartpole.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs).
+    gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 128-byte requests at 64 bytes ->
+    doubled.  Counter unit: KiB.  None when the summary is not available."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_ppo_cartpole.json")
+    key = _PMC_NAME.get(kernel)
+    if key is None or not os.path.exists(path):
+        return None
+    for name, v in json.load(open(path)).items():
+        if key in name and "FETCH_SIZE_KB_mean" in v and "WRITE_SIZE_KB_mean" in v:
+            return (2.0 * v["FETCH_SIZE_KB_mean"] + v["WRITE_SIZE_KB_mean"]) * 1024.0
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -220,7 +244,7 @@ def main():
         else:
             achieved, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
         out["roofline"] = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                           "traffic": None, "launches": n_launch, "avg_us": avg_s * 1e6, "algorithmic_work_per_launch": per_launch,
+                           "traffic": pmc_traffic(name), "launches": n_launch, "avg_us": avg_s * 1e6, "algorithmic_work_per_launch": per_launch,
                            "note": "latency-bound BASELINE shape (minibatch 256 x hidden 512); see DESIGN.md for scaled shapes"}
         out["kernel_avg_us"] = {k: round(v[1] / v[0] * 1e3, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         out["kernel_total_us_per_learn"] = {k: round(v[1] / n_learn * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
