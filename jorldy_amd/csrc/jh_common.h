@@ -126,6 +126,10 @@ struct jh_pponet {
   unsigned *flag_pin_h = nullptr, *flag_pin_d = nullptr;   // [tiles] per-tile sequence words
   unsigned act_seq = 0;
   uint64_t act_seed = 0, act_ctr = 0;  // host-side counter-based sampling stream
+  // fork/join of the independent backward GEMMs (parallel graph branches under capture)
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  int fork_backward = 1;
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
 };

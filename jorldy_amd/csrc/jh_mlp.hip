@@ -476,6 +476,12 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     memset(n->flag_pin_h, 0, sizeof(unsigned) * tiles);
     n->act_seed = seed;
   }
+  for (int i = 0; i < 2; ++i) {
+    JH_HIP(hipStreamCreateWithFlags(&n->aux[i], hipStreamNonBlocking));
+    JH_HIP(hipEventCreateWithFlags(&n->ev_join[i], hipEventDisableTiming));
+  }
+  JH_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+  if (const char* e = getenv("JH_FORK_BACKWARD")) n->fork_backward = atoi(e);
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
   const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
@@ -492,6 +498,11 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipFree(n->g_all);
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
+  for (int i = 0; i < 2; ++i) {
+    if (n->aux[i]) (void)hipStreamDestroy(n->aux[i]);
+    if (n->ev_join[i]) (void)hipEventDestroy(n->ev_join[i]);
+  }
+  if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
   delete n;
 }
 
@@ -588,19 +599,33 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
   const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
   const int n_out = head_rows(n, w, dw, b, db);
   int rc;
+  // After dh2 three chains are independent: {dW_heads}, {dW2}, {dh1 -> dW1}.  Fork the first two onto
+  // auxiliary streams (parallel branches of the captured graph; concurrent queues when eager) so their
+  // fixed per-kernel cost overlaps with the dh1 -> dW1 chain, and join before returning.
+  const bool fork = n->fork_backward != 0;
+  hipStream_t s_heads = fork ? n->aux[0] : st, s_w2 = fork ? n->aux[1] : st;
+  if (fork) {
+    JH_HIP(hipEventRecord(n->ev_fork, st));
+    JH_HIP(hipStreamWaitEvent(n->aux[0], n->ev_fork, 0));
+    JH_HIP(hipStreamWaitEvent(n->aux[1], n->ev_fork, 0));
+  }
   {  // dWh[o][k] = sum_b g[b][o] h2[b][k] ; dbh[o] = sum_b g[b][o]      (A = g_all^T stored [K=B][8])
     GemmArgs g{};
     g.M = n_out; g.N = H; g.K = B; g.A = n->g_all; g.lda = 8; g.B = n->h2; g.ldb = H;
     for (int o = 0; o < n_out; ++o) { g.rowptr[o] = dw[o]; g.rowsum_ptr[o] = db[o]; }
-    rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 1>("jh_gemm16_bwd_dWheads", g, st);
+    rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 1>("jh_gemm16_bwd_dWheads", g, s_heads);
     if (rc) return rc;
   }
   {  // dW2[o][i] = sum_b dh2[b][o] h1[b][i] ; db2[o] = sum_b dh2[b][o]  (A = dh2^T stored [K=B][M=H])
     GemmArgs g{};
     g.M = H; g.N = H; g.K = B; g.A = n->dh2; g.lda = H; g.B = n->h1; g.ldb = H; g.C = n->grads + n->o_w2; g.ldc = H;
     g.rowsum = n->grads + n->o_b2;
-    rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW2", g, st);
+    rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW2", g, s_w2);
     if (rc) return rc;
+  }
+  if (fork) {
+    JH_HIP(hipEventRecord(n->ev_join[0], n->aux[0]));
+    JH_HIP(hipEventRecord(n->ev_join[1], n->aux[1]));
   }
   {  // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]                 (B = W2 stored [K=H_out][N=H_in])
     GemmArgs g{};
@@ -615,6 +640,10 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     g.C = n->grads + n->o_w1; g.ldc = S; g.rowsum = n->grads + n->o_b1;
     rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW1", g, st);
     if (rc) return rc;
+  }
+  if (fork) {
+    JH_HIP(hipStreamWaitEvent(st, n->ev_join[0], 0));
+    JH_HIP(hipStreamWaitEvent(st, n->ev_join[1], 0));
   }
   return JH_OK;
 }
