@@ -129,7 +129,7 @@ struct jh_pponet {
   // fork/join of the independent backward GEMMs (parallel graph branches under capture)
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  int fork_backward = 1;
+  int fork_backward = 0;  // measured slower on MI355X/ROCm 7.2 (3.54 vs 3.24 ms per iteration): off by default
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
 };
