@@ -9,13 +9,15 @@
 //     batch sees the 1st as its old value) and writes the leaves;
 //   * jh_per_climb_kernel runs one workgroup per tree DEPTH (a node has exactly one depth, so no
 //     two workgroups ever touch the same node) and, for every node hit by the batch, adds the
-//     deltas in ascending batch order, in float64, one rounding per add -- exactly numpy's `+=`.
+//     deltas in ascending batch order, in float64, one rounding per add -- exactly numpy's `+=`;
+//   * both find "the items of one leaf / node, in batch order" with an in-LDS bitonic sort of
+//     (node << 12 | batch position) keys: O(B log^2 B / 256) per workgroup instead of O(B^2).
 // The descent (per_buffer.py:56-68) is a dependent chain of ~log2(N) 8-byte loads per sample:
 // latency-bound, one lane per sample, `num <= left` goes left.
 #include "jh_common.h"
 
 namespace {
-constexpr int kChunk = 2048;  // items per kernel pass (LDS: 2048 * (8+8) B = 32 KiB)
+constexpr int kChunk = 2048;  // items per kernel pass, a power of two <= 4096 (LDS: 2048 * (8+8) B = 32 KiB)
 
 struct PerWs {
   double* delta = nullptr;   // [kChunk]
@@ -47,62 +49,79 @@ __device__ __forceinline__ int node_depth(int64_t i) { return 63 - __clzll((unsi
 #define PER_DISTINCT 1  // caller guarantees all leaves distinct (push of consecutive leaves)
 #define PER_CONTIG 2    // caller guarantees each node's items are contiguous in batch order
 
+// In-LDS bitonic sort of n (power of two, <= kChunk) 64-bit keys by 256 threads.  Keys are
+// (node << 12 | batch position): equal nodes become one contiguous run ordered by batch position,
+// which is exactly the order in which the reference applies its `+= delta` to that node.
+__device__ __forceinline__ void jh_bitonic_sort(unsigned long long* keys, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < n; t += 256) {
+        const int ixj = t ^ j;
+        if (ixj > t) {
+          const unsigned long long a = keys[t], b = keys[ixj];
+          const bool up = (t & k) == 0;
+          if ((a > b) == up) { keys[t] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int jh_pow2_ge(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
 __global__ void __launch_bounds__(256) jh_per_delta_kernel(double* __restrict__ tree, double* __restrict__ maxp, int B,
                                                            const int64_t* __restrict__ idx, int64_t push_start,
                                                            const void* __restrict__ prio, int prio_dt, int mode,
                                                            int64_t tree_size, int64_t first_leaf,
                                                            double* __restrict__ delta_out) {
-  __shared__ int64_t s_idx[kChunk];
+  __shared__ unsigned long long s_key[kChunk];  // (leaf << 12) | i, sorted unless PER_DISTINCT
   __shared__ double s_new[kChunk];
   __shared__ double s_red[16];
   const double cur_max = *maxp;
-  for (int i = threadIdx.x; i < B; i += 256) {
-    int64_t ix = idx ? idx[i] : push_start + i;
-    // a bad index must not corrupt internal nodes: clamp into the leaf range
-    ix = ix < first_leaf ? first_leaf : (ix >= tree_size ? tree_size - 1 : ix);
-    double p;
-    if (!prio) p = cur_max;
-    else if (prio_dt == JH_F32) p = (double)((const float*)prio)[i];  // fp32 tensor .item() -> python float
-    else p = ((const double*)prio)[i];
-    s_idx[i] = ix;
-    s_new[i] = p;
+  const int n2 = jh_pow2_ge(B);
+  double my_max = cur_max;
+  for (int i = threadIdx.x; i < n2; i += 256) {
+    if (i < B) {
+      int64_t ix = idx ? idx[i] : push_start + i;
+      // a bad index must not corrupt internal nodes: clamp into the leaf range
+      ix = ix < first_leaf ? first_leaf : (ix >= tree_size ? tree_size - 1 : ix);
+      double p;
+      if (!prio) p = cur_max;
+      else if (prio_dt == JH_F32) p = (double)((const float*)prio)[i];  // fp32 tensor .item() -> python float
+      else p = ((const double*)prio)[i];
+      s_key[i] = ((unsigned long long)ix << 12) | (unsigned long long)i;
+      s_new[i] = p;
+      my_max = fmax(my_max, p);
+    } else {
+      s_key[i] = ~0ull;
+    }
   }
   __syncthreads();
-  double my_max = cur_max;
-  // every thread owns items i = t, t+256, ...: at most kChunk/256 = 8 of them
-  double old_v[kChunk / 256];
-  bool last_v[kChunk / 256];
-#pragma unroll
-  for (int k = 0; k < kChunk / 256; ++k) {  // fully unrolled: old_v/last_v stay in registers
-    const int i = threadIdx.x + k * 256;
-    old_v[k] = 0.0;
-    last_v[k] = false;
-    if (i < B) {
-      const int64_t ix = s_idx[i];
-      double oldp;
-      bool has_later = false;
-      if (mode & PER_DISTINCT) {
-        oldp = tree[ix];
-      } else {
-        int j = i - 1;
-        while (j >= 0 && s_idx[j] != ix) --j;
-        oldp = j >= 0 ? s_new[j] : tree[ix];
-        for (int q = i + 1; q < B; ++q)
-          if (s_idx[q] == ix) { has_later = true; break; }
-      }
-      old_v[k] = oldp;
-      last_v[k] = !has_later;
-      my_max = fmax(my_max, s_new[i]);
-    }
+  if (!(mode & PER_DISTINCT)) jh_bitonic_sort(s_key, n2);
+  // sorted position q holds item i = key & 4095 of leaf key >> 12.  Within a run of equal leaves the
+  // reference sees: old = tree[leaf] for the first write, the previous write's value afterwards, and
+  // the leaf ends up with the last write (per_buffer.py:42-46 applied in batch order).
+  for (int q = threadIdx.x; q < B; q += 256) {
+    const unsigned long long kq = s_key[q];
+    const int i = (int)(kq & 4095ull);
+    const int64_t leaf = (int64_t)(kq >> 12);
+    const bool head = q == 0 || (s_key[q - 1] >> 12) != (unsigned long long)leaf;
+    const bool tail = q == B - 1 || (s_key[q + 1] >> 12) != (unsigned long long)leaf;
+    const double oldp = head ? tree[leaf] : s_new[(int)(s_key[q - 1] & 4095ull)];
+    delta_out[i] = s_new[i] - oldp;
+    (void)tail;  // the leaf itself is written by the run tail, after the barrier below
   }
   __syncthreads();  // all leaf reads are done before any leaf is overwritten
-#pragma unroll
-  for (int k = 0; k < kChunk / 256; ++k) {
-    const int i = threadIdx.x + k * 256;
-    if (i < B) {
-      delta_out[i] = s_new[i] - old_v[k];
-      if (last_v[k]) tree[s_idx[i]] = s_new[i];
-    }
+  for (int q = threadIdx.x; q < B; q += 256) {
+    const unsigned long long kq = s_key[q];
+    const int64_t leaf = (int64_t)(kq >> 12);
+    const bool tail = q == B - 1 || (s_key[q + 1] >> 12) != (unsigned long long)leaf;
+    if (tail) tree[leaf] = s_new[(int)(kq & 4095ull)];
   }
   const double m = jh_block_reduce(my_max, s_red, JhMax(), 0.0);
   if (threadIdx.x == 0) *maxp = m;  // max(max_priority, new...) per_buffer.py:48
@@ -112,34 +131,34 @@ __global__ void __launch_bounds__(256) jh_per_climb_kernel(double* __restrict__ 
                                                            const int64_t* __restrict__ idx, int64_t push_start,
                                                            const double* __restrict__ delta, int mode,
                                                            int64_t tree_size, int64_t first_leaf) {
-  __shared__ int64_t s_node[kChunk];
+  __shared__ unsigned long long s_key[kChunk];  // (node << 12) | i ; ~0 for items without a node at this depth
   __shared__ double s_delta[kChunk];
   const int d = blockIdx.x;  // this workgroup owns every node at depth d
-  for (int i = threadIdx.x; i < B; i += 256) {
-    int64_t ix = idx ? idx[i] : push_start + i;
-    ix = ix < first_leaf ? first_leaf : (ix >= tree_size ? tree_size - 1 : ix);
-    const int dep = node_depth(ix);
-    s_node[i] = dep > d ? (((ix + 1) >> (dep - d)) - 1) : -1;
-    s_delta[i] = delta[i];
+  const int n2 = jh_pow2_ge(B);
+  for (int i = threadIdx.x; i < n2; i += 256) {
+    unsigned long long key = ~0ull;
+    if (i < B) {
+      int64_t ix = idx ? idx[i] : push_start + i;
+      ix = ix < first_leaf ? first_leaf : (ix >= tree_size ? tree_size - 1 : ix);
+      const int dep = node_depth(ix);
+      if (dep > d) key = ((unsigned long long)(((ix + 1) >> (dep - d)) - 1) << 12) | (unsigned long long)i;
+      s_delta[i] = delta[i];
+    }
+    s_key[i] = key;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < B; i += 256) {
-    const int64_t node = s_node[i];
-    if (node < 0) continue;
-    if (mode & PER_CONTIG) {
-      if (i > 0 && s_node[i - 1] == node) continue;  // not the head of this node's run
-      double v = tree[node];
-      for (int j = i; j < B && s_node[j] == node; ++j) v += s_delta[j];
-      tree[node] = v;
-    } else {
-      int j = i - 1;
-      while (j >= 0 && s_node[j] != node) --j;
-      if (j >= 0) continue;  // an earlier item owns this node
-      double v = tree[node];
-      for (int q = i; q < B; ++q)
-        if (s_node[q] == node) v += s_delta[q];
-      tree[node] = v;
-    }
+  // pushes of consecutive leaves (split at the wrap and the depth boundary by the host) already have
+  // every node's items contiguous and in order; general write-backs are sorted
+  if (!(mode & PER_CONTIG)) jh_bitonic_sort(s_key, n2);
+  for (int q = threadIdx.x; q < B; q += 256) {
+    const unsigned long long kq = s_key[q];
+    if (kq == ~0ull) continue;
+    const unsigned long long node = kq >> 12;
+    if (q > 0 && (s_key[q - 1] >> 12) == node) continue;  // not the head of this node's run
+    // ordered float64 chain: tree[node] += delta for every item that reaches the node, in batch order
+    double v = tree[node];
+    for (int j = q; j < B && (s_key[j] >> 12) == node && s_key[j] != ~0ull; ++j) v += s_delta[(int)(s_key[j] & 4095ull)];
+    tree[node] = v;
   }
 }
 
