@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) jh_per_climb_kernel(double* __restrict__ 
                                                            int64_t tree_size, int64_t first_leaf) {
   __shared__ unsigned long long s_key[kChunk];  // (node << 12) | i ; ~0 for items without a node at this depth
   __shared__ double s_delta[kChunk];
+  __shared__ double s_sd[kChunk];
   const int d = blockIdx.x;  // this workgroup owns every node at depth d
   const int n2 = jh_pow2_ge(B);
   for (int i = threadIdx.x; i < n2; i += 256) {
@@ -150,14 +151,37 @@ __global__ void __launch_bounds__(256) jh_per_climb_kernel(double* __restrict__ 
   // pushes of consecutive leaves (split at the wrap and the depth boundary by the host) already have
   // every node's items contiguous and in order; general write-backs are sorted
   if (!(mode & PER_CONTIG)) jh_bitonic_sort(s_key, n2);
+  // deltas in sorted order, so the serial chain below streams LDS instead of chasing an index
+  for (int q = threadIdx.x; q < B; q += 256) {
+    const unsigned long long kq = s_key[q];
+    s_sd[q] = kq == ~0ull ? 0.0 : s_delta[(int)(kq & 4095ull)];
+  }
+  __syncthreads();
   for (int q = threadIdx.x; q < B; q += 256) {
     const unsigned long long kq = s_key[q];
     if (kq == ~0ull) continue;
     const unsigned long long node = kq >> 12;
     if (q > 0 && (s_key[q - 1] >> 12) == node) continue;  // not the head of this node's run
+    // end of the run: first sorted position whose key exceeds (node, 4095) -- binary search
+    const unsigned long long hi_key = (node << 12) | 4095ull;
+    int lo = q, hi = B;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_key[mid] <= hi_key) lo = mid + 1;
+      else hi = mid;
+    }
     // ordered float64 chain: tree[node] += delta for every item that reaches the node, in batch order
+    // (the loads do not depend on v, so they pipeline; only the adds are serial)
     double v = tree[node];
-    for (int j = q; j < B && (s_key[j] >> 12) == node && s_key[j] != ~0ull; ++j) v += s_delta[(int)(s_key[j] & 4095ull)];
+    int j = q;
+    for (; j + 4 <= lo; j += 4) {
+      const double d0 = s_sd[j], d1 = s_sd[j + 1], d2 = s_sd[j + 2], d3 = s_sd[j + 3];
+      v += d0;
+      v += d1;
+      v += d2;
+      v += d3;
+    }
+    for (; j < lo; ++j) v += s_sd[j];
     tree[node] = v;
   }
 }
