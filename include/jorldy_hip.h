@@ -103,6 +103,7 @@ int64_t jh_store_size(const jh_store* s);          /* buffer_counter */
 int64_t jh_store_index(const jh_store* s);         /* buffer_index   */
 int64_t jh_store_capacity(const jh_store* s);
 void jh_store_clear(jh_store* s);                  /* rollout_buffer.py:19 */
+int jh_store_set_position(jh_store* s, int64_t index, int64_t counter); /* checkpoint restore */
 
 /* ------------------------------------------------------------------ prioritized replay
  * Device-resident float64 sum tree, array-heap layout identical to

@@ -50,6 +50,7 @@ _PROTOS = {
     "jh_store_index": (_i64, [_vp]),
     "jh_store_capacity": (_i64, [_vp]),
     "jh_store_clear": (None, [_vp]),
+    "jh_store_set_position": (C.c_int, [_vp, _i64, _i64]),
     "jh_per_create": (C.c_int, [_vp, _i64, _f64, _pp]),
     "jh_per_destroy": (None, [_vp]),
     "jh_per_push": (C.c_int, [_vp, _i64, _vp, _vp]),

@@ -67,6 +67,42 @@ class BaseAgent(ABC):
             for g in optimizer.param_groups:
                 g["lr"] = optimizer.defaults["lr"] * weight
 
+    # ---- complete checkpoint (beyond the reference's {"network", "optimizer"} ckpt) -------------------
+    _RESUME_ATTRS = ("time_t", "learn_stamp", "num_learn", "epsilon", "beta", "target_update_stamp", "learn_period_stamp",
+                     "num_transitions", "_adam_steps")
+
+    def save_full(self, path):
+        """`save(path)` (reference format, unchanged) + `resume.pt`: replay buffer / sum tree contents,
+        step counters, epsilon / beta, numpy + torch RNG state -- what the reference cannot resume."""
+        import os
+
+        self.save(path)
+        extra = {"attrs": {k: getattr(self, k) for k in self._RESUME_ATTRS if hasattr(self, k)},
+                 "numpy_rng": np.random.get_state(), "torch_rng": torch.get_rng_state(), "torch_cuda_rng": torch.cuda.get_rng_state(self.device)}
+        mem = getattr(self, "memory", None)
+        if mem is not None and hasattr(mem, "state_dict"):
+            extra["memory"] = mem.state_dict()
+        if hasattr(self, "target_network"):
+            extra["target_network"] = {k: v.cpu() for k, v in self.target_network.state_dict().items()}
+        torch.save(extra, os.path.join(path, "resume.pt"))
+
+    def load_full(self, path):
+        import os
+
+        self.load(path)
+        extra = torch.load(os.path.join(path, "resume.pt"), map_location="cpu", weights_only=False)
+        for k, v in extra["attrs"].items():
+            setattr(self, k, v)
+        np.random.set_state(extra["numpy_rng"])
+        torch.set_rng_state(extra["torch_rng"])
+        torch.cuda.set_rng_state(extra["torch_cuda_rng"], self.device)
+        if "memory" in extra and hasattr(self.memory, "load_state_dict"):
+            self.memory.load_state_dict(extra["memory"])
+        if "target_network" in extra:
+            self.target_network.load_state_dict(extra["target_network"])
+        if getattr(self, "_net", None) is not None:
+            self._import_optim_state()
+
     @staticmethod
     def _require_gpu(device):
         dev = torch.device(device) if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")

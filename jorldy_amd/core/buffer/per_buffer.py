@@ -72,6 +72,17 @@ class PERBuffer(ReplayBuffer):
         stats = stats.clone()
         return transitions, w32, idx, stats[0], stats[1]
 
+    # -- complete checkpoints --------------------------------------------------------------------------
+    def state_dict(self):
+        sd = super().state_dict()
+        st = self._tree.state()
+        sd.update({"sum_tree": self._tree.dump(), "max_priority": st["max_priority"], "tree_index": st["tree_index"]})
+        return sd
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self._tree.load(sd["sum_tree"], sd["max_priority"], sd["tree_index"], sd["buffer_counter"])
+
     # -- state the reference exposes ----------------------------------------------------------------
     @property
     def sum_tree(self):

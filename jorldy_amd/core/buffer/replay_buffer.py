@@ -45,6 +45,42 @@ class ReplayBuffer(BaseBuffer):
         idx = h2d_small(self.sample_indices(batch_size).astype(np.int64), self.device)
         return self.gather(idx, as_float=as_float)
 
+    # ---- complete checkpoints (the reference saves network + optimizer only,
+    # so a resumed run restarts with an empty buffer; core/agent/dqn.py:184-199) ---------------------
+    def state_dict(self):
+        """Host copy of everything needed to resume: stored rows (in slot order), ring position."""
+        cols = {}
+        if self._store is not None:
+            import torch
+
+            torch.cuda.current_stream().synchronize()
+            for name in self._store.names:
+                cols[name] = self._store.column(name)[: self.buffer_counter].cpu().numpy()
+        return {"buffer_size": self.buffer_size, "buffer_index": self.buffer_index, "buffer_counter": self.buffer_counter,
+                "layout": self._layout, "columns": cols}
+
+    def load_state_dict(self, sd):
+        assert sd["buffer_size"] == self.buffer_size
+        self._layout = None
+        self._store = None
+        self.buffer_index = self.buffer_counter = 0
+        if sd["columns"]:
+            layout = sd["layout"]
+            cols = {}
+            for key, sub, name in layout:
+                if sub is None:
+                    cols[key] = sd["columns"][name]
+                else:
+                    cols.setdefault(key, []).append(sd["columns"][name])
+            ReplayBuffer.store_soa(self, cols)
+        self.buffer_index = sd["buffer_index"]
+        self.buffer_counter = sd["buffer_counter"]
+        if self._store is not None:  # ring position of the device store follows the host counters
+            import ctypes as C
+
+            self._store.lib.jh_store_clear(self._store.h)
+            self._store.lib.jh_store_set_position(self._store.h, C.c_int64(self.buffer_index), C.c_int64(self.buffer_counter))
+
     @property
     def size(self):
         return self.buffer_counter

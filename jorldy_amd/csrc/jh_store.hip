@@ -240,6 +240,14 @@ JH_EXPORT void* jh_store_col_ptr(jh_store* s, int32_t col) {
 JH_EXPORT int64_t jh_store_size(const jh_store* s) { return s ? s->counter : -1; }
 JH_EXPORT int64_t jh_store_index(const jh_store* s) { return s ? s->index : -1; }
 JH_EXPORT int64_t jh_store_capacity(const jh_store* s) { return s ? s->capacity : -1; }
+JH_EXPORT int jh_store_set_position(jh_store* s, int64_t index, int64_t counter) {
+  JH_ARG(s != nullptr);
+  JH_ARG(index >= 0 && index < s->capacity && counter >= 0 && counter <= s->capacity);
+  s->index = index;
+  s->counter = counter;
+  return JH_OK;
+}
+
 JH_EXPORT void jh_store_clear(jh_store* s) {
   if (!s) return;
   s->index = 0;
