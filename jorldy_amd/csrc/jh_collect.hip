@@ -21,6 +21,7 @@ void jh_persist_destroy(jh_persist* p);
 int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st);
 int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action, int training);
 void jh_persist_abort(jh_persist* p);
+void jh_persist_dump_debug(jh_persist* p, int T);
 
 
 struct jh_collector {
@@ -121,6 +122,7 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
     c->t_env += std::chrono::duration<double>(t2 - t1).count();
     c->steps += 1;
   }
+  if (persistent && getenv("JH_PERSIST_DEBUG") && (c->steps % (64 * T)) == 0) jh_persist_dump_debug(c->persist, T);
   return jh_store_stage_commit(c->store, stream);
 }
 

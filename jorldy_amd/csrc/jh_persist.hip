@@ -33,6 +33,7 @@ struct PersistArgs {
   unsigned* abort_flag;                // pinned: set by the kernel on timeout / by the host to stop early
   unsigned seq0;                       // tag of the first step (tags are seq0+1 .. seq0+T)
   long max_polls;
+  unsigned long long* dbg;             // optional pinned [T][8]: per-step timestamps of workgroup 0 (diagnostics)
 };
 
 __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
@@ -88,23 +89,32 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
       if (lane == 0) s_go = ok ? 1 : 0;
     }
     __syncthreads();
+    if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 0] = wall_clock64(); p.dbg[(t - 1) * 8 + 1] = __builtin_readcyclecounter(); }
     if (!s_go) {  // timeout or host abort: tell the host and leave (all workgroups decide alike or time out too)
       if (threadIdx.x == 0) __hip_atomic_store(p.abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
-    // ---- layer 1 for the (<=16) env rows: lane k owns hidden unit k
-    for (int k = threadIdx.x; k < H; k += 256) {
-      float accr[16];
-      const float bk = b1s[k];
+    // ---- layer 1 for the (<=16) env rows ON THE MFMA: h1[16 x H] = x[16 x S] * W1^T[S x H].  K = S is
+    // tiny (one 16x16x4 MFMA per 16 hidden units when S <= 4), and this form needs one LDS read per
+    // tile instead of re-reading every observation for every hidden unit (the VALU version spent
+    // 3.2 us per step issuing ~170 LDS instructions per wave; this one ~0.2 us).
+    {
+      const int u_per_wave = H / 4;  // hidden units of this wave (H % 64 == 0)
+      for (int u0 = wid * u_per_wave; u0 < (wid + 1) * u_per_wave; u0 += 16) {
+        f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < S; q0 += 4) {
+          const int q = q0 + kq;
+          const float av = (r < p.W && q < S) ? xs[r * S + q] : 0.f;       // A[row r][k = q]
+          const float bv = q < S ? w1s[(u0 + r) * S + q] : 0.f;            // B[k = q][unit u0 + r]
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c1, 0, 0, 0);
+        }
+        const float bb = b1s[u0 + r];
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) accr[rr] = bk;
-      for (int q = 0; q < S; ++q) {
-        const float wq = w1s[k * S + q];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) accr[rr] = fmaf(rr < p.W ? xs[rr * S + q] : 0.f, wq, accr[rr]);
+        for (int i = 0; i < 4; ++i) {  // C: col = lane & 15 -> unit u0 + r, row = kq * 4 + i -> env row
+          const float v = c1[i] + bb;
+          h1s[(kq * 4 + i) * ldh + u0 + r] = v > 0.f ? v : 0.f;
+        }
       }
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) h1s[rr * ldh + k] = accr[rr] > 0.f ? accr[rr] : 0.f;
     }
     __syncthreads();
     // ---- h2 tile = h1 (16 x H) * W2_tile^T (H x 16): fp32 MFMA, this wave's K quarter
@@ -123,6 +133,10 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
     __syncthreads();
     if (wid == 0) {
       // C/D fragment: col = lane & 15 (hidden-2 column n0 + r), row = kq * 4 + i (env row)
+      // h2 tile -> LDS (transposed into A-operand order), then the head partials
+      //   part[row][o] = sum_col h2[row][col] * Wh[o][n0 + col]
+      // are ONE more 16x16x16 product on the MFMA (4 steps) -- no cross-lane shuffles at all.
+      float* h2s = s_acc;  // [16 rows][17]: safe to overwrite, every wave's partials were consumed above
       float hv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -131,18 +145,23 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
         v += misc[r];
         hv[i] = v > 0.f ? v : 0.f;
       }
-      for (int o = 0; o < p.n_out; ++o) {
-        const float w = whs[o * 16 + r];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float q = hv[i] * w;
-          q += __shfl_xor(q, 1, 64);
-          q += __shfl_xor(q, 2, 64);
-          q += __shfl_xor(q, 4, 64);
-          q += __shfl_xor(q, 8, 64);
-          const int row = kq * 4 + i;
-          if (r == 0) outs_s[row * 4 + o] = q + (tile == 0 ? misc[16 + o] : 0.f);
-        }
+      for (int i = 0; i < 4; ++i) h2s[(kq * 4 + i) * 17 + r] = hv[i];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      f32x4 ph = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float av = h2s[r * 17 + 4 * c + kq];                           // A[row r][k = col 4c+kq]
+        const float bv = r < p.n_out ? whs[r * 16 + 4 * c + kq] : 0.f;       // B[k = col][n = output r]
+        ph = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, ph, 0, 0, 0);
+      }
+      // ph: col = lane & 15 -> output o = r, row = kq * 4 + i -> env row
+      if (r < p.n_out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outs_s[(kq * 4 + i) * 4 + r] = ph[i] + (tile == 0 ? misc[16 + r] : 0.f);
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -161,6 +180,7 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
       }
     }
     __syncthreads();  // s_acc / h1s are reused by the next step
+    if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 4] = wall_clock64(); p.dbg[(t - 1) * 8 + 5] = __builtin_readcyclecounter(); }
   }
 }
 
@@ -174,6 +194,7 @@ struct jh_persist {
   unsigned seq = 0;
   int tiles = 0;
   size_t lds = 0;
+  unsigned long long *dbg_h = nullptr, *dbg_d = nullptr;
 };
 
 int jh_persist_create(jh_pponet* n, jh_persist** out) {
@@ -198,6 +219,12 @@ int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
   memset(p->gran_h, 0, sizeof(unsigned long long) * 16 * (size_t)S);
   memset(p->flag_h, 0, sizeof(unsigned) * (size_t)(p->tiles + 16));
+  if (getenv("JH_PERSIST_DEBUG")) {
+    // timestamps go to DEVICE memory (a store to host memory would stall the wave at the next barrier
+    // until the PCIe write is acknowledged and distort the measurement)
+    p->dbg_h = (unsigned long long*)malloc(sizeof(unsigned long long) * 8 * 4096);
+    JH_HIP(hipMalloc((void**)&p->dbg_d, sizeof(unsigned long long) * 8 * 4096));
+  }
   p->seq = 1000;  // tags never collide with the zero-initialised granules
   *out = p;
   return JH_OK;
@@ -224,6 +251,7 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.n_out = o;
   a.obs_gran = p->gran_d; a.part = p->part_d; a.tile_flag = p->flag_d; a.abort_flag = p->flag_d + p->tiles;
   a.seq0 = p->seq;
+  a.dbg = p->dbg_d;
   a.max_polls = 400000;  // x (~0.5 us per poll) = ~0.2 s without observations -> give up
   p->flag_h[p->tiles] = 0;
   JH_LAUNCH(jh_act_persist_kernel, dim3(p->tiles), dim3(256), p->lds, st, a);
@@ -293,6 +321,25 @@ int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action,
   }
   n->act_ctr += 1;
   return JH_OK;
+}
+
+// Diagnostics: print per-step phase durations of workgroup 0 for the last rollout.
+void jh_persist_dump_debug(jh_persist* p, int T) {
+  if (!p->dbg_h) return;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(p->dbg_h, p->dbg_d, sizeof(unsigned long long) * 8 * (size_t)T, hipMemcpyDeviceToHost);
+  double a = 0, b = 0, c = 0, cyc = 0;
+  for (int t = 1; t < T; ++t) {
+    const unsigned long long* d = p->dbg_h + (size_t)t * 8;
+    const unsigned long long* pr = p->dbg_h + (size_t)(t - 1) * 8;
+    a += (double)(d[0] - pr[4]);   // wait for observations (incl. host work + PCIe), 100 MHz ticks
+    b += (double)(d[2] - d[0]);    // layer 1
+    c += (double)(d[4] - d[2]);    // MFMA + combine + heads + store
+    cyc += (double)(d[5] - d[1]) / ((double)(d[4] - d[0]) + 1e-9);  // shader cycles per 10 ns tick
+  }
+  const double n = T - 1;
+  fprintf(stderr, "[jh_persist] per step (wall_clock64 ticks = 10 ns): wait %.1f  layer1 %.1f  gemm+heads %.1f ; shader clock ~%.0f MHz\n",
+          a / n, b / n, c / n, cyc / n * 100.0);
 }
 
 // Stop a running kernel early (error paths): it sees the word at its next poll and exits.
