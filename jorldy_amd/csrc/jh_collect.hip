@@ -57,7 +57,7 @@ JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env,
   c->ctx = ctx; c->net = net; c->env = env; c->store = store; c->W = env->W;
   c->col_state = cols[0]; c->col_action = cols[1]; c->col_reward = cols[2]; c->col_next = cols[3]; c->col_done = cols[4];
   if (const char* e = getenv("JH_COLLECT_PERSISTENT")) c->mode = atoi(e);
-  if (c->mode == 1 && c->W <= 16 && net->H % 64 == 0) {
+  if (c->mode == 1 && c->W <= 16 && net->H % 128 == 0 && net->A + 1 <= 3) {
     if (jh_persist_create(net, &c->persist) != JH_OK) c->persist = nullptr;  // e.g. LDS too small: fall back
   }
   c->obs.resize(4 * (size_t)c->W);

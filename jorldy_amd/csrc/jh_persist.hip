@@ -33,7 +33,8 @@ struct PersistArgs {
   unsigned* abort_flag;                // pinned: set by the kernel on timeout / by the host to stop early
   unsigned seq0;                       // tag of the first step (tags are seq0+1 .. seq0+T)
   long max_polls;
-  unsigned long long* dbg;             // optional pinned [T][8]: per-step timestamps of workgroup 0 (diagnostics)
+  unsigned long long* dbg;             // optional [T][8]: per-step timestamps of workgroup 0 (diagnostics)
+  int poll_sleep;                      // back-off between polls: 0 none, 1 s_sleep 1, 2 s_sleep 8, 3 s_sleep 32
 };
 
 __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
@@ -84,7 +85,9 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
         }
         if (__all(mine)) { ok = true; break; }
         if ((spin & 63) == 63 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        __builtin_amdgcn_s_sleep(8);
+        if (p.poll_sleep == 1) __builtin_amdgcn_s_sleep(1);
+        else if (p.poll_sleep == 2) __builtin_amdgcn_s_sleep(8);
+        else if (p.poll_sleep == 3) __builtin_amdgcn_s_sleep(32);
       }
       if (lane == 0) s_go = ok ? 1 : 0;
     }
@@ -100,7 +103,8 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
     // 3.2 us per step issuing ~170 LDS instructions per wave; this one ~0.2 us).
     {
       const int u_per_wave = H / 4;  // hidden units of this wave (H % 64 == 0)
-      for (int u0 = wid * u_per_wave; u0 < (wid + 1) * u_per_wave; u0 += 16) {
+#pragma unroll 4
+      for (int u0 = wid * u_per_wave; u0 < (wid + 1) * u_per_wave; u0 += 16) {  // independent tiles: overlap their LDS/MFMA latencies
         f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int q0 = 0; q0 < S; q0 += 4) {
           const int q = q0 + kq;
@@ -117,17 +121,29 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
       }
     }
     __syncthreads();
+    if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 2] = wall_clock64(); p.dbg[(t - 1) * 8 + 3] = __builtin_readcyclecounter(); }
     // ---- h2 tile = h1 (16 x H) * W2_tile^T (H x 16): fp32 MFMA, this wave's K quarter
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kbeg; k0 < kbeg + kper; k0 += 16) {
+    // two independent accumulators (the 16x16x4 fp32 MFMA has a 40-cycle dependent latency vs a
+    // 32-cycle issue interval) and an unrolled body so the ds_read_b128 of later chunks are in flight
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = kbeg; k0 < kbeg + kper; k0 += 32) {
       const int kb = k0 + 4 * kq;
       const float4 av = *reinterpret_cast<const float4*>(h1s + r * ldh + kb);
       const float4 bv = *reinterpret_cast<const float4*>(w2s + r * ldh + kb);
+      const float4 av2 = *reinterpret_cast<const float4*>(h1s + r * ldh + kb + 16);
+      const float4 bv2 = *reinterpret_cast<const float4*>(w2s + r * ldh + kb + 16);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.x, bv2.x, acc2, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.y, bv2.y, acc2, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.z, bv2.z, acc2, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.w, bv2.w, acc2, 0, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += acc2[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_acc[(wid * 64 + lane) * 4 + i] = acc[i];
     __syncthreads();
@@ -199,7 +215,7 @@ struct jh_persist {
 
 int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_ARG(n && out);
-  JH_ARG(!n->cont && n->H % 64 == 0 && n->A + 1 <= 3 && (16 * n->S) % 4 == 0);
+  JH_ARG(!n->cont && n->H % 128 == 0 && n->A + 1 <= 3 && (16 * n->S) % 4 == 0);
   jh_persist* p = new jh_persist();
   p->net = n;
   p->tiles = n->H / 16;
@@ -252,6 +268,8 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.obs_gran = p->gran_d; a.part = p->part_d; a.tile_flag = p->flag_d; a.abort_flag = p->flag_d + p->tiles;
   a.seq0 = p->seq;
   a.dbg = p->dbg_d;
+  a.poll_sleep = 2;
+  if (const char* e = getenv("JH_PERSIST_SLEEP")) a.poll_sleep = atoi(e);
   a.max_polls = 400000;  // x (~0.5 us per poll) = ~0.2 s without observations -> give up
   p->flag_h[p->tiles] = 0;
   JH_LAUNCH(jh_act_persist_kernel, dim3(p->tiles), dim3(256), p->lds, st, a);
