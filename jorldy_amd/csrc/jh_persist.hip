@@ -103,7 +103,6 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
     // 3.2 us per step issuing ~170 LDS instructions per wave; this one ~0.2 us).
     {
       const int u_per_wave = H / 4;  // hidden units of this wave (H % 64 == 0)
-#pragma unroll 4
       for (int u0 = wid * u_per_wave; u0 < (wid + 1) * u_per_wave; u0 += 16) {  // independent tiles: overlap their LDS/MFMA latencies
         f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int q0 = 0; q0 < S; q0 += 4) {
@@ -126,7 +125,6 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
     // two independent accumulators (the 16x16x4 fp32 MFMA has a 40-cycle dependent latency vs a
     // 32-cycle issue interval) and an unrolled body so the ds_read_b128 of later chunks are in flight
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
     for (int k0 = kbeg; k0 < kbeg + kper; k0 += 32) {
       const int kb = k0 + 4 * kq;
       const float4 av = *reinterpret_cast<const float4*>(h1s + r * ldh + kb);
