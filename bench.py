@@ -217,6 +217,7 @@ def main():
                 for _ in range(6):
                     agent._graph.replay()
             ops.lib_profile(True)
+            ops.lib_profile_calibrate(64)
             agent.process(transitions, step)
             prof_part = ops.lib_profile_report()
             ops.lib_profile(False)
@@ -234,6 +235,11 @@ def main():
             "jh_gradnorm_kernel": ("hbm", n_updates * 4.0 * 266755),
             "jh_gather_kernel": ("hbm", M * (44.0 + 44.0 - 7 - 3)),
         }
+        # every event pair carries a fixed recording overhead (~2 us on MI355X): measured with empty pairs in
+        # the same passes and subtracted, so the figures agree with rocprofv3's kernel durations
+        n_cal, ms_cal = prof.pop("__event_pair_overhead", (1, 0.0))
+        ovh_ms = ms_cal / n_cal
+        prof = {k: (v[0], max(v[1] - v[0] * ovh_ms, 1e-6)) for k, v in prof.items()}
         name, (n_launch, ms_total) = max(prof.items(), key=lambda kv: kv[1][1])
         bound, per_learn = work.get(name, ("hbm", 0.0))
         n_learn = 3
@@ -244,7 +250,7 @@ def main():
         else:
             achieved, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
         out["roofline"] = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                           "traffic": pmc_traffic(name), "launches": n_launch, "avg_us": avg_s * 1e6, "algorithmic_work_per_launch": per_launch,
+                           "traffic": pmc_traffic(name), "launches": n_launch, "avg_us": avg_s * 1e6, "algorithmic_work_per_launch": per_launch, "event_pair_overhead_us_subtracted": ovh_ms * 1e3,
                            "note": "latency-bound BASELINE shape (minibatch 256 x hidden 512); see DESIGN.md for scaled shapes"}
         out["kernel_avg_us"] = {k: round(v[1] / v[0] * 1e3, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         out["kernel_total_us_per_learn"] = {k: round(v[1] / n_learn * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}

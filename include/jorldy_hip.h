@@ -65,6 +65,7 @@ void jh_pinned_free(void* host);
  * "<kernel>\t<launches>\t<total_ms>\n" lines into buf.                                          */
 int jh_prof_enable(int32_t on);
 int jh_prof_report(char* buf, int64_t cap);
+int jh_prof_calibrate(int32_t n, jh_stream stream); /* n empty event pairs -> "__event_pair_overhead" */
 
 /* ------------------------------------------------------------------ transition store
  * GPU-resident struct-of-arrays ring that replaces the list-of-dicts storage of
@@ -229,6 +230,16 @@ int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t*
 /* torch.nn.utils.clip_grad_norm_(max_norm) (skipped if max_norm <= 0) + torch.optim.Adam.step
  * on the flat buckets (ppo.py:166-169).  d_norm_out: optional device float, pre-clip norm.      */
 int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_out, jh_stream stream);
+/* One whole PPO minibatch update (ppo.py:122-169: forward of `state[idx]`, clipped loss forward +
+ * backward, encoder backward, clip_grad_norm_, Adam) in 8 launches: the heads never round-trip through
+ * HBM as tensors (per-column-tile partials are summed by the loss kernel) and the global gradient norm
+ * is accumulated by the gradient GEMMs.  B <= 1024.  do_adam == 0 stops before clip + Adam
+ * (data-parallel: all-reduce the bucket, then jh_pponet_adam_step).  d_stats float32[8] as in
+ * jh_ppo_loss_*.                                                                                  */
+int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action,
+                         const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old,
+                         float eps_clip, float vf_coef, float ent_coef, float max_norm, int32_t do_adam, float* d_stats,
+                         jh_stream stream);
 /* PPO.act for W envs in one shot (ppo.py:55-69, discrete): ONE kernel launch computes the fused MLP
  * forward and writes per-column-tile partial head outputs + sequence words into device-mapped
  * pinned memory; the host polls them, sums the partials, and does softmax + multinomial (argmax

@@ -36,6 +36,7 @@ _PROTOS = {
     "jh_ctx_sync": (C.c_int, [_vp, _vp]),
     "jh_prof_enable": (C.c_int, [_i32]),
     "jh_prof_report": (C.c_int, [C.c_char_p, _i64]),
+    "jh_prof_calibrate": (C.c_int, [_i32, _vp]),
     "jh_pinned_alloc": (C.c_int, [_vp, _i64, _pp, _pp]),
     "jh_pinned_free": (None, [_vp]),
     "jh_store_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _pp]),
@@ -76,6 +77,7 @@ _PROTOS = {
     "jh_pponet_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_backward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_adam_step": (C.c_int, [_vp, _f32, _vp, _vp]),
+    "jh_pponet_ppo_update": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "jh_pponet_act_discrete": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jh_collector_create": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
     "jh_collector_destroy": (None, [_vp]),

@@ -71,6 +71,7 @@ class PPO(BaseAgent):
             raise ValueError("backend='native' needs head='mlp', an int state_size, Adam without weight decay and <= 8 head outputs")
         self.backend = "native" if (eligible and backend != "torch") else "torch"
         self.use_graph = use_graph
+        self.fused_update = os.environ.get("JH_FUSED_UPDATE", "1") != "0"
         self._net = None
         self._graph = None
         self._static = None
@@ -242,6 +243,15 @@ class PPO(BaseAgent):
             for offset in range(0, M, B):
                 b = min(B, M - offset)
                 idx = st["idx"][e * M + offset : e * M + offset + b]
+                if b <= 1024 and self.fused_update:
+                    # forward + loss + backward (+ clip + Adam) in 8 launches (jh_pponet_ppo_update)
+                    net.ppo_update(tr["state"], idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef,
+                                   self.ent_coef, self.clip_grad_norm, st["stats"][k], do_adam=self.grad_sync is None)
+                    if self.grad_sync is not None:
+                        self.grad_sync.reduce_flat(net.grads)
+                        net.adam_step(self.clip_grad_norm)
+                    k += 1
+                    continue
                 if cont:
                     mu, ls, vp = net.forward(tr["state"], idx=idx, out=(st["mb_h0"][:b], st["mb_h1"][:b], st["mb_v"][:b]))
                     g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu, ls, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])

@@ -130,6 +130,11 @@ struct jh_pponet {
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   int fork_backward = 0;  // measured slower on MI355X/ROCm 7.2 (3.54 vs 3.24 ms per iteration): off by default
+  float* fwd_part = nullptr;      // [H/16][max_rows][8] per-column-tile partial head outputs (fused forward)
+  float* g_heads = nullptr;       // [max_rows][2A+1] d(loss)/d(raw heads) of the fused update
+  float* ssq_part = nullptr;      // per-workgroup sums of squares written by the gradient GEMMs
+  int ssq_slots = 0;
+  unsigned* adam_ticket = nullptr;
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
 };

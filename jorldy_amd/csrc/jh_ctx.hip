@@ -154,6 +154,17 @@ void jh_prof_end(hipStream_t st) {
   if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, st);
 }
 
+// Record n back-to-back event pairs with nothing in between under the name "__event_pair_overhead":
+// the fixed cost that every measured kernel duration includes (subtracted by bench.py).
+JH_EXPORT int jh_prof_calibrate(int32_t n, jh_stream stream) {
+  if (!g_jh_prof_on) return jh_fail(JH_ERR_STATE, "jh_prof_calibrate: profiling is off");
+  for (int i = 0; i < n; ++i) {
+    jh_prof_begin("__event_pair_overhead", jh_s(stream));
+    jh_prof_end(jh_s(stream));
+  }
+  return JH_OK;
+}
+
 JH_EXPORT int jh_prof_enable(int32_t on) {
   for (auto& r : g_prof) {
     (void)hipEventDestroy(r.e0);

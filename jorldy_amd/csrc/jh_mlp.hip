@@ -79,6 +79,10 @@ struct GemmArgs {
   const float* hbias[8];  // bias of head output o, added by column-tile 0
   unsigned* tile_flag;   // optional [tiles] (device-mapped pinned host words): set to flag_seq per tile
   unsigned flag_seq;
+  float* h1_out;         // A_MODE 2: column-tile 0 also materialises the generated layer-1 tile (for backward)
+  int ldh1;
+  float* ssq_out;        // optional [workgroups]: sum of squares of everything this workgroup wrote (gradient
+                         // GEMMs: the global-norm clip needs no separate pass over the gradient bucket)
 };
 
 template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int U, int TM, int TN>
@@ -202,6 +206,12 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
       for (int rr = 0; rr < 16; ++rr) h1s[rr * ldh + k] = accr[rr] > 0.f ? accr[rr] : 0.f;
     }
     __syncthreads();
+    if (g.h1_out && tn_blk == 0) {
+      for (int i = threadIdx.x; i < 16 * g.K; i += 256) {
+        const int rr = i / g.K, k = i - rr * g.K;
+        if (m0 + rr < g.M) g.h1_out[(size_t)(m0 + rr) * g.ldh1 + k] = h1s[rr * ldh + k];
+      }
+    }
   }
 
   for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
@@ -234,6 +244,7 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
   }
   __syncthreads();
   if (wid != 0) return;
+  float ssq = 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (ROWSUM && tn_blk == 0) {
@@ -244,6 +255,7 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
         const int m = m0 + 16 * tm + r;
         if (EPI == EPI_ROWPTR) *g.rowsum_ptr[m] = t;
         else g.rowsum[m] = t;
+        ssq = fmaf(t, t, ssq);
       }
     }
 #pragma unroll
@@ -266,7 +278,8 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
         hv[i] = (n_ok[tn] && mm < g.M) ? v : 0.f;
         if (!n_ok[tn] || mm >= g.M) continue;
         if (EPI == EPI_ROWPTR) g.rowptr[mm][n] = v;
-        else if (EPI != EPI_HEADPART) g.C[(size_t)mm * g.ldc + n] = v;
+        else if (EPI != EPI_HEADPART || g.C) g.C[(size_t)mm * g.ldc + n] = v;
+        ssq = fmaf(v, v, ssq);
       }
       if (EPI == EPI_HEADPART) {
         // partial head outputs of this 16-column tile: reduce over the 16 lanes that share kq
@@ -288,6 +301,10 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
         }
       }
     }
+  }
+  if ((EPI == EPI_NONE || EPI == EPI_ROWPTR) && g.ssq_out) {
+    ssq = jh_wave_sum(ssq);
+    if (lane == 0) g.ssq_out[blockIdx.x] = ssq;
   }
   if (EPI == EPI_HEADPART && g.tile_flag) {
     // Acting hand-off to the HOST: the partial head outputs went to device-mapped pinned memory;
@@ -392,20 +409,31 @@ __global__ void __launch_bounds__(256) jh_gradnorm_kernel(int64_t n, const float
   }
 }
 
+// advance_step != 0 (fused-norm path, no gradnorm kernel ran): every workgroup derives the bias
+// corrections from step + 1 itself; the LAST workgroup to finish stores the new step -- all others
+// read hyper[4] at their start, i.e. before they took their ticket, so nobody can see the new value.
 __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       const float* __restrict__ partial, int n_partial,
-                                                      const float* __restrict__ hyper, float max_norm,
-                                                      float* __restrict__ norm_out) {
+                                                      float* __restrict__ hyper, float max_norm,
+                                                      float* __restrict__ norm_out, int advance_step,
+                                                      unsigned* __restrict__ ticket) {
   __shared__ float s_red[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
   const float total = sqrtf(jh_block_reduce(acc, s_red, JhAdd(), 0.f));
+  float bc1 = hyper[5], bc2s = hyper[6];
+  float t_new = 0.f;
+  if (advance_step) {
+    t_new = hyper[4] + 1.f;
+    bc1 = 1.f - powf(hyper[1], t_new);
+    bc2s = sqrtf(1.f - powf(hyper[2], t_new));
+  }
   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total + 1e-6), clamped to 1
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[5], bc2s = hyper[6];
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * coef;
@@ -416,6 +444,18 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2s + eps;
     p[i] = p[i] - step_size * (mi / denom);
+  }
+  if (advance_step) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hyper[4] = t_new;
+        hyper[5] = bc1;
+        hyper[6] = bc2s;
+      }
+    }
   }
 }
 
@@ -482,6 +522,12 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   }
   JH_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
   if (const char* e = getenv("JH_FORK_BACKWARD")) n->fork_backward = atoi(e);
+  JH_HIP(hipMalloc((void**)&n->fwd_part, sizeof(float) * 8 * (size_t)max_rows * (size_t)(H / 16)));
+  JH_HIP(hipMalloc((void**)&n->g_heads, sizeof(float) * (size_t)max_rows * (size_t)(2 * A + 1)));
+  n->ssq_slots = (H / 16) * (H / 16) + (H / 16) + (H / 16) * ((S + 15) / 16);  // dW2 + dW_heads + dW1 tiles
+  JH_HIP(hipMalloc((void**)&n->ssq_part, sizeof(float) * (size_t)n->ssq_slots));
+  JH_HIP(hipMalloc((void**)&n->adam_ticket, 64));
+  JH_HIP(hipMemset(n->adam_ticket, 0, 64));
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
   const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
@@ -498,6 +544,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipFree(n->g_all);
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
+  (void)hipFree(n->fwd_part); (void)hipFree(n->g_heads); (void)hipFree(n->ssq_part); (void)hipFree(n->adam_ticket);
   for (int i = 0; i < 2; ++i) {
     if (n->aux[i]) (void)hipStreamDestroy(n->aux[i]);
     if (n->ev_join[i]) (void)hipEventDestroy(n->ev_join[i]);
@@ -583,9 +630,17 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
 }
 
 // Backward of the LAST forward (same B, x, idx): overwrites the flat gradient bucket.
+static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0,
+                           const float* d_g_head1, const float* d_g_value, bool fused_ssq, jh_stream stream);
+
 JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx,
                                  const float* d_g_head0, const float* d_g_head1, const float* d_g_value,
                                  jh_stream stream) {
+  return pponet_backward(n, B, d_x, d_idx, d_g_head0, d_g_head1, d_g_value, false, stream);
+}
+
+static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0,
+                           const float* d_g_head1, const float* d_g_value, bool fused_ssq, jh_stream stream) {
   JH_ARG(n && d_x && d_g_head0 && d_g_value);
   JH_ARG(B > 0 && B <= n->max_rows);
   JH_ARG(!n->cont || d_g_head1);
@@ -613,6 +668,7 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     GemmArgs g{};
     g.M = n_out; g.N = H; g.K = B; g.A = n->g_all; g.lda = 8; g.B = n->h2; g.ldb = H;
     for (int o = 0; o < n_out; ++o) { g.rowptr[o] = dw[o]; g.rowsum_ptr[o] = db[o]; }
+    if (fused_ssq) g.ssq_out = n->ssq_part + (H / 16) * (H / 16);
     rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 1>("jh_gemm16_bwd_dWheads", g, s_heads);
     if (rc) return rc;
   }
@@ -620,6 +676,7 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     GemmArgs g{};
     g.M = H; g.N = H; g.K = B; g.A = n->dh2; g.lda = H; g.B = n->h1; g.ldb = H; g.C = n->grads + n->o_w2; g.ldc = H;
     g.rowsum = n->grads + n->o_b2;
+    if (fused_ssq) g.ssq_out = n->ssq_part;
     rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW2", g, s_w2);
     if (rc) return rc;
   }
@@ -638,6 +695,7 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     GemmArgs g{};
     g.M = H; g.N = S; g.K = B; g.A = n->dh1; g.lda = H; g.B = d_x; g.ldb = S; g.b_rows = d_idx;
     g.C = n->grads + n->o_w1; g.ldc = S; g.rowsum = n->grads + n->o_b1;
+    if (fused_ssq) g.ssq_out = n->ssq_part + (H / 16) * (H / 16) + (H / 16);
     rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW1", g, st);
     if (rc) return rc;
   }
@@ -656,8 +714,58 @@ JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_ou
   JH_LAUNCH(jh_gradnorm_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial, n->hyper);
   JH_LAUNCH_CHECK();
   JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
-            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out);
+            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out, 0, n->adam_ticket);
   JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// One PPO minibatch update (ppo.py:122-169) in 8 launches instead of 11:
+//   1 fused forward   layer 1 generated in LDS as the GEMM's A operand (and materialised once for the
+//                     backward), h2 stored, heads reduced per column tile in the epilogue
+//   2 loss fwd+bwd    sums the head partials in LDS, clipped surrogate / value / entropy, d(heads)
+//   3 dh2             + packed head gradients
+//   4-7 GEMMs         dW_heads, dW2, dh1, dW1 (+ bias gradients as row sums, + per-workgroup sum of
+//                     squares of everything written)
+//   8 clip + Adam     the global norm comes from the GEMMs' partials; the step counter advances inside
+// do_adam == 0 stops after launch 7 (data-parallel: all-reduce, then jh_pponet_adam_step).
+int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows,
+                              const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
+                              const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
+                              float* d_g0, float* d_g1, float* d_gv, float* d_stats, hipStream_t st);
+
+JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action,
+                                   const float* d_adv, const float* d_ret, const float* d_value_old,
+                                   const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef, float max_norm,
+                                   int32_t do_adam, float* d_stats, jh_stream stream) {
+  JH_ARG(n && d_x && d_action && d_adv && d_ret && d_value_old && d_logp_old);
+  JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
+  hipStream_t st = jh_s(stream);
+  const int H = n->H, A = n->A;
+  const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
+  const int n_out = head_rows(n, w, dw, b, db);
+  {
+    GemmArgs g{};
+    g.M = B; g.N = H; g.K = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->h2; g.ldc = H; g.aux = n->params + n->o_b2;
+    g.x = d_x; g.x_rows = d_idx; g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.S = n->S;
+    g.h1_out = n->h1; g.ldh1 = H;
+    for (int o = 0; o < n_out; ++o) { g.wh[o] = w[o]; g.hbias[o] = b[o]; }
+    g.n_out = n_out; g.part = n->fwd_part; g.part_rows = n->max_rows;
+    int rc = launch_gemm<2, true, EPI_HEADPART, false, 1, 1>("jh_gemm16_fwd_fused", g, st);
+    if (rc) return rc;
+  }
+  float* g0 = n->g_heads;
+  float* g1 = n->cont ? n->g_heads + (size_t)n->max_rows * A : nullptr;
+  float* gv = n->g_heads + (size_t)n->max_rows * (n->cont ? 2 * A : A);
+  int rc = jh_ppo_loss_from_partials(n->ctx, n->cont, B, A, n->fwd_part, H / 16, n->max_rows, d_idx, d_action, d_adv, d_ret,
+                                     d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, g0, g1, gv, d_stats, st);
+  if (rc) return rc;
+  rc = pponet_backward(n, B, d_x, d_idx, g0, g1, gv, do_adam != 0, stream);
+  if (rc) return rc;
+  if (do_adam) {
+    JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
+              n->ssq_part, n->ssq_slots, n->hyper, max_norm, (float*)nullptr, 1, n->adam_ticket);
+    JH_LAUNCH_CHECK();
+  }
   return JH_OK;
 }
 

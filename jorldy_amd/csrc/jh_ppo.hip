@@ -233,15 +233,21 @@ struct PpoArgs {
   float* partial;
   float* stats;
   int nb;
+  // optional: the heads arrive as per-column-tile PARTIAL sums straight from the encoder GEMM epilogue
+  // (hpart[tile][row][8], flat output order: head0[A], head1[A] (continuous), value); the fused kernel
+  // sums them in tile order into LDS, which saves the separate heads kernel of the forward pass
+  const float* hpart;
+  int hp_tiles, hp_rows;
 };
 
+// z0 / z1: this row's head-0 / head-1 vectors (global memory or the LDS staging), v: value prediction
 template <bool CONT>
-__device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, RowCommon& rc, float& ent_row,
-                                            float& minp_row, DiscRow& dr, int& act_k) {
+__device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, const float* z0, const float* z1, float v,
+                                            RowCommon& rc, float& ent_row, float& minp_row, DiscRow& dr, int& act_k) {
   const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
-  const float adv = a.adv[r], ret = a.ret[r], vold = a.value_old[r], v = a.value_pred[i];
+  const float adv = a.adv[r], ret = a.ret[r], vold = a.value_old[r];
   if (!CONT) {
-    const float* z = a.h0 + (size_t)i * a.A;
+    const float* z = z0;
     dr = disc_prepare(z, a.A);
     int ak = (int)a.action[r];
     ak = ak < 0 ? 0 : (ak >= a.A ? a.A - 1 : ak);
@@ -261,7 +267,7 @@ __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, RowCo
     float lsum = 0.f, ent = 0.f, minp = 3.4e38f;
     for (int k = 0; k < a.A; ++k) {
       float mu, std, z;
-      const float lp = normal_logp(a.h0[(size_t)i * a.A + k], a.h1[(size_t)i * a.A + k], a.action[r * a.A + k], mu, std, z);
+      const float lp = normal_logp(z0[k], z1[k], a.action[r * a.A + k], mu, std, z);
       lsum += lp - a.logp_old[r * a.A + k];
       ent += 0.5f + JH_HALF_LOG_2PI + logf(std);  // Normal.entropy
       minp = fminf(minp, expf(lp));
@@ -273,8 +279,8 @@ __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, RowCo
 }
 
 template <bool CONT>
-__device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const RowCommon& rc, const DiscRow& dr,
-                                            int act_k, float w1, float w2) {
+__device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const float* z0, const float* z1,
+                                            const RowCommon& rc, const DiscRow& dr, int act_k, float w1, float w2) {
   const float invB = 1.f / (float)a.B;
   const float d_ratio = -invB * (rc.g1 * rc.adv + (rc.in_clip ? rc.g2 * rc.adv : 0.f));
   const float d_logp = d_ratio * rc.ratio;
@@ -282,7 +288,7 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
   const float dv = a.vf * (w1 * 2.f * (rc.v - rc.ret) * invB + (rc.in_v ? w2 * 2.f * (rc.vclip - rc.ret) * invB : 0.f));
   a.gv[i] = dv;
   if (!CONT) {
-    const float* z = a.h0 + (size_t)i * a.A;
+    const float* z = z0;
     const float ce = a.ent * invB;  // loss += ent_coef * (-mean(H)) = ent_coef/B * sum pn*lg
     float T1 = 0.f;
     for (int k = 0; k < a.A; ++k) {
@@ -317,7 +323,7 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
     const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
     const float ce = -a.ent / (float)(a.B * a.A);  // d(ent_coef * -mean(H)) / d log(std)
     for (int k = 0; k < a.A; ++k) {
-      const float mr = a.h0[(size_t)i * a.A + k], lr = a.h1[(size_t)i * a.A + k];
+      const float mr = z0[k], lr = z1[k];
       float mu, std, z;
       (void)normal_logp(mr, lr, a.action[r * a.A + k], mu, std, z);
       const float var = std * std, dm = z - mu;
@@ -357,13 +363,38 @@ __device__ __forceinline__ void ppo_finish_stats(float s_smin, float s_e1, float
 template <bool CONT>
 __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   __shared__ float s_red[16];
+  extern __shared__ __attribute__((aligned(16))) float s_z[];  // [B][8] when the heads come as partials
   const int i = threadIdx.x;
   const bool on = i < a.B;
+  const float *z0 = nullptr, *z1 = nullptr;
+  float vpred = 0.f;
+  if (a.hpart) {
+    if (on) {
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < a.hp_tiles; ++t) {  // tile order: deterministic
+        const float4* q = reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * 8);
+        const float4 q0 = q[0], q1 = q[1];
+        z[0] += q0.x; z[1] += q0.y; z[2] += q0.z; z[3] += q0.w;
+        z[4] += q1.x; z[5] += q1.y; z[6] += q1.z; z[7] += q1.w;
+      }
+      float4* dst = reinterpret_cast<float4*>(s_z + (size_t)i * 8);
+      dst[0] = make_float4(z[0], z[1], z[2], z[3]);
+      dst[1] = make_float4(z[4], z[5], z[6], z[7]);
+    }
+    __syncthreads();
+    z0 = s_z + (size_t)i * 8;
+    z1 = z0 + a.A;
+    if (on) vpred = z0[CONT ? 2 * a.A : a.A];
+  } else if (on) {
+    z0 = a.h0 + (size_t)i * a.A;
+    z1 = CONT ? a.h1 + (size_t)i * a.A : nullptr;
+    vpred = a.value_pred[i];
+  }
   RowCommon rc{};
   DiscRow dr{};
   int act_k = 0;
   float ent_row = 0.f, minp = 3.4e38f;
-  if (on) ppo_row_fwd<CONT>(a, i, rc, ent_row, minp, dr, act_k);
+  if (on) ppo_row_fwd<CONT>(a, i, z0, z1, vpred, rc, ent_row, minp, dr, act_k);
   const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
   const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
   const float s_smin = jh_block_reduce(on ? rc.smin : 0.f, s_red, JhAdd(), 0.f);
@@ -375,7 +406,7 @@ __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   float w1, w2;
   ppo_finish_stats(s_smin, s_e1, s_e2, s_ent, mx, mn, a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
                    threadIdx.x == 0 ? a.stats : nullptr);
-  if (on) ppo_row_bwd<CONT>(a, i, rc, dr, act_k, w1, w2);
+  if (on) ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2);
 }
 
 // B > 1024: pass 1 writes per-block partials, pass 2 re-reduces them in every block (deterministic,
@@ -389,7 +420,7 @@ __global__ void __launch_bounds__(256) jh_ppo_fwd_kernel(PpoArgs<CONT> a) {
   DiscRow dr{};
   int act_k = 0;
   float ent_row = 0.f, minp = 3.4e38f;
-  if (on) ppo_row_fwd<CONT>(a, i, rc, ent_row, minp, dr, act_k);
+  if (on) ppo_row_fwd<CONT>(a, i, a.h0 + (size_t)i * a.A, CONT ? a.h1 + (size_t)i * a.A : nullptr, a.value_pred[i], rc, ent_row, minp, dr, act_k);
   const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
   const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
   const float s_smin = jh_block_reduce(on ? rc.smin : 0.f, s_red, JhAdd(), 0.f);
@@ -428,8 +459,10 @@ __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
   DiscRow dr{};
   int act_k = 0;
   float ent_row, minp;
-  ppo_row_fwd<CONT>(a, i, rc, ent_row, minp, dr, act_k);
-  ppo_row_bwd<CONT>(a, i, rc, dr, act_k, w1, w2);
+  const float* z0 = a.h0 + (size_t)i * a.A;
+  const float* z1 = CONT ? a.h1 + (size_t)i * a.A : nullptr;
+  ppo_row_fwd<CONT>(a, i, z0, z1, a.value_pred[i], rc, ent_row, minp, dr, act_k);
+  ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2);
 }
 
 template <bool CONT>
@@ -437,7 +470,8 @@ static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
   if (a.B <= 1024) {
     const int threads = ((a.B + 63) / 64) * 64;
     a.nb = 1;
-    JH_LAUNCH(jh_ppo_fused_kernel<CONT>, dim3(1), dim3(threads), 0, st, a);
+    const size_t lds = a.hpart ? sizeof(float) * 8 * (size_t)a.B : 0;
+    JH_LAUNCH(jh_ppo_fused_kernel<CONT>, dim3(1), dim3(threads), lds, st, a);
     JH_LAUNCH_CHECK();
     return JH_OK;
   }
@@ -484,4 +518,24 @@ JH_EXPORT int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const fl
   a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_mu_raw; a.g1 = d_grad_log_std_raw; a.gv = d_grad_value;
   a.stats = d_stats;
   return ppo_launch<true>(ctx, a, jh_s(stream));
+}
+
+// Internal entry (jh_mlp.hip): same losses with the heads given as encoder partial sums.
+int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows,
+                              const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
+                              const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
+                              float* d_g0, float* d_g1, float* d_gv, float* d_stats, hipStream_t st) {
+  JH_ARG(B > 0 && B <= 1024 && d_hpart);
+  if (continuous) {
+    PpoArgs<true> a{};
+    a.B = B; a.A = A; a.idx = d_idx; a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old;
+    a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_g0; a.g1 = d_g1; a.gv = d_gv;
+    a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows;
+    return ppo_launch<true>(ctx, a, st);
+  }
+  PpoArgs<false> a{};
+  a.B = B; a.A = A; a.idx = d_idx; a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old;
+  a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_g0; a.g1 = nullptr; a.gv = d_gv;
+  a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows;
+  return ppo_launch<false>(ctx, a, st);
 }

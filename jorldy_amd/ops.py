@@ -60,6 +60,11 @@ def lib_profile(enable):
     L.check(L.load().jh_prof_enable(int(bool(enable))))
 
 
+def lib_profile_calibrate(n=64):
+    """Record n empty event pairs (reported as "__event_pair_overhead")."""
+    L.check(L.load().jh_prof_calibrate(int(n), L.stream_ptr()))
+
+
 def lib_profile_report():
     """-> {kernel name: (launches, total_ms)} (synchronises the device)."""
     buf = C.create_string_buffer(1 << 16)
@@ -406,6 +411,13 @@ class PPONet:
     def adam_step(self, max_norm, norm_out=None):
         with _timed("jh_gradnorm+adam", 4.0 * self.n_params * 8):  # g (r twice, w) + p,m,v (r+w)
             L.check(self.lib.jh_pponet_adam_step(self.h, float(max_norm if max_norm else 0.0), L.ptr(norm_out), L.stream_ptr()))
+
+    def ppo_update(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, max_norm, stats, do_adam=True):
+        """One PPO minibatch update in 8 launches (jh_pponet_ppo_update).  B = idx.numel() <= 1024."""
+        B = int(idx.numel()) if idx is not None else int(x.shape[0])
+        L.check(self.lib.jh_pponet_ppo_update(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
+                                              L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
+                                              float(max_norm if max_norm else 0.0), int(bool(do_adam)), L.ptr(stats), L.stream_ptr()))
 
     # ---- acting (one launch; partial heads come back through device-mapped pinned memory) ---------
     def act_discrete(self, obs, training=True, want_logits=False):
