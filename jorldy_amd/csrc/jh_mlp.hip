@@ -191,19 +191,30 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
       xs[i] = g.x[xrow * g.S + q];
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < g.K; k += 256) {  // lane k: W1 row k (coalesced), all 16 rows
-      const float* w = g.W1 + (size_t)k * g.S;
-      const float bk = g.b1[k];
-      float accr[16];
+    // layer 1 ON THE MFMA: h1[16 x K] = x[16 x S] * W1^T[S x K]; wave w owns hidden units
+    // [w*K/4, (w+1)*K/4) in tiles of 16 (one 16x16x4 MFMA per tile when S <= 4).  The VALU form of this
+    // (16 accumulators per lane, every observation re-read from LDS per unit) cost ~3 us per workgroup.
+    {
+      const int upw = (((g.K + 3) / 4) + 15) / 16 * 16;  // units per wave, multiple of 16
+      for (int u0 = wid * upw; u0 < (wid + 1) * upw && u0 < g.K; u0 += 16) {
+        const int unit = u0 + r;
+        const int uc = unit < g.K ? unit : g.K - 1;
+        f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < g.S; q0 += 4) {
+          const int q = q0 + kq;
+          const float av = q < g.S ? xs[r * g.S + q] : 0.f;                      // A[row r][k = q]
+          const float bv = (q < g.S && unit < g.K) ? g.W1[(size_t)uc * g.S + q] : 0.f;  // B[k = q][unit]
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c1, 0, 0, 0);
+        }
+        const float bb = g.b1[uc];
+        if (unit < g.K) {
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) accr[rr] = bk;
-      for (int q = 0; q < g.S; ++q) {
-        const float wq = w[q];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) accr[rr] = fmaf(xs[rr * g.S + q], wq, accr[rr]);
+          for (int i = 0; i < 4; ++i) {  // C: col = lane & 15 -> unit, row = kq * 4 + i -> tile row
+            const float v = c1[i] + bb;
+            h1s[(kq * 4 + i) * ldh + unit] = v > 0.f ? v : 0.f;
+          }
+        }
       }
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) h1s[rr * ldh + k] = accr[rr] > 0.f ? accr[rr] : 0.f;
     }
     __syncthreads();
     if (g.h1_out && tn_blk == 0) {
