@@ -71,7 +71,12 @@ class PPO(BaseAgent):
             raise ValueError("backend='native' needs head='mlp', an int state_size, Adam without weight decay and <= 8 head outputs")
         self.backend = "native" if (eligible and backend != "torch") else "torch"
         self.use_graph = use_graph
-        self.fused_update = os.environ.get("JH_FUSED_UPDATE", "1") != "0"
+        # 8-launch fused update (jh_pponet_ppo_update): measured NOT faster than the 11-launch sequence on
+        # MI355X (2.83 vs 2.72 ms per iteration: the fused kernels serialise more phases), so opt-in
+        self.fused_update = os.environ.get("JH_FUSED_UPDATE", "0") == "1"
+        # capture the RCCL all-reduce of the data-parallel path inside the hipGraph too (falls back to
+        # eager launches if the capture is refused)
+        self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
         self._net = None
         self._graph = None
         self._static = None
@@ -278,13 +283,19 @@ class PPO(BaseAgent):
             np.random.shuffle(idxs)
             perm[e * M : (e + 1) * M] = idxs
         st["idx"].copy_(h2d_small(perm, self.device))
-        graphable = self.use_graph and self.grad_sync is None and not ops._PROF["on"] and not ops._PROF["lib"]
+        graphable = (self.use_graph and not ops._PROF["on"] and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
+                     and (self.grad_sync is None or self.graph_with_collective))
         if graphable and self._graph is None and getattr(self, "_warm", False):
-            g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                self._enqueue_learn(st)
-            self._graph = g  # capture does not execute: replay below runs this iteration's update
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    self._enqueue_learn(st)
+                self._graph = g  # capture does not execute: replay below runs this iteration's update
+            except Exception as e:  # e.g. a collective that cannot be captured: stay eager from now on
+                self._graph, self._graph_failed, graphable = None, True, False
+                torch.cuda.synchronize()
+                print(f"[jorldy_amd] hipGraph capture of learn() failed ({type(e).__name__}: {e}); running eagerly")
         if graphable and self._graph is not None:
             self._graph.replay()
         else:
