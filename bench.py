@@ -123,10 +123,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("JH_FORCE_DIST") == "1"  # exercise the DP code path on a single rank (testing)
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
@@ -143,7 +145,7 @@ def main():
                   epsilon_clip=0.1, vf_coef=1.0, ent_coef=0.01, clip_grad_norm=1.0, use_standardization=True, lr_decay=True,
                   run_step=10_000_000, num_workers=W, device=f"cuda:{local_rank}")
     agent.memory.first_store = False
-    if world > 1:
+    if dist is not None:
         agent.grad_sync = make_grad_sync(agent.network, dist)
     env = ops.CartPoleVec(W, seed=100 + rank)
     collector = (VecCollector if args.python_collector or agent.backend != "native" else NativeCollector)(env, agent, W)
