@@ -22,14 +22,15 @@ class DQN(BaseAgent):
     def __init__(self, state_size, action_size, hidden_size=512, optim_config={"name": "adam"},
                  network="discrete_q_network", head="mlp", gamma=0.99, epsilon_init=1.0, epsilon_min=0.1,
                  epsilon_eval=0.0, explore_ratio=0.1, buffer_size=50000, batch_size=64, start_train_step=2000,
-                 target_update_period=500, device=None, run_step=1e6, num_workers=1, lr_decay=True, **kwargs):
+                 target_update_period=500, device=None, run_step=1e6, num_workers=1, lr_decay=True, use_graph=True, **kwargs):
         self.device = self._require_gpu(device)
+        self.use_graph = use_graph
         self.action_size = action_size
         self.action_type = "discrete"
         self.network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
         self.target_network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
         self.target_network.load_state_dict(self.network.state_dict())
-        self.optimizer = Optimizer(**optim_config, params=self.network.parameters())
+        self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
         self.gamma = gamma
         self.epsilon = epsilon_init
         self.epsilon_init = epsilon_init
@@ -50,6 +51,10 @@ class DQN(BaseAgent):
         self.lr_decay = lr_decay
         self.clip_grad_norm = None
         self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._static = None
+        self._graph = None
+        self._warm = False
+        self._noise = None
 
     @torch.no_grad()
     def act(self, state, training=True):
@@ -63,33 +68,101 @@ class DQN(BaseAgent):
         return {"action": action}
 
     # ------------------------------------------------------------------------------------------
-    def _sample(self):
-        """-> (transitions, weights|None, indices|None, sampled_p, mean_p)"""
-        return self.memory.sample(self.batch_size), None, None, None, None
+    def _make_optimizer(self, optim_config, params):
+        """Optimizer(**optim_config) of the reference; when the torch optimizer supports it, in its
+        graph-capturable form (device-resident step / lr) so that the whole learn() -- gather, forwards,
+        HIP loss kernel, backward, step, priority write-back -- replays as ONE hipGraph."""
+        import inspect
 
-    def learn(self):
-        tr, weights, indices, sampled_p, mean_p = self._sample()
+        from ..optimizer import optimizer_dict
+
+        cfg = dict(optim_config)
+        cls = optimizer_dict.get(cfg.get("name", "adam").lower())
+        self._lr0 = None
+        if self.use_graph and cls is not None and "capturable" in inspect.signature(cls.__init__).parameters:
+            self._lr0 = float(cfg.get("lr", inspect.signature(cls.__init__).parameters["lr"].default))
+            cfg["lr"] = torch.tensor(self._lr0, dtype=torch.float32, device=self.device)
+            cfg["capturable"] = True
+        return Optimizer(**cfg, params=params)
+
+    def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
+        if self._lr0 is None:
+            return super().learning_rate_decay(step, optimizers, mode)
+        weight = {"linear": 1 - (step / self.run_step), "cosine": np.cos((np.pi / 2) * (step / self.run_step)),
+                  "sqrt": max(1 - (step / self.run_step), 0.0) ** 0.5}[mode]
+        for g in self.optimizer.param_groups:  # in place: the captured graph reads this tensor
+            g["lr"].fill_(self._lr0 * float(weight))
+
+    def _alloc_static(self):
+        """Fixed-address buffers of one learn(): sampled indices / weights and the gathered batch."""
+        B = self.batch_size
+        idx = torch.zeros(B, dtype=torch.int64, device=self.device)
+        probe = self.memory.gather(idx, idx_offset=0)  # shapes / keys of a gathered batch
+        return dict(idx=idx, w=torch.ones(B, dtype=torch.float32, device=self.device), tr=probe, store=self.memory._store)
+
+    def _draw(self, st):
+        """Host side of sampling (the reference's numpy global-RNG draws) -> st["idx"] (+ st["w"])."""
+        from ..buffer.base import h2d_small
+
+        st["idx"].copy_(h2d_small(self.memory.sample_indices(self.batch_size).astype(np.int64), self.device))
+        return None
+
+    def _idx_offset(self):
+        return 0
+
+    def _learn_body(self, st):
+        tr = self.memory.gather(st["idx"], idx_offset=self._idx_offset(), out=st["tr"])
         state, action, reward = tr["state"], tr["action"], tr["reward"]
         next_state, done = tr["next_state"], tr["done"]
         q = self.network(state)
         with torch.no_grad():
             next_target_q = self.target_network(next_state)
             next_q = self.network(next_state) if self._td["double"] else None
-        g, prio, st = ops.td_loss(q.detach(), next_target_q, action, reward, done, self.gamma, q_next_online=next_q,
-                                  weights=weights, alpha=getattr(self, "alpha", 0.0), n_step=self._td["n_step"] and self.n_step,
-                                  stats=self._stats)
+        g, prio, _ = ops.td_loss(q.detach(), next_target_q, action, reward, done, self.gamma, q_next_online=next_q,
+                                 weights=st["w"] if self._td["per"] else None, alpha=getattr(self, "alpha", 0.0),
+                                 n_step=self._td["n_step"] and self.n_step, stats=self._stats)
         if self._td["per"]:
-            self.memory.update_priorities(indices, prio)  # per.py:67-70 without the B `.item()` syncs
+            self.memory.update_priorities(st["idx"], prio)  # per.py:67-70 without the B `.item()` syncs
         self.optimizer.zero_grad(set_to_none=True)
         q.backward(g)
         if self.clip_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.clip_grad_norm)
         self.optimizer.step()
+
+    def _run_learn(self):
+        """Sample on the host (eager), then run the body: eagerly the first time (lazy optimizer state,
+        MIOpen/hipBLASLt algorithm selection), captured into a hipGraph the second time, replayed after."""
+        if self._static is None or self._static["store"] is not self.memory._store:
+            self._static, self._graph = self._alloc_static(), None
+        st = self._static
+        extra = self._draw(st)
+        graphable = self.use_graph and self._lr0 is not None and self._noise is None and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
+        if graphable and self._graph is None and self._warm:
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    self._learn_body(st)
+                self._graph = g
+            except Exception as e:
+                self._graph, self._graph_failed, graphable = None, True, False
+                torch.cuda.synchronize()
+                print(f"[jorldy_amd] hipGraph capture of {type(self).__name__}.learn() failed ({type(e).__name__}: {e}); running eagerly")
+        if graphable and self._graph is not None:
+            self._graph.replay()
+        else:
+            self._learn_body(st)
+            self._warm = True
         self.num_learn += 1
-        s = st.cpu().numpy()
+        return extra
+
+    def learn(self):
+        stats64 = self._run_learn()
+        s = self._stats.cpu().numpy()
         result = {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1])}
         if self._td["per"]:
-            result.update({"sampled_p": float(sampled_p.item()), "mean_p": float(mean_p.item())})
+            p = stats64.cpu().numpy()
+            result.update({"sampled_p": float(p[0]), "mean_p": float(p[1])})
         return result
 
     def update_target(self):
@@ -122,9 +195,35 @@ class DQN(BaseAgent):
     def epsilon_decay(self, delta_t):
         self.epsilon = max(self.epsilon_min, self.epsilon - delta_t * self.epsilon_delta)
 
+    def _portable_optim_state(self):
+        """optimizer.state_dict() in the form the reference writes (float lr, capturable off, host step
+        counters), so a ckpt saved here loads into the reference agent on any device."""
+        sd = self.optimizer.state_dict()
+        for g in sd["param_groups"]:
+            if torch.is_tensor(g.get("lr")):
+                g["lr"] = float(g["lr"])
+            if "capturable" in g:
+                g["capturable"] = False
+        for stt in sd["state"].values():
+            if torch.is_tensor(stt.get("step")):
+                stt["step"] = stt["step"].detach().cpu()
+        return sd
+
+    def _restore_capturable(self):
+        if self._lr0 is None:
+            return
+        for g in self.optimizer.param_groups:
+            g["capturable"] = True
+            if not torch.is_tensor(g["lr"]):
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
+        for stt in self.optimizer.state.values():
+            if torch.is_tensor(stt.get("step")):
+                stt["step"] = stt["step"].to(self.device, dtype=torch.float32)
+        self._graph = None  # optimizer tensors were replaced: re-capture
+
     def save(self, path):
         print(f"...Save model to {path}...")
-        torch.save({"network": self.network.state_dict(), "optimizer": self.optimizer.state_dict()}, os.path.join(path, "ckpt"))
+        torch.save({"network": self.network.state_dict(), "optimizer": self._portable_optim_state()}, os.path.join(path, "ckpt"))
 
     def load(self, path):
         print(f"...Load model from {path}...")
@@ -132,6 +231,7 @@ class DQN(BaseAgent):
         self.network.load_state_dict(checkpoint["network"])
         self.target_network.load_state_dict(checkpoint["network"])
         self.optimizer.load_state_dict(checkpoint["optimizer"])
+        self._restore_capturable()
 
     def set_distributed(self, id):
         self.epsilon = id / self.num_workers
@@ -182,8 +282,11 @@ class PER(DQN):
         self.learn_period = learn_period
         self.learn_period_stamp = 0
 
-    def _sample(self):
-        return self.memory.sample(self.beta, self.batch_size)
+    def _draw(self, st):
+        return self.memory.sample_into(self.beta, self.batch_size, st["idx"], st["w"])
+
+    def _idx_offset(self):
+        return self.memory.first_leaf_index
 
     def learn(self):
         result = super().learn()
@@ -248,8 +351,11 @@ class ApeX(DQN):
         q = np.take(q.cpu().numpy(), action)
         return {"action": action, "q": q}
 
-    def _sample(self):
-        return self.memory.sample(self.beta, self.batch_size)
+    def _draw(self, st):
+        return self.memory.sample_into(self.beta, self.batch_size, st["idx"], st["w"])
+
+    def _idx_offset(self):
+        return self.memory.first_leaf_index
 
     def learn(self):
         r = super().learn()

@@ -40,19 +40,21 @@ class C51(DQN):
             action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
         return {"action": action}
 
-    def learn(self):
-        tr = self.memory.sample(self.batch_size)
+    def _learn_body(self, st):
+        tr = self.memory.gather(st["idx"], out=st["tr"])
         B, A, K = self.batch_size, self.action_size, self.num_support
         logit = self.network(tr["state"])
         with torch.no_grad():
             target_logit = self.target_network(tr["next_state"])
-        g, _, _, st = ops.c51_loss(logit.detach().view(B, A, K), target_logit.view(B, A, K), tr["action"], tr["reward"], tr["done"],
-                                   self.v_min, self.v_max, self.gamma, shift_max=True, stats=self._stats8)
+        g, _, _, _ = ops.c51_loss(logit.detach().view(B, A, K), target_logit.view(B, A, K), tr["action"], tr["reward"], tr["done"],
+                                  self.v_min, self.v_max, self.gamma, shift_max=True, stats=self._stats8)
         self.optimizer.zero_grad(set_to_none=True)
         logit.backward(g.view_as(logit))
         self.optimizer.step()
-        self.num_learn += 1
-        s = st.cpu().numpy()
+
+    def learn(self):
+        self._run_learn()
+        s = self._stats8.cpu().numpy()
         return {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3])}
 
 
@@ -65,14 +67,17 @@ class Rainbow(DQN):
                  optim_config={"name": "adam"}, gamma=0.99, buffer_size=50000, batch_size=64, start_train_step=2000,
                  target_update_period=500, run_step=1e6, lr_decay=True, n_step=4, alpha=0.6, beta=0.4, learn_period=4,
                  uniform_sample_prob=1e-3, noise_type="factorized", v_min=-10, v_max=10, num_support=51, device=None,
-                 **kwargs):
+                 use_graph=True, **kwargs):
         self.device = self._require_gpu(device)
+        self.use_graph = use_graph
+        self._static, self._graph, self._warm, self.clip_grad_norm = None, None, False, None
+        self._td = dict(double=True, per=True, n_step=1)
         self.action_size = action_size
         self.action_type = "discrete"
         mk = lambda: Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head).to(self.device)
         self.network, self.target_network = mk(), mk()
         self.target_network.load_state_dict(self.network.state_dict())
-        self.optimizer = Optimizer(**optim_config, params=self.network.parameters())
+        self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
         self.gamma = gamma
         self.batch_size = batch_size
         self.start_train_step = start_train_step
@@ -96,7 +101,8 @@ class Rainbow(DQN):
         self.z = torch.linspace(v_min, v_max, num_support, device=self.device).view(1, -1)
         self.epsilon = 0.0
         self._stats8 = torch.zeros(8, dtype=torch.float32, device=self.device)
-        self._noise = None  # parity tests inject the Gaussian draws here
+        self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._noise = None  # parity tests inject the Gaussian draws here (forces the eager path)
 
     def logits2Q(self, logits):
         _logits = logits.view(logits.shape[0], self.action_size, self.num_support)
@@ -114,24 +120,33 @@ class Rainbow(DQN):
             action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
         return {"action": action}
 
-    def learn(self):
-        tr, weights, indices, sampled_p, mean_p = self.memory.sample(self.beta, self.batch_size)
+    def _draw(self, st):
+        return self.memory.sample_into(self.beta, self.batch_size, st["idx"], st["w"])
+
+    def _idx_offset(self):
+        return self.memory.first_leaf_index
+
+    def _learn_body(self, st):
+        tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, out=st["tr"])
         nz = self._noise or [None, None, None]
         logit = self.network(tr["state"], True, nz[0])  # [B, A, K]
         with torch.no_grad():
             next_logit = self.network(tr["next_state"], True, nz[1])
             target_logit = self.target_network(tr["next_state"], True, nz[2])
-        g, prio, kl, st = ops.c51_loss(logit.detach(), target_logit, tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max,
-                                       self.gamma, next_logit_online=next_logit, weights=weights, alpha=self.alpha,
-                                       n_step=self.n_step, stats=self._stats8)
-        self.memory.update_priorities(indices, prio)  # rainbow.py:230-231
+        g, prio, _, _ = ops.c51_loss(logit.detach(), target_logit, tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max,
+                                     self.gamma, next_logit_online=next_logit, weights=st["w"], alpha=self.alpha,
+                                     n_step=self.n_step, stats=self._stats8)
+        self.memory.update_priorities(st["idx"], prio)  # rainbow.py:230-231
         self.optimizer.zero_grad(set_to_none=True)
         logit.backward(g)
         self.optimizer.step()
-        self.num_learn += 1
-        s = st.cpu().numpy()
+
+    def learn(self):
+        stats64 = self._run_learn()
+        s = self._stats8.cpu().numpy()
+        p = stats64.cpu().numpy()
         return {"loss": float(s[0]), "beta": self.beta, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3]),
-                "sampled_p": float(sampled_p.item()), "mean_p": float(mean_p.item())}
+                "sampled_p": float(p[0]), "mean_p": float(p[1])}
 
     def process(self, transitions, step):
         """rainbow.py:255-283."""

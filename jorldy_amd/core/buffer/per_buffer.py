@@ -61,6 +61,15 @@ class PERBuffer(ReplayBuffer):
         u = np.random.uniform(size=batch_size - n_uni)
         return uni, u
 
+    def sample_into(self, beta, batch_size, idx_out, w_out):
+        """Host RNG draws (reference order) + descent / IS weights into PREALLOCATED idx / weight tensors;
+        the gather is left to the caller (captured-graph learners).  Returns the stats tensor
+        {sampled_p, mean_p, root, max_w}."""
+        assert self.buffer_counter > 0
+        uni, u = self.draw(batch_size)
+        _, _, _, stats = self._tree.sample(beta, uni, u, want_w64=False, out_idx=idx_out, out_w32=w_out)
+        return stats
+
     def sample(self, beta, batch_size, as_float=True):
         """-> (transitions, weights f32[B] device, indices i64[B] device (tree space, uniform first),
                sampled_p, mean_p) ; sampled_p/mean_p are 0-dim device float64 tensors (call .item()

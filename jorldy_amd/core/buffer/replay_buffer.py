@@ -38,8 +38,10 @@ class ReplayBuffer(BaseBuffer):
     def sample_indices(self, batch_size):
         return np.random.randint(self.buffer_counter, size=batch_size)  # replay_buffer.py:26
 
-    def gather(self, idx_device, idx_offset=0, as_float=True):
-        return self._unflatten(self._store.gather(idx_device, as_float=as_float, idx_offset=idx_offset))
+    def gather(self, idx_device, idx_offset=0, as_float=True, out=None):
+        """out: optional dict key -> preallocated tensor (or list of tensors for multimodal keys)."""
+        flat_out = None if out is None else self._flat_cols(out)
+        return self._unflatten(self._store.gather(idx_device, as_float=as_float, idx_offset=idx_offset, out=flat_out))
 
     def sample(self, batch_size, as_float=True):
         idx = h2d_small(self.sample_indices(batch_size).astype(np.int64), self.device)

@@ -245,14 +245,16 @@ class SumTree:
         assert prio.dtype in (torch.float32, torch.float64)
         L.check(self.lib.jh_per_update(self.h, int(idx.numel()), L.ptr(idx.contiguous()), L.ptr(prio.contiguous()), dt, L.stream_ptr()))
 
-    def sample(self, beta, uniform_slot, u, want_w64=True):
-        """uniform_slot int64[n_uni] (numpy), u float64[B-n_uni] (numpy).  Returns (idx i64[B], w64|None, w32, stats f64[4]) on device."""
+    def sample(self, beta, uniform_slot, u, want_w64=True, out_idx=None, out_w32=None):
+        """uniform_slot int64[n_uni] (numpy), u float64[B-n_uni] (numpy).  Returns (idx i64[B], w64|None, w32, stats f64[4]) on device.
+        out_idx / out_w32: preallocated outputs (static buffers of a captured graph)."""
         uniform_slot = np.ascontiguousarray(uniform_slot, dtype=np.int64)
         u = np.ascontiguousarray(u, dtype=np.float64)
         B = uniform_slot.size + u.size
-        idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        idx = torch.empty(B, dtype=torch.int64, device=self.device) if out_idx is None else out_idx
         w64 = torch.empty(B, dtype=torch.float64, device=self.device) if want_w64 else None
-        w32 = torch.empty(B, dtype=torch.float32, device=self.device)
+        w32 = torch.empty(B, dtype=torch.float32, device=self.device) if out_w32 is None else out_w32
+        assert idx.numel() == B and w32.numel() == B
         L.check(self.lib.jh_per_sample(self.h, B, float(beta), int(uniform_slot.size), L.ptr(uniform_slot), L.ptr(u), L.ptr(idx), L.ptr(w64), L.ptr(w32), L.ptr(self._stats), L.stream_ptr()))
         return idx, w64, w32, self._stats
 

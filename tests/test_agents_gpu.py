@@ -465,3 +465,37 @@ def test_full_checkpoint_resumes_per_agent_bit_identically(tmp_path):
     for (k, v1), (_, v2) in zip(a1.network.state_dict().items(), a2.network.state_dict().items()):
         torch.testing.assert_close(v1, v2, rtol=0, atol=0)
     np.testing.assert_array_equal(a2.memory.sum_tree, a1.memory.sum_tree)
+
+
+@pytest.mark.parametrize("name,extra", [("dqn", {}), ("per", dict(learn_period=1)), ("ape_x", dict(n_step=3, num_workers=4, learn_period=1)),
+                                         ("c51", dict(num_support=21, v_min=-2, v_max=5))])
+def test_td_agents_graph_replay_equals_eager(name, extra):
+    """learn() captured into one hipGraph (gather, forwards, HIP loss kernel, backward, capturable
+    optimizer step, priority write-back) must reproduce the eager sequence update for update."""
+    from jorldy_amd.core.agent import Agent
+
+    fx = {"dqn": "dqn", "per": "per", "ape_x": "ape_x", "c51": "c51"}[name]
+    z = load(fx)
+    res = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        agent = Agent(name, state_size=int(_h(z, "S")), action_size=int(_h(z, "A")), hidden_size=int(_h(z, "H")), optim_config={"name": "adam", "lr": 1e-3},
+                      buffer_size=256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=1000, device="cuda",
+                      use_graph=use_graph, **extra)
+        agent.network.load_state_dict(_sd(z, "sd0/"))
+        agent.target_network.load_state_dict(_sd(z, "sdt/"))
+        _fill_from_fixture(agent, z, name in ("per", "ape_x"))
+        np.random.seed(7)
+        out = []
+        for it in range(5):
+            r = agent.learn()
+            agent.learning_rate_decay(10 * (it + 1))
+            out.append(r["loss"])
+        if use_graph:
+            assert agent._graph is not None, "learn() was not captured"
+        res.append((out, torch.cat([p.detach().reshape(-1) for p in agent.network.parameters()]).clone(),
+                    agent.memory.sum_tree if hasattr(agent.memory, "_tree") else None))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+    if res[0][2] is not None:
+        np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6, atol=1e-9)
