@@ -199,6 +199,7 @@ class DQN(BaseAgent):
         """optimizer.state_dict() in the form the reference writes (float lr, capturable off, host step
         counters), so a ckpt saved here loads into the reference agent on any device."""
         sd = self.optimizer.state_dict()
+        sd = {"state": {k: dict(v) for k, v in sd["state"].items()}, "param_groups": [dict(g) for g in sd["param_groups"]]}
         for g in sd["param_groups"]:
             if torch.is_tensor(g.get("lr")):
                 g["lr"] = float(g["lr"])
