@@ -1,0 +1,956 @@
+// Rainbow network on the device: Nature-CNN or MLP head -> Linear -> noisy dueling categorical heads.
+//   reference: core/network/rainbow.py:8-94, head.py:6-61 (MLP / CNN), utils.py:55-107 (noisy linear),
+//              core/agent/rainbow.py:154-253 (the three forwards + backward + Adam of one learn()).
+//
+// Every contraction (convolutions as implicit GEMMs, linear layers, their data- and weight-gradients) runs
+// on ONE LDS-tiled fp32 MFMA kernel (jh_tgemm_kernel).  What changes between layers is only how an operand
+// tile is fetched from HBM (dense, transposed, im2col of an NHWC activation, im2col of the NCHW uint8
+// frames straight out of the replay store) -- the column matrix of a convolution is never materialised
+// in the forward pass or the weight-gradient pass.
+//
+// Private layouts (import/export in jorldy_amd/ops.py permutes to the reference's state_dict):
+//   activations  NHWC  [rows = (b, oy, ox)][channels]        (a GEMM's C is the next conv's input as is)
+//   conv weights [out][(ky, kx, c)]  (layer 1: [out][(c, ky, kx)] = the reference layout, input is NCHW)
+//   linear / noisy weights [out][in] (the reference keeps noisy weights as [in][out])
+//   a1 | v1 noisy layers stacked into one [2H][H] matrix (one GEMM feeds both streams)
+#include "jh_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+enum { OP_KCONT = 0, OP_XCONT = 1, OP_NHWC_K = 2, OP_NHWC_X = 3, OP_NCHW_K = 4, OP_NCHW_X = 5 };
+enum { TEPI_NONE = 0, TEPI_BIAS = 1, TEPI_BIAS_RELU = 2, TEPI_MASK = 3 };
+
+// One GEMM operand, element (x, k): x = the row (A) / column (B) index of C, k = reduction index.
+//   KCONT  p[x * ld + k]                      XCONT  p[k * ld + x]
+//   NHWC_K im2col(pixel = x, tap = k)         NHWC_X im2col(pixel = k, tap = x)     tap = (ky, kx, c)
+//   NCHW_K / NCHW_X the same on an NCHW image (uint8 or fp32, divided by 255: head.py:46), tap = (c, ky, kx)
+struct Opnd {
+  const void* p;
+  int ld, mode, u8, vec;
+  int C, H, W, OH, OW, KH, KW, S;
+};
+
+struct TGemm {
+  int M, N, K;
+  Opnd a, b;
+  float* C;
+  int ldc, epi;
+  const float* bias;   // [N]
+  const float* aux;    // MASK: forward activation, same indexing as C
+  int ldaux;
+  float* rowsum;       // optional [M]: sum_k A(m, k)  (bias gradients)
+  int splitk, tiles_m, tiles_n;
+  float* ws;           // split-K partials [splitk][tiles][BM*BN + BM]
+  unsigned* cnt;       // [tiles] arrival counters (zero between launches)
+};
+constexpr int kMaxGroup = 6;
+struct TGemmBatch {
+  TGemm p[kMaxGroup];
+};
+
+__device__ __forceinline__ int64_t conv_off_nhwc(const Opnd& o, int pix, int q) {
+  const int ox = pix % o.OW, t = pix / o.OW, oy = t % o.OH, b = t / o.OH;
+  const int c = q % o.C, t2 = q / o.C, kx = t2 % o.KW, ky = t2 / o.KW;
+  return (((int64_t)b * o.H + oy * o.S + ky) * o.W + ox * o.S + kx) * o.C + c;
+}
+__device__ __forceinline__ int64_t conv_off_nchw(const Opnd& o, int pix, int q) {
+  const int ox = pix % o.OW, t = pix / o.OW, oy = t % o.OH, b = t / o.OH;
+  const int kx = q % o.KW, t2 = q / o.KW, ky = t2 % o.KH, c = t2 / o.KH;
+  return (((int64_t)b * o.C + c) * o.H + oy * o.S + ky) * o.W + ox * o.S + kx;
+}
+
+__device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
+  if (o.mode == OP_KCONT) return ((const float*)o.p)[(size_t)x * o.ld + k];
+  if (o.mode == OP_XCONT) return ((const float*)o.p)[(size_t)k * o.ld + x];
+  const bool kfast = !(o.mode & 1);
+  const int pix = kfast ? x : k, q = kfast ? k : x;
+  if (o.mode <= OP_NHWC_X) return ((const float*)o.p)[conv_off_nhwc(o, pix, q)];
+  const int64_t off = conv_off_nchw(o, pix, q);
+  return (o.u8 ? (float)((const uint8_t*)o.p)[off] : ((const float*)o.p)[off]) / 255.0f;
+}
+
+// k-fast modes: v = elements (x, k..k+3).  x-fast modes: v = elements (x..x+3, k).  Zero outside X x K.
+__device__ __forceinline__ void op_fetch4(const Opnd& o, int x, int k, int X, int K, float v[4]) {
+  v[0] = v[1] = v[2] = v[3] = 0.f;
+  if (x >= X || k >= K) return;
+  const bool kfast = !(o.mode & 1);
+  const bool full = kfast ? (k + 3 < K) : (x + 3 < X);
+  if (full && o.vec) {
+    if (o.mode <= OP_XCONT) {
+      const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + (kfast ? (size_t)x * o.ld + k : (size_t)k * o.ld + x));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      return;
+    }
+    if (o.mode <= OP_NHWC_X) {
+      const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + conv_off_nhwc(o, kfast ? x : k, kfast ? k : x));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      return;
+    }
+    const int64_t off = conv_off_nchw(o, kfast ? x : k, kfast ? k : x);  // 4 consecutive kx (KW % 4 == 0)
+    if (!(off & 3)) {
+      if (o.u8) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + off);
+        v[0] = (float)(w & 255u) / 255.0f; v[1] = (float)((w >> 8) & 255u) / 255.0f;
+        v[2] = (float)((w >> 16) & 255u) / 255.0f; v[3] = (float)(w >> 24) / 255.0f;
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + off);
+        v[0] = t.x / 255.0f; v[1] = t.y / 255.0f; v[2] = t.z / 255.0f; v[3] = t.w / 255.0f;
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (kfast) {
+      if (k + i < K) v[i] = op_elem(o, x, k + i);
+    } else {
+      if (x + i < X) v[i] = op_elem(o, x + i, k);
+    }
+  }
+}
+
+// C[M][N] = sum_k A(m, k) B(k, n), workgroup tile (32 TM) x (32 TN), BK = 32, 4 waves as 2 x 2.
+// LDS tiles are [x][k] with a 36-float row stride: a lane's MFMA operands for 4 consecutive k are ONE
+// 16-byte LDS read (the k order inside a 16-wide block is permuted identically for A and B, which a
+// sum over k does not see), and the 16 rows a wave reads start in 16 distinct 4-bank groups.
+// splitk > 1: every split writes its partial tile, the last workgroup to arrive (per-tile counter) sums
+// the partials in split order -- deterministic, no atomics on data -- and runs the epilogue.
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) jh_tgemm_kernel(TGemmBatch batch) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = 36;
+  __shared__ __attribute__((aligned(16))) float sA[BM * LD];
+  __shared__ __attribute__((aligned(16))) float sB[BN * LD];
+  __shared__ int s_last;
+  const TGemm& g = batch.p[blockIdx.y];
+  const int tile = blockIdx.x, z = blockIdx.z;
+  const int tiles = g.tiles_m * g.tiles_n;
+  if (tile >= tiles || z >= g.splitk) return;
+  const int tm_blk = tile / g.tiles_n, tn_blk = tile - tm_blk * g.tiles_n;
+  const int m0 = tm_blk * BM, n0 = tn_blk * BN;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 15, kq = lane >> 4, wm = wid & 1, wn = wid >> 1;
+  const int nchunks = (g.K + BK - 1) / BK, per = (nchunks + g.splitk - 1) / g.splitk;
+  const int kbeg = z * per * BK;
+  int kend = kbeg + per * BK;
+  if (kend > g.K) kend = g.K;
+  const bool a_kfast = !(g.a.mode & 1), b_kfast = !(g.b.mode & 1);
+
+  float ra[TM][4], rb[TN][4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int e = t + 256 * i;
+      if (a_kfast) op_fetch4(g.a, m0 + (e >> 3), k0 + 4 * (e & 7), g.M, kend, ra[i]);
+      else op_fetch4(g.a, m0 + 4 * (e % (BM / 4)), k0 + e / (BM / 4), g.M, kend, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int e = t + 256 * i;
+      if (b_kfast) op_fetch4(g.b, n0 + (e >> 3), k0 + 4 * (e & 7), g.N, kend, rb[i]);
+      else op_fetch4(g.b, n0 + 4 * (e % (BN / 4)), k0 + e / (BN / 4), g.N, kend, rb[i]);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int e = t + 256 * i;
+      if (a_kfast) {
+        *reinterpret_cast<float4*>(&sA[(e >> 3) * LD + 4 * (e & 7)]) = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+      } else {
+        const int xc = e % (BM / 4), kr = e / (BM / 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sA[(4 * xc + j) * LD + kr] = ra[i][j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int e = t + 256 * i;
+      if (b_kfast) {
+        *reinterpret_cast<float4*>(&sB[(e >> 3) * LD + 4 * (e & 7)]) = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+      } else {
+        const int xc = e % (BN / 4), kr = e / (BN / 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sB[(4 * xc + j) * LD + kr] = rb[i][j];
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+  const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
+
+  if (kbeg < kend) gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    sstore();
+    __syncthreads();
+    if (k0 + BK < kend) gload(k0 + BK);  // next tile's HBM loads fly under this tile's MFMAs
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 16) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[(wm * 16 * TM + 16 * i + r) * LD + kb + 4 * kq]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[(wn * 16 * TN + 16 * j + r) * LD + kb + 4 * kq]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+        if (want_rs && wn == 0) rs[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+      }
+    }
+    __syncthreads();
+  }
+  if (want_rs && wn == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      rs[i] += __shfl_xor(rs[i], 16, 64);
+      rs[i] += __shfl_xor(rs[i], 32, 64);
+    }
+  }
+
+  auto epilogue = [&](float v, int m, int n) -> float {
+    if (g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU) v += g.bias[n];
+    if (g.epi == TEPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+    if (g.epi == TEPI_MASK) v = g.aux[(size_t)m * g.ldaux + n] > 0.f ? v : 0.f;
+    return v;
+  };
+
+  if (g.splitk == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 16 * TN + 16 * j + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+          const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
+          if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(acc[i][j][q], m, n);
+        }
+      }
+      if (want_rs && wn == 0 && kq == 0) {
+        const int m = m0 + wm * 16 * TM + 16 * i + r;
+        if (m < g.M) g.rowsum[m] = rs[i];
+      }
+    }
+    return;
+  }
+
+  constexpr int PSTRIDE = BM * BN + BM;
+  float* mine = g.ws + ((size_t)z * tiles + tile) * PSTRIDE;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wn * 16 * TN + 16 * j + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mine[(wm * 16 * TM + 16 * i + 4 * kq + q) * BN + nl] = acc[i][j][q];
+    }
+    if (want_rs && wn == 0 && kq == 0) mine[BM * BN + wm * 16 * TM + 16 * i + r] = rs[i];
+  }
+  __threadfence();
+  __syncthreads();
+  if (t == 0) {
+    const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == (unsigned)g.splitk - 1;
+    if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const float* base = g.ws + (size_t)tile * PSTRIDE;
+  const size_t zstride = (size_t)tiles * PSTRIDE;
+  for (int e = t; e < BM * BN; e += 256) {
+    const int ml = e / BN, nl = e - ml * BN, m = m0 + ml, n = n0 + nl;
+    if (m >= g.M || n >= g.N) continue;
+    float v = 0.f;
+    for (int s = 0; s < g.splitk; ++s) v += __builtin_nontemporal_load(base + s * zstride + e);
+    g.C[(size_t)m * g.ldc + n] = epilogue(v, m, n);
+  }
+  if (want_rs) {
+    for (int e = t; e < BM; e += 256) {
+      if (m0 + e >= g.M) continue;
+      float v = 0.f;
+      for (int s = 0; s < g.splitk; ++s) v += __builtin_nontemporal_load(base + s * zstride + BM * BN + e);
+      g.rowsum[m0 + e] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- noisy layers
+__device__ __forceinline__ float noise_f(float e) { return copysignf(sqrtf(fabsf(e)), e); }  // utils.py:66-67 (sign(0) = 0 either way)
+
+// Layout of one noise set (standard normal draws, reference draw order utils.py:58-60 per layer a1, v1, a2, v2):
+//   [ei_a1 H][ej_a1 H][ei_v1 H][ej_v1 H][ei_a2 H][ej_a2 NA][ei_v2 H][ej_v2 K]
+struct NoisyDims {
+  int H, NA, K;
+  int64_t o_av1, o_bav1, o_a2, o_ba2, o_v2, o_bv2, set_stride;  // inside one effective-weight set
+  int64_t p_mu_av1, p_sig_av1, p_mub_av1, p_sigb_av1, p_mu_a2, p_sig_a2, p_mub_a2, p_sigb_a2, p_mu_v2, p_sig_v2, p_mub_v2, p_sigb_v2;
+  int64_t noise_len;
+};
+
+// factor pair (f_j of the output unit, f_i of the input unit) for flat index i of the weight part
+__device__ __forceinline__ void noisy_locate(const NoisyDims& d, int64_t i, const float* e, int64_t* p_mu, int64_t* p_sig, int64_t* w_off, float* eps) {
+  const int H = d.H;
+  const int64_t n_av1 = (int64_t)2 * H * H, n_a2 = (int64_t)d.NA * H, n_v2 = (int64_t)d.K * H;
+  int64_t n, k;
+  const float *ei, *ej;
+  if (i < n_av1) {
+    n = i / H; k = i - n * H;
+    *p_mu = d.p_mu_av1 + i; *p_sig = d.p_sig_av1 + i; *w_off = d.o_av1 + i;
+    if (n < H) { ei = e; ej = e + H; } else { ei = e + 2 * H; ej = e + 3 * H; n -= H; }
+  } else if (i < n_av1 + n_a2) {
+    i -= n_av1;
+    n = i / H; k = i - n * H;
+    *p_mu = d.p_mu_a2 + i; *p_sig = d.p_sig_a2 + i; *w_off = d.o_a2 + i;
+    ei = e + 4 * H; ej = e + 5 * H;
+  } else if (i < n_av1 + n_a2 + n_v2) {
+    i -= n_av1 + n_a2;
+    n = i / H; k = i - n * H;
+    *p_mu = d.p_mu_v2 + i; *p_sig = d.p_sig_v2 + i; *w_off = d.o_v2 + i;
+    ei = e + 5 * H + d.NA; ej = e + 6 * H + d.NA;
+  } else {  // biases: eps_b = f_j (utils.py:69)
+    i -= n_av1 + n_a2 + n_v2;
+    if (i < 2 * H) {
+      *p_mu = d.p_mub_av1 + i; *p_sig = d.p_sigb_av1 + i; *w_off = d.o_bav1 + i;
+      *eps = e ? noise_f(i < H ? e[H + i] : e[3 * H + (i - H)]) : 0.f;
+    } else if (i < 2 * H + d.NA) {
+      i -= 2 * H;
+      *p_mu = d.p_mub_a2 + i; *p_sig = d.p_sigb_a2 + i; *w_off = d.o_ba2 + i;
+      *eps = e ? noise_f(e[5 * H + i]) : 0.f;
+    } else {
+      i -= 2 * H + d.NA;
+      *p_mu = d.p_mub_v2 + i; *p_sig = d.p_sigb_v2 + i; *w_off = d.o_bv2 + i;
+      *eps = e ? noise_f(e[6 * H + d.NA + i]) : 0.f;
+    }
+    return;
+  }
+  *eps = e ? noise_f(ei[k]) * noise_f(ej[n]) : 0.f;  // torch.outer(f_i, f_j)
+}
+
+struct NoiseSets {
+  const float* params[3];
+  const float* noise[3];  // null: evaluation mode, W = mu (rainbow.py network: is_train False)
+  float* weff[3];
+  int n_sets;
+};
+
+// W_eff = mu + sig * eps for up to three (parameter set, noise draw) pairs in one launch
+__global__ void __launch_bounds__(256) jh_rb_noise_kernel(NoisyDims d, NoiseSets s, int64_t n_total) {
+  const int set = blockIdx.y;
+  const float* P = s.params[set];
+  const float* e = s.noise[set];
+  float* W = s.weff[set];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_total; i += (int64_t)gridDim.x * 256) {
+    int64_t pm, ps, wo;
+    float eps;
+    noisy_locate(d, i, e, &pm, &ps, &wo, &eps);
+    W[wo] = e ? P[pm] + P[ps] * eps : P[pm];
+  }
+}
+
+// d(sig) = d(W_eff) * eps; d(mu) = d(W_eff) was written in place by the weight-gradient GEMMs
+__global__ void __launch_bounds__(256) jh_rb_noisy_grad_kernel(NoisyDims d, const float* __restrict__ e, float* __restrict__ G, int64_t n_total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_total; i += (int64_t)gridDim.x * 256) {
+    int64_t pm, ps, wo;
+    float eps;
+    noisy_locate(d, i, e, &pm, &ps, &wo, &eps);
+    G[ps] = G[pm] * eps;
+  }
+}
+
+// ---------------------------------------------------------------------------------- dueling combine
+struct DuelSets {
+  const float* xa[3];
+  const float* xv[3];
+  float* out[3];
+};
+// logits[b][a][k] = xa[b][a][k] - mean_a xa[b][.][k] + xv[b][k]   (network/rainbow.py:88-93)
+__global__ void __launch_bounds__(256) jh_rb_duel_fwd_kernel(DuelSets s, int B, int A, int K, int ld_a, int ld_v) {
+  const int set = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * K) return;
+  const int b = i / K, k = i - b * K;
+  const float* xa = s.xa[set] + (size_t)b * ld_a;
+  float sum = 0.f;
+  for (int a = 0; a < A; ++a) sum += xa[a * K + k];
+  const float mean = sum / (float)A;
+  const float v = s.xv[set][(size_t)b * ld_v + k];
+  float* o = s.out[set] + (size_t)b * A * K;
+  for (int a = 0; a < A; ++a) o[a * K + k] = (xa[a * K + k] - mean) + v;
+}
+__global__ void __launch_bounds__(256) jh_rb_duel_bwd_kernel(const float* __restrict__ g, int B, int A, int K, float* __restrict__ dxa, int ld_a,
+                                                             float* __restrict__ dxv, int ld_v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * K) return;
+  const int b = i / K, k = i - b * K;
+  const float* gb = g + (size_t)b * A * K;
+  float sum = 0.f;
+  for (int a = 0; a < A; ++a) sum += gb[a * K + k];
+  dxv[(size_t)b * ld_v + k] = sum;
+  const float mean = sum / (float)A;
+  for (int a = 0; a < A; ++a) dxa[(size_t)b * ld_a + a * K + k] = gb[a * K + k] - mean;
+}
+
+// ---------------------------------------------------------------------------------- col2im (+ relu')
+// d(act)[(b, y, x)][c] = relu'(act) * sum over the taps (ky, kx) that read this pixel of d(col)[(b, oy, ox)][(ky, kx, c)]
+__global__ void __launch_bounds__(256) jh_rb_col2im_kernel(const float* __restrict__ dcol, const float* __restrict__ act, float* __restrict__ dact,
+                                                           int n_pix, int C, int H, int W, int OH, int OW, int KH, int KW, int S) {
+  const int c4 = C / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)n_pix * c4) return;
+  const int pix = (int)(i / c4), c = 4 * (int)(i - (int64_t)pix * c4);
+  const int x = pix % W, t = pix / W, y = t % H, b = t / H;
+  const int Kp = KH * KW * C;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ky = 0; ky < KH; ++ky) {
+    const int yy = y - ky;
+    if (yy < 0 || yy % S) continue;
+    const int oy = yy / S;
+    if (oy >= OH) continue;
+    for (int kx = 0; kx < KW; ++kx) {
+      const int xx = x - kx;
+      if (xx < 0 || xx % S) continue;
+      const int ox = xx / S;
+      if (ox >= OW) continue;
+      const float4 v = *reinterpret_cast<const float4*>(dcol + ((size_t)(b * OH + oy) * OW + ox) * Kp + (ky * KW + kx) * C + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  const float4 a = *reinterpret_cast<const float4*>(act + (size_t)pix * C + c);
+  acc.x = a.x > 0.f ? acc.x : 0.f; acc.y = a.y > 0.f ? acc.y : 0.f; acc.z = a.z > 0.f ? acc.z : 0.f; acc.w = a.w > 0.f ? acc.w : 0.f;
+  *reinterpret_cast<float4*>(dact + (size_t)pix * C + c) = acc;
+}
+
+// ---------------------------------------------------------------------------------- Adam (torch.optim.Adam, no weight decay)
+// hyper (device): {lr, beta1, beta2, eps, step}.  The step counter advances inside: every workgroup derives
+// the bias corrections from step + 1 at its start; the last one to finish stores the new step.
+__global__ void __launch_bounds__(256) jh_rb_adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, float* __restrict__ hyper, unsigned* __restrict__ ticket) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  const float t_new = hyper[4] + 1.f;
+  const float bc1 = 1.f - powf(b1, t_new), bc2s = sqrtf(1.f - powf(b2, t_new));
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hyper[4] = t_new;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- host side
+inline Opnd op_dense(int mode, const float* p, int ld) {
+  Opnd o{};
+  o.p = p; o.ld = ld; o.mode = mode;
+  o.vec = (ld % 4 == 0) && (((uintptr_t)p & 15) == 0);
+  return o;
+}
+struct ConvGeom {
+  int C, H, W, OH, OW, KH, KW, S;
+};
+inline Opnd op_conv(int mode, const void* p, int u8, const ConvGeom& c) {
+  Opnd o{};
+  o.p = p; o.mode = mode; o.u8 = u8;
+  o.C = c.C; o.H = c.H; o.W = c.W; o.OH = c.OH; o.OW = c.OW; o.KH = c.KH; o.KW = c.KW; o.S = c.S;
+  if (mode <= OP_NHWC_X) o.vec = (c.C % 4 == 0) && (((uintptr_t)p & 15) == 0);
+  else o.vec = (c.KW % 4 == 0) && (((uintptr_t)p & (u8 ? 3 : 15)) == 0);
+  return o;
+}
+inline TGemm mk_gemm(int M, int N, int K, const Opnd& a, const Opnd& b, float* C, int ldc, int epi, const float* bias = nullptr,
+                     const float* aux = nullptr, int ldaux = 0, float* rowsum = nullptr) {
+  TGemm g{};
+  g.M = M; g.N = N; g.K = K; g.a = a; g.b = b; g.C = C; g.ldc = ldc; g.epi = epi; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.rowsum = rowsum;
+  return g;
+}
+
+}  // namespace
+
+enum {
+  SEG_W1, SEG_B1, SEG_W2, SEG_B2, SEG_W3, SEG_B3, SEG_WL, SEG_BL,
+  SEG_MU_AV1, SEG_SIG_AV1, SEG_MUB_AV1, SEG_SIGB_AV1, SEG_MU_A2, SEG_SIG_A2, SEG_MUB_A2, SEG_SIGB_A2,
+  SEG_MU_V2, SEG_SIG_V2, SEG_MUB_V2, SEG_SIGB_V2, SEG_COUNT
+};
+
+struct jh_rbnet {
+  jh_ctx* ctx = nullptr;
+  int cnn = 0, Cin = 0, Hin = 0, Win = 0, hidden = 0, A = 0, K = 0, NA = 0, maxB = 0, F = 0;
+  int NA4 = 0, K4 = 0;
+  ConvGeom c1{}, c2{}, c3{};
+  int P1 = 0, P2 = 0, P3 = 0;  // output pixels per sample
+  int64_t seg_off[SEG_COUNT] = {0};
+  int seg_rows[SEG_COUNT] = {0}, seg_cols[SEG_COUNT] = {0};
+  int64_t n_params = 0;
+  float *params = nullptr, *target = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+  float* hyper = nullptr;
+  unsigned* ticket = nullptr;
+  NoisyDims nd{};
+  int64_t n_noisy = 0;
+  float* weff = nullptr;                                // [3][set_stride]
+  float *act1[2] = {nullptr, nullptr}, *act2[2] = {nullptr, nullptr}, *feat[2] = {nullptr, nullptr}, *h[2] = {nullptr, nullptr};
+  float *hav = nullptr, *xa = nullptr, *xv = nullptr;  // [3][maxB][...]
+  float *dxa = nullptr, *dxv = nullptr, *dhav = nullptr, *dh = nullptr, *dfeat = nullptr, *dcol = nullptr, *dact2 = nullptr, *dact1 = nullptr;
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+  unsigned* cnt = nullptr;
+  int cnt_slots = 0;
+  const void* last_x = nullptr;  // input of the last learn_forward (backward of layer 1 reads it again)
+  int last_x_u8 = 0, last_B = 0;
+  const float* last_noise = nullptr;
+  std::vector<void*> owned;
+};
+
+static int rb_alloc(jh_rbnet* n, void** out, size_t bytes, bool zero) {
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) return jh_fail(JH_ERR_NOMEM, "jh_rbnet: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  n->owned.push_back(*out);
+  if (zero) JH_HIP(hipMemset(*out, 0, bytes));
+  return JH_OK;
+}
+
+static int launch_tgemm(jh_rbnet* net, const char* name, TGemm* probs, int n, hipStream_t st) {
+  if (n < 1 || n > kMaxGroup) return jh_fail(JH_ERR_ARG, "tgemm group of %d", n);
+  int maxM = 0, maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    if (probs[i].M > maxM) maxM = probs[i].M;
+    if (probs[i].N > maxN) maxN = probs[i].N;
+  }
+  const int TM = maxM <= 32 ? 1 : 2, TN = maxN <= 32 ? 1 : 2;
+  const int BM = 32 * TM, BN = 32 * TN;
+  int max_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    probs[i].tiles_m = (probs[i].M + BM - 1) / BM;
+    probs[i].tiles_n = (probs[i].N + BN - 1) / BN;
+    const int t = probs[i].tiles_m * probs[i].tiles_n;
+    if (t > max_tiles) max_tiles = t;
+  }
+  // fill the chip: ~2 workgroups per CU, but every split keeps at least two 32-wide K chunks
+  size_t ws_used = 0;
+  int cnt_used = 0, max_split = 1;
+  for (int i = 0; i < n; ++i) {
+    const int tiles = probs[i].tiles_m * probs[i].tiles_n;
+    const int nchunks = (probs[i].K + 31) / 32;
+    int s = 256 / (tiles > 0 ? tiles : 1);  // per problem: the problems of a group run side by side
+    if (s > nchunks / 2) s = nchunks / 2;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    const size_t pstride = (size_t)BM * BN + BM;
+    while (s > 1 && (ws_used + (size_t)s * tiles * pstride > net->ws_floats || cnt_used + tiles > net->cnt_slots)) --s;
+    // no empty splits: shrink to the number of splits that actually own chunks
+    if (s > 1) {
+      const int per = (nchunks + s - 1) / s;
+      s = (nchunks + per - 1) / per;
+    }
+    probs[i].splitk = s;
+    if (s > 1) {
+      probs[i].ws = net->ws + ws_used;
+      probs[i].cnt = net->cnt + cnt_used;
+      ws_used += (size_t)s * tiles * pstride;
+      cnt_used += tiles;
+    }
+    if (s > max_split) max_split = s;
+  }
+  TGemmBatch batch{};
+  for (int i = 0; i < n; ++i) batch.p[i] = probs[i];
+  const dim3 grid(max_tiles, n, max_split);
+  if (TM == 2 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 2>), grid, dim3(256), 0, st, batch);
+  else if (TM == 1 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<1, 2>), grid, dim3(256), 0, st, batch);
+  else if (TM == 2 && TN == 1) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 1>), grid, dim3(256), 0, st, batch);
+  else JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<1, 1>), grid, dim3(256), 0, st, batch);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+
+static int rb_layout(jh_rbnet* n, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K, int32_t max_batch) {
+  JH_ARG(hidden > 0 && hidden % 4 == 0 && A > 0 && K > 1 && max_batch > 0 && c_or_s > 0);
+  n->cnn = head_cnn ? 1 : 0;
+  n->Cin = c_or_s; n->Hin = h_in; n->Win = w_in; n->hidden = hidden; n->A = A; n->K = K; n->NA = A * K; n->maxB = max_batch;
+  n->NA4 = (int)up4(n->NA); n->K4 = (int)up4(K);
+  const int H = hidden;
+  if (n->cnn) {
+    if (h_in < 36 || w_in < 36) return jh_fail(JH_ERR_ARG, "cnn head needs images >= 36x36 (head.py:26), got %dx%d", h_in, w_in);
+    n->c1 = ConvGeom{c_or_s, h_in, w_in, (h_in - 8) / 4 + 1, (w_in - 8) / 4 + 1, 8, 8, 4};
+    n->c2 = ConvGeom{32, n->c1.OH, n->c1.OW, (n->c1.OH - 4) / 2 + 1, (n->c1.OW - 4) / 2 + 1, 4, 4, 2};
+    n->c3 = ConvGeom{64, n->c2.OH, n->c2.OW, n->c2.OH - 3 + 1, n->c2.OW - 3 + 1, 3, 3, 1};
+    n->P1 = n->c1.OH * n->c1.OW; n->P2 = n->c2.OH * n->c2.OW; n->P3 = n->c3.OH * n->c3.OW;
+    n->F = 64 * n->P3;
+  } else {
+    n->F = H;
+  }
+  auto seg = [&](int id, int rows, int cols) { n->seg_rows[id] = rows; n->seg_cols[id] = cols; };
+  if (n->cnn) {
+    seg(SEG_W1, 32, c_or_s * 64); seg(SEG_B1, 1, 32);
+    seg(SEG_W2, 64, 16 * 32); seg(SEG_B2, 1, 64);
+    seg(SEG_W3, 64, 9 * 64); seg(SEG_B3, 1, 64);
+  } else {
+    seg(SEG_W1, H, c_or_s); seg(SEG_B1, 1, H);
+  }
+  seg(SEG_WL, H, n->F); seg(SEG_BL, 1, H);
+  seg(SEG_MU_AV1, 2 * H, H); seg(SEG_SIG_AV1, 2 * H, H); seg(SEG_MUB_AV1, 1, 2 * H); seg(SEG_SIGB_AV1, 1, 2 * H);
+  seg(SEG_MU_A2, n->NA, H); seg(SEG_SIG_A2, n->NA, H); seg(SEG_MUB_A2, 1, n->NA); seg(SEG_SIGB_A2, 1, n->NA);
+  seg(SEG_MU_V2, K, H); seg(SEG_SIG_V2, K, H); seg(SEG_MUB_V2, 1, K); seg(SEG_SIGB_V2, 1, K);
+  int64_t off = 0;
+  for (int i = 0; i < SEG_COUNT; ++i) {
+    n->seg_off[i] = off;
+    off = up4(off + (int64_t)n->seg_rows[i] * n->seg_cols[i]);
+  }
+  n->n_params = off;
+  NoisyDims& d = n->nd;
+  d.H = H; d.NA = n->NA; d.K = K;
+  d.o_av1 = 0;
+  d.o_bav1 = up4(d.o_av1 + (int64_t)2 * H * H);
+  d.o_a2 = up4(d.o_bav1 + 2 * H);
+  d.o_ba2 = up4(d.o_a2 + (int64_t)n->NA * H);
+  d.o_v2 = up4(d.o_ba2 + n->NA);
+  d.o_bv2 = up4(d.o_v2 + (int64_t)K * H);
+  d.set_stride = up4(d.o_bv2 + K);
+  d.p_mu_av1 = n->seg_off[SEG_MU_AV1]; d.p_sig_av1 = n->seg_off[SEG_SIG_AV1]; d.p_mub_av1 = n->seg_off[SEG_MUB_AV1]; d.p_sigb_av1 = n->seg_off[SEG_SIGB_AV1];
+  d.p_mu_a2 = n->seg_off[SEG_MU_A2]; d.p_sig_a2 = n->seg_off[SEG_SIG_A2]; d.p_mub_a2 = n->seg_off[SEG_MUB_A2]; d.p_sigb_a2 = n->seg_off[SEG_SIGB_A2];
+  d.p_mu_v2 = n->seg_off[SEG_MU_V2]; d.p_sig_v2 = n->seg_off[SEG_SIG_V2]; d.p_mub_v2 = n->seg_off[SEG_MUB_V2]; d.p_sigb_v2 = n->seg_off[SEG_SIGB_V2];
+  d.noise_len = (int64_t)6 * H + n->NA + K;
+  n->n_noisy = (int64_t)2 * H * H + (int64_t)n->NA * H + (int64_t)K * H + 2 * H + n->NA + K;
+  return JH_OK;
+}
+
+JH_EXPORT int64_t jh_rbnet_param_count_for(int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K) {
+  jh_rbnet tmp;
+  if (rb_layout(&tmp, head_cnn, c_or_s, h_in, w_in, hidden, A, K, 1)) return -1;
+  return tmp.n_params;
+}
+
+JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K,
+                              int32_t max_batch, float* d_params, float* d_target, float* d_grads, float* d_m, float* d_v, jh_rbnet** out) {
+  JH_ARG(ctx && out && d_params && d_target && d_grads && d_m && d_v);
+  JH_HIP(hipSetDevice(ctx->device));
+  jh_rbnet* n = new jh_rbnet();
+  n->ctx = ctx;
+  int rc = rb_layout(n, head_cnn, c_or_s, h_in, w_in, hidden, A, K, max_batch);
+  if (rc) {
+    delete n;
+    return rc;
+  }
+  n->params = d_params; n->target = d_target; n->grads = d_grads; n->m = d_m; n->v = d_v;
+  const NoisyDims& d = n->nd;
+  const int H = hidden;
+  const size_t B = (size_t)max_batch;
+  auto A4 = [&](float** p, size_t floats, bool zero = true) { if (!rc) rc = rb_alloc(n, (void**)p, floats * sizeof(float), zero); };
+  A4(&n->hyper, 8);
+  if (!rc) rc = rb_alloc(n, (void**)&n->ticket, 16, true);
+  A4(&n->weff, 3 * (size_t)d.set_stride);
+  for (int s = 0; s < 2; ++s) {
+    const size_t rows = s == 0 ? 2 * B : B;
+    if (n->cnn) {
+      A4(&n->act1[s], rows * n->P1 * 32);
+      A4(&n->act2[s], rows * n->P2 * 64);
+    }
+    A4(&n->feat[s], rows * n->F);
+    A4(&n->h[s], rows * H);
+  }
+  A4(&n->hav, 3 * B * 2 * H); A4(&n->xa, 3 * B * n->NA4); A4(&n->xv, 3 * B * n->K4);
+  A4(&n->dxa, B * n->NA4); A4(&n->dxv, B * n->K4); A4(&n->dhav, B * 2 * H); A4(&n->dh, B * H); A4(&n->dfeat, B * n->F);
+  if (n->cnn) {
+    size_t dc = B * n->P3 * 576;
+    if (B * n->P2 * 512 > dc) dc = B * n->P2 * 512;
+    A4(&n->dcol, dc); A4(&n->dact2, B * n->P2 * 64); A4(&n->dact1, B * n->P1 * 32);
+  }
+  n->ws_floats = (size_t)8 << 20;  // 32 MB of split-K partials
+  A4(&n->ws, n->ws_floats, false);
+  n->cnt_slots = 8192;
+  if (!rc) rc = rb_alloc(n, (void**)&n->cnt, sizeof(unsigned) * n->cnt_slots, true);
+  if (rc) {
+    for (void* p : n->owned) (void)hipFree(p);
+    delete n;
+    return rc;
+  }
+  const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
+  JH_HIP(hipMemcpy(n->hyper, hy, sizeof(hy), hipMemcpyHostToDevice));
+  JH_HIP(hipDeviceSynchronize());
+  *out = n;
+  return JH_OK;
+}
+
+JH_EXPORT void jh_rbnet_destroy(jh_rbnet* n) {
+  if (!n) return;
+  (void)hipSetDevice(n->ctx->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : n->owned) (void)hipFree(p);
+  delete n;
+}
+
+JH_EXPORT int64_t jh_rbnet_param_count(const jh_rbnet* n) { return n ? n->n_params : -1; }
+JH_EXPORT int32_t jh_rbnet_segment_count(void) { return SEG_COUNT; }
+JH_EXPORT int jh_rbnet_segment(const jh_rbnet* n, int32_t i, int64_t* offset, int32_t* rows, int32_t* cols) {
+  JH_ARG(n && i >= 0 && i < SEG_COUNT && offset && rows && cols);
+  *offset = n->seg_off[i]; *rows = n->seg_rows[i]; *cols = n->seg_cols[i];
+  return JH_OK;
+}
+JH_EXPORT int64_t jh_rbnet_noise_len(const jh_rbnet* n) { return n ? n->nd.noise_len : -1; }
+
+JH_EXPORT int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1, float beta2, float eps, int64_t step, jh_stream stream) {
+  JH_ARG(n != nullptr);
+  jh_pinned_slab* slab = nullptr;
+  int rc = jh_ctx_slab(n->ctx, 32, &slab);
+  if (rc) return rc;
+  float* h = (float*)slab->host;
+  h[0] = lr; h[1] = beta1; h[2] = beta2; h[3] = eps; h[4] = (float)step;
+  JH_HIP(hipMemcpyAsync(n->hyper, slab->dev, 5 * sizeof(float), hipMemcpyDeviceToDevice, jh_s(stream)));
+  return jh_ctx_slab_release(n->ctx, slab, jh_s(stream));
+}
+JH_EXPORT int jh_rbnet_set_lr(jh_rbnet* n, float lr, jh_stream stream) {
+  JH_ARG(n != nullptr);
+  jh_pinned_slab* slab = nullptr;
+  int rc = jh_ctx_slab(n->ctx, 16, &slab);
+  if (rc) return rc;
+  *(float*)slab->host = lr;
+  JH_HIP(hipMemcpyAsync(n->hyper, slab->dev, sizeof(float), hipMemcpyDeviceToDevice, jh_s(stream)));
+  return jh_ctx_slab_release(n->ctx, slab, jh_s(stream));
+}
+JH_EXPORT int jh_rbnet_sync_target(jh_rbnet* n, jh_stream stream) {
+  JH_ARG(n != nullptr);
+  JH_HIP(hipMemcpyAsync(n->target, n->params, sizeof(float) * (size_t)n->n_params, hipMemcpyDeviceToDevice, jh_s(stream)));
+  return JH_OK;
+}
+
+// trunk (head + l) for up to two (parameter set, input rows) pairs -> h[slot]
+struct TrunkJob {
+  const float* P;
+  const void* x;
+  int rows, slot;
+};
+static int rb_trunk(jh_rbnet* n, const TrunkJob* jobs, int nj, int x_u8, hipStream_t st) {
+  const int H = n->hidden;
+  TGemm g[2];
+  if (n->cnn) {
+    for (int j = 0; j < nj; ++j) {
+      const TrunkJob& J = jobs[j];
+      g[j] = mk_gemm(J.rows * n->P1, 32, n->Cin * 64, op_conv(OP_NCHW_K, J.x, x_u8, n->c1), op_dense(OP_KCONT, J.P + n->seg_off[SEG_W1], n->Cin * 64),
+                     n->act1[J.slot], 32, TEPI_BIAS_RELU, J.P + n->seg_off[SEG_B1]);
+    }
+    int rc = launch_tgemm(n, "jh_tgemm_conv1_fwd", g, nj, st);
+    if (rc) return rc;
+    for (int j = 0; j < nj; ++j) {
+      const TrunkJob& J = jobs[j];
+      g[j] = mk_gemm(J.rows * n->P2, 64, 512, op_conv(OP_NHWC_K, n->act1[J.slot], 0, n->c2), op_dense(OP_KCONT, J.P + n->seg_off[SEG_W2], 512),
+                     n->act2[J.slot], 64, TEPI_BIAS_RELU, J.P + n->seg_off[SEG_B2]);
+    }
+    rc = launch_tgemm(n, "jh_tgemm_conv2_fwd", g, nj, st);
+    if (rc) return rc;
+    for (int j = 0; j < nj; ++j) {
+      const TrunkJob& J = jobs[j];
+      g[j] = mk_gemm(J.rows * n->P3, 64, 576, op_conv(OP_NHWC_K, n->act2[J.slot], 0, n->c3), op_dense(OP_KCONT, J.P + n->seg_off[SEG_W3], 576),
+                     n->feat[J.slot], 64, TEPI_BIAS_RELU, J.P + n->seg_off[SEG_B3]);
+    }
+    rc = launch_tgemm(n, "jh_tgemm_conv3_fwd", g, nj, st);
+    if (rc) return rc;
+  } else {
+    if (x_u8) return jh_fail(JH_ERR_ARG, "mlp head takes fp32 observations");
+    for (int j = 0; j < nj; ++j) {
+      const TrunkJob& J = jobs[j];
+      g[j] = mk_gemm(J.rows, H, n->Cin, op_dense(OP_KCONT, (const float*)J.x, n->Cin), op_dense(OP_KCONT, J.P + n->seg_off[SEG_W1], n->Cin),
+                     n->feat[J.slot], H, TEPI_BIAS_RELU, J.P + n->seg_off[SEG_B1]);
+    }
+    int rc = launch_tgemm(n, "jh_tgemm_head_fwd", g, nj, st);
+    if (rc) return rc;
+  }
+  for (int j = 0; j < nj; ++j) {
+    const TrunkJob& J = jobs[j];
+    g[j] = mk_gemm(J.rows, H, n->F, op_dense(OP_KCONT, n->feat[J.slot], n->F), op_dense(OP_KCONT, J.P + n->seg_off[SEG_WL], n->F), n->h[J.slot], H,
+                   TEPI_BIAS_RELU, J.P + n->seg_off[SEG_BL]);
+  }
+  return launch_tgemm(n, "jh_tgemm_fc_fwd", g, nj, st);
+}
+
+// noisy dueling heads for up to three (parameter set, noise draw, hidden rows) triples -> logits
+struct HeadJob {
+  const float* P;
+  const float* noise;
+  const float* h;  // [B][H]
+  float* logits;   // [B][A][K]
+};
+static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t st) {
+  const int H = n->hidden, NA = n->NA, K = n->K;
+  const NoisyDims& d = n->nd;
+  NoiseSets ns{};
+  ns.n_sets = nj;
+  for (int j = 0; j < nj; ++j) {
+    ns.params[j] = jobs[j].P; ns.noise[j] = jobs[j].noise; ns.weff[j] = n->weff + (size_t)j * d.set_stride;
+  }
+  {
+    int64_t blocks = (n->n_noisy + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    JH_LAUNCH(jh_rb_noise_kernel, dim3((unsigned)blocks, nj), dim3(256), 0, st, d, ns, n->n_noisy);
+    JH_LAUNCH_CHECK();
+  }
+  TGemm g[6];
+  const size_t B_ = (size_t)n->maxB;
+  for (int j = 0; j < nj; ++j) {
+    const float* W = n->weff + (size_t)j * d.set_stride;
+    g[j] = mk_gemm(B, 2 * H, H, op_dense(OP_KCONT, jobs[j].h, H), op_dense(OP_KCONT, W + d.o_av1, H), n->hav + j * B_ * 2 * H, 2 * H, TEPI_BIAS_RELU,
+                   W + d.o_bav1);
+  }
+  int rc = launch_tgemm(n, "jh_tgemm_noisy1_fwd", g, nj, st);
+  if (rc) return rc;
+  for (int j = 0; j < nj; ++j) {
+    const float* W = n->weff + (size_t)j * d.set_stride;
+    const float* hav = n->hav + j * B_ * 2 * H;
+    g[2 * j] = mk_gemm(B, NA, H, op_dense(OP_KCONT, hav, 2 * H), op_dense(OP_KCONT, W + d.o_a2, H), n->xa + j * B_ * n->NA4, n->NA4, TEPI_BIAS, W + d.o_ba2);
+    g[2 * j + 1] = mk_gemm(B, K, H, op_dense(OP_KCONT, hav + H, 2 * H), op_dense(OP_KCONT, W + d.o_v2, H), n->xv + j * B_ * n->K4, n->K4, TEPI_BIAS, W + d.o_bv2);
+  }
+  rc = launch_tgemm(n, "jh_tgemm_noisy2_fwd", g, 2 * nj, st);
+  if (rc) return rc;
+  DuelSets ds{};
+  for (int j = 0; j < nj; ++j) {
+    ds.xa[j] = n->xa + j * B_ * n->NA4; ds.xv[j] = n->xv + j * B_ * n->K4; ds.out[j] = jobs[j].logits;
+  }
+  JH_LAUNCH(jh_rb_duel_fwd_kernel, dim3((B * K + 255) / 256, nj), dim3(256), 0, st, ds, B, n->A, K, n->NA4, n->K4);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// network(x, is_train) for acting / evaluation: rows <= max_batch.  which: 0 online, 1 target.
+// noise: one noise set (jh_rbnet_noise_len floats of N(0,1)) or null for is_train = False.
+JH_EXPORT int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int32_t x_dtype, int32_t rows, const float* d_noise, float* d_logits,
+                               jh_stream stream) {
+  JH_ARG(n && d_x && d_logits);
+  JH_ARG(rows > 0 && rows <= n->maxB && (which == 0 || which == 1));
+  JH_ARG(x_dtype == JH_U8 || x_dtype == JH_F32);
+  hipStream_t st = jh_s(stream);
+  const float* P = which == 0 ? n->params : n->target;
+  TrunkJob tj{P, d_x, rows, 0};
+  int rc = rb_trunk(n, &tj, 1, x_dtype == JH_U8, st);
+  if (rc) return rc;
+  HeadJob hj{P, d_noise, n->h[0], d_logits};
+  return rb_heads(n, &hj, 1, rows, st);
+}
+
+// The three forwards of Rainbow.learn (agent/rainbow.py:160-186) in one pass:
+//   d_x = [state (B rows); next_state (B rows)]  (one contiguous batch of 2B observations)
+//   logits[0] = online(state; noise 0)   logits[1] = online(next_state; noise 1)   logits[2] = target(next_state; noise 2)
+// The online trunk runs once over all 2B rows; the target trunk shares the launches (grouped GEMMs).
+JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
+  JH_ARG(n && d_x && d_noise && d_logits);
+  JH_ARG(B > 0 && B <= n->maxB);
+  JH_ARG(x_dtype == JH_U8 || x_dtype == JH_F32);
+  hipStream_t st = jh_s(stream);
+  const size_t row_elems = n->cnn ? (size_t)n->Cin * n->Hin * n->Win : (size_t)n->Cin;
+  const size_t esz = x_dtype == JH_U8 ? 1 : 4;
+  const void* x_next = (const char*)d_x + (size_t)B * row_elems * esz;
+  TrunkJob tj[2] = {{n->params, d_x, 2 * B, 0}, {n->target, x_next, B, 1}};
+  int rc = rb_trunk(n, tj, 2, x_dtype == JH_U8, st);
+  if (rc) return rc;
+  const int64_t L = n->nd.noise_len;
+  const size_t lsz = (size_t)B * n->NA;
+  HeadJob hj[3] = {{n->params, d_noise, n->h[0], d_logits},
+                   {n->params, d_noise + L, n->h[0] + (size_t)B * n->hidden, d_logits + lsz},
+                   {n->target, d_noise + 2 * L, n->h[1], d_logits + 2 * lsz}};
+  rc = rb_heads(n, hj, 3, B, st);
+  if (rc) return rc;
+  n->last_x = d_x; n->last_x_u8 = x_dtype == JH_U8; n->last_B = B; n->last_noise = d_noise;
+  return JH_OK;
+}
+
+// Backward of logits[0] of the last jh_rbnet_learn_forward: d_g = d(loss)/d(logits) [B][A][K]; fills the
+// gradient bucket (same layout as the parameters).  Effective weights of noise set 0 and all online
+// activations of the `state` rows are still in place.
+JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream) {
+  JH_ARG(n && d_g);
+  if (!n->last_x) return jh_fail(JH_ERR_STATE, "jh_rbnet_backward without a preceding jh_rbnet_learn_forward");
+  hipStream_t st = jh_s(stream);
+  const int B = n->last_B, H = n->hidden, NA = n->NA, K = n->K, F = n->F;
+  const NoisyDims& d = n->nd;
+  const float* W0 = n->weff;  // noise set 0
+  const float* hav0 = n->hav;
+  float* G = n->grads;
+  JH_LAUNCH(jh_rb_duel_bwd_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, d_g, B, n->A, K, n->dxa, n->NA4, n->dxv, n->K4);
+  JH_LAUNCH_CHECK();
+  TGemm g[4];
+  // second noisy layer: weight gradients (+ bias gradients as row sums) and data gradients (+ relu')
+  g[0] = mk_gemm(NA, H, B, op_dense(OP_XCONT, n->dxa, n->NA4), op_dense(OP_XCONT, hav0, 2 * H), G + n->seg_off[SEG_MU_A2], H, TEPI_NONE, nullptr, nullptr, 0,
+                 G + n->seg_off[SEG_MUB_A2]);
+  g[1] = mk_gemm(K, H, B, op_dense(OP_XCONT, n->dxv, n->K4), op_dense(OP_XCONT, hav0 + H, 2 * H), G + n->seg_off[SEG_MU_V2], H, TEPI_NONE, nullptr, nullptr, 0,
+                 G + n->seg_off[SEG_MUB_V2]);
+  g[2] = mk_gemm(B, H, NA, op_dense(OP_KCONT, n->dxa, n->NA4), op_dense(OP_XCONT, W0 + d.o_a2, H), n->dhav, 2 * H, TEPI_MASK, nullptr, hav0, 2 * H);
+  g[3] = mk_gemm(B, H, K, op_dense(OP_KCONT, n->dxv, n->K4), op_dense(OP_XCONT, W0 + d.o_v2, H), n->dhav + H, 2 * H, TEPI_MASK, nullptr, hav0 + H, 2 * H);
+  int rc = launch_tgemm(n, "jh_tgemm_noisy2_bwd", g, 4, st);
+  if (rc) return rc;
+  // first noisy layer (a1 | v1 stacked)
+  g[0] = mk_gemm(2 * H, H, B, op_dense(OP_XCONT, n->dhav, 2 * H), op_dense(OP_XCONT, n->h[0], H), G + n->seg_off[SEG_MU_AV1], H, TEPI_NONE, nullptr, nullptr, 0,
+                 G + n->seg_off[SEG_MUB_AV1]);
+  g[1] = mk_gemm(B, H, 2 * H, op_dense(OP_KCONT, n->dhav, 2 * H), op_dense(OP_XCONT, W0 + d.o_av1, H), n->dh, H, TEPI_MASK, nullptr, n->h[0], H);
+  rc = launch_tgemm(n, "jh_tgemm_noisy1_bwd", g, 2, st);
+  if (rc) return rc;
+  {
+    int64_t blocks = (n->n_noisy + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    JH_LAUNCH(jh_rb_noisy_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, n->last_noise, G, n->n_noisy);
+    JH_LAUNCH_CHECK();
+  }
+  // l: F -> H
+  g[0] = mk_gemm(H, F, B, op_dense(OP_XCONT, n->dh, H), op_dense(OP_XCONT, n->feat[0], F), G + n->seg_off[SEG_WL], F, TEPI_NONE, nullptr, nullptr, 0,
+                 G + n->seg_off[SEG_BL]);
+  g[1] = mk_gemm(B, F, H, op_dense(OP_KCONT, n->dh, H), op_dense(OP_XCONT, n->params + n->seg_off[SEG_WL], F), n->dfeat, F, TEPI_MASK, nullptr, n->feat[0], F);
+  rc = launch_tgemm(n, "jh_tgemm_fc_bwd", g, 2, st);
+  if (rc) return rc;
+  if (!n->cnn) {
+    g[0] = mk_gemm(H, n->Cin, B, op_dense(OP_XCONT, n->dfeat, H), op_dense(OP_XCONT, (const float*)n->last_x, n->Cin), G + n->seg_off[SEG_W1], n->Cin, TEPI_NONE,
+                   nullptr, nullptr, 0, G + n->seg_off[SEG_B1]);
+    return launch_tgemm(n, "jh_tgemm_head_bwd", g, 1, st);
+  }
+  // conv3: d(feat) is d(act3) in NHWC [B*P3][64]
+  g[0] = mk_gemm(64, 576, B * n->P3, op_dense(OP_XCONT, n->dfeat, 64), op_conv(OP_NHWC_X, n->act2[0], 0, n->c3), G + n->seg_off[SEG_W3], 576, TEPI_NONE, nullptr,
+                 nullptr, 0, G + n->seg_off[SEG_B3]);
+  g[1] = mk_gemm(B * n->P3, 576, 64, op_dense(OP_KCONT, n->dfeat, 64), op_dense(OP_XCONT, n->params + n->seg_off[SEG_W3], 576), n->dcol, 576, TEPI_NONE);
+  rc = launch_tgemm(n, "jh_tgemm_conv3_bwd", g, 2, st);
+  if (rc) return rc;
+  {
+    const int n_pix = B * n->P2;
+    JH_LAUNCH(jh_rb_col2im_kernel, dim3((unsigned)(((int64_t)n_pix * 16 + 255) / 256)), dim3(256), 0, st, n->dcol, n->act2[0], n->dact2, n_pix, 64, n->c3.H,
+              n->c3.W, n->c3.OH, n->c3.OW, 3, 3, 1);
+    JH_LAUNCH_CHECK();
+  }
+  g[0] = mk_gemm(64, 512, B * n->P2, op_dense(OP_XCONT, n->dact2, 64), op_conv(OP_NHWC_X, n->act1[0], 0, n->c2), G + n->seg_off[SEG_W2], 512, TEPI_NONE, nullptr,
+                 nullptr, 0, G + n->seg_off[SEG_B2]);
+  g[1] = mk_gemm(B * n->P2, 512, 64, op_dense(OP_KCONT, n->dact2, 64), op_dense(OP_XCONT, n->params + n->seg_off[SEG_W2], 512), n->dcol, 512, TEPI_NONE);
+  rc = launch_tgemm(n, "jh_tgemm_conv2_bwd", g, 2, st);
+  if (rc) return rc;
+  {
+    const int n_pix = B * n->P1;
+    JH_LAUNCH(jh_rb_col2im_kernel, dim3((unsigned)(((int64_t)n_pix * 8 + 255) / 256)), dim3(256), 0, st, n->dcol, n->act1[0], n->dact1, n_pix, 32, n->c2.H,
+              n->c2.W, n->c2.OH, n->c2.OW, 4, 4, 2);
+    JH_LAUNCH_CHECK();
+  }
+  g[0] = mk_gemm(32, n->Cin * 64, B * n->P1, op_dense(OP_XCONT, n->dact1, 32), op_conv(OP_NCHW_X, n->last_x, n->last_x_u8, n->c1), G + n->seg_off[SEG_W1],
+                 n->Cin * 64, TEPI_NONE, nullptr, nullptr, 0, G + n->seg_off[SEG_B1]);
+  return launch_tgemm(n, "jh_tgemm_conv1_bwd", g, 1, st);
+}
+
+JH_EXPORT int jh_rbnet_adam_step(jh_rbnet* n, jh_stream stream) {
+  JH_ARG(n != nullptr);
+  JH_LAUNCH(jh_rb_adam_kernel, dim3(512), dim3(256), 0, jh_s(stream), n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}

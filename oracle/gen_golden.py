@@ -358,12 +358,16 @@ def gen_ppo(out_dir):
 # ----------------------------------------------------------------------------
 def _fill(agent, n, S, A, rng, n_step=None, with_q=False):
     """Drive interact_callback + memory.store the way Actor.run / run_mode do."""
+    if isinstance(S, int):
+        draw = lambda: rng.randn(1, S).astype(np.float32)
+    else:  # image observation: uint8 frames, as the Atari wrapper hands them over (atari.py:147-149)
+        draw = lambda: rng.randint(0, 256, size=(1,) + tuple(S)).astype(np.uint8)
     for i in range(n):
         t = {
-            "state": rng.randn(1, S).astype(np.float32),
+            "state": draw(),
             "action": rng.randint(0, A, size=(1, 1)),
             "reward": rng.choice([-1.0, 0.0, 1.0, 0.5], size=(1, 1)),
-            "next_state": rng.randn(1, S).astype(np.float32),
+            "next_state": draw(),
             "done": np.asarray([[rng.rand() < 0.1]]),
         }
         if with_q:
@@ -373,7 +377,7 @@ def _fill(agent, n, S, A, rng, n_step=None, with_q=False):
             agent.memory.store([t])
 
 
-def gen_dqn_family(out_dir):
+def gen_dqn_family(out_dir, only=None):
     import torch
     from core.agent.dqn import DQN
     from core.agent.double import Double
@@ -406,11 +410,18 @@ def gen_dqn_family(out_dir):
         ("c51", C51, dict(v_min=-2, v_max=5, num_support=21), dict(markers=["logit", "p_logit", "q_action", "p_action", "target_p_logit", "target_q_action", "target_action", "target_p_action", "Tz", "b", "l", "u", "target_dist", "loss"])),
         ("rainbow", Rainbow, dict(n_step=3, alpha=0.5, beta=0.4, learn_period=1, uniform_sample_prob=0.05, v_min=-1, v_max=10, num_support=51), dict(markers=["logit", "p_logit", "q_action", "p_action", "next_q_action", "target_p_logit", "target_action", "target_p_action", "Tz", "b", "l", "u", "target_dist", "KL", "p_j", "loss", "weights", "indices", "reward", "done"])),
     ]
+    # Nature-CNN head on a small non-square image (conv 8/4, 4/2, 3/1 -> 2x3x64 features)
+    specs.append(("rainbow_cnn", Rainbow, dict(n_step=3, alpha=0.5, beta=0.4, learn_period=1, uniform_sample_prob=0.05, v_min=-1, v_max=10, num_support=51),
+                  dict(markers=specs[-1][3]["markers"], over=dict(state_size=(4, 44, 52), head="cnn", batch_size=8, buffer_size=64), fill=40)))
     for name, cls, extra, opt in specs:
+        if (only is None) == (name == "rainbow_cnn") or (only is not None and name != only):
+            continue
         torch.manual_seed(3)
         np.random.seed(3)
         kw = dict(common)
         kw.update(extra)
+        kw.update(opt.get("over", {}))
+        S, B = kw["state_size"], kw["batch_size"]
         agent = cls(**kw)
         with torch.no_grad():
             for p in agent.network.parameters():
@@ -420,7 +431,7 @@ def gen_dqn_family(out_dir):
                 p.add_(0.1 * torch.randn_like(p))
         agent.memory.first_store = False
         rng = np.random.RandomState(17)
-        _fill(agent, 200, S, A, rng, with_q=opt.get("with_q", False))
+        _fill(agent, opt.get("fill", 200), S, A, rng, with_q=opt.get("with_q", False))
         is_per = hasattr(agent.memory, "sum_tree")
         if is_per:
             # non-trivial priorities before the sampled learn
@@ -482,7 +493,7 @@ def gen_dqn_family(out_dir):
         if is_per:
             out["tree1"] = agent.memory.sum_tree.copy()
             out["maxp1"] = np.asarray(agent.memory.max_priority)
-        hyper = dict(gamma=0.99, lr=1e-3, B=B, S=S, A=A, H=H, np_seed=42, torch_seed=42)
+        hyper = dict(gamma=0.99, lr=1e-3, B=B, S=np.asarray(S), A=A, H=H, np_seed=42, torch_seed=42)
         hyper.update({k: v for k, v in extra.items() if isinstance(v, (int, float))})
         for k, v in hyper.items():
             out[f"hyper/{k}"] = np.asarray(v)
@@ -567,6 +578,8 @@ def main():
             gen_dqn_family(out_dir)
         if "nstep" in todo:
             gen_nstep(out_dir)
+        if "rainbow_cnn" in todo:
+            gen_dqn_family(out_dir, only="rainbow_cnn")
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
     print("golden fixtures written to", out_dir)

@@ -72,19 +72,31 @@ def main():
     for _ in range(args.warmup):
         env_steps_and_learn()
     torch.cuda.synchronize()
-    ops.lib_profile(True)
     t0 = time.perf_counter()
     for _ in range(args.updates):
         r = env_steps_and_learn()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    graphed = agent._graph is not None
+    # per-kernel HIP-event timing needs eager launches: separate short pass, not part of `dt`
+    ops.lib_profile(True)
+    for _ in range(20):
+        env_steps_and_learn()
+    torch.cuda.synchronize()
     prof = ops.lib_profile_report()
     ops.lib_profile(False)
+    t0 = time.perf_counter()
+    for _ in range(40):
+        agent.learn()
+    torch.cuda.synchronize()
+    dt_learn = (time.perf_counter() - t0) / 40
     out = {
         "workload": f"config.rainbow.atari breakout-shaped, synthetic uint8 (4,84,84), B=32, n=3, K=51, PER N={N} ({filled} filled), CNN encoder via torch/MIOpen",
         "learner_updates_per_s": args.updates / dt,
         "env_steps_per_s_ceiling": 4 * args.updates / dt,
         "ms_per_update_incl_4_stores": dt / args.updates * 1e3,
+        "ms_per_learn_only": dt_learn * 1e3,
+        "learn_in_hipgraph": graphed,
         "fill_MB_per_s": filled * 2 * 28224 / fill_s / 1e6,
         "last_result": {k: float(v) for k, v in r.items()},
         "lib_kernel_avg_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
