@@ -58,26 +58,102 @@ class C51(DQN):
         return {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3])}
 
 
+class _NativeNet:
+    """What the agent code expects from `agent.network` / `agent.target_network` (an nn.Module) on top of
+    ops.RainbowNet's flat buckets: state_dict in the reference's keys / shapes, callable forward."""
+
+    def __init__(self, net, which):
+        self._net, self._which, self.training = net, which, True
+
+    def _bucket(self):
+        return self._net.params if self._which == 0 else self._net.target
+
+    def state_dict(self):
+        return self._net.export_state(self._bucket())
+
+    def load_state_dict(self, sd, strict=True):
+        self._net.import_state(sd, self._bucket())
+
+    def parameters(self):
+        return list(self.state_dict().values())
+
+    def named_parameters(self):
+        return list(self.state_dict().items())
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def pack_noise(self, noise, out=None):
+        """{tag: (e_in, e_out)} (the torch mirror's injection format) -> one flat noise set."""
+        flat = torch.cat([torch.cat([noise[t][0].reshape(-1), noise[t][1].reshape(-1)]) for t in ("a1", "v1", "a2", "v2")]).to(self._net.device, torch.float32)
+        assert flat.numel() == self._net.noise_len
+        if out is not None:
+            out.copy_(flat)
+            return out
+        return flat
+
+    @torch.no_grad()
+    def __call__(self, x, is_train, noise=None):
+        net = self._net
+        x = x.contiguous()
+        nz = None
+        if is_train:
+            nz = self.pack_noise(noise) if noise is not None else torch.randn(net.noise_len, device=net.device)
+        outs = [net.forward(x[o : o + net.maxB], self._which, nz) for o in range(0, x.shape[0], net.maxB)]  # one draw per call, like the reference
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
 class Rainbow(DQN):
     """core/agent/rainbow.py:14-308: noisy dueling categorical net, n-step double-Q projection, PER
     with priorities KL^alpha.  The projection + KL + backward-to-logits + priorities are one HIP
-    kernel (jh_c51_loss); priorities go straight into the device sum tree (no B `.item()` syncs)."""
+    kernel (jh_c51_loss); priorities go straight into the device sum tree (no B `.item()` syncs).
+
+    backend="native" (default when the configuration allows it: factorised noise, mlp / cnn head, Adam):
+    the network itself runs on libjorldy_hip (ops.RainbowNet): convolutions as implicit GEMMs on the fp32
+    MFMA reading the uint8 frames straight out of the replay store, the three forwards of learn() share
+    their launches, backward + Adam are native; ~30 launches per learn(), replayed as one hipGraph.
+    backend="torch": the PyTorch mirror of the reference modules (MIOpen / hipBLASLt) around the same
+    HIP loss / PER kernels."""
 
     def __init__(self, state_size, action_size, hidden_size=512, network="rainbow", head="mlp",
                  optim_config={"name": "adam"}, gamma=0.99, buffer_size=50000, batch_size=64, start_train_step=2000,
                  target_update_period=500, run_step=1e6, lr_decay=True, n_step=4, alpha=0.6, beta=0.4, learn_period=4,
                  uniform_sample_prob=1e-3, noise_type="factorized", v_min=-10, v_max=10, num_support=51, device=None,
-                 use_graph=True, **kwargs):
+                 use_graph=True, backend=None, **kwargs):
         self.device = self._require_gpu(device)
         self.use_graph = use_graph
         self._static, self._graph, self._warm, self.clip_grad_norm = None, None, False, None
         self._td = dict(double=True, per=True, n_step=1)
         self.action_size = action_size
         self.action_type = "discrete"
+        can_native = (network == "rainbow" and noise_type == "factorized" and head in ("mlp", "cnn") and hidden_size % 4 == 0
+                      and not isinstance(state_size, list) and (head == "cnn") == (not np.isscalar(state_size))
+                      and optim_config.get("name", "adam").lower() == "adam"
+                      and set(optim_config) <= {"name", "lr", "betas", "eps"})
+        self.backend = backend or ("native" if can_native else "torch")
+        assert self.backend in ("native", "torch")
+        if self.backend == "native" and not can_native:
+            raise ValueError("backend='native' needs network='rainbow', factorized noise, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam")
         mk = lambda: Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head).to(self.device)
-        self.network, self.target_network = mk(), mk()
-        self.target_network.load_state_dict(self.network.state_dict())
-        self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
+        self._net = None
+        if self.backend == "native":
+            self._net = ops.RainbowNet(state_size, action_size, num_support, hidden_size, head, batch_size, self.device)
+            self._net.import_state(mk().state_dict())  # the reference's initialisation (orthogonal / uniform, utils.py:89-124)
+            self._net.sync_target()
+            self.network, self.target_network = _NativeNet(self._net, 0), _NativeNet(self._net, 1)
+            self._optim_config = dict(optim_config)
+            d = Optimizer(**optim_config, params=[torch.nn.Parameter(torch.zeros(1))]).defaults
+            self._lr0, self._lr_now, self._adam_steps = float(d["lr"]), float(d["lr"]), 0
+            self._net.set_hyper(d["lr"], d["betas"][0], d["betas"][1], d["eps"], 0)
+            self.optimizer = None
+        else:
+            self.network, self.target_network = mk(), mk()
+            self.target_network.load_state_dict(self.network.state_dict())
+            self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
         self.gamma = gamma
         self.batch_size = batch_size
         self.start_train_step = start_train_step
@@ -126,7 +202,101 @@ class Rainbow(DQN):
     def _idx_offset(self):
         return self.memory.first_leaf_index
 
+    # ---- native backend ---------------------------------------------------------------------
+    def _as_float(self):
+        # frames stay uint8 until the first convolution's operand fetch; everything else fp32 (as_tensor)
+        return {"state": False, "next_state": False} if (self._net is not None and self._net.cnn) else True
+
+    def _alloc_static(self):
+        if self._net is None:
+            return super()._alloc_static()
+        B = self.batch_size
+        idx = torch.zeros(B, dtype=torch.int64, device=self.device)
+        probe = self.memory.gather(idx, idx_offset=0, as_float=self._as_float())
+        x_all = torch.empty((2 * B,) + tuple(probe["state"].shape[1:]), dtype=probe["state"].dtype, device=self.device)
+        tr = dict(probe)
+        tr["state"], tr["next_state"] = x_all[:B], x_all[B:]  # one contiguous [state; next_state] batch
+        return dict(idx=idx, w=torch.ones(B, dtype=torch.float32, device=self.device), tr=tr, store=self.memory._store, x_all=x_all,
+                    noise=torch.zeros(3, self._net.noise_len, dtype=torch.float32, device=self.device),
+                    logits=torch.empty(3, B, self.action_size, self.num_support, dtype=torch.float32, device=self.device))
+
+    def _learn_body_native(self, st):
+        net, B = self._net, self.batch_size
+        tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, as_float=self._as_float(), out=st["tr"])
+        if self._noise is None:
+            st["noise"].normal_()  # three independent draws: network(s), network(s'), target_network(s') (rainbow.py:160-186)
+        else:
+            for i in range(3):
+                self.network.pack_noise(self._noise[i], st["noise"][i])
+        lg = net.learn_forward(st["x_all"], B, st["noise"], st["logits"])
+        g, prio, _, _ = ops.c51_loss(lg[0], lg[2], tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max, self.gamma,
+                                     next_logit_online=lg[1], weights=st["w"], alpha=self.alpha, n_step=self.n_step, stats=self._stats8)
+        self.memory.update_priorities(st["idx"], prio)  # rainbow.py:230-231
+        net.backward(g)
+        net.adam_step()
+
+    def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
+        if self._net is None:
+            return super().learning_rate_decay(step, optimizers, mode)
+        weight = {"linear": 1 - (step / self.run_step), "cosine": np.cos((np.pi / 2) * (step / self.run_step)),
+                  "sqrt": max(1 - (step / self.run_step), 0.0) ** 0.5}[mode]
+        self._lr_now = self._lr0 * float(weight)
+        self._net.set_lr(self._lr_now)  # a device scalar: the captured graph reads it
+
+    def update_target(self):
+        if self._net is None:
+            return super().update_target()
+        self._net.sync_target()
+
+    def _shadow_optimizer(self):
+        """torch.optim.Adam over copies of the parameters carrying the native moments: the reference's ckpt
+        format ({"network", "optimizer"}, rainbow.py / dqn.py:184-199) both ways."""
+        sd = self._net.export_state()
+        params = [torch.nn.Parameter(v) for v in sd.values()]
+        opt = Optimizer(**self._optim_config, params=params)
+        for grp in opt.param_groups:
+            grp["lr"] = self._lr_now
+        return opt, params, list(sd.keys())
+
+    def save(self, path):
+        if self._net is None:
+            return super().save(path)
+        import os
+
+        print(f"...Save model to {path}...")
+        opt, params, keys = self._shadow_optimizer()
+        if self._adam_steps > 0:
+            m, v = self._net.export_state(self._net.m), self._net.export_state(self._net.v)
+            for p, k in zip(params, keys):
+                opt.state[p] = {"step": torch.tensor(float(self._adam_steps)), "exp_avg": m[k], "exp_avg_sq": v[k]}
+        torch.save({"network": self.network.state_dict(), "optimizer": opt.state_dict()}, os.path.join(path, "ckpt"))
+
+    def load(self, path):
+        if self._net is None:
+            return super().load(path)
+        import os
+
+        print(f"...Load model from {path}...")
+        checkpoint = torch.load(os.path.join(path, "ckpt"), map_location=self.device, weights_only=False)
+        self.network.load_state_dict(checkpoint["network"])
+        self.target_network.load_state_dict(checkpoint["network"])
+        opt, params, keys = self._shadow_optimizer()
+        opt.load_state_dict(checkpoint["optimizer"])
+        steps = 0
+        if opt.state:
+            self._net.import_state({k: opt.state[p]["exp_avg"] for p, k in zip(params, keys)}, self._net.m)
+            self._net.import_state({k: opt.state[p]["exp_avg_sq"] for p, k in zip(params, keys)}, self._net.v)
+            steps = int(float(opt.state[params[0]]["step"]))
+        else:
+            self._net.m.zero_()
+            self._net.v.zero_()
+        g0 = opt.param_groups[0]
+        self._adam_steps, self._lr_now = steps, float(g0["lr"])
+        self._net.set_hyper(g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"], steps)
+
     def _learn_body(self, st):
+        if self._net is not None:
+            return self._learn_body_native(st)
         tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, out=st["tr"])
         nz = self._noise or [None, None, None]
         logit = self.network(tr["state"], True, nz[0])  # [B, A, K]
@@ -141,8 +311,13 @@ class Rainbow(DQN):
         logit.backward(g)
         self.optimizer.step()
 
+    def _import_optim_state(self):  # load_full(): load() above already imported the moments
+        pass
+
     def learn(self):
         stats64 = self._run_learn()
+        if self._net is not None:
+            self._adam_steps += 1
         s = self._stats8.cpu().numpy()
         p = stats64.cpu().numpy()
         return {"loss": float(s[0]), "beta": self.beta, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3]),

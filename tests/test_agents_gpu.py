@@ -131,21 +131,29 @@ def test_c51_agent_learn_matches_reference():
     _cmp_sd(agent.network, _sd(z, "sd1/"), _h(z, "lr"), 1)
 
 
-def test_rainbow_agent_learn_matches_reference():
+@pytest.mark.parametrize("fixture,backend", [("rainbow", "native"), ("rainbow", "torch"), ("rainbow_cnn", "native"), ("rainbow_cnn", "torch")])
+def test_rainbow_agent_learn_matches_reference(fixture, backend):
     """The reference draws NoisyNet noise with the CPU generator inside forward (utils.py:58-60); the
     same draws are regenerated here (same seed, same order) and injected so the whole update is
-    comparable."""
+    comparable.  backend native = the network itself on libjorldy_hip (jh_rbnet_*), torch = the PyTorch
+    mirror modules; rainbow_cnn = Nature-CNN head on uint8 frames."""
     from jorldy_amd.core.agent import Agent
 
-    z = load("rainbow")
+    z = load(fixture)
     H, A, K = int(_h(z, "H")), int(_h(z, "A")), int(_h(z, "num_support"))
-    agent = Agent("rainbow", state_size=int(_h(z, "S")), action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": _h(z, "lr")},
-                  gamma=_h(z, "gamma"), buffer_size=256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=100000,
+    S = z["hyper/S"]
+    cnn = S.ndim > 0
+    agent = Agent("rainbow", state_size=tuple(int(v) for v in S) if cnn else int(S), action_size=A, hidden_size=H, head="cnn" if cnn else "mlp",
+                  optim_config={"name": "adam", "lr": _h(z, "lr")},
+                  gamma=_h(z, "gamma"), buffer_size=64 if cnn else 256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=100000,
                   n_step=int(_h(z, "n_step")), alpha=_h(z, "alpha"), beta=_h(z, "beta"), learn_period=1, uniform_sample_prob=_h(z, "uniform_sample_prob"),
-                  v_min=_h(z, "v_min"), v_max=_h(z, "v_max"), num_support=K, device="cuda")
+                  v_min=_h(z, "v_min"), v_max=_h(z, "v_max"), num_support=K, device="cuda", backend=backend)
+    assert agent.backend == backend
     agent.network.load_state_dict(_sd(z, "sd0/"))
     agent.target_network.load_state_dict(_sd(z, "sdt/"))
     n = _fill_from_fixture(agent, z, True)
+    if cnn:
+        assert agent.memory._store.column("state").dtype == torch.uint8  # frames stay uint8 in HBM
     torch.manual_seed(int(_h(z, "torch_seed")))
     noise = []
     for _ in range(3):  # network(state), network(next_state), target_network(next_state)
@@ -159,8 +167,79 @@ def test_rainbow_agent_learn_matches_reference():
     for k in ("loss", "max_Q", "max_logit", "min_logit"):
         np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=5e-5, err_msg=k)
     np.testing.assert_allclose(result["sampled_p"], z["result/sampled_p"], rtol=1e-12)
-    np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=1e-4 if cnn else 2e-5, atol=1e-6)
+    if backend == "native":  # gradients of every parameter against the reference's autograd
+        grads = agent._net.export_state(agent._net.grads)
+        for k, v in grads.items():
+            ref = z[f"grad/{k}"]
+            assert float(np.abs(v.cpu().numpy() - ref).max()) <= 5e-5 * (float(np.abs(ref).max()) + 1e-12) + 1e-9, k
     _cmp_sd(agent.network, _sd(z, "sd1/"), _h(z, "lr"), 1)
+
+
+def test_rainbow_native_graph_replay_equals_eager_and_torch_backend_statistics():
+    """Native learn() as one hipGraph == the same launches issued eagerly (same device RNG stream)."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load("rainbow_cnn")
+    H, A, K = int(_h(z, "H")), int(_h(z, "A")), int(_h(z, "num_support"))
+    res = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        agent = Agent("rainbow", state_size=(4, 44, 52), action_size=A, hidden_size=H, head="cnn", optim_config={"name": "adam", "lr": 1e-3},
+                      buffer_size=64, batch_size=8, start_train_step=0, target_update_period=3, run_step=1000, n_step=3, alpha=0.5, beta=0.4,
+                      learn_period=1, uniform_sample_prob=0.05, v_min=-1, v_max=10, num_support=K, device="cuda", use_graph=use_graph)
+        assert agent.backend == "native"
+        agent.network.load_state_dict(_sd(z, "sd0/"))
+        agent.target_network.load_state_dict(_sd(z, "sdt/"))
+        _fill_from_fixture(agent, z, True)
+        np.random.seed(7)
+        torch.manual_seed(11)
+        out = []
+        for it in range(6):
+            r = agent.learn()
+            agent.learning_rate_decay(10 * (it + 1))
+            if it == 3:
+                agent.update_target()
+            out.append(r["loss"])
+        if use_graph:
+            assert agent._graph is not None, "learn() was not captured"
+        res.append((out, torch.cat([p.reshape(-1) for p in agent.network.parameters()]).clone(), agent.memory.sum_tree))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=0, atol=0)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def test_rainbow_native_checkpoint_interchanges_with_torch_backend(tmp_path):
+    """ckpt written by the native backend = the reference's format: loads into the torch-mirror agent (and
+    back) with parameters and Adam moments intact."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load("rainbow")
+    H, A, K = int(_h(z, "H")), int(_h(z, "A")), int(_h(z, "num_support"))
+    mk = lambda backend: Agent("rainbow", state_size=int(z["hyper/S"]), action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": 1e-3}, buffer_size=256,
+                               batch_size=int(_h(z, "B")), start_train_step=0, run_step=1000, n_step=3, num_support=K, device="cuda", backend=backend, use_graph=False)
+    a = mk("native")
+    a.network.load_state_dict(_sd(z, "sd0/"))
+    _fill_from_fixture(a, z, True)
+    np.random.seed(1)
+    for _ in range(3):
+        a.learn()
+    a.save(str(tmp_path))
+    b = mk("torch")
+    b.load(str(tmp_path))
+    for (k, v1), (_, v2) in zip(a.network.state_dict().items(), b.network.state_dict().items()):
+        assert torch.equal(v1, v2), k
+    st = b.optimizer.state_dict()["state"]
+    assert len(st) == len(list(b.network.parameters())) and all(int(float(s["step"])) == 3 for s in st.values())
+    m_nat = a._net.export_state(a._net.m)
+    for (k, v), s in zip(m_nat.items(), st.values()):
+        assert torch.equal(v, s["exp_avg"].to(v.device)), k
+    (tmp_path / "b").mkdir()
+    b.save(str(tmp_path / "b"))
+    c = mk("native")
+    c.load(str(tmp_path / "b"))
+    assert c._adam_steps == 3
+    assert torch.equal(c._net.params, a._net.params) and torch.equal(c._net.m, a._net.m) and torch.equal(c._net.v, a._net.v)
 
 
 # ---- the reference's own smoke/bookkeeping assertions (jorldy/test/core/agent/*.py) ------------------

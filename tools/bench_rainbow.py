@@ -4,7 +4,7 @@ mode): learner-side hot path at Atari shapes with synthetic transitions (SURVEY.
 uint8 (4,84,84) frames, A=4, n_step=3, K=51, B=32, PER alpha .5, buffer N slots.
 
 Per env step: PERBuffer.store of one transition; every `learn_period`=4 steps one Rainbow.learn()
-(PER sample -> gather -> 3 CNN forwards + backward (torch/MIOpen in this round) -> jh_c51_loss ->
+(PER sample -> gather -> 3 CNN forwards + backward (jh_rbnet_*, or torch/MIOpen with --backend torch) -> jh_c51_loss ->
 priority write-back -> Adam).  Reports learner updates/s and the implied env-steps/s ceiling
 (learn_period x updates/s), next to the same loop on the CPU reference port when --cpu is given.
 
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--buffer", type=int, default=100000)
     ap.add_argument("--updates", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--backend", default="native", choices=["native", "torch"])
     args = ap.parse_args()
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
@@ -35,7 +36,7 @@ def main():
     N, B, n = args.buffer, 32, 3
     agent = Agent("rainbow", state_size=[4, 84, 84], action_size=4, hidden_size=512, head="cnn", optim_config={"name": "adam", "lr": 6.25e-5},
                   gamma=0.99, buffer_size=N, batch_size=B, start_train_step=0, target_update_period=10000, run_step=30_000_000, n_step=n,
-                  alpha=0.5, beta=0.4, learn_period=4, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51, device="cuda")
+                  alpha=0.5, beta=0.4, learn_period=4, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51, device="cuda", backend=args.backend)
     agent.memory.first_store = False
     rng = np.random.RandomState(0)
     # fill the buffer with synthetic n-step transitions in chunks (SoA fast path)
@@ -91,7 +92,8 @@ def main():
     torch.cuda.synchronize()
     dt_learn = (time.perf_counter() - t0) / 40
     out = {
-        "workload": f"config.rainbow.atari breakout-shaped, synthetic uint8 (4,84,84), B=32, n=3, K=51, PER N={N} ({filled} filled), CNN encoder via torch/MIOpen",
+        "workload": f"config.rainbow.atari breakout-shaped, synthetic uint8 (4,84,84), B=32, n=3, K=51, PER N={N} ({filled} filled), network backend {args.backend}",
+        "backend": args.backend,
         "learner_updates_per_s": args.updates / dt,
         "env_steps_per_s_ceiling": 4 * args.updates / dt,
         "ms_per_update_incl_4_stores": dt / args.updates * 1e3,
