@@ -131,7 +131,8 @@ class Rainbow(DQN):
         self.action_size = action_size
         self.action_type = "discrete"
         can_native = (network == "rainbow" and noise_type == "factorized" and head in ("mlp", "cnn") and hidden_size % 4 == 0
-                      and not isinstance(state_size, list) and (head == "cnn") == (not np.isscalar(state_size))
+                      and ((head == "mlp" and np.isscalar(state_size))
+                           or (head == "cnn" and not np.isscalar(state_size) and len(state_size) == 3 and all(np.isscalar(v) for v in state_size)))
                       and optim_config.get("name", "adam").lower() == "adam"
                       and set(optim_config) <= {"name", "lr", "betas", "eps"})
         self.backend = backend or ("native" if can_native else "torch")

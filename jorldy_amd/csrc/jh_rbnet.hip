@@ -29,7 +29,10 @@ enum { TEPI_NONE = 0, TEPI_BIAS = 1, TEPI_BIAS_RELU = 2, TEPI_MASK = 3 };
 struct Opnd {
   const void* p;
   int ld, mode, u8, vec;
-  int C, H, W, OH, OW, KH, KW, S;
+  // im2col modes: element (pixel, tap) lives at p[pix_tab[pixel] + tap_tab[tap]] -- two small L2-resident
+  // tables built once per layer geometry instead of six integer divisions per fetch
+  const int* pix_tab;
+  const int* tap_tab;
 };
 
 struct TGemm {
@@ -50,24 +53,12 @@ struct TGemmBatch {
   TGemm p[kMaxGroup];
 };
 
-__device__ __forceinline__ int64_t conv_off_nhwc(const Opnd& o, int pix, int q) {
-  const int ox = pix % o.OW, t = pix / o.OW, oy = t % o.OH, b = t / o.OH;
-  const int c = q % o.C, t2 = q / o.C, kx = t2 % o.KW, ky = t2 / o.KW;
-  return (((int64_t)b * o.H + oy * o.S + ky) * o.W + ox * o.S + kx) * o.C + c;
-}
-__device__ __forceinline__ int64_t conv_off_nchw(const Opnd& o, int pix, int q) {
-  const int ox = pix % o.OW, t = pix / o.OW, oy = t % o.OH, b = t / o.OH;
-  const int kx = q % o.KW, t2 = q / o.KW, ky = t2 % o.KH, c = t2 / o.KH;
-  return (((int64_t)b * o.C + c) * o.H + oy * o.S + ky) * o.W + ox * o.S + kx;
-}
-
 __device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
   if (o.mode == OP_KCONT) return ((const float*)o.p)[(size_t)x * o.ld + k];
   if (o.mode == OP_XCONT) return ((const float*)o.p)[(size_t)k * o.ld + x];
   const bool kfast = !(o.mode & 1);
-  const int pix = kfast ? x : k, q = kfast ? k : x;
-  if (o.mode <= OP_NHWC_X) return ((const float*)o.p)[conv_off_nhwc(o, pix, q)];
-  const int64_t off = conv_off_nchw(o, pix, q);
+  const int off = o.pix_tab[kfast ? x : k] + o.tap_tab[kfast ? k : x];
+  if (o.mode <= OP_NHWC_X) return ((const float*)o.p)[off];
   return (o.u8 ? (float)((const uint8_t*)o.p)[off] : ((const float*)o.p)[off]) / 255.0f;
 }
 
@@ -83,12 +74,13 @@ __device__ __forceinline__ void op_fetch4(const Opnd& o, int x, int k, int X, in
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
       return;
     }
-    if (o.mode <= OP_NHWC_X) {
-      const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + conv_off_nhwc(o, kfast ? x : k, kfast ? k : x));
+    const int off = o.pix_tab[kfast ? x : k] + o.tap_tab[kfast ? k : x];
+    if (o.mode <= OP_NHWC_X) {  // 4 consecutive channels of one tap (C % 4 == 0)
+      const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + off);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
       return;
     }
-    const int64_t off = conv_off_nchw(o, kfast ? x : k, kfast ? k : x);  // 4 consecutive kx (KW % 4 == 0)
+    // NCHW: 4 consecutive kx (KW % 4 == 0)
     if (!(off & 3)) {
       if (o.u8) {
         const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + off);
@@ -247,6 +239,10 @@ __global__ void __launch_bounds__(256) jh_tgemm_kernel(TGemmBatch batch) {
     return;
   }
 
+  // Split-K hand-off without __threadfence(): on a multi-XCD part an agent-scope fence writes back / invalidates
+  // the whole per-XCD L2, which costs more than the GEMM.  Partials are written and read with agent-scope
+  // relaxed atomics instead (sc1 accesses: coherent across XCDs by themselves); s_waitcnt vmcnt(0) makes sure
+  // this wave's partial stores have completed before its workgroup takes a ticket.
   constexpr int PSTRIDE = BM * BN + BM;
   float* mine = g.ws + ((size_t)z * tiles + tile) * PSTRIDE;
 #pragma unroll
@@ -255,36 +251,44 @@ __global__ void __launch_bounds__(256) jh_tgemm_kernel(TGemmBatch batch) {
     for (int j = 0; j < TN; ++j) {
       const int nl = wn * 16 * TN + 16 * j + r;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mine[(wm * 16 * TM + 16 * i + 4 * kq + q) * BN + nl] = acc[i][j][q];
+      for (int q = 0; q < 4; ++q)
+        __hip_atomic_store(mine + (wm * 16 * TM + 16 * i + 4 * kq + q) * BN + nl, acc[i][j][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (want_rs && wn == 0 && kq == 0) mine[BM * BN + wm * 16 * TM + 16 * i + r] = rs[i];
+    if (want_rs && wn == 0 && kq == 0)
+      __hip_atomic_store(mine + BM * BN + wm * 16 * TM + 16 * i + r, rs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) {
-    const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = old == (unsigned)g.splitk - 1;
     if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   const float* base = g.ws + (size_t)tile * PSTRIDE;
   const size_t zstride = (size_t)tiles * PSTRIDE;
-  for (int e = t; e < BM * BN; e += 256) {
-    const int ml = e / BN, nl = e - ml * BN, m = m0 + ml, n = n0 + nl;
-    if (m >= g.M || n >= g.N) continue;
-    float v = 0.f;
-    for (int s = 0; s < g.splitk; ++s) v += __builtin_nontemporal_load(base + s * zstride + e);
-    g.C[(size_t)m * g.ldc + n] = epilogue(v, m, n);
+  constexpr int EPT = BM * BN / 256;  // outputs per thread
+  float sum[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) sum[i] = 0.f;
+  for (int sp = 0; sp < g.splitk; ++sp) {  // split order: deterministic
+    float part[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) part[i] = __hip_atomic_load(base + sp * zstride + t + 256 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) sum[i] += part[i];
   }
-  if (want_rs) {
-    for (int e = t; e < BM; e += 256) {
-      if (m0 + e >= g.M) continue;
-      float v = 0.f;
-      for (int s = 0; s < g.splitk; ++s) v += __builtin_nontemporal_load(base + s * zstride + BM * BN + e);
-      g.rowsum[m0 + e] = v;
-    }
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = t + 256 * i;
+    const int ml = e / BN, nl = e - ml * BN, m = m0 + ml, n = n0 + nl;
+    if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(sum[i], m, n);
+  }
+  if (want_rs && t < BM && m0 + t < g.M) {
+    float v = 0.f;
+    for (int sp = 0; sp < g.splitk; ++sp) v += __hip_atomic_load(base + sp * zstride + BM * BN + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g.rowsum[m0 + t] = v;
   }
 }
 
@@ -469,11 +473,12 @@ inline Opnd op_dense(int mode, const float* p, int ld) {
 }
 struct ConvGeom {
   int C, H, W, OH, OW, KH, KW, S;
+  const int* pix_tab = nullptr;  // device tables, see Opnd
+  const int* tap_tab = nullptr;
 };
 inline Opnd op_conv(int mode, const void* p, int u8, const ConvGeom& c) {
   Opnd o{};
-  o.p = p; o.mode = mode; o.u8 = u8;
-  o.C = c.C; o.H = c.H; o.W = c.W; o.OH = c.OH; o.OW = c.OW; o.KH = c.KH; o.KW = c.KW; o.S = c.S;
+  o.p = p; o.mode = mode; o.u8 = u8; o.pix_tab = c.pix_tab; o.tap_tab = c.tap_tab;
   if (mode <= OP_NHWC_X) o.vec = (c.C % 4 == 0) && (((uintptr_t)p & 15) == 0);
   else o.vec = (c.KW % 4 == 0) && (((uintptr_t)p & (u8 ? 3 : 15)) == 0);
   return o;
@@ -552,9 +557,10 @@ static int launch_tgemm(jh_rbnet* net, const char* name, TGemm* probs, int n, hi
   for (int i = 0; i < n; ++i) {
     const int tiles = probs[i].tiles_m * probs[i].tiles_n;
     const int nchunks = (probs[i].K + 31) / 32;
-    int s = 256 / (tiles > 0 ? tiles : 1);  // per problem: the problems of a group run side by side
-    if (s > nchunks / 2) s = nchunks / 2;
-    if (s > 64) s = 64;
+    // split K only when the tiles alone leave most of the 256 CUs idle; every split keeps >= 4 chunks of 32
+    int s = tiles >= 128 ? 1 : 256 / (tiles > 0 ? tiles : 1);
+    if (s > nchunks / 4) s = nchunks / 4;
+    if (s > 32) s = 32;
     if (s < 1) s = 1;
     const size_t pstride = (size_t)BM * BN + BM;
     while (s > 1 && (ws_used + (size_t)s * tiles * pstride > net->ws_floats || cnt_used + tiles > net->cnt_slots)) --s;
@@ -593,9 +599,9 @@ static int rb_layout(jh_rbnet* n, int32_t head_cnn, int32_t c_or_s, int32_t h_in
   const int H = hidden;
   if (n->cnn) {
     if (h_in < 36 || w_in < 36) return jh_fail(JH_ERR_ARG, "cnn head needs images >= 36x36 (head.py:26), got %dx%d", h_in, w_in);
-    n->c1 = ConvGeom{c_or_s, h_in, w_in, (h_in - 8) / 4 + 1, (w_in - 8) / 4 + 1, 8, 8, 4};
-    n->c2 = ConvGeom{32, n->c1.OH, n->c1.OW, (n->c1.OH - 4) / 2 + 1, (n->c1.OW - 4) / 2 + 1, 4, 4, 2};
-    n->c3 = ConvGeom{64, n->c2.OH, n->c2.OW, n->c2.OH - 3 + 1, n->c2.OW - 3 + 1, 3, 3, 1};
+    n->c1 = ConvGeom{c_or_s, h_in, w_in, (h_in - 8) / 4 + 1, (w_in - 8) / 4 + 1, 8, 8, 4, nullptr, nullptr};
+    n->c2 = ConvGeom{32, n->c1.OH, n->c1.OW, (n->c1.OH - 4) / 2 + 1, (n->c1.OW - 4) / 2 + 1, 4, 4, 2, nullptr, nullptr};
+    n->c3 = ConvGeom{64, n->c2.OH, n->c2.OW, n->c2.OH - 3 + 1, n->c2.OW - 3 + 1, 3, 3, 1, nullptr, nullptr};
     n->P1 = n->c1.OH * n->c1.OW; n->P2 = n->c2.OH * n->c2.OW; n->P3 = n->c3.OH * n->c3.OW;
     n->F = 64 * n->P3;
   } else {
@@ -676,6 +682,35 @@ JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t head_cnn, int32_t c_or_s, int
     size_t dc = B * n->P3 * 576;
     if (B * n->P2 * 512 > dc) dc = B * n->P2 * 512;
     A4(&n->dcol, dc); A4(&n->dact2, B * n->P2 * 64); A4(&n->dact1, B * n->P1 * 32);
+  }
+  if (n->cnn && !rc) {
+    ConvGeom* gs[3] = {&n->c1, &n->c2, &n->c3};
+    for (int li = 0; li < 3 && !rc; ++li) {
+      ConvGeom& c = *gs[li];
+      const bool nchw = li == 0;
+      const int n_pix = 2 * max_batch * c.OH * c.OW, n_tap = c.C * c.KH * c.KW;
+      std::vector<int> tab((size_t)n_pix + n_tap);
+      for (int pix = 0; pix < n_pix; ++pix) {
+        const int ox = pix % c.OW, t = pix / c.OW, oy = t % c.OH, b = t / c.OH;
+        const int64_t off = nchw ? ((int64_t)b * c.C * c.H + oy * c.S) * c.W + ox * c.S : (((int64_t)b * c.H + oy * c.S) * c.W + ox * c.S) * c.C;
+        if (off > 0x7fffffff - (int64_t)c.C * c.H * c.W) rc = jh_fail(JH_ERR_ARG, "batch x image too large for 32-bit im2col offsets");
+        tab[pix] = (int)off;
+      }
+      for (int q = 0; q < n_tap; ++q) {
+        if (nchw) {
+          const int kx = q % c.KW, t2 = q / c.KW, ky = t2 % c.KH, ch = t2 / c.KH;
+          tab[n_pix + q] = (ch * c.H + ky) * c.W + kx;
+        } else {
+          const int ch = q % c.C, t2 = q / c.C, kx = t2 % c.KW, ky = t2 / c.KW;
+          tab[n_pix + q] = (ky * c.W + kx) * c.C + ch;
+        }
+      }
+      int* d_tab = nullptr;
+      if (!rc) rc = rb_alloc(n, (void**)&d_tab, tab.size() * sizeof(int), false);
+      if (!rc && hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = jh_fail(JH_ERR_HIP, "im2col table upload failed");
+      c.pix_tab = d_tab;
+      c.tap_tab = d_tab + n_pix;
+    }
   }
   n->ws_floats = (size_t)8 << 20;  // 32 MB of split-K partials
   A4(&n->ws, n->ws_floats, false);
