@@ -40,6 +40,7 @@ class DQN(BaseAgent):
         self.epsilon_delta = (epsilon_init - epsilon_min) / self.explore_step
         self.buffer_size = buffer_size
         self.memory = ReplayBuffer(buffer_size, device=self.device)
+        self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.batch_size = batch_size
         self.start_train_step = start_train_step
         self.target_update_stamp = 0
@@ -135,6 +136,7 @@ class DQN(BaseAgent):
         if self._static is None or self._static["store"] is not self.memory._store:
             self._static, self._graph = self._alloc_static(), None
         st = self._static
+        self.memory.flush()  # held per-step stores -> HBM before anything (possibly a replayed graph) reads the ring
         extra = self._draw(st)
         graphable = self.use_graph and self._lr0 is not None and self._noise is None and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
         if graphable and self._graph is None and self._warm:
@@ -277,6 +279,7 @@ class PER(DQN):
     def __init__(self, alpha=0.6, beta=0.4, learn_period=16, uniform_sample_prob=1e-3, run_step=1e6, **kwargs):
         super().__init__(run_step=run_step, **kwargs)
         self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device)
+        self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.alpha = alpha
         self.beta = beta
         self.beta_add = (1 - beta) / run_step
@@ -337,6 +340,7 @@ class ApeX(DQN):
         self.beta_add = (1 - beta) / self.run_step
         self.n_step = n_step
         self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device)
+        self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.tmp_buffer = deque(maxlen=n_step + 1)
 
     @torch.no_grad()

@@ -174,6 +174,7 @@ class Rainbow(DQN):
         self.beta_add = (1 - beta) / run_step
         self.v_min, self.v_max, self.num_support = v_min, v_max, num_support
         self.memory = PERBuffer(buffer_size, uniform_sample_prob, device=self.device)
+        self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.delta_z = (v_max - v_min) / (num_support - 1)
         self.z = torch.linspace(v_min, v_max, num_support, device=self.device).view(1, -1)
         self.epsilon = 0.0

@@ -21,13 +21,33 @@ class PERBuffer(ReplayBuffer):
         self.first_leaf_index = self.buffer_size - 1
         self.uniform_sample_prob = uniform_sample_prob
         self._tree = ops.SumTree(self.buffer_size, uniform_sample_prob, device=self.device)
+        self._next_prio = None
 
     # -- store ------------------------------------------------------------------------------------
     def store_soa(self, cols, priorities=None):
         cols = {k: v for k, v in cols.items() if k != "priority"}
+        self._next_prio = None if priorities is None else np.array(priorities, dtype=np.float64, copy=True).reshape(-1)
         n = super().store_soa(cols)
-        self._tree.push(n, priorities)  # per_buffer.py:27-33 (max_priority when no actor-side priority)
+        if not self._was_deferred:  # rows are in HBM, leaves follow now
+            self._tree.push(n, self._next_prio)   # per_buffer.py:27-33 (max_priority when no actor-side priority)
         return n
+
+    def _defer(self, flat, n, extra=None):
+        super()._defer(flat, n, self._next_prio)
+
+    def flush(self):
+        """Held rows -> ring, then their leaves in the same order.  Rows without an actor-side priority take
+        max_priority, which cannot have changed since they were stored: every priority update flushes first."""
+        done = self._flush_rows()
+        i = 0
+        while i < len(done):  # one tree push per run of the same kind (with / without explicit priorities)
+            j, n = i, 0
+            has = done[i][1] is not None
+            while j < len(done) and (done[j][1] is not None) == has:
+                n += done[j][0]
+                j += 1
+            self._tree.push(n, np.concatenate([d[1] for d in done[i:j]]) if has else None)
+            i = j
 
     def store(self, transitions):
         if self.first_store:
@@ -44,10 +64,12 @@ class PERBuffer(ReplayBuffer):
         """Batched write-back: indices int64 device tensor (tree space), priorities float32/float64
         device tensor; equivalent to `for i, p in zip(indices, p_j): update_priority(p.item(), i)`
         (per.py:69-70, rainbow.py:230-231) without the B host syncs."""
+        self.flush()
         self._tree.update(indices.reshape(-1), priorities.reshape(-1))
 
     def update_priority(self, new_priority, index):
         """Scalar compatibility path (per_buffer.py:42-48)."""
+        self.flush()
         idx = h2d_small(np.asarray([index], dtype=np.int64), self.device)
         p = h2d_small(np.asarray([float(np.asarray(new_priority).reshape(-1)[0])], dtype=np.float64), self.device)
         self._tree.update(idx, p)
@@ -66,6 +88,7 @@ class PERBuffer(ReplayBuffer):
         the gather is left to the caller (captured-graph learners).  Returns the stats tensor
         {sampled_p, mean_p, root, max_w}."""
         assert self.buffer_counter > 0
+        self.flush()
         uni, u = self.draw(batch_size)
         _, _, _, stats = self._tree.sample(beta, uni, u, want_w64=False, out_idx=idx_out, out_w32=w_out)
         return stats
@@ -75,6 +98,7 @@ class PERBuffer(ReplayBuffer):
                sampled_p, mean_p) ; sampled_p/mean_p are 0-dim device float64 tensors (call .item()
                when logging)."""
         assert self.buffer_counter > 0
+        self.flush()
         uni, u = self.draw(batch_size)
         idx, w64, w32, stats = self._tree.sample(beta, uni, u, want_w64=False)
         transitions = self.gather(idx, idx_offset=self.first_leaf_index, as_float=as_float)
@@ -83,7 +107,7 @@ class PERBuffer(ReplayBuffer):
 
     # -- complete checkpoints --------------------------------------------------------------------------
     def state_dict(self):
-        sd = super().state_dict()
+        sd = super().state_dict()  # flushes
         st = self._tree.state()
         sd.update({"sum_tree": self._tree.dump(), "max_priority": st["max_priority"], "tree_index": st["tree_index"]})
         return sd
@@ -95,12 +119,15 @@ class PERBuffer(ReplayBuffer):
     # -- state the reference exposes ----------------------------------------------------------------
     @property
     def sum_tree(self):
+        self.flush()
         return self._tree.dump()
 
     @property
     def max_priority(self):
+        self.flush()
         return self._tree.state()["max_priority"]
 
     @property
     def tree_index(self):
+        self.flush()
         return self._tree.state()["tree_index"]

@@ -17,16 +17,47 @@ class ReplayBuffer(BaseBuffer):
         self.buffer_size = int(buffer_size)
         self.buffer_index = 0
         self.buffer_counter = 0
+        # Coalesced stores (opt-in, set by the agents): pushes of <= defer_rows transitions are held on
+        # the host and written to HBM as ONE ring append right before the next device-side read
+        # (gather / sample / priority update / checkpoint).  Nothing observable changes -- buffer_index,
+        # buffer_counter and size advance immediately, sampling never runs between store and flush --
+        # but the per-env-step cost drops from ~8 HIP API calls to a numpy copy (Rainbow: a store every
+        # step, a learn() every 4).
+        self.defer_rows = 0
+        self._pending, self._pending_rows = [], 0
 
     # fast path: already-SoA numpy columns [n, ...]
     def store_soa(self, cols, n=None):
         if self._store is None:
             self._make_store(cols, self.buffer_size)
         flat = self._flat_cols(cols)
-        n = self._store.push(flat)
+        n = len(next(iter(flat.values())))
+        self._was_deferred = 0 < n <= self.defer_rows and self._pending_rows + n <= min(4 * self.defer_rows, self.buffer_size)
+        if self._was_deferred:
+            self._defer(flat, n)
+        else:
+            self.flush()
+            n = self._store.push(flat)
         self.buffer_index = (self.buffer_index + n) % self.buffer_size
         self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
         return n
+
+    def _defer(self, flat, n, extra=None):
+        self._pending.append(({k: np.array(v, copy=True) for k, v in flat.items()}, n, extra))  # the caller may reuse its arrays
+        self._pending_rows += n
+
+    def _flush_rows(self):
+        """Concatenate and push the held rows; returns [(n, extra)] in store order."""
+        if not self._pending:
+            return []
+        pend, self._pending, self._pending_rows = self._pending, [], 0
+        names = list(pend[0][0].keys())
+        cat = {k: (pend[0][0][k] if len(pend) == 1 else np.concatenate([np.asarray(p[0][k]).reshape(p[1], -1) for p in pend], 0)) for k in names}
+        self._store.push(cat)
+        return [(p[1], p[2]) for p in pend]
+
+    def flush(self):
+        self._flush_rows()
 
     def store(self, transitions):
         if self.first_store:
@@ -40,6 +71,7 @@ class ReplayBuffer(BaseBuffer):
 
     def gather(self, idx_device, idx_offset=0, as_float=True, out=None):
         """out: optional dict key -> preallocated tensor (or list of tensors for multimodal keys)."""
+        self.flush()
         flat_out = None if out is None else self._flat_cols(out)
         return self._unflatten(self._store.gather(idx_device, as_float=as_float, idx_offset=idx_offset, out=flat_out))
 
@@ -52,6 +84,7 @@ class ReplayBuffer(BaseBuffer):
     def state_dict(self):
         """Host copy of everything needed to resume: stored rows (in slot order), ring position."""
         cols = {}
+        self.flush()
         if self._store is not None:
             import torch
 
@@ -63,6 +96,7 @@ class ReplayBuffer(BaseBuffer):
 
     def load_state_dict(self, sd):
         assert sd["buffer_size"] == self.buffer_size
+        self._pending, self._pending_rows = [], 0
         self._layout = None
         self._store = None
         self.buffer_index = self.buffer_counter = 0

@@ -53,39 +53,58 @@ struct TGemmBatch {
   TGemm p[kMaxGroup];
 };
 
+// uint8 / 255 correctly rounded without a division: q = b * (1/255), one Newton correction with exact
+// remainders (verified == b / 255.0f for all 256 byte values; tests compare against the fp32-frame path)
+__device__ __forceinline__ float u8_unit(uint32_t b) {
+  const float x = (float)b, r = 1.0f / 255.0f;
+  const float q = x * r;
+  return fmaf(fmaf(-q, 255.0f, x), r, q);
+}
+
 __device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
   if (o.mode == OP_KCONT) return ((const float*)o.p)[(size_t)x * o.ld + k];
   if (o.mode == OP_XCONT) return ((const float*)o.p)[(size_t)k * o.ld + x];
   const bool kfast = !(o.mode & 1);
   const int off = o.pix_tab[kfast ? x : k] + o.tap_tab[kfast ? k : x];
   if (o.mode <= OP_NHWC_X) return ((const float*)o.p)[off];
-  return (o.u8 ? (float)((const uint8_t*)o.p)[off] : ((const float*)o.p)[off]) / 255.0f;
+  return o.u8 ? u8_unit(((const uint8_t*)o.p)[off]) : ((const float*)o.p)[off] / 255.0f;
 }
 
 // k-fast modes: v = elements (x, k..k+3).  x-fast modes: v = elements (x..x+3, k).  Zero outside X x K.
-__device__ __forceinline__ void op_fetch4(const Opnd& o, int x, int k, int X, int K, float v[4]) {
+__device__ __forceinline__ void op_fetch4_dense(const Opnd& o, int x, int k, int X, int K, float v[4]) {
   v[0] = v[1] = v[2] = v[3] = 0.f;
   if (x >= X || k >= K) return;
   const bool kfast = !(o.mode & 1);
-  const bool full = kfast ? (k + 3 < K) : (x + 3 < X);
-  if (full && o.vec) {
-    if (o.mode <= OP_XCONT) {
-      const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + (kfast ? (size_t)x * o.ld + k : (size_t)k * o.ld + x));
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      return;
-    }
-    const int off = o.pix_tab[kfast ? x : k] + o.tap_tab[kfast ? k : x];
+  const float* p = (const float*)o.p + (kfast ? (size_t)x * o.ld + k : (size_t)k * o.ld + x);
+  if ((kfast ? (k + 3 < K) : (x + 3 < X)) && o.vec) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return;
+  }
+  const int n = kfast ? K - k : X - x;
+  const size_t st = kfast ? 1 : (size_t)o.ld;
+  // (x-fast elements are contiguous too: p[k*ld + x + i]; k-fast: p[x*ld + k + i])
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < n) v[i] = p[i];
+  (void)st;
+}
+// im2col operand: `off` = pix_tab[pixel] + tap_tab[tap] of the first element (the caller holds one of the two
+// terms in a register and the other in LDS)
+__device__ __forceinline__ void op_fetch4_conv(const Opnd& o, int x, int k, int X, int K, int off, float v[4]) {
+  v[0] = v[1] = v[2] = v[3] = 0.f;
+  if (x >= X || k >= K) return;
+  const bool kfast = !(o.mode & 1);
+  if ((kfast ? (k + 3 < K) : (x + 3 < X)) && o.vec) {
     if (o.mode <= OP_NHWC_X) {  // 4 consecutive channels of one tap (C % 4 == 0)
       const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + off);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
       return;
     }
-    // NCHW: 4 consecutive kx (KW % 4 == 0)
-    if (!(off & 3)) {
+    if (!(off & 3)) {  // NCHW: 4 consecutive kx (KW % 4 == 0)
       if (o.u8) {
         const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + off);
-        v[0] = (float)(w & 255u) / 255.0f; v[1] = (float)((w >> 8) & 255u) / 255.0f;
-        v[2] = (float)((w >> 16) & 255u) / 255.0f; v[3] = (float)(w >> 24) / 255.0f;
+        v[0] = u8_unit(w & 255u); v[1] = u8_unit((w >> 8) & 255u); v[2] = u8_unit((w >> 16) & 255u); v[3] = u8_unit(w >> 24);
       } else {
         const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + off);
         v[0] = t.x / 255.0f; v[1] = t.y / 255.0f; v[2] = t.z / 255.0f; v[3] = t.w / 255.0f;
@@ -109,11 +128,13 @@ __device__ __forceinline__ void op_fetch4(const Opnd& o, int x, int k, int X, in
 // sum over k does not see), and the 16 rows a wave reads start in 16 distinct 4-bank groups.
 // splitk > 1: every split writes its partial tile, the last workgroup to arrive (per-tile counter) sums
 // the partials in split order -- deterministic, no atomics on data -- and runs the epilogue.
+constexpr int kTabMax = 1024;  // k-range of one split that an im2col operand can address through its LDS table
 template <int TM, int TN>
-__global__ void __launch_bounds__(256) jh_tgemm_kernel(TGemmBatch batch) {
+__global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = 36;
   __shared__ __attribute__((aligned(16))) float sA[BM * LD];
   __shared__ __attribute__((aligned(16))) float sB[BN * LD];
+  __shared__ int sTabA[kTabMax], sTabB[kTabMax];
   __shared__ int s_last;
   const TGemm& g = batch.p[blockIdx.y];
   const int tile = blockIdx.x, z = blockIdx.z;
@@ -128,19 +149,49 @@ __global__ void __launch_bounds__(256) jh_tgemm_kernel(TGemmBatch batch) {
   if (kend > g.K) kend = g.K;
   const bool a_kfast = !(g.a.mode & 1), b_kfast = !(g.b.mode & 1);
 
+  // im2col operands: the offset term that follows k (taps for k-fast, pixels for x-fast) is staged in LDS for
+  // this split's whole k range; the term that follows x is fixed per thread slot and sits in a register.
+  const bool a_conv = g.a.mode >= OP_NHWC_K, b_conv = g.b.mode >= OP_NHWC_K;
+  int ax[TM], bx[TN];
+  if (a_conv) {
+    const int* ktab = a_kfast ? g.a.tap_tab : g.a.pix_tab;
+    const int* xtab = a_kfast ? g.a.pix_tab : g.a.tap_tab;
+    for (int i = t; i < kend - kbeg; i += 256) sTabA[i] = ktab[kbeg + i];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int e = t + 256 * i, x = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
+      ax[i] = x < g.M ? xtab[x] : 0;
+    }
+  }
+  if (b_conv) {
+    const int* ktab = b_kfast ? g.b.tap_tab : g.b.pix_tab;
+    const int* xtab = b_kfast ? g.b.pix_tab : g.b.tap_tab;
+    for (int i = t; i < kend - kbeg; i += 256) sTabB[i] = ktab[kbeg + i];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int e = t + 256 * i, x = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
+      bx[i] = x < g.N ? xtab[x] : 0;
+    }
+  }
+  if (a_conv || b_conv) __syncthreads();
+
   float ra[TM][4], rb[TN][4];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int e = t + 256 * i;
-      if (a_kfast) op_fetch4(g.a, m0 + (e >> 3), k0 + 4 * (e & 7), g.M, kend, ra[i]);
-      else op_fetch4(g.a, m0 + 4 * (e % (BM / 4)), k0 + e / (BM / 4), g.M, kend, ra[i]);
+      const int x = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
+      const int k = a_kfast ? k0 + 4 * (e & 7) : k0 + e / (BM / 4);
+      if (a_conv) op_fetch4_conv(g.a, x, k, g.M, kend, ax[i] + sTabA[(k < kend ? k : kend - 1) - kbeg], ra[i]);
+      else op_fetch4_dense(g.a, x, k, g.M, kend, ra[i]);
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int e = t + 256 * i;
-      if (b_kfast) op_fetch4(g.b, n0 + (e >> 3), k0 + 4 * (e & 7), g.N, kend, rb[i]);
-      else op_fetch4(g.b, n0 + 4 * (e % (BN / 4)), k0 + e / (BN / 4), g.N, kend, rb[i]);
+      const int x = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
+      const int k = b_kfast ? k0 + 4 * (e & 7) : k0 + e / (BN / 4);
+      if (b_conv) op_fetch4_conv(g.b, x, k, g.N, kend, bx[i] + sTabB[(k < kend ? k : kend - 1) - kbeg], rb[i]);
+      else op_fetch4_dense(g.b, x, k, g.N, kend, rb[i]);
     }
   };
   auto sstore = [&]() {
@@ -560,14 +611,20 @@ static int launch_tgemm(jh_rbnet* net, const char* name, TGemm* probs, int n, hi
     // split K only when the tiles alone leave most of the 256 CUs idle; every split keeps >= 4 chunks of 32
     int s = tiles >= 128 ? 1 : 256 / (tiles > 0 ? tiles : 1);
     if (s > nchunks / 4) s = nchunks / 4;
-    if (s > 32) s = 32;
+    if (s > 64) s = 64;
     if (s < 1) s = 1;
+    const bool conv = probs[i].a.mode >= OP_NHWC_K || probs[i].b.mode >= OP_NHWC_K;
+    const int min_s = conv ? (nchunks * 32 + kTabMax - 1) / kTabMax : 1;  // an im2col operand's k range must fit its LDS table
+    if (s < min_s) s = min_s;
     const size_t pstride = (size_t)BM * BN + BM;
-    while (s > 1 && (ws_used + (size_t)s * tiles * pstride > net->ws_floats || cnt_used + tiles > net->cnt_slots)) --s;
+    while (s > min_s && (ws_used + (size_t)s * tiles * pstride > net->ws_floats || cnt_used + tiles > net->cnt_slots)) --s;
+    if (s > 1 && (ws_used + (size_t)s * tiles * pstride > net->ws_floats || cnt_used + tiles > net->cnt_slots))
+      return jh_fail(JH_ERR_NOMEM, "%s: split-K workspace too small (%d tiles x %d splits)", name, tiles, s);
     // no empty splits: shrink to the number of splits that actually own chunks
     if (s > 1) {
       const int per = (nchunks + s - 1) / s;
       s = (nchunks + per - 1) / per;
+      if (conv && per * 32 > kTabMax) return jh_fail(JH_ERR_STATE, "%s: im2col k range %d exceeds the LDS table", name, per * 32);
     }
     probs[i].splitk = s;
     if (s > 1) {

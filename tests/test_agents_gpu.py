@@ -579,3 +579,41 @@ def test_td_agents_graph_replay_equals_eager(name, extra):
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
     if res[0][2] is not None:
         np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-7)  # priorities = |fp32 TD error|^alpha
+
+
+def test_deferred_stores_are_invisible_per_buffer():
+    """Coalesced per-step stores (ReplayBuffer.defer_rows) == immediate stores: same ring contents, same sum
+    tree (bit-exact), same samples -- across ring wrap, mixed actor-side / max priorities and priority updates."""
+    from jorldy_amd.core.buffer import PERBuffer
+
+    rng = np.random.RandomState(3)
+    bufs = [PERBuffer(24, 0.1, device="cuda"), PERBuffer(24, 0.1, device="cuda")]
+    bufs[1].defer_rows = 4
+    for b in bufs:
+        b.first_store = False
+    for step in range(70):
+        t = {"state": rng.randn(1, 5).astype(np.float32), "action": rng.randint(0, 3, size=(1, 1)), "reward": rng.randn(1, 1),
+             "next_state": rng.randn(1, 5).astype(np.float32), "done": np.asarray([[rng.rand() < 0.2]])}
+        if step % 3 == 0:
+            t["priority"] = np.asarray([[rng.rand() + 0.1]])
+        for b in bufs:
+            b.store([dict(t)])
+        assert bufs[0].size == bufs[1].size and bufs[0].buffer_index == bufs[1].buffer_index
+        if step % 7 == 6:
+            outs = []
+            for b in bufs:
+                np.random.seed(step)
+                tr, w, idx, sp, mp = b.sample(0.5, 6)
+                b.update_priorities(idx, (w * 0 + 1.0 + 0.01 * step).double() ** 0.5)
+                outs.append((tr, w, idx, float(sp), float(mp)))
+            assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][3:] == outs[1][3:]
+            for k in outs[0][0]:
+                assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    for b in bufs:
+        b.store([dict(t)])
+    assert bufs[1]._pending_rows > 0 and bufs[0]._pending_rows == 0  # something is still held ...
+    np.testing.assert_array_equal(bufs[0].sum_tree, bufs[1].sum_tree)  # ... and reading the tree flushes it
+    assert bufs[0].max_priority == bufs[1].max_priority and bufs[0].tree_index == bufs[1].tree_index
+    sd0, sd1 = bufs[0].state_dict(), bufs[1].state_dict()
+    for k in sd0["columns"]:
+        np.testing.assert_array_equal(sd0["columns"][k], sd1["columns"][k])
