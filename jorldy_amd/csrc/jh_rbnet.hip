@@ -70,55 +70,48 @@ __device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
   return o.u8 ? u8_unit(((const uint8_t*)o.p)[off]) : ((const float*)o.p)[off] / 255.0f;
 }
 
+// Rare cases (tile edges, operands that do not allow 16-byte accesses, fp32 NCHW frames): element-wise, out of
+// line so that the hot loop stays small enough for the instruction cache.
 // k-fast modes: v = elements (x, k..k+3).  x-fast modes: v = elements (x..x+3, k).  Zero outside X x K.
-__device__ __forceinline__ void op_fetch4_dense(const Opnd& o, int x, int k, int X, int K, float v[4]) {
-  v[0] = v[1] = v[2] = v[3] = 0.f;
-  if (x >= X || k >= K) return;
+__device__ __noinline__ float4 op_fetch4_slow(Opnd o, int x, int k, int X, int K) {
   const bool kfast = !(o.mode & 1);
-  const float* p = (const float*)o.p + (kfast ? (size_t)x * o.ld + k : (size_t)k * o.ld + x);
-  if ((kfast ? (k + 3 < K) : (x + 3 < X)) && o.vec) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    return;
-  }
-  const int n = kfast ? K - k : X - x;
-  const size_t st = kfast ? 1 : (size_t)o.ld;
-  // (x-fast elements are contiguous too: p[k*ld + x + i]; k-fast: p[x*ld + k + i])
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i < n) v[i] = p[i];
-  (void)st;
+  const int dx = kfast ? 0 : 1, dk = kfast ? 1 : 0;
+  float4 r;
+  r.x = (x < X && k < K) ? op_elem(o, x, k) : 0.f;
+  r.y = (x + dx < X && k + dk < K) ? op_elem(o, x + dx, k + dk) : 0.f;
+  r.z = (x + 2 * dx < X && k + 2 * dk < K) ? op_elem(o, x + 2 * dx, k + 2 * dk) : 0.f;
+  r.w = (x + 3 * dx < X && k + 3 * dk < K) ? op_elem(o, x + 3 * dx, k + 3 * dk) : 0.f;
+  return r;
 }
-// im2col operand: `off` = pix_tab[pixel] + tap_tab[tap] of the first element (the caller holds one of the two
-// terms in a register and the other in LDS)
-__device__ __forceinline__ void op_fetch4_conv(const Opnd& o, int x, int k, int X, int K, int off, float v[4]) {
+
+// One fetch = an address and a kind: 0 nothing (outside the matrix), 1 four floats, 2 four uint8 frames bytes,
+// 3 the slow path.  `conv_off` = pix_tab[pixel] + tap_tab[tap] of the first element for im2col operands (the
+// caller holds one term in a register, the other in LDS).
+__device__ __forceinline__ void op_fetch4(const Opnd& o, int x, int k, int X, int K, int conv_off, float v[4]) {
   v[0] = v[1] = v[2] = v[3] = 0.f;
   if (x >= X || k >= K) return;
   const bool kfast = !(o.mode & 1);
-  if ((kfast ? (k + 3 < K) : (x + 3 < X)) && o.vec) {
-    if (o.mode <= OP_NHWC_X) {  // 4 consecutive channels of one tap (C % 4 == 0)
-      const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + off);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      return;
-    }
-    if (!(off & 3)) {  // NCHW: 4 consecutive kx (KW % 4 == 0)
-      if (o.u8) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + off);
-        v[0] = u8_unit(w & 255u); v[1] = u8_unit((w >> 8) & 255u); v[2] = u8_unit((w >> 16) & 255u); v[3] = u8_unit(w >> 24);
-      } else {
-        const float4 t = *reinterpret_cast<const float4*>((const float*)o.p + off);
-        v[0] = t.x / 255.0f; v[1] = t.y / 255.0f; v[2] = t.z / 255.0f; v[3] = t.w / 255.0f;
-      }
-      return;
-    }
+  const bool full = kfast ? (k + 3 < K) : (x + 3 < X);
+  int kind = 3;
+  const float* pf = (const float*)o.p;
+  if (o.mode <= OP_XCONT) {
+    pf += kfast ? (size_t)x * o.ld + k : (size_t)k * o.ld + x;
+    if (full && o.vec) kind = 1;
+  } else if (o.mode <= OP_NHWC_X) {
+    pf += conv_off;
+    if (full && o.vec) kind = 1;
+  } else if (full && o.vec && o.u8 && !(conv_off & 3)) {
+    kind = 2;
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (kfast) {
-      if (k + i < K) v[i] = op_elem(o, x, k + i);
-    } else {
-      if (x + i < X) v[i] = op_elem(o, x + i, k);
-    }
+  if (kind == 1) {
+    const float4 t = *reinterpret_cast<const float4*>(pf);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if (kind == 2) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + conv_off);
+    v[0] = u8_unit(w & 255u); v[1] = u8_unit((w >> 8) & 255u); v[2] = u8_unit((w >> 16) & 255u); v[3] = u8_unit(w >> 24);
+  } else {
+    const float4 t = op_fetch4_slow(o, x, k, X, K);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
 }
 
@@ -175,26 +168,24 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   }
   if (a_conv || b_conv) __syncthreads();
 
-  float ra[TM][4], rb[TN][4];
-  auto gload = [&](int k0) {
+  float ra0[TM][4], rb0[TN][4];
+  auto gload = [&](int k0, float (&ra)[TM][4], float (&rb)[TN][4]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int e = t + 256 * i;
       const int x = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
       const int k = a_kfast ? k0 + 4 * (e & 7) : k0 + e / (BM / 4);
-      if (a_conv) op_fetch4_conv(g.a, x, k, g.M, kend, ax[i] + sTabA[(k < kend ? k : kend - 1) - kbeg], ra[i]);
-      else op_fetch4_dense(g.a, x, k, g.M, kend, ra[i]);
+      op_fetch4(g.a, x, k, g.M, kend, a_conv ? ax[i] + sTabA[(k < kend ? k : kend - 1) - kbeg] : 0, ra[i]);
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int e = t + 256 * i;
       const int x = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
       const int k = b_kfast ? k0 + 4 * (e & 7) : k0 + e / (BN / 4);
-      if (b_conv) op_fetch4_conv(g.b, x, k, g.N, kend, bx[i] + sTabB[(k < kend ? k : kend - 1) - kbeg], rb[i]);
-      else op_fetch4_dense(g.b, x, k, g.N, kend, rb[i]);
+      op_fetch4(g.b, x, k, g.N, kend, b_conv ? bx[i] + sTabB[(k < kend ? k : kend - 1) - kbeg] : 0, rb[i]);
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](float (&ra)[TM][4], float (&rb)[TN][4]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int e = t + 256 * i;
@@ -229,11 +220,7 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   for (int i = 0; i < TM; ++i) rs[i] = 0.f;
   const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
 
-  if (kbeg < kend) gload(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    sstore();
-    __syncthreads();
-    if (k0 + BK < kend) gload(k0 + BK);  // next tile's HBM loads fly under this tile's MFMAs
+  auto mma_tile = [&]() {
 #pragma unroll
     for (int kb = 0; kb < BK; kb += 16) {
       float4 a[TM], b[TN];
@@ -253,6 +240,15 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
         if (want_rs && wn == 0) rs[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
       }
     }
+  };
+  // tile i: registers -> LDS, refill the registers with tile i + 1 (its HBM loads fly under the MFMAs of tile i)
+  if (kbeg < kend) gload(kbeg, ra0, rb0);
+#pragma unroll 1
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    sstore(ra0, rb0);
+    __syncthreads();
+    if (k0 + BK < kend) gload(k0 + BK, ra0, rb0);
+    mma_tile();
     __syncthreads();
   }
   if (want_rs && wn == 0) {
@@ -323,12 +319,25 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   float sum[EPT];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) sum[i] = 0.f;
-  for (int sp = 0; sp < g.splitk; ++sp) {  // split order: deterministic
-    float part[EPT];
+  // all loads of UNR splits are in flight together (the partials come from HBM / MALL, ~1 us each way);
+  // the additions stay in split order: deterministic
+  constexpr int UNR = EPT >= 16 ? 4 : 8;
+  for (int sp = 0; sp < g.splitk; sp += UNR) {
+    float part[UNR][EPT];
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) part[i] = __hip_atomic_load(base + sp * zstride + t + 256 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int u = 0; u < UNR; ++u) {
+      if (sp + u < g.splitk) {
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) sum[i] += part[i];
+        for (int i = 0; i < EPT; ++i) part[u][i] = __hip_atomic_load(base + (sp + u) * zstride + t + 256 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (sp + u < g.splitk) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) sum[i] += part[u][i];
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
