@@ -266,89 +266,89 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
     return v;
   };
 
-  if (g.splitk == 1) {
+  if (g.splitk > 1) {
+    // Split-K hand-off without __threadfence(): on a multi-XCD part an agent-scope fence writes back / invalidates
+    // the whole per-XCD L2, which costs more than the GEMM.  Partials are written and read with sc1 (agent-coherent)
+    // 16-byte accesses instead; s_waitcnt vmcnt(0) makes sure this wave's partial stores have completed before its
+    // workgroup takes a ticket.  Partials are stored fragment-major ([wave][tile i][tile j][lane][4]): a lane's
+    // accumulator registers are one 16-byte store, and the last workgroup to arrive rebuilds ITS accumulators as
+    // the sum over all splits in split order (deterministic) and falls through to the common epilogue.
+    constexpr int PSTRIDE = BM * BN + BM;
+    float* mine = g.ws + ((size_t)z * tiles + tile) * PSTRIDE;
+    const int frag0 = (wid * TM * TN * 64 + lane) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 16 * TN + 16 * j + r;
+        const float* dst = mine + frag0 + (i * TN + j) * 256;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+      }
+      if (want_rs && wn == 0 && kq == 0)
+        __hip_atomic_store(mine + BM * BN + wm * 16 * TM + 16 * i + r, rs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == (unsigned)g.splitk - 1;
+      if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* base = g.ws + (size_t)tile * PSTRIDE;
+    const size_t zstride = (size_t)tiles * PSTRIDE;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
-          const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
-          if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(acc[i][j][q], m, n);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int UNR = 4;  // UNR x TM x TN 16-byte loads in flight per lane
+    for (int sp = 0; sp < g.splitk; sp += UNR) {
+      f32x4 part[UNR][TM * TN];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int spc = sp + u < g.splitk ? sp + u : g.splitk - 1;  // clamped: uniform control flow around the asm loads
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          const float* src = base + spc * zstride + frag0 + q * 256;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[u][q]) : "v"(src) : "memory");
         }
       }
-      if (want_rs && wn == 0 && kq == 0) {
-        const int m = m0 + wm * 16 * TM + 16 * i + r;
-        if (m < g.M) g.rowsum[m] = rs[i];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          asm volatile("" : "+v"(part[u][q]));  // the values are only valid after the wait above
+          if (sp + u < g.splitk) acc[q / TN][q % TN] += part[u][q];
+        }
       }
     }
-    return;
+    if (want_rs && wn == 0 && kq == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v = 0.f;
+        for (int sp = 0; sp < g.splitk; ++sp)
+          v += __hip_atomic_load(base + sp * zstride + BM * BN + wm * 16 * TM + 16 * i + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rs[i] = v;
+      }
+    }
   }
 
-  // Split-K hand-off without __threadfence(): on a multi-XCD part an agent-scope fence writes back / invalidates
-  // the whole per-XCD L2, which costs more than the GEMM.  Partials are written and read with agent-scope
-  // relaxed atomics instead (sc1 accesses: coherent across XCDs by themselves); s_waitcnt vmcnt(0) makes sure
-  // this wave's partial stores have completed before its workgroup takes a ticket.
-  constexpr int PSTRIDE = BM * BN + BM;
-  float* mine = g.ws + ((size_t)z * tiles + tile) * PSTRIDE;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int nl = wn * 16 * TN + 16 * j + r;
+      const int n = n0 + wn * 16 * TN + 16 * j + r;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        __hip_atomic_store(mine + (wm * 16 * TM + 16 * i + 4 * kq + q) * BN + nl, acc[i][j][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (want_rs && wn == 0 && kq == 0)
-      __hip_atomic_store(mine + BM * BN + wm * 16 * TM + 16 * i + r, rs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) {
-    const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = old == (unsigned)g.splitk - 1;
-    if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const float* base = g.ws + (size_t)tile * PSTRIDE;
-  const size_t zstride = (size_t)tiles * PSTRIDE;
-  constexpr int EPT = BM * BN / 256;  // outputs per thread
-  float sum[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) sum[i] = 0.f;
-  // all loads of UNR splits are in flight together (the partials come from HBM / MALL, ~1 us each way);
-  // the additions stay in split order: deterministic
-  constexpr int UNR = EPT >= 16 ? 4 : 8;
-  for (int sp = 0; sp < g.splitk; sp += UNR) {
-    float part[UNR][EPT];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (sp + u < g.splitk) {
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) part[u][i] = __hip_atomic_load(base + (sp + u) * zstride + t + 256 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+        const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
+        if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(acc[i][j][q], m, n);
       }
     }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (sp + u < g.splitk) {
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) sum[i] += part[u][i];
-      }
+    if (want_rs && wn == 0 && kq == 0) {
+      const int m = m0 + wm * 16 * TM + 16 * i + r;
+      if (m < g.M) g.rowsum[m] = rs[i];
     }
-  }
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int e = t + 256 * i;
-    const int ml = e / BN, nl = e - ml * BN, m = m0 + ml, n = n0 + nl;
-    if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(sum[i], m, n);
-  }
-  if (want_rs && t < BM && m0 + t < g.M) {
-    float v = 0.f;
-    for (int sp = 0; sp < g.splitk; ++sp) v += __hip_atomic_load(base + sp * zstride + BM * BN + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    g.rowsum[m0 + t] = v;
   }
 }
 
