@@ -45,12 +45,14 @@ struct TGemm {
   int ldaux;
   float* rowsum;       // optional [M]: sum_k A(m, k)  (bias gradients)
   int splitk, tiles_m, tiles_n;
+  int wg_begin;        // first workgroup of this problem in the linear grid (tiles x splits workgroups each)
   float* ws;           // split-K partials [splitk][tiles][BM*BN + BM]
   unsigned* cnt;       // [tiles] arrival counters (zero between launches)
 };
 constexpr int kMaxGroup = 6;
 struct TGemmBatch {
   TGemm p[kMaxGroup];
+  int n;
 };
 
 // uint8 / 255 correctly rounded without a division: q = b * (1/255), one Newton correction with exact
@@ -70,9 +72,9 @@ __device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
   return o.u8 ? u8_unit(((const uint8_t*)o.p)[off]) : ((const float*)o.p)[off] / 255.0f;
 }
 
-// Rare cases (tile edges, operands that do not allow 16-byte accesses, fp32 NCHW frames): element-wise, out of
-// line so that the hot loop stays small enough for the instruction cache.
-// k-fast modes: v = elements (x, k..k+3).  x-fast modes: v = elements (x..x+3, k).  Zero outside X x K.
+// Rare cases (ragged edges, operands that do not allow 16-byte accesses, fp32 NCHW frames): element-wise, out
+// of line so that the hot loop stays small and branch-free.
+// k-fast modes: elements (x, k..k+3).  x-fast modes: elements (x..x+3, k).  Zero outside X x K.
 __device__ __noinline__ float4 op_fetch4_slow(Opnd o, int x, int k, int X, int K) {
   const bool kfast = !(o.mode & 1);
   const int dx = kfast ? 0 : 1, dk = kfast ? 1 : 0;
@@ -84,43 +86,17 @@ __device__ __noinline__ float4 op_fetch4_slow(Opnd o, int x, int k, int X, int K
   return r;
 }
 
-// One fetch = an address and a kind: 0 nothing (outside the matrix), 1 four floats, 2 four uint8 frames bytes,
-// 3 the slow path.  `conv_off` = pix_tab[pixel] + tap_tab[tap] of the first element for im2col operands (the
-// caller holds one term in a register, the other in LDS).
-__device__ __forceinline__ void op_fetch4(const Opnd& o, int x, int k, int X, int K, int conv_off, float v[4]) {
-  v[0] = v[1] = v[2] = v[3] = 0.f;
-  if (x >= X || k >= K) return;
-  const bool kfast = !(o.mode & 1);
-  const bool full = kfast ? (k + 3 < K) : (x + 3 < X);
-  int kind = 3;
-  const float* pf = (const float*)o.p;
-  if (o.mode <= OP_XCONT) {
-    pf += kfast ? (size_t)x * o.ld + k : (size_t)k * o.ld + x;
-    if (full && o.vec) kind = 1;
-  } else if (o.mode <= OP_NHWC_X) {
-    pf += conv_off;
-    if (full && o.vec) kind = 1;
-  } else if (full && o.vec && o.u8 && !(conv_off & 3)) {
-    kind = 2;
-  }
-  if (kind == 1) {
-    const float4 t = *reinterpret_cast<const float4*>(pf);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else if (kind == 2) {
-    const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + conv_off);
-    v[0] = u8_unit(w & 255u); v[1] = u8_unit((w >> 8) & 255u); v[2] = u8_unit((w >> 16) & 255u); v[3] = u8_unit(w >> 24);
-  } else {
-    const float4 t = op_fetch4_slow(o, x, k, X, K);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  }
-}
-
 // C[M][N] = sum_k A(m, k) B(k, n), workgroup tile (32 TM) x (32 TN), BK = 32, 4 waves as 2 x 2.
 // LDS tiles are [x][k] with a 36-float row stride: a lane's MFMA operands for 4 consecutive k are ONE
 // 16-byte LDS read (the k order inside a 16-wide block is permuted identically for A and B, which a
 // sum over k does not see), and the 16 rows a wave reads start in 16 distinct 4-bank groups.
-// splitk > 1: every split writes its partial tile, the last workgroup to arrive (per-tile counter) sums
-// the partials in split order -- deterministic, no atomics on data -- and runs the epilogue.
+// Operand fetch: every lane owns fixed 4-element pieces of the A and B tiles.  When the operand allows
+// 16-byte accesses and the extent that the 4 elements run along is a multiple of 4 (a uniform, per-operand
+// test) a piece is either wholly inside or wholly outside the matrix: ONE load from a clamped address plus a
+// select, no divergent branches; anything else goes through op_fetch4_slow.
+// The grid is linear over (problem, tile, split); splitk > 1: every split writes its partial tile, the last
+// workgroup to arrive (per-tile counter) sums the partials in split order -- deterministic, no atomics on
+// data -- and runs the epilogue.
 constexpr int kTabMax = 1024;  // k-range of one split that an im2col operand can address through its LDS table
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
@@ -129,10 +105,14 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   __shared__ __attribute__((aligned(16))) float sB[BN * LD];
   __shared__ int sTabA[kTabMax], sTabB[kTabMax];
   __shared__ int s_last;
-  const TGemm& g = batch.p[blockIdx.y];
-  const int tile = blockIdx.x, z = blockIdx.z;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.p[i].wg_begin) pi = i;
+  const TGemm& g = batch.p[pi];
   const int tiles = g.tiles_m * g.tiles_n;
-  if (tile >= tiles || z >= g.splitk) return;
+  const int local = blockIdx.x - g.wg_begin;
+  const int z = local / tiles, tile = local - z * tiles;
   const int tm_blk = tile / g.tiles_n, tn_blk = tile - tm_blk * g.tiles_n;
   const int m0 = tm_blk * BM, n0 = tn_blk * BN;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 15, kq = lane >> 4, wm = wid & 1, wn = wid >> 1;
@@ -141,71 +121,89 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   int kend = kbeg + per * BK;
   if (kend > g.K) kend = g.K;
   const bool a_kfast = !(g.a.mode & 1), b_kfast = !(g.b.mode & 1);
-
-  // im2col operands: the offset term that follows k (taps for k-fast, pixels for x-fast) is staged in LDS for
-  // this split's whole k range; the term that follows x is fixed per thread slot and sits in a register.
   const bool a_conv = g.a.mode >= OP_NHWC_K, b_conv = g.b.mode >= OP_NHWC_K;
-  int ax[TM], bx[TN];
+  // fast (branch-free) fetch possible?  fp32 NCHW frames always take the slow path (true division by 255)
+  const bool a_fast = g.a.vec && !((a_kfast ? kend : g.M) & 3) && (g.a.mode < OP_NCHW_K || g.a.u8);
+  const bool b_fast = g.b.vec && !((b_kfast ? kend : g.N) & 3) && (g.b.mode < OP_NCHW_K || g.b.u8);
+
+  // per-slot invariants: position of the piece inside the tile, clamped coordinates, base offsets
+  int a_x[TM], a_k[TM], a_off[TM], b_x[TN], b_k[TN], b_off[TN];
+  // im2col operands: the offset term that follows k (taps for k-fast, pixels for x-fast) is staged in LDS for
+  // this split's whole k range; the term that follows x is fixed per slot and sits in a register.
   if (a_conv) {
     const int* ktab = a_kfast ? g.a.tap_tab : g.a.pix_tab;
-    const int* xtab = a_kfast ? g.a.pix_tab : g.a.tap_tab;
     for (int i = t; i < kend - kbeg; i += 256) sTabA[i] = ktab[kbeg + i];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int e = t + 256 * i, x = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
-      ax[i] = x < g.M ? xtab[x] : 0;
-    }
   }
   if (b_conv) {
     const int* ktab = b_kfast ? g.b.tap_tab : g.b.pix_tab;
-    const int* xtab = b_kfast ? g.b.pix_tab : g.b.tap_tab;
     for (int i = t; i < kend - kbeg; i += 256) sTabB[i] = ktab[kbeg + i];
+  }
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int e = t + 256 * i, x = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
-      bx[i] = x < g.N ? xtab[x] : 0;
-    }
+  for (int i = 0; i < TM; ++i) {
+    const int e = t + 256 * i;
+    a_x[i] = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
+    a_k[i] = a_kfast ? 4 * (e & 7) : e / (BM / 4);
+    const int xc = a_kfast ? (a_x[i] < g.M ? a_x[i] : g.M - 1) : (a_x[i] + 3 < g.M ? a_x[i] : (g.M >= 4 ? g.M - 4 : 0));
+    a_off[i] = a_conv ? (a_kfast ? g.a.pix_tab : g.a.tap_tab)[xc] : (a_kfast ? xc * g.a.ld : xc);
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int e = t + 256 * i;
+    b_x[i] = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
+    b_k[i] = b_kfast ? 4 * (e & 7) : e / (BN / 4);
+    const int xc = b_kfast ? (b_x[i] < g.N ? b_x[i] : g.N - 1) : (b_x[i] + 3 < g.N ? b_x[i] : (g.N >= 4 ? g.N - 4 : 0));
+    b_off[i] = b_conv ? (b_kfast ? g.b.pix_tab : g.b.tap_tab)[xc] : (b_kfast ? xc * g.b.ld : xc);
   }
   if (a_conv || b_conv) __syncthreads();
 
-  float ra0[TM][4], rb0[TN][4];
-  auto gload = [&](int k0, float (&ra)[TM][4], float (&rb)[TN][4]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int e = t + 256 * i;
-      const int x = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
-      const int k = a_kfast ? k0 + 4 * (e & 7) : k0 + e / (BM / 4);
-      op_fetch4(g.a, x, k, g.M, kend, a_conv ? ax[i] + sTabA[(k < kend ? k : kend - 1) - kbeg] : 0, ra[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int e = t + 256 * i;
-      const int x = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
-      const int k = b_kfast ? k0 + 4 * (e & 7) : k0 + e / (BN / 4);
-      op_fetch4(g.b, x, k, g.N, kend, b_conv ? bx[i] + sTabB[(k < kend ? k : kend - 1) - kbeg] : 0, rb[i]);
+  // one piece: (operand, fast?, conv?, kfast?, x, in-tile k, slot offset, LDS table, extent X) at chunk k0
+  auto fetch = [&](const Opnd& o, bool fast, bool conv, bool kfast, int x, int kin, int off, const int* tab, int X, int k0, float (&v)[4]) {
+    const int k = k0 + kin;
+    if (fast) {
+      const int last = kfast ? kend - 4 : kend - 1;       // clamped: the load itself is always in bounds
+      const int kc = k < last ? k : last;
+      const bool ok = (kfast ? x < X : x + 3 < X) && k < kend;
+      float4 q;
+      if (!conv) {
+        q = *reinterpret_cast<const float4*>((const float*)o.p + (kfast ? (size_t)off + kc : (size_t)kc * o.ld + off));
+      } else if (o.mode <= OP_NHWC_X) {
+        q = *reinterpret_cast<const float4*>((const float*)o.p + off + tab[kc - kbeg]);
+      } else {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + off + tab[kc - kbeg]);
+        q = make_float4(u8_unit(w & 255u), u8_unit((w >> 8) & 255u), u8_unit((w >> 16) & 255u), u8_unit(w >> 24));
+      }
+      v[0] = ok ? q.x : 0.f; v[1] = ok ? q.y : 0.f; v[2] = ok ? q.z : 0.f; v[3] = ok ? q.w : 0.f;
+    } else {
+      const float4 q = op_fetch4_slow(o, x, k, X, kend);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     }
   };
-  auto sstore = [&](float (&ra)[TM][4], float (&rb)[TN][4]) {
+  float ra[TM][4], rb[TN][4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fetch(g.a, a_fast, a_conv, a_kfast, a_x[i], a_k[i], a_off[i], sTabA, g.M, k0, ra[i]);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fetch(g.b, b_fast, b_conv, b_kfast, b_x[i], b_k[i], b_off[i], sTabB, g.N, k0, rb[i]);
+  };
+  auto sstore = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int e = t + 256 * i;
+      const int xr = a_x[i] - m0;
       if (a_kfast) {
-        *reinterpret_cast<float4*>(&sA[(e >> 3) * LD + 4 * (e & 7)]) = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+        *reinterpret_cast<float4*>(&sA[xr * LD + a_k[i]]) = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
       } else {
-        const int xc = e % (BM / 4), kr = e / (BM / 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sA[(4 * xc + j) * LD + kr] = ra[i][j];
+        for (int j = 0; j < 4; ++j) sA[(xr + j) * LD + a_k[i]] = ra[i][j];
       }
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int e = t + 256 * i;
+      const int xr = b_x[i] - n0;
       if (b_kfast) {
-        *reinterpret_cast<float4*>(&sB[(e >> 3) * LD + 4 * (e & 7)]) = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+        *reinterpret_cast<float4*>(&sB[xr * LD + b_k[i]]) = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
       } else {
-        const int xc = e % (BN / 4), kr = e / (BN / 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sB[(4 * xc + j) * LD + kr] = rb[i][j];
+        for (int j = 0; j < 4; ++j) sB[(xr + j) * LD + b_k[i]] = rb[i][j];
       }
     }
   };
@@ -220,35 +218,35 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   for (int i = 0; i < TM; ++i) rs[i] = 0.f;
   const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
 
-  auto mma_tile = [&]() {
-#pragma unroll
-    for (int kb = 0; kb < BK; kb += 16) {
-      float4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[(wm * 16 * TM + 16 * i + r) * LD + kb + 4 * kq]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[(wn * 16 * TN + 16 * j + r) * LD + kb + 4 * kq]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-        if (want_rs && wn == 0) rs[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
-      }
-    }
-  };
   // tile i: registers -> LDS, refill the registers with tile i + 1 (its HBM loads fly under the MFMAs of tile i)
-  if (kbeg < kend) gload(kbeg, ra0, rb0);
+  if (kbeg < kend) gload(kbeg);
 #pragma unroll 1
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    sstore(ra0, rb0);
+    sstore();
     __syncthreads();
-    if (k0 + BK < kend) gload(k0 + BK, ra0, rb0);
-    mma_tile();
+    if (k0 + BK < kend) gload(k0 + BK);
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 16) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 q = *reinterpret_cast<const float4*>(&sA[(wm * 16 * TM + 16 * i + r) * LD + kb + 4 * kq]);
+        a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
+        if (want_rs && wn == 0) rs[i] += (q.x + q.y) + (q.z + q.w);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(&sB[(wn * 16 * TN + 16 * j + r) * LD + kb + 4 * kq]);
+        b[j][0] = q.x; b[j][1] = q.y; b[j][2] = q.z; b[j][3] = q.w;
+      }
+      // consecutive MFMAs go to different accumulators (dependent issue costs 40 cycles instead of 32)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c], b[j][c], acc[i][j], 0, 0, 0);
+    }
     __syncthreads();
   }
   if (want_rs && wn == 0) {
@@ -540,7 +538,7 @@ inline Opnd op_conv(int mode, const void* p, int u8, const ConvGeom& c) {
   Opnd o{};
   o.p = p; o.mode = mode; o.u8 = u8; o.pix_tab = c.pix_tab; o.tap_tab = c.tap_tab;
   if (mode <= OP_NHWC_X) o.vec = (c.C % 4 == 0) && (((uintptr_t)p & 15) == 0);
-  else o.vec = (c.KW % 4 == 0) && (((uintptr_t)p & (u8 ? 3 : 15)) == 0);
+  else o.vec = (c.KW % 4 == 0) && (c.W % 4 == 0) && (c.S % 4 == 0) && (((uintptr_t)p & (u8 ? 3 : 15)) == 0);  // every 4-tap piece aligned
   return o;
 }
 inline TGemm mk_gemm(int M, int N, int K, const Opnd& a, const Opnd& b, float* C, int ldc, int epi, const float* bias = nullptr,
@@ -645,8 +643,15 @@ static int launch_tgemm(jh_rbnet* net, const char* name, TGemm* probs, int n, hi
     if (s > max_split) max_split = s;
   }
   TGemmBatch batch{};
-  for (int i = 0; i < n; ++i) batch.p[i] = probs[i];
-  const dim3 grid(max_tiles, n, max_split);
+  int wgs = 0;
+  for (int i = 0; i < n; ++i) {
+    probs[i].wg_begin = wgs;
+    wgs += probs[i].tiles_m * probs[i].tiles_n * probs[i].splitk;
+    batch.p[i] = probs[i];
+  }
+  batch.n = n;
+  (void)max_tiles; (void)max_split;
+  const dim3 grid(wgs);
   if (TM == 2 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 2>), grid, dim3(256), 0, st, batch);
   else if (TM == 1 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<1, 2>), grid, dim3(256), 0, st, batch);
   else if (TM == 2 && TN == 1) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 1>), grid, dim3(256), 0, st, batch);
