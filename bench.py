@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--python-collector", action="store_true", help="per-timestep Python loop instead of jh_collector_run")
+    ap.add_argument("--no-rainbow", action="store_true", help="skip the Rainbow (configs[2]) learner leg")
+    ap.add_argument("--rainbow-updates", type=int, default=300)
     return ap.parse_args()
 
 
@@ -98,6 +100,66 @@ _PMC_NAME = {
     "jh_gemm16_bwd_dWheads": "jh_gemm16_kernel<1, false, 3,", "jh_adam_kernel": "jh_adam_kernel", "jh_gae_kernel": "jh_gae_kernel",
     "jh_ppo_fused_kernel<CONT>": "jh_ppo_fused_kernel<false>", "jh_gather_kernel": "jh_gather_kernel",
 }
+
+
+def rainbow_leg(rank, world, local_rank, dist, updates, warmup):
+    """Second half of BASELINE.json's metric: learner updates/s of Rainbow at config.rainbow.atari shapes
+    (configs[2]; uint8 (4,84,84) frames, A=4, B=32 per GPU, n=3, K=51, PER), synthetic transitions.  One env
+    step = one PERBuffer.store, one learn() per 4 env steps (learn_period); every rank is a learner with its
+    own replay shard, gradients averaged with one RCCL all-reduce per learn() (weak scaling)."""
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.parallel import attach_data_parallel
+
+    N, B, n, filled = 100_000, 32, 3, 8192
+    torch.manual_seed(4321)
+    agent = Agent("rainbow", state_size=[4, 84, 84], action_size=4, hidden_size=512, head="cnn", optim_config={"name": "adam", "lr": 6.25e-5},
+                  gamma=0.99, buffer_size=N, batch_size=B, start_train_step=0, target_update_period=10000, run_step=30_000_000, n_step=n,
+                  alpha=0.5, beta=0.4, learn_period=4, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51, device=f"cuda:{local_rank}")
+    agent.memory.first_store = False
+    rng = np.random.RandomState(100 + rank)
+    for o in range(0, filled, 2048):
+        m = 2048
+        cols = {"state": rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8), "action": rng.randint(0, 4, size=(m, 1)),
+                "reward": rng.choice([-1.0, 0.0, 1.0], p=[0.02, 0.9, 0.08], size=(m, n, 1)).astype(np.float32),
+                "next_state": rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8), "done": (rng.rand(m, n, 1) < 1e-3)}
+        agent.memory.store_soa(cols)
+    idx = torch.arange(agent.memory.first_leaf_index, agent.memory.first_leaf_index + filled, device="cuda")
+    for o in range(0, filled, 2048):
+        agent.memory.update_priorities(idx[o : o + 2048], torch.rand(2048, device="cuda") ** 0.5)
+    if dist is not None:
+        attach_data_parallel(agent, dist)
+    one = {k: v[:1] for k, v in cols.items()}
+    np.random.seed(99 + rank)
+
+    def update():
+        for _ in range(4):
+            agent.memory.store_soa(one)
+        return agent.learn()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        update()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        r = update()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"metric": "learner_updates_per_s (Rainbow, config.rainbow.atari shapes, B=32 per GPU)", "value": world * updates / dt, "unit": "updates/s",
+            "env_steps_per_s": 4 * world * updates / dt, "ms_per_update_incl_4_stores": dt / updates * 1e3, "updates": updates, "n_gpus": world,
+            "scaling": "weak", "backend": agent.backend, "hipgraph": bool(agent._graph is not None), "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config.rainbow.atari breakout-shaped (BASELINE.json configs[2]): uint8 (4,84,84) frames, A=4, B=32, n=3, K=51, PER "
+                                   f"N={N} ({filled} filled), one store per env step, one learn() per 4", "parallelism": f"dp{world}"},
+            "loss": float(r["loss"]), "cpu_reference_updates_per_s": 34.0, "cpu_reference_note": "BASELINE.md §2: reference Rainbow.learn on 8 host cores (survey box)"}
 
 
 def pmc_traffic(kernel):
@@ -256,6 +318,9 @@ def main():
                            "note": "latency-bound BASELINE shape (minibatch 256 x hidden 512); see DESIGN.md for scaled shapes"}
         out["kernel_avg_us"] = {k: round(v[1] / v[0] * 1e3, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         out["kernel_total_us_per_learn"] = {k: round(v[1] / n_learn * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    if not args.no_rainbow:
+        del collector, env
+        out["rainbow"] = rainbow_leg(rank, world, local_rank, dist, args.rainbow_updates, 30)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters, W, T)
     if rank == 0:

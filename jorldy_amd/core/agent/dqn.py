@@ -25,6 +25,8 @@ class DQN(BaseAgent):
                  target_update_period=500, device=None, run_step=1e6, num_workers=1, lr_decay=True, use_graph=True, **kwargs):
         self.device = self._require_gpu(device)
         self.use_graph = use_graph
+        self.grad_sync = None  # data-parallel hook (jorldy_amd.parallel.attach_data_parallel)
+        self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
         self.action_size = action_size
         self.action_type = "discrete"
         self.network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
@@ -126,6 +128,8 @@ class DQN(BaseAgent):
             self.memory.update_priorities(st["idx"], prio)  # per.py:67-70 without the B `.item()` syncs
         self.optimizer.zero_grad(set_to_none=True)
         q.backward(g)
+        if self.grad_sync is not None:  # data-parallel learners: mean gradient over ranks (jorldy_amd.parallel)
+            self.grad_sync()
         if self.clip_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.clip_grad_norm)
         self.optimizer.step()
@@ -138,7 +142,8 @@ class DQN(BaseAgent):
         st = self._static
         self.memory.flush()  # held per-step stores -> HBM before anything (possibly a replayed graph) reads the ring
         extra = self._draw(st)
-        graphable = self.use_graph and self._lr0 is not None and self._noise is None and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
+        graphable = (self.use_graph and self._lr0 is not None and self._noise is None and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
+                     and (self.grad_sync is None or self.graph_with_collective))
         if graphable and self._graph is None and self._warm:
             try:
                 g = torch.cuda.CUDAGraph()

@@ -1,3 +1,4 @@
+import os
 from collections import deque
 
 import numpy as np
@@ -50,6 +51,8 @@ class C51(DQN):
                                   self.v_min, self.v_max, self.gamma, shift_max=True, stats=self._stats8)
         self.optimizer.zero_grad(set_to_none=True)
         logit.backward(g.view_as(logit))
+        if self.grad_sync is not None:
+            self.grad_sync()
         self.optimizer.step()
 
     def learn(self):
@@ -126,6 +129,8 @@ class Rainbow(DQN):
                  use_graph=True, backend=None, **kwargs):
         self.device = self._require_gpu(device)
         self.use_graph = use_graph
+        self.grad_sync = None  # data-parallel hook (jorldy_amd.parallel.attach_data_parallel)
+        self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
         self._static, self._graph, self._warm, self.clip_grad_norm = None, None, False, None
         self._td = dict(double=True, per=True, n_step=1)
         self.action_size = action_size
@@ -235,6 +240,8 @@ class Rainbow(DQN):
                                      next_logit_online=lg[1], weights=st["w"], alpha=self.alpha, n_step=self.n_step, stats=self._stats8)
         self.memory.update_priorities(st["idx"], prio)  # rainbow.py:230-231
         net.backward(g)
+        if self.grad_sync is not None:  # data-parallel learners: one all-reduce of the flat gradient bucket
+            self.grad_sync.reduce_flat(net.grads)
         net.adam_step()
 
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
@@ -311,6 +318,8 @@ class Rainbow(DQN):
         self.memory.update_priorities(st["idx"], prio)  # rainbow.py:230-231
         self.optimizer.zero_grad(set_to_none=True)
         logit.backward(g)
+        if self.grad_sync is not None:
+            self.grad_sync()
         self.optimizer.step()
 
     def _import_optim_state(self):  # load_full(): load() above already imported the moments

@@ -1,6 +1,8 @@
 """End-to-end parity of the drop-in agents on the GPU against the reference's own learn() runs
 (fixtures from oracle/gen_golden.py): same inputs, same initial weights, same numpy RNG seed ->
 same sampled indices (bit-exact), losses within 1e-5, updated weights within Adam-step noise."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -617,3 +619,38 @@ def test_deferred_stores_are_invisible_per_buffer():
     sd0, sd1 = bufs[0].state_dict(), bufs[1].state_dict()
     for k in sd0["columns"]:
         np.testing.assert_array_equal(sd0["columns"][k], sd1["columns"][k])
+
+
+def test_rainbow_native_data_parallel_hook_single_rank_rccl():
+    """attach_data_parallel on a 1-rank RCCL group: the all-reduce of the flat gradient bucket sits between
+    backward and Adam (captured into the learn() graph when RCCL allows it); with world size 1 the mean is the
+    identity, so the run must reproduce the hook-free learner bit for bit."""
+    import torch.distributed as dist
+
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.parallel import attach_data_parallel
+
+    z = load("rainbow")
+    H, A, K = int(_h(z, "H")), int(_h(z, "A")), int(_h(z, "num_support"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        res = []
+        for dp in (False, True):
+            torch.manual_seed(0)
+            agent = Agent("rainbow", state_size=int(z["hyper/S"]), action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": 1e-3}, buffer_size=256,
+                          batch_size=int(_h(z, "B")), start_train_step=0, run_step=1000, n_step=3, num_support=K, device="cuda")
+            agent.network.load_state_dict(_sd(z, "sd0/"))
+            agent.target_network.load_state_dict(_sd(z, "sdt/"))
+            _fill_from_fixture(agent, z, True)
+            if dp:
+                attach_data_parallel(agent, dist)
+                assert agent.grad_sync is not None
+            np.random.seed(3)
+            torch.manual_seed(4)
+            losses = [agent.learn()["loss"] for _ in range(4)]
+            res.append((losses, agent._net.params.clone()))
+        assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    finally:
+        dist.destroy_process_group()

@@ -67,3 +67,29 @@ def test_flat_grad_sync_equals_single_learner(tmp_path):
     for k, v in net.state_dict().items():
         torch.testing.assert_close(sd[0][k], sd[1][k], rtol=0, atol=0)  # ranks stay bit-identical
         torch.testing.assert_close(sd[0][k], v, rtol=1e-5, atol=1e-6)
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jorldy_amd.parallel import BucketSync
+
+    sync = BucketSync(dist)
+    params = torch.full((37,), float(rank + 1))
+    moments = torch.full((37,), float(10 * (rank + 1)))
+    sync.broadcast(params, moments)  # identical start: rank 0's buckets everywhere
+    grads = torch.arange(37, dtype=torch.float32) * (rank + 1)
+    sync.reduce_flat(grads)  # mean over ranks, in place
+    torch.save({"params": params, "moments": moments, "grads": grads}, os.path.join(out_dir, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_bucket_sync_mean_gradient_and_broadcast(tmp_path):
+    """The flat-bucket form used by the native Rainbow learner (ops.RainbowNet buckets)."""
+    world = 2
+    mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out = [torch.load(os.path.join(tmp_path, f"b{r}.pt")) for r in range(world)]
+    for r in range(world):
+        assert torch.equal(out[r]["params"], torch.full((37,), 1.0)) and torch.equal(out[r]["moments"], torch.full((37,), 10.0))
+        assert torch.equal(out[r]["grads"], torch.arange(37, dtype=torch.float32) * 1.5)
