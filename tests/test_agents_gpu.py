@@ -654,3 +654,61 @@ def test_rainbow_native_data_parallel_hook_single_rank_rccl():
         assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_nstep_assemblers_of_the_agents_match_reference_fixture():
+    """interact_callback of Rainbow / Multistep / Ape-X (rainbow.py:294-308, multistep.py:90-104,
+    ape_x.py:174-199) against the windows the reference emitted for the same 12 raw transitions (two episode
+    ends inside: windows straddle them; Ape-X adds the actor-side priority |G_n - q_t|)."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load("nstep")
+    keys = ["state", "action", "reward", "next_state", "done"]
+    S, A = z["in_state"].shape[1], 2
+    agents = {
+        "rainbow": Agent("rainbow", state_size=S, action_size=A, hidden_size=8, n_step=3, buffer_size=16, device="cuda"),
+        "multistep": Agent("multistep", state_size=S, action_size=A, hidden_size=8, n_step=3, buffer_size=16, device="cuda"),
+        "apex": Agent("ape_x", state_size=S, action_size=A, hidden_size=8, n_step=3, buffer_size=16, num_workers=4, device="cuda"),
+    }
+    for name, agent in agents.items():
+        ref = "rainbow" if name == "multistep" else name  # multistep.py's assembler is the same window as rainbow.py's
+        out, emitted = {}, []
+        for i in range(z["in_state"].shape[0]):
+            t = {k: z[f"in_{k}"][i : i + 1] for k in keys}
+            if name == "apex":
+                t["q"] = z["in_q"][i : i + 1]
+            e = agent.interact_callback(t)
+            emitted.append(bool(e))
+            for k, v in e.items():
+                out.setdefault(k, []).append(np.asarray(v))
+        np.testing.assert_array_equal(emitted, z[f"{ref}_emitted"])
+        for k, v in out.items():
+            np.testing.assert_array_equal(np.concatenate(v, 0), z[f"{ref}_{k}"], err_msg=f"{name}.{k}")
+
+
+def test_multimodal_list_valued_keys_through_the_device_store():
+    """base.py:42-56 stack_transition stacks list-valued keys (multimodal observations: [image, vector]) per
+    element; the device store keeps one column per element (uint8 stays uint8) and gather returns lists."""
+    from jorldy_amd.core.buffer import ReplayBuffer
+    from oracle import jorldy_oracle as O
+
+    rng = np.random.RandomState(0)
+    mk = lambda: [rng.randint(0, 256, size=(1, 2, 6, 5)).astype(np.uint8), rng.randn(1, 3).astype(np.float32)]
+    trs = [{"state": mk(), "action": rng.randint(0, 4, size=(1, 1)), "reward": rng.randn(1, 1), "next_state": mk(), "done": np.asarray([[i % 5 == 4]])} for i in range(11)]
+    buf = ReplayBuffer(8, device="cuda")  # wraps
+    ora = O.ReplayOracle(8)
+    for i in range(0, 11, 3):
+        buf.store(trs[i : i + 3])
+        ora.store(trs[i : i + 3])
+    assert buf.size == ora.size == 8 and buf.buffer_index == ora.buffer_index
+    np.random.seed(4)
+    want = ora.sample(6)
+    np.random.seed(4)
+    got = buf.sample(6, as_float=False)
+    assert isinstance(got["state"], list) and got["state"][0].dtype == torch.uint8
+    for k in ("state", "next_state"):
+        for a, b in zip(got[k], want[k]):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+    for k in ("action", "reward", "done"):
+        # float64 rewards become fp32 on the device, as in the reference's as_tensor (base.py:61-73)
+        np.testing.assert_array_equal(got[k].cpu().numpy().astype(np.float32), np.asarray(want[k]).astype(np.float32))
