@@ -273,48 +273,58 @@ int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream str
  * actions, and stepping the envs + writing the transitions.                                        */
 int jh_collector_stats(jh_collector* c, double* act_us_per_step, double* env_us_per_step, int32_t reset);
 
-/* ------------------------------------------------------------------ native Rainbow network
- * core/network/rainbow.py:8-94 (noisy dueling categorical net) on core/network/head.py:6-61 (MLP or
- * Nature-CNN head), utils.py:55-107 (factorised noisy linear), and the network side of
- * core/agent/rainbow.py:160-186,236-238 (three forwards, backward, Adam).  Convolutions are implicit
- * GEMMs on the fp32 MFMA; uint8 NCHW frames are read straight from the replay store (divide by 255
- * inside the operand fetch, head.py:46).  Parameters live in flat fp32 buckets with a
- * private layout; jh_rbnet_segment describes it (rows x cols, row-major, 16-byte aligned offsets):
+/* ------------------------------------------------------------------ native value networks
+ * The encoders of the DQN / Rainbow / Ape-X family with their learn()-side network work:
+ *   kind 0  rainbow  core/network/rainbow.py:8-94: head -> l -> noisy a1|v1 -> noisy a2, v2 -> dueling over K atoms
+ *                    (utils.py:55-107 factorised noisy linear)
+ *   kind 1  dueling  core/network/dueling.py:8-35: head -> l1_a|l1_v -> l2_a, l2_v -> dueling combine  (K = 1)
+ *   kind 2  q        core/network/q_network.py:8-20: head -> l -> q                                    (K = 1)
+ * on core/network/head.py:6-61 (MLP or Nature-CNN head), plus the three forwards / backward / optimizer step
+ * of the agents' learn() (rainbow.py:160-186,236-238; dqn.py:128-147; ape_x.py:96-131).  Convolutions are
+ * implicit GEMMs on the fp32 MFMA; uint8 NCHW frames are read straight from the replay store (divide by 255
+ * inside the operand fetch, head.py:46).  Parameters live in flat fp32 buckets with a private layout;
+ * jh_rbnet_segment describes it (rows x cols, row-major, 16-byte aligned offsets, rows = 0: absent):
  *   0 conv1.weight [32][(c,ky,kx)] | head.l.weight [H][S] (mlp)     1 its bias
  *   2 conv2.weight [64][(ky,kx,c)]   3 bias    4 conv3.weight [64][(ky,kx,c)]   5 bias   (cnn only)
- *   6 l.weight [H][F] (cnn: F ordered (y,x,c))   7 l.bias
- *   8 mu_w  [a1;v1] stacked [2H][H] (= reference mu_w_a1^T over mu_w_v1^T)   9 sig_w   10 mu_b [2H]   11 sig_b
- *   12-15 a2: mu_w [A*K][H], sig_w, mu_b, sig_b        16-19 v2: mu_w [K][H], sig_w, mu_b, sig_b      */
+ *   6 l.weight [H][F] (cnn: F ordered (y,x,c))   7 l.bias                         (kinds 0, 2)
+ *   8 first stream layer, a|v stacked [2H][in] (in = H, or F for kind 1; rainbow: mu_w^T)   9 sig_w   10 bias [2H]   11 sig_b
+ *   12-15 a2 / l2_a / q: weight [A*K][H], sig_w, bias, sig_b        16-19 v2 / l2_v: weight [K][H], sig_w, bias, sig_b
+ * (sig_* only for kind 0).                                                                              */
 typedef struct jh_rbnet jh_rbnet;
-int64_t jh_rbnet_param_count_for(int32_t head_cnn, int32_t channels_or_state_size, int32_t height, int32_t width, int32_t hidden,
-                                 int32_t action_size, int32_t num_support);
+int64_t jh_rbnet_param_count_for(int32_t kind, int32_t head_cnn, int32_t channels_or_state_size, int32_t height, int32_t width,
+                                 int32_t hidden, int32_t action_size, int32_t num_support);
 /* d_params (online), d_target, d_grads, d_m, d_v: caller-owned flat fp32 device buckets of
- * jh_rbnet_param_count_for(...) floats each (16-byte aligned), borrowed for the net's lifetime.        */
-int jh_rbnet_create(jh_ctx* ctx, int32_t head_cnn, int32_t channels_or_state_size, int32_t height, int32_t width,
+ * jh_rbnet_param_count_for(...) floats each (16-byte aligned), borrowed for the net's lifetime.
+ * d_m / d_v: Adam exp_avg / exp_avg_sq, or RMSprop grad_avg / square_avg.                               */
+int jh_rbnet_create(jh_ctx* ctx, int32_t kind, int32_t head_cnn, int32_t channels_or_state_size, int32_t height, int32_t width,
                     int32_t hidden, int32_t action_size, int32_t num_support, int32_t max_batch, float* d_params,
                     float* d_target, float* d_grads, float* d_m, float* d_v, jh_rbnet** out);
 void jh_rbnet_destroy(jh_rbnet* n);
 int64_t jh_rbnet_param_count(const jh_rbnet* n);
 int32_t jh_rbnet_segment_count(void);
 int jh_rbnet_segment(const jh_rbnet* n, int32_t i, int64_t* offset, int32_t* rows, int32_t* cols);
-/* Length of one noise set: N(0,1) draws in the reference's draw order (utils.py:58-60, layers a1, v1,
+/* Length of one noise set (kind 0): N(0,1) draws in the reference's draw order (utils.py:58-60, layers a1, v1,
  * a2, v2): [e_in a1 H][e_out a1 H][e_in v1 H][e_out v1 H][e_in a2 H][e_out a2 A*K][e_in v2 H][e_out v2 K] */
 int64_t jh_rbnet_noise_len(const jh_rbnet* n);
-int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1, float beta2, float eps, int64_t step, jh_stream stream);
+/* Adam: (lr, beta1, beta2, eps).  RMSprop: (lr, alpha, unused, eps) + centered.  step = optimizer step counter. */
+int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1_or_alpha, float beta2, float eps, int64_t step, int32_t centered,
+                       jh_stream stream);
 int jh_rbnet_set_lr(jh_rbnet* n, float lr, jh_stream stream);
-/* rainbow.py:270-271 update_target: target <- online                                                 */
+/* update_target (dqn.py:162-163, rainbow.py:270-271): target <- online                                  */
 int jh_rbnet_sync_target(jh_rbnet* n, jh_stream stream);
-/* network(x, is_train): rows <= max_batch observations (JH_U8 or JH_F32; NCHW images or [rows][S]),
- * which 0 online / 1 target, d_noise one noise set or NULL for is_train = False -> logits [rows][A][K] */
+/* network(x[, is_train]): rows <= max_batch observations (JH_U8 or JH_F32; NCHW images or [rows][S]),
+ * which 0 online / 1 target, d_noise one noise set or NULL (kind 0: is_train = False) -> logits [rows][A][K] */
 int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int32_t x_dtype, int32_t rows, const float* d_noise,
                      float* d_logits, jh_stream stream);
-/* The three forwards of Rainbow.learn (rainbow.py:160-186): d_x = [state; next_state] (2B rows),
- * d_noise three noise sets -> d_logits [3][B][A][K] = online(state), online(next_state), target(next_state) */
+/* The three forwards of learn(): d_x = [state; next_state] (2B rows), d_noise three noise sets (kind 0, else
+ * NULL) -> d_logits [3][B][A][K] = online(state), online(next_state), target(next_state)                */
 int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits,
                            jh_stream stream);
-/* loss.backward() given d(loss)/d(online(state) logits) [B][A][K] (e.g. from jh_c51_loss); fills d_grads */
+/* loss.backward() given d(loss)/d(online(state) output) [B][A][K] (from jh_c51_loss / jh_td_loss); fills d_grads */
 int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream);
-/* optimizer.step(): torch.optim.Adam semantics on d_params from d_grads; advances the step counter     */
+/* [clip_grad_norm_(max_norm) when max_norm > 0 (ape_x.py:128),] optimizer.step(): optimizer 0 torch.optim.Adam,
+ * 1 torch.optim.RMSprop (momentum 0, centered per set_hyper); advances the step counter                 */
+int jh_rbnet_optim_step(jh_rbnet* n, int32_t optimizer, float max_norm, jh_stream stream);
 int jh_rbnet_adam_step(jh_rbnet* n, jh_stream stream);
 
 #ifdef __cplusplus

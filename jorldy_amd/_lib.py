@@ -81,14 +81,15 @@ _PROTOS = {
     "jh_pponet_act_discrete": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jh_collector_create": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
     "jh_collector_destroy": (None, [_vp]),
-    "jh_rbnet_param_count_for": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
-    "jh_rbnet_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _pp]),
+    "jh_rbnet_param_count_for": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "jh_rbnet_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _pp]),
     "jh_rbnet_destroy": (None, [_vp]),
     "jh_rbnet_param_count": (_i64, [_vp]),
     "jh_rbnet_segment_count": (_i32, []),
     "jh_rbnet_segment": (C.c_int, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)]),
     "jh_rbnet_noise_len": (_i64, [_vp]),
-    "jh_rbnet_set_hyper": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _i64, _vp]),
+    "jh_rbnet_set_hyper": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _i64, _i32, _vp]),
+    "jh_rbnet_optim_step": (C.c_int, [_vp, _i32, _f32, _vp]),
     "jh_rbnet_set_lr": (C.c_int, [_vp, _f32, _vp]),
     "jh_rbnet_sync_target": (C.c_int, [_vp, _vp]),
     "jh_rbnet_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),

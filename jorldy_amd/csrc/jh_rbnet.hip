@@ -495,22 +495,65 @@ __global__ void __launch_bounds__(256) jh_rb_col2im_kernel(const float* __restri
   *reinterpret_cast<float4*>(dact + (size_t)pix * C + c) = acc;
 }
 
-// ---------------------------------------------------------------------------------- Adam (torch.optim.Adam, no weight decay)
-// hyper (device): {lr, beta1, beta2, eps, step}.  The step counter advances inside: every workgroup derives
-// the bias corrections from step + 1 at its start; the last one to finish stores the new step.
-__global__ void __launch_bounds__(256) jh_rb_adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                         float* __restrict__ v, float* __restrict__ hyper, unsigned* __restrict__ ticket) {
+// ---------------------------------------------------------------------------------- optimizers
+// hyper (device): {lr, beta1 | alpha, beta2, eps, step, centered}.  The step counter advances inside: every
+// workgroup derives what it needs from step + 1 at its start; the last one to finish stores the new step.
+// Optional global-norm clip (torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)), applied
+// to the gradient in place like the reference): `partial` holds per-workgroup sums of squares.
+__global__ void __launch_bounds__(256) jh_rb_gradnorm_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ partial) {
+  __shared__ float s_red[16];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+  acc = jh_block_reduce(acc, s_red, JhAdd(), 0.f);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+template <int OPT>  // 0 torch.optim.Adam, 1 torch.optim.RMSprop (momentum 0, optionally centered); no weight decay
+__global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, float* __restrict__ hyper, unsigned* __restrict__ ticket,
+                                                          const float* __restrict__ partial, int n_partial, float max_norm) {
+  __shared__ float s_red[16];
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+    const float total = sqrtf(jh_block_reduce(acc, s_red, JhAdd(), 0.f));
+    coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  }
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float t_new = hyper[4] + 1.f;
-  const float bc1 = 1.f - powf(b1, t_new), bc2s = sqrtf(1.f - powf(b2, t_new));
+  const bool centered = hyper[5] != 0.f;
+  float bc1 = 1.f, bc2s = 1.f;
+  if (OPT == 0) {
+    bc1 = 1.f - powf(b1, t_new);
+    bc2s = sqrtf(1.f - powf(b2, t_new));
+  }
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i];
-    const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    float gi = g[i];
+    if (max_norm > 0.f) {
+      gi *= coef;
+      g[i] = gi;
+    }
+    if (OPT == 0) {
+      const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    } else {
+      const float vi = v[i] * b1 + (1.f - b1) * gi * gi;  // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
+      v[i] = vi;
+      float avg;
+      if (centered) {
+        const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // grad_avg.lerp_(grad, 1 - alpha)
+        m[i] = mi;
+        avg = sqrtf(vi - mi * mi) + eps;                   // square_avg.addcmul(grad_avg, grad_avg, value=-1).sqrt_().add_(eps)
+      } else {
+        avg = sqrtf(vi) + eps;
+      }
+      p[i] = p[i] - lr * (gi / avg);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -559,6 +602,11 @@ enum {
 struct jh_rbnet {
   jh_ctx* ctx = nullptr;
   int cnn = 0, Cin = 0, Hin = 0, Win = 0, hidden = 0, A = 0, K = 0, NA = 0, maxB = 0, F = 0;
+  // kind 0 rainbow: head -> l -> noisy a1|v1 -> noisy a2, v2 -> dueling over K atoms   (network/rainbow.py:8-94)
+  //      1 dueling: head -> l1_a|l1_v -> l2_a, l2_v -> dueling combine (K = 1)         (network/dueling.py:8-35)
+  //      2 q:       head -> l -> q                                                      (network/q_network.py:8-20)
+  int kind = 0, noisy = 1, dueling = 1, has_l = 1, has_av1 = 1, in1 = 0;
+  float* norm_partial = nullptr;
   int NA4 = 0, K4 = 0;
   ConvGeom c1{}, c2{}, c3{};
   int P1 = 0, P2 = 0, P3 = 0;  // output pixels per sample
@@ -662,8 +710,12 @@ static int launch_tgemm(jh_rbnet* net, const char* name, TGemm* probs, int n, hi
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
-static int rb_layout(jh_rbnet* n, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K, int32_t max_batch) {
-  JH_ARG(hidden > 0 && hidden % 4 == 0 && A > 0 && K > 1 && max_batch > 0 && c_or_s > 0);
+static int rb_layout(jh_rbnet* n, int32_t kind, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K,
+                     int32_t max_batch) {
+  JH_ARG(kind >= 0 && kind <= 2);
+  JH_ARG(hidden > 0 && hidden % 4 == 0 && A > 0 && max_batch > 0 && c_or_s > 0);
+  JH_ARG(kind == 0 ? K > 1 : K == 1);
+  n->kind = kind; n->noisy = kind == 0; n->dueling = kind != 2; n->has_l = kind != 1; n->has_av1 = kind != 2;
   n->cnn = head_cnn ? 1 : 0;
   n->Cin = c_or_s; n->Hin = h_in; n->Win = w_in; n->hidden = hidden; n->A = A; n->K = K; n->NA = A * K; n->maxB = max_batch;
   n->NA4 = (int)up4(n->NA); n->K4 = (int)up4(K);
@@ -686,10 +738,18 @@ static int rb_layout(jh_rbnet* n, int32_t head_cnn, int32_t c_or_s, int32_t h_in
   } else {
     seg(SEG_W1, H, c_or_s); seg(SEG_B1, 1, H);
   }
-  seg(SEG_WL, H, n->F); seg(SEG_BL, 1, H);
-  seg(SEG_MU_AV1, 2 * H, H); seg(SEG_SIG_AV1, 2 * H, H); seg(SEG_MUB_AV1, 1, 2 * H); seg(SEG_SIGB_AV1, 1, 2 * H);
-  seg(SEG_MU_A2, n->NA, H); seg(SEG_SIG_A2, n->NA, H); seg(SEG_MUB_A2, 1, n->NA); seg(SEG_SIGB_A2, 1, n->NA);
-  seg(SEG_MU_V2, K, H); seg(SEG_SIG_V2, K, H); seg(SEG_MUB_V2, 1, K); seg(SEG_SIGB_V2, 1, K);
+  n->in1 = n->has_l ? H : n->F;
+  if (n->has_l) { seg(SEG_WL, H, n->F); seg(SEG_BL, 1, H); }
+  if (n->has_av1) {
+    seg(SEG_MU_AV1, 2 * H, n->in1); seg(SEG_MUB_AV1, 1, 2 * H);
+    if (n->noisy) { seg(SEG_SIG_AV1, 2 * H, n->in1); seg(SEG_SIGB_AV1, 1, 2 * H); }
+  }
+  seg(SEG_MU_A2, n->NA, H); seg(SEG_MUB_A2, 1, n->NA);
+  if (n->noisy) { seg(SEG_SIG_A2, n->NA, H); seg(SEG_SIGB_A2, 1, n->NA); }
+  if (n->dueling) {
+    seg(SEG_MU_V2, K, H); seg(SEG_MUB_V2, 1, K);
+    if (n->noisy) { seg(SEG_SIG_V2, K, H); seg(SEG_SIGB_V2, 1, K); }
+  }
   int64_t off = 0;
   for (int i = 0; i < SEG_COUNT; ++i) {
     n->seg_off[i] = off;
@@ -713,19 +773,19 @@ static int rb_layout(jh_rbnet* n, int32_t head_cnn, int32_t c_or_s, int32_t h_in
   return JH_OK;
 }
 
-JH_EXPORT int64_t jh_rbnet_param_count_for(int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K) {
+JH_EXPORT int64_t jh_rbnet_param_count_for(int32_t kind, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K) {
   jh_rbnet tmp;
-  if (rb_layout(&tmp, head_cnn, c_or_s, h_in, w_in, hidden, A, K, 1)) return -1;
+  if (rb_layout(&tmp, kind, head_cnn, c_or_s, h_in, w_in, hidden, A, K, 1)) return -1;
   return tmp.n_params;
 }
 
-JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K,
+JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t kind, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K,
                               int32_t max_batch, float* d_params, float* d_target, float* d_grads, float* d_m, float* d_v, jh_rbnet** out) {
   JH_ARG(ctx && out && d_params && d_target && d_grads && d_m && d_v);
   JH_HIP(hipSetDevice(ctx->device));
   jh_rbnet* n = new jh_rbnet();
   n->ctx = ctx;
-  int rc = rb_layout(n, head_cnn, c_or_s, h_in, w_in, hidden, A, K, max_batch);
+  int rc = rb_layout(n, kind, head_cnn, c_or_s, h_in, w_in, hidden, A, K, max_batch);
   if (rc) {
     delete n;
     return rc;
@@ -736,6 +796,7 @@ JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t head_cnn, int32_t c_or_s, int
   const size_t B = (size_t)max_batch;
   auto A4 = [&](float** p, size_t floats, bool zero = true) { if (!rc) rc = rb_alloc(n, (void**)p, floats * sizeof(float), zero); };
   A4(&n->hyper, 8);
+  A4(&n->norm_partial, 256);
   if (!rc) rc = rb_alloc(n, (void**)&n->ticket, 16, true);
   A4(&n->weff, 3 * (size_t)d.set_stride);
   for (int s = 0; s < 2; ++s) {
@@ -816,14 +877,14 @@ JH_EXPORT int jh_rbnet_segment(const jh_rbnet* n, int32_t i, int64_t* offset, in
 }
 JH_EXPORT int64_t jh_rbnet_noise_len(const jh_rbnet* n) { return n ? n->nd.noise_len : -1; }
 
-JH_EXPORT int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1, float beta2, float eps, int64_t step, jh_stream stream) {
+JH_EXPORT int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1, float beta2, float eps, int64_t step, int32_t centered, jh_stream stream) {
   JH_ARG(n != nullptr);
   jh_pinned_slab* slab = nullptr;
   int rc = jh_ctx_slab(n->ctx, 32, &slab);
   if (rc) return rc;
   float* h = (float*)slab->host;
-  h[0] = lr; h[1] = beta1; h[2] = beta2; h[3] = eps; h[4] = (float)step;
-  JH_HIP(hipMemcpyAsync(n->hyper, slab->dev, 5 * sizeof(float), hipMemcpyDeviceToDevice, jh_s(stream)));
+  h[0] = lr; h[1] = beta1; h[2] = beta2; h[3] = eps; h[4] = (float)step; h[5] = centered ? 1.f : 0.f;
+  JH_HIP(hipMemcpyAsync(n->hyper, slab->dev, 6 * sizeof(float), hipMemcpyDeviceToDevice, jh_s(stream)));
   return jh_ctx_slab_release(n->ctx, slab, jh_s(stream));
 }
 JH_EXPORT int jh_rbnet_set_lr(jh_rbnet* n, float lr, jh_stream stream) {
@@ -882,12 +943,29 @@ static int rb_trunk(jh_rbnet* n, const TrunkJob* jobs, int nj, int x_u8, hipStre
     int rc = launch_tgemm(n, "jh_tgemm_head_fwd", g, nj, st);
     if (rc) return rc;
   }
+  if (!n->has_l) return JH_OK;  // dueling.py: the streams read the head's features directly
   for (int j = 0; j < nj; ++j) {
     const TrunkJob& J = jobs[j];
     g[j] = mk_gemm(J.rows, H, n->F, op_dense(OP_KCONT, n->feat[J.slot], n->F), op_dense(OP_KCONT, J.P + n->seg_off[SEG_WL], n->F), n->h[J.slot], H,
                    TEPI_BIAS_RELU, J.P + n->seg_off[SEG_BL]);
   }
   return launch_tgemm(n, "jh_tgemm_fc_fwd", g, nj, st);
+}
+
+// weights of the stream layers as the GEMMs see them: the materialised noisy set, or the parameters themselves
+struct StreamW {
+  const float *av1, *bav1, *a2, *ba2, *v2, *bv2;
+};
+static StreamW stream_w(const jh_rbnet* n, const float* P, int set) {
+  StreamW w{};
+  if (n->noisy) {
+    const float* W = n->weff + (size_t)set * n->nd.set_stride;
+    w.av1 = W + n->nd.o_av1; w.bav1 = W + n->nd.o_bav1; w.a2 = W + n->nd.o_a2; w.ba2 = W + n->nd.o_ba2; w.v2 = W + n->nd.o_v2; w.bv2 = W + n->nd.o_bv2;
+  } else {
+    w.av1 = P + n->seg_off[SEG_MU_AV1]; w.bav1 = P + n->seg_off[SEG_MUB_AV1]; w.a2 = P + n->seg_off[SEG_MU_A2]; w.ba2 = P + n->seg_off[SEG_MUB_A2];
+    w.v2 = P + n->seg_off[SEG_MU_V2]; w.bv2 = P + n->seg_off[SEG_MUB_V2];
+  }
+  return w;
 }
 
 // noisy dueling heads for up to three (parameter set, noise draw, hidden rows) triples -> logits
@@ -898,14 +976,14 @@ struct HeadJob {
   float* logits;   // [B][A][K]
 };
 static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t st) {
-  const int H = n->hidden, NA = n->NA, K = n->K;
+  const int H = n->hidden, NA = n->NA, K = n->K, in1 = n->in1;
   const NoisyDims& d = n->nd;
-  NoiseSets ns{};
-  ns.n_sets = nj;
-  for (int j = 0; j < nj; ++j) {
-    ns.params[j] = jobs[j].P; ns.noise[j] = jobs[j].noise; ns.weff[j] = n->weff + (size_t)j * d.set_stride;
-  }
-  {
+  if (n->noisy) {
+    NoiseSets ns{};
+    ns.n_sets = nj;
+    for (int j = 0; j < nj; ++j) {
+      ns.params[j] = jobs[j].P; ns.noise[j] = jobs[j].noise; ns.weff[j] = n->weff + (size_t)j * d.set_stride;
+    }
     int64_t blocks = (n->n_noisy + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     JH_LAUNCH(jh_rb_noise_kernel, dim3((unsigned)blocks, nj), dim3(256), 0, st, d, ns, n->n_noisy);
@@ -913,21 +991,28 @@ static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t
   }
   TGemm g[6];
   const size_t B_ = (size_t)n->maxB;
-  for (int j = 0; j < nj; ++j) {
-    const float* W = n->weff + (size_t)j * d.set_stride;
-    g[j] = mk_gemm(B, 2 * H, H, op_dense(OP_KCONT, jobs[j].h, H), op_dense(OP_KCONT, W + d.o_av1, H), n->hav + j * B_ * 2 * H, 2 * H, TEPI_BIAS_RELU,
-                   W + d.o_bav1);
+  int rc;
+  if (n->has_av1) {
+    for (int j = 0; j < nj; ++j) {
+      const StreamW w = stream_w(n, jobs[j].P, j);
+      g[j] = mk_gemm(B, 2 * H, in1, op_dense(OP_KCONT, jobs[j].h, in1), op_dense(OP_KCONT, w.av1, in1), n->hav + j * B_ * 2 * H, 2 * H, TEPI_BIAS_RELU, w.bav1);
+    }
+    rc = launch_tgemm(n, "jh_tgemm_stream1_fwd", g, nj, st);
+    if (rc) return rc;
   }
-  int rc = launch_tgemm(n, "jh_tgemm_noisy1_fwd", g, nj, st);
-  if (rc) return rc;
+  int ng = 0;
   for (int j = 0; j < nj; ++j) {
-    const float* W = n->weff + (size_t)j * d.set_stride;
-    const float* hav = n->hav + j * B_ * 2 * H;
-    g[2 * j] = mk_gemm(B, NA, H, op_dense(OP_KCONT, hav, 2 * H), op_dense(OP_KCONT, W + d.o_a2, H), n->xa + j * B_ * n->NA4, n->NA4, TEPI_BIAS, W + d.o_ba2);
-    g[2 * j + 1] = mk_gemm(B, K, H, op_dense(OP_KCONT, hav + H, 2 * H), op_dense(OP_KCONT, W + d.o_v2, H), n->xv + j * B_ * n->K4, n->K4, TEPI_BIAS, W + d.o_bv2);
+    const StreamW w = stream_w(n, jobs[j].P, j);
+    const float* in_a = n->has_av1 ? n->hav + j * B_ * 2 * H : jobs[j].h;  // q-network: the q layer reads h
+    const int ld_in = n->has_av1 ? 2 * H : H;
+    float* out_a = n->dueling ? n->xa + j * B_ * n->NA4 : jobs[j].logits;
+    g[ng++] = mk_gemm(B, NA, H, op_dense(OP_KCONT, in_a, ld_in), op_dense(OP_KCONT, w.a2, H), out_a, n->dueling ? n->NA4 : NA, TEPI_BIAS, w.ba2);
+    if (n->dueling)
+      g[ng++] = mk_gemm(B, K, H, op_dense(OP_KCONT, in_a + H, ld_in), op_dense(OP_KCONT, w.v2, H), n->xv + j * B_ * n->K4, n->K4, TEPI_BIAS, w.bv2);
   }
-  rc = launch_tgemm(n, "jh_tgemm_noisy2_fwd", g, 2 * nj, st);
+  rc = launch_tgemm(n, "jh_tgemm_stream2_fwd", g, ng, st);
   if (rc) return rc;
+  if (!n->dueling) return JH_OK;
   DuelSets ds{};
   for (int j = 0; j < nj; ++j) {
     ds.xa[j] = n->xa + j * B_ * n->NA4; ds.xv[j] = n->xv + j * B_ * n->K4; ds.out[j] = jobs[j].logits;
@@ -949,7 +1034,7 @@ JH_EXPORT int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int3
   TrunkJob tj{P, d_x, rows, 0};
   int rc = rb_trunk(n, &tj, 1, x_dtype == JH_U8, st);
   if (rc) return rc;
-  HeadJob hj{P, d_noise, n->h[0], d_logits};
+  HeadJob hj{P, n->noisy ? d_noise : nullptr, n->has_l ? n->h[0] : n->feat[0], d_logits};
   return rb_heads(n, &hj, 1, rows, st);
 }
 
@@ -958,7 +1043,8 @@ JH_EXPORT int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int3
 //   logits[0] = online(state; noise 0)   logits[1] = online(next_state; noise 1)   logits[2] = target(next_state; noise 2)
 // The online trunk runs once over all 2B rows; the target trunk shares the launches (grouped GEMMs).
 JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
-  JH_ARG(n && d_x && d_noise && d_logits);
+  JH_ARG(n && d_x && d_logits);
+  JH_ARG(d_noise || !n->noisy);
   JH_ARG(B > 0 && B <= n->maxB);
   JH_ARG(x_dtype == JH_U8 || x_dtype == JH_F32);
   hipStream_t st = jh_s(stream);
@@ -968,11 +1054,13 @@ JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dty
   TrunkJob tj[2] = {{n->params, d_x, 2 * B, 0}, {n->target, x_next, B, 1}};
   int rc = rb_trunk(n, tj, 2, x_dtype == JH_U8, st);
   if (rc) return rc;
-  const int64_t L = n->nd.noise_len;
+  const int64_t L = n->noisy ? n->nd.noise_len : 0;
   const size_t lsz = (size_t)B * n->NA;
-  HeadJob hj[3] = {{n->params, d_noise, n->h[0], d_logits},
-                   {n->params, d_noise + L, n->h[0] + (size_t)B * n->hidden, d_logits + lsz},
-                   {n->target, d_noise + 2 * L, n->h[1], d_logits + 2 * lsz}};
+  const float* nz = n->noisy ? d_noise : nullptr;
+  float* const* sin = n->has_l ? n->h : n->feat;  // what the streams read
+  HeadJob hj[3] = {{n->params, nz, sin[0], d_logits},
+                   {n->params, nz ? nz + L : nullptr, sin[0] + (size_t)B * n->in1, d_logits + lsz},
+                   {n->target, nz ? nz + 2 * L : nullptr, sin[1], d_logits + 2 * lsz}};
   rc = rb_heads(n, hj, 3, B, st);
   if (rc) return rc;
   n->last_x = d_x; n->last_x_u8 = x_dtype == JH_U8; n->last_B = B; n->last_noise = d_noise;
@@ -986,41 +1074,56 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
   JH_ARG(n && d_g);
   if (!n->last_x) return jh_fail(JH_ERR_STATE, "jh_rbnet_backward without a preceding jh_rbnet_learn_forward");
   hipStream_t st = jh_s(stream);
-  const int B = n->last_B, H = n->hidden, NA = n->NA, K = n->K, F = n->F;
-  const NoisyDims& d = n->nd;
-  const float* W0 = n->weff;  // noise set 0
+  const int B = n->last_B, H = n->hidden, NA = n->NA, K = n->K, F = n->F, in1 = n->in1;
+  const StreamW w0 = stream_w(n, n->params, 0);  // noise set 0 / the online parameters
   const float* hav0 = n->hav;
+  const float* sin0 = n->has_l ? n->h[0] : n->feat[0];  // input of the streams (rows of `state`)
+  float* dsin = n->has_l ? n->dh : n->dfeat;
   float* G = n->grads;
-  JH_LAUNCH(jh_rb_duel_bwd_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, d_g, B, n->A, K, n->dxa, n->NA4, n->dxv, n->K4);
-  JH_LAUNCH_CHECK();
+  const float* dxa = d_g;
+  int ld_dxa = NA;
+  if (n->dueling) {
+    JH_LAUNCH(jh_rb_duel_bwd_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, d_g, B, n->A, K, n->dxa, n->NA4, n->dxv, n->K4);
+    JH_LAUNCH_CHECK();
+    dxa = n->dxa;
+    ld_dxa = n->NA4;
+  }
   TGemm g[4];
-  // second noisy layer: weight gradients (+ bias gradients as row sums) and data gradients (+ relu')
-  g[0] = mk_gemm(NA, H, B, op_dense(OP_XCONT, n->dxa, n->NA4), op_dense(OP_XCONT, hav0, 2 * H), G + n->seg_off[SEG_MU_A2], H, TEPI_NONE, nullptr, nullptr, 0,
-                 G + n->seg_off[SEG_MUB_A2]);
-  g[1] = mk_gemm(K, H, B, op_dense(OP_XCONT, n->dxv, n->K4), op_dense(OP_XCONT, hav0 + H, 2 * H), G + n->seg_off[SEG_MU_V2], H, TEPI_NONE, nullptr, nullptr, 0,
-                 G + n->seg_off[SEG_MUB_V2]);
-  g[2] = mk_gemm(B, H, NA, op_dense(OP_KCONT, n->dxa, n->NA4), op_dense(OP_XCONT, W0 + d.o_a2, H), n->dhav, 2 * H, TEPI_MASK, nullptr, hav0, 2 * H);
-  g[3] = mk_gemm(B, H, K, op_dense(OP_KCONT, n->dxv, n->K4), op_dense(OP_XCONT, W0 + d.o_v2, H), n->dhav + H, 2 * H, TEPI_MASK, nullptr, hav0 + H, 2 * H);
-  int rc = launch_tgemm(n, "jh_tgemm_noisy2_bwd", g, 4, st);
+  int ng = 0, rc;
+  // last stream layer(s): weight gradients (+ bias gradients as row sums) and data gradients (+ relu')
+  const float* in_a = n->has_av1 ? hav0 : sin0;
+  const int ld_in = n->has_av1 ? 2 * H : H;
+  float* d_in = n->has_av1 ? n->dhav : dsin;
+  g[ng++] = mk_gemm(NA, H, B, op_dense(OP_XCONT, dxa, ld_dxa), op_dense(OP_XCONT, in_a, ld_in), G + n->seg_off[SEG_MU_A2], H, TEPI_NONE, nullptr, nullptr, 0,
+                    G + n->seg_off[SEG_MUB_A2]);
+  g[ng++] = mk_gemm(B, H, NA, op_dense(OP_KCONT, dxa, ld_dxa), op_dense(OP_XCONT, w0.a2, H), d_in, ld_in, TEPI_MASK, nullptr, in_a, ld_in);
+  if (n->dueling) {
+    g[ng++] = mk_gemm(K, H, B, op_dense(OP_XCONT, n->dxv, n->K4), op_dense(OP_XCONT, in_a + H, ld_in), G + n->seg_off[SEG_MU_V2], H, TEPI_NONE, nullptr, nullptr, 0,
+                      G + n->seg_off[SEG_MUB_V2]);
+    g[ng++] = mk_gemm(B, H, K, op_dense(OP_KCONT, n->dxv, n->K4), op_dense(OP_XCONT, w0.v2, H), d_in + H, ld_in, TEPI_MASK, nullptr, in_a + H, ld_in);
+  }
+  rc = launch_tgemm(n, "jh_tgemm_stream2_bwd", g, ng, st);
   if (rc) return rc;
-  // first noisy layer (a1 | v1 stacked)
-  g[0] = mk_gemm(2 * H, H, B, op_dense(OP_XCONT, n->dhav, 2 * H), op_dense(OP_XCONT, n->h[0], H), G + n->seg_off[SEG_MU_AV1], H, TEPI_NONE, nullptr, nullptr, 0,
-                 G + n->seg_off[SEG_MUB_AV1]);
-  g[1] = mk_gemm(B, H, 2 * H, op_dense(OP_KCONT, n->dhav, 2 * H), op_dense(OP_XCONT, W0 + d.o_av1, H), n->dh, H, TEPI_MASK, nullptr, n->h[0], H);
-  rc = launch_tgemm(n, "jh_tgemm_noisy1_bwd", g, 2, st);
-  if (rc) return rc;
-  {
+  if (n->has_av1) {  // first stream layer (a1 | v1 stacked)
+    g[0] = mk_gemm(2 * H, in1, B, op_dense(OP_XCONT, n->dhav, 2 * H), op_dense(OP_XCONT, sin0, in1), G + n->seg_off[SEG_MU_AV1], in1, TEPI_NONE, nullptr, nullptr, 0,
+                   G + n->seg_off[SEG_MUB_AV1]);
+    g[1] = mk_gemm(B, in1, 2 * H, op_dense(OP_KCONT, n->dhav, 2 * H), op_dense(OP_XCONT, w0.av1, in1), dsin, in1, TEPI_MASK, nullptr, sin0, in1);
+    rc = launch_tgemm(n, "jh_tgemm_stream1_bwd", g, 2, st);
+    if (rc) return rc;
+  }
+  if (n->noisy) {
     int64_t blocks = (n->n_noisy + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    JH_LAUNCH(jh_rb_noisy_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, n->last_noise, G, n->n_noisy);
+    JH_LAUNCH(jh_rb_noisy_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n->nd, n->last_noise, G, n->n_noisy);
     JH_LAUNCH_CHECK();
   }
-  // l: F -> H
-  g[0] = mk_gemm(H, F, B, op_dense(OP_XCONT, n->dh, H), op_dense(OP_XCONT, n->feat[0], F), G + n->seg_off[SEG_WL], F, TEPI_NONE, nullptr, nullptr, 0,
-                 G + n->seg_off[SEG_BL]);
-  g[1] = mk_gemm(B, F, H, op_dense(OP_KCONT, n->dh, H), op_dense(OP_XCONT, n->params + n->seg_off[SEG_WL], F), n->dfeat, F, TEPI_MASK, nullptr, n->feat[0], F);
-  rc = launch_tgemm(n, "jh_tgemm_fc_bwd", g, 2, st);
-  if (rc) return rc;
+  if (n->has_l) {  // l: F -> H
+    g[0] = mk_gemm(H, F, B, op_dense(OP_XCONT, n->dh, H), op_dense(OP_XCONT, n->feat[0], F), G + n->seg_off[SEG_WL], F, TEPI_NONE, nullptr, nullptr, 0,
+                   G + n->seg_off[SEG_BL]);
+    g[1] = mk_gemm(B, F, H, op_dense(OP_KCONT, n->dh, H), op_dense(OP_XCONT, n->params + n->seg_off[SEG_WL], F), n->dfeat, F, TEPI_MASK, nullptr, n->feat[0], F);
+    rc = launch_tgemm(n, "jh_tgemm_fc_bwd", g, 2, st);
+    if (rc) return rc;
+  }
   if (!n->cnn) {
     g[0] = mk_gemm(H, n->Cin, B, op_dense(OP_XCONT, n->dfeat, H), op_dense(OP_XCONT, (const float*)n->last_x, n->Cin), G + n->seg_off[SEG_W1], n->Cin, TEPI_NONE,
                    nullptr, nullptr, 0, G + n->seg_off[SEG_B1]);
@@ -1054,9 +1157,21 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
   return launch_tgemm(n, "jh_tgemm_conv1_bwd", g, 1, st);
 }
 
-JH_EXPORT int jh_rbnet_adam_step(jh_rbnet* n, jh_stream stream) {
+JH_EXPORT int jh_rbnet_optim_step(jh_rbnet* n, int32_t optimizer, float max_norm, jh_stream stream) {
   JH_ARG(n != nullptr);
-  JH_LAUNCH(jh_rb_adam_kernel, dim3(512), dim3(256), 0, jh_s(stream), n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket);
+  JH_ARG(optimizer == 0 || optimizer == 1);
+  hipStream_t st = jh_s(stream);
+  if (max_norm > 0.f) {
+    JH_LAUNCH(jh_rb_gradnorm_kernel, dim3(256), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial);
+    JH_LAUNCH_CHECK();
+  }
+  if (optimizer == 0) {
+    JH_LAUNCH(jh_rb_optim_kernel<0>, dim3(512), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
+  } else {
+    JH_LAUNCH(jh_rb_optim_kernel<1>, dim3(512), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
+  }
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
+
+JH_EXPORT int jh_rbnet_adam_step(jh_rbnet* n, jh_stream stream) { return jh_rbnet_optim_step(n, 0, 0.f, stream); }

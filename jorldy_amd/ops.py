@@ -502,36 +502,41 @@ class CartPoleVec:
 
 
 class RainbowNet:
-    """jh_rbnet_*: the Rainbow network (MLP or Nature-CNN head -> Linear -> noisy dueling categorical
-    heads) with its three learn() forwards, backward and Adam as grouped MFMA GEMM launches.
+    """jh_rbnet_*: the value networks of the DQN / Rainbow / Ape-X family -- kind "rainbow" (MLP or Nature-CNN
+    head -> Linear -> noisy dueling categorical heads), "dueling" (head -> l1_a|l1_v -> l2_a, l2_v) and "q"
+    (head -> l -> q) -- with the three learn() forwards, backward and the optimizer step as grouped MFMA GEMM
+    launches.
 
-    Parameters live in flat fp32 buckets in the library's private layout; `export_state` /
-    `import_state` convert to and from the reference's `state_dict` (network/rainbow.py:8-94 key
-    names, shapes and order), so checkpoints and sync_in / sync_out payloads interchange."""
+    Parameters live in flat fp32 buckets in the library's private layout; `export_state` / `import_state`
+    convert to and from the reference's `state_dict` (network/{rainbow,dueling,q_network}.py key names, shapes
+    and order), so checkpoints and sync_in / sync_out payloads interchange."""
 
     _SEG = ("w1", "b1", "w2", "b2", "w3", "b3", "wl", "bl", "mu_av1", "sig_av1", "mub_av1", "sigb_av1", "mu_a2", "sig_a2", "mub_a2", "sigb_a2",
             "mu_v2", "sig_v2", "mub_v2", "sigb_v2")
+    _KIND = {"rainbow": 0, "dueling": 1, "q": 2}
 
-    def __init__(self, state_size, action_size, num_support, hidden, head, max_batch, device):
+    def __init__(self, state_size, action_size, num_support, hidden, head, max_batch, device, kind="rainbow"):
         self.lib = L.load()
         self.device = torch.device(device)
         self.ctx = L.ctx(self.device.index)
+        self.kind = kind
         self.cnn = head == "cnn"
         if self.cnn:
             self.Cin, self.Hin, self.Win = (int(v) for v in state_size)
         else:
             self.Cin, self.Hin, self.Win = int(state_size), 0, 0
         self.H, self.A, self.K, self.maxB = int(hidden), int(action_size), int(num_support), int(max_batch)
-        n = int(self.lib.jh_rbnet_param_count_for(int(self.cnn), self.Cin, self.Hin, self.Win, self.H, self.A, self.K))
+        kid = self._KIND[kind]
+        n = int(self.lib.jh_rbnet_param_count_for(kid, int(self.cnn), self.Cin, self.Hin, self.Win, self.H, self.A, self.K))
         if n <= 0:
             L.check(-2)
         self.n_params = n
         mk = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
         self.params, self.target, self.grads, self.m, self.v = mk(), mk(), mk(), mk(), mk()
         self.h = C.c_void_p()
-        L.check(self.lib.jh_rbnet_create(self.ctx, int(self.cnn), self.Cin, self.Hin, self.Win, self.H, self.A, self.K, self.maxB, L.ptr(self.params),
+        L.check(self.lib.jh_rbnet_create(self.ctx, kid, int(self.cnn), self.Cin, self.Hin, self.Win, self.H, self.A, self.K, self.maxB, L.ptr(self.params),
                                          L.ptr(self.target), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), C.byref(self.h)))
-        self.noise_len = int(self.lib.jh_rbnet_noise_len(self.h))
+        self.noise_len = int(self.lib.jh_rbnet_noise_len(self.h)) if kind == "rainbow" else 0
         self.seg = {}
         for i, name in enumerate(self._SEG):
             off, rows, cols = C.c_int64(), C.c_int32(), C.c_int32()
@@ -555,32 +560,46 @@ class RainbowNet:
         off, rows, cols = self.seg[name]
         return bucket[off : off + rows * cols].view(rows, cols)
 
+    def _feat_cols(self, w):
+        """[R][F] weight that reads the head's features: the CNN head's features are (y, x, c) here and
+        (c, y, x) in the reference -> a 4-D [R][c][y][x] view (export reshapes it, import views the source)."""
+        return w.view(w.shape[0], self.d3[0], self.d3[1], 64).permute(0, 3, 1, 2) if self.cnn else w
+
     def _pairs(self, bucket):
-        """[(reference key, view of the bucket shaped/strided like the reference tensor)].  Every
-        entry is a VIEW (possibly transposed / permuted) except l.weight of the CNN head, which is
-        returned as a 4-D permuted view that the caller reshapes (copy)."""
+        """[(reference key, view of the bucket shaped / strided like the reference tensor)] in the order of
+        the reference module's state_dict (own parameters first, then sub-modules in registration order)."""
         H = self.H
-        out = []  # nn.Module.state_dict order: the module's own parameters first, then head.*, then l.*
-        av1 = {k: self._v(bucket, f"{k}_av1") for k in ("mu", "sig")}
-        bav1 = {k: self._v(bucket, f"{k}b_av1").view(-1) for k in ("mu", "sig")}
-        for tag, sl in (("a1", slice(0, H)), ("v1", slice(H, 2 * H))):
-            out += [(f"mu_w_{tag}", av1["mu"][sl].t()), (f"sig_w_{tag}", av1["sig"][sl].t()), (f"mu_b_{tag}", bav1["mu"][sl]), (f"sig_b_{tag}", bav1["sig"][sl])]
-        for tag in ("a2", "v2"):
-            out += [(f"mu_w_{tag}", self._v(bucket, f"mu_{tag}").t()), (f"sig_w_{tag}", self._v(bucket, f"sig_{tag}").t()),
-                    (f"mu_b_{tag}", self._v(bucket, f"mub_{tag}").view(-1)), (f"sig_b_{tag}", self._v(bucket, f"sigb_{tag}").view(-1))]
+        out, head = [], []
         if self.cnn:
-            out.append(("head.conv1.weight", self._v(bucket, "w1").view(32, self.Cin, 8, 8)))
-            out.append(("head.conv1.bias", self._v(bucket, "b1").view(-1)))
-            out.append(("head.conv2.weight", self._v(bucket, "w2").view(64, 4, 4, 32).permute(0, 3, 1, 2)))
-            out.append(("head.conv2.bias", self._v(bucket, "b2").view(-1)))
-            out.append(("head.conv3.weight", self._v(bucket, "w3").view(64, 3, 3, 64).permute(0, 3, 1, 2)))
-            out.append(("head.conv3.bias", self._v(bucket, "b3").view(-1)))
-            out.append(("l.weight", self._v(bucket, "wl").view(H, self.d3[0], self.d3[1], 64).permute(0, 3, 1, 2)))  # [H][c][y][x]
+            head.append(("head.conv1.weight", self._v(bucket, "w1").view(32, self.Cin, 8, 8)))
+            head.append(("head.conv1.bias", self._v(bucket, "b1").view(-1)))
+            head.append(("head.conv2.weight", self._v(bucket, "w2").view(64, 4, 4, 32).permute(0, 3, 1, 2)))
+            head.append(("head.conv2.bias", self._v(bucket, "b2").view(-1)))
+            head.append(("head.conv3.weight", self._v(bucket, "w3").view(64, 3, 3, 64).permute(0, 3, 1, 2)))
+            head.append(("head.conv3.bias", self._v(bucket, "b3").view(-1)))
         else:
-            out.append(("head.l.weight", self._v(bucket, "w1")))
-            out.append(("head.l.bias", self._v(bucket, "b1").view(-1)))
-            out.append(("l.weight", self._v(bucket, "wl")))
-        out.append(("l.bias", self._v(bucket, "bl").view(-1)))
+            head.append(("head.l.weight", self._v(bucket, "w1")))
+            head.append(("head.l.bias", self._v(bucket, "b1").view(-1)))
+        if self.kind == "rainbow":
+            av1 = {k: self._v(bucket, f"{k}_av1") for k in ("mu", "sig")}
+            bav1 = {k: self._v(bucket, f"{k}b_av1").view(-1) for k in ("mu", "sig")}
+            for tag, sl in (("a1", slice(0, H)), ("v1", slice(H, 2 * H))):
+                out += [(f"mu_w_{tag}", av1["mu"][sl].t()), (f"sig_w_{tag}", av1["sig"][sl].t()), (f"mu_b_{tag}", bav1["mu"][sl]), (f"sig_b_{tag}", bav1["sig"][sl])]
+            for tag in ("a2", "v2"):
+                out += [(f"mu_w_{tag}", self._v(bucket, f"mu_{tag}").t()), (f"sig_w_{tag}", self._v(bucket, f"sig_{tag}").t()),
+                        (f"mu_b_{tag}", self._v(bucket, f"mub_{tag}").view(-1)), (f"sig_b_{tag}", self._v(bucket, f"sigb_{tag}").view(-1))]
+            out += head
+            out += [("l.weight", self._feat_cols(self._v(bucket, "wl"))), ("l.bias", self._v(bucket, "bl").view(-1))]
+        elif self.kind == "dueling":
+            av1, bav1 = self._v(bucket, "mu_av1"), self._v(bucket, "mub_av1").view(-1)
+            out += head
+            out += [("l1_a.weight", self._feat_cols(av1[:H])), ("l1_a.bias", bav1[:H]), ("l1_v.weight", self._feat_cols(av1[H:])), ("l1_v.bias", bav1[H:]),
+                    ("l2_a.weight", self._v(bucket, "mu_a2")), ("l2_a.bias", self._v(bucket, "mub_a2").view(-1)),
+                    ("l2_v.weight", self._v(bucket, "mu_v2")), ("l2_v.bias", self._v(bucket, "mub_v2").view(-1))]
+        else:
+            out += head
+            out += [("l.weight", self._feat_cols(self._v(bucket, "wl"))), ("l.bias", self._v(bucket, "bl").view(-1)),
+                    ("q.weight", self._v(bucket, "mu_a2")), ("q.bias", self._v(bucket, "mub_a2").view(-1))]
         return out
 
     def export_state(self, bucket=None):
@@ -589,7 +608,7 @@ class RainbowNet:
         bucket = self.params if bucket is None else bucket
         sd = OrderedDict()
         for k, v in self._pairs(bucket):
-            sd[k] = (v.reshape(self.H, -1) if (k == "l.weight" and v.dim() == 4) else v).clone(memory_format=torch.contiguous_format)
+            sd[k] = (v.reshape(v.shape[0], -1) if (v.dim() == 4 and not k.startswith("head.")) else v).clone(memory_format=torch.contiguous_format)
         return sd
 
     @torch.no_grad()
@@ -601,15 +620,16 @@ class RainbowNet:
             raise KeyError(f"state_dict is missing {missing}")
         for k, v in pairs.items():
             src = torch.as_tensor(sd[k]).to(self.device, torch.float32)
-            if k == "l.weight" and v.dim() == 4:
-                src = src.view(self.H, 64, self.d3[0], self.d3[1])
+            if v.dim() == 4 and not k.startswith("head."):
+                src = src.view(v.shape[0], 64, self.d3[0], self.d3[1])
             if tuple(src.shape) != tuple(v.shape):
                 raise ValueError(f"{k}: expected {tuple(v.shape)}, got {tuple(src.shape)}")
             v.copy_(src)
 
     # ---- engine ---------------------------------------------------------------------------------
-    def set_hyper(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=0):
-        L.check(self.lib.jh_rbnet_set_hyper(self.h, float(lr), float(beta1), float(beta2), float(eps), int(step), L.stream_ptr()))
+    def set_hyper(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=0, centered=False):
+        """Adam: (lr, beta1, beta2, eps); RMSprop: (lr, alpha -> beta1, -, eps, centered)."""
+        L.check(self.lib.jh_rbnet_set_hyper(self.h, float(lr), float(beta1), float(beta2), float(eps), int(step), int(bool(centered)), L.stream_ptr()))
 
     def set_lr(self, lr):
         L.check(self.lib.jh_rbnet_set_lr(self.h, float(lr), L.stream_ptr()))
@@ -634,8 +654,8 @@ class RainbowNet:
         return out
 
     def learn_forward(self, x_all, B, noise, out):
-        """x_all = [state; next_state] (2B rows), noise [3, noise_len] -> out [3, B, A, K]."""
-        assert x_all.is_contiguous() and noise.is_contiguous() and out.is_contiguous() and int(x_all.shape[0]) == 2 * B
+        """x_all = [state; next_state] (2B rows), noise [3, noise_len] (rainbow; else None) -> out [3, B, A, K]."""
+        assert x_all.is_contiguous() and (noise is None or noise.is_contiguous()) and out.is_contiguous() and int(x_all.shape[0]) == 2 * B
         L.check(self.lib.jh_rbnet_learn_forward(self.h, L.ptr(x_all), self._xdt(x_all), int(B), L.ptr(noise), L.ptr(out), L.stream_ptr()))
         return out
 
@@ -645,3 +665,7 @@ class RainbowNet:
 
     def adam_step(self):
         L.check(self.lib.jh_rbnet_adam_step(self.h, L.stream_ptr()))
+
+    def optim_step(self, optimizer="adam", max_norm=None):
+        """[clip_grad_norm_(max_norm)] + optimizer.step(); optimizer in {"adam", "rmsprop"}."""
+        L.check(self.lib.jh_rbnet_optim_step(self.h, {"adam": 0, "rmsprop": 1}[optimizer], float(max_norm or 0.0), L.stream_ptr()))
