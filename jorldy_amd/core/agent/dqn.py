@@ -9,12 +9,18 @@ from ..buffer import PERBuffer, ReplayBuffer
 from ..network import Network
 from ..optimizer import Optimizer
 from .base import BaseAgent
+from .native_net import NativeValueNetMixin, native_supported
 
 
-class DQN(BaseAgent):
+class DQN(NativeValueNetMixin, BaseAgent):
     """core/agent/dqn.py:14-203.  learn(): uniform sample (same numpy draw as the reference) ->
     fused gather -> Q(s), Q_target(s') -> jh_td_loss (target, Huber, dQ) -> backward -> Adam.
-    One host sync per learn (loss/max_Q read-back), not three."""
+    One host sync per learn (loss/max_Q read-back), not three.
+
+    backend="native" (default when the configuration allows it: discrete_q_network / dueling with an mlp / cnn
+    head, Adam or RMSprop): the network, its backward and the optimizer step run on libjorldy_hip
+    (ops.RainbowNet, jh_rbnet_*); backend="torch": PyTorch mirror modules around the same HIP loss kernels.
+    Either way learn() is replayed as one hipGraph."""
 
     action_type = "discrete"
     _td = dict(double=False, per=False, n_step=0)
@@ -22,17 +28,27 @@ class DQN(BaseAgent):
     def __init__(self, state_size, action_size, hidden_size=512, optim_config={"name": "adam"},
                  network="discrete_q_network", head="mlp", gamma=0.99, epsilon_init=1.0, epsilon_min=0.1,
                  epsilon_eval=0.0, explore_ratio=0.1, buffer_size=50000, batch_size=64, start_train_step=2000,
-                 target_update_period=500, device=None, run_step=1e6, num_workers=1, lr_decay=True, use_graph=True, **kwargs):
+                 target_update_period=500, device=None, run_step=1e6, num_workers=1, lr_decay=True, use_graph=True, backend=None,
+                 **kwargs):
         self.device = self._require_gpu(device)
         self.use_graph = use_graph
         self.grad_sync = None  # data-parallel hook (jorldy_amd.parallel.attach_data_parallel)
         self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
         self.action_size = action_size
         self.action_type = "discrete"
-        self.network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
-        self.target_network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
-        self.target_network.load_state_dict(self.network.state_dict())
-        self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
+        can_native = native_supported(network, head, state_size, hidden_size, optim_config)
+        self.backend = backend or ("native" if can_native else "torch")
+        assert self.backend in ("native", "torch")
+        if self.backend == "native" and not can_native:
+            raise ValueError("backend='native' needs a discrete_q_network / dueling network, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam / RMSprop")
+        mk = lambda: Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
+        self._net = None
+        if self.backend == "native":
+            self._init_native(network, state_size, action_size, 1, hidden_size, head, batch_size, optim_config, mk())
+        else:
+            self.network, self.target_network = mk(), mk()
+            self.target_network.load_state_dict(self.network.state_dict())
+            self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
         self.gamma = gamma
         self.epsilon = epsilon_init
         self.epsilon_init = epsilon_init
@@ -89,6 +105,8 @@ class DQN(BaseAgent):
         return Optimizer(**cfg, params=params)
 
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
+        if self._net is not None:
+            return self._native_lr_decay(step, mode)
         if self._lr0 is None:
             return super().learning_rate_decay(step, optimizers, mode)
         weight = {"linear": 1 - (step / self.run_step), "cosine": np.cos((np.pi / 2) * (step / self.run_step)),
@@ -98,6 +116,8 @@ class DQN(BaseAgent):
 
     def _alloc_static(self):
         """Fixed-address buffers of one learn(): sampled indices / weights and the gathered batch."""
+        if self._net is not None:
+            return self._alloc_static_native()
         B = self.batch_size
         idx = torch.zeros(B, dtype=torch.int64, device=self.device)
         probe = self.memory.gather(idx, idx_offset=0)  # shapes / keys of a gathered batch
@@ -113,7 +133,24 @@ class DQN(BaseAgent):
     def _idx_offset(self):
         return 0
 
+    def _learn_body_native(self, st):
+        net, B, A = self._net, self.batch_size, self.action_size
+        tr = self.memory.gather(st["idx"], idx_offset=self._idx_offset(), as_float=self._as_float(), out=st["tr"])
+        lg = net.learn_forward(st["x_all"], B, None, st["logits"])  # online(s), online(s'), target(s') in shared launches
+        q, next_q, next_target_q = lg[0].view(B, A), lg[1].view(B, A), lg[2].view(B, A)
+        g, prio, _ = ops.td_loss(q, next_target_q, tr["action"], tr["reward"], tr["done"], self.gamma, q_next_online=next_q if self._td["double"] else None,
+                                 weights=st["w"] if self._td["per"] else None, alpha=getattr(self, "alpha", 0.0),
+                                 n_step=self._td["n_step"] and self.n_step, stats=self._stats)
+        if self._td["per"]:
+            self.memory.update_priorities(st["idx"], prio)
+        net.backward(g)
+        if self.grad_sync is not None:  # data-parallel learners: one all-reduce of the flat gradient bucket
+            self.grad_sync.reduce_flat(net.grads)
+        net.optim_step(self._opt_name, self.clip_grad_norm)
+
     def _learn_body(self, st):
+        if self._net is not None:
+            return self._learn_body_native(st)
         tr = self.memory.gather(st["idx"], idx_offset=self._idx_offset(), out=st["tr"])
         state, action, reward = tr["state"], tr["action"], tr["reward"]
         next_state, done = tr["next_state"], tr["done"]
@@ -161,6 +198,8 @@ class DQN(BaseAgent):
             self._learn_body(st)
             self._warm = True
         self.num_learn += 1
+        if self._net is not None:
+            self._adam_steps += 1
         return extra
 
     def learn(self):
@@ -173,6 +212,8 @@ class DQN(BaseAgent):
         return result
 
     def update_target(self):
+        if self._net is not None:
+            return self._net.sync_target()
         self.target_network.load_state_dict(self.network.state_dict())
 
     def _store(self, transitions):
@@ -230,10 +271,14 @@ class DQN(BaseAgent):
         self._graph = None  # optimizer tensors were replaced: re-capture
 
     def save(self, path):
+        if self._net is not None:
+            return self._native_save(path)
         print(f"...Save model to {path}...")
         torch.save({"network": self.network.state_dict(), "optimizer": self._portable_optim_state()}, os.path.join(path, "ckpt"))
 
     def load(self, path):
+        if self._net is not None:
+            return self._native_load(path)
         print(f"...Load model from {path}...")
         checkpoint = torch.load(os.path.join(path, "ckpt"), map_location=self.device, weights_only=False)
         self.network.load_state_dict(checkpoint["network"])

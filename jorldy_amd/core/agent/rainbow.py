@@ -9,6 +9,7 @@ from ..buffer import PERBuffer
 from ..network import Network
 from ..optimizer import Optimizer
 from .dqn import DQN
+from .native_net import native_supported
 
 
 class C51(DQN):
@@ -42,8 +43,19 @@ class C51(DQN):
         return {"action": action}
 
     def _learn_body(self, st):
-        tr = self.memory.gather(st["idx"], out=st["tr"])
         B, A, K = self.batch_size, self.action_size, self.num_support
+        if self._net is not None:  # q-network with A*K outputs on the native engine
+            net = self._net
+            tr = self.memory.gather(st["idx"], as_float=self._as_float(), out=st["tr"])
+            lg = net.learn_forward(st["x_all"], B, None, st["logits"])
+            g, _, _, _ = ops.c51_loss(lg[0].view(B, A, K), lg[2].view(B, A, K), tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max, self.gamma,
+                                      shift_max=True, stats=self._stats8)
+            net.backward(g.view(B, A * K))
+            if self.grad_sync is not None:
+                self.grad_sync.reduce_flat(net.grads)
+            net.optim_step(self._opt_name, self.clip_grad_norm)
+            return
+        tr = self.memory.gather(st["idx"], out=st["tr"])
         logit = self.network(tr["state"])
         with torch.no_grad():
             target_logit = self.target_network(tr["next_state"])
@@ -59,55 +71,6 @@ class C51(DQN):
         self._run_learn()
         s = self._stats8.cpu().numpy()
         return {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3])}
-
-
-class _NativeNet:
-    """What the agent code expects from `agent.network` / `agent.target_network` (an nn.Module) on top of
-    ops.RainbowNet's flat buckets: state_dict in the reference's keys / shapes, callable forward."""
-
-    def __init__(self, net, which):
-        self._net, self._which, self.training = net, which, True
-
-    def _bucket(self):
-        return self._net.params if self._which == 0 else self._net.target
-
-    def state_dict(self):
-        return self._net.export_state(self._bucket())
-
-    def load_state_dict(self, sd, strict=True):
-        self._net.import_state(sd, self._bucket())
-
-    def parameters(self):
-        return list(self.state_dict().values())
-
-    def named_parameters(self):
-        return list(self.state_dict().items())
-
-    def train(self, mode=True):
-        self.training = mode
-        return self
-
-    def eval(self):
-        return self.train(False)
-
-    def pack_noise(self, noise, out=None):
-        """{tag: (e_in, e_out)} (the torch mirror's injection format) -> one flat noise set."""
-        flat = torch.cat([torch.cat([noise[t][0].reshape(-1), noise[t][1].reshape(-1)]) for t in ("a1", "v1", "a2", "v2")]).to(self._net.device, torch.float32)
-        assert flat.numel() == self._net.noise_len
-        if out is not None:
-            out.copy_(flat)
-            return out
-        return flat
-
-    @torch.no_grad()
-    def __call__(self, x, is_train, noise=None):
-        net = self._net
-        x = x.contiguous()
-        nz = None
-        if is_train:
-            nz = self.pack_noise(noise) if noise is not None else torch.randn(net.noise_len, device=net.device)
-        outs = [net.forward(x[o : o + net.maxB], self._which, nz) for o in range(0, x.shape[0], net.maxB)]  # one draw per call, like the reference
-        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 class Rainbow(DQN):
@@ -135,27 +98,15 @@ class Rainbow(DQN):
         self._td = dict(double=True, per=True, n_step=1)
         self.action_size = action_size
         self.action_type = "discrete"
-        can_native = (network == "rainbow" and noise_type == "factorized" and head in ("mlp", "cnn") and hidden_size % 4 == 0
-                      and ((head == "mlp" and np.isscalar(state_size))
-                           or (head == "cnn" and not np.isscalar(state_size) and len(state_size) == 3 and all(np.isscalar(v) for v in state_size)))
-                      and optim_config.get("name", "adam").lower() == "adam"
-                      and set(optim_config) <= {"name", "lr", "betas", "eps"})
+        can_native = native_supported(network, head, state_size, hidden_size, optim_config, noise_type)
         self.backend = backend or ("native" if can_native else "torch")
         assert self.backend in ("native", "torch")
         if self.backend == "native" and not can_native:
-            raise ValueError("backend='native' needs network='rainbow', factorized noise, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam")
+            raise ValueError("backend='native' needs network='rainbow', factorized noise, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam / RMSprop")
         mk = lambda: Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head).to(self.device)
         self._net = None
         if self.backend == "native":
-            self._net = ops.RainbowNet(state_size, action_size, num_support, hidden_size, head, batch_size, self.device)
-            self._net.import_state(mk().state_dict())  # the reference's initialisation (orthogonal / uniform, utils.py:89-124)
-            self._net.sync_target()
-            self.network, self.target_network = _NativeNet(self._net, 0), _NativeNet(self._net, 1)
-            self._optim_config = dict(optim_config)
-            d = Optimizer(**optim_config, params=[torch.nn.Parameter(torch.zeros(1))]).defaults
-            self._lr0, self._lr_now, self._adam_steps = float(d["lr"]), float(d["lr"]), 0
-            self._net.set_hyper(d["lr"], d["betas"][0], d["betas"][1], d["eps"], 0)
-            self.optimizer = None
+            self._init_native(network, state_size, action_size, num_support, hidden_size, head, batch_size, optim_config, mk())
         else:
             self.network, self.target_network = mk(), mk()
             self.target_network.load_state_dict(self.network.state_dict())
@@ -209,24 +160,7 @@ class Rainbow(DQN):
     def _idx_offset(self):
         return self.memory.first_leaf_index
 
-    # ---- native backend ---------------------------------------------------------------------
-    def _as_float(self):
-        # frames stay uint8 until the first convolution's operand fetch; everything else fp32 (as_tensor)
-        return {"state": False, "next_state": False} if (self._net is not None and self._net.cnn) else True
-
-    def _alloc_static(self):
-        if self._net is None:
-            return super()._alloc_static()
-        B = self.batch_size
-        idx = torch.zeros(B, dtype=torch.int64, device=self.device)
-        probe = self.memory.gather(idx, idx_offset=0, as_float=self._as_float())
-        x_all = torch.empty((2 * B,) + tuple(probe["state"].shape[1:]), dtype=probe["state"].dtype, device=self.device)
-        tr = dict(probe)
-        tr["state"], tr["next_state"] = x_all[:B], x_all[B:]  # one contiguous [state; next_state] batch
-        return dict(idx=idx, w=torch.ones(B, dtype=torch.float32, device=self.device), tr=tr, store=self.memory._store, x_all=x_all,
-                    noise=torch.zeros(3, self._net.noise_len, dtype=torch.float32, device=self.device),
-                    logits=torch.empty(3, B, self.action_size, self.num_support, dtype=torch.float32, device=self.device))
-
+    # ---- native backend (plumbing: native_net.NativeValueNetMixin via DQN) -------------------
     def _learn_body_native(self, st):
         net, B = self._net, self.batch_size
         tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, as_float=self._as_float(), out=st["tr"])
@@ -242,66 +176,7 @@ class Rainbow(DQN):
         net.backward(g)
         if self.grad_sync is not None:  # data-parallel learners: one all-reduce of the flat gradient bucket
             self.grad_sync.reduce_flat(net.grads)
-        net.adam_step()
-
-    def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
-        if self._net is None:
-            return super().learning_rate_decay(step, optimizers, mode)
-        weight = {"linear": 1 - (step / self.run_step), "cosine": np.cos((np.pi / 2) * (step / self.run_step)),
-                  "sqrt": max(1 - (step / self.run_step), 0.0) ** 0.5}[mode]
-        self._lr_now = self._lr0 * float(weight)
-        self._net.set_lr(self._lr_now)  # a device scalar: the captured graph reads it
-
-    def update_target(self):
-        if self._net is None:
-            return super().update_target()
-        self._net.sync_target()
-
-    def _shadow_optimizer(self):
-        """torch.optim.Adam over copies of the parameters carrying the native moments: the reference's ckpt
-        format ({"network", "optimizer"}, rainbow.py / dqn.py:184-199) both ways."""
-        sd = self._net.export_state()
-        params = [torch.nn.Parameter(v) for v in sd.values()]
-        opt = Optimizer(**self._optim_config, params=params)
-        for grp in opt.param_groups:
-            grp["lr"] = self._lr_now
-        return opt, params, list(sd.keys())
-
-    def save(self, path):
-        if self._net is None:
-            return super().save(path)
-        import os
-
-        print(f"...Save model to {path}...")
-        opt, params, keys = self._shadow_optimizer()
-        if self._adam_steps > 0:
-            m, v = self._net.export_state(self._net.m), self._net.export_state(self._net.v)
-            for p, k in zip(params, keys):
-                opt.state[p] = {"step": torch.tensor(float(self._adam_steps)), "exp_avg": m[k], "exp_avg_sq": v[k]}
-        torch.save({"network": self.network.state_dict(), "optimizer": opt.state_dict()}, os.path.join(path, "ckpt"))
-
-    def load(self, path):
-        if self._net is None:
-            return super().load(path)
-        import os
-
-        print(f"...Load model from {path}...")
-        checkpoint = torch.load(os.path.join(path, "ckpt"), map_location=self.device, weights_only=False)
-        self.network.load_state_dict(checkpoint["network"])
-        self.target_network.load_state_dict(checkpoint["network"])
-        opt, params, keys = self._shadow_optimizer()
-        opt.load_state_dict(checkpoint["optimizer"])
-        steps = 0
-        if opt.state:
-            self._net.import_state({k: opt.state[p]["exp_avg"] for p, k in zip(params, keys)}, self._net.m)
-            self._net.import_state({k: opt.state[p]["exp_avg_sq"] for p, k in zip(params, keys)}, self._net.v)
-            steps = int(float(opt.state[params[0]]["step"]))
-        else:
-            self._net.m.zero_()
-            self._net.v.zero_()
-        g0 = opt.param_groups[0]
-        self._adam_steps, self._lr_now = steps, float(g0["lr"])
-        self._net.set_hyper(g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"], steps)
+        net.optim_step(self._opt_name, self.clip_grad_norm)
 
     def _learn_body(self, st):
         if self._net is not None:
@@ -322,13 +197,8 @@ class Rainbow(DQN):
             self.grad_sync()
         self.optimizer.step()
 
-    def _import_optim_state(self):  # load_full(): load() above already imported the moments
-        pass
-
     def learn(self):
         stats64 = self._run_learn()
-        if self._net is not None:
-            self._adam_steps += 1
         s = self._stats8.cpu().numpy()
         p = stats64.cpu().numpy()
         return {"loss": float(s[0]), "beta": self.beta, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3]),

@@ -89,8 +89,11 @@ def _h(z, k):
     return z[f"hyper/{k}"].item()
 
 
+@pytest.mark.parametrize("backend", ["native", "torch"])
 @pytest.mark.parametrize("name", ["dqn", "double", "multistep", "per", "ape_x"])
-def test_td_agents_learn_matches_reference(name):
+def test_td_agents_learn_matches_reference(name, backend):
+    """backend native = the q-network / dueling encoder, its backward and the optimizer on libjorldy_hip
+    (jh_rbnet_*), torch = the PyTorch mirror modules; both around the same HIP loss / PER kernels."""
     from jorldy_amd.core.agent import Agent
 
     z = load(name)
@@ -99,7 +102,9 @@ def test_td_agents_learn_matches_reference(name):
         if f"hyper/{k}" in z.files:
             extra[k] = _h(z, k)
     agent = Agent(name, state_size=int(_h(z, "S")), action_size=int(_h(z, "A")), hidden_size=int(_h(z, "H")), optim_config={"name": "adam", "lr": _h(z, "lr")},
-                  gamma=_h(z, "gamma"), buffer_size=256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=100000, device="cuda", **extra)
+                  gamma=_h(z, "gamma"), buffer_size=256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=100000, device="cuda",
+                  backend=backend, **extra)
+    assert agent.backend == backend
     agent.network.load_state_dict(_sd(z, "sd0/"))
     agent.target_network.load_state_dict(_sd(z, "sdt/"))
     per = name in ("per", "ape_x")
