@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Learner-side measurement at BASELINE.json configs[3] shapes (config.ape_x.atari --env.name pong,
+distributed): dueling Nature-CNN, uint8 (4,84,84) frames, A=6, n_step=3, distributed_batch_size=512,
+centered RMSprop, clip_grad_norm 40, PER alpha .6 with ACTOR-SIDE initial priorities, synthetic transitions.
+
+One learner iteration = ingest one actor chunk (update_period=100 n-step transitions + their priorities, one
+coalesced ring append + one sum-tree push) and one ApeX.learn() (PER sample -> gather -> 3 CNN forwards +
+backward + clip + RMSprop on jh_rbnet_* -> jh_td_loss -> priority write-back), replayed as one hipGraph.
+
+    python tools/bench_apex.py [--updates 100] [--backend native|torch]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--buffer", type=int, default=200000)
+    ap.add_argument("--updates", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--backend", default="native", choices=["native", "torch"])
+    ap.add_argument("--batch", type=int, default=512)
+    args = ap.parse_args()
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    N, B, n, chunk_rows, filled = args.buffer, args.batch, 3, 100, 16384
+    agent = Agent("ape_x", state_size=[4, 84, 84], action_size=6, hidden_size=512, network="dueling", head="cnn",
+                  optim_config={"name": "rmsprop", "eps": 1.5e-7, "lr": 2.5e-4 / 4, "centered": True}, gamma=0.99, buffer_size=N, batch_size=B,
+                  clip_grad_norm=40.0, start_train_step=0, target_update_period=2500, run_step=30_000_000, n_step=n, alpha=0.6, beta=0.4,
+                  uniform_sample_prob=1e-3, num_workers=64, device="cuda", backend=args.backend)
+    agent.memory.first_store = False
+    rng = np.random.RandomState(0)
+
+    def synth(m):
+        return {"state": rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8), "action": rng.randint(0, 6, size=(m, 1)),
+                "reward": rng.choice([-1.0, 0.0, 1.0], p=[0.02, 0.9, 0.08], size=(m, n, 1)).astype(np.float32),
+                "next_state": rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8), "done": (rng.rand(m, n, 1) < 1e-3)}
+
+    for o in range(0, filled, 2048):
+        agent.memory.store_soa(synth(2048), rng.rand(2048) ** 0.5 + 1e-3)
+    chunk, chunk_prio = synth(chunk_rows), rng.rand(chunk_rows) + 1e-3
+
+    def iteration():
+        agent.memory.store_soa(chunk, chunk_prio)  # one actor's update_period transitions + actor-side priorities
+        return agent.learn()
+
+    for _ in range(args.warmup):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.updates):
+        r = iteration()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(30):
+        agent.learn()
+    torch.cuda.synchronize()
+    dt_learn = (time.perf_counter() - t0) / 30
+    graphed = agent._graph is not None
+    ops.lib_profile(True)
+    for _ in range(5):
+        iteration()
+    torch.cuda.synchronize()
+    prof = ops.lib_profile_report()
+    ops.lib_profile(False)
+    P1, P2, P3 = 400, 81, 49
+    flops = {  # forward rows: online 2B + target B; backward: B
+        "jh_tgemm_conv1_fwd": 2.0 * 3 * B * P1 * 32 * 256, "jh_tgemm_conv2_fwd": 2.0 * 3 * B * P2 * 64 * 512, "jh_tgemm_conv3_fwd": 2.0 * 3 * B * P3 * 64 * 576,
+        "jh_tgemm_stream1_fwd": 2.0 * 3 * B * 1024 * 3136, "jh_tgemm_stream1_bwd": 2.0 * 2 * B * 1024 * 3136,
+        "jh_tgemm_conv3_bwd": 2.0 * 2 * B * P3 * 64 * 576, "jh_tgemm_conv2_bwd": 2.0 * 2 * B * P2 * 64 * 512, "jh_tgemm_conv1_bwd": 2.0 * B * P1 * 32 * 256,
+    }
+    kern = {k: {"avg_us": round(v[1] / v[0] * 1e3, 2), **({"TFLOP/s": round(flops[k] / (v[1] / v[0] * 1e-3) / 1e12, 1), "frac_of_157.3_f32_mfma_peak": round(flops[k] / (v[1] / v[0] * 1e-3) / 157.3e12, 3)} if k in flops else {})}
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    out = {
+        "workload": f"config.ape_x.atari pong-shaped (BASELINE.json configs[3]), synthetic uint8 (4,84,84), A=6, B={B}, n=3, dueling CNN, centered RMSprop, clip 40, "
+                    f"PER N={N} ({filled} filled), backend {args.backend}",
+        "learner_updates_per_s": args.updates / dt,
+        "sampled_transitions_per_s": B * args.updates / dt,
+        "ingested_transitions_per_s": chunk_rows * args.updates / dt,
+        "ms_per_iteration_incl_ingest": dt / args.updates * 1e3,
+        "ms_per_learn_only": dt_learn * 1e3,
+        "learn_in_hipgraph": graphed,
+        "last_result": {k: float(v) for k, v in r.items()},
+        "lib_kernels": kern,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
