@@ -327,6 +327,30 @@ int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream);
 int jh_rbnet_optim_step(jh_rbnet* n, int32_t optimizer, float max_norm, jh_stream stream);
 int jh_rbnet_adam_step(jh_rbnet* n, jh_stream stream);
 
+/* ------------------------------------------------------------------ asynchronous actor -> learner staging
+ * Replaces the async path's transport (run_mode.py:212-363 async_distributed_train: Ray actors -> manager
+ * process -> multiprocessing trans_queue -> `gather_thread` spinning on flags, process.py:7-31,82-97) for
+ * many-actor / one-learner agents (Ape-X, ape_x.py:174-199 actor-side priorities): one bounded lock-free
+ * multi-producer / single-consumer ring of transitions in pinned host memory with the replay store's column
+ * layout.  Actor threads produce rows (+ priorities); the learner thread drains what is published with
+ * hipMemcpyAsync straight from the ring's pinned slots into the device store (+ the sum-tree leaves).
+ * ctx may be NULL for a host-only ring (pageable memory, jh_ring_consume_host only).                      */
+typedef struct jh_ring jh_ring;
+int jh_ring_create(jh_ctx* ctx, int64_t slots, int32_t n_cols, const jh_col_desc* cols, int32_t with_priority, jh_ring** out);
+void jh_ring_destroy(jh_ring* r);
+/* Any thread.  n <= slots rows, h_cols[c] = n rows of column c, h_prio[n] when the ring carries priorities.
+ * Blocks while the ring is full; timeout_ms >= 0 bounds that wait (JH_ERR_STATE, nothing written), < 0 forever. */
+int jh_ring_produce(jh_ring* r, int64_t n, const void* const* h_cols, const double* h_prio, int32_t timeout_ms);
+/* The consumer thread.  Appends every published row (<= max_rows; <= 0: as many as the store holds) to the device
+ * store and, with per != NULL, pushes the leaves (actor priorities, or max_priority for a ring without).
+ * Asynchronous on `stream`; slots are recycled when the copies have executed.  *n_out = rows taken.        */
+int jh_ring_drain(jh_ring* r, jh_store* s, jh_per* per, int64_t max_rows, jh_stream stream, int64_t* n_out);
+/* Consumer thread: recycle the slots of drains whose copies have executed (wait != 0: wait for all of them).  */
+int jh_ring_reclaim(jh_ring* r, int32_t wait);
+/* Host-side consumer (tests / CPU plumbing): rows are copied to h_out_cols and their slots recycled at once. */
+int jh_ring_consume_host(jh_ring* r, int64_t max_rows, void* const* h_out_cols, double* h_prio_out, int64_t* n_out);
+int jh_ring_stats(jh_ring* r, int64_t* produced, int64_t* drained, double* producer_wait_ms);
+
 #ifdef __cplusplus
 }
 #endif

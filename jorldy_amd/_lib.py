@@ -96,6 +96,13 @@ _PROTOS = {
     "jh_rbnet_learn_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "jh_rbnet_backward": (C.c_int, [_vp, _vp, _vp]),
     "jh_rbnet_adam_step": (C.c_int, [_vp, _vp]),
+    "jh_ring_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _i32, _pp]),
+    "jh_ring_destroy": (None, [_vp]),
+    "jh_ring_produce": (C.c_int, [_vp, _i64, _pp, _vp, _i32]),
+    "jh_ring_drain": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.POINTER(_i64)]),
+    "jh_ring_consume_host": (C.c_int, [_vp, _i64, _pp, _vp, C.POINTER(_i64)]),
+    "jh_ring_reclaim": (C.c_int, [_vp, _i32]),
+    "jh_ring_stats": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_f64)]),
     "jh_collector_stats": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), _i32]),
     "jh_collector_run": (C.c_int, [_vp, _i32, _i32, _vp]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),

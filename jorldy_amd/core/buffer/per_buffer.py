@@ -59,6 +59,9 @@ class PERBuffer(ReplayBuffer):
             prio = np.asarray([np.asarray(t["priority"]).reshape(-1)[0] for t in transitions], dtype=np.float64)
         self.store_soa(self.stack_transition(transitions, skip=("priority",)), prio)
 
+    def _drain_tree(self):
+        return self._tree  # drained rows get their leaves in the same call (actor priorities or max_priority)
+
     # -- priorities -------------------------------------------------------------------------------
     def update_priorities(self, indices, priorities):
         """Batched write-back: indices int64 device tensor (tree space), priorities float32/float64

@@ -59,6 +59,35 @@ class ReplayBuffer(BaseBuffer):
     def flush(self):
         self._flush_rows()
 
+    # ---- asynchronous ingestion (many actor threads -> this learner's store) ------------
+    def make_ring(self, slots, example=None, with_priority=False):
+        """Pinned lock-free staging ring with this buffer's column layout.  `example`: one SoA batch (dict key ->
+        array [n, ...]) to fix the layout when nothing has been stored yet.  Actor threads call
+        `ring.produce(self.ring_columns(cols), priorities)`; the learner calls `self.drain()`."""
+        from ... import ops
+
+        if self._store is None:
+            assert example is not None, "the buffer has no layout yet: pass an example batch"
+            self._make_store(example, self.buffer_size)
+        self._ring = ops.StagingRing(slots, self._store.columns, with_priority=with_priority, device=self.device)
+        return self._ring
+
+    def ring_columns(self, cols):
+        """agent-side keys (incl. list-valued multimodal keys) -> the ring's / store's flat column names"""
+        return self._flat_cols(cols)
+
+    def _drain_tree(self):
+        return None
+
+    def drain(self, max_rows=0):
+        """Learner thread: move everything the actors have published into the device ring (async copies on the
+        current stream, no intermediate host copy); returns the number of transitions taken."""
+        self.flush()
+        n = self._ring.drain(self._store, self._drain_tree(), max_rows)
+        self.buffer_index = (self.buffer_index + n) % self.buffer_size
+        self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
+        return n
+
     def store(self, transitions):
         if self.first_store:
             self.check_dim(transitions[0])

@@ -102,6 +102,8 @@ struct jh_store {
   std::vector<size_t> staged_off;
 };
 
+int jh_store_append(jh_store* s, int64_t n, const void* const* cols, hipMemcpyKind kind, hipStream_t st);
+
 struct jh_cartpole {
   int W = 0;
   std::vector<double> s;  // [W][4]: x, x_dot, theta, theta_dot

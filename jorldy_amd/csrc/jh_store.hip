@@ -104,22 +104,26 @@ JH_EXPORT int jh_store_push(jh_store* s, int64_t n, const void* const* h_cols, j
   return jh_store_stage_commit(s, stream);
 }
 
-JH_EXPORT int jh_store_push_device(jh_store* s, int64_t n, const void* const* d_cols, jh_stream stream) {
-  JH_ARG(s && d_cols);
-  JH_ARG(n >= 0 && n <= s->capacity);
-  if (n == 0) return JH_OK;
-  hipStream_t st = jh_s(stream);
+// ring append of n <= capacity rows from per-column sources the copy engine can read asynchronously
+// (device memory, or pinned host memory that stays untouched until `st` reaches this point)
+int jh_store_append(jh_store* s, int64_t n, const void* const* cols, hipMemcpyKind kind, hipStream_t st) {
   const int64_t first = s->capacity - s->index < n ? s->capacity - s->index : n;
   for (int c = 0; c < s->n_cols; ++c) {
     const size_t rb = s->row_bytes[c];
-    const char* src = (const char*)d_cols[c];
-    JH_HIP(hipMemcpyAsync((char*)s->dev[c] + rb * (size_t)s->index, src, rb * (size_t)first, hipMemcpyDeviceToDevice, st));
-    if (first < n)
-      JH_HIP(hipMemcpyAsync(s->dev[c], src + rb * (size_t)first, rb * (size_t)(n - first), hipMemcpyDeviceToDevice, st));
+    const char* src = (const char*)cols[c];
+    JH_HIP(hipMemcpyAsync((char*)s->dev[c] + rb * (size_t)s->index, src, rb * (size_t)first, kind, st));
+    if (first < n) JH_HIP(hipMemcpyAsync(s->dev[c], src + rb * (size_t)first, rb * (size_t)(n - first), kind, st));
   }
   s->index = (s->index + n) % s->capacity;
   s->counter = s->counter + n < s->capacity ? s->counter + n : s->capacity;
   return JH_OK;
+}
+
+JH_EXPORT int jh_store_push_device(jh_store* s, int64_t n, const void* const* d_cols, jh_stream stream) {
+  JH_ARG(s && d_cols);
+  JH_ARG(n >= 0 && n <= s->capacity);
+  if (n == 0) return JH_OK;
+  return jh_store_append(s, n, d_cols, hipMemcpyDeviceToDevice, jh_s(stream));
 }
 
 // ------------------------------------------------------------------------------ gather

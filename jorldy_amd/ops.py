@@ -669,3 +669,78 @@ class RainbowNet:
     def optim_step(self, optimizer="adam", max_norm=None):
         """[clip_grad_norm_(max_norm)] + optimizer.step(); optimizer in {"adam", "rmsprop"}."""
         L.check(self.lib.jh_rbnet_optim_step(self.h, {"adam": 0, "rmsprop": 1}[optimizer], float(max_norm or 0.0), L.stream_ptr()))
+
+
+class StagingRing:
+    """jh_ring_*: bounded lock-free multi-producer / single-consumer ring of transitions in pinned host memory
+    (the async Ape-X transport).  `produce` may be called from any number of actor threads (the GIL is released
+    inside the C call); `drain` belongs to the learner thread.
+
+    columns: list of (name, jh_dtype, elems, shape) -- pass `store.columns` to stage for a DeviceStore.
+    device=None builds a host-only ring (pageable memory; `consume_host` only)."""
+
+    def __init__(self, slots, columns, with_priority=False, device="cuda"):
+        self.lib = L.load()
+        self.columns = list(columns)
+        self.names = [c[0] for c in columns]
+        self.slots, self.with_priority = int(slots), bool(with_priority)
+        ctx = None
+        if device is not None:
+            self.device = torch.device(device)
+            ctx = L.ctx(self.device.index if self.device.index is not None else torch.cuda.current_device())
+        descs = (L.ColDesc * len(columns))(*[L.ColDesc(int(c[1]), int(c[2])) for c in columns])
+        self.h = C.c_void_p()
+        L.check(self.lib.jh_ring_create(ctx, self.slots, len(columns), descs, int(self.with_priority), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jh_ring_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def produce(self, cols, priorities=None, timeout_ms=10000):
+        """cols: dict name -> numpy array [n, ...] (converted to the stored dtype); thread-safe.  Blocks while the
+        ring is full -- slots come back when the LEARNER thread drains / reclaims -- for at most timeout_ms
+        (JhError, nothing written); timeout_ms < 0 waits forever."""
+        arrs, n = [], None
+        for name, dt, elems, _ in self.columns:
+            a = np.ascontiguousarray(np.asarray(cols[name]).reshape(len(cols[name]), -1), dtype=_NP_OF[dt])
+            assert a.shape[1] == elems, f"column {name}: expected {elems} elems, got {a.shape[1]}"
+            n = a.shape[0] if n is None else n
+            assert a.shape[0] == n
+            arrs.append(a)
+        p = None
+        if self.with_priority:
+            p = np.ascontiguousarray(priorities, dtype=np.float64).reshape(-1)
+            assert p.size == n
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        L.check(self.lib.jh_ring_produce(self.h, int(n), ptrs, None if p is None else p.ctypes.data, int(timeout_ms)))
+        return n
+
+    def drain(self, store, tree=None, max_rows=0):
+        """Learner thread: everything published so far -> `store` (DeviceStore) [+ leaves into `tree` (SumTree)]."""
+        n = C.c_int64()
+        L.check(self.lib.jh_ring_drain(self.h, store.h, tree.h if tree is not None else None, int(max_rows), L.stream_ptr(), C.byref(n)))
+        return int(n.value)
+
+    def reclaim(self, wait=False):
+        """Learner thread: give the slots of completed drains back to the producers (drain() does this too)."""
+        L.check(self.lib.jh_ring_reclaim(self.h, int(bool(wait))))
+
+    def consume_host(self, max_rows=0):
+        """-> (dict name -> numpy [n, elems], priorities float64[n]) of the rows published so far."""
+        cap = self.slots if max_rows <= 0 else int(max_rows)
+        outs = [np.empty((cap, elems), dtype=_NP_OF[dt]) for _, dt, elems, _ in self.columns]
+        prio = np.empty(cap, np.float64)
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        n = C.c_int64()
+        L.check(self.lib.jh_ring_consume_host(self.h, cap, ptrs, prio.ctypes.data, C.byref(n)))
+        k = int(n.value)
+        return {name: o[:k] for name, o in zip(self.names, outs)}, prio[:k]
+
+    def stats(self):
+        a, b, w = C.c_int64(), C.c_int64(), C.c_double()
+        L.check(self.lib.jh_ring_stats(self.h, C.byref(a), C.byref(b), C.byref(w)))
+        return {"produced": a.value, "drained": b.value, "producer_wait_ms": w.value}

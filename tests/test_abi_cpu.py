@@ -78,3 +78,69 @@ def test_native_cartpole_matches_oracle_bit_exact(lib):
         np.testing.assert_array_equal(nat.obs(), orc.obs())  # includes post-reset states
         dones += int(d2.sum())
     assert dones > 20
+
+
+def test_staging_ring_many_producers_one_consumer_host_only():
+    """jh_ring_* (the async Ape-X transport) without a GPU: 8 producer threads x 400 rows through a 64-slot ring
+    (so producers block on a full ring and slots recycle many times); every row arrives exactly once, rows of one
+    produce() call stay contiguous and in order, priorities travel with their rows."""
+    import threading
+
+    import numpy as np
+
+    from jorldy_amd import _lib as L
+    from jorldy_amd import ops
+
+    cols = [("state", L.JH_F32, 3, (3,)), ("action", L.JH_I64, 1, (1,)), ("frame", L.JH_U8, 16, (16,))]
+    ring = ops.StagingRing(64, cols, with_priority=True, device=None)
+    P, CHUNKS, ROWS = 8, 80, 5
+    errors = []
+
+    def actor(pid):
+        try:
+            for c in range(CHUNKS):
+                base = (pid * CHUNKS + c) * ROWS
+                ids = np.arange(base, base + ROWS)
+                ring.produce({"state": np.stack([ids, ids * 2, ids * 3], 1).astype(np.float32), "action": ids.reshape(-1, 1),
+                              "frame": np.repeat((ids % 251).astype(np.uint8)[:, None], 16, 1)}, priorities=ids + 0.5, timeout_ms=20000)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=actor, args=(p,)) for p in range(P)]
+    for t in threads:
+        t.start()
+    got_ids, got = [], 0
+    total = P * CHUNKS * ROWS
+    import time
+
+    t0 = time.time()
+    while got < total and time.time() - t0 < 60:
+        out, prio = ring.consume_host()
+        n = len(prio)
+        if n == 0:
+            time.sleep(0.0005)
+            continue
+        ids = out["action"][:, 0]
+        np.testing.assert_array_equal(out["state"], np.stack([ids, ids * 2, ids * 3], 1).astype(np.float32))
+        np.testing.assert_array_equal(out["frame"], np.repeat((ids % 251).astype(np.uint8)[:, None], 16, 1))
+        np.testing.assert_array_equal(prio, ids + 0.5)
+        got_ids.append(ids.copy())
+        got += n
+    for t in threads:
+        t.join(timeout=30)
+    assert not errors and got == total
+    ids = np.concatenate(got_ids)
+    assert sorted(ids.tolist()) == list(range(total))  # exactly once
+    # rows of one produce() call are contiguous and ordered
+    assert np.all(np.diff(ids.reshape(-1, ROWS), axis=1) == 1) and np.all(ids.reshape(-1, ROWS)[:, 0] % ROWS == 0)
+    st = ring.stats()
+    assert st["produced"] == total and st["drained"] == total
+    # a full ring with a bounded wait reports JH_ERR_STATE and writes nothing
+    small = ops.StagingRing(4, cols, with_priority=False, device=None)
+    z = {"state": np.zeros((4, 3), np.float32), "action": np.zeros((4, 1), np.int64), "frame": np.zeros((4, 16), np.uint8)}
+    small.produce(z)
+    import pytest
+
+    with pytest.raises(L.JhError):
+        small.produce({k: v[:1] for k, v in z.items()}, timeout_ms=50)
+    assert small.stats()["produced"] == 4

@@ -717,3 +717,82 @@ def test_multimodal_list_valued_keys_through_the_device_store():
     for k in ("action", "reward", "done"):
         # float64 rewards become fp32 on the device, as in the reference's as_tensor (base.py:61-73)
         np.testing.assert_array_equal(got[k].cpu().numpy().astype(np.float32), np.asarray(want[k]).astype(np.float32))
+
+
+def test_staging_ring_drain_equals_direct_stores_and_survives_concurrent_actors():
+    """PERBuffer.make_ring / drain (jh_ring_drain: hipMemcpyAsync from the pinned ring slots into the device ring
+    + leaves with the actors' priorities): (1) one producer, several drains incl. both wrap-arounds == the same rows
+    through store_soa, bit for bit (rows, tree, counters); (2) 6 concurrent actor threads while the learner drains
+    and samples: every row lands exactly once and the tree's root is the sum of the priorities."""
+    import threading
+
+    from jorldy_amd.core.buffer import PERBuffer
+
+    rng = np.random.RandomState(1)
+
+    def batch(n, base):
+        ids = np.arange(base, base + n)
+        return {"state": rng.randint(0, 256, size=(n, 2, 4, 4)).astype(np.uint8), "action": ids.reshape(-1, 1), "reward": rng.randn(n, 3, 1).astype(np.float32),
+                "next_state": rng.randint(0, 256, size=(n, 2, 4, 4)).astype(np.uint8), "done": (rng.rand(n, 3, 1) < 0.1)}, rng.rand(n) + 0.05
+
+    direct, ringed = PERBuffer(40, 0.1, device="cuda"), PERBuffer(40, 0.1, device="cuda")
+    direct.first_store = ringed.first_store = False
+    ex, _ = batch(1, 0)
+    ring = ringed.make_ring(16, example=ex, with_priority=True)
+    base = 0
+    for n in (7, 9, 16, 3, 11, 16, 5):  # 67 rows through a 16-slot ring into a 40-slot store
+        cols, prio = batch(n, base)
+        base += n
+        direct.store_soa(cols, prio)
+        ring.produce(ringed.ring_columns(cols), prio, timeout_ms=5000)
+        assert ringed.drain() == n
+        ring.reclaim(wait=True)  # single-threaded here: nobody else would recycle the slots before the next produce
+        assert ringed.size == direct.size and ringed.buffer_index == direct.buffer_index
+    np.testing.assert_array_equal(ringed.sum_tree, direct.sum_tree)
+    assert ringed.max_priority == direct.max_priority and ringed.tree_index == direct.tree_index
+    a, b = direct.state_dict()["columns"], ringed.state_dict()["columns"]
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+    big = PERBuffer(4096, 1e-3, device="cuda")
+    big.first_store = False
+    ring = big.make_ring(256, example=ex, with_priority=True)
+    P, CH, ROWS = 6, 40, 8
+    sent = {}
+
+    def actor(pid):
+        r = np.random.RandomState(100 + pid)
+        for c in range(CH):
+            ids = np.arange((pid * CH + c) * ROWS, (pid * CH + c + 1) * ROWS)
+            cols = {"state": r.randint(0, 256, size=(ROWS, 2, 4, 4)).astype(np.uint8), "action": ids.reshape(-1, 1), "reward": np.zeros((ROWS, 3, 1), np.float32),
+                    "next_state": np.zeros((ROWS, 2, 4, 4), np.uint8), "done": np.zeros((ROWS, 3, 1), bool)}
+            prio = 0.5 + (ids % 7)
+            sent[(pid, c)] = (ids, cols["state"].copy(), prio)
+            ring.produce(big.ring_columns(cols), prio, timeout_ms=30000)
+
+    threads = [threading.Thread(target=actor, args=(p,)) for p in range(P)]
+    for t in threads:
+        t.start()
+    total, got = P * CH * ROWS, 0
+    import time
+
+    t0 = time.time()
+    while got < total and time.time() - t0 < 60:
+        got += big.drain()
+        if big.size >= 16:
+            big.sample(0.4, 16)  # the learner keeps sampling while actors produce
+    for t in threads:
+        t.join(timeout=30)
+    assert got == total == big.size
+    cols = big.state_dict()["columns"]
+    ids = cols["action"][:, 0]
+    assert sorted(ids.tolist()) == list(range(total))
+    by_id = {int(i): k for k, i in enumerate(ids)}
+    for (pid, c), (sid, st, prio) in sent.items():
+        rows = [by_id[int(i)] for i in sid]
+        assert rows == list(range(rows[0], rows[0] + ROWS))  # one produce() call stays contiguous
+        np.testing.assert_array_equal(cols["state"][rows], st)
+    tree = big.sum_tree
+    np.testing.assert_allclose(tree[0], sum(float(p.sum()) for _, _, p in sent.values()), rtol=1e-12)
+    leaves = tree[big.first_leaf_index : big.first_leaf_index + total]
+    np.testing.assert_array_equal(leaves, 0.5 + (ids % 7))  # every leaf carries ITS row's actor-side priority
