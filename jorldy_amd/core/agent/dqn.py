@@ -418,11 +418,15 @@ class ApeX(DQN):
                 "num_learn": self.num_learn, "num_transitions": self.num_transitions}
 
     def process(self, transitions, step):
-        """ape_x.py:135-164."""
+        """ape_x.py:135-164.  transitions=None: the actors publish into the staging ring (`memory.make_ring`,
+        jh_ring_*) instead of handing lists over; take whatever has arrived."""
         result = {}
-        self.num_transitions += len(next(iter(transitions.values()))) if isinstance(transitions, dict) else len(transitions)
         delta_t = step - self.time_t
-        self._store(transitions)
+        if transitions is None:
+            self.num_transitions += self.memory.drain()
+        else:
+            self.num_transitions += len(next(iter(transitions.values()))) if isinstance(transitions, dict) else len(transitions)
+            self._store(transitions)
         self.time_t = step
         self.target_update_stamp += delta_t
         self.learn_period_stamp += delta_t

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--backend", default="native", choices=["native", "torch"])
     ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--actors", type=int, default=0, help="N > 0: N host actor threads publish chunks into the staging ring while the learner runs")
+    ap.add_argument("--actor-hz", type=float, default=0.0, help="env steps/s per actor (0: as fast as the ring takes them = ingestion capacity)")
     args = ap.parse_args()
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
@@ -54,14 +56,55 @@ def main():
         agent.memory.store_soa(chunk, chunk_prio)  # one actor's update_period transitions + actor-side priorities
         return agent.learn()
 
+    async_stats = None
+    if args.actors > 0:
+        # async mode (run_mode.py:212-363 re-expressed): actor threads publish update_period-sized chunks (with their
+        # priorities) into the pinned staging ring as fast as they can; the learner loop = drain + learn()
+        import threading
+
+        ring = agent.memory.make_ring(64 * chunk_rows, with_priority=True)
+        flat = agent.memory.ring_columns(chunk)
+        stop = threading.Event()
+
+        def actor():
+            period = chunk_rows / args.actor_hz if args.actor_hz > 0 else 0.0
+            nxt = time.perf_counter()
+            while not stop.is_set():
+                try:
+                    ring.produce(flat, chunk_prio, timeout_ms=200)
+                except Exception:
+                    pass  # ring full for 200 ms: the learner is the bottleneck; try again
+                if period:
+                    nxt += period
+                    time.sleep(max(0.0, nxt - time.perf_counter()))
+
+        threads = [threading.Thread(target=actor, daemon=True) for _ in range(args.actors)]
+        for t in threads:
+            t.start()
+        step = 0
+
+        def iteration():
+            nonlocal step
+            step += 1
+            agent.learn_period_stamp = agent.learn_period  # one learn() per learner iteration, like the sync loop below
+            return agent.process(None, step)
+
     for _ in range(args.warmup):
         iteration()
     torch.cuda.synchronize()
+    n0 = agent.num_transitions
     t0 = time.perf_counter()
     for _ in range(args.updates):
         r = iteration()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.actors > 0:
+        stop.set()
+        for t in threads:
+            t.join(timeout=5)
+        async_stats = {"actors": args.actors, "actor_hz": args.actor_hz, "ingested_transitions_per_s": (agent.num_transitions - n0) / dt, "ingested_GB_per_s": (agent.num_transitions - n0) * 2 * 28224 / dt / 1e9,
+                       **ring.stats()}
+        iteration = lambda: agent.learn()
     t0 = time.perf_counter()
     for _ in range(30):
         agent.learn()
@@ -87,7 +130,8 @@ def main():
                     f"PER N={N} ({filled} filled), backend {args.backend}",
         "learner_updates_per_s": args.updates / dt,
         "sampled_transitions_per_s": B * args.updates / dt,
-        "ingested_transitions_per_s": chunk_rows * args.updates / dt,
+        "ingested_transitions_per_s": async_stats["ingested_transitions_per_s"] if async_stats else chunk_rows * args.updates / dt,
+        "async": async_stats,
         "ms_per_iteration_incl_ingest": dt / args.updates * 1e3,
         "ms_per_learn_only": dt_learn * 1e3,
         "learn_in_hipgraph": graphed,
