@@ -97,6 +97,10 @@ int jh_store_push_device(jh_store* s, int64_t n, const void* const* d_cols, jh_s
  * core/agent/base.py:61-73).  out_dtype[c] is JH_F32 (as_tensor semantics) or the stored
  * dtype (keeps uint8 frames 4x smaller).  d_idx: int64[B]; idx_offset lets PER pass
  * tree-space indices (leaf = idx - (N-1), per_buffer.py:95).                             */
+/* Positional writes: row i of the host columns lands in slot h_slots[i] (0 <= slot < capacity); index / counter
+ * of the ring are not touched.  Used for the frame pool of the de-duplicated image replay (SURVEY.md §8f rank 2:
+ * single 84x84 frames + per-transition frame indices instead of two 4-frame stacks per transition).       */
+int jh_store_write_rows(jh_store* s, int64_t n, const int64_t* h_slots, const void* const* h_cols, jh_stream stream);
 int jh_store_gather(jh_store* s, int64_t B, const int64_t* d_idx, int64_t idx_offset, int32_t n_sel,
                     const int32_t* sel_cols, void* const* d_out, const int32_t* out_dtype, jh_stream stream);
 void* jh_store_col_ptr(jh_store* s, int32_t col);  /* device base of a column (rollout "sample" is a view) */

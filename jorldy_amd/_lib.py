@@ -45,6 +45,7 @@ _PROTOS = {
     "jh_store_push_device": (C.c_int, [_vp, _i64, _pp, _vp]),
     "jh_store_stage_begin": (C.c_int, [_vp, _i64, _pp]),
     "jh_store_stage_commit": (C.c_int, [_vp, _vp]),
+    "jh_store_write_rows": (C.c_int, [_vp, _i64, _vp, _pp, _vp]),
     "jh_store_gather": (C.c_int, [_vp, _i64, _vp, _i64, _i32, C.POINTER(_i32), _pp, C.POINTER(_i32), _vp]),
     "jh_store_col_ptr": (_vp, [_vp, _i32]),
     "jh_store_size": (_i64, [_vp]),

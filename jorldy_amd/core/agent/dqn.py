@@ -29,7 +29,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
                  network="discrete_q_network", head="mlp", gamma=0.99, epsilon_init=1.0, epsilon_min=0.1,
                  epsilon_eval=0.0, explore_ratio=0.1, buffer_size=50000, batch_size=64, start_train_step=2000,
                  target_update_period=500, device=None, run_step=1e6, num_workers=1, lr_decay=True, use_graph=True, backend=None,
-                 **kwargs):
+                 frame_dedup=False, **kwargs):
         self.device = self._require_gpu(device)
         self.use_graph = use_graph
         self.grad_sync = None  # data-parallel hook (jorldy_amd.parallel.attach_data_parallel)
@@ -57,7 +57,8 @@ class DQN(NativeValueNetMixin, BaseAgent):
         self.explore_step = run_step * explore_ratio
         self.epsilon_delta = (epsilon_init - epsilon_min) / self.explore_step
         self.buffer_size = buffer_size
-        self.memory = ReplayBuffer(buffer_size, device=self.device)
+        self._frame_dedup = bool(frame_dedup)  # image replay as single frames + slot numbers (buffer/frame_dedup.py)
+        self.memory = ReplayBuffer(buffer_size, device=self.device, frame_dedup=self._frame_dedup)
         self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.batch_size = batch_size
         self.start_train_step = start_train_step
@@ -328,7 +329,7 @@ class PER(DQN):
 
     def __init__(self, alpha=0.6, beta=0.4, learn_period=16, uniform_sample_prob=1e-3, run_step=1e6, **kwargs):
         super().__init__(run_step=run_step, **kwargs)
-        self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device)
+        self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device, frame_dedup=self._frame_dedup)
         self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.alpha = alpha
         self.beta = beta
@@ -389,7 +390,7 @@ class ApeX(DQN):
         self.uniform_sample_prob = uniform_sample_prob
         self.beta_add = (1 - beta) / self.run_step
         self.n_step = n_step
-        self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device)
+        self.memory = PERBuffer(self.buffer_size, uniform_sample_prob, device=self.device, frame_dedup=self._frame_dedup)
         self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.tmp_buffer = deque(maxlen=n_step + 1)
 

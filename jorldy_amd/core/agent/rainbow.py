@@ -89,7 +89,7 @@ class Rainbow(DQN):
                  optim_config={"name": "adam"}, gamma=0.99, buffer_size=50000, batch_size=64, start_train_step=2000,
                  target_update_period=500, run_step=1e6, lr_decay=True, n_step=4, alpha=0.6, beta=0.4, learn_period=4,
                  uniform_sample_prob=1e-3, noise_type="factorized", v_min=-10, v_max=10, num_support=51, device=None,
-                 use_graph=True, backend=None, **kwargs):
+                 use_graph=True, backend=None, frame_dedup=False, **kwargs):
         self.device = self._require_gpu(device)
         self.use_graph = use_graph
         self.grad_sync = None  # data-parallel hook (jorldy_amd.parallel.attach_data_parallel)
@@ -129,7 +129,7 @@ class Rainbow(DQN):
         self.uniform_sample_prob = uniform_sample_prob
         self.beta_add = (1 - beta) / run_step
         self.v_min, self.v_max, self.num_support = v_min, v_max, num_support
-        self.memory = PERBuffer(buffer_size, uniform_sample_prob, device=self.device)
+        self.memory = PERBuffer(buffer_size, uniform_sample_prob, device=self.device, frame_dedup=frame_dedup)
         self.memory.defer_rows = 16  # per-step stores coalesce into one ring append before the next learn()
         self.delta_z = (v_max - v_min) / (num_support - 1)
         self.z = torch.linspace(v_min, v_max, num_support, device=self.device).view(1, -1)

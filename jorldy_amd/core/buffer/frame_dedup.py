@@ -1,0 +1,102 @@
+"""Frame de-duplication for image replay.
+
+The reference's Atari wrapper hands over `state` / `next_state` as stacks of the last C frames
+(core/env/atari.py:147-149), and the n-step assembler (rainbow.py:294-308) copies them again: consecutive
+transitions share C - 1 of their C frames, and `next_state` of step t is `state` of step t + n.  Stored as is,
+a transition costs 2 x C x H x W bytes of HBM and of PCIe traffic (56 KB for 4 x 84 x 84).
+
+Here every distinct FRAME is stored once in a device frame pool and a transition keeps 2 x C int64 slot numbers:
+the drop-in `store` API is unchanged -- frames are recognised by a 128-bit content hash (xxh3) on the host, only
+new ones are uploaded (typically one 7 KB frame per env step: 8 x less H2D and HBM) -- and `gather` rebuilds the
+stacks on the device with the ordinary row-gather kernel (frame pool rows indexed by the gathered slot numbers).
+Slots are reference counted on the host and recycled when the transitions that use them are overwritten.
+"""
+import numpy as np
+import torch
+import xxhash
+
+from ... import _lib as L
+from ... import ops
+
+
+class FramePool:
+    KEYS = ("state", "next_state")
+
+    def __init__(self, buffer_size, C, frame_shape, device, pool_factor=2.0):
+        self.N, self.C, self.frame_shape = int(buffer_size), int(C), tuple(int(v) for v in frame_shape)
+        self.elems = int(np.prod(self.frame_shape))
+        self.F = int(self.N * pool_factor) + 4 * self.C + 64
+        self.pool = ops.DeviceStore(self.F, [("frame", L.JH_U8, self.elems, self.frame_shape)], device=device)
+        self.device = self.pool.device
+        self.free = list(range(self.F - 1, -1, -1))
+        self.ref = np.zeros(self.F, np.int32)
+        self.table = {}  # content hash -> slot
+        self.slot_key = [None] * self.F
+        self.row_slots = np.full((self.N, 2 * self.C), -1, np.int64)  # what each transition row references
+        self._pend_frames, self._pend_slots = [], []
+        self._idx_buf = {}
+        self.frames_uploaded = 0
+        self.frames_referenced = 0
+
+    def _release_row(self, pos):
+        old = self.row_slots[pos]
+        if old[0] < 0:
+            return
+        for s in old:
+            self.ref[s] -= 1
+            if self.ref[s] == 0:
+                del self.table[self.slot_key[s]]
+                self.slot_key[s] = None
+                self.free.append(int(s))
+        self.row_slots[pos] = -1
+
+    def encode(self, cols, positions):
+        """cols["state"], cols["next_state"]: uint8 [n, C, *frame_shape] -> int64 [n, C] slot numbers (new frames are
+        queued for upload); `positions` = the ring rows these transitions will occupy (their old contents die)."""
+        n, C = len(positions), self.C
+        for p in positions:
+            self._release_row(int(p))
+        fidx = np.empty((n, 2 * C), np.int64)
+        stacks = [np.ascontiguousarray(cols[k]).reshape(n, C, self.elems) for k in self.KEYS]
+        for i in range(n):
+            for j in range(2 * C):
+                frame = stacks[j // C][i, j % C]
+                key = xxhash.xxh3_128_digest(frame)
+                s = self.table.get(key)
+                if s is None:
+                    if not self.free:
+                        raise RuntimeError(f"frame pool exhausted ({self.F} frames for {self.N} transitions): raise frame_pool_factor "
+                                           "(observations share fewer frames than the frame-stacking wrapper implies)")
+                    s = self.free.pop()
+                    self.table[key] = s
+                    self.slot_key[s] = key
+                    self._pend_frames.append(frame.copy())
+                    self._pend_slots.append(s)
+                self.ref[s] += 1
+                fidx[i, j] = s
+            self.row_slots[positions[i]] = fidx[i]
+        self.frames_referenced += n * 2 * C
+        out = dict(cols)
+        out["state"], out["next_state"] = fidx[:, :C], fidx[:, C:]
+        return out
+
+    def flush(self):
+        if self._pend_slots:
+            self.pool.write_rows(np.asarray(self._pend_slots, np.int64), {"frame": np.stack(self._pend_frames, 0)})
+            self.frames_uploaded += len(self._pend_slots)
+            self._pend_frames, self._pend_slots = [], []
+
+    def idx_buffer(self, B):
+        if B not in self._idx_buf:
+            self._idx_buf[B] = torch.zeros(2 * B, self.C, dtype=torch.int64, device=self.device)
+        return self._idx_buf[B]
+
+    def decode(self, fidx, out, as_float):
+        """fidx int64 [m, C] (device) -> out [m, C, *frame_shape] (uint8, or fp32 = as_tensor semantics)."""
+        self.pool.gather(fidx.reshape(-1), names=["frame"], as_float=as_float, out={"frame": out.view((-1,) + self.frame_shape)})
+        return out
+
+    def stats(self):
+        return {"frames_uploaded": self.frames_uploaded, "frames_referenced": self.frames_referenced, "pool_slots": self.F,
+                "pool_in_use": self.F - len(self.free), "bytes_per_transition_plain": 2 * self.C * self.elems,
+                "bytes_uploaded_per_transition": self.frames_uploaded * self.elems / max(1, self.frames_referenced // (2 * self.C))}

@@ -15,8 +15,8 @@ class PERBuffer(ReplayBuffer):
     three numpy global-RNG draws of `sample` stay on the host, in the reference's order.
     """
 
-    def __init__(self, buffer_size, uniform_sample_prob=1e-3, device=None):
-        super().__init__(buffer_size, device)
+    def __init__(self, buffer_size, uniform_sample_prob=1e-3, device=None, frame_dedup=False, frame_pool_factor=2.0):
+        super().__init__(buffer_size, device, frame_dedup=frame_dedup, frame_pool_factor=frame_pool_factor)
         self.tree_size = self.buffer_size * 2 - 1
         self.first_leaf_index = self.buffer_size - 1
         self.uniform_sample_prob = uniform_sample_prob

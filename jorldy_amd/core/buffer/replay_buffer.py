@@ -12,9 +12,12 @@ class ReplayBuffer(BaseBuffer):
                the reference, so sampled indices are bit-identical -- then one fused gather kernel.
     """
 
-    def __init__(self, buffer_size, device=None):
+    def __init__(self, buffer_size, device=None, frame_dedup=False, frame_pool_factor=2.0):
         super().__init__(device)
         self.buffer_size = int(buffer_size)
+        # frame_dedup: image observations (uint8 [C, H, W] frame stacks) are stored as single frames + slot numbers
+        # (frame_dedup.py: 8 x less HBM and H2D for 4-frame Atari stacks); the API and the samples are unchanged
+        self.frame_dedup, self.frame_pool_factor, self._frames = bool(frame_dedup), float(frame_pool_factor), None
         self.buffer_index = 0
         self.buffer_counter = 0
         # Coalesced stores (opt-in, set by the agents): pushes of <= defer_rows transitions are held on
@@ -27,7 +30,24 @@ class ReplayBuffer(BaseBuffer):
         self._pending, self._pending_rows = [], 0
 
     # fast path: already-SoA numpy columns [n, ...]
+    def _dedup_encode(self, cols):
+        st = cols.get("state")
+        if self._frames is None:
+            ok = (isinstance(st, np.ndarray) and st.dtype == np.uint8 and st.ndim == 4 and isinstance(cols.get("next_state"), np.ndarray)
+                  and cols["next_state"].shape == st.shape and cols["next_state"].dtype == np.uint8)
+            if not ok:
+                raise ValueError("frame_dedup=True needs uint8 image observations 'state' / 'next_state' of shape [n, C, H, W]")
+            from .frame_dedup import FramePool
+
+            self._frames = FramePool(self.buffer_size, st.shape[1], st.shape[2:], self.device, self.frame_pool_factor)
+        n = len(st)
+        assert n <= self.buffer_size
+        positions = (self.buffer_index + np.arange(n)) % self.buffer_size
+        return self._frames.encode(cols, positions)
+
     def store_soa(self, cols, n=None):
+        if self.frame_dedup:
+            cols = self._dedup_encode(cols)
         if self._store is None:
             self._make_store(cols, self.buffer_size)
         flat = self._flat_cols(cols)
@@ -48,6 +68,8 @@ class ReplayBuffer(BaseBuffer):
 
     def _flush_rows(self):
         """Concatenate and push the held rows; returns [(n, extra)] in store order."""
+        if self._frames is not None:
+            self._frames.flush()  # frames the held / just-pushed rows refer to
         if not self._pending:
             return []
         pend, self._pending, self._pending_rows = self._pending, [], 0
@@ -66,6 +88,7 @@ class ReplayBuffer(BaseBuffer):
         `ring.produce(self.ring_columns(cols), priorities)`; the learner calls `self.drain()`."""
         from ... import ops
 
+        assert not self.frame_dedup, "the staging ring carries whole transitions; frame_dedup encodes on the storing thread"
         if self._store is None:
             assert example is not None, "the buffer has no layout yet: pass an example batch"
             self._make_store(example, self.buffer_size)
@@ -101,8 +124,44 @@ class ReplayBuffer(BaseBuffer):
     def gather(self, idx_device, idx_offset=0, as_float=True, out=None):
         """out: optional dict key -> preallocated tensor (or list of tensors for multimodal keys)."""
         self.flush()
+        if self._frames is not None:
+            return self._gather_dedup(idx_device, idx_offset, as_float, out)
         flat_out = None if out is None else self._flat_cols(out)
         return self._unflatten(self._store.gather(idx_device, as_float=as_float, idx_offset=idx_offset, out=flat_out))
+
+    def _gather_dedup(self, idx_device, idx_offset, as_float, out):
+        """Gather the slot numbers with the other columns, then rebuild the frame stacks from the frame pool (one
+        more row-gather launch; both on static buffers: captured with the rest of learn())."""
+        import torch
+
+        fr, B = self._frames, int(idx_device.numel())
+        keep = {k: (not as_float) if not isinstance(as_float, dict) else (not as_float.get(k, True)) for k in fr.KEYS}
+        meta_float = dict(as_float) if isinstance(as_float, dict) else {n: as_float for n in self._store.names}
+        meta_float.update({k: False for k in fr.KEYS})  # slot numbers stay int64
+        ibuf = fr.idx_buffer(B)
+        meta_out = None
+        if out is not None:
+            meta_out = dict(out)
+            meta_out["state"], meta_out["next_state"] = ibuf[:B], ibuf[B:]
+        got = self._store.gather(idx_device, as_float=meta_float, idx_offset=idx_offset, out=meta_out)
+        if out is None:
+            ibuf[:B].copy_(got["state"])
+            ibuf[B:].copy_(got["next_state"])
+        res = dict(got)
+        shape = (B, fr.C) + fr.frame_shape
+        tgt = {k: (out[k] if out is not None else torch.empty(shape, dtype=torch.uint8 if keep[k] else torch.float32, device=self.device)) for k in fr.KEYS}
+        s, ns = tgt["state"], tgt["next_state"]
+        one_buffer = (keep["state"] == keep["next_state"] and s.is_contiguous() and ns.is_contiguous()
+                      and s.untyped_storage().data_ptr() == ns.untyped_storage().data_ptr()
+                      and ns.data_ptr() == s.data_ptr() + s.numel() * s.element_size())
+        if one_buffer:
+            both = torch.as_strided(s, (2 * B, fr.C) + fr.frame_shape, s.stride())  # [state; next_state] is one buffer: one launch
+            fr.decode(ibuf, both, as_float=not keep["state"])
+        else:
+            fr.decode(ibuf[:B], s, as_float=not keep["state"])
+            fr.decode(ibuf[B:], ns, as_float=not keep["next_state"])
+        res["state"], res["next_state"] = s, ns
+        return res
 
     def sample(self, batch_size, as_float=True):
         idx = h2d_small(self.sample_indices(batch_size).astype(np.int64), self.device)
@@ -120,12 +179,20 @@ class ReplayBuffer(BaseBuffer):
             torch.cuda.current_stream().synchronize()
             for name in self._store.names:
                 cols[name] = self._store.column(name)[: self.buffer_counter].cpu().numpy()
+            if self._frames is not None:  # portable form: the full stacks, as a plain buffer would hold them
+                for k in self._frames.KEYS:
+                    fidx = torch.as_tensor(cols[k], device=self.device)
+                    full = torch.empty((len(fidx), self._frames.C) + self._frames.frame_shape, dtype=torch.uint8, device=self.device)
+                    for o in range(0, len(fidx), 4096):
+                        self._frames.decode(fidx[o : o + 4096].contiguous(), full[o : o + 4096], as_float=False)
+                    cols[k] = full.cpu().numpy()
         return {"buffer_size": self.buffer_size, "buffer_index": self.buffer_index, "buffer_counter": self.buffer_counter,
                 "layout": self._layout, "columns": cols}
 
     def load_state_dict(self, sd):
         assert sd["buffer_size"] == self.buffer_size
         self._pending, self._pending_rows = [], 0
+        self._frames = None
         self._layout = None
         self._store = None
         self.buffer_index = self.buffer_counter = 0

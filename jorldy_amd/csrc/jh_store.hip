@@ -126,6 +126,53 @@ JH_EXPORT int jh_store_push_device(jh_store* s, int64_t n, const void* const* d_
   return jh_store_append(s, n, d_cols, hipMemcpyDeviceToDevice, jh_s(stream));
 }
 
+// ------------------------------------------------------------------------------ positional row writes
+// rows land at caller-chosen slots (frame pool of the de-duplicated Atari replay): the
+// rows and their slot numbers are staged in one pinned, device-mapped slab that the kernel reads in place.
+__global__ void __launch_bounds__(256) jh_scatter_rows_kernel(const char* __restrict__ src, const int64_t* __restrict__ slots, int64_t n, int64_t row_bytes,
+                                                              char* __restrict__ dst, int64_t capacity) {
+  const int64_t row = blockIdx.y;
+  const int64_t slot = slots[row];
+  if (slot < 0 || slot >= capacity) return;
+  const char* s = src + row * row_bytes;
+  char* d = dst + slot * row_bytes;
+  if ((row_bytes & 15) == 0) {
+    const int64_t nv = row_bytes >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256)
+      reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+  }
+}
+
+JH_EXPORT int jh_store_write_rows(jh_store* s, int64_t n, const int64_t* h_slots, const void* const* h_cols, jh_stream stream) {
+  JH_ARG(s && h_slots && h_cols);
+  JH_ARG(n >= 0 && n <= 65535);
+  if (n == 0) return JH_OK;
+  hipStream_t st = jh_s(stream);
+  size_t total = ((sizeof(int64_t) * (size_t)n) + 255) & ~(size_t)255;
+  std::vector<size_t> off(s->n_cols);
+  for (int c = 0; c < s->n_cols; ++c) {
+    off[c] = total;
+    total += (s->row_bytes[c] * (size_t)n + 255) & ~(size_t)255;
+  }
+  jh_pinned_slab* slab = nullptr;
+  int rc = jh_ctx_slab(s->ctx, total, &slab);
+  if (rc) return rc;
+  memcpy(slab->host, h_slots, sizeof(int64_t) * (size_t)n);
+  for (int c = 0; c < s->n_cols; ++c) memcpy((char*)slab->host + off[c], h_cols[c], s->row_bytes[c] * (size_t)n);
+  for (int c = 0; c < s->n_cols; ++c) {
+    const int64_t rb = (int64_t)s->row_bytes[c];
+    unsigned gx = (unsigned)((rb / 16 + 255) / 256);
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    JH_LAUNCH(jh_scatter_rows_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, (const char*)slab->dev + off[c], (const int64_t*)slab->dev, n, rb, (char*)s->dev[c],
+              s->capacity);
+    JH_LAUNCH_CHECK();
+  }
+  return jh_ctx_slab_release(s->ctx, slab, st);
+}
+
 // ------------------------------------------------------------------------------ gather
 struct GatherCol {
   const void* src;

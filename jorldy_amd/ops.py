@@ -134,6 +134,21 @@ class DeviceStore:
         L.check(self.lib.jh_store_push(self.h, n, ptrs, L.stream_ptr()))
         return n
 
+    def write_rows(self, slots, cols):
+        """Positional writes: row i of cols (dict name -> numpy [n, ...]) lands in slot slots[i]; the ring position
+        is not touched (frame pool of the de-duplicated image replay)."""
+        slots = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        arrs = []
+        for name, dt, elems, _ in self.columns:
+            a = np.ascontiguousarray(np.asarray(cols[name]).reshape(len(cols[name]), -1), dtype=_NP_OF[dt])
+            assert a.shape == (slots.size, elems)
+            arrs.append(a)
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        for o in range(0, slots.size, 32768):  # grid.y limit
+            m = min(32768, slots.size - o)
+            sub = (C.c_void_p * len(arrs))(*[a[o : o + m].ctypes.data for a in arrs])
+            L.check(self.lib.jh_store_write_rows(self.h, m, slots[o : o + m].ctypes.data, sub, L.stream_ptr()))
+
     def push_device(self, cols, n):
         """cols: dict name -> CUDA tensor [n, ...] already in the stored dtype (device-to-device ring append)."""
         ts = []

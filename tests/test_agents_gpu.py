@@ -796,3 +796,98 @@ def test_staging_ring_drain_equals_direct_stores_and_survives_concurrent_actors(
     np.testing.assert_allclose(tree[0], sum(float(p.sum()) for _, _, p in sent.values()), rtol=1e-12)
     leaves = tree[big.first_leaf_index : big.first_leaf_index + total]
     np.testing.assert_array_equal(leaves, 0.5 + (ids % 7))  # every leaf carries ITS row's actor-side priority
+
+
+def _frame_stream(rng, steps, C=4, H=12, W=10, n=3, p_done=0.08):
+    """Frame-stacking env wrapper + n-step assembler as the reference wires them (atari.py:147-149 stack of the last
+    C frames, reset repeats the first frame; rainbow.py:294-308 windows that straddle episode ends)."""
+    from collections import deque
+
+    frames, out, win = None, [], deque(maxlen=n)
+    for t in range(steps):
+        if frames is None:
+            f0 = rng.randint(0, 256, size=(H, W)).astype(np.uint8)
+            frames = deque([f0] * C, maxlen=C)
+        state = np.stack(frames, 0)[None]
+        done = rng.rand() < p_done
+        frames.append(rng.randint(0, 256, size=(H, W)).astype(np.uint8))
+        nxt = np.stack(frames, 0)[None]
+        win.append({"state": state, "action": np.asarray([[t % 4]]), "reward": np.asarray([[float(t)]]), "next_state": nxt, "done": np.asarray([[done]])})
+        if done:
+            frames = None
+        if len(win) == n:
+            out.append({"state": win[0]["state"], "action": win[0]["action"], "next_state": win[-1]["next_state"],
+                        "reward": np.stack([w["reward"] for w in win], 1), "done": np.stack([w["done"] for w in win], 1)})
+    return out
+
+
+def test_frame_dedup_replay_is_invisible_and_stores_one_frame_per_step():
+    """frame_dedup=True (single frames in a device pool + slot numbers per transition, frames recognised by content
+    hash): samples, trees and checkpoints equal the plain buffer's bit for bit across ring wrap (slot recycling),
+    single and bulk stores; ~1 new frame per env step is uploaded instead of 2 x C."""
+    from jorldy_amd.core.buffer import PERBuffer
+
+    rng = np.random.RandomState(7)
+    trs = _frame_stream(rng, 260)
+    plain, dd = PERBuffer(64, 0.05, device="cuda"), PERBuffer(64, 0.05, device="cuda", frame_dedup=True, frame_pool_factor=1.6)
+    for b in (plain, dd):
+        b.first_store = False
+        b.defer_rows = 4
+    i = 0
+    for step, chunk in enumerate([1, 1, 1, 5, 1, 1, 17, 1, 1, 1, 1, 30, 1, 1, 1] * 40):
+        if i + chunk > len(trs):
+            break
+        for b in (plain, dd):
+            b.store(trs[i : i + chunk])
+        i += chunk
+        if step % 6 == 5:
+            outs = []
+            for b in (plain, dd):
+                np.random.seed(step)
+                tr, w, idx, sp, mp = b.sample(0.5, 8, as_float=(step % 12 == 5))
+                b.update_priorities(idx, w.double() * 0 + 0.3 + 0.01 * step)
+                outs.append((tr, w, idx))
+            assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][1], outs[1][1])
+            for k in outs[0][0]:
+                assert outs[0][0][k].dtype == outs[1][0][k].dtype and torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert i > 200 and dd.size == plain.size == 64
+    np.testing.assert_array_equal(plain.sum_tree, dd.sum_tree)
+    a, b = plain.state_dict(), dd.state_dict()
+    for k in a["columns"]:
+        np.testing.assert_array_equal(a["columns"][k], b["columns"][k], err_msg=k)
+    st = dd._frames.stats()
+    per_tr = st["frames_uploaded"] / i
+    assert per_tr < 1.6, st  # 2 x C = 8 without de-duplication; ~1 + (C - 1) * P(reset)
+    assert st["pool_in_use"] <= 64 * 1.6 + 80
+    # round trip through a checkpoint (portable: full stacks) into a fresh de-duplicating buffer
+    dd2 = PERBuffer(64, 0.05, device="cuda", frame_dedup=True)
+    dd2.load_state_dict(b)
+    c = dd2.state_dict()
+    for k in a["columns"]:
+        np.testing.assert_array_equal(a["columns"][k], c["columns"][k], err_msg=k)
+    np.testing.assert_array_equal(dd2.sum_tree, plain.sum_tree)
+
+
+def test_rainbow_native_learns_identically_from_a_deduplicated_replay():
+    """Rainbow (native CNN backend, hipGraph learn) on frame_dedup storage == on plain storage: same losses, same weights."""
+    from jorldy_amd.core.agent import Agent
+
+    rng = np.random.RandomState(3)
+    trs = _frame_stream(rng, 120, C=4, H=44, W=52, n=3)
+    res = []
+    for dedup in (False, True):
+        torch.manual_seed(0)
+        agent = Agent("rainbow", state_size=(4, 44, 52), action_size=4, hidden_size=32, head="cnn", optim_config={"name": "adam", "lr": 1e-3}, buffer_size=96,
+                      batch_size=8, start_train_step=0, run_step=1000, n_step=3, num_support=11, v_min=-1, v_max=10, device="cuda", frame_dedup=dedup)
+        agent.memory.first_store = False
+        np.random.seed(5)
+        torch.manual_seed(6)
+        losses = []
+        for t in trs:
+            agent.memory.store([t])
+            if agent.memory.size >= 16 and len(losses) < 12 and agent.memory.size % 6 == 0:
+                losses.append(agent.learn()["loss"])
+        res.append((losses, agent._net.params.clone()))
+        if dedup:
+            assert agent._graph is not None and agent.memory._frames is not None
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
