@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--updates", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--backend", default="native", choices=["native", "torch"])
+    ap.add_argument("--stream", action="store_true", help="frame-stack stream (consecutive transitions share frames, as the Atari wrapper produces) instead of i.i.d. stacks")
+    ap.add_argument("--frame-dedup", action="store_true", help="store single frames + slot numbers (implies --stream)")
     args = ap.parse_args()
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
@@ -36,20 +38,37 @@ def main():
     N, B, n = args.buffer, 32, 3
     agent = Agent("rainbow", state_size=[4, 84, 84], action_size=4, hidden_size=512, head="cnn", optim_config={"name": "adam", "lr": 6.25e-5},
                   gamma=0.99, buffer_size=N, batch_size=B, start_train_step=0, target_update_period=10000, run_step=30_000_000, n_step=n,
-                  alpha=0.5, beta=0.4, learn_period=4, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51, device="cuda", backend=args.backend)
+                  alpha=0.5, beta=0.4, learn_period=4, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51, device="cuda", backend=args.backend,
+                  frame_dedup=args.frame_dedup)
     agent.memory.first_store = False
     rng = np.random.RandomState(0)
     # fill the buffer with synthetic n-step transitions in chunks (SoA fast path)
     chunk = 2048
     t0 = time.perf_counter()
     filled = 0
+    stream = args.stream or args.frame_dedup
+    t_next = 0
+    seq = rng.randint(0, 256, size=(20480 + 4096 + 8, 84, 84), dtype=np.uint8) if stream else None  # one long episode of frames
+
+    def stacks(t0, m):
+        """state_t = frames t..t+3, next_state_t = frames t+n..t+n+3 (4-frame stack, n-step assembler)"""
+        win = np.lib.stride_tricks.sliding_window_view(seq, 4, axis=0)  # [T-3, 84, 84, 4]
+        st = np.ascontiguousarray(np.moveaxis(win[t0 : t0 + m], -1, 1))
+        ns = np.ascontiguousarray(np.moveaxis(win[t0 + n : t0 + n + m], -1, 1))
+        return st, ns
+
     while filled < min(N, 20000):
         m = min(chunk, N - filled)
+        if stream:
+            st, ns = stacks(t_next, m)
+            t_next += m
+        else:
+            st, ns = rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8), rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8)
         cols = {
-            "state": rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8),
+            "state": st,
             "action": rng.randint(0, 4, size=(m, 1)),
             "reward": rng.choice([-1.0, 0.0, 1.0], p=[0.02, 0.9, 0.08], size=(m, n, 1)).astype(np.float32),
-            "next_state": rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8),
+            "next_state": ns,
             "done": (rng.rand(m, n, 1) < 1e-3),
         }
         agent.memory.store_soa(cols)
@@ -64,9 +83,12 @@ def main():
     step = 0
 
     def env_steps_and_learn():
-        nonlocal step
+        nonlocal step, t_next
         for _ in range(4):  # learn_period env steps: one store each (rainbow.py:255-262)
             step += 1
+            if stream and t_next + n + 5 < len(seq):
+                one["state"], one["next_state"] = stacks(t_next, 1)
+                t_next += 1
             agent.memory.store_soa(one)
         return agent.learn()
 
@@ -94,6 +116,8 @@ def main():
     out = {
         "workload": f"config.rainbow.atari breakout-shaped, synthetic uint8 (4,84,84), B=32, n=3, K=51, PER N={N} ({filled} filled), network backend {args.backend}",
         "backend": args.backend,
+        "stream": stream,
+        "frame_dedup": agent.memory._frames.stats() if agent.memory._frames is not None else None,
         "learner_updates_per_s": args.updates / dt,
         "env_steps_per_s_ceiling": 4 * args.updates / dt,
         "ms_per_update_incl_4_stores": dt / args.updates * 1e3,
