@@ -143,7 +143,6 @@ class DeviceStore:
             a = np.ascontiguousarray(np.asarray(cols[name]).reshape(len(cols[name]), -1), dtype=_NP_OF[dt])
             assert a.shape == (slots.size, elems)
             arrs.append(a)
-        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         for o in range(0, slots.size, 32768):  # grid.y limit
             m = min(32768, slots.size - o)
             sub = (C.c_void_p * len(arrs))(*[a[o : o + m].ctypes.data for a in arrs])
