@@ -139,6 +139,14 @@ struct jh_pponet {
   unsigned* adam_ticket = nullptr;
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
+  // grouped backward (jh_tgemm): dW2, dh1 and the head weight gradients in ONE launch.  Measured SLOWER end to end
+  // (2.67 vs 2.36 ms per bench iteration: one 19 us split-K kernel against three 6-12 us kernels that pipeline
+  // inside the graph): opt-in with JH_PPO_GROUPED_BACKWARD=1
+  int grouped_backward = 0;
+  float* tg_ws = nullptr;
+  size_t tg_ws_floats = 0;
+  unsigned* tg_cnt = nullptr;
+  int tg_cnt_slots = 0;
 };
 
 // ---------------------------------------------------------------- device helpers (wave = 64)

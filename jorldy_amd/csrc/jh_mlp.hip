@@ -17,7 +17,7 @@
 //     same permutation of K for A and B, so the sum is unchanged and every load is 16 B wide;
 //   * bias gradients (column sums of the upstream gradient) fall out of the A fragments as row
 //     sums, so they cost no extra pass.
-#include "jh_common.h"
+#include "jh_tgemm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -533,6 +533,12 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   }
   JH_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
   if (const char* e = getenv("JH_FORK_BACKWARD")) n->fork_backward = atoi(e);
+  if (const char* e = getenv("JH_PPO_GROUPED_BACKWARD")) n->grouped_backward = atoi(e);
+  n->tg_ws_floats = (size_t)4 << 20;
+  n->tg_cnt_slots = 4096;
+  JH_HIP(hipMalloc((void**)&n->tg_ws, sizeof(float) * n->tg_ws_floats));
+  JH_HIP(hipMalloc((void**)&n->tg_cnt, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
+  JH_HIP(hipMemset(n->tg_cnt, 0, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
   JH_HIP(hipMalloc((void**)&n->fwd_part, sizeof(float) * 8 * (size_t)max_rows * (size_t)(H / 16)));
   JH_HIP(hipMalloc((void**)&n->g_heads, sizeof(float) * (size_t)max_rows * (size_t)(2 * A + 1)));
   n->ssq_slots = (H / 16) * (H / 16) + (H / 16) + (H / 16) * ((S + 15) / 16);  // dW2 + dW_heads + dW1 tiles
@@ -556,6 +562,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
   (void)hipFree(n->fwd_part); (void)hipFree(n->g_heads); (void)hipFree(n->ssq_part); (void)hipFree(n->adam_ticket);
+  (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt);
   for (int i = 0; i < 2; ++i) {
     if (n->aux[i]) (void)hipStreamDestroy(n->aux[i]);
     if (n->ev_join[i]) (void)hipEventDestroy(n->ev_join[i]);
@@ -665,6 +672,33 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
   const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
   const int n_out = head_rows(n, w, dw, b, db);
   int rc;
+  if (n->grouped_backward && !fused_ssq) {
+    // dW2, dh1 and the head weight gradients only need dh2 / g_all: ONE grouped launch of the tiled MFMA GEMM
+    // (split-K over the batch / the hidden width) instead of three launches of 10-16 us each.
+    const int A = n->A;
+    TGemm g[6];
+    int ng = 0;
+    // dW2[o][i] = sum_b dh2[b][o] h1[b][i], db2 as the A-operand row sum
+    g[ng++] = mk_gemm(H, H, B, op_dense(OP_XCONT, n->dh2, H), op_dense(OP_XCONT, n->h1, H), n->grads + n->o_w2, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b2);
+    // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]
+    g[ng++] = mk_gemm(B, H, H, op_dense(OP_KCONT, n->dh2, H), op_dense(OP_XCONT, n->params + n->o_w2, H), n->dh1, H, TEPI_MASK, nullptr, n->h1, H);
+    // head weight gradients: g_all is [B][8] = (head0 A cols | head1 A cols (continuous) | value)
+    g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh0, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh0);
+    int col = A;
+    if (n->cont) {
+      g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh1, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh1);
+      col += A;
+    }
+    g[ng++] = mk_gemm(1, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wv, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bv);
+    TGemmWorkspace tw;
+    tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
+    rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd", g, ng, st);
+    if (rc) return rc;
+    GemmArgs g1{};  // dW1[j][s] = sum_b dh1[b][j] x[r(b)][s] ; db1[j] = sum_b dh1[b][j]  (B = gathered x rows [K=B][N=S])
+    g1.M = H; g1.N = S; g1.K = B; g1.A = n->dh1; g1.lda = H; g1.B = d_x; g1.ldb = S; g1.b_rows = d_idx;
+    g1.C = n->grads + n->o_w1; g1.ldc = S; g1.rowsum = n->grads + n->o_b1;
+    return launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW1", g1, st);
+  }
   // After dh2 three chains are independent: {dW_heads}, {dW2}, {dh1 -> dW1}.  Fork the first two onto
   // auxiliary streams (parallel branches of the captured graph; concurrent queues when eager) so their
   // fixed per-kernel cost overlaps with the dh1 -> dW1 chain, and join before returning.

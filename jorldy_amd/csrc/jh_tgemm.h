@@ -1,0 +1,77 @@
+// Grouped LDS-tiled fp32 MFMA GEMM engine (jh_tgemm.hip) shared by the value networks (jh_rbnet.hip) and the
+// PPO policy-value net's backward (jh_mlp.hip).
+#pragma once
+#include "jh_common.h"
+
+
+enum { OP_KCONT = 0, OP_XCONT = 1, OP_NHWC_K = 2, OP_NHWC_X = 3, OP_NCHW_K = 4, OP_NCHW_X = 5 };
+enum { TEPI_NONE = 0, TEPI_BIAS = 1, TEPI_BIAS_RELU = 2, TEPI_MASK = 3 };
+
+// One GEMM operand, element (x, k): x = the row (A) / column (B) index of C, k = reduction index.
+//   KCONT  p[x * ld + k]                      XCONT  p[k * ld + x]
+//   NHWC_K im2col(pixel = x, tap = k)         NHWC_X im2col(pixel = k, tap = x)     tap = (ky, kx, c)
+//   NCHW_K / NCHW_X the same on an NCHW image (uint8 or fp32, divided by 255: head.py:46), tap = (c, ky, kx)
+struct Opnd {
+  const void* p;
+  int ld, mode, u8, vec;
+  // im2col modes: element (pixel, tap) lives at p[pix_tab[pixel] + tap_tab[tap]] -- two small L2-resident
+  // tables built once per layer geometry instead of six integer divisions per fetch
+  const int* pix_tab;
+  const int* tap_tab;
+};
+
+struct TGemm {
+  int M, N, K;
+  Opnd a, b;
+  float* C;
+  int ldc, epi;
+  const float* bias;   // [N]
+  const float* aux;    // MASK: forward activation, same indexing as C
+  int ldaux;
+  float* rowsum;       // optional [M]: sum_k A(m, k)  (bias gradients)
+  int splitk, tiles_m, tiles_n;
+  int wg_begin;        // first workgroup of this problem in the linear grid (tiles x splits workgroups each)
+  float* ws;           // split-K partials [splitk][tiles][BM*BN + BM]
+  unsigned* cnt;       // [tiles] arrival counters (zero between launches)
+};
+constexpr int kMaxGroup = 6;
+struct TGemmBatch {
+  TGemm p[kMaxGroup];
+  int n;
+};
+
+// ---- host-side helpers
+inline Opnd op_dense(int mode, const float* p, int ld) {
+  Opnd o{};
+  o.p = p; o.ld = ld; o.mode = mode;
+  o.vec = (ld % 4 == 0) && (((uintptr_t)p & 15) == 0);
+  return o;
+}
+struct ConvGeom {
+  int C, H, W, OH, OW, KH, KW, S;
+  const int* pix_tab = nullptr;  // device tables, see Opnd
+  const int* tap_tab = nullptr;
+};
+inline Opnd op_conv(int mode, const void* p, int u8, const ConvGeom& c) {
+  Opnd o{};
+  o.p = p; o.mode = mode; o.u8 = u8; o.pix_tab = c.pix_tab; o.tap_tab = c.tap_tab;
+  if (mode <= OP_NHWC_X) o.vec = (c.C % 4 == 0) && (((uintptr_t)p & 15) == 0);
+  else o.vec = (c.KW % 4 == 0) && (c.W % 4 == 0) && (c.S % 4 == 0) && (((uintptr_t)p & (u8 ? 3 : 15)) == 0);  // every 4-tap piece aligned
+  return o;
+}
+inline TGemm mk_gemm(int M, int N, int K, const Opnd& a, const Opnd& b, float* C, int ldc, int epi, const float* bias = nullptr,
+                     const float* aux = nullptr, int ldaux = 0, float* rowsum = nullptr) {
+  TGemm g{};
+  g.M = M; g.N = N; g.K = K; g.a = a; g.b = b; g.C = C; g.ldc = ldc; g.epi = epi; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.rowsum = rowsum;
+  return g;
+}
+
+// Workspace of the split-K hand-off: `ws` floats of partial tiles + zero-initialised arrival counters.
+struct TGemmWorkspace {
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+  unsigned* cnt = nullptr;
+  int cnt_slots = 0;
+};
+// One launch for up to kMaxGroup independent problems (same tile shape, linear grid over (problem, tile, split)).
+int jh_tgemm_launch(const TGemmWorkspace& w, const char* name, TGemm* probs, int n, hipStream_t st);

@@ -1,0 +1,372 @@
+// Grouped LDS-tiled fp32 MFMA GEMM (16x16x4 MFMA): every contraction of the value networks (implicit-GEMM
+// convolutions, linear layers, data / weight gradients) and the PPO net's backward GEMMs.  See jh_tgemm.h.
+#include "jh_tgemm.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// uint8 / 255 correctly rounded without a division: q = b * (1/255), one Newton correction with exact
+// remainders (verified == b / 255.0f for all 256 byte values; tests compare against the fp32-frame path)
+__device__ __forceinline__ float u8_unit(uint32_t b) {
+  const float x = (float)b, r = 1.0f / 255.0f;
+  const float q = x * r;
+  return fmaf(fmaf(-q, 255.0f, x), r, q);
+}
+
+__device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
+  if (o.mode == OP_KCONT) return ((const float*)o.p)[(size_t)x * o.ld + k];
+  if (o.mode == OP_XCONT) return ((const float*)o.p)[(size_t)k * o.ld + x];
+  const bool kfast = !(o.mode & 1);
+  const int off = o.pix_tab[kfast ? x : k] + o.tap_tab[kfast ? k : x];
+  if (o.mode <= OP_NHWC_X) return ((const float*)o.p)[off];
+  return o.u8 ? u8_unit(((const uint8_t*)o.p)[off]) : ((const float*)o.p)[off] / 255.0f;
+}
+
+// Rare cases (ragged edges, operands that do not allow 16-byte accesses, fp32 NCHW frames): element-wise, out
+// of line so that the hot loop stays small and branch-free.
+// k-fast modes: elements (x, k..k+3).  x-fast modes: elements (x..x+3, k).  Zero outside X x K.
+__device__ __noinline__ float4 op_fetch4_slow(Opnd o, int x, int k, int X, int K) {
+  const bool kfast = !(o.mode & 1);
+  const int dx = kfast ? 0 : 1, dk = kfast ? 1 : 0;
+  float4 r;
+  r.x = (x < X && k < K) ? op_elem(o, x, k) : 0.f;
+  r.y = (x + dx < X && k + dk < K) ? op_elem(o, x + dx, k + dk) : 0.f;
+  r.z = (x + 2 * dx < X && k + 2 * dk < K) ? op_elem(o, x + 2 * dx, k + 2 * dk) : 0.f;
+  r.w = (x + 3 * dx < X && k + 3 * dk < K) ? op_elem(o, x + 3 * dx, k + 3 * dk) : 0.f;
+  return r;
+}
+
+// C[M][N] = sum_k A(m, k) B(k, n), workgroup tile (32 TM) x (32 TN), BK = 32, 4 waves as 2 x 2.
+// LDS tiles are [x][k] with a 36-float row stride: a lane's MFMA operands for 4 consecutive k are ONE
+// 16-byte LDS read (the k order inside a 16-wide block is permuted identically for A and B, which a
+// sum over k does not see), and the 16 rows a wave reads start in 16 distinct 4-bank groups.
+// Operand fetch: every lane owns fixed 4-element pieces of the A and B tiles.  When the operand allows
+// 16-byte accesses and the extent that the 4 elements run along is a multiple of 4 (a uniform, per-operand
+// test) a piece is either wholly inside or wholly outside the matrix: ONE load from a clamped address plus a
+// select, no divergent branches; anything else goes through op_fetch4_slow.
+// The grid is linear over (problem, tile, split); splitk > 1: every split writes its partial tile, the last
+// workgroup to arrive (per-tile counter) sums the partials in split order -- deterministic, no atomics on
+// data -- and runs the epilogue.
+constexpr int kTabMax = 1024;  // k-range of one split that an im2col operand can address through its LDS table
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = 36;
+  __shared__ __attribute__((aligned(16))) float sA[BM * LD];
+  __shared__ __attribute__((aligned(16))) float sB[BN * LD];
+  __shared__ int sTabA[kTabMax], sTabB[kTabMax];
+  __shared__ int s_last;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.p[i].wg_begin) pi = i;
+  const TGemm& g = batch.p[pi];
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int local = blockIdx.x - g.wg_begin;
+  const int z = local / tiles, tile = local - z * tiles;
+  const int tm_blk = tile / g.tiles_n, tn_blk = tile - tm_blk * g.tiles_n;
+  const int m0 = tm_blk * BM, n0 = tn_blk * BN;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 15, kq = lane >> 4, wm = wid & 1, wn = wid >> 1;
+  const int nchunks = (g.K + BK - 1) / BK, per = (nchunks + g.splitk - 1) / g.splitk;
+  const int kbeg = z * per * BK;
+  int kend = kbeg + per * BK;
+  if (kend > g.K) kend = g.K;
+  const bool a_kfast = !(g.a.mode & 1), b_kfast = !(g.b.mode & 1);
+  const bool a_conv = g.a.mode >= OP_NHWC_K, b_conv = g.b.mode >= OP_NHWC_K;
+  // fast (branch-free) fetch possible?  fp32 NCHW frames always take the slow path (true division by 255)
+  const bool a_fast = g.a.vec && !((a_kfast ? kend : g.M) & 3) && (g.a.mode < OP_NCHW_K || g.a.u8);
+  const bool b_fast = g.b.vec && !((b_kfast ? kend : g.N) & 3) && (g.b.mode < OP_NCHW_K || g.b.u8);
+
+  // per-slot invariants: position of the piece inside the tile, clamped coordinates, base offsets
+  int a_x[TM], a_k[TM], a_off[TM], b_x[TN], b_k[TN], b_off[TN];
+  // im2col operands: the offset term that follows k (taps for k-fast, pixels for x-fast) is staged in LDS for
+  // this split's whole k range; the term that follows x is fixed per slot and sits in a register.
+  if (a_conv) {
+    const int* ktab = a_kfast ? g.a.tap_tab : g.a.pix_tab;
+    for (int i = t; i < kend - kbeg; i += 256) sTabA[i] = ktab[kbeg + i];
+  }
+  if (b_conv) {
+    const int* ktab = b_kfast ? g.b.tap_tab : g.b.pix_tab;
+    for (int i = t; i < kend - kbeg; i += 256) sTabB[i] = ktab[kbeg + i];
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int e = t + 256 * i;
+    a_x[i] = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
+    a_k[i] = a_kfast ? 4 * (e & 7) : e / (BM / 4);
+    const int xc = a_kfast ? (a_x[i] < g.M ? a_x[i] : g.M - 1) : (a_x[i] + 3 < g.M ? a_x[i] : (g.M >= 4 ? g.M - 4 : 0));
+    a_off[i] = a_conv ? (a_kfast ? g.a.pix_tab : g.a.tap_tab)[xc] : (a_kfast ? xc * g.a.ld : xc);
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int e = t + 256 * i;
+    b_x[i] = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
+    b_k[i] = b_kfast ? 4 * (e & 7) : e / (BN / 4);
+    const int xc = b_kfast ? (b_x[i] < g.N ? b_x[i] : g.N - 1) : (b_x[i] + 3 < g.N ? b_x[i] : (g.N >= 4 ? g.N - 4 : 0));
+    b_off[i] = b_conv ? (b_kfast ? g.b.pix_tab : g.b.tap_tab)[xc] : (b_kfast ? xc * g.b.ld : xc);
+  }
+  if (a_conv || b_conv) __syncthreads();
+
+  // one piece: (operand, fast?, conv?, kfast?, x, in-tile k, slot offset, LDS table, extent X) at chunk k0
+  auto fetch = [&](const Opnd& o, bool fast, bool conv, bool kfast, int x, int kin, int off, const int* tab, int X, int k0, float (&v)[4]) {
+    const int k = k0 + kin;
+    if (fast) {
+      const int last = kfast ? kend - 4 : kend - 1;       // clamped: the load itself is always in bounds
+      const int kc = k < last ? k : last;
+      const bool ok = (kfast ? x < X : x + 3 < X) && k < kend;
+      float4 q;
+      if (!conv) {
+        q = *reinterpret_cast<const float4*>((const float*)o.p + (kfast ? (size_t)off + kc : (size_t)kc * o.ld + off));
+      } else if (o.mode <= OP_NHWC_X) {
+        q = *reinterpret_cast<const float4*>((const float*)o.p + off + tab[kc - kbeg]);
+      } else {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>((const uint8_t*)o.p + off + tab[kc - kbeg]);
+        q = make_float4(u8_unit(w & 255u), u8_unit((w >> 8) & 255u), u8_unit((w >> 16) & 255u), u8_unit(w >> 24));
+      }
+      v[0] = ok ? q.x : 0.f; v[1] = ok ? q.y : 0.f; v[2] = ok ? q.z : 0.f; v[3] = ok ? q.w : 0.f;
+    } else {
+      const float4 q = op_fetch4_slow(o, x, k, X, kend);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+  };
+  float ra[TM][4], rb[TN][4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fetch(g.a, a_fast, a_conv, a_kfast, a_x[i], a_k[i], a_off[i], sTabA, g.M, k0, ra[i]);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fetch(g.b, b_fast, b_conv, b_kfast, b_x[i], b_k[i], b_off[i], sTabB, g.N, k0, rb[i]);
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int xr = a_x[i] - m0;
+      if (a_kfast) {
+        *reinterpret_cast<float4*>(&sA[xr * LD + a_k[i]]) = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sA[(xr + j) * LD + a_k[i]] = ra[i][j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int xr = b_x[i] - n0;
+      if (b_kfast) {
+        *reinterpret_cast<float4*>(&sB[xr * LD + b_k[i]]) = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sB[(xr + j) * LD + b_k[i]] = rb[i][j];
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+  const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
+
+  // tile i: registers -> LDS, refill the registers with tile i + 1 (its HBM loads fly under the MFMAs of tile i)
+  if (kbeg < kend) gload(kbeg);
+#pragma unroll 1
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    sstore();
+    __syncthreads();
+    if (k0 + BK < kend) gload(k0 + BK);
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 16) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 q = *reinterpret_cast<const float4*>(&sA[(wm * 16 * TM + 16 * i + r) * LD + kb + 4 * kq]);
+        a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
+        if (want_rs && wn == 0) rs[i] += (q.x + q.y) + (q.z + q.w);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(&sB[(wn * 16 * TN + 16 * j + r) * LD + kb + 4 * kq]);
+        b[j][0] = q.x; b[j][1] = q.y; b[j][2] = q.z; b[j][3] = q.w;
+      }
+      // consecutive MFMAs go to different accumulators (dependent issue costs 40 cycles instead of 32)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c], b[j][c], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (want_rs && wn == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      rs[i] += __shfl_xor(rs[i], 16, 64);
+      rs[i] += __shfl_xor(rs[i], 32, 64);
+    }
+  }
+
+  auto epilogue = [&](float v, int m, int n) -> float {
+    if (g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU) v += g.bias[n];
+    if (g.epi == TEPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+    if (g.epi == TEPI_MASK) v = g.aux[(size_t)m * g.ldaux + n] > 0.f ? v : 0.f;
+    return v;
+  };
+
+  if (g.splitk > 1) {
+    // Split-K hand-off without __threadfence(): on a multi-XCD part an agent-scope fence writes back / invalidates
+    // the whole per-XCD L2, which costs more than the GEMM.  Partials are written and read with sc1 (agent-coherent)
+    // 16-byte accesses instead; s_waitcnt vmcnt(0) makes sure this wave's partial stores have completed before its
+    // workgroup takes a ticket.  Partials are stored fragment-major ([wave][tile i][tile j][lane][4]): a lane's
+    // accumulator registers are one 16-byte store, and the last workgroup to arrive rebuilds ITS accumulators as
+    // the sum over all splits in split order (deterministic) and falls through to the common epilogue.
+    constexpr int PSTRIDE = BM * BN + BM;
+    float* mine = g.ws + ((size_t)z * tiles + tile) * PSTRIDE;
+    const int frag0 = (wid * TM * TN * 64 + lane) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* dst = mine + frag0 + (i * TN + j) * 256;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+      }
+      if (want_rs && wn == 0 && kq == 0)
+        __hip_atomic_store(mine + BM * BN + wm * 16 * TM + 16 * i + r, rs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == (unsigned)g.splitk - 1;
+      if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* base = g.ws + (size_t)tile * PSTRIDE;
+    const size_t zstride = (size_t)tiles * PSTRIDE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int UNR = 4;  // UNR x TM x TN 16-byte loads in flight per lane
+    for (int sp = 0; sp < g.splitk; sp += UNR) {
+      f32x4 part[UNR][TM * TN];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int spc = sp + u < g.splitk ? sp + u : g.splitk - 1;  // clamped: uniform control flow around the asm loads
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          const float* src = base + spc * zstride + frag0 + q * 256;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[u][q]) : "v"(src) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          asm volatile("" : "+v"(part[u][q]));  // the values are only valid after the wait above
+          if (sp + u < g.splitk) acc[q / TN][q % TN] += part[u][q];
+        }
+      }
+    }
+    if (want_rs && wn == 0 && kq == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v = 0.f;
+        for (int sp = 0; sp < g.splitk; ++sp)
+          v += __hip_atomic_load(base + sp * zstride + BM * BN + wm * 16 * TM + 16 * i + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rs[i] = v;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 16 * TN + 16 * j + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+        const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
+        if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(acc[i][j][q], m, n);
+      }
+    }
+    if (want_rs && wn == 0 && kq == 0) {
+      const int m = m0 + wm * 16 * TM + 16 * i + r;
+      if (m < g.M) g.rowsum[m] = rs[i];
+    }
+  }
+}
+
+}  // namespace
+
+int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs, int n, hipStream_t st) {
+  if (n < 1 || n > kMaxGroup) return jh_fail(JH_ERR_ARG, "tgemm group of %d", n);
+  int maxM = 0, maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    if (probs[i].M > maxM) maxM = probs[i].M;
+    if (probs[i].N > maxN) maxN = probs[i].N;
+  }
+  const int TM = maxM <= 32 ? 1 : 2, TN = maxN <= 32 ? 1 : 2;
+  const int BM = 32 * TM, BN = 32 * TN;
+  int max_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    probs[i].tiles_m = (probs[i].M + BM - 1) / BM;
+    probs[i].tiles_n = (probs[i].N + BN - 1) / BN;
+    const int t = probs[i].tiles_m * probs[i].tiles_n;
+    if (t > max_tiles) max_tiles = t;
+  }
+  // fill the chip: ~2 workgroups per CU, but every split keeps at least two 32-wide K chunks
+  size_t ws_used = 0;
+  int cnt_used = 0, max_split = 1;
+  for (int i = 0; i < n; ++i) {
+    const int tiles = probs[i].tiles_m * probs[i].tiles_n;
+    const int nchunks = (probs[i].K + 31) / 32;
+    // split K only when the tiles alone leave most of the 256 CUs idle; every split keeps >= 4 chunks of 32
+    int s = tiles >= 128 ? 1 : 256 / (tiles > 0 ? tiles : 1);
+    if (s > nchunks / 4) s = nchunks / 4;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    const bool conv = probs[i].a.mode >= OP_NHWC_K || probs[i].b.mode >= OP_NHWC_K;
+    const int min_s = conv ? (nchunks * 32 + kTabMax - 1) / kTabMax : 1;  // an im2col operand's k range must fit its LDS table
+    if (s < min_s) s = min_s;
+    const size_t pstride = (size_t)BM * BN + BM;
+    while (s > min_s && (ws_used + (size_t)s * tiles * pstride > net_w.ws_floats || cnt_used + tiles > net_w.cnt_slots)) --s;
+    if (s > 1 && (ws_used + (size_t)s * tiles * pstride > net_w.ws_floats || cnt_used + tiles > net_w.cnt_slots))
+      return jh_fail(JH_ERR_NOMEM, "%s: split-K workspace too small (%d tiles x %d splits)", name, tiles, s);
+    // no empty splits: shrink to the number of splits that actually own chunks
+    if (s > 1) {
+      const int per = (nchunks + s - 1) / s;
+      s = (nchunks + per - 1) / per;
+      if (conv && per * 32 > kTabMax) return jh_fail(JH_ERR_STATE, "%s: im2col k range %d exceeds the LDS table", name, per * 32);
+    }
+    probs[i].splitk = s;
+    if (s > 1) {
+      probs[i].ws = net_w.ws + ws_used;
+      probs[i].cnt = net_w.cnt + cnt_used;
+      ws_used += (size_t)s * tiles * pstride;
+      cnt_used += tiles;
+    }
+    if (s > max_split) max_split = s;
+  }
+  TGemmBatch batch{};
+  int wgs = 0;
+  for (int i = 0; i < n; ++i) {
+    probs[i].wg_begin = wgs;
+    wgs += probs[i].tiles_m * probs[i].tiles_n * probs[i].splitk;
+    batch.p[i] = probs[i];
+  }
+  batch.n = n;
+  (void)max_tiles; (void)max_split;
+  const dim3 grid(wgs);
+  if (TM == 2 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 2>), grid, dim3(256), 0, st, batch);
+  else if (TM == 1 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<1, 2>), grid, dim3(256), 0, st, batch);
+  else if (TM == 2 && TN == 1) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 1>), grid, dim3(256), 0, st, batch);
+  else JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<1, 1>), grid, dim3(256), 0, st, batch);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
