@@ -142,7 +142,8 @@ struct jh_pponet {
   // grouped backward (jh_tgemm): dW2, dh1 and the head weight gradients in ONE launch.  Measured SLOWER end to end
   // (2.67 vs 2.36 ms per bench iteration: one 19 us split-K kernel against three 6-12 us kernels that pipeline
   // inside the graph): opt-in with JH_PPO_GROUPED_BACKWARD=1
-  int grouped_backward = 0;
+  int grouped_backward = -1;  // -1 auto: minibatches >= 1024 rows (there the LDS-tiled engine wins by a wide margin), 0 never, 1 always
+  float* xg = nullptr;        // [max_rows][S] gathered observation rows (B operand of dW1 on the tiled engine)
   float* tg_ws = nullptr;
   size_t tg_ws_floats = 0;
   unsigned* tg_cnt = nullptr;

@@ -536,6 +536,7 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   if (const char* e = getenv("JH_PPO_GROUPED_BACKWARD")) n->grouped_backward = atoi(e);
   n->tg_ws_floats = (size_t)4 << 20;
   n->tg_cnt_slots = 4096;
+  JH_HIP(hipMalloc((void**)&n->xg, sizeof(float) * (size_t)max_rows * (size_t)S));
   JH_HIP(hipMalloc((void**)&n->tg_ws, sizeof(float) * n->tg_ws_floats));
   JH_HIP(hipMalloc((void**)&n->tg_cnt, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
   JH_HIP(hipMemset(n->tg_cnt, 0, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
@@ -562,7 +563,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
   (void)hipFree(n->fwd_part); (void)hipFree(n->g_heads); (void)hipFree(n->ssq_part); (void)hipFree(n->adam_ticket);
-  (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt);
+  (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt); (void)hipFree(n->xg);
   for (int i = 0; i < 2; ++i) {
     if (n->aux[i]) (void)hipStreamDestroy(n->aux[i]);
     if (n->ev_join[i]) (void)hipEventDestroy(n->ev_join[i]);
@@ -625,6 +626,15 @@ static int head_rows(jh_pponet* n, const float* w[8], float* dw[8], const float*
 
 // x: [*, S] rows (device, or pinned host memory mapped into the device address space), gathered
 // through d_idx when given.  Activations h1/h2 stay in the net's workspace for a following backward.
+static inline bool pponet_use_tiled(const jh_pponet* n, int B) { return n->grouped_backward == 1 || (n->grouped_backward < 0 && B >= 1024); }
+
+__global__ void __launch_bounds__(256) jh_rowgather_f32_kernel(int B, int S, const float* __restrict__ x, const int64_t* __restrict__ idx, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * S) return;
+  const int b = (int)(i / S), s = (int)(i - (int64_t)b * S);
+  out[i] = x[(idx ? idx[b] : (int64_t)b) * S + s];
+}
+
 JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, float* d_head0,
                                 float* d_head1, float* d_value, jh_stream stream) {
   JH_ARG(n && d_x && d_head0 && d_value);
@@ -636,10 +646,18 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   JH_LAUNCH(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, H, d_x, d_idx,
             n->params + n->o_w1, n->params + n->o_b1, n->h1);
   JH_LAUNCH_CHECK();
-  GemmArgs g{};
-  g.M = B; g.N = H; g.K = H; g.A = n->h1; g.lda = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->h2; g.ldc = H;
-  g.aux = n->params + n->o_b2;
-  int rc = launch_gemm<0, true, EPI_BIAS_RELU, false, 1, 1>("jh_gemm16_fwd_h2", g, st);
+  int rc;
+  if (pponet_use_tiled(n, B)) {  // large batches: LDS-tiled engine (operand reuse across the 64 x 64 tile)
+    TGemm tg = mk_gemm(B, H, H, op_dense(OP_KCONT, n->h1, H), op_dense(OP_KCONT, n->params + n->o_w2, H), n->h2, H, TEPI_BIAS_RELU, n->params + n->o_b2);
+    TGemmWorkspace tw;
+    tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
+    rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_fwd_h2", &tg, 1, st);
+  } else {
+    GemmArgs g{};
+    g.M = B; g.N = H; g.K = H; g.A = n->h1; g.lda = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->h2; g.ldc = H;
+    g.aux = n->params + n->o_b2;
+    rc = launch_gemm<0, true, EPI_BIAS_RELU, false, 1, 1>("jh_gemm16_fwd_h2", g, st);
+  }
   if (rc) return rc;
   HeadPtrs hp = head_ptrs(n, d_head0, d_head1, d_value, nullptr, nullptr, nullptr);
   JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp);
@@ -672,7 +690,7 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
   const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
   const int n_out = head_rows(n, w, dw, b, db);
   int rc;
-  if (n->grouped_backward && !fused_ssq) {
+  if (pponet_use_tiled(n, B) && !fused_ssq) {
     // dW2, dh1 and the head weight gradients only need dh2 / g_all: ONE grouped launch of the tiled MFMA GEMM
     // (split-K over the batch / the hidden width) instead of three launches of 10-16 us each.
     const int A = n->A;
@@ -694,6 +712,12 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
     tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
     rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd", g, ng, st);
     if (rc) return rc;
+    if (B >= 1024) {  // dW1 on the tiled engine too (K = B is long): gather the observation rows once
+      JH_LAUNCH(jh_rowgather_f32_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, st, B, S, d_x, d_idx, n->xg);
+      JH_LAUNCH_CHECK();
+      g[0] = mk_gemm(H, S, B, op_dense(OP_XCONT, n->dh1, H), op_dense(OP_XCONT, n->xg, S), n->grads + n->o_w1, S, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b1);
+      return jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd_dW1", g, 1, st);
+    }
     GemmArgs g1{};  // dW1[j][s] = sum_b dh1[b][j] x[r(b)][s] ; db1[j] = sum_b dh1[b][j]  (B = gathered x rows [K=B][N=S])
     g1.M = H; g1.N = S; g1.K = B; g1.A = n->dh1; g1.lda = H; g1.B = d_x; g1.ldb = S; g1.b_rows = d_idx;
     g1.C = n->grads + n->o_w1; g1.ldc = S; g1.rowsum = n->grads + n->o_b1;
