@@ -331,6 +331,14 @@ int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream);
 int jh_rbnet_optim_step(jh_rbnet* n, int32_t optimizer, float max_norm, jh_stream stream);
 int jh_rbnet_adam_step(jh_rbnet* n, jh_stream stream);
 
+/* The dense form of the grouped LDS-tiled fp32 MFMA GEMM every value-network layer runs on (nn.Linear forward /
+ * data gradient / weight gradient of the core/network modules): C[M][N] = sum_k A(m,k) B(k,n) with a fused epilogue.
+ *   a_kcont != 0: A stored [M][K] (lda), else [K][M];   b_kcont != 0: B stored [N][K] (ldb), else [K][N]
+ *   epi 0 none | 1 + bias[n] | 2 relu(. + bias[n]) | 3 zero where aux[m][n] <= 0;  d_rowsum (optional) [M] = sum_k A(m,k) */
+int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* d_a, int32_t lda, int32_t a_kcont, const float* d_b,
+                   int32_t ldb, int32_t b_kcont, float* d_c, int32_t ldc, int32_t epi, const float* d_bias, const float* d_aux,
+                   int32_t ldaux, float* d_rowsum, jh_stream stream);
+
 /* ------------------------------------------------------------------ asynchronous actor -> learner staging
  * Replaces the async path's transport (run_mode.py:212-363 async_distributed_train: Ray actors -> manager
  * process -> multiprocessing trans_queue -> `gather_thread` spinning on flags, process.py:7-31,82-97) for

@@ -370,3 +370,33 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   return JH_OK;
 }
 
+
+// C-ABI entry for the dense modes (parity tests; also usable on its own): C[M][N] = A (.) B with a fused epilogue.
+//   a_kcont != 0: A stored [M][K] (lda)   else stored [K][M] (transposed operand of a weight gradient)
+//   b_kcont != 0: B stored [N][K] (ldb)   else stored [K][N]
+//   epi 0 none | 1 + bias[n] | 2 relu(+ bias[n]) | 3 mask by aux[m][n] > 0;  d_rowsum (optional) [M] = sum_k A(m, k)
+struct jh_tgemm_ws_holder {
+  TGemmWorkspace w;
+};
+static thread_local jh_tgemm_ws_holder g_dense_ws;
+
+JH_EXPORT int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* d_a, int32_t lda, int32_t a_kcont, const float* d_b, int32_t ldb,
+                             int32_t b_kcont, float* d_c, int32_t ldc, int32_t epi, const float* d_bias, const float* d_aux, int32_t ldaux, float* d_rowsum,
+                             jh_stream stream) {
+  JH_ARG(ctx && d_a && d_b && d_c);
+  JH_ARG(M > 0 && N > 0 && K > 0 && epi >= 0 && epi <= 3);
+  JH_ARG((epi != 1 && epi != 2) || d_bias);
+  JH_ARG(epi != 3 || d_aux);
+  JH_HIP(hipSetDevice(ctx->device));
+  TGemmWorkspace& w = g_dense_ws.w;
+  if (!w.ws) {  // one lazily created workspace per calling thread (split-K partials + arrival counters)
+    w.ws_floats = (size_t)4 << 20;
+    w.cnt_slots = 4096;
+    JH_HIP(hipMalloc((void**)&w.ws, sizeof(float) * w.ws_floats));
+    JH_HIP(hipMalloc((void**)&w.cnt, sizeof(unsigned) * (size_t)w.cnt_slots));
+    JH_HIP(hipMemset(w.cnt, 0, sizeof(unsigned) * (size_t)w.cnt_slots));
+  }
+  TGemm g = mk_gemm(M, N, K, op_dense(a_kcont ? OP_KCONT : OP_XCONT, d_a, lda), op_dense(b_kcont ? OP_KCONT : OP_XCONT, d_b, ldb), d_c, ldc, epi, d_bias, d_aux, ldaux,
+                    d_rowsum);
+  return jh_tgemm_launch(w, "jh_tgemm_dense", &g, 1, jh_s(stream));
+}

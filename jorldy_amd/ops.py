@@ -758,3 +758,19 @@ class StagingRing:
         a, b, w = C.c_int64(), C.c_int64(), C.c_double()
         L.check(self.lib.jh_ring_stats(self.h, C.byref(a), C.byref(b), C.byref(w)))
         return {"produced": a.value, "drained": b.value, "producer_wait_ms": w.value}
+
+
+def tgemm_dense(a, b, a_kcont=True, b_kcont=True, epi=0, bias=None, aux=None, rowsum=False, M=None, N=None, K=None):
+    """jh_tgemm_dense: C = A (.) B on the grouped LDS-tiled fp32 MFMA engine (dense operand modes).
+    a: [M, K] if a_kcont else [K, M];  b: [N, K] if b_kcont else [K, N]  (row-major, any row stride)."""
+    lib = L.load()
+    M = (a.shape[0] if a_kcont else a.shape[1]) if M is None else M
+    K = (a.shape[1] if a_kcont else a.shape[0]) if K is None else K
+    N = (b.shape[0] if b_kcont else b.shape[1]) if N is None else N
+    assert a.stride(-1) == 1 and b.stride(-1) == 1 and a.dtype == b.dtype == torch.float32
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    rs = torch.empty(M, dtype=torch.float32, device=a.device) if rowsum else None
+    pa, pb = C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr())  # row-strided views are fine: the stride is passed as lda / ldb
+    L.check(lib.jh_tgemm_dense(L.ctx(a.device.index), int(M), int(N), int(K), pa, int(a.stride(0)), int(bool(a_kcont)), pb, int(b.stride(0)), int(bool(b_kcont)),
+                               L.ptr(c), int(c.stride(0)), int(epi), L.ptr(bias), L.ptr(aux), int(aux.stride(0)) if aux is not None else 0, L.ptr(rs), L.stream_ptr()))
+    return (c, rs) if rowsum else c
