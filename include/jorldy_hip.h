@@ -281,6 +281,7 @@ int jh_collector_stats(jh_collector* c, double* act_us_per_step, double* env_us_
  * The encoders of the DQN / Rainbow / Ape-X family with their learn()-side network work:
  *   kind 0  rainbow  core/network/rainbow.py:8-94: head -> l -> noisy a1|v1 -> noisy a2, v2 -> dueling over K atoms
  *                    (utils.py:55-107 factorised noisy linear)
+ *   kind 3  rainbow with independent Gaussian noise (utils.py:72-79): one draw per weight instead of the outer product
  *   kind 1  dueling  core/network/dueling.py:8-35: head -> l1_a|l1_v -> l2_a, l2_v -> dueling combine  (K = 1)
  *   kind 2  q        core/network/q_network.py:8-20: head -> l -> q                                    (K = 1)
  * on core/network/head.py:6-61 (MLP or Nature-CNN head), plus the three forwards / backward / optimizer step
@@ -308,7 +309,8 @@ int64_t jh_rbnet_param_count(const jh_rbnet* n);
 int32_t jh_rbnet_segment_count(void);
 int jh_rbnet_segment(const jh_rbnet* n, int32_t i, int64_t* offset, int32_t* rows, int32_t* cols);
 /* Length of one noise set (kind 0): N(0,1) draws in the reference's draw order (utils.py:58-60, layers a1, v1,
- * a2, v2): [e_in a1 H][e_out a1 H][e_in v1 H][e_out v1 H][e_in a2 H][e_out a2 A*K][e_in v2 H][e_out v2 K] */
+ * a2, v2): [e_in a1 H][e_out a1 H][e_in v1 H][e_out v1 H][e_in a2 H][e_out a2 A*K][e_in v2 H][e_out v2 K];
+ * kind 3: per layer [eps_w (in x out, row-major like the reference's mu_w)][eps_b (out)]                   */
 int64_t jh_rbnet_noise_len(const jh_rbnet* n);
 /* Adam: (lr, beta1, beta2, eps).  RMSprop: (lr, alpha, unused, eps) + centered.  step = optimizer step counter. */
 int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1_or_alpha, float beta2, float eps, int64_t step, int32_t centered,

@@ -24,7 +24,7 @@ def native_supported(network, head, state_size, hidden_size, optim_config, noise
         ok_opt = False
     ok_state = (head == "mlp" and np.isscalar(state_size)) or (
         head == "cnn" and not np.isscalar(state_size) and len(state_size) == 3 and all(np.isscalar(v) for v in state_size))
-    return (network in _KIND_OF and (network != "rainbow" or noise_type == "factorized") and ok_state and hidden_size % 4 == 0 and ok_opt)
+    return (network in _KIND_OF and (network != "rainbow" or noise_type in ("factorized", "independent")) and ok_state and hidden_size % 4 == 0 and ok_opt)
 
 
 class NativeNet:
@@ -60,7 +60,8 @@ class NativeNet:
         return self
 
     def pack_noise(self, noise, out=None):
-        """{tag: (e_in, e_out)} (the torch mirror's injection format) -> one flat noise set."""
+        """{tag: (e_in, e_out)} / {tag: (eps_w [in, out], eps_b)} (the torch mirror's injection format for factorised /
+        independent noise) -> one flat noise set."""
         flat = torch.cat([torch.cat([noise[t][0].reshape(-1), noise[t][1].reshape(-1)]) for t in ("a1", "v1", "a2", "v2")]).to(self._net.device, torch.float32)
         assert flat.numel() == self._net.noise_len
         if out is not None:
@@ -84,8 +85,8 @@ class NativeValueNetMixin:
     """Agent-side plumbing of the native backend (state kept on the agent: _net, _opt_name, _optim_config,
     _lr0, _lr_now, _adam_steps)."""
 
-    def _init_native(self, network, state_size, action_size, num_support, hidden_size, head, batch_size, optim_config, torch_net):
-        self._net = ops.RainbowNet(state_size, action_size, num_support, hidden_size, head, batch_size, self.device, kind=_KIND_OF[network])
+    def _init_native(self, network, state_size, action_size, num_support, hidden_size, head, batch_size, optim_config, torch_net, noise_type="factorized"):
+        self._net = ops.RainbowNet(state_size, action_size, num_support, hidden_size, head, batch_size, self.device, kind=_KIND_OF[network], noise_type=noise_type)
         self._net.import_state(torch_net.state_dict())  # the reference's initialisation (orthogonal / uniform, utils.py:89-124)
         self._net.sync_target()
         self.network, self.target_network = NativeNet(self._net, 0), NativeNet(self._net, 1)

@@ -106,7 +106,7 @@ class Rainbow(DQN):
         mk = lambda: Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head).to(self.device)
         self._net = None
         if self.backend == "native":
-            self._init_native(network, state_size, action_size, num_support, hidden_size, head, batch_size, optim_config, mk())
+            self._init_native(network, state_size, action_size, num_support, hidden_size, head, batch_size, optim_config, mk(), noise_type=noise_type)
         else:
             self.network, self.target_network = mk(), mk()
             self.target_network.load_state_dict(self.network.state_dict())

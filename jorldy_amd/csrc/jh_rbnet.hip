@@ -29,6 +29,7 @@ struct NoisyDims {
   int64_t o_av1, o_bav1, o_a2, o_ba2, o_v2, o_bv2, set_stride;  // inside one effective-weight set
   int64_t p_mu_av1, p_sig_av1, p_mub_av1, p_sigb_av1, p_mu_a2, p_sig_a2, p_mub_a2, p_sigb_a2, p_mu_v2, p_sig_v2, p_mub_v2, p_sigb_v2;
   int64_t noise_len;
+  int independent;  // utils.py:73-76: a full eps_w [in][out] + eps_b [out] per layer instead of the outer product
 };
 
 // factor pair (f_j of the output unit, f_i of the input unit) for flat index i of the weight part
@@ -37,37 +38,46 @@ __device__ __forceinline__ void noisy_locate(const NoisyDims& d, int64_t i, cons
   const int64_t n_av1 = (int64_t)2 * H * H, n_a2 = (int64_t)d.NA * H, n_v2 = (int64_t)d.K * H;
   int64_t n, k;
   const float *ei, *ej;
+  // independent noise, one set: [eps_w a1 H x H (in, out)][eps_b a1 H][eps_w v1][eps_b v1][eps_w a2 H x NA][eps_b a2 NA][eps_w v2 H x K][eps_b v2 K]
+  const int64_t hh = (int64_t)H * H, i_a1 = 0, i_v1 = hh + H, i_a2 = 2 * (hh + H), i_v2 = i_a2 + (int64_t)H * d.NA + d.NA;
+  int64_t ind = 0;  // index of this weight's own draw (independent noise)
   if (i < n_av1) {
     n = i / H; k = i - n * H;
     *p_mu = d.p_mu_av1 + i; *p_sig = d.p_sig_av1 + i; *w_off = d.o_av1 + i;
-    if (n < H) { ei = e; ej = e + H; } else { ei = e + 2 * H; ej = e + 3 * H; n -= H; }
+    if (n < H) { ei = e; ej = e + H; ind = i_a1 + k * H + n; } else { ei = e + 2 * H; ej = e + 3 * H; n -= H; ind = i_v1 + k * H + n; }
   } else if (i < n_av1 + n_a2) {
     i -= n_av1;
     n = i / H; k = i - n * H;
     *p_mu = d.p_mu_a2 + i; *p_sig = d.p_sig_a2 + i; *w_off = d.o_a2 + i;
     ei = e + 4 * H; ej = e + 5 * H;
+    ind = i_a2 + k * d.NA + n;
   } else if (i < n_av1 + n_a2 + n_v2) {
     i -= n_av1 + n_a2;
     n = i / H; k = i - n * H;
     *p_mu = d.p_mu_v2 + i; *p_sig = d.p_sig_v2 + i; *w_off = d.o_v2 + i;
     ei = e + 5 * H + d.NA; ej = e + 6 * H + d.NA;
-  } else {  // biases: eps_b = f_j (utils.py:69)
+    ind = i_v2 + k * d.K + n;
+  } else {  // biases: eps_b = f_j (utils.py:69) / its own draw (utils.py:76)
     i -= n_av1 + n_a2 + n_v2;
     if (i < 2 * H) {
       *p_mu = d.p_mub_av1 + i; *p_sig = d.p_sigb_av1 + i; *w_off = d.o_bav1 + i;
-      *eps = e ? noise_f(i < H ? e[H + i] : e[3 * H + (i - H)]) : 0.f;
+      if (d.independent) *eps = e ? (i < H ? e[i_a1 + hh + i] : e[i_v1 + hh + (i - H)]) : 0.f;
+      else *eps = e ? noise_f(i < H ? e[H + i] : e[3 * H + (i - H)]) : 0.f;
     } else if (i < 2 * H + d.NA) {
       i -= 2 * H;
       *p_mu = d.p_mub_a2 + i; *p_sig = d.p_sigb_a2 + i; *w_off = d.o_ba2 + i;
-      *eps = e ? noise_f(e[5 * H + i]) : 0.f;
+      if (d.independent) *eps = e ? e[i_a2 + (int64_t)H * d.NA + i] : 0.f;
+      else *eps = e ? noise_f(e[5 * H + i]) : 0.f;
     } else {
       i -= 2 * H + d.NA;
       *p_mu = d.p_mub_v2 + i; *p_sig = d.p_sigb_v2 + i; *w_off = d.o_bv2 + i;
-      *eps = e ? noise_f(e[6 * H + d.NA + i]) : 0.f;
+      if (d.independent) *eps = e ? e[i_v2 + (int64_t)H * d.K + i] : 0.f;
+      else *eps = e ? noise_f(e[6 * H + d.NA + i]) : 0.f;
     }
     return;
   }
-  *eps = e ? noise_f(ei[k]) * noise_f(ej[n]) : 0.f;  // torch.outer(f_i, f_j)
+  if (d.independent) *eps = e ? e[ind] : 0.f;
+  else *eps = e ? noise_f(ei[k]) * noise_f(ej[n]) : 0.f;  // torch.outer(f_i, f_j)
 }
 
 struct NoiseSets {
@@ -248,7 +258,7 @@ struct jh_rbnet {
   // kind 0 rainbow: head -> l -> noisy a1|v1 -> noisy a2, v2 -> dueling over K atoms   (network/rainbow.py:8-94)
   //      1 dueling: head -> l1_a|l1_v -> l2_a, l2_v -> dueling combine (K = 1)         (network/dueling.py:8-35)
   //      2 q:       head -> l -> q                                                      (network/q_network.py:8-20)
-  int kind = 0, noisy = 1, dueling = 1, has_l = 1, has_av1 = 1, in1 = 0;
+  int kind = 0, noisy = 1, dueling = 1, has_l = 1, has_av1 = 1, in1 = 0, noise_independent = 0;
   float* norm_partial = nullptr;
   int NA4 = 0, K4 = 0;
   ConvGeom c1{}, c2{}, c3{};
@@ -294,7 +304,11 @@ static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
 static int rb_layout(jh_rbnet* n, int32_t kind, int32_t head_cnn, int32_t c_or_s, int32_t h_in, int32_t w_in, int32_t hidden, int32_t A, int32_t K,
                      int32_t max_batch) {
-  JH_ARG(kind >= 0 && kind <= 2);
+  JH_ARG(kind >= 0 && kind <= 3);
+  if (kind == 3) {  // rainbow with independent Gaussian noise (utils.py:72-79)
+    n->noise_independent = 1;
+    kind = 0;
+  }
   JH_ARG(hidden > 0 && hidden % 4 == 0 && A > 0 && max_batch > 0 && c_or_s > 0);
   JH_ARG(kind == 0 ? K > 1 : K == 1);
   n->kind = kind; n->noisy = kind == 0; n->dueling = kind != 2; n->has_l = kind != 1; n->has_av1 = kind != 2;
@@ -350,7 +364,8 @@ static int rb_layout(jh_rbnet* n, int32_t kind, int32_t head_cnn, int32_t c_or_s
   d.p_mu_av1 = n->seg_off[SEG_MU_AV1]; d.p_sig_av1 = n->seg_off[SEG_SIG_AV1]; d.p_mub_av1 = n->seg_off[SEG_MUB_AV1]; d.p_sigb_av1 = n->seg_off[SEG_SIGB_AV1];
   d.p_mu_a2 = n->seg_off[SEG_MU_A2]; d.p_sig_a2 = n->seg_off[SEG_SIG_A2]; d.p_mub_a2 = n->seg_off[SEG_MUB_A2]; d.p_sigb_a2 = n->seg_off[SEG_SIGB_A2];
   d.p_mu_v2 = n->seg_off[SEG_MU_V2]; d.p_sig_v2 = n->seg_off[SEG_SIG_V2]; d.p_mub_v2 = n->seg_off[SEG_MUB_V2]; d.p_sigb_v2 = n->seg_off[SEG_SIGB_V2];
-  d.noise_len = (int64_t)6 * H + n->NA + K;
+  d.independent = n->noise_independent;
+  d.noise_len = d.independent ? (int64_t)2 * ((int64_t)H * H + H) + (int64_t)H * n->NA + n->NA + (int64_t)H * K + K : (int64_t)6 * H + n->NA + K;
   n->n_noisy = (int64_t)2 * H * H + (int64_t)n->NA * H + (int64_t)K * H + 2 * H + n->NA + K;
   return JH_OK;
 }

@@ -529,7 +529,7 @@ class RainbowNet:
             "mu_v2", "sig_v2", "mub_v2", "sigb_v2")
     _KIND = {"rainbow": 0, "dueling": 1, "q": 2}
 
-    def __init__(self, state_size, action_size, num_support, hidden, head, max_batch, device, kind="rainbow"):
+    def __init__(self, state_size, action_size, num_support, hidden, head, max_batch, device, kind="rainbow", noise_type="factorized"):
         self.lib = L.load()
         self.device = torch.device(device)
         self.ctx = L.ctx(self.device.index)
@@ -541,6 +541,9 @@ class RainbowNet:
             self.Cin, self.Hin, self.Win = int(state_size), 0, 0
         self.H, self.A, self.K, self.maxB = int(hidden), int(action_size), int(num_support), int(max_batch)
         kid = self._KIND[kind]
+        self.noise_type = noise_type
+        if kind == "rainbow" and noise_type == "independent":
+            kid = 3
         n = int(self.lib.jh_rbnet_param_count_for(kid, int(self.cnn), self.Cin, self.Hin, self.Win, self.H, self.A, self.K))
         if n <= 0:
             L.check(-2)

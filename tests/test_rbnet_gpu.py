@@ -282,3 +282,46 @@ def test_tgemm_dense_random_shapes_modes_and_epilogues_match_torch():
         assert err < 2e-6, (case, M, N, K, a_kc, b_kc, epi, err)
         rs_err = float((rs.double() - a2.double().sum(1)).abs().max()) / (float(a2.abs().double().sum(1).max()) + 1e-9)
         assert rs_err < 2e-6, (case, M, N, K, "rowsum", rs_err)
+
+
+def test_rbnet_independent_noise_matches_torch():
+    """noise_type="independent" (utils.py:72-79: one Gaussian draw per weight): three forwards + backward."""
+    import torch
+    from jorldy_amd import ops
+    from jorldy_amd.core.network import Network
+
+    S, A, K, H, B = 5, 3, 11, 32, 8
+    torch.manual_seed(0)
+    ref = Network("rainbow", S, A, K, "independent", D_hidden=H, head="mlp").cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    nat = ops.RainbowNet(S, A, K, H, "mlp", B, "cuda:0", noise_type="independent")
+    nat.import_state(ref.state_dict(), nat.params)
+    nat.import_state(ref.state_dict(), nat.target)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x_all = torch.randn(2 * B, S, device="cuda", generator=g)
+    noise = torch.randn(3, nat.noise_len, device="cuda", generator=g)
+    assert nat.noise_len == 2 * (H * H + H) + H * A * K + A * K + H * K + K
+    nd = []
+    for s in range(3):
+        e, o, d = noise[s], 0, {}
+        for tag, n_out in (("a1", H), ("v1", H), ("a2", A * K), ("v2", K)):
+            d[tag] = (e[o : o + H * n_out].view(H, n_out), e[o + H * n_out : o + H * n_out + n_out])
+            o += H * n_out + n_out
+        nd.append(d)
+    out = torch.empty(3, B, A, K, device="cuda")
+    nat.learn_forward(x_all, B, noise, out)
+    l0 = ref(x_all[:B], True, nd[0])
+    with torch.no_grad():
+        l1, l2 = ref(x_all[B:], True, nd[1]), ref(x_all[B:], True, nd[2])
+    _close(out[0], l0.detach(), what="online(state)")
+    _close(out[1], l1, what="online(next_state)")
+    _close(out[2], l2, what="target(next_state)")
+    gl = torch.randn(B, A, K, device="cuda", generator=g) / B
+    ref.zero_grad()
+    l0.backward(gl)
+    nat.backward(gl.contiguous())
+    grads = nat.export_state(nat.grads)
+    for k, p in ref.named_parameters():
+        _close(grads[k], p.grad, tol=5e-5, what=f"grad {k}")
