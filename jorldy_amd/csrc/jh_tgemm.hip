@@ -1,5 +1,7 @@
 // Grouped LDS-tiled fp32 MFMA GEMM (16x16x4 MFMA): every contraction of the value networks (implicit-GEMM
 // convolutions, linear layers, data / weight gradients) and the PPO net's backward GEMMs.  See jh_tgemm.h.
+#include <stdlib.h>
+
 #include "jh_tgemm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -325,9 +327,11 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   for (int i = 0; i < n; ++i) {
     const int tiles = probs[i].tiles_m * probs[i].tiles_n;
     const int nchunks = (probs[i].K + 31) / 32;
-    // split K only when the tiles alone leave most of the 256 CUs idle; every split keeps >= 4 chunks of 32
-    int s = tiles >= 128 ? 1 : 256 / (tiles > 0 ? tiles : 1);
-    if (s > nchunks / 4) s = nchunks / 4;
+    // split K only when the tiles alone leave most of the 256 CUs idle; every split keeps >= kMinChunks chunks of 32
+    static const int kTargetWgs = getenv("JH_TGEMM_TARGET_WGS") ? atoi(getenv("JH_TGEMM_TARGET_WGS")) : 256;
+    static const int kMinChunks = getenv("JH_TGEMM_MIN_CHUNKS") ? atoi(getenv("JH_TGEMM_MIN_CHUNKS")) : 4;
+    int s = tiles >= kTargetWgs / 2 ? 1 : kTargetWgs / (tiles > 0 ? tiles : 1);
+    if (s > nchunks / kMinChunks) s = nchunks / kMinChunks;
     if (s > 64) s = 64;
     if (s < 1) s = 1;
     const bool conv = probs[i].a.mode >= OP_NHWC_K || probs[i].b.mode >= OP_NHWC_K;
