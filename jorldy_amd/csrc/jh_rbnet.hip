@@ -208,31 +208,41 @@ __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __re
     bc2s = sqrtf(1.f - powf(b2, t_new));
   }
   const float step_size = lr / bc1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float gi = g[i];
-    if (max_norm > 0.f) {
-      gi *= coef;
-      g[i] = gi;
-    }
+  auto update = [&](float& pi, float& gi, float& mi, float& vi) {
+    if (max_norm > 0.f) gi *= coef;
     if (OPT == 0) {
-      const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // exp_avg.lerp_(grad, 1 - beta1)
-      const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-      m[i] = mi;
-      v[i] = vi;
-      p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+      mi = mi + (1.f - b1) * (gi - mi);  // exp_avg.lerp_(grad, 1 - beta1)
+      vi = vi * b2 + (1.f - b2) * gi * gi;
+      pi = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
     } else {
-      const float vi = v[i] * b1 + (1.f - b1) * gi * gi;  // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
-      v[i] = vi;
+      vi = vi * b1 + (1.f - b1) * gi * gi;  // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
       float avg;
       if (centered) {
-        const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // grad_avg.lerp_(grad, 1 - alpha)
-        m[i] = mi;
-        avg = sqrtf(vi - mi * mi) + eps;                   // square_avg.addcmul(grad_avg, grad_avg, value=-1).sqrt_().add_(eps)
+        mi = mi + (1.f - b1) * (gi - mi);   // grad_avg.lerp_(grad, 1 - alpha)
+        avg = sqrtf(vi - mi * mi) + eps;    // square_avg.addcmul(grad_avg, grad_avg, value=-1).sqrt_().add_(eps)
       } else {
         avg = sqrtf(vi) + eps;
       }
-      p[i] = p[i] - lr * (gi / avg);
+      pi = pi - lr * (gi / avg);
     }
+  };
+  // 16-byte accesses: the buckets are 16-byte aligned and n is a multiple of 4 (segment offsets are)
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 p4 = reinterpret_cast<float4*>(p)[i], g4 = reinterpret_cast<float4*>(g)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+    update(p4.x, g4.x, m4.x, v4.x);
+    update(p4.y, g4.y, m4.y, v4.y);
+    update(p4.z, g4.z, m4.z, v4.z);
+    update(p4.w, g4.w, m4.w, v4.w);
+    reinterpret_cast<float4*>(p)[i] = p4;
+    if (max_norm > 0.f) reinterpret_cast<float4*>(g)[i] = g4;
+    if (OPT == 0 || centered) reinterpret_cast<float4*>(m)[i] = m4;
+    reinterpret_cast<float4*>(v)[i] = v4;
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+    update(pi, gi, mi, vi);
+    p[i] = pi; g[i] = gi; m[i] = mi; v[i] = vi;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
