@@ -178,6 +178,74 @@ def test_per_random_ops_vs_oracle_bit_exact(ops, O, N):
         assert s["max_priority"] == orc.max_priority and s["tree_index"] == orc.tree_index and s["counter"] == orc.buffer_counter
 
 
+def test_per_full_size_tree_properties(ops):
+    """BASELINE size (config.rainbow.atari: N = 1e6; here 2^20 + 3 so the leaf level wraps a depth boundary): the
+    float64 nodes are defined by the ORDER of the `+= delta` that reached them (per_buffer.py:50-54), so after pushing
+    leaves in order every node must equal the left-to-right running sum of its leaves (np.cumsum is that sum), and a
+    batched write-back must move the root by the deltas added one after the other in batch order -- bit for bit."""
+    N = (1 << 20) + 3
+    rng = np.random.RandomState(0)
+    pr = rng.rand(N) * 3 + 1e-3
+    tree = ops.SumTree(N, 1e-3)
+    for o in range(0, N, 100_000):  # actor-sized chunks
+        tree.push(len(pr[o : o + 100_000]), pr[o : o + 100_000])
+    t = tree.dump()
+    first_leaf = N - 1
+    np.testing.assert_array_equal(t[first_leaf:], pr)
+    # leaf slot i (tree index first_leaf + i); a node's leaves in PUSH order = increasing leaf slot
+    def node_leaves(node):
+        lo = hi = node
+        while lo < first_leaf:
+            lo, hi = 2 * lo + 1, 2 * hi + 2
+        return lo - first_leaf, min(hi, 2 * N - 2) - first_leaf  # may straddle the depth boundary: handled below
+    def seq_sum(node):
+        # leaves below `node` sit on one or two depth levels; walk children explicitly, summing in leaf-slot order
+        stack, leaves = [node], []
+        while stack:
+            k = stack.pop()
+            if k >= first_leaf:
+                leaves.append(k - first_leaf)
+            else:
+                stack += [2 * k + 2, 2 * k + 1]
+        leaves.sort()
+        return float(np.cumsum(pr[leaves])[-1]) if len(leaves) else 0.0
+    for node in [1 << 12, (1 << 12) + 77, (1 << 15) + 5, (1 << 18) - 1, first_leaf - 1, first_leaf - 2]:
+        assert t[node] == seq_sum(node), node
+    assert t[0] == float(np.cumsum(pr)[-1])
+    # sampling: leaf of a mass u * root == first slot whose running sum reaches it (searchsorted on the same cumsum),
+    # except within one ulp-sized band of a boundary
+    B = 4096
+    u = rng.rand(B)
+    idx, w64, w32, stats = tree.sample(0.4, np.empty(0, np.int64), u)
+    got = npy(idx) - first_leaf
+    # left-to-right order of the leaves in the heap (N is not a power of two: the leaves sit on two levels and the
+    # deeper ones come first): sort by the heap position left-aligned to the deepest level
+    k = np.arange(first_leaf, 2 * N - 1, dtype=np.int64) + 1
+    depth = np.floor(np.log2(k)).astype(np.int64)
+    order = np.argsort(k << (depth.max() - depth), kind="stable")  # leaf slots, left to right
+    pos = np.searchsorted(np.cumsum(pr[order]), u * t[0], side="left")
+    want = order[np.minimum(pos, N - 1)]
+    # the descent subtracts left-subtree sums level by level, the cumsum adds leaf by leaf: equal up to fp64 rounding at
+    # the boundaries of a leaf's mass interval, i.e. the neighbouring leaf at worst, and only rarely
+    rank = np.empty(N, np.int64)
+    rank[order] = np.arange(N)
+    assert (got == want).mean() > 0.999 and np.abs(rank[got] - rank[want]).max() <= 1
+    # write-back with duplicates: the root moves by the deltas in batch order
+    upd = rng.randint(0, N, size=2048)
+    upd[100:140] = upd[100]
+    newp = (rng.rand(2048) * 5).astype(np.float64)
+    tree.update(cu(upd + first_leaf), cu(newp))
+    leaves = pr.copy()
+    root = t[0]
+    for i, p in zip(upd, newp):
+        root = root + (p - leaves[i])
+        leaves[i] = p
+    t2 = tree.dump()
+    assert t2[0] == root
+    np.testing.assert_array_equal(t2[first_leaf:], leaves)
+    assert tree.state()["max_priority"] == max(1.0, float(newp.max()))
+
+
 def test_per_load_dump_roundtrip(ops):
     rng = np.random.RandomState(1)
     t = ops.SumTree(100, 1e-3)
