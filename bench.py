@@ -197,7 +197,9 @@ def main():
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
     from jorldy_amd.manager import NativeCollector, VecCollector
-    from jorldy_amd.parallel import make_grad_sync
+    from jorldy_amd.parallel import make_grad_sync, pin_rank_to_cores
+
+    cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
 
     W, T = args.workers, 128
     np.random.seed(1234 + rank)
@@ -259,7 +261,8 @@ def main():
         "config": {"workload": "config.ppo.cartpole --sync --train.num_workers 8 (BASELINE.json configs[1]): synthetic CartPole-v1, "
                                "W=8 x T=128 = 1024 transitions/iteration/GPU, MLP 4-512-512-{2,1}, 3 epochs x 4 minibatches of 256",
                    "workers_per_gpu": W, "n_step": T, "batch_size": 256, "n_epoch": 3, "parallelism": f"dp{world}",
-                   "backend": agent.backend, "hipgraph": bool(agent._graph is not None), "collector": type(collector).__name__},
+                   "backend": agent.backend, "hipgraph": bool(agent._graph is not None), "collector": type(collector).__name__,
+                   "host_cores_per_rank": len(cores) if cores else None},
         "learner_updates_per_s": world * n_updates * args.steps / dt,
         "last_result": {k: float(v) for k, v in result.items()},
     }

@@ -83,3 +83,20 @@ def attach_data_parallel(agent, dist, group=None):
     agent.grad_sync = sync
     agent._graph = None
     return sync
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """North star: "actors pinned to host cores".  One process per GPU, each with its collector thread (busy-polling
+    the acting exchange area) and its host envs: give every rank its own contiguous slice of the cores this process
+    may run on, so the ranks' pollers never share a core.  Returns the core list (or None when affinity is not
+    controllable here)."""
+    import os
+
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        per = max(1, len(avail) // max(1, local_world))
+        mine = avail[local_rank * per : (local_rank + 1) * per] or avail
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return None

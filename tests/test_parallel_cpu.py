@@ -93,3 +93,20 @@ def test_bucket_sync_mean_gradient_and_broadcast(tmp_path):
     for r in range(world):
         assert torch.equal(out[r]["params"], torch.full((37,), 1.0)) and torch.equal(out[r]["moments"], torch.full((37,), 10.0))
         assert torch.equal(out[r]["grads"], torch.arange(37, dtype=torch.float32) * 1.5)
+
+
+def test_pin_rank_to_cores_partitions_the_allowed_cores():
+    from jorldy_amd.parallel import pin_rank_to_cores
+
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        world = min(4, len(before))
+        seen = []
+        for r in range(world):
+            os.sched_setaffinity(0, before)
+            mine = pin_rank_to_cores(r, world)
+            assert mine and sorted(os.sched_getaffinity(0)) == mine
+            seen += mine
+        assert len(seen) == len(set(seen)) and set(seen) <= set(before)  # disjoint slices of the allowed cores
+    finally:
+        os.sched_setaffinity(0, before)
