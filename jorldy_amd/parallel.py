@@ -85,7 +85,7 @@ def attach_data_parallel(agent, dist, group=None):
     return sync
 
 
-def pin_rank_to_cores(local_rank, local_world):
+def pin_rank_to_cores(local_rank, local_world, min_cores=4):
     """North star: "actors pinned to host cores".  One process per GPU, each with its collector thread (busy-polling
     the acting exchange area) and its host envs: give every rank its own contiguous slice of the cores this process
     may run on, so the ranks' pollers never share a core.  Returns the core list (or None when affinity is not
@@ -94,7 +94,9 @@ def pin_rank_to_cores(local_rank, local_world):
 
     try:
         avail = sorted(os.sched_getaffinity(0))
-        per = max(1, len(avail) // max(1, local_world))
+        per = len(avail) // max(1, local_world)
+        if per < min_cores:  # a rank also runs the HIP runtime's helper threads: do not squeeze it onto one or two cores
+            return None
         mine = avail[local_rank * per : (local_rank + 1) * per] or avail
         os.sched_setaffinity(0, mine)
         return mine

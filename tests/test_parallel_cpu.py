@@ -104,7 +104,7 @@ def test_pin_rank_to_cores_partitions_the_allowed_cores():
         seen = []
         for r in range(world):
             os.sched_setaffinity(0, before)
-            mine = pin_rank_to_cores(r, world)
+            mine = pin_rank_to_cores(r, world, min_cores=1)
             assert mine and sorted(os.sched_getaffinity(0)) == mine
             seen += mine
         assert len(seen) == len(set(seen)) and set(seen) <= set(before)  # disjoint slices of the allowed cores
