@@ -38,8 +38,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 matrix peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workers", type=int, default=8, help="sync workers per GPU (config: train.num_workers 8)")
     ap.add_argument("--cpu-baseline-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
