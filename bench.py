@@ -197,9 +197,11 @@ def main():
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
     from jorldy_amd.manager import NativeCollector, VecCollector
-    from jorldy_amd.parallel import make_grad_sync, pin_rank_to_cores
+    from jorldy_amd.parallel import make_grad_sync, pin_to_gpu_node
 
-    cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
+    # "actors pinned to host cores": every rank's collector thread on the cores next to ITS GPU (two PCIe crossings per
+    # timestep; the far socket costs +40 % per step); ranks sharing a NUMA node (4 GPUs per socket) split its cores
+    cores = pin_to_gpu_node(local_rank, local_rank=local_rank % 4, ranks_on_node=min(4, world))
 
     W, T = args.workers, 128
     np.random.seed(1234 + rank)

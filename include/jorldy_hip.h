@@ -53,6 +53,10 @@ const char* jh_last_error(void);
 int jh_device_count(void);                       /* 0 when no GPU is visible (never an error) */
 int jh_ctx_create(int device, jh_ctx** out);     /* binds the device, allocates pinned staging */
 void jh_ctx_destroy(jh_ctx* ctx);
+/* Host cores local to this context's GPU (sysfs local_cpulist of its PCI function, e.g. "64-127,192-255"): the
+ * collector thread (Actor.run's replacement, manager/distributed_manager.py:76-92) should run there -- acting crosses
+ * PCIe twice per timestep and the far socket adds ~1.8 us per crossing.                                   */
+int jh_ctx_local_cpulist(jh_ctx* ctx, char* out, int64_t len);
 int jh_ctx_sync(jh_ctx* ctx, jh_stream stream);  /* hipStreamSynchronize */
 /* Pinned host memory mapped into the device address space (the pinned staging of the collector:
  * observations written by the host are read in place by the acting kernels, actions come back

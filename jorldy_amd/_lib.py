@@ -34,6 +34,7 @@ _PROTOS = {
     "jh_ctx_create": (C.c_int, [C.c_int, _pp]),
     "jh_ctx_destroy": (None, [_vp]),
     "jh_ctx_sync": (C.c_int, [_vp, _vp]),
+    "jh_ctx_local_cpulist": (C.c_int, [_vp, C.c_char_p, _i64]),
     "jh_prof_enable": (C.c_int, [_i32]),
     "jh_prof_report": (C.c_int, [C.c_char_p, _i64]),
     "jh_prof_calibrate": (C.c_int, [_i32, _vp]),

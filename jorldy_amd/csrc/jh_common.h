@@ -111,6 +111,9 @@ struct jh_cartpole {
   std::vector<uint64_t> rng;
 };
 
+void jh_cartpole_obs_rows(const jh_cartpole* e, int r0, int r1, float* h_obs);
+void jh_cartpole_step_rows(jh_cartpole* e, int r0, int r1, const int64_t* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done);
+
 struct jh_pponet {
   jh_ctx* ctx = nullptr;
   int S = 0, H = 0, A = 0, cont = 0, max_rows = 0;

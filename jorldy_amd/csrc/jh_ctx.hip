@@ -197,3 +197,24 @@ JH_EXPORT int jh_prof_report(char* buf, int64_t cap) {
   memcpy(buf, out.c_str(), out.size() + 1);
   return JH_OK;
 }
+
+// Host cores that sit on the same NUMA node / PCIe root as this context's GPU (sysfs local_cpulist of the device's
+// PCI function), e.g. "64-127,192-255".  Acting crosses PCIe twice per timestep; from the far socket every crossing
+// costs ~1.8 us more (measured: 12.9 vs 9.3 us per timestep), so collectors pin their host thread to these cores.
+JH_EXPORT int jh_ctx_local_cpulist(jh_ctx* ctx, char* out, int64_t len) {
+  JH_ARG(ctx && out && len > 16);
+  char bus[64] = {0};
+  JH_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, ctx->device));
+  for (char* c = bus; *c; ++c)
+    if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');  // sysfs names are lower case
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
+  FILE* f = fopen(path, "r");
+  if (!f) return jh_fail(JH_ERR_STATE, "cannot read %s", path);
+  const size_t n = fread(out, 1, (size_t)len - 1, f);
+  fclose(f);
+  out[n] = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (out[i] == '\n') out[i] = 0;
+  return JH_OK;
+}

@@ -53,11 +53,21 @@ JH_EXPORT int jh_cartpole_obs(const jh_cartpole* e, float* h_obs) {
   return JH_OK;
 }
 
+// envs [r0, r1) only (the arrays are indexed by env, i.e. the caller passes the full-width buffers)
+void jh_cartpole_obs_rows(const jh_cartpole* e, int r0, int r1, float* h_obs) {
+  for (size_t i = 4 * (size_t)r0; i < 4 * (size_t)r1; ++i) h_obs[i] = (float)e->s[i];
+}
+
 JH_EXPORT int jh_cartpole_step(jh_cartpole* e, const int64_t* h_action, float* h_next_obs, float* h_reward,
                                uint8_t* h_done) {
   JH_ARG(e && h_action && h_next_obs && h_reward && h_done);
+  jh_cartpole_step_rows(e, 0, e->W, h_action, h_next_obs, h_reward, h_done);
+  return JH_OK;
+}
+
+void jh_cartpole_step_rows(jh_cartpole* e, int r0, int r1, const int64_t* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done) {
   const double total_mass = kMc + kMp, pml = kMp * kLen;
-  for (int w = 0; w < e->W; ++w) {
+  for (int w = r0; w < r1; ++w) {
     double* s = &e->s[4 * (size_t)w];
     double x = s[0], xd = s[1], th = s[2], thd = s[3];
     const double force = h_action[w] == 1 ? kFmag : -kFmag;
@@ -77,5 +87,4 @@ JH_EXPORT int jh_cartpole_step(jh_cartpole* e, const int64_t* h_action, float* h
     h_reward[w] = d ? -1.0f : 0.1f;  // gym_env.py:78
     if (d) reset_env(e, w);          // distributed_manager.py:91
   }
-  return JH_OK;
 }

@@ -35,6 +35,8 @@ struct PersistArgs {
   long max_polls;
   unsigned long long* dbg;             // optional [T][8]: per-step timestamps of workgroup 0 (diagnostics)
   int poll_sleep;                      // back-off between polls: 0 none, 1 s_sleep 1, 2 s_sleep 8, 3 s_sleep 32
+  int groups;                          // 1, or 2: the env rows are served as two half-batches per timestep so that the host
+                                       // (sampling, env.step, next observations) of one half overlaps the GPU work of the other
 };
 
 __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
@@ -69,16 +71,18 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
   __syncthreads();
   const int kper = H / 4;  // H % 64 == 0 is checked on the host
   const int kbeg = wid * kper;
-  const int n_x = p.W * S;
 
-  for (int t = 1; t <= p.T; ++t) {
+  const int rows_per = p.W / p.groups;
+  for (int tg = 0; tg < p.T * p.groups; ++tg) {
+    const int t = tg / p.groups + 1, grp = tg - (t - 1) * p.groups;
+    const int row0 = grp * rows_per, row1 = row0 + rows_per;  // the env rows of this half-batch
     const unsigned tag = p.seq0 + (unsigned)t;
     // ---- wait for the host's observations of step t (granule sweep, bounded)
     if (wid == 0) {
       bool ok = false;
       for (long spin = 0; spin < p.max_polls; ++spin) {
         bool mine = true;
-        for (int i = lane; i < n_x; i += 64) {
+        for (int i = row0 * S + lane; i < row1 * S; i += 64) {
           const unsigned long long gq = __hip_atomic_load(p.obs_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           if ((unsigned)(gq >> 32) == tag) xs[i] = __uint_as_float((unsigned)gq);
           else mine = false;
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
       // store W consecutive granules with ONE instruction (W*16 contiguous bytes -> one or two PCIe
       // write TLPs per tile instead of dozens of 4-byte ones); fire and forget: no release fence, no
       // acknowledgement wait on the per-step critical path.
-      if (lane < p.W) {
+      if (lane >= row0 && lane < row1) {
         const float4 o4 = *reinterpret_cast<const float4*>(outs_s + lane * 4);
         const f32x4 gq = (f32x4){o4.x, o4.y, o4.z, __uint_as_float(tag)};
         float4* dst = p.part + (size_t)tile * 16 + lane;
@@ -206,6 +210,7 @@ struct jh_persist {
   float4 *part_h = nullptr, *part_d = nullptr;
   unsigned *flag_h = nullptr, *flag_d = nullptr;  // [tiles] + abort word at [tiles]
   unsigned seq = 0;
+  int groups = 1;
   int tiles = 0;
   size_t lds = 0;
   unsigned long long *dbg_h = nullptr, *dbg_d = nullptr;
@@ -253,9 +258,11 @@ void jh_persist_destroy(jh_persist* p) {
 }
 
 // Launch the persistent kernel for T steps of W <= 16 envs.
-int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
+int jh_persist_begin(jh_persist* p, int W, int T, int groups, hipStream_t st) {
   jh_pponet* n = p->net;
   JH_ARG(W > 0 && W <= 16 && T > 0);
+  JH_ARG(groups == 1 || (groups == 2 && W % 2 == 0));
+  p->groups = groups;
   PersistArgs a{};
   a.W = W; a.S = n->S; a.H = n->H; a.T = T;
   a.W1 = n->params + n->o_w1; a.b1 = n->params + n->o_b1; a.W2 = n->params + n->o_w2; a.b2 = n->params + n->o_b2;
@@ -266,6 +273,7 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.obs_gran = p->gran_d; a.part = p->part_d; a.tile_flag = p->flag_d; a.abort_flag = p->flag_d + p->tiles;
   a.seq0 = p->seq;
   a.dbg = p->dbg_d;
+  a.groups = groups;
   a.poll_sleep = 2;
   if (const char* e = getenv("JH_PERSIST_SLEEP")) a.poll_sleep = atoi(e);
   a.max_polls = 400000;  // x (~0.5 us per poll) = ~0.2 s without observations -> give up
@@ -275,18 +283,24 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   return JH_OK;
 }
 
-// One timestep: publish the observations, wait for every tile, finish the heads on the host.
-// Returns JH_ERR_STATE if the kernel gave up (caller falls back to jh_pponet_act_discrete).
-int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action, int training) {
-  jh_pponet* n = p->net;
-  const unsigned tag = ++p->seq;
-  const int n_x = W * n->S;
-  for (int i = 0; i < n_x; ++i) {
+// Tag of the next timestep (all half-batches of a timestep share it).
+unsigned jh_persist_next_tag(jh_persist* p) { return ++p->seq; }
+
+// Publish the observations of env rows [r0, r1) for the timestep `tag` (h_obs is the full [W][S] array).
+void jh_persist_publish(jh_persist* p, int r0, int r1, const float* h_obs, unsigned tag) {
+  const int S = p->net->S;
+  for (int i = r0 * S; i < r1 * S; ++i) {
     unsigned bits;
     memcpy(&bits, h_obs + i, 4);
     __atomic_store_n(p->gran_h + i, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELEASE);
   }
-  // ---- wait until every partial granule of this step carries the tag, summing as they arrive
+}
+
+// Wait until every tile's partial granules of rows [r0, r1) carry `tag`, finish the heads on the host and sample.
+// The sampling stream is keyed by (act_ctr, row): identical whichever way the rows are batched; the caller advances
+// act_ctr once per timestep (jh_persist_end_step).  JH_ERR_STATE if the kernel gave up.
+int jh_persist_collect(jh_persist* p, int r0, int r1, unsigned tag, int64_t* h_action, int training) {
+  jh_pponet* n = p->net;
   const int A = n->A, n_out = A + 1;
   volatile unsigned* abort_w = p->flag_h + p->tiles;
   const volatile unsigned* part = reinterpret_cast<const volatile unsigned*>(p->part_h);  // [tiles][16][4 words]
@@ -294,7 +308,7 @@ int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action,
   for (long spin = 0; spin < 40000000L && !all; ++spin) {
     all = true;
     for (int t = 0; t < p->tiles && all; ++t)
-      for (int wq = 0; wq < W; ++wq)
+      for (int wq = r0; wq < r1; ++wq)
         if (part[((size_t)t * 16 + wq) * 4 + 3] != tag) { all = false; break; }
     if (!all) {
       if ((spin & 1023) == 1023 && *abort_w == 2u) break;  // the kernel timed out
@@ -303,7 +317,7 @@ int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action,
   }
   if (!all) return jh_fail(JH_ERR_STATE, "persistent acting kernel did not answer step tag %u", tag);
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  for (int wq = 0; wq < W; ++wq) {
+  for (int wq = r0; wq < r1; ++wq) {
     float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < p->tiles; ++t) {
       for (int o = 0; o < n_out; ++o) {
@@ -335,7 +349,18 @@ int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action,
     }
     h_action[wq] = act;
   }
-  n->act_ctr += 1;
+  return JH_OK;
+}
+
+void jh_persist_end_step(jh_persist* p) { p->net->act_ctr += 1; }
+
+// One whole timestep, all rows at once (groups == 1).
+int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action, int training) {
+  const unsigned tag = jh_persist_next_tag(p);
+  jh_persist_publish(p, 0, W, h_obs, tag);
+  int rc = jh_persist_collect(p, 0, W, tag, h_action, training);
+  if (rc) return rc;
+  jh_persist_end_step(p);
   return JH_OK;
 }
 

@@ -67,6 +67,9 @@ class NativeCollector:
         self.lib = L.load()
         self.env, self.agent = env_vec, agent
         self.num_workers = env_vec.W
+        from ..parallel import pin_to_gpu_node
+
+        self.host_cores = pin_to_gpu_node(agent.device.index)  # the rollout loop runs on this thread: keep it next to the GPU
         self.h = None
         self._store_h = None
         self._net_h = None
