@@ -28,6 +28,10 @@ class VecCollector:
         self.num_workers = env_vec.W if num_workers is None else num_workers
         assert self.num_workers == env_vec.W
         self.state = self.env.obs()  # (W, S) float32
+        from ..parallel import pin_to_gpu_node
+
+        dev = getattr(agent, "device", None)
+        self.host_cores = pin_to_gpu_node(dev.index) if dev is not None else None  # acting = PCIe round trips per step: stay next to the GPU
 
     def run(self, step=1):
         """-> (SoA dict in worker-major order, completed_ratio) like DistributedManager.run (:26-31)."""
