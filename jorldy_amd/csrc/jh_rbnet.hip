@@ -1,9 +1,13 @@
-// Rainbow network on the device: Nature-CNN or MLP head -> Linear -> noisy dueling categorical heads.
-//   reference: core/network/rainbow.py:8-94, head.py:6-61 (MLP / CNN), utils.py:55-107 (noisy linear),
-//              core/agent/rainbow.py:154-253 (the three forwards + backward + Adam of one learn()).
+// The value networks of the DQN / Rainbow / Ape-X family on the device: Nature-CNN or MLP head, then
+//   kind 0 / 3  rainbow  -> Linear -> noisy dueling categorical heads (factorised / independent noise)
+//   kind 1      dueling  -> l1_a | l1_v -> l2_a, l2_v -> dueling combine
+//   kind 2      q        -> Linear -> q
+//   reference: core/network/rainbow.py:8-94, dueling.py:8-35, q_network.py:8-20, head.py:6-61 (MLP / CNN),
+//              utils.py:55-107 (noisy linear); the three forwards + backward + optimizer step of one learn()
+//              (core/agent/rainbow.py:154-253, dqn.py:128-147, ape_x.py:96-131).
 //
 // Every contraction (convolutions as implicit GEMMs, linear layers, their data- and weight-gradients) runs
-// on ONE LDS-tiled fp32 MFMA kernel (jh_tgemm_kernel).  What changes between layers is only how an operand
+// on ONE grouped LDS-tiled fp32 MFMA kernel (jh_tgemm.hip).  What changes between layers is only how an operand
 // tile is fetched from HBM (dense, transposed, im2col of an NHWC activation, im2col of the NCHW uint8
 // frames straight out of the replay store) -- the column matrix of a convolution is never materialised
 // in the forward pass or the weight-gradient pass.
