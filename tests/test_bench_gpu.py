@@ -1,0 +1,34 @@
+"""The driver's contract for bench.py: one JSON line on stdout with the agreed keys (metric / value / unit / n_gpus /
+steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline +
+cpu_baseline), value consistent with ms_per_step, plus the Rainbow leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_emits_one_contract_json_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-baseline-iters", "2", "--rainbow-updates", "20"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    # value = whole-job transitions / measured time
+    assert abs(d["value"] - 8 * 128 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    rb = d["rainbow"]
+    assert rb["value"] > 0 and rb["unit"] == "updates/s" and rb["backend"] == "native" and rb["n_gpus"] == 1
