@@ -322,6 +322,153 @@ __global__ void __launch_bounds__(256) jh_c51_kernel(C51Args a) {
   }
 }
 
+
+// Small batches (the configs' B = 32): ONE WORKGROUP per sample, the per-action softmaxes spread over its 4 waves.
+// The wave-per-sample kernel above runs 2A + 1 softmaxes (three dependent wave reductions each) one after the other
+// on a single wave -- at B = 32 that chain, not bandwidth, is the whole cost.  Every value is computed by the same
+// instruction sequence as above (one wave per softmax row, same shuffle trees, same source-atom order in the
+// projection), so the results are bit-identical.
+// Dynamic LDS: [K] p_act, [K] l, u, wl, wu, tp, [A] selector Q, [4][3] per-wave stats.
+__global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x, K = a.K;
+  float* s_pact = smem;
+  float* s_l = s_pact + K;
+  float* s_u = s_l + K;
+  float* s_wl = s_u + K;
+  float* s_wu = s_wl + K;
+  float* s_tp = s_wu + K;
+  float* s_qsel = s_tp + K;       // [A]
+  float* s_stat = s_qsel + a.A;   // [4][3]: max Q, max logit, min logit of the rows this wave saw
+  int act = (int)a.action[b];
+  act = act < 0 ? 0 : (act >= a.A ? a.A - 1 : act);
+  // ---- phase 1: online softmaxes (stats + the taken action's distribution) and the selector's Q, actions strided over waves
+  float maxq = -3.4e38f, maxl = -3.4e38f, minl = 3.4e38f;
+  const float* sel = (a.flags & JH_C51_DOUBLE) ? a.next_logit : a.target_logit;
+  for (int aa = wid; aa < a.A; aa += 4) {
+    float p[4], rmx, rmn;
+    const float q = atom_softmax(a.logit + ((size_t)b * a.A + aa) * K, K, lane, a.v_min, a.v_max, p, rmx, rmn);
+    maxq = fmaxf(maxq, q);
+    maxl = fmaxf(maxl, rmx);
+    minl = fminf(minl, rmn);
+    if (aa == act) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (lane + 64 * s < K) s_pact[lane + 64 * s] = p[s];
+    }
+    float p2[4];
+    const float q2 = atom_softmax(sel + ((size_t)b * a.A + aa) * K, K, lane, a.v_min, a.v_max, p2, rmx, rmn);
+    if (lane == 0) s_qsel[aa] = q2;
+  }
+  if (lane == 0) { s_stat[wid * 3 + 0] = maxq; s_stat[wid * 3 + 1] = maxl; s_stat[wid * 3 + 2] = minl; }
+  __syncthreads();
+  if (wid != 0) {
+    // ---- the other waves only write the zero gradient rows of the actions that were not taken (phase 4 needs nothing from them)
+    for (int aa = wid - 1; aa < a.A; aa += 3) {
+      if (aa == act) continue;
+      float* g = a.grad + ((size_t)b * a.A + aa) * K;
+      for (int k = lane; k < K; k += 64) g[k] = 0.f;
+    }
+    return;
+  }
+  // ---- wave 0 from here: greedy next action = first maximum (rainbow.py:177-181 / c51.py:76-80)
+  int best = 0;
+  float bq = -3.4e38f;
+  for (int aa = 0; aa < a.A; ++aa) {
+    const float q = s_qsel[aa];
+    if (q > bq) { bq = q; best = aa; }
+  }
+  float tp[4], rmx, rmn;
+  (void)atom_softmax(a.target_logit + ((size_t)b * a.A + best) * K, K, lane, a.v_min, a.v_max, tp, rmx, rmn);
+  float p_act[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) p_act[s] = (lane + 64 * s < K) ? s_pact[lane + 64 * s] : 0.f;
+  // ---- n-step Bellman image of every atom and its two neighbours on the support
+  const float range = a.v_max - a.v_min;
+  const float dz = (float)(((double)a.v_max - (double)a.v_min) / (double)(K - 1));
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int j = lane + 64 * s;
+    if (j < K) {
+      float Tz = support_z(j, K, a.v_min, a.v_max);
+      for (int i = a.n - 1; i >= 0; --i) {  // rainbow.py:188-193
+        const float r = a.reward[(size_t)b * a.n + i], d = a.done[(size_t)b * a.n + i];
+        Tz = r + (1.f - d) * a.gamma * Tz;
+      }
+      const float bb = fminf(fmaxf(Tz - a.v_min, 0.f), range) / dz;  // rainbow.py:195
+      const float l = floorf(bb), u = ceilf(bb);
+      s_l[j] = l;
+      s_u[j] = u;
+      s_wl[j] = u - bb;  // mass to l;  integral b -> l == u -> both weights 0 (quirk kept)
+      s_wu[j] = bb - l;
+      s_tp[j] = tp[s];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const float d0 = a.done[(size_t)b * a.n];  // terminal branch keyed on done[:,0]  rainbow.py:212
+  float m[4];
+  float msum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = lane + 64 * s;
+    float term = 0.f, non = 0.f;
+    if (k < K) {
+      const float kf = (float)k;
+      for (int j = 0; j < K; ++j) {  // ascending source atom, like the sum over dim 1
+        const float l = s_l[j], u = s_u[j];
+        const float val = (l == kf ? s_wl[j] : 0.f) + (u == kf ? s_wu[j] : 0.f);
+        term += ((l == kf && u == kf) ? 1.f : 0.f) + val;  // rainbow.py:212-214
+        non += s_tp[j] * val;                              // rainbow.py:215-217
+      }
+      term = term / (float)K;  // torch.mean over the source atoms
+    }
+    m[s] = k < K ? d0 * term + (1.f - d0) * non : 0.f;
+    msum += m[s];
+  }
+  msum = jh_wave_sum(msum);
+  const float norm = fmaxf(msum, 1e-8f);  // rainbow.py:218-220
+  float klp = 0.f, mt_sum = 0.f;
+  float mt[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    m[s] = m[s] / norm;
+    const float pc = fmaxf(p_act[s], 1e-8f);
+    klp += (lane + 64 * s < K) ? m[s] * logf(pc) : 0.f;
+    mt[s] = (p_act[s] >= 1e-8f) ? m[s] : 0.f;  // clamp(min=1e-8) blocks the gradient below it
+    mt_sum += mt[s];
+  }
+  const float kl = -jh_wave_sum(klp);  // rainbow.py:227
+  mt_sum = jh_wave_sum(mt_sum);
+  float weff = 1.f;  // rainbow's (B,1)*(B,) broadcast makes the per-sample weight the batch MEAN
+  if (a.flags & JH_C51_PER) {
+    float ws = 0.f;
+    for (int i = lane; i < a.B; i += 64) ws += a.weights[i];
+    weff = jh_wave_sum(ws) / (float)a.B;
+  }
+  const float scale = weff / (float)a.B;
+  float* g = a.grad + ((size_t)b * a.A + act) * K;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = lane + 64 * s;
+    if (k < K) g[k] = (-mt[s] + p_act[s] * mt_sum) * scale;
+  }
+  if (lane == 0) {
+    if (a.kl) a.kl[b] = kl;
+    if (a.prio) a.prio[b] = powf(kl, a.alpha);  // rainbow.py:228
+    float mq = -3.4e38f, ml = -3.4e38f, nl = 3.4e38f;
+    const int nw = a.A < 4 ? a.A : 4;  // waves that saw at least one action row
+    for (int w = 0; w < nw; ++w) {
+      mq = fmaxf(mq, s_stat[w * 3 + 0]);
+      ml = fmaxf(ml, s_stat[w * 3 + 1]);
+      nl = fminf(nl, s_stat[w * 3 + 2]);
+    }
+    float* p = a.partial + 4 * (size_t)b;
+    p[0] = kl; p[1] = mq; p[2] = ml; p[3] = nl;
+  }
+}
+
 __global__ void __launch_bounds__(256) jh_c51_finish_kernel(int nb, C51Args a) {
   __shared__ float s_red[16];
   float sk = 0.f, mq = -3.4e38f, ml = -3.4e38f, nl = 3.4e38f, ws = 0.f;
@@ -363,13 +510,19 @@ JH_EXPORT int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t 
   a.logit = d_logit; a.next_logit = d_next_logit_online; a.target_logit = d_target_logit; a.action = d_action;
   a.reward = d_reward; a.done = d_done; a.weights = d_weights; a.v_min = v_min; a.v_max = v_max; a.gamma = gamma;
   a.alpha = alpha; a.grad = d_grad_logit; a.prio = d_prio; a.kl = d_kl; a.stats = d_stats;
-  const int nb = (B + 3) / 4;
+  const bool per_block = B <= 1024;  // latency regime: one workgroup per sample, softmaxes spread over its waves
+  const int nb = per_block ? B : (B + 3) / 4;
   void* scratch = nullptr;
   int rc = jh_ctx_scratch(ctx, sizeof(float) * 4 * (size_t)nb, &scratch);
   if (rc) return rc;
   a.partial = (float*)scratch;
-  const size_t lds = sizeof(float) * 4 * 5 * (size_t)K;
-  JH_LAUNCH(jh_c51_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);
+  if (per_block) {
+    const size_t lds = sizeof(float) * (6 * (size_t)K + (size_t)A + 12);
+    JH_LAUNCH(jh_c51_block_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);
+  } else {
+    const size_t lds = sizeof(float) * 4 * 5 * (size_t)K;
+    JH_LAUNCH(jh_c51_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);
+  }
   JH_LAUNCH_CHECK();
   JH_LAUNCH(jh_c51_finish_kernel, dim3(1), dim3(256), 0, jh_s(stream), nb, a);
   JH_LAUNCH_CHECK();
