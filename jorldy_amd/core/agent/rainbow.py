@@ -69,7 +69,7 @@ class C51(DQN):
 
     def learn(self):
         self._run_learn()
-        s = self._stats8.cpu().numpy()
+        (s,) = self._read_stats(self._stats8)
         return {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3])}
 
 
@@ -199,8 +199,7 @@ class Rainbow(DQN):
 
     def learn(self):
         stats64 = self._run_learn()
-        s = self._stats8.cpu().numpy()
-        p = stats64.cpu().numpy()
+        s, p = self._read_stats(self._stats8, stats64)
         return {"loss": float(s[0]), "beta": self.beta, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3]),
                 "sampled_p": float(p[0]), "mean_p": float(p[1])}
 
