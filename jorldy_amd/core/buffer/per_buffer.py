@@ -46,7 +46,7 @@ class PERBuffer(ReplayBuffer):
             while j < len(done) and (done[j][1] is not None) == has:
                 n += done[j][0]
                 j += 1
-            self._tree.push(n, np.concatenate([d[1] for d in done[i:j]]) if has else None)
+            self._tree.push(n, (done[i][1] if j == i + 1 else np.concatenate([d[1] for d in done[i:j]])) if has else None)
             i = j
 
     def store(self, transitions):

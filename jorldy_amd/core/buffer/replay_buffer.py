@@ -1,5 +1,6 @@
 import numpy as np
 
+from ... import ops
 from .base import BaseBuffer, h2d_small
 
 
@@ -27,7 +28,7 @@ class ReplayBuffer(BaseBuffer):
         # but the per-env-step cost drops from ~8 HIP API calls to a numpy copy (Rainbow: a store every
         # step, a learn() every 4).
         self.defer_rows = 0
-        self._pending, self._pending_rows = [], 0
+        self._pending, self._pending_rows, self._pend_cols = [], 0, None
 
     # fast path: already-SoA numpy columns [n, ...]
     def _dedup_encode(self, cols):
@@ -63,20 +64,30 @@ class ReplayBuffer(BaseBuffer):
         return n
 
     def _defer(self, flat, n, extra=None):
-        self._pending.append(({k: np.array(v, copy=True) for k, v in flat.items()}, n, extra))  # the caller may reuse its arrays
+        # rows are copied (the caller may reuse its arrays) straight into preallocated host columns of the stored dtype:
+        # no per-store allocations, no concatenate at flush time
+        cap = min(4 * self.defer_rows, self.buffer_size)
+        if self._pend_cols is not None and len(next(iter(self._pend_cols.values()))) < cap:
+            self.flush()  # defer_rows was raised: held rows out first, then bigger host columns
+            self._pend_cols = None
+        if self._pend_cols is None:
+            self._pend_cols = {name: np.empty((cap, elems), dtype=ops._NP_OF[dt]) for name, dt, elems, _ in self._store.columns}
+        k = self._pending_rows
+        for name, v in flat.items():
+            self._pend_cols[name][k : k + n] = np.asarray(v).reshape(n, -1)
+        self._pending.append((n, extra))
         self._pending_rows += n
 
     def _flush_rows(self):
-        """Concatenate and push the held rows; returns [(n, extra)] in store order."""
+        """Push the held rows; returns [(n, extra)] in store order."""
         if self._frames is not None:
             self._frames.flush()  # frames the held / just-pushed rows refer to
         if not self._pending:
             return []
-        pend, self._pending, self._pending_rows = self._pending, [], 0
-        names = list(pend[0][0].keys())
-        cat = {k: (pend[0][0][k] if len(pend) == 1 else np.concatenate([np.asarray(p[0][k]).reshape(p[1], -1) for p in pend], 0)) for k in names}
-        self._store.push(cat)
-        return [(p[1], p[2]) for p in pend]
+        pend, rows = self._pending, self._pending_rows
+        self._pending, self._pending_rows = [], 0
+        self._store.push({name: buf[:rows] for name, buf in self._pend_cols.items()})
+        return pend
 
     def flush(self):
         self._flush_rows()
@@ -191,7 +202,7 @@ class ReplayBuffer(BaseBuffer):
 
     def load_state_dict(self, sd):
         assert sd["buffer_size"] == self.buffer_size
-        self._pending, self._pending_rows = [], 0
+        self._pending, self._pending_rows, self._pend_cols = [], 0, None
         self._frames = None
         self._layout = None
         self._store = None
