@@ -71,6 +71,20 @@ class BaseAgent(ABC):
     _RESUME_ATTRS = ("time_t", "learn_stamp", "num_learn", "epsilon", "beta", "target_update_stamp", "learn_period_stamp",
                      "num_transitions", "_adam_steps")
 
+    def _read_stats(self, *device_tensors):
+        """The learn() statistics in ONE host synchronisation: asynchronous copies into pinned host buffers, one stream
+        sync (a `.cpu()` per tensor is a blocking hipMemcpy each)."""
+        pins = self.__dict__.setdefault("_stat_pins", {})
+        outs = []
+        for i, t in enumerate(device_tensors):
+            key = (i, t.dtype, tuple(t.shape))
+            if key not in pins:
+                pins[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            pins[key].copy_(t, non_blocking=True)
+            outs.append(pins[key])
+        torch.cuda.current_stream().synchronize()
+        return [o.numpy() for o in outs]
+
     def save_full(self, path):
         """`save(path)` (reference format, unchanged) + `resume.pt`: replay buffer / sum tree contents,
         step counters, epsilon / beta, numpy + torch RNG state -- what the reference cannot resume."""

@@ -203,20 +203,6 @@ class DQN(NativeValueNetMixin, BaseAgent):
             self._adam_steps += 1
         return extra
 
-    def _read_stats(self, *device_tensors):
-        """The learn() statistics in ONE host synchronisation: asynchronous copies into pinned host buffers, one stream
-        sync (a `.cpu()` per tensor is a blocking hipMemcpy each)."""
-        pins = self.__dict__.setdefault("_stat_pins", {})
-        outs = []
-        for i, t in enumerate(device_tensors):
-            key = (i, t.dtype, tuple(t.shape))
-            if key not in pins:
-                pins[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            pins[key].copy_(t, non_blocking=True)
-            outs.append(pins[key])
-        torch.cuda.current_stream().synchronize()
-        return [o.numpy() for o in outs]
-
     def learn(self):
         stats64 = self._run_learn()
         if self._td["per"]:

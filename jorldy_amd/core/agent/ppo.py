@@ -303,7 +303,7 @@ class PPO(BaseAgent):
             self._warm = True
         self.memory._store.clear()
         self._adam_steps += st["n_upd"]
-        s = st["stats"].cpu().numpy().astype(np.float64)  # the only host sync of learn()
+        s = self._read_stats(st["stats"])[0].astype(np.float64)  # the only host sync of learn()
         return self._result(s, st["n_upd"])
 
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
