@@ -29,6 +29,9 @@ import tempfile
 
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import synth  # noqa: E402  (recipes shared with the tests: weights / frames regenerated from a seed)
+
 
 def _to_np(v):
     import torch
@@ -86,6 +89,9 @@ class LineTap:
 
     def __exit__(self, *a):
         sys.settrace(None)
+
+
+RECIPE_SEED = 20260925
 
 
 def flat(prefix, d, out):
@@ -217,18 +223,26 @@ def gen_buffers(out_dir):
 # ----------------------------------------------------------------------------
 # PPO
 # ----------------------------------------------------------------------------
-def gen_ppo(out_dir):
+def gen_ppo(out_dir, only=None):
     import torch
     from core.agent.ppo import PPO
 
     cases = [
-        # name, S, A, hidden, W, T, batch, n_epoch, continuous
-        ("ppo_disc_small", 4, 3, 32, 4, 16, 16, 2, False),
-        ("ppo_disc_cartpole", 4, 2, 64, 8, 128, 256, 3, False),
-        ("ppo_cont_small", 5, 3, 32, 4, 16, 32, 2, True),
-        ("ppo_cont_hopper", 11, 3, 64, 4, 64, 64, 2, True),
+        # name, S, A, hidden, W, T, batch, n_epoch, continuous, recipe
+        ("ppo_disc_small", 4, 3, 32, 4, 16, 16, 2, False, False),
+        ("ppo_disc_cartpole", 4, 2, 64, 8, 128, 256, 3, False, False),
+        ("ppo_cont_small", 5, 3, 32, 4, 16, 32, 2, True, False),
+        ("ppo_cont_hopper", 11, 3, 64, 4, 64, 64, 2, True, False),
+        # BASELINE widths (recipe = initial weights regenerated from a seed, big arrays stored thinned):
+        # config.ppo.cartpole exactly (hidden 512, 8 x 128, minibatch 256, 3 epochs; config/ppo/cartpole.py:9-40)
+        ("ppo_disc_cartpole_h512", 4, 2, 512, 8, 128, 256, 3, False, True),
+        # config.ppo.mujoco Hopper shapes (S=11, A=3, hidden 512, T=2048, distributed batch 2048;
+        # config/ppo/mujoco.py:8-41) with 2 workers x 2 epochs = 4 minibatches of 2048 rows
+        ("ppo_cont_hopper_real", 11, 3, 512, 2, 2048, 2048, 2, True, True),
     ]
-    for name, S, A, H, W, T, B, E, cont in cases:
+    for name, S, A, H, W, T, B, E, cont, recipe in cases:
+        if only is not None and name not in only:
+            continue
         torch.manual_seed(11)
         np.random.seed(11)
         agent = PPO(
@@ -250,29 +264,20 @@ def gen_ppo(out_dir):
             num_workers=W,
             device="cpu",
         )
-        # perturb the heads so pi is not ~uniform / value not ~0 (policy gain is 0.01)
         with torch.no_grad():
-            for p in agent.network.parameters():
-                p.add_(0.05 * torch.randn_like(p))
+            if recipe:
+                rec = synth.ppo_recipe({k: v.shape for k, v in agent.network.state_dict().items()}, RECIPE_SEED)
+                for k, p in agent.network.named_parameters():
+                    p.copy_(torch.from_numpy(rec[k]))
+            else:
+                # perturb the heads so pi is not ~uniform / value not ~0 (policy gain is 0.01)
+                for p in agent.network.parameters():
+                    p.add_(0.05 * torch.randn_like(p))
         sd0 = sd_to_np(agent.network.state_dict())
 
         rng = np.random.RandomState(5)
         M = W * T
-        trs = []
-        for i in range(M):
-            t = {
-                "state": rng.randn(1, S).astype(np.float32),
-                "next_state": rng.randn(1, S).astype(np.float32),
-                "reward": rng.randn(1, 1) * 0.5,
-                "done": np.asarray([[rng.rand() < 0.05]]),
-            }
-            if cont:
-                t["action"] = np.tanh(rng.randn(1, A)).astype(np.float32)
-                if i % 17 == 0:
-                    t["action"][0, 0] = 1.0  # hits the atanh clamp
-            else:
-                t["action"] = rng.randint(0, A, size=(1, 1))
-            trs.append(t)
+        trs = synth.ppo_rollout(rng, M, S, A, cont, clamp_every=0 if recipe else 17)
         agent.memory.first_store = False
 
         # capture pre-softmax / pre-clamp head outputs with grads
@@ -333,10 +338,20 @@ def gen_ppo(out_dir):
         out["cfg"] = np.asarray([S, A, H, W, T, B, E, int(cont)])
         out["hyper"] = np.asarray([0.99, 0.95, 0.1, 1.0, 0.01, 1.0, 2.5e-4])  # gamma, lambda, eps, vf, ent, clip, lr
         out["np_seed"] = np.asarray(21)
-        for k in ("state", "next_state", "reward", "done", "action"):
-            out[f"in_{k}"] = np.concatenate([t[k] for t in trs], 0)
-        flat("sd0/", sd0, out)
-        flat("sd1/", sd_to_np(agent.network.state_dict()), out)
+        th = synth.thin if recipe else (lambda a: a)
+        if recipe:
+            # inputs: synth.ppo_rollout(RandomState(5), M, S, A, cont); weights: synth.ppo_recipe
+            out["recipe_seed"] = np.asarray(RECIPE_SEED)
+            out["rollout_seed"] = np.asarray(5)
+            for k in ("state", "reward", "action"):
+                out[f"in_{k}_check"] = synth.row_checksum(np.concatenate([t[k] for t in trs], 0).astype(np.float32))[:: max(1, M // 64)]
+            flat("sd0_thin/", {k: th(v) for k, v in sd0.items()}, out)
+            flat("sd1_thin/", {k: th(v) for k, v in sd_to_np(agent.network.state_dict()).items()}, out)
+        else:
+            for k in ("state", "next_state", "reward", "done", "action"):
+                out[f"in_{k}"] = np.concatenate([t[k] for t in trs], 0)
+            flat("sd0/", sd0, out)
+            flat("sd1/", sd_to_np(agent.network.state_dict()), out)
         flat("gae/", tap.records["gae_done"][0], out)
         nmb = len(tap.records["mb_loss"])
         out["n_minibatch"] = np.asarray(nmb)
@@ -344,8 +359,12 @@ def gen_ppo(out_dir):
             flat(f"mb{i}/", tap.records["mb_loss"][i], out)
             flat(f"mb{i}/head/", head_grads[i], out)
             if i in (0, nmb - 1):  # param grads are big; keep first and last only
-                flat(f"mb{i}/grad_raw/", grads_raw[i], out)
-                flat(f"mb{i}/grad_clip/", grads_clip[i], out)
+                flat(f"mb{i}/grad_raw/", {k: th(v) for k, v in grads_raw[i].items()}, out)
+                flat(f"mb{i}/grad_clip/", {k: th(v) for k, v in grads_clip[i].items()}, out)
+                if recipe:
+                    out[f"mb{i}/grad_raw_norm"] = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in grads_raw[i].values()))
+                    for k, v in grads_raw[i].items():
+                        out[f"mb{i}/grad_raw_absmax/{k}"] = np.abs(v).max()
         for k, v in result.items():
             out[f"result/{k}"] = np.asarray(v)
         out["lr_after"] = np.asarray(agent.optimizer.param_groups[0]["lr"])
@@ -358,20 +377,8 @@ def gen_ppo(out_dir):
 # ----------------------------------------------------------------------------
 def _fill(agent, n, S, A, rng, n_step=None, with_q=False):
     """Drive interact_callback + memory.store the way Actor.run / run_mode do."""
-    if isinstance(S, int):
-        draw = lambda: rng.randn(1, S).astype(np.float32)
-    else:  # image observation: uint8 frames, as the Atari wrapper hands them over (atari.py:147-149)
-        draw = lambda: rng.randint(0, 256, size=(1,) + tuple(S)).astype(np.uint8)
     for i in range(n):
-        t = {
-            "state": draw(),
-            "action": rng.randint(0, A, size=(1, 1)),
-            "reward": rng.choice([-1.0, 0.0, 1.0, 0.5], size=(1, 1)),
-            "next_state": draw(),
-            "done": np.asarray([[rng.rand() < 0.1]]),
-        }
-        if with_q:
-            t["q"] = rng.randn(1, 1).astype(np.float32)
+        t = synth.raw_transition(rng, S, A, with_q)
         t = agent.interact_callback(t)
         if t:
             agent.memory.store([t])
@@ -413,22 +420,37 @@ def gen_dqn_family(out_dir, only=None):
     # Nature-CNN head on a small non-square image (conv 8/4, 4/2, 3/1 -> 2x3x64 features)
     specs.append(("rainbow_cnn", Rainbow, dict(n_step=3, alpha=0.5, beta=0.4, learn_period=1, uniform_sample_prob=0.05, v_min=-1, v_max=10, num_support=51),
                   dict(markers=specs[-1][3]["markers"], over=dict(state_size=(4, 44, 52), head="cnn", batch_size=8, buffer_size=64), fill=40)))
+    # config.rainbow.atari shapes exactly ((4,84,84) uint8 frames, A=4 = Breakout, B=32, hidden 512, n=3, K=51,
+    # v in [-1,10], alpha .5, beta .4; config/rainbow/atari.py:16-44), PER of 64 slots filled by 60 env steps.
+    # recipe: frames + initial weights regenerated from seeds (oracle/synth.py), big outputs stored thinned.
+    specs.append(("rainbow_cnn_atari", Rainbow, dict(n_step=3, alpha=0.5, beta=0.4, learn_period=1, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51),
+                  dict(markers=specs[-2][3]["markers"], over=dict(state_size=(4, 84, 84), action_size=4, hidden_size=512, head="cnn", batch_size=32, buffer_size=64,
+                                                                  optim_config={"name": "adam", "lr": 6.25e-5}), fill=60, recipe=True)))
+    big = ("rainbow_cnn", "rainbow_cnn_atari")
     for name, cls, extra, opt in specs:
-        if (only is None) == (name == "rainbow_cnn") or (only is not None and name != only):
+        if (only is None and name in big) or (only is not None and name != only):
             continue
         torch.manual_seed(3)
         np.random.seed(3)
         kw = dict(common)
         kw.update(extra)
         kw.update(opt.get("over", {}))
-        S, B = kw["state_size"], kw["batch_size"]
+        S, B, A, H = kw["state_size"], kw["batch_size"], kw["action_size"], kw["hidden_size"]
+        recipe = opt.get("recipe", False)
         agent = cls(**kw)
         with torch.no_grad():
-            for p in agent.network.parameters():
-                p.add_(0.1 * torch.randn_like(p))
-            # target differs from online so double-Q is not degenerate
-            for p in agent.target_network.parameters():
-                p.add_(0.1 * torch.randn_like(p))
+            if recipe:
+                shapes = {k: v.shape for k, v in agent.network.state_dict().items()}
+                for net, seed in ((agent.network, RECIPE_SEED), (agent.target_network, RECIPE_SEED + 1)):
+                    rec = synth.recipe_state_dict(shapes, seed)
+                    for k, p in net.named_parameters():
+                        p.copy_(torch.from_numpy(rec[k]))
+            else:
+                for p in agent.network.parameters():
+                    p.add_(0.1 * torch.randn_like(p))
+                # target differs from online so double-Q is not degenerate
+                for p in agent.target_network.parameters():
+                    p.add_(0.1 * torch.randn_like(p))
         agent.memory.first_store = False
         rng = np.random.RandomState(17)
         _fill(agent, opt.get("fill", 200), S, A, rng, with_q=opt.get("with_q", False))
@@ -447,7 +469,17 @@ def gen_dqn_family(out_dir, only=None):
         for k in keys:
             if k == "priority":
                 continue
-            out[f"buf_{k}"] = np.concatenate([agent.memory.buffer[i][k] for i in range(n)], 0)
+            col = np.concatenate([agent.memory.buffer[i][k] for i in range(n)], 0)
+            if recipe and k in ("state", "next_state"):
+                # frames: raw = [synth.raw_transition(RandomState(17), S, A) ...]; slot i holds raw[i].state and
+                # raw[i + n_step - 1].next_state (rainbow.py:294-308); the checksums pin the regenerated frames
+                out[f"buf_{k}_check"] = synth.row_checksum(col)
+            else:
+                out[f"buf_{k}"] = col
+        if recipe:
+            out["fill"] = np.asarray(opt["fill"])
+            out["fill_seed"] = np.asarray(17)
+            out["recipe_seed"] = np.asarray(RECIPE_SEED)
         if is_per:
             out["tree0"] = agent.memory.sum_tree.copy()
             out["maxp0"] = np.asarray(agent.memory.max_priority)
@@ -456,7 +488,7 @@ def gen_dqn_family(out_dir, only=None):
         is_dist = name in ("c51", "rainbow")
         loss_line = "self.optimizer.zero_grad"
         markers = {
-            "pre_step": (loss_line, opt["markers"] + ["state", "action", "next_state"]),
+            "pre_step": (loss_line, opt["markers"] + (["action"] if recipe else ["state", "action", "next_state"])),
             "step": ("self.optimizer.step()", []),
         }
         tap = LineTap(cls.learn, markers)
@@ -484,16 +516,25 @@ def gen_dqn_family(out_dir, only=None):
         rec = tap.records["pre_step"][0]
         flat("learn/", rec, out)
         flat("learn/", head, out)
-        flat("grad/", graw, out)
-        flat("sd0/", sd0, out)
-        flat("sdt/", sdt, out)
-        flat("sd1/", sd_to_np(agent.network.state_dict()), out)
+        if recipe:
+            flat("grad_thin/", {k: synth.thin(v) for k, v in graw.items()}, out)
+            out["grad_norm"] = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in graw.values()))
+            for k, v in graw.items():
+                out[f"grad_absmax/{k}"] = np.abs(v).max()
+            flat("sd0_thin/", {k: synth.thin(v) for k, v in sd0.items()}, out)
+            flat("sdt_thin/", {k: synth.thin(v) for k, v in sdt.items()}, out)
+            flat("sd1_thin/", {k: synth.thin(v) for k, v in sd_to_np(agent.network.state_dict()).items()}, out)
+        else:
+            flat("grad/", graw, out)
+            flat("sd0/", sd0, out)
+            flat("sdt/", sdt, out)
+            flat("sd1/", sd_to_np(agent.network.state_dict()), out)
         for k, v in result.items():
             out[f"result/{k}"] = np.asarray(v)
         if is_per:
             out["tree1"] = agent.memory.sum_tree.copy()
             out["maxp1"] = np.asarray(agent.memory.max_priority)
-        hyper = dict(gamma=0.99, lr=1e-3, B=B, S=np.asarray(S), A=A, H=H, np_seed=42, torch_seed=42)
+        hyper = dict(gamma=0.99, lr=kw["optim_config"]["lr"], B=B, S=np.asarray(S), A=A, H=H, np_seed=42, torch_seed=42)
         hyper.update({k: v for k, v in extra.items() if isinstance(v, (int, float))})
         for k, v in hyper.items():
             out[f"hyper/{k}"] = np.asarray(v)
@@ -569,17 +610,21 @@ def main():
 
     torch.set_num_threads(1)  # deterministic reductions in the fixtures
     try:
-        todo = args.only.split(",") if args.only else ["buffers", "ppo", "dqn", "nstep"]
+        todo = args.only.split(",") if args.only else ["buffers", "ppo", "dqn", "nstep"]  # + rainbow_cnn, rainbow_cnn_atari on request
         if "buffers" in todo:
             gen_buffers(out_dir)
         if "ppo" in todo:
             gen_ppo(out_dir)
+        ppo_only = [t for t in todo if t.startswith("ppo_")]
+        if ppo_only:
+            gen_ppo(out_dir, only=ppo_only)
         if "dqn" in todo:
             gen_dqn_family(out_dir)
         if "nstep" in todo:
             gen_nstep(out_dir)
-        if "rainbow_cnn" in todo:
-            gen_dqn_family(out_dir, only="rainbow_cnn")
+        for nm in ("rainbow_cnn", "rainbow_cnn_atari"):
+            if nm in todo:
+                gen_dqn_family(out_dir, only=nm)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
     print("golden fixtures written to", out_dir)

@@ -1,0 +1,259 @@
+"""Parity at the BASELINE.json widths, against runs of the unmodified reference (oracle/gen_golden.py):
+
+  ppo_disc_cartpole_h512   config.ppo.cartpole exactly: 4-512-512-{2,1}, 8 x 128 rows, minibatch 256, 3 epochs
+  ppo_cont_hopper_real     config.ppo.mujoco Hopper shapes: 11-512-512-{3,3,1}, T = 2048, minibatch 2048
+                           -> the LDS-tiled engine (jh_tgemm_ppo_fwd_h2 / _bwd / _bwd_dW1) that minibatches
+                           >= 1024 rows switch to
+  rainbow_cnn_atari        config.rainbow.atari exactly: (4,84,84) uint8 frames, A = 4, B = 32, hidden 512
+
+Initial weights and frames are regenerated from seeds (oracle/synth.py) -- the same values the generator
+wrote into the reference agent -- and pinned by checksums / strided samples stored in the fixture.
+Tolerances: north_star's 1e-5 on every loss of the FIRST update (and on the gradients it produces,
+relative to the largest gradient entry of the tensor); later updates are compared with a per-update
+bound and the measured drift is written to gpurun_out/parity_drift_<fixture>.json.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from tests.util import load, npy
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _report(name, payload):
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"parity_drift_{name}.json"), "w") as f:
+        json.dump(payload, f, indent=1)
+
+
+def _thin_cmp(ours, z, prefix, scale_of=None, tol=1e-5, what=""):
+    """ours: {name: array}; fixture holds synth.thin(ref) under prefix+name.  |diff| <= tol * scale where
+    scale = the tensor's largest |reference entry| (stored when thinned, else computed)."""
+    worst = {}
+    for k, v in ours.items():
+        ref = z[prefix + k]
+        got = synth.thin(np.asarray(v))
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        scale = float(scale_of(k)) if scale_of else float(np.abs(ref).max())
+        err = float(np.abs(got - ref).max()) / (scale + 1e-30)
+        worst[k] = err
+        assert err <= tol, f"{what} {k}: max |diff| = {err:.3e} x the tensor's largest entry (allowed {tol:.1e})"
+    return worst
+
+
+def _ppo_agent(z, **kw):
+    from jorldy_amd.core.agent import Agent
+
+    S, A, H, W, T, B, E, cont = [int(x) for x in z["cfg"]]
+    gamma, lam, eps, vf, ent, clip, lr = z["hyper"]
+    agent = Agent("ppo", state_size=S, action_size=A, hidden_size=H, network="continuous_policy_value" if cont else "discrete_policy_value",
+                  optim_config={"name": "adam", "lr": lr}, batch_size=B, n_step=T, n_epoch=E, _lambda=lam, epsilon_clip=eps, vf_coef=vf,
+                  ent_coef=ent, clip_grad_norm=clip, gamma=gamma, run_step=100000, num_workers=W, device="cuda", backend="native", **kw)
+    assert agent.backend == "native"
+    rec = synth.ppo_recipe({k: v.shape for k, v in agent.network.state_dict().items()}, int(z["recipe_seed"]))
+    agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in rec.items()})
+    _thin_cmp({k: npy(v) for k, v in agent.network.state_dict().items()}, z, "sd0_thin/", tol=0.0, what="initial weights")
+    M = W * T
+    trs = synth.ppo_rollout(np.random.RandomState(int(z["rollout_seed"])), M, S, A, bool(cont), clamp_every=0)
+    cols = {k: np.concatenate([t[k] for t in trs], 0) for k in ("state", "next_state", "reward", "done", "action")}
+    for k in ("state", "reward", "action"):
+        assert np.array_equal(synth.row_checksum(cols[k].astype(np.float32))[:: max(1, M // 64)], z[f"in_{k}_check"]), k
+    agent.memory.first_store = False
+    return agent, cols, (S, A, H, W, T, B, E, cont), float(lr)
+
+
+PPO_WIDE = ["ppo_disc_cartpole_h512", "ppo_cont_hopper_real"]
+
+
+@pytest.mark.parametrize("name", PPO_WIDE)
+def test_ppo_first_minibatch_forward_loss_backward(name):
+    """Minibatch 0 of the reference's run, step by step through the C ABI: no-grad passes + GAE, the minibatch
+    forward, the clipped loss (fwd+bwd), the backward into the flat gradient bucket.  For ppo_cont_hopper_real
+    (2048 rows) this is the tiled path: jh_tgemm_ppo_fwd_h2, jh_tgemm_ppo_bwd (grouped dW2 | dh1 | heads), _bwd_dW1."""
+    from jorldy_amd import ops
+
+    z = load(name)
+    agent, cols, (S, A, H, W, T, B, E, cont), lr = _ppo_agent(z, use_graph=False)
+    gamma, lam, eps, vf, ent, clip, _ = [float(v) for v in z["hyper"]]
+    net = agent._net
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    state, nstate, action = dev(cols["state"]), dev(cols["next_state"]), dev(cols["action"])
+    reward, done = dev(cols["reward"]), dev(cols["done"])
+    agent._grow_native(W * T)
+    net = agent._net
+    outs_n = net.forward(nstate)
+    next_value = outs_n[-1].clone()
+    outs = [o.clone() if o is not None else None for o in net.forward(state)]
+    value = outs[-1]
+    np.testing.assert_allclose(npy(value), z["gae/value"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(npy(next_value), z["gae/next_value"], rtol=1e-5, atol=1e-5)
+    logp_old = ops.logp_continuous(outs[0], outs[1], action) if cont else ops.logp_discrete(outs[0], action)
+    np.testing.assert_allclose(npy(logp_old), z["gae/log_prob_old"], rtol=1e-5, atol=1e-5)
+    adv, ret = ops.gae(reward, done, value, next_value, T, gamma, lam, True)
+    np.testing.assert_allclose(npy(adv), z["gae/adv"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(npy(ret), z["gae/ret"], rtol=1e-5, atol=1e-5)
+    # minibatch 0 with the reference's own values upstream (isolates this step)
+    idx = torch.from_numpy(z["mb0/idx"].astype(np.int64)).cuda()
+    adv_r, ret_r, v_r, lp_r = dev(z["gae/adv"]), dev(z["gae/ret"]), dev(z["gae/value"]), dev(z["gae/log_prob_old"])
+    stats = torch.zeros(8, device="cuda")
+    if cont:
+        mu, ls, vp = net.forward(state, idx=idx)
+        np.testing.assert_allclose(npy(mu), z["mb0/head/mu_raw"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(npy(ls), z["mb0/head/log_std_raw"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(npy(vp), z["mb0/head/v"], rtol=1e-5, atol=1e-5)
+        g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu, ls, vp, idx, action, adv_r, ret_r, v_r, lp_r, eps, vf, ent, stats=stats)
+        heads = {"mu_raw": g_mu, "log_std_raw": g_ls, "v": g_v}
+        net.backward(state, idx, g_mu, g_ls, g_v)
+    else:
+        zz, vp = net.forward(state, idx=idx)
+        np.testing.assert_allclose(npy(zz), z["mb0/head/logits"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(npy(vp), z["mb0/head/v"], rtol=1e-5, atol=1e-5)
+        g_z, g_v, _ = ops.ppo_loss_discrete(zz, vp, idx, action, adv_r, ret_r, v_r, lp_r, eps, vf, ent, stats=stats)
+        heads = {"logits": g_z, "v": g_v}
+        net.backward(state, idx, g_z, None, g_v)
+    s = npy(stats)
+    for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")):
+        np.testing.assert_allclose(s[j], z[f"mb0/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
+    for tag, g in heads.items():
+        ref = z[f"mb0/head/d_{tag}"]
+        assert float(np.abs(npy(g) - ref).max()) <= 1e-5 * float(np.abs(ref).max()), tag
+    grads = {k: npy(p.grad) for k, p in agent.network.named_parameters()}
+    worst = _thin_cmp(grads, z, "mb0/grad_raw/", scale_of=lambda k: z[f"mb0/grad_raw_absmax/{k}"], tol=1e-5, what="d(loss)/d")
+    norm = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
+    np.testing.assert_allclose(norm, float(z["mb0/grad_raw_norm"]), rtol=1e-5)
+    _report(name + "_mb0", {"grad_err_rel_to_absmax": worst, "grad_norm": norm, "grad_norm_ref": float(z["mb0/grad_raw_norm"])})
+
+
+# per-update bound on |ours - ref| / (1 + |ref|) for the four loss scalars of update i: 1e-5 at update 0
+# (north_star); afterwards Adam (which normalises every step to ~lr whatever the gradient's size) lets two
+# fp32 trajectories separate: measured drift is in gpurun_out/parity_drift_*.json and DESIGN.md §2.
+def _bound(i):
+    return 1e-5 if i == 0 else 1e-5 + 4e-6 * i
+
+
+@pytest.mark.parametrize("name", PPO_WIDE)
+@pytest.mark.parametrize("graph", [False, True])
+def test_ppo_learn_at_baseline_width(name, graph):
+    z = load(name)
+    agent, cols, (S, A, H, W, T, B, E, cont), lr = _ppo_agent(z, use_graph=graph)
+    n_upd = int(z["n_minibatch"])
+    sd0 = {k: v.clone() for k, v in agent.network.state_dict().items()}
+    for rep in range(3 if graph else 1):  # graph: eager warm-up, capture + replay, replay
+        agent.network.load_state_dict(sd0)
+        agent._net.m.zero_()
+        agent._net.v.zero_()
+        agent._adam_steps = 0
+        agent._net.set_hyper(lr, 0.9, 0.999, 1e-8, step=0.0)
+        agent.time_t, agent.learn_stamp = 0, 0
+        np.random.seed(int(z["np_seed"]))
+        result = agent.process(cols, T)
+        if graph and rep >= 1:
+            assert agent._graph is not None
+        s = npy(agent._stats[:n_upd]).astype(np.float64)
+        drift = []
+        for i in range(n_upd):
+            e = max(abs(s[i, j] - float(z[f"mb{i}/{k}"])) / (1.0 + abs(float(z[f"mb{i}/{k}"])))
+                    for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")))
+            drift.append(e)
+        _report(f"{name}_{'graph' if graph else 'eager'}", {"per_update_max_err_over_1_plus_abs_ref": drift, "bound": [_bound(i) for i in range(n_upd)]})
+        for i, e in enumerate(drift):
+            assert e <= _bound(i), f"{name} rep {rep} update {i}: {e:.3e} > {_bound(i):.1e}  (all: {['%.1e' % d for d in drift]})"
+        for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
+            np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=2e-5, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(agent.optimizer.param_groups[0]["lr"], z["lr_after"], rtol=1e-12)
+        # clipped gradients of the LAST minibatch are what the bucket holds after learn()
+        last = n_upd - 1
+        grads = {k: npy(p.grad) for k, p in agent.network.named_parameters()}
+        _thin_cmp(grads, z, f"mb{last}/grad_clip/", scale_of=lambda k: z[f"mb{last}/grad_raw_absmax/{k}"], tol=2e-4, what="last clipped gradient")
+        # updated weights: Adam moves a weight by ~lr per step whatever its gradient, so weights with a ~0
+        # gradient may land a step apart; 99.5 % within 2e-5, none further than the possible travel
+        tot = bad = 0
+        worst = 0.0
+        for k, v in agent.network.state_dict().items():
+            d = np.abs(synth.thin(npy(v)) - z[f"sd1_thin/{k}"])
+            tot += d.size
+            bad += int((d > 2e-5).sum())
+            worst = max(worst, float(d.max()))
+        assert bad <= 0.005 * tot and worst <= 2.1 * lr * n_upd, (bad, tot, worst)
+
+
+def test_rainbow_learn_at_atari_shapes():
+    """config.rainbow.atari: one Rainbow.learn() of the reference on (4,84,84) uint8 frames, B = 32, hidden 512,
+    A = 4 (conv 8/4, 4/2, 3/1 -> 3136 -> 512 -> noisy 512 x 2 -> {4 x 51, 51}) vs the native network + PER + C51
+    kernels.  Sampled indices and IS weights bit-exact; losses, KL, priorities, logits within 1e-5; every
+    parameter gradient within 1e-5 of the tensor's largest entry."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load("rainbow_cnn_atari")
+    h = lambda k: z[f"hyper/{k}"].item()
+    H, A, K, B, n = int(h("H")), int(h("A")), int(h("num_support")), int(h("B")), int(h("n_step"))
+    S = tuple(int(v) for v in z["hyper/S"])
+    agent = Agent("rainbow", state_size=S, action_size=A, hidden_size=H, head="cnn", optim_config={"name": "adam", "lr": h("lr")},
+                  gamma=h("gamma"), buffer_size=64, batch_size=B, start_train_step=0, target_update_period=10000, run_step=100000,
+                  n_step=n, alpha=h("alpha"), beta=h("beta"), learn_period=1, uniform_sample_prob=h("uniform_sample_prob"),
+                  v_min=h("v_min"), v_max=h("v_max"), num_support=K, device="cuda", backend="native", use_graph=False)
+    assert agent.backend == "native"
+    shapes = {k: v.shape for k, v in agent.network.state_dict().items()}
+    seed = int(z["recipe_seed"])
+    agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, seed).items()})
+    agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, seed + 1).items()})
+    _thin_cmp({k: npy(v) for k, v in agent.network.state_dict().items()}, z, "sd0_thin/", tol=0.0, what="initial weights")
+    _thin_cmp({k: npy(v) for k, v in agent.target_network.state_dict().items()}, z, "sdt_thin/", tol=0.0, what="target weights")
+    # frames: the env steps the generator drew; slot i = (raw[i].state, raw[i+n-1].next_state) (rainbow.py:294-308)
+    rng = np.random.RandomState(int(z["fill_seed"]))
+    raw = [synth.raw_transition(rng, S, A) for _ in range(int(z["fill"]))]
+    n_rows = len(raw) - n + 1
+    cols = {"state": np.concatenate([raw[i]["state"] for i in range(n_rows)], 0),
+            "next_state": np.concatenate([raw[i + n - 1]["next_state"] for i in range(n_rows)], 0)}
+    for k in ("state", "next_state"):
+        assert np.array_equal(synth.row_checksum(cols[k]), z[f"buf_{k}_check"]), k
+    for k in ("action", "reward", "done"):
+        cols[k] = z[f"buf_{k}"]
+    agent.memory.first_store = False
+    agent.memory.store_soa(cols)
+    agent.memory._tree.load(z["tree0"], float(np.asarray(z["maxp0"]).reshape(-1)[0]), int(z["tree_index0"]), n_rows)
+    assert agent.memory._store.column("state").dtype == torch.uint8
+    torch.manual_seed(int(h("torch_seed")))
+    noise = []
+    for _ in range(3):  # network(state), network(next_state), target_network(next_state): utils.py:58-60 draw order
+        d = {}
+        for tag, (i, o) in (("a1", (H, H)), ("v1", (H, H)), ("a2", (H, K * A)), ("v2", (H, K))):
+            d[tag] = (torch.randn(i).cuda(), torch.randn(o).cuda())
+        noise.append(d)
+    agent._noise = noise
+    np.random.seed(int(h("np_seed")))
+    result = agent.learn()
+    errs = {}
+    for k in ("loss", "max_Q", "max_logit", "min_logit"):
+        errs[k] = abs(result[k] - float(z[f"result/{k}"])) / (1.0 + abs(float(z[f"result/{k}"])))
+        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(result["sampled_p"], z["result/sampled_p"], rtol=1e-12)
+    assert result["mean_p"] == z["result/mean_p"].item()
+    st = agent._static
+    assert np.array_equal(npy(st["idx"]), z["learn/indices"].astype(np.int64)), "sampled tree indices"
+    assert np.array_equal(npy(st["w"]), z["learn/weights"].astype(np.float32).reshape(-1)), "IS weights (fp32, as_tensor)"
+    np.testing.assert_allclose(npy(st["logits"][0]), z["learn/logit"], rtol=1e-5, atol=1e-5, err_msg="online logits")
+    errs["logit_max_abs"] = float(np.abs(npy(st["logits"][0]) - z["learn/logit"]).max())
+    # tree after the write-back of OUR fp32 priorities KL^alpha
+    np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=2e-5, atol=1e-6)
+    grads = {k: v.cpu().numpy() for k, v in agent._net.export_state(agent._net.grads).items()}
+    worst = _thin_cmp(grads, z, "grad_thin/", scale_of=lambda k: z[f"grad_absmax/{k}"], tol=1e-5, what="d(loss)/d")
+    norm = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
+    np.testing.assert_allclose(norm, float(z["grad_norm"]), rtol=1e-5)
+    _report("rainbow_cnn_atari", {"result_err_over_1_plus_abs_ref": errs, "grad_err_rel_to_absmax": worst, "grad_norm": norm, "grad_norm_ref": float(z["grad_norm"])})
+    lr = float(h("lr"))
+    tot = bad = 0
+    for k, v in agent.network.state_dict().items():
+        d = np.abs(synth.thin(npy(v)) - z[f"sd1_thin/{k}"])
+        tot += d.size
+        bad += int((d > 0.05 * lr).sum())
+        assert float(d.max()) <= 2.1 * lr, k
+    assert bad <= 0.005 * tot, (bad, tot)
