@@ -37,6 +37,24 @@ def _cmp_sd(net, gold, lr, n_updates, atol=2e-5):
 PPO_CASES = ["ppo_disc_small", "ppo_disc_cartpole", "ppo_cont_small", "ppo_cont_hopper"]
 
 
+def _drift(name, s, z, n_upd, later):
+    """Per-update error of the four loss scalars, |ours - ref| / (1 + |ref|): north_star's 1e-5 on update 0,
+    `later` on the following ones (two fp32 Adam trajectories separate); the measured values go to
+    gpurun_out/parity_drift_<name>.json."""
+    import json
+
+    drift = []
+    for i in range(n_upd):
+        drift.append(max(abs(float(s[i, j]) - float(z[f"mb{i}/{k}"])) / (1.0 + abs(float(z[f"mb{i}/{k}"])))
+                         for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss"))))
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"parity_drift_{name}.json"), "w") as f:
+        json.dump({"per_update_max_err_over_1_plus_abs_ref": drift}, f, indent=1)
+    for i, e in enumerate(drift):
+        assert e <= (1e-5 if i == 0 else later), f"{name} update {i}: {e:.3e}  (all: {['%.1e' % v for v in drift]})"
+
+
 @pytest.mark.parametrize("name", PPO_CASES)
 @pytest.mark.parametrize("soa", [False, True])
 def test_ppo_learn_matches_reference(name, soa):
@@ -61,12 +79,9 @@ def test_ppo_learn_matches_reference(name, soa):
     # per-update losses (the reference's .item() values) and the reported means
     n_upd = int(z["n_minibatch"])
     s = npy(agent._stats[:n_upd])
-    for i in range(n_upd):
-        for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")):
-            tol = 5e-5 if cont else 2e-5
-            np.testing.assert_allclose(s[i, j], z[f"mb{i}/{k}"], rtol=tol, atol=tol, err_msg=f"{name} update {i} {k}")
+    _drift(f"{name}_torch_{'soa' if soa else 'rows'}", s, z, n_upd, later=1e-5)
     for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
-        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
     np.testing.assert_allclose(result["max_ratio"], z["result/max_ratio"], rtol=1e-3)
     np.testing.assert_allclose(agent.optimizer.param_groups[0]["lr"], z["lr_after"], rtol=1e-12)
     _cmp_sd(agent.network, _sd(z, "sd1/"), lr, n_upd)
@@ -111,7 +126,7 @@ def test_td_agents_learn_matches_reference(name, backend):
     _fill_from_fixture(agent, z, per)
     np.random.seed(int(_h(z, "np_seed")))
     result = agent.learn()
-    np.testing.assert_allclose(result["loss"], z["result/loss"], rtol=2e-5)
+    np.testing.assert_allclose(result["loss"], z["result/loss"], rtol=1e-5)
     np.testing.assert_allclose(result["max_Q"], z["result/max_Q"], rtol=1e-5)
     if per:
         np.testing.assert_allclose(result["sampled_p"], z["result/sampled_p"], rtol=1e-12)
@@ -134,7 +149,7 @@ def test_c51_agent_learn_matches_reference():
     np.random.seed(int(_h(z, "np_seed")))
     result = agent.learn()
     for k in ("loss", "max_Q", "max_logit", "min_logit"):
-        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=2e-5, err_msg=k)
+        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-5, err_msg=k)
     _cmp_sd(agent.network, _sd(z, "sd1/"), _h(z, "lr"), 1)
 
 
@@ -172,7 +187,7 @@ def test_rainbow_agent_learn_matches_reference(fixture, backend):
     np.random.seed(int(_h(z, "np_seed")))
     result = agent.learn()
     for k in ("loss", "max_Q", "max_logit", "min_logit"):
-        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=5e-5, err_msg=k)
+        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-5, err_msg=k)
     np.testing.assert_allclose(result["sampled_p"], z["result/sampled_p"], rtol=1e-12)
     np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=1e-4 if cnn else 2e-5, atol=1e-6)
     if backend == "native":  # gradients of every parameter against the reference's autograd
@@ -391,12 +406,9 @@ def test_ppo_native_backend_matches_reference(name, graph):
             assert agent._graph is not None
         n_upd = int(z["n_minibatch"])
         s = npy(agent._stats[:n_upd])
-        for i in range(n_upd):
-            for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")):
-                tol = 1e-4 if cont else 3e-5
-                np.testing.assert_allclose(s[i, j], z[f"mb{i}/{k}"], rtol=tol, atol=tol, err_msg=f"{name} rep {rep} update {i} {k}")
+        _drift(f"{name}_native_{'graph' if graph else 'eager'}", s, z, n_upd, later=1e-5)
         for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
-            np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-4, atol=3e-5, err_msg=k)
+            np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
         np.testing.assert_allclose(agent.optimizer.param_groups[0]["lr"], z["lr_after"], rtol=1e-12)
         _cmp_sd(agent.network, _sd(z, "sd1/"), lr, n_upd, atol=3e-5)
 

@@ -8,9 +8,9 @@
 
 Initial weights and frames are regenerated from seeds (oracle/synth.py) -- the same values the generator
 wrote into the reference agent -- and pinned by checksums / strided samples stored in the fixture.
-Tolerances: north_star's 1e-5 on every loss of the FIRST update (and on the gradients it produces,
-relative to the largest gradient entry of the tensor); later updates are compared with a per-update
-bound and the measured drift is written to gpurun_out/parity_drift_<fixture>.json.
+Tolerances: north_star's 1e-5 on every loss of EVERY update (|ours - ref| / (1 + |ref|)) and on the gradients
+of the first update (relative to the largest gradient entry of the tensor); the measured per-update drift is
+written to gpurun_out/parity_drift_<fixture>.json (committed copies: profiles/r02_parity_drift_*.json).
 """
 import json
 import os
@@ -132,11 +132,10 @@ def test_ppo_first_minibatch_forward_loss_backward(name):
     _report(name + "_mb0", {"grad_err_rel_to_absmax": worst, "grad_norm": norm, "grad_norm_ref": float(z["mb0/grad_raw_norm"])})
 
 
-# per-update bound on |ours - ref| / (1 + |ref|) for the four loss scalars of update i: 1e-5 at update 0
-# (north_star); afterwards Adam (which normalises every step to ~lr whatever the gradient's size) lets two
-# fp32 trajectories separate: measured drift is in gpurun_out/parity_drift_*.json and DESIGN.md §2.
+# bound on |ours - ref| / (1 + |ref|) for the four loss scalars of EVERY update: north_star's 1e-5.  Measured
+# (profiles/r02_parity_drift_*.json): 1.3e-7 at update 0, <= 3.6e-7 after 4 Hopper / 12 CartPole updates.
 def _bound(i):
-    return 1e-5 if i == 0 else 1e-5 + 4e-6 * i
+    return 1e-5
 
 
 @pytest.mark.parametrize("name", PPO_WIDE)
