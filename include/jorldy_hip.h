@@ -153,6 +153,14 @@ int jh_per_dump(jh_per* p, double* h_tree, jh_stream stream);
 int jh_gae(jh_ctx* ctx, int32_t W, int32_t T, float gamma, float lambda, const float* d_reward, const float* d_done,
            const float* d_value, const float* d_next_value, float* d_adv, float* d_ret, int32_t standardize,
            jh_stream stream);
+/* ppo.py:118-125 gathers state[idx], action[idx], adv[idx], ret[idx], value[idx], log_prob_old[idx] inside the
+ * minibatch loop; the index lists of all epochs exist before the loop, so the rows are gathered ONCE per learn():
+ * row i of d_dst[c] ([n][elems[c]] float32) = row d_idx[i] of d_src[c].  n_cols <= 8.  The minibatch kernels then
+ * read consecutive rows (jh_pponet_ppo_update with d_idx = NULL).                                                   */
+int jh_ppo_minibatch_rows(jh_ctx* ctx, int64_t n, const int64_t* d_idx, int32_t n_cols, const int32_t* elems,
+                          const float* const* d_src, float* const* d_dst, jh_stream stream);
+/* ppo.py:112 `ret.mean()`: *d_out = mean of n floats, one workgroup, fixed summation order.                          */
+int jh_mean_f32(jh_ctx* ctx, int64_t n, const float* d_x, float* d_out, jh_stream stream);
 /* log pi_old(a|s): ppo.py:90-92 `pi.gather(1, action).log()` with pi = exp(log_softmax(logits)). */
 int jh_logp_discrete(jh_ctx* ctx, int64_t M, int32_t A, const float* d_logits, const float* d_action, float* d_logp,
                      jh_stream stream);
@@ -239,11 +247,13 @@ int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t*
  * on the flat buckets (ppo.py:166-169).  d_norm_out: optional device float, pre-clip norm.      */
 int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_out, jh_stream stream);
 /* One whole PPO minibatch update (ppo.py:122-169: forward of `state[idx]`, clipped loss forward +
- * backward, encoder backward, clip_grad_norm_, Adam) in 8 launches: the heads never round-trip through
- * HBM as tensors (per-column-tile partials are summed by the loss kernel) and the global gradient norm
- * is accumulated by the gradient GEMMs.  B <= 1024.  do_adam == 0 stops before clip + Adam
- * (data-parallel: all-reduce the bucket, then jh_pponet_adam_step).  d_stats float32[8] as in
- * jh_ppo_loss_*.                                                                                  */
+ * backward, encoder backward, clip_grad_norm_, Adam) in 5 launches (csrc/jh_ppo_mb.hip): layer 1 is
+ * generated in the operand fetch, the heads never exist as tensors (per-column-tile partials are summed
+ * by the loss kernel), d(loss)/d(h2) is generated in the operand fetch of its two consumers, and ONE
+ * backward grid produces every gradient (dh1 only as the per-row-tile partial sums of dW1 / db1).
+ * B <= 1024, hidden_size % 32 == 0.  d_idx may be NULL (rows already gathered: jh_ppo_minibatch_rows).
+ * do_adam == 0 stops after the backward with a complete gradient bucket (data-parallel: all-reduce, then
+ * jh_pponet_adam_step).  d_stats float32[8] as in jh_ppo_loss_*.                                    */
 int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action,
                          const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old,
                          float eps_clip, float vf_coef, float ent_coef, float max_norm, int32_t do_adam, float* d_stats,

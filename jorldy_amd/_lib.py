@@ -65,6 +65,8 @@ _PROTOS = {
     "jh_per_load": (C.c_int, [_vp, _vp, _f64, _i64, _i64]),
     "jh_per_dump": (C.c_int, [_vp, _vp, _vp]),
     "jh_gae": (C.c_int, [_vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "jh_ppo_minibatch_rows": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "jh_mean_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "jh_logp_discrete": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "jh_logp_continuous": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "jh_ppo_loss_discrete": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),

@@ -71,9 +71,9 @@ class PPO(BaseAgent):
             raise ValueError("backend='native' needs head='mlp', an int state_size, Adam without weight decay and <= 8 head outputs")
         self.backend = "native" if (eligible and backend != "torch") else "torch"
         self.use_graph = use_graph
-        # 8-launch fused update (jh_pponet_ppo_update): measured NOT faster than the 11-launch sequence on
-        # MI355X (2.83 vs 2.72 ms per iteration: the fused kernels serialise more phases), so opt-in
-        self.fused_update = os.environ.get("JH_FUSED_UPDATE", "0") == "1"
+        # five-launch minibatch update (jh_pponet_ppo_update) for minibatches < 1024 rows; JH_FUSED_UPDATE=0
+        # keeps the forward / loss / backward / Adam calls separate (same results; used by the A/B in bench)
+        self.fused_update = os.environ.get("JH_FUSED_UPDATE", "1") == "1"
         # capture the RCCL all-reduce of the data-parallel path inside the hipGraph too (falls back to
         # eager launches if the capture is refused)
         self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
@@ -87,6 +87,7 @@ class PPO(BaseAgent):
     # ---------------------------------------------------------------------------------- native engine
     def _init_native(self, S, A, H, seed, max_rows=4096):
         cont = self.action_type == "continuous"
+        self._seed = seed
         net = ops.PPONet(S, H, A, cont, max_rows, self.device, seed=seed)
         params = list(self.network.parameters())
         assert sum(p.numel() for p in params) == net.n_params, "state_dict layout mismatch with libjorldy_hip"
@@ -109,7 +110,7 @@ class PPO(BaseAgent):
             return
         old = self._net
         S, H, A = old.S, old.H, old.A
-        net = ops.PPONet(S, H, A, old.cont, max(rows, 2 * old.max_rows), self.device)
+        net = ops.PPONet(S, H, A, old.cont, max(rows, 2 * old.max_rows), self.device, seed=self._seed)
         for dst, src in ((net.params, old.params), (net.grads, old.grads), (net.m, old.m), (net.v, old.v)):
             dst.copy_(src)
         o = 0
@@ -215,16 +216,27 @@ class PPO(BaseAgent):
         n_mb = (M + self.batch_size - 1) // self.batch_size
         n_upd = self.n_epoch * n_mb
         B = self.batch_size
+        # [state; next_state] and their heads are adjacent so that the two no-grad passes of ppo.py:83-94 are ONE
+        # forward over 2M rows when that fits the latency-oriented kernel
+        x_all, h0_all, v_all = f(2 * M, S), f(2 * M, A), f(2 * M, 1)
+        h1_all = f(2 * M, A) if cont else None
         st = dict(
-            M=M, n_upd=n_upd,
-            tr={"state": f(M, S), "action": f(M, A if cont else 1), "reward": f(M, 1), "next_state": f(M, S), "done": f(M, 1)},
+            M=M, n_upd=n_upd, x_all=x_all, h0_all=h0_all, h1_all=h1_all, v_all=v_all,
+            tr={"state": x_all[:M], "action": f(M, A if cont else 1), "reward": f(M, 1), "next_state": x_all[M:], "done": f(M, 1)},
             arange=torch.arange(M, dtype=torch.int64, device=self.device),
             idx=torch.zeros(self.n_epoch * M, dtype=torch.int64, device=self.device),
-            h0=f(M, A), h1=f(M, A) if cont else None, value=f(M, 1), nh0=f(M, A), nh1=f(M, A) if cont else None, next_value=f(M, 1),
-            logp_old=f(M, A if cont else 1), adv=None, ret=None,
+            h0=h0_all[:M], h1=h1_all[:M] if cont else None, value=v_all[:M], nh0=h0_all[M:], nh1=h1_all[M:] if cont else None, next_value=v_all[M:],
+            logp_old=f(M, A if cont else 1), adv=f(M, 1), ret=f(M, 1),
             mb_h0=f(B, A), mb_h1=f(B, A) if cont else None, mb_v=f(B, 1),
             stats=torch.zeros(n_upd + 1, 8, dtype=torch.float32, device=self.device),
         )
+        # rows of every minibatch of every epoch, gathered once per learn() (jh_ppo_minibatch_rows) when all
+        # minibatches take the five-launch update
+        E = self.n_epoch
+        if self.fused_update and all(self._net.fused_ok(min(B, M - o)) for o in range(0, M, B)):
+            srcs = [st["tr"]["state"], st["tr"]["action"], st["adv"], st["ret"], st["value"], st["logp_old"]]
+            st["mb"] = [f(E * M, int(t.numel() // M)) for t in srcs]
+            st["rows"] = ops.MinibatchRows(srcs, st["mb"])
         self._stats = st["stats"]
         return st
 
@@ -235,28 +247,37 @@ class PPO(BaseAgent):
         cont = net.cont
         tr = st["tr"]
         self.memory._store.gather(st["arange"], as_float=True, out={k: tr[k] for k in tr})
-        net.forward(tr["next_state"], out=(st["nh0"], st["nh1"], st["next_value"]))
-        net.forward(tr["state"], out=(st["h0"], st["h1"], st["value"]))
-        if cont:
-            logp_old = ops.logp_continuous(st["h0"], st["h1"], tr["action"])
+        if 2 * M <= min(net.max_rows, 8192):
+            net.forward(st["x_all"], out=(st["h0_all"], st["h1_all"], st["v_all"]))
         else:
-            logp_old = ops.logp_discrete(st["h0"], tr["action"])
-        adv, ret = ops.gae(tr["reward"], tr["done"], st["value"], st["next_value"], self.n_step, self.gamma, self._lambda, self.use_standardization)
-        st["stats"][st["n_upd"], 0:1].copy_(ret.mean().reshape(1))
+            net.forward(tr["next_state"], out=(st["nh0"], st["nh1"], st["next_value"]))
+            net.forward(tr["state"], out=(st["h0"], st["h1"], st["value"]))
+        if cont:
+            logp_old = ops.logp_continuous(st["h0"], st["h1"], tr["action"], out=st["logp_old"])
+        else:
+            logp_old = ops.logp_discrete(st["h0"], tr["action"], out=st["logp_old"])
+        adv, ret = ops.gae(tr["reward"], tr["done"], st["value"], st["next_value"], self.n_step, self.gamma, self._lambda, self.use_standardization,
+                           out=(st["adv"], st["ret"]))
+        ops.mean_into(ret, st["stats"][st["n_upd"], 0:1])  # ppo.py:112
         k = 0
-        for e in range(self.n_epoch):
-            for offset in range(0, M, B):
-                b = min(B, M - offset)
-                idx = st["idx"][e * M + offset : e * M + offset + b]
-                if b <= 1024 and self.fused_update:
-                    # forward + loss + backward (+ clip + Adam) in 8 launches (jh_pponet_ppo_update)
-                    net.ppo_update(tr["state"], idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef,
+        if "rows" in st:
+            # x[idx] of every epoch in one launch, then forward + loss + backward (+ clip + Adam) in 5 launches per
+            # minibatch on consecutive rows (jh_pponet_ppo_update)
+            xs, acts, advs, rets, vals, lps = st["rows"](st["idx"])
+            for e in range(self.n_epoch):
+                for offset in range(0, M, B):
+                    o0, o1 = e * M + offset, e * M + min(offset + B, M)
+                    net.ppo_update(xs[o0:o1], None, acts[o0:o1], advs[o0:o1], rets[o0:o1], vals[o0:o1], lps[o0:o1], self.epsilon_clip, self.vf_coef,
                                    self.ent_coef, self.clip_grad_norm, st["stats"][k], do_adam=self.grad_sync is None)
                     if self.grad_sync is not None:
                         self.grad_sync.reduce_flat(net.grads)
                         net.adam_step(self.clip_grad_norm)
                     k += 1
-                    continue
+            return
+        for e in range(self.n_epoch):
+            for offset in range(0, M, B):
+                b = min(B, M - offset)
+                idx = st["idx"][e * M + offset : e * M + offset + b]
                 if cont:
                     mu, ls, vp = net.forward(tr["state"], idx=idx, out=(st["mb_h0"][:b], st["mb_h1"][:b], st["mb_v"][:b]))
                     g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu, ls, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])
@@ -272,7 +293,7 @@ class PPO(BaseAgent):
 
     def _learn_native(self):
         M = self.memory.size
-        self._grow_native(M)
+        self._grow_native(2 * M if 2 * M <= 8192 else M)
         if self._static is None or self._static["M"] != M:
             self._static, self._graph = self._alloc_static(M), None
         st = self._static

@@ -18,15 +18,12 @@
 struct jh_persist;
 int jh_persist_create(jh_pponet* n, jh_persist** out);
 void jh_persist_destroy(jh_persist* p);
-int jh_persist_begin(jh_persist* p, int W, int T, int groups, hipStream_t st);
-int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action, int training);
-unsigned jh_persist_next_tag(jh_persist* p);
-void jh_persist_publish(jh_persist* p, int r0, int r1, const float* h_obs, unsigned tag);
-int jh_persist_collect(jh_persist* p, int r0, int r1, unsigned tag, int64_t* h_action, int training);
-void jh_persist_end_step(jh_persist* p);
+int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st);
+unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs);
+int jh_persist_collect(jh_persist* p, int W, unsigned tag, float* h_heads);
+int jh_persist_heads(const jh_persist* p);
 void jh_persist_abort(jh_persist* p);
 void jh_persist_dump_debug(jh_persist* p, int T);
-
 
 struct jh_collector {
   jh_ctx* ctx = nullptr;
@@ -35,17 +32,40 @@ struct jh_collector {
   jh_store* store = nullptr;
   int W = 0;
   int col_state = 0, col_action = 1, col_reward = 2, col_next = 3, col_done = 4;
-  std::vector<float> obs, next_obs, reward;
+  std::vector<float> obs, next_obs, reward, heads;
   std::vector<int64_t> act;
   std::vector<uint8_t> done;
   jh_persist* persist = nullptr;  // null: one launch per timestep
-  int mode = 1;                   // 1: persistent acting kernel (default), 0: launch per step
-  int groups = 1;                 // persistent mode: env rows served as this many half-batches per timestep (1 | 2).  Two halves in
-                                  // flight (JH_PERSIST_GROUPS=2) measured SLOWER (11.2 vs 9.3 us per timestep): the kernel's work per
-                                  // half is latency, not rows, so each half pays a full compute + poll-detection round
+  int mode = 1;                   // 1: persistent acting kernel (default), 0: launch per step (JH_COLLECT_PERSISTENT=0)
   double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
   int64_t steps = 0;
 };
+
+// Categorical(softmax(z)).sample() for row wq of timestep act_ctr (ppo.py:66): inverse CDF on a counter-based
+// splitmix64 uniform, the same stream whichever acting path produced z; argmax when !training.
+static int64_t sample_discrete(const jh_pponet* n, const float* z, int wq, int training) {
+  const int A = n->A;
+  int act = 0;
+  float mx = z[0];
+  for (int k = 1; k < A; ++k)
+    if (z[k] > mx) { mx = z[k]; act = k; }
+  if (!training) return act;
+  float e[16], se = 0.f;
+  for (int k = 0; k < A; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
+  uint64_t x = n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq;
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x = x ^ (x >> 31);
+  const float u = (float)((double)(x >> 11) * (1.0 / 9007199254740992.0)) * se;
+  float c = 0.f;
+  act = A - 1;
+  for (int k = 0; k < A; ++k) {
+    c += e[k];
+    if (u < c) { act = k; break; }
+  }
+  return act;
+}
 
 JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store,
                                   const int32_t* cols /* state, action, reward, next_state, done */,
@@ -64,21 +84,26 @@ JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env,
   c->ctx = ctx; c->net = net; c->env = env; c->store = store; c->W = env->W;
   c->col_state = cols[0]; c->col_action = cols[1]; c->col_reward = cols[2]; c->col_next = cols[3]; c->col_done = cols[4];
   if (const char* e = getenv("JH_COLLECT_PERSISTENT")) c->mode = atoi(e);
-  if (const char* e = getenv("JH_PERSIST_GROUPS")) c->groups = atoi(e) == 2 ? 2 : 1;
-  if (c->W % 2) c->groups = 1;
-  if (c->mode == 1 && c->W <= 16 && net->H % 128 == 0 && net->A + 1 <= 3) {
-    if (jh_persist_create(net, &c->persist) != JH_OK) c->persist = nullptr;  // e.g. LDS too small: fall back
+  if (c->mode == 1 && c->W <= 16 && c->W * net->S <= 64) {
+    if (jh_persist_create(net, &c->persist) != JH_OK) c->persist = nullptr;  // unsupported width: one launch per step
   }
   c->obs.resize(4 * (size_t)c->W);
   c->act.resize(c->W);
   c->next_obs.resize(4 * (size_t)c->W);
   c->reward.resize(c->W);
   c->done.resize(c->W);
+  c->heads.resize(16 * (size_t)c->W);
   *out = c;
   return JH_OK;
 }
 
 JH_EXPORT void jh_collector_destroy(jh_collector* c) {
+  if (!c) return;
+  if (c->persist) {
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipDeviceSynchronize();
+    jh_persist_destroy(c->persist);
+  }
   delete c;
 }
 
@@ -97,7 +122,7 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
   uint8_t* dn = (uint8_t*)cols[c->col_done];
   bool persistent = c->persist != nullptr;
   if (persistent) {
-    rc = jh_persist_begin(c->persist, W, T, c->groups, jh_s(stream));
+    rc = jh_persist_begin(c->persist, W, T, jh_s(stream));
     if (rc) persistent = false;
   }
   auto record = [&](int t, int r0, int r1) {
@@ -110,58 +135,20 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
       dn[row] = c->done[w];
     }
   };
-  int t_start = 0;
-  if (persistent && c->groups == 2) {
-    // Two half-batches in flight: while the host samples / steps / republishes half A, the kernel works on half B.
-    // Per-env trajectories and the sampling stream (keyed by timestep and row) are the same as with one batch.
-    const int half = W / 2;
-    jh_cartpole_obs(c->env, c->obs.data());
-    unsigned tag = jh_persist_next_tag(c->persist);
-    jh_persist_publish(c->persist, 0, half, c->obs.data(), tag);
-    jh_persist_publish(c->persist, half, W, c->obs.data(), tag);
-    int t = 0;
-    for (; t < T && persistent; ++t) {
-      const unsigned tag_next = t + 1 < T ? jh_persist_next_tag(c->persist) : 0u;
-      for (int g = 0; g < 2; ++g) {
-        const int r0 = g * half, r1 = r0 + half;
-        const auto t0 = std::chrono::steady_clock::now();
-        rc = jh_persist_collect(c->persist, r0, r1, tag, c->act.data(), training);
-        if (rc) {  // the kernel gave up: finish THIS timestep's remaining rows and the rest of the rollout with per-step launches
-          jh_persist_abort(c->persist);
-          JH_HIP(hipStreamSynchronize(jh_s(stream)));
-          persistent = false;
-          rc = jh_pponet_act_discrete(c->net, W - r0, c->obs.data() + 4 * r0, c->act.data() + r0, nullptr, nullptr, training, stream);
-          if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
-          jh_cartpole_step_rows(c->env, r0, W, c->act.data(), c->next_obs.data(), c->reward.data(), c->done.data());
-          record(t, r0, W);
-          break;
-        }
-        const auto t1 = std::chrono::steady_clock::now();
-        jh_cartpole_step_rows(c->env, r0, r1, c->act.data(), c->next_obs.data(), c->reward.data(), c->done.data());
-        record(t, r0, r1);
-        if (t + 1 < T) {
-          jh_cartpole_obs_rows(c->env, r0, r1, c->obs.data());  // next state, or the reset state where the episode ended
-          jh_persist_publish(c->persist, r0, r1, c->obs.data(), tag_next);
-        }
-        const auto t2 = std::chrono::steady_clock::now();
-        c->t_act += std::chrono::duration<double>(t1 - t0).count();
-        c->t_env += std::chrono::duration<double>(t2 - t1).count();
-      }
-      jh_persist_end_step(c->persist);
-      c->steps += 1;
-      tag = tag_next;
-    }
-    t_start = t;  // == T, or (after a fall-back) the first timestep the generic loop below still has to do
-  }
-  for (int t = t_start; t < T; ++t) {
+  for (int t = 0; t < T; ++t) {
     jh_cartpole_obs(c->env, c->obs.data());  // current state of every env (reset state where it just finished)
     const auto t0 = std::chrono::steady_clock::now();
     if (persistent) {
-      rc = jh_persist_step(c->persist, W, c->obs.data(), c->act.data(), training);
+      const unsigned tag = jh_persist_publish(c->persist, W, c->obs.data());
+      rc = jh_persist_collect(c->persist, W, tag, c->heads.data());
       if (rc) {  // the kernel gave up (it exits by itself): finish this rollout with per-step launches
         jh_persist_abort(c->persist);
         JH_HIP(hipStreamSynchronize(jh_s(stream)));
         persistent = false;
+      } else {
+        const int no = jh_persist_heads(c->persist);
+        for (int w = 0; w < W; ++w) c->act[w] = sample_discrete(c->net, c->heads.data() + (size_t)w * no, w, training);
+        c->net->act_ctr += 1;
       }
     }
     if (!persistent) {

@@ -131,21 +131,10 @@ struct jh_pponet {
   unsigned *flag_pin_h = nullptr, *flag_pin_d = nullptr;   // [tiles] per-tile sequence words
   unsigned act_seq = 0;
   uint64_t act_seed = 0, act_ctr = 0;  // host-side counter-based sampling stream
-  // fork/join of the independent backward GEMMs (parallel graph branches under capture)
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  int fork_backward = 0;  // measured slower on MI355X/ROCm 7.2 (3.54 vs 3.24 ms per iteration): off by default
-  float* fwd_part = nullptr;      // [H/16][max_rows][8] per-column-tile partial head outputs (fused forward)
-  float* g_heads = nullptr;       // [max_rows][2A+1] d(loss)/d(raw heads) of the fused update
-  float* ssq_part = nullptr;      // per-workgroup sums of squares written by the gradient GEMMs
-  int ssq_slots = 0;
-  unsigned* adam_ticket = nullptr;
+  float* fwd_part = nullptr;      // [H/16][max_rows][8] per-column-tile partial head outputs (jh_ppo_mb.hip forward)
+  float* part_w1 = nullptr;       // [min(max_rows,1024)/16][H*S + H] per-row-tile partial (dW1 | db1) sums
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
-  // grouped backward (jh_tgemm): dW2, dh1 and the head weight gradients in ONE launch.  Measured SLOWER end to end
-  // (2.67 vs 2.36 ms per bench iteration: one 19 us split-K kernel against three 6-12 us kernels that pipeline
-  // inside the graph): opt-in with JH_PPO_GROUPED_BACKWARD=1
-  int grouped_backward = -1;  // -1 auto: minibatches >= 1024 rows (there the LDS-tiled engine wins by a wide margin), 0 never, 1 always
   float* xg = nullptr;        // [max_rows][S] gathered observation rows (B operand of dW1 on the tiled engine)
   float* tg_ws = nullptr;
   size_t tg_ws_floats = 0;

@@ -17,6 +17,7 @@
 //     same permutation of K for A and B, so the sum is unchanged and every load is 16 B wide;
 //   * bias gradients (column sums of the upstream gradient) fall out of the A fragments as row
 //     sums, so they cost no extra pass.
+#include "jh_ppo_mb.h"
 #include "jh_tgemm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -79,10 +80,6 @@ struct GemmArgs {
   const float* hbias[8];  // bias of head output o, added by column-tile 0
   unsigned* tile_flag;   // optional [tiles] (device-mapped pinned host words): set to flag_seq per tile
   unsigned flag_seq;
-  float* h1_out;         // A_MODE 2: column-tile 0 also materialises the generated layer-1 tile (for backward)
-  int ldh1;
-  float* ssq_out;        // optional [workgroups]: sum of squares of everything this workgroup wrote (gradient
-                         // GEMMs: the global-norm clip needs no separate pass over the gradient bucket)
 };
 
 template <int A_MODE, bool B_KCONT, int EPI, bool ROWSUM, int U, int TM, int TN>
@@ -217,12 +214,6 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
       }
     }
     __syncthreads();
-    if (g.h1_out && tn_blk == 0) {
-      for (int i = threadIdx.x; i < 16 * g.K; i += 256) {
-        const int rr = i / g.K, k = i - rr * g.K;
-        if (m0 + rr < g.M) g.h1_out[(size_t)(m0 + rr) * g.ldh1 + k] = h1s[rr * ldh + k];
-      }
-    }
   }
 
   for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
@@ -255,7 +246,6 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
   }
   __syncthreads();
   if (wid != 0) return;
-  float ssq = 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (ROWSUM && tn_blk == 0) {
@@ -266,7 +256,6 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
         const int m = m0 + 16 * tm + r;
         if (EPI == EPI_ROWPTR) *g.rowsum_ptr[m] = t;
         else g.rowsum[m] = t;
-        ssq = fmaf(t, t, ssq);
       }
     }
 #pragma unroll
@@ -290,7 +279,6 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
         if (!n_ok[tn] || mm >= g.M) continue;
         if (EPI == EPI_ROWPTR) g.rowptr[mm][n] = v;
         else if (EPI != EPI_HEADPART || g.C) g.C[(size_t)mm * g.ldc + n] = v;
-        ssq = fmaf(v, v, ssq);
       }
       if (EPI == EPI_HEADPART) {
         // partial head outputs of this 16-column tile: reduce over the 16 lanes that share kq
@@ -312,10 +300,6 @@ __global__ void __launch_bounds__(256) jh_gemm16_kernel(GemmArgs g) {
         }
       }
     }
-  }
-  if ((EPI == EPI_NONE || EPI == EPI_ROWPTR) && g.ssq_out) {
-    ssq = jh_wave_sum(ssq);
-    if (lane == 0) g.ssq_out[blockIdx.x] = ssq;
   }
   if (EPI == EPI_HEADPART && g.tile_flag) {
     // Acting hand-off to the HOST: the partial head outputs went to device-mapped pinned memory;
@@ -420,53 +404,42 @@ __global__ void __launch_bounds__(256) jh_gradnorm_kernel(int64_t n, const float
   }
 }
 
-// advance_step != 0 (fused-norm path, no gradnorm kernel ran): every workgroup derives the bias
-// corrections from step + 1 itself; the LAST workgroup to finish stores the new step -- all others
-// read hyper[4] at their start, i.e. before they took their ticket, so nobody can see the new value.
 __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       const float* __restrict__ partial, int n_partial,
-                                                      float* __restrict__ hyper, float max_norm,
-                                                      float* __restrict__ norm_out, int advance_step,
-                                                      unsigned* __restrict__ ticket) {
+                                                      const float* __restrict__ hyper, float max_norm,
+                                                      float* __restrict__ norm_out) {
   __shared__ float s_red[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
   const float total = sqrtf(jh_block_reduce(acc, s_red, JhAdd(), 0.f));
-  float bc1 = hyper[5], bc2s = hyper[6];
-  float t_new = 0.f;
-  if (advance_step) {
-    t_new = hyper[4] + 1.f;
-    bc1 = 1.f - powf(hyper[1], t_new);
-    bc2s = sqrtf(1.f - powf(hyper[2], t_new));
-  }
+  const float bc1 = hyper[5], bc2s = hyper[6];
   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total + 1e-6), clamped to 1
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float step_size = lr / bc1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * coef;
-    g[i] = gi;                                         // clip is in place, like the reference
-    const float mi = m[i] + (1.f - b1) * (gi - m[i]);  // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
+  auto upd = [&](float& pi, float& gi_, float& mi_, float& vi_) {
+    const float gi = gi_ * coef;
+    gi_ = gi;                                        // clip is in place, like the reference
+    const float mi = mi_ + (1.f - b1) * (gi - mi_);  // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = vi_ * b2 + (1.f - b2) * gi * gi;
+    mi_ = mi;
+    vi_ = vi;
     const float denom = sqrtf(vi) / bc2s + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    pi = pi - step_size * (mi / denom);
+  };
+  const int64_t n4 = n >> 2;  // the buckets are 16-byte aligned: 16-byte accesses + <= 3 trailing elements
+  float4 *p4 = reinterpret_cast<float4*>(p), *g4 = reinterpret_cast<float4*>(g), *m4 = reinterpret_cast<float4*>(m), *v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+    p4[i] = pp; g4[i] = gg; m4[i] = mm; v4[i] = vv;
   }
-  if (advance_step) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tk == gridDim.x - 1) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hyper[4] = t_new;
-        hyper[5] = bc1;
-        hyper[6] = bc2s;
-      }
-    }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - (n4 << 2))) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    upd(p[i], g[i], m[i], v[i]);
   }
 }
 
@@ -527,25 +500,20 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     memset(n->flag_pin_h, 0, sizeof(unsigned) * tiles);
     n->act_seed = seed;
   }
-  for (int i = 0; i < 2; ++i) {
-    JH_HIP(hipStreamCreateWithFlags(&n->aux[i], hipStreamNonBlocking));
-    JH_HIP(hipEventCreateWithFlags(&n->ev_join[i], hipEventDisableTiming));
-  }
-  JH_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
-  if (const char* e = getenv("JH_FORK_BACKWARD")) n->fork_backward = atoi(e);
-  if (const char* e = getenv("JH_PPO_GROUPED_BACKWARD")) n->grouped_backward = atoi(e);
   n->tg_ws_floats = (size_t)4 << 20;
   n->tg_cnt_slots = 4096;
   JH_HIP(hipMalloc((void**)&n->xg, sizeof(float) * (size_t)max_rows * (size_t)S));
   JH_HIP(hipMalloc((void**)&n->tg_ws, sizeof(float) * n->tg_ws_floats));
   JH_HIP(hipMalloc((void**)&n->tg_cnt, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
   JH_HIP(hipMemset(n->tg_cnt, 0, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
-  JH_HIP(hipMalloc((void**)&n->fwd_part, sizeof(float) * 8 * (size_t)max_rows * (size_t)(H / 16)));
-  JH_HIP(hipMalloc((void**)&n->g_heads, sizeof(float) * (size_t)max_rows * (size_t)(2 * A + 1)));
-  n->ssq_slots = (H / 16) * (H / 16) + (H / 16) + (H / 16) * ((S + 15) / 16);  // dW2 + dW_heads + dW1 tiles
-  JH_HIP(hipMalloc((void**)&n->ssq_part, sizeof(float) * (size_t)n->ssq_slots));
-  JH_HIP(hipMalloc((void**)&n->adam_ticket, 64));
-  JH_HIP(hipMemset(n->adam_ticket, 0, 64));
+  {
+    const size_t part_bytes = sizeof(float) * 8 * (size_t)max_rows * (size_t)(H / 16);
+    JH_HIP(hipMalloc((void**)&n->fwd_part, part_bytes));
+    JH_HIP(hipMemset(n->fwd_part, 0, part_bytes));  // head slots >= n_out are never written: they must read as 0
+    JH_HIP(hipMemset(n->g_all, 0, sizeof(float) * 8 * (size_t)max_rows));
+    const size_t slabs = (size_t)(((max_rows < 1024 ? max_rows : 1024) + 15) / 16);
+    JH_HIP(hipMalloc((void**)&n->part_w1, sizeof(float) * slabs * ((size_t)H * S + H)));
+  }
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
   const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
@@ -562,13 +530,8 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipFree(n->g_all);
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
-  (void)hipFree(n->fwd_part); (void)hipFree(n->g_heads); (void)hipFree(n->ssq_part); (void)hipFree(n->adam_ticket);
+  (void)hipFree(n->fwd_part); (void)hipFree(n->part_w1);
   (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt); (void)hipFree(n->xg);
-  for (int i = 0; i < 2; ++i) {
-    if (n->aux[i]) (void)hipStreamDestroy(n->aux[i]);
-    if (n->ev_join[i]) (void)hipEventDestroy(n->ev_join[i]);
-  }
-  if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
   delete n;
 }
 
@@ -624,9 +587,16 @@ static int head_rows(jh_pponet* n, const float* w[8], float* dw[8], const float*
   return o + 1;
 }
 
-// x: [*, S] rows (device, or pinned host memory mapped into the device address space), gathered
-// through d_idx when given.  Activations h1/h2 stay in the net's workspace for a following backward.
-static inline bool pponet_use_tiled(const jh_pponet* n, int B) { return n->grouped_backward == 1 || (n->grouped_backward < 0 && B >= 1024); }
+// Minibatches of >= kTiledRows rows (config.ppo.mujoco: 2048) run on the LDS-tiled engine (operand reuse across
+// a 64 x 64 tile); smaller ones on the latency-oriented kernels of jh_ppo_mb.hip / jh_gemm16.
+constexpr int kTiledRows = 1024;
+static inline bool pponet_use_tiled(int B) { return B >= kTiledRows; }
+
+static PmbHeads pmb_heads(jh_pponet* n) {
+  PmbHeads hd{};
+  hd.n_out = head_rows(n, hd.w, hd.dw, hd.b, hd.db);
+  return hd;
+}
 
 __global__ void __launch_bounds__(256) jh_rowgather_f32_kernel(int B, int S, const float* __restrict__ x, const int64_t* __restrict__ idx, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -635,6 +605,26 @@ __global__ void __launch_bounds__(256) jh_rowgather_f32_kernel(int B, int S, con
   out[i] = x[(idx ? idx[b] : (int64_t)b) * S + s];
 }
 
+static int pponet_l1(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
+  const int64_t bh = (int64_t)B * n->H;
+  JH_LAUNCH(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, n->H, d_x, d_idx,
+            n->params + n->o_w1, n->params + n->o_b1, n->h1);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// Forward into the per-column-tile partial heads (n->fwd_part) + activations: the first launch of the
+// five-launch update and of every no-grad pass.  Layer 1 is generated in registers for S <= 8.
+static int pponet_forward_partials(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
+  const PmbHeads hd = pmb_heads(n);
+  if (n->S <= 8) return jh_pmb_forward(n, B, d_x, d_idx, hd, nullptr, true, st);
+  int rc = pponet_l1(n, B, d_x, d_idx, st);
+  if (rc) return rc;
+  return jh_pmb_forward(n, B, d_x, d_idx, hd, n->h1, true, st);
+}
+
+// x: [*, S] rows (device, or pinned host memory mapped into the device address space), gathered
+// through d_idx when given.  Activations h1/h2 stay in the net's workspace for a following backward.
 JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, float* d_head0,
                                 float* d_head1, float* d_value, jh_stream stream) {
   JH_ARG(n && d_x && d_head0 && d_value);
@@ -642,12 +632,14 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   JH_ARG(!n->cont || d_head1);
   hipStream_t st = jh_s(stream);
   const int H = n->H;
-  const int64_t bh = (int64_t)B * H;
-  JH_LAUNCH(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, H, d_x, d_idx,
-            n->params + n->o_w1, n->params + n->o_b1, n->h1);
-  JH_LAUNCH_CHECK();
-  int rc;
-  if (pponet_use_tiled(n, B)) {  // large batches: LDS-tiled engine (operand reuse across the 64 x 64 tile)
+  if (jh_pmb_eligible(n, B) && B <= 8192) {
+    int rc = pponet_forward_partials(n, B, d_x, d_idx, st);
+    if (rc) return rc;
+    return jh_pmb_heads_finish(n, B, d_head0, d_head1, d_value, st);
+  }
+  int rc = pponet_l1(n, B, d_x, d_idx, st);
+  if (rc) return rc;
+  if (pponet_use_tiled(B)) {
     TGemm tg = mk_gemm(B, H, H, op_dense(OP_KCONT, n->h1, H), op_dense(OP_KCONT, n->params + n->o_w2, H), n->h2, H, TEPI_BIAS_RELU, n->params + n->o_b2);
     TGemmWorkspace tw;
     tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
@@ -665,18 +657,12 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   return JH_OK;
 }
 
-// Backward of the LAST forward (same B, x, idx): overwrites the flat gradient bucket.
-static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0,
-                           const float* d_g_head1, const float* d_g_value, bool fused_ssq, jh_stream stream);
-
+// Backward of the LAST forward (same B, x, idx) given d(loss)/d(raw heads) as separate arrays: overwrites the
+// flat gradient bucket.  (The PPO agent's minibatches of < kTiledRows rows go through jh_pponet_ppo_update
+// instead, where the head gradients never leave the packed [B][8] form.)
 JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx,
                                  const float* d_g_head0, const float* d_g_head1, const float* d_g_value,
                                  jh_stream stream) {
-  return pponet_backward(n, B, d_x, d_idx, d_g_head0, d_g_head1, d_g_value, false, stream);
-}
-
-static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0,
-                           const float* d_g_head1, const float* d_g_value, bool fused_ssq, jh_stream stream) {
   JH_ARG(n && d_x && d_g_head0 && d_g_value);
   JH_ARG(B > 0 && B <= n->max_rows);
   JH_ARG(!n->cont || d_g_head1);
@@ -690,9 +676,9 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
   const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
   const int n_out = head_rows(n, w, dw, b, db);
   int rc;
-  if (pponet_use_tiled(n, B) && !fused_ssq) {
+  if (pponet_use_tiled(B)) {
     // dW2, dh1 and the head weight gradients only need dh2 / g_all: ONE grouped launch of the tiled MFMA GEMM
-    // (split-K over the batch / the hidden width) instead of three launches of 10-16 us each.
+    // (split-K over the batch / the hidden width), then dW1 over the gathered observation rows (K = B is long)
     const int A = n->A;
     TGemm g[6];
     int ng = 0;
@@ -712,46 +698,24 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
     tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
     rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd", g, ng, st);
     if (rc) return rc;
-    if (B >= 1024) {  // dW1 on the tiled engine too (K = B is long): gather the observation rows once
-      JH_LAUNCH(jh_rowgather_f32_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, st, B, S, d_x, d_idx, n->xg);
-      JH_LAUNCH_CHECK();
-      g[0] = mk_gemm(H, S, B, op_dense(OP_XCONT, n->dh1, H), op_dense(OP_XCONT, n->xg, S), n->grads + n->o_w1, S, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b1);
-      return jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd_dW1", g, 1, st);
-    }
-    GemmArgs g1{};  // dW1[j][s] = sum_b dh1[b][j] x[r(b)][s] ; db1[j] = sum_b dh1[b][j]  (B = gathered x rows [K=B][N=S])
-    g1.M = H; g1.N = S; g1.K = B; g1.A = n->dh1; g1.lda = H; g1.B = d_x; g1.ldb = S; g1.b_rows = d_idx;
-    g1.C = n->grads + n->o_w1; g1.ldc = S; g1.rowsum = n->grads + n->o_b1;
-    return launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW1", g1, st);
-  }
-  // After dh2 three chains are independent: {dW_heads}, {dW2}, {dh1 -> dW1}.  Fork the first two onto
-  // auxiliary streams (parallel branches of the captured graph; concurrent queues when eager) so their
-  // fixed per-kernel cost overlaps with the dh1 -> dW1 chain, and join before returning.
-  const bool fork = n->fork_backward != 0;
-  hipStream_t s_heads = fork ? n->aux[0] : st, s_w2 = fork ? n->aux[1] : st;
-  if (fork) {
-    JH_HIP(hipEventRecord(n->ev_fork, st));
-    JH_HIP(hipStreamWaitEvent(n->aux[0], n->ev_fork, 0));
-    JH_HIP(hipStreamWaitEvent(n->aux[1], n->ev_fork, 0));
+    JH_LAUNCH(jh_rowgather_f32_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, st, B, S, d_x, d_idx, n->xg);
+    JH_LAUNCH_CHECK();
+    g[0] = mk_gemm(H, S, B, op_dense(OP_XCONT, n->dh1, H), op_dense(OP_XCONT, n->xg, S), n->grads + n->o_w1, S, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b1);
+    return jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd_dW1", g, 1, st);
   }
   {  // dWh[o][k] = sum_b g[b][o] h2[b][k] ; dbh[o] = sum_b g[b][o]      (A = g_all^T stored [K=B][8])
     GemmArgs g{};
     g.M = n_out; g.N = H; g.K = B; g.A = n->g_all; g.lda = 8; g.B = n->h2; g.ldb = H;
     for (int o = 0; o < n_out; ++o) { g.rowptr[o] = dw[o]; g.rowsum_ptr[o] = db[o]; }
-    if (fused_ssq) g.ssq_out = n->ssq_part + (H / 16) * (H / 16);
-    rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 1>("jh_gemm16_bwd_dWheads", g, s_heads);
+    rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 1>("jh_gemm16_bwd_dWheads", g, st);
     if (rc) return rc;
   }
   {  // dW2[o][i] = sum_b dh2[b][o] h1[b][i] ; db2[o] = sum_b dh2[b][o]  (A = dh2^T stored [K=B][M=H])
     GemmArgs g{};
     g.M = H; g.N = H; g.K = B; g.A = n->dh2; g.lda = H; g.B = n->h1; g.ldb = H; g.C = n->grads + n->o_w2; g.ldc = H;
     g.rowsum = n->grads + n->o_b2;
-    if (fused_ssq) g.ssq_out = n->ssq_part;
-    rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW2", g, s_w2);
+    rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW2", g, st);
     if (rc) return rc;
-  }
-  if (fork) {
-    JH_HIP(hipEventRecord(n->ev_join[0], n->aux[0]));
-    JH_HIP(hipEventRecord(n->ev_join[1], n->aux[1]));
   }
   {  // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]                 (B = W2 stored [K=H_out][N=H_in])
     GemmArgs g{};
@@ -764,14 +728,16 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
     GemmArgs g{};
     g.M = H; g.N = S; g.K = B; g.A = n->dh1; g.lda = H; g.B = d_x; g.ldb = S; g.b_rows = d_idx;
     g.C = n->grads + n->o_w1; g.ldc = S; g.rowsum = n->grads + n->o_b1;
-    if (fused_ssq) g.ssq_out = n->ssq_part + (H / 16) * (H / 16) + (H / 16);
     rc = launch_gemm<1, false, EPI_NONE, true, 1, 1>("jh_gemm16_bwd_dW1", g, st);
     if (rc) return rc;
   }
-  if (fork) {
-    JH_HIP(hipStreamWaitEvent(st, n->ev_join[0], 0));
-    JH_HIP(hipStreamWaitEvent(st, n->ev_join[1], 0));
-  }
+  return JH_OK;
+}
+
+static int pponet_adam(jh_pponet* n, float max_norm, float* d_norm_out, hipStream_t st) {
+  JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
+            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out);
+  JH_LAUNCH_CHECK();
   return JH_OK;
 }
 
@@ -782,60 +748,36 @@ JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_ou
   hipStream_t st = jh_s(stream);
   JH_LAUNCH(jh_gradnorm_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial, n->hyper);
   JH_LAUNCH_CHECK();
-  JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
-            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out, 0, n->adam_ticket);
-  JH_LAUNCH_CHECK();
-  return JH_OK;
+  return pponet_adam(n, max_norm, d_norm_out, st);
 }
 
-// One PPO minibatch update (ppo.py:122-169) in 8 launches instead of 11:
-//   1 fused forward   layer 1 generated in LDS as the GEMM's A operand (and materialised once for the
-//                     backward), h2 stored, heads reduced per column tile in the epilogue
-//   2 loss fwd+bwd    sums the head partials in LDS, clipped surrogate / value / entropy, d(heads)
-//   3 dh2             + packed head gradients
-//   4-7 GEMMs         dW_heads, dW2, dh1, dW1 (+ bias gradients as row sums, + per-workgroup sum of
-//                     squares of everything written)
-//   8 clip + Adam     the global norm comes from the GEMMs' partials; the step counter advances inside
-// do_adam == 0 stops after launch 7 (data-parallel: all-reduce, then jh_pponet_adam_step).
-int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows,
+int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows, int part_ld,
                               const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
                               const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
-                              float* d_g0, float* d_g1, float* d_gv, float* d_stats, hipStream_t st);
+                              float* d_g_all, float* d_stats, hipStream_t st);
 
+// One PPO minibatch update (ppo.py:122-169) in five launches (jh_ppo_mb.hip): forward into partial heads,
+// loss fwd+bwd -> packed head gradients, ONE backward grid (dh1 -> dW1/db1 partials | dW2/db2 | head weights),
+// partial combine + global norm, clip + Adam.  do_adam == 0 stops after the backward with a complete gradient
+// bucket (data-parallel: all-reduce, then jh_pponet_adam_step).
 JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action,
                                    const float* d_adv, const float* d_ret, const float* d_value_old,
                                    const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef, float max_norm,
                                    int32_t do_adam, float* d_stats, jh_stream stream) {
   JH_ARG(n && d_x && d_action && d_adv && d_ret && d_value_old && d_logp_old);
   JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
+  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update needs hidden_size %% 32 == 0 (H = %d)", n->H);
   hipStream_t st = jh_s(stream);
-  const int H = n->H, A = n->A;
-  const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
-  const int n_out = head_rows(n, w, dw, b, db);
-  {
-    GemmArgs g{};
-    g.M = B; g.N = H; g.K = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = n->h2; g.ldc = H; g.aux = n->params + n->o_b2;
-    g.x = d_x; g.x_rows = d_idx; g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.S = n->S;
-    g.h1_out = n->h1; g.ldh1 = H;
-    for (int o = 0; o < n_out; ++o) { g.wh[o] = w[o]; g.hbias[o] = b[o]; }
-    g.n_out = n_out; g.part = n->fwd_part; g.part_rows = n->max_rows;
-    int rc = launch_gemm<2, true, EPI_HEADPART, false, 1, 1>("jh_gemm16_fwd_fused", g, st);
-    if (rc) return rc;
-  }
-  float* g0 = n->g_heads;
-  float* g1 = n->cont ? n->g_heads + (size_t)n->max_rows * A : nullptr;
-  float* gv = n->g_heads + (size_t)n->max_rows * (n->cont ? 2 * A : A);
-  int rc = jh_ppo_loss_from_partials(n->ctx, n->cont, B, A, n->fwd_part, H / 16, n->max_rows, d_idx, d_action, d_adv, d_ret,
-                                     d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, g0, g1, gv, d_stats, st);
+  int rc = pponet_forward_partials(n, B, d_x, d_idx, st);
   if (rc) return rc;
-  rc = pponet_backward(n, B, d_x, d_idx, g0, g1, gv, do_adam != 0, stream);
+  rc = jh_ppo_loss_from_partials(n->ctx, n->cont, B, n->A, n->fwd_part, n->H / 16, n->max_rows, (n->cont ? 2 * n->A + 1 : n->A + 1) <= 4 ? 4 : 8, d_idx, d_action, d_adv, d_ret,
+                                 d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, n->g_all, d_stats, st);
   if (rc) return rc;
-  if (do_adam) {
-    JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
-              n->ssq_part, n->ssq_slots, n->hyper, max_norm, (float*)nullptr, 1, n->adam_ticket);
-    JH_LAUNCH_CHECK();
-  }
-  return JH_OK;
+  rc = jh_pmb_backward(n, B, d_x, d_idx, pmb_heads(n), st);
+  if (rc) return rc;
+  rc = jh_pmb_finalize(n, B, do_adam != 0, st);
+  if (rc) return rc;
+  return do_adam ? pponet_adam(n, max_norm, nullptr, st) : JH_OK;
 }
 
 // Batched acting for W envs (PPO.act, ppo.py:55-69, discrete): ONE launch + host finish.

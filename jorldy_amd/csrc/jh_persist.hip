@@ -2,204 +2,247 @@
 // acting"): ONE launch serves all T timesteps of a rollout.
 //
 // Per-timestep acting is a latency problem, not a throughput problem: W = 8 rows through a
-// 4-512-512-3 MLP is ~4 MFLOP, but a launch costs ~5 us of dispatch latency plus ~4 us of fixed
-// kernel overhead plus PCIe round trips, 128 times per iteration.  This kernel removes all of it:
-//   * grid = H/16 workgroups, each owns 16 hidden-2 columns and keeps ITS slice of every weight
-//     (W2 rows, W1, biases, head-weight columns) resident in LDS for the whole rollout: no global
-//     load on the per-step critical path;
-//   * the host publishes the observations of step t as 8-byte {tag = t, value} granules in
-//     device-mapped pinned memory ("the data IS the flag", CDNA guide G16/R2): one PCIe read round
-//     trip both detects the step and fetches the data;
-//   * every workgroup computes h1 (VALU) and its h2 tile (fp32 MFMA, in-workgroup split-K), reduces
-//     the tile against the head weights and writes its partial head outputs as 16-byte row granules
-//     {out0, out1, out2, tag} straight into pinned host memory -- W consecutive granules per
-//     workgroup in one store instruction, fire and forget (no fence, no acknowledgement wait); the
-//     host sums the 32 partials per output, samples, steps the envs;
-//   * no inter-workgroup communication on the device at all -> nothing to deadlock on; every poll
-//     loop is bounded and a timeout makes all workgroups exit (the host then falls back to the
-//     one-launch-per-step path).
+// 4-512-512-3 MLP is ~4 MFLOP, but it happens 128 times per iteration between two PCIe crossings.
+// Round 2 rebuilt the kernel around the two things that were left on the per-step critical path
+// (round 1: 6-10 us waiting for the observations + 3.2 us of kernel per step):
+//   * EVERY weight a lane needs lives in its REGISTERS for the whole rollout: its 4 k-values x NCH
+//     chunks of the W2 column it owns, the W1 rows + biases of exactly those k.  A step is then:
+//     read the env row's S observations from LDS, S x 4 x NCH FMAs generate the layer-1 fragment in
+//     place (no layer-1 MFMA pass, no h1 round trip through LDS, one barrier less), 4 x NCH MFMAs,
+//     in-workgroup split-K combine, head partials on one more MFMA pass.  LDS staging buffers are
+//     double-buffered by step parity, which removes the end-of-step barrier as well;
+//   * PIPELINED POLLING: a poll of the host's observation granules is a PCIe read round trip
+//     (~1.6 us); polling "load, wait, compare, repeat" detects a publication 0.5-1.5 round trips
+//     late, and the host can only continue when the SLOWEST of the 32 workgroups has answered.
+//     Here wave 0 keeps D polls in flight as LDS-DMA loads (global_load_lds_dwordx4: no VGPR
+//     destination, so polls that are still in flight when the step is detected just land in their
+//     LDS ring slot later and are consumed -- stale -- at the start of the next step), paced
+//     period ticks apart: a publication is seen ~ one round trip + period later by every workgroup.
+//   * unchanged: the host publishes observations as 8-byte {tag, value} granules in device-mapped
+//     pinned memory ("the data IS the flag", CDNA guide G16/R2); every workgroup answers with 16-byte
+//     {out, out, out, tag} row granules written through to pinned host memory, fire and forget; no
+//     inter-workgroup communication on the device; every poll loop is bounded and a timeout makes
+//     all workgroups exit (the host then falls back to one launch per step).
+// Heads: G = ceil(n_out / 3) granules per (tile, row): discrete A <= 9 logits, or mu / log_std of a
+// continuous policy with A <= 4 (the value head is not needed to act: ppo.py:55-69).
 #include "jh_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct PersistArgs {
-  int W, S, H, n_out, T;
+  int W, S, H, n_out, T, G;
   const float *W1, *b1, *W2, *b2;
-  const float* wh[8];
-  const float* hbias[8];
+  const float* wh[12];
+  const float* hbias[12];
   const unsigned long long* obs_gran;  // pinned: [W*S] granules {tag << 32 | float bits}
-  float4* part;                        // pinned: [tiles][16] row granules {out0, out1, out2, tag bits}
-  unsigned* tile_flag;                 // pinned: [tiles] (unused by the granule protocol, kept for debugging)
+  float4* part;                        // pinned: [tiles][G][16] row granules {out, out, out, tag bits}
   unsigned* abort_flag;                // pinned: set by the kernel on timeout / by the host to stop early
   unsigned seq0;                       // tag of the first step (tags are seq0+1 .. seq0+T)
   long max_polls;
   unsigned long long* dbg;             // optional [T][8]: per-step timestamps of workgroup 0 (diagnostics)
-  int poll_sleep;                      // back-off between polls: 0 none, 1 s_sleep 1, 2 s_sleep 8, 3 s_sleep 32
-  int groups;                          // 1, or 2: the env rows are served as two half-batches per timestep so that the host
-                                       // (sampling, env.step, next observations) of one half overlaps the GPU work of the other
+  int period;                          // spacing of the polls in flight, wall_clock64 ticks (10 ns)
+  unsigned long long* mbox;            // device memory [64] granules: relay of the observations (null: every workgroup polls the host)
 };
 
-__global__ void __launch_bounds__(256) jh_act_persist_kernel(PersistArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int H = p.H, S = p.S, ldh = H + 4;
-  float* w2s = smem;                 // [16][H+4]  this tile's rows of W2 (B operand, k contiguous)
-  float* h1s = w2s + 16 * ldh;       // [16][H+4]  layer-1 activations of the current step
-  float* w1s = h1s + 16 * ldh;       // [H][S]
-  float* b1s = w1s + H * S;          // [H]
-  float* xs = b1s + H;               // [16][S]
-  float* whs = xs + 16 * S;          // [8][16] head-weight columns of this tile
-  float* misc = whs + 8 * 16;        // [16] b2 slice, [8] head biases
-  float* outs_s = misc + 32;         // [16][4] staging of this tile's partial head outputs
-  float* s_acc = outs_s + 64;        // [4][64][4] split-K combine
-  __shared__ int s_go;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// One poll: lanes 0..n16-1 of the calling wave each fetch 16 bytes (two granules) of the observation area
+// straight into LDS (lane-linear at lds_off).  No VGPR destination: hipcc neither tracks nor waits for it.
+__device__ __forceinline__ void persist_poll_issue(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+
+template <int SP, int NCH, int D>
+__global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned long long s_ring[D][64];  // poll landing slots
+  __shared__ __attribute__((aligned(16))) float s_x[2][16][SP];
+  __shared__ __attribute__((aligned(16))) float s_acc[2][4][64][4];
+  __shared__ float s_h2[16][17];
+  __shared__ float s_wh[12][16];
+  __shared__ float s_b2[16], s_hb[12];
+  __shared__ __attribute__((aligned(16))) float s_out[16][12];
+  __shared__ int s_go[2];
+  const int H = p.H, S = p.S;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: an SGPR
   const int tile = blockIdx.x, n0 = tile * 16;
   const int r = lane & 15, kq = lane >> 4;
-  // ---- one-time: weights into LDS
-  for (int i = threadIdx.x; i < 16 * H; i += 256) {
-    const int rr = i / H, k = i - rr * H;
-    w2s[rr * ldh + k] = p.W2[(size_t)(n0 + rr) * H + k];
+  const int kbeg = wid * 16 * NCH;  // H == 64 * NCH
+  // ---- one-time: this lane's weight fragments into registers
+  float w2f[NCH][4], b1f[NCH][4], w1f[NCH][4][SP];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int kb = kbeg + 16 * u + 4 * kq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w2f[u][j] = p.W2[(size_t)(n0 + r) * H + kb + j];
+      b1f[u][j] = p.b1[kb + j];
+#pragma unroll
+      for (int q = 0; q < SP; ++q) w1f[u][j][q] = q < S ? p.W1[(size_t)(kb + j) * S + q] : 0.f;
+    }
   }
-  for (int i = threadIdx.x; i < H * S; i += 256) w1s[i] = p.W1[i];
-  for (int i = threadIdx.x; i < H; i += 256) b1s[i] = p.b1[i];
-  if (threadIdx.x < 16) misc[threadIdx.x] = p.b2[n0 + threadIdx.x];
-  if (threadIdx.x < 8) misc[16 + threadIdx.x] = threadIdx.x < p.n_out ? *p.hbias[threadIdx.x] : 0.f;
-  for (int i = threadIdx.x; i < 8 * 16; i += 256) {
+  for (int i = threadIdx.x; i < 12 * 16; i += 256) {
     const int o = i >> 4, c = i & 15;
-    whs[i] = o < p.n_out ? p.wh[o][n0 + c] : 0.f;
+    s_wh[o][c] = o < p.n_out ? p.wh[o][n0 + c] : 0.f;
   }
+  if (threadIdx.x < 16) s_b2[threadIdx.x] = p.b2[n0 + threadIdx.x];
+  if (threadIdx.x < 12) s_hb[threadIdx.x] = threadIdx.x < p.n_out ? *p.hbias[threadIdx.x] : 0.f;
+  for (int i = threadIdx.x; i < 2 * 16 * SP; i += 256) (&s_x[0][0][0])[i] = 0.f;  // rows >= W / columns >= S stay 0
+  for (int i = threadIdx.x; i < D * 64; i += 256) (&s_ring[0][0])[i] = 0ull;
   __syncthreads();
-  const int kper = H / 4;  // H % 64 == 0 is checked on the host
-  const int kbeg = wid * kper;
 
-  const int rows_per = p.W / p.groups;
-  for (int tg = 0; tg < p.T * p.groups; ++tg) {
-    const int t = tg / p.groups + 1, grp = tg - (t - 1) * p.groups;
-    const int row0 = grp * rows_per, row1 = row0 + rows_per;  // the env rows of this half-batch
+  const int n_gran = p.W * S;            // <= 64
+  const int n16 = (n_gran + 1) >> 1;     // lanes that fetch 16 bytes per poll
+  const char* my_src = reinterpret_cast<const char*>(p.obs_gran) + 16 * (lane < n16 ? lane : 0);
+  unsigned long long next_issue = 0;
+  int slot = 0;  // ring slot of the OLDEST poll in flight (wave 0)
+  const unsigned ring_lane = (unsigned)(uintptr_t)&s_ring[0][0] + 8u * (unsigned)lane;  // LDS byte address of this lane's granule in slot 0
+  // Every load issued so far (the weight fragments) must have LANDED here: hipcc would otherwise wait for them
+  // lazily at their first use INSIDE the step loop with s_waitcnt vmcnt(N..0), and a vmcnt(0) in the loop body
+  // also waits for the polls in flight and the previous step's PCIe store (measured: +2.4 us per step).  The
+  // builtin (unlike an asm wait) clears the compiler's own scoreboard.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+  if (wid == 0 && (!p.mbox || blockIdx.x == 0)) {
+    if (lane < n16) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) persist_poll_issue(my_src, __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&s_ring[d][0]));
+    }
+    next_issue = wall_clock64();
+  }
+
+  for (int t = 1; t <= p.T; ++t) {
+    const int par = t & 1;
     const unsigned tag = p.seq0 + (unsigned)t;
-    // ---- wait for the host's observations of step t (granule sweep, bounded)
-    if (wid == 0) {
+    // ---- wait for the host's observations of step t
+    // Relay (p.mbox): only workgroup 0 polls the HOST; it republishes the granules in device memory and the other
+    // workgroups poll that.  32 workgroups x 256 bytes of PCIe reads in flight queue behind each other on the
+    // link's non-posted request tags (measured: every extra poll in flight per workgroup ADDS microseconds);
+    // one poller sees the bare PCIe round trip, and the fan-out is an on-chip hand-off (~1 us).
+    if (wid == 0 && p.mbox && blockIdx.x != 0) {
+      bool ok = false;
+      for (long spin = 0; spin < p.max_polls * 4; ++spin) {
+        const unsigned long long gq = __hip_atomic_load(p.mbox + (lane < n_gran ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool mine = lane >= n_gran || (unsigned)(gq >> 32) == tag;
+        if (__all(mine)) {
+          if (lane < n_gran) {
+            const int row = lane / S, q = lane - row * S;
+            s_x[par][row][q] = __uint_as_float((unsigned)gq);
+          }
+          ok = true;
+          break;
+        }
+        if ((spin & 1023) == 1023 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+      }
+      if (lane == 0) s_go[par] = ok ? 1 : 0;
+    } else if (wid == 0) {
       bool ok = false;
       for (long spin = 0; spin < p.max_polls; ++spin) {
-        bool mine = true;
-        for (int i = row0 * S + lane; i < row1 * S; i += 64) {
-          const unsigned long long gq = __hip_atomic_load(p.obs_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if ((unsigned)(gq >> 32) == tag) xs[i] = __uint_as_float((unsigned)gq);
-          else mine = false;
+        // the oldest of the D polls in flight has landed once at most D-1 are outstanding (loads return in order;
+        // this wave's granule stores of the previous step can only make the wait longer, never shorter)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
+        // (a ds_read in asm: through a generic pointer hipcc emits flat_load + s_waitcnt vmcnt(0), which would wait
+        // for EVERY poll in flight and serialise the ring)
+        unsigned long long gq;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(gq) : "v"(ring_lane + (unsigned)slot * 512u) : "memory");
+        const bool mine = lane >= n_gran || (unsigned)(gq >> 32) == tag;
+        const bool done = __all(mine);
+        if (done && lane < n_gran) {
+          const int row = lane / S, q = lane - row * S;
+          s_x[par][row][q] = __uint_as_float((unsigned)gq);
+          if (p.mbox) __hip_atomic_store(p.mbox + lane, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: the granule is its own flag
         }
-        if (__all(mine)) { ok = true; break; }
-        if ((spin & 63) == 63 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        if (p.poll_sleep == 1) __builtin_amdgcn_s_sleep(1);
-        else if (p.poll_sleep == 2) __builtin_amdgcn_s_sleep(8);
-        else if (p.poll_sleep == 3) __builtin_amdgcn_s_sleep(32);
+        // re-arm the slot (the LDS read above has returned), paced so that the D polls in flight stay ~period apart
+        // instead of bunching up behind the one that just landed (not when the step was just detected: nothing may
+        // delay the compute)
+        if (p.period > 0 && !done) {
+          while (wall_clock64() < next_issue) __builtin_amdgcn_s_sleep(1);
+        }
+        next_issue = wall_clock64() + (unsigned long long)p.period;
+        if (lane < n16) persist_poll_issue(my_src, __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&s_ring[slot][0]));
+        slot = __builtin_amdgcn_readfirstlane(slot + 1 == D ? 0 : slot + 1);
+        if (done) { ok = true; break; }
+        if ((spin & 255) == 255 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
       }
-      if (lane == 0) s_go = ok ? 1 : 0;
+      if (lane == 0) s_go[par] = ok ? 1 : 0;
     }
     __syncthreads();
     if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 0] = wall_clock64(); p.dbg[(t - 1) * 8 + 1] = __builtin_readcyclecounter(); }
-    if (!s_go) {  // timeout or host abort: tell the host and leave (all workgroups decide alike or time out too)
+    if (!s_go[par]) {  // timeout or host abort: tell the host and leave (all workgroups decide alike or time out too)
       if (threadIdx.x == 0) __hip_atomic_store(p.abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
+      break;
     }
-    // ---- layer 1 for the (<=16) env rows ON THE MFMA: h1[16 x H] = x[16 x S] * W1^T[S x H].  K = S is
-    // tiny (one 16x16x4 MFMA per 16 hidden units when S <= 4), and this form needs one LDS read per
-    // tile instead of re-reading every observation for every hidden unit (the VALU version spent
-    // 3.2 us per step issuing ~170 LDS instructions per wave; this one ~0.2 us).
+    // ---- layer 1 generated in registers as the A operand, straight into the MFMAs of this wave's K quarter
+    float xr[SP];
     {
-      const int u_per_wave = H / 4;  // hidden units of this wave (H % 64 == 0)
-      for (int u0 = wid * u_per_wave; u0 < (wid + 1) * u_per_wave; u0 += 16) {  // independent tiles: overlap their LDS/MFMA latencies
-        f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int q0 = 0; q0 < S; q0 += 4) {
-          const int q = q0 + kq;
-          const float av = (r < p.W && q < S) ? xs[r * S + q] : 0.f;       // A[row r][k = q]
-          const float bv = q < S ? w1s[(u0 + r) * S + q] : 0.f;            // B[k = q][unit u0 + r]
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c1, 0, 0, 0);
-        }
-        const float bb = b1s[u0 + r];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // C: col = lane & 15 -> unit u0 + r, row = kq * 4 + i -> env row
-          const float v = c1[i] + bb;
-          h1s[(kq * 4 + i) * ldh + u0 + r] = v > 0.f ? v : 0.f;
-        }
+      const float4 v0 = *reinterpret_cast<const float4*>(&s_x[par][r][0]);
+      xr[0] = v0.x; xr[1] = v0.y; xr[2] = v0.z; xr[3] = v0.w;
+      if (SP > 4) {
+        const float4 v1 = *reinterpret_cast<const float4*>(&s_x[par][r][4]);
+        xr[4] = v1.x; xr[5] = v1.y; xr[6] = v1.z; xr[7] = v1.w;
       }
     }
-    __syncthreads();
-    if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 2] = wall_clock64(); p.dbg[(t - 1) * 8 + 3] = __builtin_readcyclecounter(); }
-    // ---- h2 tile = h1 (16 x H) * W2_tile^T (H x 16): fp32 MFMA, this wave's K quarter
-    // two independent accumulators (the 16x16x4 fp32 MFMA has a 40-cycle dependent latency vs a
-    // 32-cycle issue interval) and an unrolled body so the ds_read_b128 of later chunks are in flight
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kbeg; k0 < kbeg + kper; k0 += 32) {
-      const int kb = k0 + 4 * kq;
-      const float4 av = *reinterpret_cast<const float4*>(h1s + r * ldh + kb);
-      const float4 bv = *reinterpret_cast<const float4*>(w2s + r * ldh + kb);
-      const float4 av2 = *reinterpret_cast<const float4*>(h1s + r * ldh + kb + 16);
-      const float4 bv2 = *reinterpret_cast<const float4*>(w2s + r * ldh + kb + 16);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.x, bv2.x, acc2, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.y, bv2.y, acc2, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.z, bv2.z, acc2, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2.w, bv2.w, acc2, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < SP; ++q) a = fmaf(xr[q], w1f[u][j][q], a);
+        a += b1f[u][j];
+        a = a > 0.f ? a : 0.f;
+        // two accumulators: the 16x16x4 fp32 MFMA has a 40-cycle dependent latency vs a 32-cycle issue interval
+        if (j & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w2f[u][j], acc2, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w2f[u][j], acc, 0, 0, 0);
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] += acc2[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_acc[(wid * 64 + lane) * 4 + i] = acc[i];
+    for (int i = 0; i < 4; ++i) s_acc[par][wid][lane][i] = acc[i] + acc2[i];
     __syncthreads();
     if (wid == 0) {
       // C/D fragment: col = lane & 15 (hidden-2 column n0 + r), row = kq * 4 + i (env row)
-      // h2 tile -> LDS (transposed into A-operand order), then the head partials
-      //   part[row][o] = sum_col h2[row][col] * Wh[o][n0 + col]
-      // are ONE more 16x16x16 product on the MFMA (4 steps) -- no cross-lane shuffles at all.
-      float* h2s = s_acc;  // [16 rows][17]: safe to overwrite, every wave's partials were consumed above
       float hv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float v = ((s_acc[(0 * 64 + lane) * 4 + i] + s_acc[(1 * 64 + lane) * 4 + i]) + s_acc[(2 * 64 + lane) * 4 + i]) +
-                  s_acc[(3 * 64 + lane) * 4 + i];
-        v += misc[r];
+        float v = ((s_acc[par][0][lane][i] + s_acc[par][1][lane][i]) + s_acc[par][2][lane][i]) + s_acc[par][3][lane][i];
+        v += s_b2[r];
         hv[i] = v > 0.f ? v : 0.f;
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // h2 tile -> LDS in A-operand order; the head partials part[row][o] = sum_col h2[row][col] * Wh[o][n0 + col]
+      // are one more 16x16x16 product on the MFMA (4 steps)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) h2s[(kq * 4 + i) * 17 + r] = hv[i];
+      for (int i = 0; i < 4; ++i) s_h2[kq * 4 + i][r] = hv[i];
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       f32x4 ph = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float av = h2s[r * 17 + 4 * c + kq];                           // A[row r][k = col 4c+kq]
-        const float bv = r < p.n_out ? whs[r * 16 + 4 * c + kq] : 0.f;       // B[k = col][n = output r]
+        const float av = s_h2[r][4 * c + kq];                        // A[row r][k = col 4c+kq]
+        const float bv = r < 12 ? s_wh[r][4 * c + kq] : 0.f;         // B[k = col][n = output r]
         ph = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, ph, 0, 0, 0);
       }
       // ph: col = lane & 15 -> output o = r, row = kq * 4 + i -> env row
-      if (r < p.n_out) {
+      if (r < 12) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) outs_s[(kq * 4 + i) * 4 + r] = ph[i] + (tile == 0 ? misc[16 + r] : 0.f);
+        for (int i = 0; i < 4; ++i) s_out[kq * 4 + i][r] = ph[i] + (tile == 0 ? s_hb[r] : 0.f);
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      // One 16-byte row granule {out0, out1, out2, tag}: the partial IS its own flag.  Lanes 0..W-1
-      // store W consecutive granules with ONE instruction (W*16 contiguous bytes -> one or two PCIe
-      // write TLPs per tile instead of dozens of 4-byte ones); fire and forget: no release fence, no
-      // acknowledgement wait on the per-step critical path.
-      if (lane >= row0 && lane < row1) {
-        const float4 o4 = *reinterpret_cast<const float4*>(outs_s + lane * 4);
-        const f32x4 gq = (f32x4){o4.x, o4.y, o4.z, __uint_as_float(tag)};
-        float4* dst = p.part + (size_t)tile * 16 + lane;
-        // write-through system-scope 16-byte store (a plain store lingers in L2 for milliseconds); hipcc
-        // does not track asm stores: nothing here waits for it on purpose, the s_nop keeps the data
-        // registers intact until the store has read them (CDNA guide §5.7)
+      // 16-byte row granules {out 3g, out 3g+1, out 3g+2, tag}: the partial IS its own flag.  Lanes (g, row) store
+      // W consecutive granules per g with ONE instruction; fire and forget (no fence, no acknowledgement wait)
+      const int g = lane >> 4, row = lane & 15;
+      if (g < p.G && row < p.W) {
+        const f32x4 gq = (f32x4){s_out[row][3 * g], s_out[row][3 * g + 1], s_out[row][3 * g + 2], __uint_as_float(tag)};
+        float4* dst = p.part + ((size_t)tile * p.G + g) * 16 + row;
+        // write-through system-scope 16-byte store (a plain store lingers in L2 for milliseconds); hipcc does not
+        // track asm stores: the s_nop keeps the data registers intact until the store has read them (CDNA guide §5.7)
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
       }
     }
-    __syncthreads();  // s_acc / h1s are reused by the next step
+    // no end-of-step barrier: s_x / s_acc alternate by step parity, s_h2 / s_out belong to wave 0
     if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 4] = wall_clock64(); p.dbg[(t - 1) * 8 + 5] = __builtin_readcyclecounter(); }
   }
+  // the polls still in flight target this workgroup's LDS: let them land before the wave ends
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -208,36 +251,37 @@ struct jh_persist {
   unsigned long long* gran_h = nullptr;
   unsigned long long* gran_d = nullptr;
   float4 *part_h = nullptr, *part_d = nullptr;
-  unsigned *flag_h = nullptr, *flag_d = nullptr;  // [tiles] + abort word at [tiles]
+  unsigned *flag_h = nullptr, *flag_d = nullptr;  // abort word
   unsigned seq = 0;
-  int groups = 1;
-  int tiles = 0;
-  size_t lds = 0;
+  int tiles = 0, n_out = 0, G = 0;
   unsigned long long *dbg_h = nullptr, *dbg_d = nullptr;
+  unsigned long long* mbox = nullptr;  // device: relay of the observation granules
 };
+
+// heads needed to ACT: A logits (discrete) | A mu + A log_std (continuous); the value head is not (ppo.py:55-69)
+static int persist_heads(const jh_pponet* n) { return n->cont ? 2 * n->A : n->A; }
 
 int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_ARG(n && out);
-  JH_ARG(!n->cont && n->H % 128 == 0 && n->A + 1 <= 3 && (16 * n->S) % 4 == 0);
+  const int H = n->H, S = n->S;
+  JH_ARG(S >= 1 && S <= 8 && (H == 64 || H == 128 || H == 256 || H == 512) && persist_heads(n) <= 12);
   jh_persist* p = new jh_persist();
   p->net = n;
-  p->tiles = n->H / 16;
-  const int H = n->H, S = n->S;
-  p->lds = sizeof(float) * ((size_t)2 * 16 * (H + 4) + (size_t)H * S + H + 16 * (size_t)S + 8 * 16 + 32 + 64 + 4 * 64 * 4);
-  if (p->lds > 160 * 1024) {
-    delete p;
-    return jh_fail(JH_ERR_ARG, "persistent acting needs %zu B of LDS (> 160 KiB) for H=%d S=%d", p->lds, H, S);
-  }
-  JH_HIP(hipFuncSetAttribute((const void*)jh_act_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
-  JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 16 * (size_t)S, hipHostMallocMapped));
+  p->tiles = H / 16;
+  p->n_out = persist_heads(n);
+  p->G = (p->n_out + 2) / 3;
+  JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 64, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->gran_d, p->gran_h, 0));
-  JH_HIP(hipHostMalloc((void**)&p->part_h, sizeof(float4) * 16 * (size_t)p->tiles, hipHostMallocMapped));
-  memset(p->part_h, 0, sizeof(float4) * 16 * (size_t)p->tiles);
+  const size_t part_bytes = sizeof(float4) * 16 * (size_t)p->tiles * p->G;
+  JH_HIP(hipHostMalloc((void**)&p->part_h, part_bytes, hipHostMallocMapped));
+  memset(p->part_h, 0, part_bytes);
   JH_HIP(hipHostGetDevicePointer((void**)&p->part_d, p->part_h, 0));
-  JH_HIP(hipHostMalloc((void**)&p->flag_h, sizeof(unsigned) * (size_t)(p->tiles + 16), hipHostMallocMapped));
+  JH_HIP(hipHostMalloc((void**)&p->flag_h, sizeof(unsigned) * 16, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
-  memset(p->gran_h, 0, sizeof(unsigned long long) * 16 * (size_t)S);
-  memset(p->flag_h, 0, sizeof(unsigned) * (size_t)(p->tiles + 16));
+  JH_HIP(hipMalloc((void**)&p->mbox, sizeof(unsigned long long) * 64));
+  JH_HIP(hipMemset(p->mbox, 0, sizeof(unsigned long long) * 64));
+  memset(p->gran_h, 0, sizeof(unsigned long long) * 64);
+  memset(p->flag_h, 0, sizeof(unsigned) * 16);
   if (getenv("JH_PERSIST_DEBUG")) {
     // timestamps go to DEVICE memory (a store to host memory would stall the wave at the next barrier
     // until the PCIe write is acknowledged and distort the measurement)
@@ -254,61 +298,76 @@ void jh_persist_destroy(jh_persist* p) {
   (void)hipHostFree(p->gran_h);
   (void)hipHostFree(p->part_h);
   (void)hipHostFree(p->flag_h);
+  (void)hipFree(p->mbox);
+  if (p->dbg_d) (void)hipFree(p->dbg_d);
+  free(p->dbg_h);
   delete p;
 }
 
-// Launch the persistent kernel for T steps of W <= 16 envs.
-int jh_persist_begin(jh_persist* p, int W, int T, int groups, hipStream_t st) {
+template <int SP, int NCH>
+static void persist_launch(int depth, int tiles, hipStream_t st, const PersistArgs& a) {
+  if (depth >= 8) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 8>), dim3(tiles), dim3(256), 0, st, a);
+  else if (depth >= 4) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 4>), dim3(tiles), dim3(256), 0, st, a);
+  else if (depth >= 2) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 2>), dim3(tiles), dim3(256), 0, st, a);
+  else JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 1>), dim3(tiles), dim3(256), 0, st, a);
+}
+
+// Launch the persistent kernel for T steps of W <= 16 envs (W * S <= 64 observation granules).
+int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   jh_pponet* n = p->net;
-  JH_ARG(W > 0 && W <= 16 && T > 0);
-  JH_ARG(groups == 1 || (groups == 2 && W % 2 == 0));
-  p->groups = groups;
+  JH_ARG(W > 0 && W <= 16 && W * n->S <= 64 && T > 0);
   PersistArgs a{};
-  a.W = W; a.S = n->S; a.H = n->H; a.T = T;
+  a.W = W; a.S = n->S; a.H = n->H; a.T = T; a.G = p->G;
   a.W1 = n->params + n->o_w1; a.b1 = n->params + n->o_b1; a.W2 = n->params + n->o_w2; a.b2 = n->params + n->o_b2;
   int o = 0;
   for (int k = 0; k < n->A; ++k, ++o) { a.wh[o] = n->params + n->o_wh0 + (int64_t)k * n->H; a.hbias[o] = n->params + n->o_bh0 + k; }
-  a.wh[o] = n->params + n->o_wv; a.hbias[o] = n->params + n->o_bv; ++o;
+  if (n->cont)
+    for (int k = 0; k < n->A; ++k, ++o) { a.wh[o] = n->params + n->o_wh1 + (int64_t)k * n->H; a.hbias[o] = n->params + n->o_bh1 + k; }
   a.n_out = o;
-  a.obs_gran = p->gran_d; a.part = p->part_d; a.tile_flag = p->flag_d; a.abort_flag = p->flag_d + p->tiles;
+  a.obs_gran = p->gran_d; a.part = p->part_d; a.abort_flag = p->flag_d;
   a.seq0 = p->seq;
   a.dbg = p->dbg_d;
-  a.groups = groups;
-  a.poll_sleep = 2;
-  if (const char* e = getenv("JH_PERSIST_SLEEP")) a.poll_sleep = atoi(e);
-  a.max_polls = 400000;  // x (~0.5 us per poll) = ~0.2 s without observations -> give up
-  p->flag_h[p->tiles] = 0;
-  JH_LAUNCH(jh_act_persist_kernel, dim3(p->tiles), dim3(256), p->lds, st, a);
+  // polls in flight per workgroup and their spacing (10 ns ticks): 4 x 0.4 us covers a ~1.6 us PCIe read round trip
+  static const int depth = getenv("JH_PERSIST_DEPTH") ? atoi(getenv("JH_PERSIST_DEPTH")) : 4;
+  static const int period = getenv("JH_PERSIST_PERIOD") ? atoi(getenv("JH_PERSIST_PERIOD")) : 20;
+  a.period = depth > 1 ? period : 0;
+  static const int relay = getenv("JH_PERSIST_RELAY") ? atoi(getenv("JH_PERSIST_RELAY")) : 1;
+  a.mbox = relay ? p->mbox : nullptr;
+  a.max_polls = 600000;  // x (>= 0.3 us per consumed poll) = >= 0.2 s without observations -> give up
+  p->flag_h[0] = 0;
+  const int nch = n->H / 64;
+  const bool sp8 = n->S > 4;
+#define JH_PERSIST_CASE(NCH) \
+  if (nch == NCH) { if (sp8) persist_launch<8, NCH>(depth, p->tiles, st, a); else persist_launch<4, NCH>(depth, p->tiles, st, a); }
+  JH_PERSIST_CASE(1) else JH_PERSIST_CASE(2) else JH_PERSIST_CASE(4) else JH_PERSIST_CASE(8)
+#undef JH_PERSIST_CASE
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
 
-// Tag of the next timestep (all half-batches of a timestep share it).
-unsigned jh_persist_next_tag(jh_persist* p) { return ++p->seq; }
-
-// Publish the observations of env rows [r0, r1) for the timestep `tag` (h_obs is the full [W][S] array).
-void jh_persist_publish(jh_persist* p, int r0, int r1, const float* h_obs, unsigned tag) {
-  const int S = p->net->S;
-  for (int i = r0 * S; i < r1 * S; ++i) {
+// Publish the observations of all W env rows for the next timestep; returns its tag.
+unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs) {
+  const unsigned tag = ++p->seq;
+  const int n = W * p->net->S;
+  for (int i = 0; i < n; ++i) {
     unsigned bits;
     memcpy(&bits, h_obs + i, 4);
     __atomic_store_n(p->gran_h + i, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELEASE);
   }
+  return tag;
 }
 
-// Wait until every tile's partial granules of rows [r0, r1) carry `tag`, finish the heads on the host and sample.
-// The sampling stream is keyed by (act_ctr, row): identical whichever way the rows are batched; the caller advances
-// act_ctr once per timestep (jh_persist_end_step).  JH_ERR_STATE if the kernel gave up.
-int jh_persist_collect(jh_persist* p, int r0, int r1, unsigned tag, int64_t* h_action, int training) {
-  jh_pponet* n = p->net;
-  const int A = n->A, n_out = A + 1;
-  volatile unsigned* abort_w = p->flag_h + p->tiles;
-  const volatile unsigned* part = reinterpret_cast<const volatile unsigned*>(p->part_h);  // [tiles][16][4 words]
+// Wait until every tile's granules of all W rows carry `tag`, then sum the per-tile partials in tile order:
+// h_heads [W][n_out] raw head outputs (logits | mu_raw, log_std_raw).  JH_ERR_STATE if the kernel gave up.
+int jh_persist_collect(jh_persist* p, int W, unsigned tag, float* h_heads) {
+  const int n_out = p->n_out, G = p->G;
+  volatile unsigned* abort_w = p->flag_h;
+  const volatile unsigned* part = reinterpret_cast<const volatile unsigned*>(p->part_h);  // [tiles][G][16][4 words]
   bool all = false;
   for (long spin = 0; spin < 40000000L && !all; ++spin) {
     all = true;
-    for (int t = 0; t < p->tiles && all; ++t)
-      for (int wq = r0; wq < r1; ++wq)
+    for (int t = 0; t < p->tiles * G && all; ++t)
+      for (int wq = 0; wq < W; ++wq)
         if (part[((size_t)t * 16 + wq) * 4 + 3] != tag) { all = false; break; }
     if (!all) {
       if ((spin & 1023) == 1023 && *abort_w == 2u) break;  // the kernel timed out
@@ -317,71 +376,39 @@ int jh_persist_collect(jh_persist* p, int r0, int r1, unsigned tag, int64_t* h_a
   }
   if (!all) return jh_fail(JH_ERR_STATE, "persistent acting kernel did not answer step tag %u", tag);
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  for (int wq = r0; wq < r1; ++wq) {
-    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = 0; t < p->tiles; ++t) {
+  for (int wq = 0; wq < W; ++wq) {
+    float z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < p->tiles; ++t)
       for (int o = 0; o < n_out; ++o) {
-        const unsigned bits = part[((size_t)t * 16 + wq) * 4 + o];
+        const unsigned bits = part[(((size_t)t * G + o / 3) * 16 + wq) * 4 + o % 3];
         float v;
         memcpy(&v, &bits, 4);
         z[o] += v;
       }
-    }
-    int act = 0;
-    float mx = z[0];
-    for (int k = 1; k < A; ++k)
-      if (z[k] > mx) { mx = z[k]; act = k; }
-    if (training) {
-      float e[8], se = 0.f;
-      for (int k = 0; k < A; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
-      uint64_t x = n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq;
-      x += 0x9E3779B97F4A7C15ull;
-      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-      x = x ^ (x >> 31);
-      const float u = (float)((double)(x >> 11) * (1.0 / 9007199254740992.0)) * se;
-      float c = 0.f;
-      act = A - 1;
-      for (int k = 0; k < A; ++k) {
-        c += e[k];
-        if (u < c) { act = k; break; }
-      }
-    }
-    h_action[wq] = act;
+    memcpy(h_heads + (size_t)wq * n_out, z, sizeof(float) * n_out);
   }
   return JH_OK;
 }
 
-void jh_persist_end_step(jh_persist* p) { p->net->act_ctr += 1; }
-
-// One whole timestep, all rows at once (groups == 1).
-int jh_persist_step(jh_persist* p, int W, const float* h_obs, int64_t* h_action, int training) {
-  const unsigned tag = jh_persist_next_tag(p);
-  jh_persist_publish(p, 0, W, h_obs, tag);
-  int rc = jh_persist_collect(p, 0, W, tag, h_action, training);
-  if (rc) return rc;
-  jh_persist_end_step(p);
-  return JH_OK;
-}
+int jh_persist_heads(const jh_persist* p) { return p->n_out; }
 
 // Diagnostics: print per-step phase durations of workgroup 0 for the last rollout.
 void jh_persist_dump_debug(jh_persist* p, int T) {
   if (!p->dbg_h) return;
   (void)hipDeviceSynchronize();
   (void)hipMemcpy(p->dbg_h, p->dbg_d, sizeof(unsigned long long) * 8 * (size_t)T, hipMemcpyDeviceToHost);
-  double a = 0, b = 0, c = 0, cyc = 0;
+  double a = 0, c = 0, cyc = 0;
   for (int t = 1; t < T; ++t) {
     const unsigned long long* d = p->dbg_h + (size_t)t * 8;
     const unsigned long long* pr = p->dbg_h + (size_t)(t - 1) * 8;
     a += (double)(d[0] - pr[4]);   // wait for observations (incl. host work + PCIe), 100 MHz ticks
-    b += (double)(d[2] - d[0]);    // layer 1
-    c += (double)(d[4] - d[2]);    // MFMA + combine + heads + store
+    c += (double)(d[4] - d[0]);    // layer 1 + MFMA + combine + heads + store
     cyc += (double)(d[5] - d[1]) / ((double)(d[4] - d[0]) + 1e-9);  // shader cycles per 10 ns tick
   }
   const double n = T - 1;
-  fprintf(stderr, "[jh_persist] per step (wall_clock64 ticks = 10 ns): wait %.1f  layer1 %.1f  gemm+heads %.1f ; shader clock ~%.0f MHz\n",
-          a / n, b / n, c / n, cyc / n * 100.0);
+  fprintf(stderr, "[jh_persist] per step (wall_clock64 ticks = 10 ns): wait %.1f  compute %.1f ; shader clock ~%.0f MHz\n",
+          a / n, c / n, cyc / n * 100.0);
 }
 
-// Stop a running kernel early (error paths): it sees the word at its next poll and exits.
-void jh_persist_abort(jh_persist* p) { __atomic_store_n(p->flag_h + p->tiles, 1u, __ATOMIC_RELEASE); }
+// Stop a running kernel early (error paths): it sees the word at its next abort check and exits.
+void jh_persist_abort(jh_persist* p) { __atomic_store_n(p->flag_h, 1u, __ATOMIC_RELEASE); }

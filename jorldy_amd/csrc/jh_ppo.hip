@@ -81,6 +81,66 @@ JH_EXPORT int jh_gae(jh_ctx* ctx, int32_t W, int32_t T, float gamma, float lambd
   return JH_OK;
 }
 
+// ============================================================================ minibatch rows of every epoch, once
+// ppo.py:118-125 gathers state[idx], action[idx], adv[idx], ... inside the minibatch loop.  The index lists of all
+// epochs are known before the loop, so the gathers are done ONCE here: the minibatch kernels then read plain
+// consecutive rows (no idx -> row dependent load chain in front of every kernel of the update).
+struct RowsArgs {
+  int64_t n;
+  const int64_t* idx;
+  int n_cols, row_len;
+  int off[8];        // first element of column c inside a packed row of row_len floats
+  const float* src[8];
+  float* dst[8];
+};
+__global__ void __launch_bounds__(256) jh_rows_gather_kernel(RowsArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n * a.row_len) return;
+  const int64_t row = i / a.row_len;
+  const int e = (int)(i - row * a.row_len);
+  int c = 0;
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    if (k < a.n_cols && e >= a.off[k]) c = k;
+  const int w = (c + 1 < a.n_cols ? a.off[c + 1] : a.row_len) - a.off[c];
+  const int j = e - a.off[c];
+  a.dst[c][row * w + j] = a.src[c][a.idx[row] * w + j];
+}
+
+JH_EXPORT int jh_ppo_minibatch_rows(jh_ctx* ctx, int64_t n, const int64_t* d_idx, int32_t n_cols, const int32_t* elems,
+                                    const float* const* d_src, float* const* d_dst, jh_stream stream) {
+  JH_ARG(ctx && d_idx && elems && d_src && d_dst);
+  JH_ARG(n > 0 && n_cols > 0 && n_cols <= 8);
+  RowsArgs a{};
+  a.n = n; a.idx = d_idx; a.n_cols = n_cols;
+  int o = 0;
+  for (int c = 0; c < n_cols; ++c) {
+    JH_ARG(elems[c] > 0 && d_src[c] && d_dst[c]);
+    a.off[c] = o; o += elems[c]; a.src[c] = d_src[c]; a.dst[c] = d_dst[c];
+  }
+  a.row_len = o;
+  const int64_t tot = n * o;
+  JH_LAUNCH(jh_rows_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, jh_s(stream), a);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// mean of n floats (ppo.py:112 `ret.mean()`): one workgroup, fixed order
+__global__ void __launch_bounds__(1024) jh_mean_kernel(int64_t n, const float* __restrict__ x, float* __restrict__ out) {
+  __shared__ float s_red[16];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+  acc = jh_block_reduce(acc, s_red, JhAdd(), 0.f);
+  if (threadIdx.x == 0) *out = acc / (float)n;
+}
+
+JH_EXPORT int jh_mean_f32(jh_ctx* ctx, int64_t n, const float* d_x, float* d_out, jh_stream stream) {
+  JH_ARG(ctx && d_x && d_out && n > 0);
+  JH_LAUNCH(jh_mean_kernel, dim3(1), dim3(1024), 0, jh_s(stream), n, d_x, d_out);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
 // ============================================================================ shared row math
 #define JH_EPS32 1.1920929e-07f        // torch.finfo(float32).eps used by Categorical's clamp
 #define JH_HALF_LOG_2PI 0.9189385332f  // log(sqrt(2*pi))
@@ -230,6 +290,7 @@ struct PpoArgs {
   float* g0;  // d logits | d mu_raw
   float* g1;  // unused   | d log_std_raw
   float* gv;  // d value_pred
+  int ldg, ldv;  // row strides of g0 / g1 and of gv (A and 1; 8 and 8 when all three are packed into [B][8])
   float* partial;
   float* stats;
   int nb;
@@ -237,7 +298,7 @@ struct PpoArgs {
   // (hpart[tile][row][8], flat output order: head0[A], head1[A] (continuous), value); the fused kernel
   // sums them in tile order into LDS, which saves the separate heads kernel of the forward pass
   const float* hpart;
-  int hp_tiles, hp_rows;
+  int hp_tiles, hp_rows, hp_ld;  // hp_ld = floats per (tile, row): 4 when there are <= 4 head outputs, else 8
 };
 
 // z0 / z1: this row's head-0 / head-1 vectors (global memory or the LDS staging), v: value prediction
@@ -286,7 +347,7 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
   const float d_logp = d_ratio * rc.ratio;
   // critic = max(c1, c2): weights w1/w2 (ties split); clamp passes grad inside [-eps, eps]
   const float dv = a.vf * (w1 * 2.f * (rc.v - rc.ret) * invB + (rc.in_v ? w2 * 2.f * (rc.vclip - rc.ret) * invB : 0.f));
-  a.gv[i] = dv;
+  a.gv[(size_t)i * a.ldv] = dv;
   if (!CONT) {
     const float* z = z0;
     const float ce = a.ent * invB;  // loss += ent_coef * (-mean(H)) = ent_coef/B * sum pn*lg
@@ -317,7 +378,7 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
       const float g_lg = (k == act_k ? d_logp : 0.f) + ce * pn;
       const float g_pn = ce * lg + (inr ? g_lg / c : 0.f);
       const float g_p = g_pn / s - T1 / (s * s);
-      a.g0[(size_t)i * a.A + k] = g_p * p - p * T2;  // log_softmax backward
+      a.g0[(size_t)i * a.ldg + k] = g_p * p - p * T2;  // log_softmax backward
     }
   } else {
     const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
@@ -331,8 +392,8 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
       float d_std = d_logp * ((dm * dm) / (var * std) - 1.f / std);
       d_std += ce / std;
       const float th = tanhf(lr);
-      a.g0[(size_t)i * a.A + k] = (mr >= -5.f && mr <= 5.f) ? d_mu : 0.f;
-      a.g1[(size_t)i * a.A + k] = d_std * std * (1.f - th * th);
+      a.g0[(size_t)i * a.ldg + k] = (mr >= -5.f && mr <= 5.f) ? d_mu : 0.f;
+      a.g1[(size_t)i * a.ldg + k] = d_std * std * (1.f - th * th);
     }
   }
 }
@@ -358,11 +419,37 @@ __device__ __forceinline__ void ppo_finish_stats(float s_smin, float s_e1, float
   }
 }
 
+// {sum, sum, sum, sum, max, min} over the workgroup (<= 16 waves)
+__device__ __forceinline__ void ppo_block_reduce6(float (&v)[6], float (*red)[6]) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += __shfl_xor(v[k], o, 64);
+    v[4] = fmaxf(v[4], __shfl_xor(v[4], o, 64));
+    v[5] = fminf(v[5], __shfl_xor(v[5], o, 64));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[wid][k] = v[k];
+  }
+  __syncthreads();
+  float r[6] = {0.f, 0.f, 0.f, 0.f, -3.4e38f, 3.4e38f};
+  for (int w = 0; w < nw; ++w) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] += red[w][k];
+    r[4] = fmaxf(r[4], red[w][4]);
+    r[5] = fminf(r[5], red[w][5]);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = r[k];
+}
+
 // B <= 1024: one workgroup does forward, the 6 block reductions and backward with the row terms
 // still in registers (one launch per minibatch instead of two).
 template <bool CONT>
 __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
-  __shared__ float s_red[16];
+  __shared__ float s_red6[16][6];
   extern __shared__ __attribute__((aligned(16))) float s_z[];  // [B][8] when the heads come as partials
   const int i = threadIdx.x;
   const bool on = i < a.B;
@@ -371,20 +458,21 @@ __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   if (a.hpart) {
     if (on) {
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int t0 = 0; t0 < a.hp_tiles; t0 += 8) {  // tile order: deterministic; 16 loads in flight per batch
+      const bool wide = a.hp_ld == 8;
+      for (int t0 = 0; t0 < a.hp_tiles; t0 += 8) {  // tile order: deterministic; 8-16 loads in flight per batch
         float4 q0[8], q1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int t = t0 + u < a.hp_tiles ? t0 + u : a.hp_tiles - 1;
-          const float4* q = reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * 8);
+          const float4* q = reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * a.hp_ld);
           q0[u] = q[0];
-          q1[u] = q[1];
+          if (wide) q1[u] = q[1];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           if (t0 + u < a.hp_tiles) {
             z[0] += q0[u].x; z[1] += q0[u].y; z[2] += q0[u].z; z[3] += q0[u].w;
-            z[4] += q1[u].x; z[5] += q1[u].y; z[6] += q1[u].z; z[7] += q1[u].w;
+            if (wide) { z[4] += q1[u].x; z[5] += q1[u].y; z[6] += q1[u].z; z[7] += q1[u].w; }
           }
         }
       }
@@ -408,14 +496,12 @@ __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   if (on) ppo_row_fwd<CONT>(a, i, z0, z1, vpred, rc, ent_row, minp, dr, act_k);
   const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
   const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
-  const float s_smin = jh_block_reduce(on ? rc.smin : 0.f, s_red, JhAdd(), 0.f);
-  const float s_e1 = jh_block_reduce(e1, s_red, JhAdd(), 0.f);
-  const float s_e2 = jh_block_reduce(e2, s_red, JhAdd(), 0.f);
-  const float s_ent = jh_block_reduce(on ? ent_row : 0.f, s_red, JhAdd(), 0.f);
-  const float mx = jh_block_reduce(on ? rc.ratio : -3.4e38f, s_red, JhMax(), -3.4e38f);
-  const float mn = jh_block_reduce(on ? minp : 3.4e38f, s_red, JhMin(), 3.4e38f);
+  // the six block reductions share one shuffle tree pass and ONE LDS exchange (same arithmetic order as six
+  // jh_block_reduce calls: fixed tree inside a wave, wave partials combined in wave order)
+  float v6[6] = {on ? rc.smin : 0.f, e1, e2, on ? ent_row : 0.f, on ? rc.ratio : -3.4e38f, on ? minp : 3.4e38f};
+  ppo_block_reduce6(v6, s_red6);
   float w1, w2;
-  ppo_finish_stats(s_smin, s_e1, s_e2, s_ent, mx, mn, a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
+  ppo_finish_stats(v6[0], v6[1], v6[2], v6[3], v6[4], v6[5], a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
                    threadIdx.x == 0 ? a.stats : nullptr);
   if (on) ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2);
 }
@@ -510,6 +596,7 @@ JH_EXPORT int jh_ppo_loss_discrete(jh_ctx* ctx, int32_t B, int32_t A, const floa
   a.B = B; a.A = A; a.h0 = d_logits; a.h1 = nullptr; a.value_pred = d_value_pred; a.idx = d_idx;
   a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
   a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_logits; a.g1 = nullptr; a.gv = d_grad_value;
+  a.ldg = A; a.ldv = 1;
   a.stats = d_stats;
   return ppo_launch<false>(ctx, a, jh_s(stream));
 }
@@ -527,26 +614,31 @@ JH_EXPORT int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const fl
   a.B = B; a.A = A; a.h0 = d_mu_raw; a.h1 = d_log_std_raw; a.value_pred = d_value_pred; a.idx = d_idx;
   a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
   a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_mu_raw; a.g1 = d_grad_log_std_raw; a.gv = d_grad_value;
+  a.ldg = A; a.ldv = 1;
   a.stats = d_stats;
   return ppo_launch<true>(ctx, a, jh_s(stream));
 }
 
-// Internal entry (jh_mlp.hip): same losses with the heads given as encoder partial sums.
-int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows,
+// Internal entry (jh_mlp.hip): same losses with the heads given as encoder partial sums (jh_pmb_fwd_kernel) and
+// the head gradients written PACKED, d_g_all [B][8] = (d head0 [A] | d head1 [A] (continuous) | d value | zeros):
+// the operand layout of the backward grid (jh_pmb_bwd_kernel).
+int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows, int part_ld,
                               const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
                               const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
-                              float* d_g0, float* d_g1, float* d_gv, float* d_stats, hipStream_t st) {
-  JH_ARG(B > 0 && B <= 1024 && d_hpart);
+                              float* d_g_all, float* d_stats, hipStream_t st) {
+  JH_ARG(B > 0 && B <= 1024 && d_hpart && d_g_all);
   if (continuous) {
     PpoArgs<true> a{};
     a.B = B; a.A = A; a.idx = d_idx; a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old;
-    a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_g0; a.g1 = d_g1; a.gv = d_gv;
-    a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows;
+    a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef;
+    a.g0 = d_g_all; a.g1 = d_g_all + A; a.gv = d_g_all + 2 * A; a.ldg = 8; a.ldv = 8;
+    a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld;
     return ppo_launch<true>(ctx, a, st);
   }
   PpoArgs<false> a{};
   a.B = B; a.A = A; a.idx = d_idx; a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old;
-  a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_g0; a.g1 = nullptr; a.gv = d_gv;
-  a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows;
+  a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef;
+  a.g0 = d_g_all; a.g1 = nullptr; a.gv = d_g_all + A; a.ldg = 8; a.ldv = 8;
+  a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld;
   return ppo_launch<false>(ctx, a, st);
 }

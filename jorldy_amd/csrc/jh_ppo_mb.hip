@@ -1,0 +1,564 @@
+// The PPO minibatch update (core/agent/ppo.py:122-169) of the policy-value MLP in FIVE launches
+// for minibatches of <= 1024 rows (config.ppo.cartpole: 256 rows, hidden 512):
+//
+//   1 jh_pmb_fwd_kernel     h2 = relu(relu(x[idx] W1^T + b1) W2^T + b2); layer 1 is GENERATED IN REGISTERS as the
+//                           A operand (K = S <= 8 is 4-8 FMAs per element: no h1 round trip, no layer-1 launch);
+//                           the epilogue reduces each 16-column tile against the head weights -> partial heads
+//   2 jh_ppo_fused_kernel   (jh_ppo.hip) sums the partials in tile order, clipped loss fwd + bwd -> g_all [B][8]
+//   3 jh_pmb_bwd_kernel     ONE grid, three roles: dh1 (+ the dW1 / db1 partial sums of its 16 rows: dh1 itself is
+//                           never stored), dW2 / db2, head weight gradients.  dh2 = relu'(h2) * (g Wh) is generated
+//                           in the operand fetch of both consumers instead of a dh2 kernel + 2 x 512 KB round trip
+//   4 jh_pmb_norm_kernel    sums the dW1 / db1 partials in row-tile order (deterministic) + global-norm partials
+//   5 jh_adam_kernel        (jh_mlp.hip) clip + Adam
+//
+// against eleven before (l1, GEMM, heads, loss, dh2, dW_heads, dW2, dh1, dW1, norm, Adam), each of which costs
+// >= 4.5 us of launch ramp / drain at these sizes whatever it computes.
+//
+// Operand layouts on the fp32 MFMA (v_mfma_f32_16x16x4_f32; lane = (r = lane & 15, kq = lane >> 4) supplies
+// A[m = r][k = kq], B[k = kq][n = r], holds C[4 kq + i][r]):
+//   * k-contiguous operands: one 16-byte load = 4 consecutive k, element j feeds MFMA step j of BOTH operands
+//     (the same permutation of K on both sides: the sum is unchanged);
+//   * n- (or m-) contiguous operands (W2 in dh1 = dh2 W2; dh2^T, h1 in dW2 = dh2^T h1): the 16 lanes of a k
+//     read 2 consecutive columns each (one 8-byte load) and use element t for COLUMN TILE t, i.e. tile t of a
+//     32-wide workgroup tile owns the columns n0 + 2 r + t.  The interleave is undone for free in the epilogue
+//     (a lane then holds 2 adjacent columns of a row: one 8-byte store).  This replaces the scalar 4-byte
+//     operand loads that made dh1 the slowest kernel of round 1 (14 us, 4 x its algorithmic HBM traffic).
+#include "jh_ppo_mb.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ============================================================================ 1. forward
+struct PmbFwd {
+  int M, H, S;
+  const float* x;
+  const int64_t* x_rows;
+  const float *W1, *b1, *W2, *b2;
+  const float* h1_in;  // !GEN: layer 1 precomputed [M][H]
+  float* h1_out;       // GEN: column-tile 0 stores the generated layer 1 (the backward reads it)
+  float* h2_out;       // nullable
+  const float* wh[8];
+  const float* hb[8];
+  int n_out;
+  float* part;  // [H/16][part_rows][part_ld]
+  int part_rows, part_ld;
+};
+
+// SV: S == 4 * SV -> W1 rows / observations as float4 (SV = 1, 2); SV = 0: any S <= 8, scalar loads
+template <int SV, bool GEN, int U>
+__global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
+  __shared__ float s_acc[4][64][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int K = g.H, tiles_n = K / 16;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * 16, n = tn * 16 + r;
+  const int kper = ((K + 63) / 64) * 16, kbeg = wid * kper;
+  const int kend = kbeg + kper < K ? kbeg + kper : K;
+  const int m = m0 + r;
+  const bool m_ok = m < g.M;
+  const int mc = m_ok ? m : g.M - 1;
+  float xr[8];
+  if (GEN) {
+    const int64_t row = g.x_rows ? g.x_rows[mc] : (int64_t)mc;
+    if (SV > 0) {
+#pragma unroll
+      for (int q = 0; q < SV; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(g.x + row * g.S + 4 * q);
+        xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xr[s] = s < g.S ? g.x[row * g.S + s] : 0.f;
+    }
+  }
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool st_h1 = GEN && g.h1_out && tn == 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
+    float4 bw[U], av[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // every weight load of the batch in flight first
+      const int kb = k0 + 16 * u + 4 * kq;
+      const int kc = kb < kend ? kb : kbeg;
+      bw[u] = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * K + kc);
+      if (!GEN) av[u] = *reinterpret_cast<const float4*>(g.h1_in + (size_t)mc * K + kc);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = k0 + 16 * u + 4 * kq;
+      const int kc = kb < kend ? kb : kbeg;
+      const bool ok = m_ok && kb < kend;
+      if (GEN) {
+        // layer 1 exactly as jh_mlp_l1_kernel: fmaf chain over s from 0, + bias, relu
+        const float4 bb = *reinterpret_cast<const float4*>(g.b1 + kc);
+        const float bj[4] = {bb.x, bb.y, bb.z, bb.w};
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = 0.f;
+          if (SV > 0) {
+#pragma unroll
+            for (int q = 0; q < SV; ++q) {
+              const float4 w = *reinterpret_cast<const float4*>(g.W1 + (size_t)(kc + j) * g.S + 4 * q);
+              t = fmaf(xr[4 * q], w.x, t); t = fmaf(xr[4 * q + 1], w.y, t); t = fmaf(xr[4 * q + 2], w.z, t); t = fmaf(xr[4 * q + 3], w.w, t);
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+              if (s < g.S) t = fmaf(xr[s], g.W1[(size_t)(kc + j) * g.S + s], t);
+          }
+          t += bj[j];
+          a[j] = t > 0.f ? t : 0.f;
+        }
+        av[u] = make_float4(a[0], a[1], a[2], a[3]);
+        if (st_h1 && ok) *reinterpret_cast<float4*>(g.h1_out + (size_t)m * K + kb) = av[u];
+      }
+      if (!ok) av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bw[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bw[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bw[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bw[u].w, acc, 0, 0, 0);
+    }
+  }
+  // in-workgroup split-K combine, fixed wave order
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s_acc[wid][lane][i] = acc[i];
+  __syncthreads();
+  if (wid != 0) return;
+  const float b2 = g.b2[n];
+  float hv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mm = m0 + kq * 4 + i;
+    float v = ((s_acc[0][lane][i] + s_acc[1][lane][i]) + s_acc[2][lane][i]) + s_acc[3][lane][i];
+    v += b2;
+    v = v > 0.f ? v : 0.f;
+    hv[i] = mm < g.M ? v : 0.f;
+    if (mm < g.M && g.h2_out) g.h2_out[(size_t)mm * K + n] = v;
+  }
+  // partial head outputs of this 16-column tile (reduced over the 16 lanes that share kq)
+  for (int o = 0; o < g.n_out; ++o) {
+    const float w = g.wh[o][n];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float p = hv[i] * w;
+      p += __shfl_xor(p, 1, 64);
+      p += __shfl_xor(p, 2, 64);
+      p += __shfl_xor(p, 4, 64);
+      p += __shfl_xor(p, 8, 64);
+      const int mm = m0 + kq * 4 + i;
+      if (r == 0 && mm < g.M) {
+        if (tn == 0) p += *g.hb[o];
+        g.part[((size_t)tn * g.part_rows + mm) * g.part_ld + o] = p;
+      }
+    }
+  }
+}
+
+// heads = sum of the per-tile partials in tile order (the order the loss kernel uses: the same bits)
+__global__ void __launch_bounds__(256) jh_pmb_heads_finish_kernel(int M, int tiles, int part_rows, int part_ld, const float* __restrict__ part,
+                                                                  int A, int cont, float* __restrict__ h0, float* __restrict__ h1,
+                                                                  float* __restrict__ v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool wide = part_ld == 8;
+  for (int t0 = 0; t0 < tiles; t0 += 8) {
+    float4 q0[8], q1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u < tiles ? t0 + u : tiles - 1;
+      const float4* q = reinterpret_cast<const float4*>(part + ((size_t)t * part_rows + i) * part_ld);
+      q0[u] = q[0];
+      if (wide) q1[u] = q[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (t0 + u < tiles) {
+        z[0] += q0[u].x; z[1] += q0[u].y; z[2] += q0[u].z; z[3] += q0[u].w;
+        if (wide) { z[4] += q1[u].x; z[5] += q1[u].y; z[6] += q1[u].z; z[7] += q1[u].w; }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < A) h0[(size_t)i * A + k] = z[k];
+    if (cont && k >= A && k < 2 * A) h1[(size_t)i * A + (k - A)] = z[k];
+    if (k == (cont ? 2 * A : A)) v[i] = z[k];
+  }
+}
+
+// ============================================================================ 3. backward
+struct PmbBwd {
+  int B, H, S, n_out;
+  const float* x;
+  const int64_t* x_rows;
+  const float *h1, *h2, *g_all, *W2;
+  const float* wh[8];
+  float* dW2;
+  float* db2;
+  float* dwh[8];
+  float* dbh[8];
+  float* part_w1;  // [ceil(B/16)][H*S + H]: per-row-tile partial sums of (dW1 | db1), flat-bucket order
+  int n_dh1, n_dw2;  // workgroups of the first two roles (the rest: head weight gradients)
+};
+
+// ---- role: dh1 = relu'(h1) * (dh2 W2) for a 16-row x 32-column tile, reduced on the spot against the
+// observation rows into partial dW1 / db1 (dh1 never reaches HBM)
+template <int NO, int U>
+__device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s_acc)[4][64][4], float* s_wh) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int H = g.H, tiles_n = H / 32;
+  const int tm = blk / tiles_n, tn = blk - tm * tiles_n;
+  const int m0 = tm * 16, i0 = tn * 32;
+  for (int q = threadIdx.x; q < NO * H; q += 256) {  // head weight rows -> LDS (rows >= n_out: zeros)
+    const int j = q / H, k = q - j * H;
+    s_wh[q] = j < g.n_out ? g.wh[j][k] : 0.f;
+  }
+  const int m = m0 + r;
+  const bool m_ok = m < g.B;
+  const int mc = m_ok ? m : g.B - 1;
+  float gj[NO];
+  {
+    const float4 a = *reinterpret_cast<const float4*>(g.g_all + (size_t)mc * 8);
+    gj[0] = a.x; gj[1] = a.y; gj[2] = a.z; gj[3] = a.w;
+    if (NO > 4) {
+      const float4 b = *reinterpret_cast<const float4*>(g.g_all + (size_t)mc * 8 + 4);
+      gj[4] = b.x; gj[5] = b.y; gj[6] = b.z; gj[7] = b.w;
+    }
+  }
+  __syncthreads();
+  const int kper = ((H + 63) / 64) * 16, kbeg = wid * kper;
+  const int kend = kbeg + kper < H ? kbeg + kper : H;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
+    float4 h2v[U];
+    float2 bw[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = k0 + 16 * u + 4 * kq;
+      const int kc = kb < kend ? kb : kbeg;
+      h2v[u] = *reinterpret_cast<const float4*>(g.h2 + (size_t)mc * H + kc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bw[u][j] = *reinterpret_cast<const float2*>(g.W2 + (size_t)(kc + j) * H + i0 + 2 * r);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = k0 + 16 * u + 4 * kq;
+      const int kc = kb < kend ? kb : kbeg;
+      const bool ok = m_ok && kb < kend;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < NO; ++jj) {  // dh2[m][k] = sum_o g[m][o] Wh[o][k] (output order, fmaf chain)
+        const float4 w = *reinterpret_cast<const float4*>(s_wh + jj * H + kc);
+        a[0] = fmaf(gj[jj], w.x, a[0]); a[1] = fmaf(gj[jj], w.y, a[1]); a[2] = fmaf(gj[jj], w.z, a[2]); a[3] = fmaf(gj[jj], w.w, a[3]);
+      }
+      const float hq[4] = {h2v[u].x, h2v[u].y, h2v[u].z, h2v[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float aj = (ok && hq[j] > 0.f) ? a[j] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, bw[u][j].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, bw[u][j].y, acc[1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_acc[wid][t][lane][i] = acc[t][i];
+  __syncthreads();
+  if (wid != 0) return;
+  float v[2][4];
+  int64_t xrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mm = m0 + kq * 4 + i;
+    const int mmc = mm < g.B ? mm : g.B - 1;
+    const float2 hh = *reinterpret_cast<const float2*>(g.h1 + (size_t)mmc * H + i0 + 2 * r);
+    const float s0 = ((s_acc[0][0][lane][i] + s_acc[1][0][lane][i]) + s_acc[2][0][lane][i]) + s_acc[3][0][lane][i];
+    const float s1 = ((s_acc[0][1][lane][i] + s_acc[1][1][lane][i]) + s_acc[2][1][lane][i]) + s_acc[3][1][lane][i];
+    v[0][i] = (mm < g.B && hh.x > 0.f) ? s0 : 0.f;  // relu'(h1)
+    v[1][i] = (mm < g.B && hh.y > 0.f) ? s1 : 0.f;
+    xrow[i] = g.x_rows ? g.x_rows[mmc] : (int64_t)mmc;
+  }
+  float* slab = g.part_w1 + (size_t)tm * ((size_t)H * g.S + H);
+  for (int s = 0; s < g.S; ++s) {
+    const float x0 = g.x[xrow[0] * g.S + s], x1 = g.x[xrow[1] * g.S + s], x2 = g.x[xrow[2] * g.S + s], x3 = g.x[xrow[3] * g.S + s];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float p = 0.f;
+      p = fmaf(v[t][0], x0, p); p = fmaf(v[t][1], x1, p); p = fmaf(v[t][2], x2, p); p = fmaf(v[t][3], x3, p);
+      p += __shfl_xor(p, 16, 64);
+      p += __shfl_xor(p, 32, 64);
+      if (kq == 0) slab[(size_t)(i0 + 2 * r + t) * g.S + s] = p;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float p = ((v[t][0] + v[t][1]) + v[t][2]) + v[t][3];
+    p += __shfl_xor(p, 16, 64);
+    p += __shfl_xor(p, 32, 64);
+    if (kq == 0) slab[(size_t)H * g.S + i0 + 2 * r + t] = p;
+  }
+}
+
+// ---- role: dW2[o][i] = sum_b dh2[b][o] h1[b][i] (32 x 32 tile, both operands 2-column interleaved), db2 = row sums
+template <int NO>
+__device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s_acc)[4][64][4], float (*s_rs)[2][64]) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int H = g.H, tiles_n = H / 32;
+  const int tm = blk / tiles_n, tn = blk - tm * tiles_n;
+  const int o0 = tm * 32, i0 = tn * 32;
+  float whr[NO][2];
+#pragma unroll
+  for (int jj = 0; jj < NO; ++jj) {
+    whr[jj][0] = jj < g.n_out ? g.wh[jj][o0 + 2 * r] : 0.f;
+    whr[jj][1] = jj < g.n_out ? g.wh[jj][o0 + 2 * r + 1] : 0.f;
+  }
+  const int kper = ((g.B + 15) / 16) * 4, kbeg = wid * kper;  // rows per wave, multiple of 4
+  const int kend = kbeg + kper < g.B ? kbeg + kper : g.B;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rs[2] = {0.f, 0.f};
+  constexpr int U = 8;
+  for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
+    float4 g0[U], g1[U];
+    float2 h2v[U], h1v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = k0 + 4 * u + kq;
+      const int bc = b < kend ? b : g.B - 1;
+      g0[u] = *reinterpret_cast<const float4*>(g.g_all + (size_t)bc * 8);
+      if (NO > 4) g1[u] = *reinterpret_cast<const float4*>(g.g_all + (size_t)bc * 8 + 4);
+      h2v[u] = *reinterpret_cast<const float2*>(g.h2 + (size_t)bc * H + o0 + 2 * r);
+      h1v[u] = *reinterpret_cast<const float2*>(g.h1 + (size_t)bc * H + i0 + 2 * r);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = k0 + 4 * u + kq < kend;
+      float gq[8] = {g0[u].x, g0[u].y, g0[u].z, g0[u].w, 0.f, 0.f, 0.f, 0.f};
+      if (NO > 4) { gq[4] = g1[u].x; gq[5] = g1[u].y; gq[6] = g1[u].z; gq[7] = g1[u].w; }
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NO; ++jj) {
+        a0 = fmaf(gq[jj], whr[jj][0], a0);
+        a1 = fmaf(gq[jj], whr[jj][1], a1);
+      }
+      a0 = (ok && h2v[u].x > 0.f) ? a0 : 0.f;  // relu'(h2)
+      a1 = (ok && h2v[u].y > 0.f) ? a1 : 0.f;
+      rs[0] += a0;
+      rs[1] += a1;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, h1v[u].x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, h1v[u].y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, h1v[u].x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, h1v[u].y, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s_acc[wid][t * 2 + u][lane][i] = acc[t][u][i];
+    s_rs[wid][t][lane] = rs[t];
+  }
+  __syncthreads();
+  if (wid != 0) return;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = o0 + 2 * (kq * 4 + i) + t;  // row tile t owns the rows o0 + 2 * row + t
+      float2 out;
+      out.x = ((s_acc[0][t * 2][lane][i] + s_acc[1][t * 2][lane][i]) + s_acc[2][t * 2][lane][i]) + s_acc[3][t * 2][lane][i];
+      out.y = ((s_acc[0][t * 2 + 1][lane][i] + s_acc[1][t * 2 + 1][lane][i]) + s_acc[2][t * 2 + 1][lane][i]) + s_acc[3][t * 2 + 1][lane][i];
+      *reinterpret_cast<float2*>(g.dW2 + (size_t)o * H + i0 + 2 * r) = out;
+    }
+    if (tn == 0) {
+      float s = ((s_rs[0][t][lane] + s_rs[1][t][lane]) + s_rs[2][t][lane]) + s_rs[3][t][lane];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (kq == 0) g.db2[o0 + 2 * r + t] = s;
+    }
+  }
+}
+
+// ---- role: head weight gradients dWh[j][k] = sum_b g[b][j] h2[b][k] (rows j < n_out of a 16 x 32 tile), dbh = row sums
+__device__ __forceinline__ void pmb_role_dwh(const PmbBwd& g, int blk, float (*s_acc)[4][64][4], float (*s_rs)[2][64]) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int H = g.H, c0 = blk * 32;
+  const int kper = ((g.B + 15) / 16) * 4, kbeg = wid * kper;
+  const int kend = kbeg + kper < g.B ? kbeg + kper : g.B;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  float rs = 0.f;
+  constexpr int U = 8;
+  for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
+    float av[U];
+    float2 hv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = k0 + 4 * u + kq;
+      const int bc = b < kend ? b : g.B - 1;
+      av[u] = g.g_all[(size_t)bc * 8 + (r & 7)];
+      hv[u] = *reinterpret_cast<const float2*>(g.h2 + (size_t)bc * H + c0 + 2 * r);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float a = (k0 + 4 * u + kq < kend && r < g.n_out) ? av[u] : 0.f;
+      rs += a;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, hv[u].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, hv[u].y, acc[1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_acc[wid][t][lane][i] = acc[t][i];
+  s_rs[wid][0][lane] = rs;
+  __syncthreads();
+  if (wid != 0) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = kq * 4 + i;
+    if (j < g.n_out) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        g.dwh[j][c0 + 2 * r + t] = ((s_acc[0][t][lane][i] + s_acc[1][t][lane][i]) + s_acc[2][t][lane][i]) + s_acc[3][t][lane][i];
+    }
+  }
+  if (blk == 0) {
+    float s = ((s_rs[0][0][lane] + s_rs[1][0][lane]) + s_rs[2][0][lane]) + s_rs[3][0][lane];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (kq == 0 && r < g.n_out) *g.dbh[r] = s;
+  }
+}
+
+template <int NO, int U1>
+__global__ void __launch_bounds__(256) jh_pmb_bwd_kernel(PmbBwd g) {
+  __shared__ float s_acc[4][4][64][4];
+  __shared__ float s_rs[4][2][64];
+  extern __shared__ __attribute__((aligned(16))) float s_wh[];  // [NO][H] (dh1 role)
+  const int b = blockIdx.x;
+  if (b < g.n_dh1) pmb_role_dh1<NO, U1>(g, b, s_acc, s_wh);  // the longest chains first
+  else if (b < g.n_dh1 + g.n_dw2) pmb_role_dw2<NO>(g, b - g.n_dh1, s_acc, s_rs);
+  else pmb_role_dwh(g, b - g.n_dh1 - g.n_dw2, s_acc, s_rs);
+}
+
+// ============================================================================ 4. dW1 / db1 combine + global norm
+// hyper (device): [0] lr [1] beta1 [2] beta2 [3] eps [4] step [5] 1-beta1^t [6] sqrt(1-beta2^t)
+__global__ void __launch_bounds__(256) jh_pmb_norm_kernel(int64_t n, float* __restrict__ grads, const float* __restrict__ part,
+                                                          int tiles_m, int64_t n_head, float* __restrict__ partial,
+                                                          float* __restrict__ hyper, int do_norm) {
+  __shared__ float s_red[16];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2, h4 = n_head >> 2;  // n_head % 4 == 0 (H % 32 == 0); the buckets are 16-byte aligned
+  const int64_t lim4 = do_norm ? n4 : h4;
+  float4* g4 = reinterpret_cast<float4*>(grads);
+  const float4* p4 = reinterpret_cast<const float4*>(part);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < lim4; i += (int64_t)gridDim.x * 256) {
+    float4 v;
+    if (i < h4) {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t0 = 0; t0 < tiles_m; t0 += 8) {  // row-tile order: deterministic; 8 loads in flight
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = p4[(size_t)(t0 + u < tiles_m ? t0 + u : tiles_m - 1) * h4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (t0 + u < tiles_m) { v.x += q[u].x; v.y += q[u].y; v.z += q[u].z; v.w += q[u].w; }
+      }
+      g4[i] = v;
+    } else {
+      v = g4[i];
+    }
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+  }
+  if (!do_norm) return;
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - (n4 << 2))) {  // the <= 3 trailing elements
+    const float v = grads[(n4 << 2) + threadIdx.x];
+    acc = fmaf(v, v, acc);
+  }
+  acc = jh_block_reduce(acc, s_red, JhAdd(), 0.f);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // advance Adam's step (nobody reads hyper in this kernel)
+    const float t = hyper[4] + 1.f;
+    hyper[4] = t;
+    hyper[5] = 1.f - powf(hyper[1], t);
+    hyper[6] = sqrtf(1.f - powf(hyper[2], t));
+  }
+}
+
+// ============================================================================ host side
+bool jh_pmb_eligible(const jh_pponet* n, int B) { return n->H % 32 == 0 && B > 0 && B <= n->max_rows; }
+
+template <int SV, bool GEN>
+static int pmb_fwd_launch(const PmbFwd& g, hipStream_t st) {
+  const int tiles = ((g.M + 15) / 16) * (g.H / 16);
+  const int kper = ((g.H + 63) / 64) * 16;
+  if (kper > 64) JH_LAUNCH_NAMED("jh_pmb_fwd", (jh_pmb_fwd_kernel<SV, GEN, 8>), dim3(tiles), dim3(256), 0, st, g);
+  else if (kper > 32) JH_LAUNCH_NAMED("jh_pmb_fwd", (jh_pmb_fwd_kernel<SV, GEN, 4>), dim3(tiles), dim3(256), 0, st, g);
+  else JH_LAUNCH_NAMED("jh_pmb_fwd", (jh_pmb_fwd_kernel<SV, GEN, 2>), dim3(tiles), dim3(256), 0, st, g);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+int jh_pmb_forward(jh_pponet* n, int M, const float* d_x, const int64_t* d_idx, const PmbHeads& hd, const float* h1_in,
+                   bool store_act, hipStream_t st) {
+  PmbFwd g{};
+  g.M = M; g.H = n->H; g.S = n->S; g.x = d_x; g.x_rows = d_idx;
+  g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.W2 = n->params + n->o_w2; g.b2 = n->params + n->o_b2;
+  g.h1_in = h1_in; g.h1_out = store_act ? n->h1 : nullptr; g.h2_out = store_act ? n->h2 : nullptr;
+  for (int o = 0; o < hd.n_out; ++o) { g.wh[o] = hd.w[o]; g.hb[o] = hd.b[o]; }
+  g.n_out = hd.n_out; g.part = n->fwd_part; g.part_rows = n->max_rows; g.part_ld = hd.n_out <= 4 ? 4 : 8;
+  if (h1_in) return pmb_fwd_launch<0, false>(g, st);
+  const bool al = (((uintptr_t)d_x) & 15) == 0 && (((uintptr_t)g.W1) & 15) == 0;
+  if (n->S == 4 && al) return pmb_fwd_launch<1, true>(g, st);
+  if (n->S == 8 && al) return pmb_fwd_launch<2, true>(g, st);
+  return pmb_fwd_launch<0, true>(g, st);
+}
+
+int jh_pmb_heads_finish(jh_pponet* n, int M, float* d_head0, float* d_head1, float* d_value, hipStream_t st) {
+  JH_LAUNCH(jh_pmb_heads_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, n->H / 16, n->max_rows, (n->cont ? 2 * n->A + 1 : n->A + 1) <= 4 ? 4 : 8, n->fwd_part, n->A,
+            n->cont, d_head0, d_head1, d_value);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+int jh_pmb_backward(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, const PmbHeads& hd, hipStream_t st) {
+  PmbBwd g{};
+  g.B = B; g.H = n->H; g.S = n->S; g.n_out = hd.n_out; g.x = d_x; g.x_rows = d_idx;
+  g.h1 = n->h1; g.h2 = n->h2; g.g_all = n->g_all; g.W2 = n->params + n->o_w2;
+  g.dW2 = n->grads + n->o_w2; g.db2 = n->grads + n->o_b2;
+  for (int o = 0; o < hd.n_out; ++o) { g.wh[o] = hd.w[o]; g.dwh[o] = hd.dw[o]; g.dbh[o] = hd.db[o]; }
+  g.part_w1 = n->part_w1;
+  const int t32 = n->H / 32;
+  g.n_dh1 = ((B + 15) / 16) * t32;
+  g.n_dw2 = t32 * t32;
+  const int grid = g.n_dh1 + g.n_dw2 + t32;
+  static const int u1 = getenv("JH_PMB_U1") ? atoi(getenv("JH_PMB_U1")) : 8;  // k-chunks of dh1 loaded ahead of the MFMAs
+  const bool deep = u1 >= 8 && n->H >= 512;
+  if (hd.n_out <= 4) {
+    if (deep) JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<4, 8>), dim3(grid), dim3(256), sizeof(float) * 4 * (size_t)n->H, st, g);
+    else JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<4, 4>), dim3(grid), dim3(256), sizeof(float) * 4 * (size_t)n->H, st, g);
+  } else {
+    if (deep) JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<8, 8>), dim3(grid), dim3(256), sizeof(float) * 8 * (size_t)n->H, st, g);
+    else JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<8, 4>), dim3(grid), dim3(256), sizeof(float) * 8 * (size_t)n->H, st, g);
+  }
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+int jh_pmb_finalize(jh_pponet* n, int B, bool with_norm, hipStream_t st) {
+  const int64_t n_head = (int64_t)n->H * n->S + n->H;
+  const int tiles_m = (B + 15) / 16;
+  const int blocks = with_norm ? 256 : (int)((n_head / 4 + 255) / 256);
+  JH_LAUNCH(jh_pmb_norm_kernel, dim3(blocks), dim3(256), 0, st, n->n_params, n->grads, n->part_w1, tiles_m, n_head, n->norm_partial,
+            n->hyper, with_norm ? 1 : 0);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}

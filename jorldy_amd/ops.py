@@ -289,35 +289,68 @@ class SumTree:
 
 
 # ============================================================================= PPO math
-def gae(reward, done, value, next_value, n_step, gamma, lam, standardize=True):
+def gae(reward, done, value, next_value, n_step, gamma, lam, standardize=True, out=None):
     """ppo.py:95-110.  Inputs float32 CUDA [M,1] (or [M]), M = W*n_step, worker-major.
-    Returns (adv [M,1], ret [M,1])."""
+    Returns (adv [M,1], ret [M,1]); `out` = preallocated (adv, ret)."""
     lib = L.load()
     r, d, v, vn = (_f32(x).reshape(-1) for x in (reward, done, value, next_value))
     M = r.numel()
     assert M % n_step == 0
-    adv = torch.empty(M, dtype=torch.float32, device=r.device)
-    ret = torch.empty(M, dtype=torch.float32, device=r.device)
+    if out is None:
+        adv = torch.empty(M, dtype=torch.float32, device=r.device)
+        ret = torch.empty(M, dtype=torch.float32, device=r.device)
+    else:
+        adv, ret = (_f32(t).reshape(-1) for t in out)
     with _timed("jh_gae_kernel", 24 * M):  # 4 reads + 2 writes of fp32 per transition (SURVEY.md §8d)
       L.check(lib.jh_gae(L.ctx(_dev(r)), M // n_step, int(n_step), float(gamma), float(lam), L.ptr(r), L.ptr(d), L.ptr(v), L.ptr(vn), L.ptr(adv), L.ptr(ret), int(bool(standardize)), L.stream_ptr()))
     return adv.view(-1, 1), ret.view(-1, 1)
 
 
-def logp_discrete(logits, action):
+def mean_into(x, out):
+    """out[0] = mean(x) (ppo.py:112), one deterministic workgroup."""
+    x = _f32(x).reshape(-1)
+    L.check(L.load().jh_mean_f32(L.ctx(_dev(x)), int(x.numel()), L.ptr(x), L.ptr(out), L.stream_ptr()))
+    return out
+
+
+class MinibatchRows:
+    """jh_ppo_minibatch_rows: the `x[idx]` gathers of every epoch of ppo.py:118-125 done once per learn().
+    srcs / dsts: lists of float32 CUDA tensors [M, e_c] / [n, e_c] (static addresses: capturable)."""
+
+    def __init__(self, srcs, dsts):
+        self.lib = L.load()
+        assert len(srcs) == len(dsts) <= 8
+        self.srcs, self.dsts = [_f32(t) for t in srcs], list(dsts)
+        n = len(srcs)
+        self.n = int(dsts[0].shape[0])
+        el = [int(t.numel() // t.shape[0]) for t in self.srcs]
+        assert all(int(d.numel()) == self.n * e and d.is_contiguous() for d, e in zip(self.dsts, el))
+        self._elems = (C.c_int32 * n)(*el)
+        self._src = (C.c_void_p * n)(*[t.data_ptr() for t in self.srcs])
+        self._dst = (C.c_void_p * n)(*[t.data_ptr() for t in self.dsts])
+        self.ctx = L.ctx(_dev(self.srcs[0]))
+
+    def __call__(self, idx):
+        assert idx.dtype == torch.int64 and int(idx.numel()) == self.n
+        L.check(self.lib.jh_ppo_minibatch_rows(self.ctx, self.n, L.ptr(idx), len(self.srcs), self._elems, self._src, self._dst, L.stream_ptr()))
+        return self.dsts
+
+
+def logp_discrete(logits, action, out=None):
     lib = L.load()
     z = _f32(logits)
     M, A = z.shape
     a = _f32(action).reshape(-1)
-    out = torch.empty(M, dtype=torch.float32, device=z.device)
+    out = torch.empty(M, dtype=torch.float32, device=z.device) if out is None else _f32(out).reshape(-1)
     L.check(lib.jh_logp_discrete(L.ctx(_dev(z)), M, A, L.ptr(z), L.ptr(a), L.ptr(out), L.stream_ptr()))
     return out.view(-1, 1)
 
 
-def logp_continuous(mu_raw, log_std_raw, action):
+def logp_continuous(mu_raw, log_std_raw, action, out=None):
     lib = L.load()
     mu, ls, a = _f32(mu_raw), _f32(log_std_raw), _f32(action)
     M, A = mu.shape
-    out = torch.empty(M, A, dtype=torch.float32, device=mu.device)
+    out = torch.empty(M, A, dtype=torch.float32, device=mu.device) if out is None else _f32(out)
     L.check(lib.jh_logp_continuous(L.ctx(_dev(mu)), M, A, L.ptr(mu), L.ptr(ls), L.ptr(a), L.ptr(out), L.stream_ptr()))
     return out
 
@@ -428,8 +461,13 @@ class PPONet:
         with _timed("jh_gradnorm+adam", 4.0 * self.n_params * 8):  # g (r twice, w) + p,m,v (r+w)
             L.check(self.lib.jh_pponet_adam_step(self.h, float(max_norm if max_norm else 0.0), L.ptr(norm_out), L.stream_ptr()))
 
+    def fused_ok(self, B):
+        """Minibatches the five-launch update (jh_pponet_ppo_update) takes: < 1024 rows (from there on the
+        LDS-tiled engine wins), hidden width a multiple of 32."""
+        return self.H % 32 == 0 and 0 < B < 1024
+
     def ppo_update(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, max_norm, stats, do_adam=True):
-        """One PPO minibatch update in 8 launches (jh_pponet_ppo_update).  B = idx.numel() <= 1024."""
+        """One whole PPO minibatch update in 5 launches (jh_pponet_ppo_update).  B = idx.numel() <= 1024."""
         B = int(idx.numel()) if idx is not None else int(x.shape[0])
         L.check(self.lib.jh_pponet_ppo_update(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
                                               L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),

@@ -376,6 +376,57 @@ def test_pponet_forward_backward_adam_vs_torch():
             net.v.copy_(torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ref.parameters()]))
 
 
+@pytest.mark.parametrize("cont,S,H,A,B", [(False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8), (False, 8, 64, 3, 250), (True, 3, 96, 2, 1000)])
+def test_ppo_update_five_launches_equal_separate_calls(cont, S, H, A, B):
+    """jh_pponet_ppo_update (forward into partial heads, loss on the partials, one backward grid with the dW1 partials,
+    combine + norm, Adam) against jh_pponet_forward -> jh_ppo_loss_* -> jh_pponet_backward -> jh_pponet_adam_step on the
+    same inputs: same statistics, same gradient bucket (raw with do_adam = 0, clipped with 1), same parameters.
+    Shapes cover layer 1 in registers (S = 4 / 8 vector loads, S = 7 / 3 scalar), the l1 kernel (S = 11), ragged B."""
+    from jorldy_amd import ops
+
+    torch.manual_seed(S * 1000 + B)
+    M = 1500
+    x = torch.randn(M, S, device="cuda")
+    action = torch.tanh(torch.randn(M, A, device="cuda")) if cont else torch.randint(0, A, (M, 1), device="cuda").float()
+    adv, ret, vold = torch.randn(M, 1, device="cuda"), torch.randn(M, 1, device="cuda"), torch.randn(M, 1, device="cuda")
+    logp_old = -torch.rand(M, A if cont else 1, device="cuda") - 0.3
+    idx = torch.randperm(M, device="cuda")[:B].contiguous()
+    nets = [ops.PPONet(S, H, A, cont, 2048, "cuda:0") for _ in range(3)]
+    p0 = torch.randn(nets[0].n_params, device="cuda") * (0.7 / np.sqrt(H))
+    for net in nets:
+        net.params.copy_(p0)
+        net.set_hyper(1e-3, 0.9, 0.999, 1e-8, step=0.0)
+    eps, vf, ent, clip = 0.1, 1.0, 0.01, 0.5
+    # reference sequence on net 0
+    n0 = nets[0]
+    st0 = torch.zeros(8, device="cuda")
+    if cont:
+        mu, ls, vp = n0.forward(x, idx=idx)
+        g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu, ls, vp, idx, action, adv, ret, vold, logp_old, eps, vf, ent, stats=st0)
+        n0.backward(x, idx, g_mu, g_ls, g_v)
+    else:
+        z, vp = n0.forward(x, idx=idx)
+        g_z, g_v, _ = ops.ppo_loss_discrete(z, vp, idx, action, adv, ret, vold, logp_old, eps, vf, ent, stats=st0)
+        n0.backward(x, idx, g_z, None, g_v)
+    raw = n0.grads.clone()
+    n0.adam_step(clip)
+    # five launches without Adam (data-parallel form), then the separate optimizer step
+    n1, n2 = nets[1], nets[2]
+    st1, st2 = torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda")
+    n1.ppo_update(x, idx, action, adv, ret, vold, logp_old, eps, vf, ent, clip, st1, do_adam=False)
+    scale = float(raw.abs().max())
+    assert float((n1.grads - raw).abs().max()) <= 1e-5 * scale, "raw gradient bucket"
+    torch.testing.assert_close(st1, st0, rtol=1e-5, atol=1e-6)
+    n1.adam_step(clip)
+    n2.ppo_update(x, idx, action, adv, ret, vold, logp_old, eps, vf, ent, clip, st2, do_adam=True)
+    torch.testing.assert_close(st2, st1, rtol=0, atol=0)  # same kernels, same bits
+    for n in (n1, n2):
+        assert float((n.grads - n0.grads).abs().max()) <= 1e-5 * float(n0.grads.abs().max()), "clipped gradient bucket"
+        d = (n.params - n0.params).abs()
+        assert float((d > 2e-5).float().mean()) < 0.005 and float(d.max()) <= 2.1e-3
+    torch.testing.assert_close(n2.params, n1.params, rtol=0, atol=1e-7)
+
+
 @pytest.mark.parametrize("name", PPO_CASES)
 @pytest.mark.parametrize("graph", [False, True])
 def test_ppo_native_backend_matches_reference(name, graph):
