@@ -32,6 +32,11 @@ class PERBuffer(ReplayBuffer):
             self._tree.push(n, self._next_prio)   # per_buffer.py:27-33 (max_priority when no actor-side priority)
         return n
 
+    def store_device(self, cols, example=None, priorities=None):
+        n = super().store_device(cols, example)
+        self._tree.push(n, None if priorities is None else np.asarray(priorities, dtype=np.float64).reshape(-1))
+        return n
+
     def _defer(self, flat, n, extra=None):
         super()._defer(flat, n, self._next_prio)
 

@@ -63,6 +63,23 @@ class ReplayBuffer(BaseBuffer):
         self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
         return n
 
+    def store_device(self, cols, example=None):
+        """Rows that are already in HBM (a device-side producer, synthetic prefills): `cols` maps the agent-side keys
+        to CUDA tensors [n, ...] in the STORED dtype (uint8 frames, float32, int64 actions, uint8 done flags);
+        device-to-device ring append, same bookkeeping as store().  `example`: one host SoA batch that fixes the
+        column layout when nothing has been stored yet."""
+        assert not self.frame_dedup, "frame_dedup recognises frames on the host"
+        if self._store is None:
+            assert example is not None, "the buffer has no layout yet: pass an example batch"
+            self._make_store(example, self.buffer_size)
+        self.flush()
+        flat = self._flat_cols(cols)
+        n = int(next(iter(flat.values())).shape[0])
+        self._store.push_device(flat, n)
+        self.buffer_index = (self.buffer_index + n) % self.buffer_size
+        self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
+        return n
+
     def _defer(self, flat, n, extra=None):
         # rows are copied (the caller may reuse its arrays) straight into preallocated host columns of the stored dtype:
         # no per-store allocations, no concatenate at flush time

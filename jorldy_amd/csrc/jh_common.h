@@ -35,16 +35,24 @@ int jh_fail(int code, const char* fmt, ...);
   } while (0)
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
-// Disabled by default: JH_LAUNCH is then exactly hipLaunchKernelGGL.
+// Disabled by default: JH_LAUNCH is then exactly hipLaunchKernelGGL.  jh_prof_enable(R > 1): kernels launched
+// through JH_LAUNCH_IDEM (idempotent: same inputs -> same outputs, no counters advanced) run R times back to back
+// inside ONE event pair, so the pair's fixed cost (~4 us, more than most kernels here) is amortised and the
+// average is the kernel's duration in a dependent chain -- comparable with rocprofv3's kernel-trace average.
 extern bool g_jh_prof_on;
-void jh_prof_begin(const char* name, hipStream_t st);
+extern int g_jh_prof_repeat;
+void jh_prof_begin(const char* name, hipStream_t st, int reps, double work);
 void jh_prof_end(hipStream_t st);
-#define JH_LAUNCH_NAMED(NAME, KERNEL, GRID, BLOCK, LDS, ST, ...)       \
-  do {                                                                 \
-    if (g_jh_prof_on) jh_prof_begin(NAME, ST);                         \
-    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__);     \
-    if (g_jh_prof_on) jh_prof_end(ST);                                 \
+#define JH_LAUNCH_WORK(NAME, WORK, REPS, KERNEL, GRID, BLOCK, LDS, ST, ...)  \
+  do {                                                                       \
+    const int _reps = g_jh_prof_on ? (REPS) : 1;                             \
+    if (g_jh_prof_on) jh_prof_begin(NAME, ST, _reps, WORK);                  \
+    for (int _i = 0; _i < _reps; ++_i) hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__); \
+    if (g_jh_prof_on) jh_prof_end(ST);                                       \
   } while (0)
+#define JH_LAUNCH_NAMED(NAME, KERNEL, GRID, BLOCK, LDS, ST, ...) JH_LAUNCH_WORK(NAME, 0.0, 1, KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__)
+// idempotent kernel with a declared amount of work (flops) per launch
+#define JH_LAUNCH_IDEM(NAME, WORK, KERNEL, GRID, BLOCK, LDS, ST, ...) JH_LAUNCH_WORK(NAME, WORK, g_jh_prof_repeat, KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__)
 #define JH_LAUNCH(KERNEL, GRID, BLOCK, LDS, ST, ...) JH_LAUNCH_NAMED(#KERNEL, KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__)
 
 static inline hipStream_t jh_s(jh_stream s) { return reinterpret_cast<hipStream_t>(s); }

@@ -135,16 +135,19 @@ JH_EXPORT void jh_pinned_free(void* host) {
 // ------------------------------------------------------------------------------ kernel profiler
 #include <map>
 bool g_jh_prof_on = false;
+int g_jh_prof_repeat = 1;
 namespace {
 struct ProfRec {
   const char* name;
   hipEvent_t e0, e1;
+  int reps;
+  double work;
 };
 std::vector<ProfRec> g_prof;
 }  // namespace
 
-void jh_prof_begin(const char* name, hipStream_t st) {
-  ProfRec r{name, nullptr, nullptr};
+void jh_prof_begin(const char* name, hipStream_t st, int reps, double work) {
+  ProfRec r{name, nullptr, nullptr, reps, work};
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
   (void)hipEventRecord(r.e0, st);
   g_prof.push_back(r);
@@ -159,7 +162,7 @@ void jh_prof_end(hipStream_t st) {
 JH_EXPORT int jh_prof_calibrate(int32_t n, jh_stream stream) {
   if (!g_jh_prof_on) return jh_fail(JH_ERR_STATE, "jh_prof_calibrate: profiling is off");
   for (int i = 0; i < n; ++i) {
-    jh_prof_begin("__event_pair_overhead", jh_s(stream));
+    jh_prof_begin("__event_pair_overhead", jh_s(stream), 1, 0.0);
     jh_prof_end(jh_s(stream));
   }
   return JH_OK;
@@ -172,25 +175,29 @@ JH_EXPORT int jh_prof_enable(int32_t on) {
   }
   g_prof.clear();
   g_jh_prof_on = on != 0;
+  g_jh_prof_repeat = on > 1 ? on : 1;
   return JH_OK;
 }
 
-// Writes one line per kernel: "<name>\t<launches>\t<total_ms>\n" (synchronises the device).
+// Writes one line per kernel: "<name>\t<launches>\t<total_ms>\t<work>\n" (synchronises the device); work = flops of
+// the MFMA kernels that declare it (per launch x launches), 0 otherwise.
 JH_EXPORT int jh_prof_report(char* buf, int64_t cap) {
   JH_ARG(buf && cap > 0);
   JH_HIP(hipDeviceSynchronize());
-  std::map<std::string, std::pair<long, double>> agg;
+  struct Agg { long n = 0; double ms = 0, work = 0; };
+  std::map<std::string, Agg> agg;
   for (auto& r : g_prof) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     auto& a = agg[r.name];
-    a.first += 1;
-    a.second += ms;
+    a.n += r.reps;
+    a.ms += ms;
+    a.work += r.work * r.reps;
   }
   std::string out;
   char line[512];
   for (auto& kv : agg) {
-    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.work);
     out += line;
   }
   if ((int64_t)out.size() + 1 > cap) return jh_fail(JH_ERR_ARG, "jh_prof_report: buffer too small (%zu needed)", out.size() + 1);

@@ -329,7 +329,7 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.dbg = p->dbg_d;
   // polls in flight per workgroup and their spacing (10 ns ticks): 4 x 0.4 us covers a ~1.6 us PCIe read round trip
   static const int depth = getenv("JH_PERSIST_DEPTH") ? atoi(getenv("JH_PERSIST_DEPTH")) : 4;
-  static const int period = getenv("JH_PERSIST_PERIOD") ? atoi(getenv("JH_PERSIST_PERIOD")) : 20;
+  static const int period = getenv("JH_PERSIST_PERIOD") ? atoi(getenv("JH_PERSIST_PERIOD")) : 10;
   a.period = depth > 1 ? period : 0;
   static const int relay = getenv("JH_PERSIST_RELAY") ? atoi(getenv("JH_PERSIST_RELAY")) : 1;
   a.mbox = relay ? p->mbox : nullptr;

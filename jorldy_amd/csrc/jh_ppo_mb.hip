@@ -500,9 +500,12 @@ template <int SV, bool GEN>
 static int pmb_fwd_launch(const PmbFwd& g, hipStream_t st) {
   const int tiles = ((g.M + 15) / 16) * (g.H / 16);
   const int kper = ((g.H + 63) / 64) * 16;
-  if (kper > 64) JH_LAUNCH_NAMED("jh_pmb_fwd", (jh_pmb_fwd_kernel<SV, GEN, 8>), dim3(tiles), dim3(256), 0, st, g);
-  else if (kper > 32) JH_LAUNCH_NAMED("jh_pmb_fwd", (jh_pmb_fwd_kernel<SV, GEN, 4>), dim3(tiles), dim3(256), 0, st, g);
-  else JH_LAUNCH_NAMED("jh_pmb_fwd", (jh_pmb_fwd_kernel<SV, GEN, 2>), dim3(tiles), dim3(256), 0, st, g);
+  // flops: layer 1 (generated) + the H x H contraction + the heads
+  const double fl = 2.0 * g.M * (double)g.H * ((GEN ? g.S : 0) + g.H + g.n_out);
+  const char* nm = g.M > 1024 ? "jh_pmb_fwd_nograd" : "jh_pmb_fwd";  // the no-grad pass over [state; next_state] vs a minibatch
+  if (kper > 64) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 8>), dim3(tiles), dim3(256), 0, st, g);
+  else if (kper > 32) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 4>), dim3(tiles), dim3(256), 0, st, g);
+  else JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 2>), dim3(tiles), dim3(256), 0, st, g);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
@@ -542,12 +545,14 @@ int jh_pmb_backward(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx,
   const int grid = g.n_dh1 + g.n_dw2 + t32;
   static const int u1 = getenv("JH_PMB_U1") ? atoi(getenv("JH_PMB_U1")) : 8;  // k-chunks of dh1 loaded ahead of the MFMAs
   const bool deep = u1 >= 8 && n->H >= 512;
+  // flops: dW2 + dh1 (B x H x H each), head weight gradients, dW1 partials, dh2 generated twice
+  const double fl = 2.0 * B * (double)n->H * (2.0 * n->H + hd.n_out + n->S + 2.0 * hd.n_out);
   if (hd.n_out <= 4) {
-    if (deep) JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<4, 8>), dim3(grid), dim3(256), sizeof(float) * 4 * (size_t)n->H, st, g);
-    else JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<4, 4>), dim3(grid), dim3(256), sizeof(float) * 4 * (size_t)n->H, st, g);
+    if (deep) JH_LAUNCH_IDEM("jh_pmb_bwd", fl, (jh_pmb_bwd_kernel<4, 8>), dim3(grid), dim3(256), sizeof(float) * 4 * (size_t)n->H, st, g);
+    else JH_LAUNCH_IDEM("jh_pmb_bwd", fl, (jh_pmb_bwd_kernel<4, 4>), dim3(grid), dim3(256), sizeof(float) * 4 * (size_t)n->H, st, g);
   } else {
-    if (deep) JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<8, 8>), dim3(grid), dim3(256), sizeof(float) * 8 * (size_t)n->H, st, g);
-    else JH_LAUNCH_NAMED("jh_pmb_bwd", (jh_pmb_bwd_kernel<8, 4>), dim3(grid), dim3(256), sizeof(float) * 8 * (size_t)n->H, st, g);
+    if (deep) JH_LAUNCH_IDEM("jh_pmb_bwd", fl, (jh_pmb_bwd_kernel<8, 8>), dim3(grid), dim3(256), sizeof(float) * 8 * (size_t)n->H, st, g);
+    else JH_LAUNCH_IDEM("jh_pmb_bwd", fl, (jh_pmb_bwd_kernel<8, 4>), dim3(grid), dim3(256), sizeof(float) * 8 * (size_t)n->H, st, g);
   }
   JH_LAUNCH_CHECK();
   return JH_OK;

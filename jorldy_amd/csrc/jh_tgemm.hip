@@ -366,10 +366,13 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   batch.n = n;
   (void)max_tiles; (void)max_split;
   const dim3 grid(wgs);
-  if (TM == 2 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 2>), grid, dim3(256), 0, st, batch);
-  else if (TM == 1 && TN == 2) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<1, 2>), grid, dim3(256), 0, st, batch);
-  else if (TM == 2 && TN == 1) JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<2, 1>), grid, dim3(256), 0, st, batch);
-  else JH_LAUNCH_NAMED(name, (jh_tgemm_kernel<1, 1>), grid, dim3(256), 0, st, batch);
+  double flops = 0.0;  // profiling: 2 M N K of every problem of the group (the launch is idempotent: partial slabs are
+                       // rewritten, arrival counters return to zero)
+  for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * (double)probs[i].K;
+  if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2>), grid, dim3(256), 0, st, batch);
+  else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2>), grid, dim3(256), 0, st, batch);
+  else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1>), grid, dim3(256), 0, st, batch);
+  else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1>), grid, dim3(256), 0, st, batch);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }

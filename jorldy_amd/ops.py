@@ -54,10 +54,11 @@ def profile_collect():
     return out
 
 
-def lib_profile(enable):
-    """Bracket every kernel launched by libjorldy_hip with HIP events on its launch stream."""
+def lib_profile(enable, repeat=1):
+    """Bracket every kernel launched by libjorldy_hip with HIP events on its launch stream.  repeat > 1: the
+    idempotent MFMA kernels run `repeat` times back to back inside one event pair (amortises the pair's ~4 us)."""
     _PROF["lib"] = bool(enable)
-    L.check(L.load().jh_prof_enable(int(bool(enable))))
+    L.check(L.load().jh_prof_enable(int(max(1, repeat)) if enable else 0))
 
 
 def lib_profile_calibrate(n=64):
@@ -66,13 +67,14 @@ def lib_profile_calibrate(n=64):
 
 
 def lib_profile_report():
-    """-> {kernel name: (launches, total_ms)} (synchronises the device)."""
+    """-> {kernel name: (launches, total_ms, total_flops)} (synchronises the device); flops only for the MFMA
+    kernels that declare them, else 0."""
     buf = C.create_string_buffer(1 << 16)
     L.check(L.load().jh_prof_report(buf, len(buf)))
     out = {}
     for line in buf.value.decode().splitlines():
-        name, n, ms = line.split("\t")
-        out[name] = (int(n), float(ms))
+        name, n, ms, work = line.split("\t")
+        out[name] = (int(n), float(ms), float(work))
     return out
 
 

@@ -140,3 +140,26 @@ def pin_to_gpu_node(device_index=None, local_rank=0, ranks_on_node=1, min_cores=
         return mine
     except Exception:
         return None
+
+
+def _gpu_local_cpulist(index):
+    """sysfs local_cpulist of HIP device `index`'s PCI function (no HIP context is created for it)."""
+    import torch
+
+    p = torch.cuda.get_device_properties(index)
+    bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+        return f.read().strip()
+
+
+def ranks_sharing_node(local_rank, local_world):
+    """(slot, count) of this rank among the local ranks whose GPU hangs off the same NUMA node / PCIe root (equal
+    sysfs local_cpulist), rank r using GPU r: the ranks of one node split its cores between them (pin_to_gpu_node).
+    Nothing about the topology is assumed (round 1 hard-coded 4 GPUs per socket); when sysfs cannot be read every
+    local rank is taken to share one node (smaller, still disjoint slices)."""
+    try:
+        lists = [_gpu_local_cpulist(i) for i in range(local_world)]
+        same = [i for i, l in enumerate(lists) if l == lists[local_rank]]
+        return same.index(local_rank), len(same)
+    except Exception:
+        return local_rank, max(1, local_world)

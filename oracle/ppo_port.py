@@ -183,3 +183,65 @@ def sync_iteration(agent, envs, states, update_period):
             state = after if done[0, 0] else next_state
         states[w] = state
     return transitions
+
+
+# ---------------------------------------------------------------------------------------------------
+# "8 procs" variant of the CPU baseline (SURVEY.md §8d / BASELINE.md §3): the reference's sync mode runs
+# its Actors as separate processes (Ray); every iteration the learner ships the full state_dict to them
+# (DistributedManager.sync, distributed_manager.py:55-60) and gets update_period x num_workers transition
+# dicts back (run, :26-31).  Ray is not installable here: plain `multiprocessing` (spawn) workers with
+# pipes play its part -- same per-step work in the actors, same pickled payloads in both directions.
+def _worker_main(conn, seed, S, A, H, cont):
+    torch.set_num_threads(1)
+    agent = PPOPort(S, A, H, cont)
+    env = _OneEnv(seed=seed)
+    state = env.reset_obs()
+    while True:
+        msg = conn.recv()
+        if msg is None:
+            break
+        weights, steps = msg
+        agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})  # BaseAgent.sync_in
+        out = []
+        for _ in range(steps):  # Actor.run, distributed_manager.py:76-92
+            action_dict = agent.act(state, training=True)
+            next_state, reward, done, after = env.step(action_dict["action"])
+            tr = {"state": state, "next_state": next_state, "reward": reward, "done": done}
+            tr.update(action_dict)
+            out.append(tr)
+            state = after if done[0, 0] else next_state
+        conn.send(out)
+
+
+class ProcWorkers:
+    """num_workers actor processes; run(agent, T) = sync(weights) + one DistributedManager.run."""
+
+    def __init__(self, num_workers, S, A, H, cont=False):
+        import multiprocessing as mp
+
+        ctx = mp.get_context("spawn")  # the bench process holds a HIP context: never fork it
+        self.conns, self.procs = [], []
+        for w in range(num_workers):
+            a, b = ctx.Pipe()
+            p = ctx.Process(target=_worker_main, args=(b, w, S, A, H, cont), daemon=True)
+            p.start()
+            self.conns.append(a)
+            self.procs.append(p)
+
+    def run(self, agent, steps):
+        weights = {k: v.detach().cpu().numpy() for k, v in agent.network.state_dict().items()}  # BaseAgent.sync_out
+        for c in self.conns:
+            c.send((weights, steps))
+        transitions = []
+        for c in self.conns:  # worker-major concat
+            transitions += c.recv()
+        return transitions
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(None)
+            except Exception:
+                pass
+        for p in self.procs:
+            p.join(timeout=5)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_emits_one_contract_json_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-baseline-iters", "2", "--rainbow-updates", "20"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-baseline-iters", "2", "--rainbow-updates", "20", "--rainbow-filled", "8192"],
                          cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -30,5 +30,10 @@ def test_bench_emits_one_contract_json_line():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert r["kernel"].startswith("jh_pmb_") and r["launches"] > 0 and r["avg_us"] > 0 and "traffic" in r
+    assert set(c["variants"]) == {"sequential_in_process", "8_actor_processes"}
+    a = d["acting"]
+    assert a["kernel"] == "jh_act_persist_kernel" and 0 < a["share_of_step"] < 1
     rb = d["rainbow"]
     assert rb["value"] > 0 and rb["unit"] == "updates/s" and rb["backend"] == "native" and rb["n_gpus"] == 1
+    assert "N=1000000" in rb["config"]["workload"] and 0 < rb["roofline"]["frac"] < 1 and rb["cpu_reference"]["value"] > 0
