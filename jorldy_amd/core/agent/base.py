@@ -85,35 +85,93 @@ class BaseAgent(ABC):
         torch.cuda.current_stream().synchronize()
         return [o.numpy() for o in outs]
 
-    def save_full(self, path):
-        """`save(path)` (reference format, unchanged) + `resume.pt`: replay buffer / sum tree contents,
-        step counters, epsilon / beta, numpy + torch RNG state -- what the reference cannot resume."""
+    RESUME_FORMAT, RESUME_VERSION = "jorldy_amd.resume", 2
+
+    def _resume_extra_attrs(self):
+        """Subclass hook: more JSON-able state for the manifest (e.g. the native acting RNG counters)."""
+        return {}
+
+    def _resume_load_extra_attrs(self, d):
+        pass
+
+    def save_full(self, path, version=None):
+        """`save(path)` (the reference's ckpt, unchanged) + everything the reference cannot resume (SURVEY.md §8f rank 4,
+        core/agent/dqn.py:184-199): replay buffer / sum tree contents, step counters, epsilon / beta, numpy + torch
+        RNG state.
+
+        Format version 2 (default): directory `path/resume/` with `manifest.json` ({"format", "version", ...}) and one
+        raw file per replay column, streamed from HBM in 64 MB chunks -- no host copy of the whole buffer (56 GB of
+        frames at config.rainbow.atari's N = 1e6).  version=1 writes round 1's single `resume.pt` pickle (kept so that
+        old checkpoints stay loadable and testable)."""
+        import json
         import os
 
+        version = self.RESUME_VERSION if version is None else version
         self.save(path)
-        extra = {"attrs": {k: getattr(self, k) for k in self._RESUME_ATTRS if hasattr(self, k)},
-                 "numpy_rng": np.random.get_state(), "torch_rng": torch.get_rng_state(), "torch_cuda_rng": torch.cuda.get_rng_state(self.device)}
         mem = getattr(self, "memory", None)
-        if mem is not None and hasattr(mem, "state_dict"):
-            extra["memory"] = mem.state_dict()
+        if version == 1:
+            extra = {"attrs": {k: getattr(self, k) for k in self._RESUME_ATTRS if hasattr(self, k)},
+                     "numpy_rng": np.random.get_state(), "torch_rng": torch.get_rng_state(), "torch_cuda_rng": torch.cuda.get_rng_state(self.device)}
+            if mem is not None and hasattr(mem, "state_dict"):
+                extra["memory"] = mem.state_dict()
+            if hasattr(self, "target_network"):
+                extra["target_network"] = {k: v.cpu() for k, v in self.target_network.state_dict().items()}
+            torch.save(extra, os.path.join(path, "resume.pt"))
+            return
+        assert version == 2, f"unknown resume format version {version}"
+        d = os.path.join(path, "resume")
+        os.makedirs(d, exist_ok=True)
+        num = lambda v: v.item() if isinstance(v, (np.generic, torch.Tensor)) else v
+        rs = np.random.get_state()
+        man = {"format": self.RESUME_FORMAT, "version": 2, "agent": type(self).__name__,
+               "attrs": {k: num(getattr(self, k)) for k in self._RESUME_ATTRS if hasattr(self, k)},
+               "extra_attrs": self._resume_extra_attrs(),
+               "numpy_rng": {"kind": rs[0], "pos": int(rs[2]), "has_gauss": int(rs[3]), "cached_gaussian": float(rs[4]), "keys": "numpy_rng_keys.u32"},
+               "torch_rng": "torch_rng.u8", "torch_cuda_rng": "torch_cuda_rng.u8"}
+        np.asarray(rs[1], dtype=np.uint32).tofile(os.path.join(d, man["numpy_rng"]["keys"]))
+        torch.get_rng_state().numpy().tofile(os.path.join(d, man["torch_rng"]))
+        torch.cuda.get_rng_state(self.device).numpy().tofile(os.path.join(d, man["torch_cuda_rng"]))
+        if mem is not None and hasattr(mem, "save_stream"):
+            man["memory"] = mem.save_stream(d)
         if hasattr(self, "target_network"):
-            extra["target_network"] = {k: v.cpu() for k, v in self.target_network.state_dict().items()}
-        torch.save(extra, os.path.join(path, "resume.pt"))
+            torch.save({k: v.cpu() for k, v in self.target_network.state_dict().items()}, os.path.join(d, "target_network.pt"))
+            man["target_network"] = "target_network.pt"
+        with open(os.path.join(d, "manifest.json"), "w") as f:
+            json.dump(man, f, indent=1)
 
     def load_full(self, path):
+        """Loads either resume format: `path/resume/manifest.json` (version 2) or round 1's `path/resume.pt` (version 1)."""
+        import json
         import os
 
         self.load(path)
-        extra = torch.load(os.path.join(path, "resume.pt"), map_location="cpu", weights_only=False)
-        for k, v in extra["attrs"].items():
-            setattr(self, k, v)
-        np.random.set_state(extra["numpy_rng"])
-        torch.set_rng_state(extra["torch_rng"])
-        torch.cuda.set_rng_state(extra["torch_cuda_rng"], self.device)
-        if "memory" in extra and hasattr(self.memory, "load_state_dict"):
-            self.memory.load_state_dict(extra["memory"])
-        if "target_network" in extra:
-            self.target_network.load_state_dict(extra["target_network"])
+        d = os.path.join(path, "resume")
+        if os.path.exists(os.path.join(d, "manifest.json")):
+            man = json.load(open(os.path.join(d, "manifest.json")))
+            if man.get("format") != self.RESUME_FORMAT or man.get("version") != 2:
+                raise ValueError(f"unsupported resume manifest: format {man.get('format')!r} version {man.get('version')!r}")
+            for k, v in man["attrs"].items():
+                setattr(self, k, v)
+            r = man["numpy_rng"]
+            np.random.set_state((r["kind"], np.fromfile(os.path.join(d, r["keys"]), dtype=np.uint32), r["pos"], r["has_gauss"], r["cached_gaussian"]))
+            torch.set_rng_state(torch.from_numpy(np.fromfile(os.path.join(d, man["torch_rng"]), dtype=np.uint8)))
+            torch.cuda.set_rng_state(torch.from_numpy(np.fromfile(os.path.join(d, man["torch_cuda_rng"]), dtype=np.uint8)), self.device)
+            if "memory" in man and hasattr(self.memory, "load_stream"):
+                self.memory.load_stream(d, man["memory"])
+            if "target_network" in man:
+                self.target_network.load_state_dict(torch.load(os.path.join(d, man["target_network"]), map_location="cpu", weights_only=False))
+            self._resume_load_extra_attrs(man.get("extra_attrs", {}))
+        else:
+            extra = torch.load(os.path.join(path, "resume.pt"), map_location="cpu", weights_only=False)  # version 1
+            for k, v in extra["attrs"].items():
+                setattr(self, k, v)
+            np.random.set_state(extra["numpy_rng"])
+            torch.set_rng_state(extra["torch_rng"])
+            torch.cuda.set_rng_state(extra["torch_cuda_rng"], self.device)
+            if "memory" in extra and hasattr(self.memory, "load_state_dict"):
+                self.memory.load_state_dict(extra["memory"])
+            if "target_network" in extra:
+                self.target_network.load_state_dict(extra["target_network"])
         if getattr(self, "_net", None) is not None:
             self._import_optim_state()
 

@@ -122,7 +122,25 @@ class PERBuffer(ReplayBuffer):
 
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
+        self._next_prio = None
         self._tree.load(sd["sum_tree"], sd["max_priority"], sd["tree_index"], sd["buffer_counter"])
+
+    def save_stream(self, dirpath):
+        import os
+
+        meta = super().save_stream(dirpath)
+        st = self._tree.state()
+        self._tree.dump().tofile(os.path.join(dirpath, "sum_tree.f64"))
+        meta.update({"sum_tree": "sum_tree.f64", "max_priority": st["max_priority"], "tree_index": st["tree_index"]})
+        return meta
+
+    def load_stream(self, dirpath, meta):
+        import os
+
+        super().load_stream(dirpath, meta)
+        tree = np.fromfile(os.path.join(dirpath, meta["sum_tree"]), dtype=np.float64)
+        self._next_prio = None
+        self._tree.load(tree, meta["max_priority"], meta["tree_index"], meta["buffer_counter"])
 
     # -- state the reference exposes ----------------------------------------------------------------
     @property

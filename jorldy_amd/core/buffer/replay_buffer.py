@@ -232,12 +232,101 @@ class ReplayBuffer(BaseBuffer):
                     cols[key] = sd["columns"][name]
                 else:
                     cols.setdefault(key, []).append(sd["columns"][name])
-            ReplayBuffer.store_soa(self, cols)
+            # restored rows go STRAIGHT into the ring: a deferred store (<= defer_rows rows are held on the host) would
+            # be flushed after set_position below and land behind the restored rows, leaving slots [0, n) unwritten
+            keep, self.defer_rows = self.defer_rows, 0
+            try:
+                ReplayBuffer.store_soa(self, cols)
+            finally:
+                self.defer_rows = keep
+            assert not self._pending
         self.buffer_index = sd["buffer_index"]
         self.buffer_counter = sd["buffer_counter"]
         if self._store is not None:  # ring position of the device store follows the host counters
             import ctypes as C
 
+            self._store.lib.jh_store_clear(self._store.h)
+            self._store.lib.jh_store_set_position(self._store.h, C.c_int64(self.buffer_index), C.c_int64(self.buffer_counter))
+
+    # ---- streamed form (resume format version 2): one raw file per column, written / read in bounded chunks straight
+    # from / into HBM -- no host copy of the whole replay (56 GB of frames at config.rainbow.atari's N = 1e6) -----------
+    _STREAM_CHUNK_BYTES = 64 << 20
+
+    def save_stream(self, dirpath):
+        """Write every stored column to `dirpath`/col_<i>.bin (slot order, stored dtype) and return the JSON-able
+        description load_stream needs."""
+        import os
+
+        import torch
+
+        self.flush()
+        meta = {"buffer_size": self.buffer_size, "buffer_index": self.buffer_index, "buffer_counter": self.buffer_counter,
+                "frame_dedup": bool(self._frames is not None), "layout": None, "columns": []}
+        if self._store is None:
+            return meta
+        meta["layout"] = [[k, sub, name] for k, sub, name in self._layout]
+        n = self.buffer_counter
+        torch.cuda.current_stream().synchronize()
+        for i, (name, dt, elems, shape) in enumerate(self._store.columns):
+            col = self._store.column(name)
+            dec = self._frames is not None and name in self._frames.KEYS  # portable form: full frame stacks
+            row_shape = ((self._frames.C,) + tuple(self._frames.frame_shape)) if dec else tuple(shape)
+            np_dt = np.dtype(np.uint8) if dec else np.dtype(ops._NP_OF[dt])
+            row_bytes = int(np.prod(row_shape)) * np_dt.itemsize
+            rows_per = max(1, self._STREAM_CHUNK_BYTES // row_bytes)
+            fn = f"col_{i}.bin"
+            with open(os.path.join(dirpath, fn), "wb") as f:
+                for o in range(0, n, rows_per):
+                    m = min(rows_per, n - o)
+                    if dec:
+                        fidx = col[o : o + m].contiguous()
+                        full = torch.empty((m,) + row_shape, dtype=torch.uint8, device=self.device)
+                        for q in range(0, m, 4096):
+                            self._frames.decode(fidx[q : q + 4096].contiguous(), full[q : q + 4096], as_float=False)
+                        chunk = full
+                    else:
+                        chunk = col[o : o + m]
+                    f.write(chunk.cpu().numpy().tobytes())
+            meta["columns"].append({"name": name, "dtype": np_dt.str, "shape": list(row_shape), "file": fn, "rows": n})
+        return meta
+
+    def load_stream(self, dirpath, meta):
+        import ctypes as C
+        import os
+
+        assert meta["buffer_size"] == self.buffer_size
+        self._pending, self._pending_rows, self._pend_cols = [], 0, None
+        self._frames = self._layout = self._store = None
+        self.buffer_index = self.buffer_counter = 0
+        n = int(meta["buffer_counter"])
+        if meta["columns"] and n > 0:
+            layout = [tuple(x) for x in meta["layout"]]
+            by_name = {c["name"]: c for c in meta["columns"]}
+            row_bytes = sum(int(np.prod(c["shape"])) * np.dtype(c["dtype"]).itemsize for c in meta["columns"])
+            rows_per = max(1, self._STREAM_CHUNK_BYTES // max(1, row_bytes))
+            files = {name: open(os.path.join(dirpath, c["file"]), "rb") for name, c in by_name.items()}
+            keep, self.defer_rows = self.defer_rows, 0  # straight into the ring, never held on the host
+            try:
+                for o in range(0, n, rows_per):
+                    m = min(rows_per, n - o)
+                    cols = {}
+                    for key, sub, name in layout:
+                        c = by_name[name]
+                        a = np.frombuffer(files[name].read(m * int(np.prod(c["shape"])) * np.dtype(c["dtype"]).itemsize), dtype=np.dtype(c["dtype"]))
+                        a = a.reshape((m,) + tuple(c["shape"]))
+                        if sub is None:
+                            cols[key] = a
+                        else:
+                            cols.setdefault(key, []).append(a)
+                    ReplayBuffer.store_soa(self, cols)
+            finally:
+                self.defer_rows = keep
+                for f in files.values():
+                    f.close()
+            assert not self._pending
+        self.buffer_index = int(meta["buffer_index"])
+        self.buffer_counter = n
+        if self._store is not None:  # ring position of the device store follows the host counters
             self._store.lib.jh_store_clear(self._store.h)
             self._store.lib.jh_store_set_position(self._store.h, C.c_int64(self.buffer_index), C.c_int64(self.buffer_counter))
 

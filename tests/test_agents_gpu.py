@@ -282,10 +282,10 @@ class _MockEnv:
         return np.random.random((1, self.state_size)), np.random.random((1, 1)), done
 
 
-def _interact(env, agent, run_step):
+def _interact(env, agent, run_step, start=0):
     """test/core/agent/utils.py:5-24."""
     state = env.reset()
-    for step in range(1, run_step + 1):
+    for step in range(start + 1, start + run_step + 1):
         action_dict = agent.act(state, training=True)
         assert action_dict["action"].shape == (1, 1) or action_dict["action"].shape[0] == 1
         next_state, reward, done = env.step(action_dict["action"])
@@ -586,35 +586,73 @@ def test_ppo_native_data_parallel_path_single_rank_rccl():
         dist.destroy_process_group()
 
 
-def test_full_checkpoint_resumes_per_agent_bit_identically(tmp_path):
-    """save_full/load_full: buffer rows, sum tree, counters, beta/epsilon and RNG state survive, so a
-    resumed agent continues EXACTLY like the uninterrupted one (the reference restarts from an empty
-    buffer)."""
+@pytest.mark.parametrize("version", [1, 2])
+@pytest.mark.parametrize("name,steps", [("per", 50), ("per", 12), ("dqn", 50), ("dqn", 12)])
+def test_full_checkpoint_resumes_bit_identically(tmp_path, name, steps, version):
+    """save_full/load_full: buffer rows, sum tree, counters, beta/epsilon and RNG state survive, so a resumed agent
+    continues EXACTLY like the uninterrupted one (the reference restarts from an empty buffer).
+    version 2 = manifest + raw column files streamed from HBM, version 1 = round 1's resume.pt pickle (must stay
+    loadable); 50 steps wrap the 32-slot ring, 12 steps leave fewer rows than the agents' deferred-store threshold
+    (a restore through the deferred path would append them BEHIND the restored ring position)."""
+    import json
+
     from jorldy_amd.core.agent import Agent
 
     S, A = 6, 3
-    mk = lambda: Agent("per", state_size=S, action_size=A, hidden_size=16, batch_size=8, start_train_step=5, buffer_size=32, run_step=200, learn_period=2, device="cuda",
+    mk = lambda: Agent(name, state_size=S, action_size=A, hidden_size=16, batch_size=8, start_train_step=5, buffer_size=32, run_step=200, learn_period=2, device="cuda",
                        use_graph=False)  # replayed-graph GEMMs may pick another hipBLASLt algorithm than the eager first call: last-bit differences
     np.random.seed(5)
     torch.manual_seed(5)
     a1 = mk()
     a1.memory.first_store = False
-    _interact(_MockEnv(S, A), a1, 50)  # wraps the 32-slot ring
-    a1.save_full(str(tmp_path))
+    assert a1.memory.defer_rows >= 12
+    _interact(_MockEnv(S, A), a1, steps)
+    a1.save_full(str(tmp_path), version=version)
+    if version == 2:
+        man = json.load(open(tmp_path / "resume" / "manifest.json"))
+        assert man["format"] == "jorldy_amd.resume" and man["version"] == 2 and man["memory"]["buffer_counter"] == a1.memory.size
+        assert all((tmp_path / "resume" / c["file"]).stat().st_size == c["rows"] * int(np.prod(c["shape"])) * np.dtype(c["dtype"]).itemsize for c in man["memory"]["columns"])
+        assert not (tmp_path / "resume.pt").exists()
+    else:
+        assert (tmp_path / "resume.pt").exists()
     a2 = mk()
     a2.memory.first_store = False
     a2.load_full(str(tmp_path))
     assert a2.memory.size == a1.memory.size and a2.memory.buffer_index == a1.memory.buffer_index and a2.time_t == a1.time_t
-    np.testing.assert_array_equal(a2.memory.sum_tree, a1.memory.sum_tree)
-    assert a2.memory.max_priority == a1.memory.max_priority and a2.beta == a1.beta and a2.epsilon == a1.epsilon
-    r = []
-    for ag in (a1, a2):
+    assert not a2.memory._pending
+    for k in a1.memory._store.names:  # every stored row, slot by slot
+        assert torch.equal(a1.memory._store.column(k)[: a1.memory.size], a2.memory._store.column(k)[: a2.memory.size]), k
+    per = name == "per"
+    if per:
+        np.testing.assert_array_equal(a2.memory.sum_tree, a1.memory.sum_tree)
+        assert a2.memory.max_priority == a1.memory.max_priority and a2.beta == a1.beta
+    assert a2.epsilon == a1.epsilon
+    env1, env2 = _MockEnv(S, A), _MockEnv(S, A)
+    for ag, env in ((a1, env1), (a2, env2)):  # more stores + learns after the resume: same ring slots, same samples
         np.random.seed(99)
-        r.append(ag.learn())
-    assert r[0] == r[1]
+        torch.manual_seed(99)
+        _interact(env, ag, 6, start=steps)
     for (k, v1), (_, v2) in zip(a1.network.state_dict().items(), a2.network.state_dict().items()):
         torch.testing.assert_close(v1, v2, rtol=0, atol=0)
-    np.testing.assert_array_equal(a2.memory.sum_tree, a1.memory.sum_tree)
+    for k in a1.memory._store.names:
+        assert torch.equal(a1.memory._store.column(k)[: a1.memory.size], a2.memory._store.column(k)[: a2.memory.size]), k
+    if per:
+        np.testing.assert_array_equal(a2.memory.sum_tree, a1.memory.sum_tree)
+
+
+def test_resume_manifest_rejects_unknown_version(tmp_path):
+    import json
+
+    from jorldy_amd.core.agent import Agent
+
+    a = Agent("dqn", state_size=4, action_size=2, hidden_size=16, batch_size=4, buffer_size=16, device="cuda")
+    a.save_full(str(tmp_path))
+    mp = tmp_path / "resume" / "manifest.json"
+    man = json.load(open(mp))
+    man["version"] = 3
+    json.dump(man, open(mp, "w"))
+    with pytest.raises(ValueError, match="unsupported resume manifest"):
+        a.load_full(str(tmp_path))
 
 
 @pytest.mark.parametrize("name,extra", [("dqn", {}), ("per", dict(learn_period=1)), ("ape_x", dict(n_step=3, num_workers=4, learn_period=1)),
