@@ -22,6 +22,7 @@ class PERBuffer(ReplayBuffer):
         self.uniform_sample_prob = uniform_sample_prob
         self._tree = ops.SumTree(self.buffer_size, uniform_sample_prob, device=self.device)
         self._next_prio = None
+        self._shards = None  # (dist, group) when this buffer is one shard of a data-parallel logical buffer
 
     # -- store ------------------------------------------------------------------------------------
     def store_soa(self, cols, priorities=None):
@@ -91,6 +92,19 @@ class PERBuffer(ReplayBuffer):
         u = np.random.uniform(size=batch_size - n_uni)
         return uni, u
 
+    def attach_shards(self, dist, group=None):
+        """Data-parallel learners (jorldy_amd.parallel.attach_data_parallel): this rank's buffer becomes one shard of
+        a logical buffer of world_size x buffer_size slots; sampling stays local, the IS weights are normalised over
+        the global batch against the global root / count (parallel.sharded_is_weights)."""
+        self._shards = (dist, group)
+
+    def _global_weights(self, beta, idx, w_out, stats):
+        from ...parallel import sharded_is_weights
+
+        dist, group = self._shards
+        w = sharded_is_weights(self._tree.view()[idx], stats[2], float(self.buffer_counter), self.uniform_sample_prob, beta, dist, group)
+        w_out.copy_(w.to(w_out.dtype))
+
     def sample_into(self, beta, batch_size, idx_out, w_out):
         """Host RNG draws (reference order) + descent / IS weights into PREALLOCATED idx / weight tensors;
         the gather is left to the caller (captured-graph learners).  Returns the stats tensor
@@ -99,6 +113,8 @@ class PERBuffer(ReplayBuffer):
         self.flush()
         uni, u = self.draw(batch_size)
         _, _, _, stats = self._tree.sample(beta, uni, u, want_w64=False, out_idx=idx_out, out_w32=w_out)
+        if self._shards is not None:
+            self._global_weights(beta, idx_out, w_out, stats)
         return stats
 
     def sample(self, beta, batch_size, as_float=True):
@@ -109,6 +125,8 @@ class PERBuffer(ReplayBuffer):
         self.flush()
         uni, u = self.draw(batch_size)
         idx, w64, w32, stats = self._tree.sample(beta, uni, u, want_w64=False)
+        if self._shards is not None:
+            self._global_weights(beta, idx, w32, stats)
         transitions = self.gather(idx, idx_offset=self.first_leaf_index, as_float=as_float)
         stats = stats.clone()
         return transitions, w32, idx, stats[0], stats[1]

@@ -274,6 +274,10 @@ class SumTree:
         L.check(self.lib.jh_per_sample(self.h, B, float(beta), int(uniform_slot.size), L.ptr(uniform_slot), L.ptr(u), L.ptr(idx), L.ptr(w64), L.ptr(w32), L.ptr(self._stats), L.stream_ptr()))
         return idx, w64, w32, self._stats
 
+    def view(self):
+        """Zero-copy float64 [2N-1] torch view of the device tree (the library owns the memory)."""
+        return _wrap_device(self.lib.jh_per_tree_ptr(self.h), (self.tree_size,), torch.float64, self.device, owner=self)
+
     def state(self):
         mp, root, ti, cnt = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
         L.check(self.lib.jh_per_state(self.h, C.byref(mp), C.byref(root), C.byref(ti), C.byref(cnt), L.stream_ptr()))

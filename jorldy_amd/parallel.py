@@ -65,11 +65,41 @@ class BucketSync:
             self.dist.broadcast(b, src=src, group=self.group)
 
 
+def sharded_is_weights(p_sampled, root, count, usp, beta, dist=None, group=None):
+    """Importance-sampling weights of per_buffer.py:88-94 for ONE logical PER buffer whose slots are sharded over the
+    data-parallel ranks (every rank owns a shard with its own sum tree and samples its part of the global batch from
+    it -- SURVEY.md §8e):
+
+        P_i = (1 - usp) p_i / ROOT + usp / COUNT        ROOT = sum_g root_g      COUNT = sum_g count_g
+        w_i = ((1 / COUNT) / P_i)^beta / max_j w_j      max over the GLOBAL batch (all ranks' samples)
+
+    w is decreasing in p, so max_j w_j belongs to the smallest sampled priority of the global batch: one all-gather
+    of three float64 per rank {root_g, count_g, min sampled p_g} is the only collective.  The result equals the
+    weights of a single tree holding all shards for the same index lists.  Works on CPU (gloo) and device tensors;
+    dist=None: a single shard (then identical to the local normalisation)."""
+    p = p_sampled.reshape(-1).to(torch.float64)
+    loc = torch.stack([torch.as_tensor(root, dtype=torch.float64, device=p.device).reshape(()),
+                       torch.as_tensor(count, dtype=torch.float64, device=p.device).reshape(()), p.min()])
+    if dist is not None and dist.get_world_size(group) > 1:
+        parts = [torch.empty_like(loc) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, loc, group=group)
+        allv = torch.stack(parts)
+    else:
+        allv = loc.unsqueeze(0)
+    root_t, count_t, min_p = allv[:, 0].sum(), allv[:, 1].sum(), allv[:, 2].min()
+    uni = 1.0 / count_t
+    prob = lambda q: (1.0 - usp) * (q / root_t) + usp * uni  # operation order of per_buffer.py:90-92
+    w = (uni / prob(p)) ** beta
+    w_max = (uni / prob(min_p)) ** beta
+    return w / w_max
+
+
 def attach_data_parallel(agent, dist, group=None):
     """One learner per GPU (north star: Ape-X's many-actor / one-learner re-expressed as DP learners):
     every rank keeps its own actors and its own replay shard / sum tree (no data-path collective), samples
     its own minibatch of `batch_size`, and the gradients are averaged before the optimizer step so all
-    ranks hold identical weights.  Works for PPO (native or torch), the torch-encoder DQN family and the
+    ranks hold identical weights.  PER: the IS weights are those of the single logical buffer (sharded_is_weights:
+    one all-gather of {root, count, min sampled p} per learn()).  Works for PPO (native or torch), the torch-encoder DQN family and the
     native Rainbow network.  Returns the hook (also stored as agent.grad_sync)."""
     net = getattr(agent, "_net", None)
     if net is not None and hasattr(net, "target"):  # ops.RainbowNet
@@ -80,6 +110,9 @@ def attach_data_parallel(agent, dist, group=None):
         if hasattr(agent, "target_network"):
             for p in agent.target_network.parameters():
                 dist.broadcast(p.data, src=0, group=group)
+    mem = getattr(agent, "memory", None)
+    if mem is not None and hasattr(mem, "attach_shards"):  # PER: this rank's buffer is one shard of the logical buffer
+        mem.attach_shards(dist, group)
     agent.grad_sync = sync
     agent._graph = None
     return sync

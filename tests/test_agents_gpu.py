@@ -752,12 +752,15 @@ def test_rainbow_native_data_parallel_hook_single_rank_rccl():
             _fill_from_fixture(agent, z, True)
             if dp:
                 attach_data_parallel(agent, dist)
-                assert agent.grad_sync is not None
+                assert agent.grad_sync is not None and agent.memory._shards is not None  # PER shard: global IS-weight normalisation
             np.random.seed(3)
             torch.manual_seed(4)
             losses = [agent.learn()["loss"] for _ in range(4)]
             res.append((losses, agent._net.params.clone()))
-        assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+        # one shard = the whole logical buffer: the sharded weights (float64 torch ops + all-gather) must equal the
+        # sum-tree kernel's local normalisation up to the last bit of pow()
+        np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=0, atol=1e-6)
     finally:
         dist.destroy_process_group()
 
@@ -967,6 +970,19 @@ def test_frame_dedup_replay_is_invisible_and_stores_one_frame_per_step():
     for k in a["columns"]:
         np.testing.assert_array_equal(a["columns"][k], c["columns"][k], err_msg=k)
     np.testing.assert_array_equal(dd2.sum_tree, plain.sum_tree)
+    # the streamed form (resume format version 2): de-duplicated -> files of full stacks -> plain AND de-duplicating buffers
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        meta = dd.save_stream(d)
+        assert meta["frame_dedup"] and all(c["rows"] == dd.size for c in meta["columns"])
+        for tgt in (PERBuffer(64, 0.05, device="cuda"), PERBuffer(64, 0.05, device="cuda", frame_dedup=True)):
+            tgt.load_stream(d, meta)
+            e = tgt.state_dict()
+            for k in a["columns"]:
+                np.testing.assert_array_equal(a["columns"][k], e["columns"][k], err_msg=k)
+            np.testing.assert_array_equal(tgt.sum_tree, plain.sum_tree)
+            assert tgt.buffer_index == plain.buffer_index and tgt.size == plain.size
 
 
 def test_rainbow_native_learns_identically_from_a_deduplicated_replay():
