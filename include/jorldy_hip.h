@@ -214,6 +214,17 @@ int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t n_step, in
                 float gamma, float alpha, float* d_grad_logit, float* d_prio, float* d_kl, float* d_stats,
                 jh_stream stream);
 
+/* Batched acting of the value-net agents: DQN.act / ApeX.act / C51.act / Rainbow.act (core/agent/dqn.py:76-92,
+ * ape_x.py:64-77, c51.py:50-66, rainbow.py:140-152) for N actors in one call.  d_logits [N][A][K] are the network's
+ * outputs (K = 1: Q values; K > 1: atom logits, Q = expectation under softmax over the support linspace(v_min,
+ * v_max, K), rainbow.py:285-292).  Epsilon-greedy per actor with the HOST's draws (h_eps float32[N], h_u float64[N]
+ * = np.random.random(), h_rand_action int64[N] = np.random.randint(A); all three NULL: greedy).  Outputs (device):
+ * d_action int64[N] (first maximum, like torch.argmax), d_q_taken float32[N] (Q of the action taken; NULL ok),
+ * d_q_all float32[N][A] (NULL ok).                                                                                */
+int jh_value_act(jh_ctx* ctx, int32_t N, int32_t A, int32_t K, const float* d_logits, float v_min, float v_max,
+                 const float* h_eps, const double* h_u, const int64_t* h_rand_action, int64_t* d_action,
+                 float* d_q_taken, float* d_q_all, jh_stream stream);
+
 /* ------------------------------------------------------------------ native policy-value MLP
  * The encoder of the PPO configs (core/network/head.py:6-18 MLP head + policy_value.py:8-57):
  * S -> H relu -> H relu -> {A logits | A mu, A log_std} + value, as hand-written kernels

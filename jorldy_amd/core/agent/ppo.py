@@ -310,7 +310,7 @@ class PPO(BaseAgent):
             try:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (batched actors, staging ring) keep issuing HIP work on their own streams
                     self._enqueue_learn(st)
                 self._graph = g  # capture does not execute: replay below runs this iteration's update
             except Exception as e:  # e.g. a collective that cannot be captured: stay eager from now on

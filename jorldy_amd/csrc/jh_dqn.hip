@@ -528,3 +528,76 @@ JH_EXPORT int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t 
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
+
+// ============================================================================ batched acting of the value-net agents
+// DQN.act / ApeX.act / C51.act / Rainbow.act (dqn.py:76-92, ape_x.py:64-77, c51.py:50-66, rainbow.py:140-152) for N
+// actors in ONE call: Q(s) from the network's outputs (K = 1: the outputs are Q; K > 1: expectation of the atoms under
+// softmax, rainbow.py:285-292), per-actor epsilon-greedy with the HOST's random draws (the reference draws
+// `np.random.random() < epsilon` and `np.random.randint` per act() call: passing them in keeps that RNG stream),
+// first maximum like torch.argmax, and Q of the action taken (Ape-X's actor-side priority needs it).
+// One wave per actor row: lanes over the atoms (K > 1) / one lane (K = 1).
+__global__ void __launch_bounds__(256) jh_value_act_kernel(int N, int A, int K, const float* __restrict__ logits, float v_min, float dz,
+                                                           const float* __restrict__ eps, const double* __restrict__ u,
+                                                           const int64_t* __restrict__ rand_action, int64_t* __restrict__ action,
+                                                           float* __restrict__ q_taken, float* __restrict__ q_all) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float best = -3.4e38f, q_rand = 0.f;
+  int best_a = 0;
+  const int ra = rand_action ? (int)rand_action[row] : 0;
+  for (int a = 0; a < A; ++a) {
+    float q;
+    const float* z = logits + ((size_t)row * A + a) * K;
+    if (K == 1) {
+      q = z[0];
+    } else {
+      float m = -3.4e38f;
+      for (int k = lane; k < K; k += 64) m = fmaxf(m, z[k]);
+      m = jh_wave_max(m);
+      float se = 0.f, sz = 0.f;
+      for (int k = lane; k < K; k += 64) {
+        const float e = expf(z[k] - m);
+        se += e;
+        sz += e * (v_min + dz * (float)k);
+      }
+      q = jh_wave_sum(sz) / jh_wave_sum(se);
+    }
+    if (q_all && lane == 0) q_all[(size_t)row * A + a] = q;
+    if (q > best) { best = q; best_a = a; }
+    if (a == ra) q_rand = q;
+  }
+  if (lane == 0) {
+    const bool explore = eps && u && u[row] < (double)eps[row];
+    action[row] = explore ? ra : best_a;
+    if (q_taken) q_taken[row] = explore ? q_rand : best;
+  }
+}
+
+JH_EXPORT int jh_value_act(jh_ctx* ctx, int32_t N, int32_t A, int32_t K, const float* d_logits, float v_min, float v_max,
+                           const float* h_eps, const double* h_u, const int64_t* h_rand_action, int64_t* d_action,
+                           float* d_q_taken, float* d_q_all, jh_stream stream) {
+  JH_ARG(ctx && d_logits && d_action);
+  JH_ARG(N > 0 && A > 0 && K > 0);
+  JH_ARG((h_eps == nullptr) == (h_u == nullptr) && (h_eps == nullptr) == (h_rand_action == nullptr));
+  hipStream_t st = jh_s(stream);
+  const float* d_eps = nullptr;
+  const double* d_u = nullptr;
+  const int64_t* d_ra = nullptr;
+  jh_pinned_slab* slab = nullptr;
+  if (h_eps) {  // the draws ride in a pinned, device-mapped slab the kernel reads in place
+    const size_t o_u = ((sizeof(float) * (size_t)N + 255) & ~(size_t)255), o_r = o_u + ((sizeof(double) * (size_t)N + 255) & ~(size_t)255);
+    int rc = jh_ctx_slab(ctx, o_r + sizeof(int64_t) * (size_t)N + 256, &slab);
+    if (rc) return rc;
+    memcpy(slab->host, h_eps, sizeof(float) * (size_t)N);
+    memcpy((char*)slab->host + o_u, h_u, sizeof(double) * (size_t)N);
+    memcpy((char*)slab->host + o_r, h_rand_action, sizeof(int64_t) * (size_t)N);
+    d_eps = (const float*)slab->dev;
+    d_u = (const double*)((char*)slab->dev + o_u);
+    d_ra = (const int64_t*)((char*)slab->dev + o_r);
+  }
+  const float dz = K > 1 ? (v_max - v_min) / (float)(K - 1) : 0.f;
+  JH_LAUNCH(jh_value_act_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, A, K, d_logits, v_min, dz, d_eps, d_u, d_ra, d_action, d_q_taken, d_q_all);
+  JH_LAUNCH_CHECK();
+  return slab ? jh_ctx_slab_release(ctx, slab, st) : JH_OK;
+}

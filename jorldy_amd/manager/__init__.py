@@ -1,3 +1,4 @@
+from .batched_actors import BatchedValueActors, VecNStepApeX
 from .collector import NativeCollector, VecCollector
 
-__all__ = ["VecCollector", "NativeCollector"]
+__all__ = ["VecCollector", "NativeCollector", "BatchedValueActors", "VecNStepApeX"]

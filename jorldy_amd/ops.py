@@ -491,6 +491,23 @@ class PPONet:
         return (act, logits, val) if want_logits else act
 
 
+def value_act(logits, v_min=0.0, v_max=0.0, eps=None, u=None, rand_action=None, out=None, want_q_all=False):
+    """jh_value_act: network outputs [N, A, K] (K = 1: Q values) -> (action int64 [N], q_taken float32 [N], q_all | None)
+    on the device.  eps / u / rand_action: numpy float32 / float64 / int64 [N] (the host's epsilon-greedy draws) or
+    all None for greedy."""
+    lg = _f32(logits)
+    N, A, K = (int(v) for v in lg.shape)
+    dev = lg.device
+    act, q = (torch.empty(N, dtype=torch.int64, device=dev), torch.empty(N, dtype=torch.float32, device=dev)) if out is None else out
+    q_all = torch.empty(N, A, dtype=torch.float32, device=dev) if want_q_all else None
+    if eps is not None:
+        eps, u, rand_action = (np.ascontiguousarray(eps, dtype=np.float32), np.ascontiguousarray(u, dtype=np.float64), np.ascontiguousarray(rand_action, dtype=np.int64))
+        assert eps.size == N and u.size == N and rand_action.size == N
+    L.check(L.load().jh_value_act(L.ctx(_dev(lg)), N, A, K, L.ptr(lg), float(v_min), float(v_max), L.ptr(eps), L.ptr(u), L.ptr(rand_action), L.ptr(act), L.ptr(q),
+                                  L.ptr(q_all), L.stream_ptr()))
+    return act, q, q_all
+
+
 # ============================================================================= TD / C51
 def td_loss(q, q_next_target, action, reward, done, gamma, q_next_online=None, weights=None, alpha=0.0, n_step=0, stats=None):
     """Returns (grad_q [B,A], prio [B], stats f32[4] = {loss, max_Q, mean_td, 0})."""

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--actors", type=int, default=0, help="N > 0: N host actor threads publish chunks into the staging ring while the learner runs")
     ap.add_argument("--actor-hz", type=float, default=0.0, help="env steps/s per actor (0: as fast as the ring takes them = ingestion capacity)")
+    ap.add_argument("--e2e", type=int, default=0, help="N > 0: END-TO-END async Ape-X with N actors that really ACT: one batched forward per tick on the GPU "
+                                                       "(BatchedValueActors), synthetic Atari-shaped envs, vectorised n-step assembly with actor-side priorities, staging ring, learner")
+    ap.add_argument("--sync-period", type=int, default=100, help="--e2e: actor ticks between weight syncs (config.ape_x.atari update_period)")
     args = ap.parse_args()
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
@@ -89,15 +92,84 @@ def main():
             agent.learn_period_stamp = agent.learn_period  # one learn() per learner iteration, like the sync loop below
             return agent.process(None, step)
 
+    e2e_stats = None
+    if args.e2e > 0:
+        # configs[3] end to end (run_mode.py:212-363 + process.py:7-31,82-97 + distributed_manager.py:33-51 re-expressed):
+        #   actor thread  N synthetic Atari-shaped envs stepped in lockstep; per tick ONE batched forward on the GPU for all
+        #                 of them (own stream, acting copy of the network, synced every --sync-period ticks), n-step
+        #                 windows + actor-side priorities assembled for all N at once, N transitions into the staging ring
+        #   learner       (this thread) drain the ring into the device store + sum tree, one ApeX.learn() per iteration
+        import threading
+
+        from jorldy_amd.manager import BatchedValueActors, VecNStepApeX
+
+        NA = args.e2e
+        ring = agent.memory.make_ring(max(16, 64 * 100 // NA) * NA, with_priority=True)
+        actors = BatchedValueActors(agent, NA)
+        nstep = VecNStepApeX(NA, n, 0.99, (4, 84, 84), np.uint8)
+        frames = rng.randint(0, 256, size=(257, 84, 84), dtype=np.uint8)  # frame pool of the synthetic envs
+        stop = threading.Event()
+        counters = {"ticks": 0, "t_act": 0.0, "t_host": 0.0}
+
+        def actor_loop():
+            torch.cuda.set_device(agent.device)
+            arng = np.random.RandomState(7)
+            obs = actors.obs_slab
+            pos = arng.randint(0, 257, size=NA)
+            for c in range(4):
+                obs[:, c] = frames[(pos + c) % 257]
+            while not stop.is_set():
+                t0 = time.perf_counter()
+                out = actors.act(None, training=True)
+                t1 = time.perf_counter()
+                # env.step for all actors: reward / done draws of SURVEY.md §8d C4, next frame stack = shift in one new frame
+                reward = arng.choice([-1.0, 0.0, 1.0], p=[0.02, 0.9, 0.08], size=(NA, 1)).astype(np.float32)
+                done = (arng.rand(NA, 1) < 1e-3).astype(np.float32)
+                emitted = nstep.push(obs, out["action"], reward, done, out["q"])
+                pos = (pos + 1) % 257
+                obs[:, :3] = obs[:, 1:]
+                obs[:, 3] = frames[(pos + 3) % 257]
+                if emitted is not None:
+                    cols, prio = emitted
+                    try:
+                        ring.produce(agent.memory.ring_columns(cols), prio + 1e-3, timeout_ms=500)
+                    except Exception:
+                        pass  # ring full: the learner is behind; drop this tick's transitions like a full queue would
+                counters["ticks"] += 1
+                if counters["ticks"] % args.sync_period == 0:
+                    actors.sync()
+                counters["t_act"] += t1 - t0
+                counters["t_host"] += time.perf_counter() - t1
+
+        th = threading.Thread(target=actor_loop, daemon=True)
+        th.start()
+        step = 0
+
+        def iteration():
+            nonlocal step
+            step += 1
+            agent.learn_period_stamp = agent.learn_period
+            return agent.process(None, step)
+
     for _ in range(args.warmup):
         iteration()
     torch.cuda.synchronize()
+    if args.e2e > 0:
+        tick0, tact0, thost0 = counters["ticks"], counters["t_act"], counters["t_host"]
     n0 = agent.num_transitions
     t0 = time.perf_counter()
     for _ in range(args.updates):
         r = iteration()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.e2e > 0:
+        ticks = counters["ticks"] - tick0
+        e2e_stats = {"actors": args.e2e, "actor_ticks_per_s": ticks / dt, "env_steps_per_s": ticks * args.e2e / dt,
+                     "act_ms_per_tick": (counters["t_act"] - tact0) / max(1, ticks) * 1e3, "host_ms_per_tick": (counters["t_host"] - thost0) / max(1, ticks) * 1e3,
+                     "ingested_transitions_per_s": (agent.num_transitions - n0) / dt, "weight_sync_every_ticks": args.sync_period, **ring.stats()}
+        stop.set()
+        th.join(timeout=10)
+        iteration = lambda: agent.learn()
     if args.actors > 0:
         stop.set()
         for t in threads:
@@ -130,8 +202,9 @@ def main():
                     f"PER N={N} ({filled} filled), backend {args.backend}",
         "learner_updates_per_s": args.updates / dt,
         "sampled_transitions_per_s": B * args.updates / dt,
-        "ingested_transitions_per_s": async_stats["ingested_transitions_per_s"] if async_stats else chunk_rows * args.updates / dt,
+        "ingested_transitions_per_s": (async_stats or e2e_stats)["ingested_transitions_per_s"] if (async_stats or e2e_stats) else chunk_rows * args.updates / dt,
         "async": async_stats,
+        "end_to_end": e2e_stats,
         "ms_per_iteration_incl_ingest": dt / args.updates * 1e3,
         "ms_per_learn_only": dt_learn * 1e3,
         "learn_in_hipgraph": graphed,
