@@ -276,6 +276,10 @@ int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_
  * ordinary HOST pointers; BLOCKING: returns when the actions are available.                     */
 int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs, int64_t* h_action, float* h_logits_out,
                            float* h_value_out, int32_t training, jh_stream stream);
+/* The continuous policy (ppo.py:55-63): h_action [W][A] = tanh(Normal(clamp(mu_raw, -5, 5), exp(tanh(log_std_raw)))
+ * .sample()), tanh(mu) when training == 0; h_mu_raw_out / h_log_std_raw_out [W][A] optional.                      */
+int jh_pponet_act_continuous(jh_pponet* n, int32_t W, const float* h_obs, float* h_action, float* h_mu_raw_out,
+                             float* h_log_std_raw_out, int32_t training, jh_stream stream);
 
 /* ------------------------------------------------------------------ vectorised host collector
  * Synthetic CartPole-v1 (gym is not installable in the build image): W envs stepped in one
@@ -287,6 +291,16 @@ int jh_cartpole_obs(const jh_cartpole* e, float* h_obs /* [W][4] */);
 int jh_cartpole_step(jh_cartpole* e, const int64_t* h_action /* [W] */, float* h_next_obs /* [W][4] */,
                      float* h_reward /* [W] */, uint8_t* h_done /* [W] */);
 
+/* Synthetic continuous-control env at config.ppo.mujoco shapes (MuJoCo is not installable in the build image; Hopper-v3
+ * is S = 11, A = 3, actions in [-1, 1]): deterministic float64 dynamics (csrc/jh_env.hip), float32 observations,
+ * auto-reset like Actor.run (manager/distributed_manager.py:91); mirrored bit for bit by oracle ControlOracle.  */
+typedef struct jh_control jh_control;
+int jh_control_create(int32_t W, int32_t S, int32_t A, uint64_t seed, jh_control** out);
+void jh_control_destroy(jh_control* e);
+int jh_control_obs(const jh_control* e, float* h_obs /* [W][S] */);
+int jh_control_step(jh_control* e, const float* h_action /* [W][A] */, float* h_next_obs /* [W][S] */,
+                    float* h_reward /* [W] */, uint8_t* h_done /* [W] */);
+
 /* ------------------------------------------------------------------ native sync collector
  * DistributedManager.run + Actor.run (manager/distributed_manager.py:26-31,76-92) for every worker
  * and T steps in one call: batched on-GPU acting through device-mapped pinned memory, host env
@@ -296,6 +310,10 @@ int jh_cartpole_step(jh_cartpole* e, const int64_t* h_action /* [W] */, float* h
 typedef struct jh_collector jh_collector;
 int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store, const int32_t* cols,
                         jh_collector** out);
+/* The same for a CONTINUOUS policy (PPO.act, ppo.py:55-63: tanh(Normal(mu, std).sample())) on jh_control: the
+ * persistent acting kernel returns mu / log_std partials, the host samples; action column f32[A], state f32[S].   */
+int jh_collector_create_control(jh_ctx* ctx, jh_pponet* net, jh_control* env, jh_store* store, const int32_t* cols,
+                                jh_collector** out);
 void jh_collector_destroy(jh_collector* c);
 int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream);
 /* Host-side timing of the collection loop (microseconds per timestep): launching + waiting for the

@@ -84,6 +84,12 @@ _PROTOS = {
     "jh_pponet_adam_step": (C.c_int, [_vp, _f32, _vp, _vp]),
     "jh_pponet_ppo_update": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "jh_pponet_act_discrete": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "jh_pponet_act_continuous": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "jh_control_create": (C.c_int, [_i32, _i32, _i32, C.c_uint64, _pp]),
+    "jh_control_destroy": (None, [_vp]),
+    "jh_control_obs": (C.c_int, [_vp, _vp]),
+    "jh_control_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "jh_collector_create_control": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
     "jh_collector_create": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
     "jh_collector_destroy": (None, [_vp]),
     "jh_rbnet_param_count_for": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),

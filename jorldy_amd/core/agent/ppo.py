@@ -130,9 +130,10 @@ class PPO(BaseAgent):
     # ---------------------------------------------------------------------------------- act
     @torch.no_grad()
     def act(self, state, training=True):
-        if self._net is not None and self.action_type == "discrete" and not isinstance(state, list):
+        if self._net is not None and not isinstance(state, list):
             self._grow_native(len(state))
-            return {"action": self._net.act_discrete(np.asarray(state, dtype=np.float32), training)}
+            obs = np.asarray(state, dtype=np.float32)
+            return {"action": self._net.act_discrete(obs, training) if self.action_type == "discrete" else self._net.act_continuous(obs, training)}
         self.network.train(training)
         if self.action_type == "continuous":
             mu, std, _ = self.network(self.as_tensor(state))

@@ -1,6 +1,7 @@
 // Shared internals of libjorldy_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -119,6 +120,14 @@ struct jh_cartpole {
   std::vector<uint64_t> rng;
 };
 
+// synthetic continuous-control env (jh_env.hip): stands in for MuJoCo Hopper at config.ppo.mujoco shapes
+struct jh_control {
+  int W = 0, S = 0, A = 0;
+  std::vector<double> s;  // [W][S]
+  std::vector<int64_t> t;
+  std::vector<uint64_t> rng;
+};
+
 void jh_cartpole_obs_rows(const jh_cartpole* e, int r0, int r1, float* h_obs);
 void jh_cartpole_step_rows(jh_cartpole* e, int r0, int r1, const int64_t* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done);
 
@@ -149,6 +158,54 @@ struct jh_pponet {
   unsigned* tg_cnt = nullptr;
   int tg_cnt_slots = 0;
 };
+
+// ---------------------------------------------------------------- host-side action sampling (PPO.act, ppo.py:55-69)
+// Counter-based splitmix64 streams keyed by (net seed, timestep counter, env row[, dim]): the same actions
+// whichever acting path (persistent kernel / one launch per step) produced the raw heads.
+static inline uint64_t jh_mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static inline double jh_u01_of(uint64_t key) { return (double)(jh_mix64(key) >> 11) * (1.0 / 9007199254740992.0); }
+
+// Categorical(softmax(z)).sample() by inverse CDF (torch.multinomial(pi, 1)); argmax when !training
+static inline int64_t jh_sample_discrete(const jh_pponet* n, const float* z, int wq, int training) {
+  const int A = n->A;
+  int act = 0;
+  float mx = z[0];
+  for (int k = 1; k < A; ++k)
+    if (z[k] > mx) { mx = z[k]; act = k; }
+  if (!training) return act;
+  float e[16], se = 0.f;
+  for (int k = 0; k < A; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
+  const float u = (float)jh_u01_of(n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq) * se;
+  float c = 0.f;
+  act = A - 1;
+  for (int k = 0; k < A; ++k) {
+    c += e[k];
+    if (u < c) { act = k; break; }
+  }
+  return act;
+}
+
+// z = (mu_raw[A], log_std_raw[A]): mu = clamp(mu_raw, -5, 5), std = exp(tanh(log_std_raw)) (policy_value.py:54-56);
+// action = tanh(Normal(mu, std).sample()) when training (Box-Muller on two counter-based uniforms), tanh(mu) otherwise
+static inline void jh_sample_continuous(const jh_pponet* n, const float* z, int wq, int training, float* action) {
+  const int A = n->A;
+  for (int k = 0; k < A; ++k) {
+    const float mu = fminf(fmaxf(z[k], -5.f), 5.f);
+    float v = mu;
+    if (training) {
+      const float sd = expf(tanhf(z[A + k]));
+      const uint64_t key = n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq * 64u + (uint64_t)k;
+      const double u1 = 1.0 - jh_u01_of(key * 2 + 1), u2 = jh_u01_of(key * 2 + 2);  // u1 in (0, 1]
+      v = mu + sd * (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+    }
+    action[k] = tanhf(v);
+  }
+}
 
 // ---------------------------------------------------------------- device helpers (wave = 64)
 #ifdef __HIPCC__

@@ -88,3 +88,66 @@ void jh_cartpole_step_rows(jh_cartpole* e, int r0, int r1, const int64_t* h_acti
     if (d) reset_env(e, w);          // distributed_manager.py:91
   }
 }
+
+// ------------------------------------------------------------------------------ synthetic continuous control
+// MuJoCo is not installable in the build image; config.ppo.mujoco (Hopper-v3: S = 11, A = 3, continuous actions in
+// [-1, 1]) gets a deterministic stand-in of the same shapes so that the native collector has an environment to
+// drive: float64 dynamics
+//     s'_i = 0.95 s_i + 0.05 sum_j P[i][j] a_j + 0.02 sin(s_{(i+1) mod S}),   P[i][j] = 0.5 sin(1.7 (i+1) + 2.3 (j+1))
+//     reward = s'_0 + 0.1 - 0.001 |a|^2,   done when |s'_0| > 2 or after 1000 steps,   reset U(-0.05, 0.05)^S
+// float32 observations, auto-reset like Actor.run (manager/distributed_manager.py:91).  The CPU oracle
+// (oracle/jorldy_oracle.py: ControlOracle) reproduces every trajectory bit for bit.
+namespace {
+inline void reset_control(jh_control* e, int w) {
+  for (int k = 0; k < e->S; ++k) e->s[(size_t)e->S * w + k] = -0.05 + 0.1 * next_u01(e->rng[w]);
+  e->t[w] = 0;
+}
+}  // namespace
+
+JH_EXPORT int jh_control_create(int32_t W, int32_t S, int32_t A, uint64_t seed, jh_control** out) {
+  JH_ARG(out != nullptr && W > 0 && S > 0 && S <= 64 && A > 0 && A <= 16);
+  jh_control* e = new jh_control();
+  e->W = W; e->S = S; e->A = A;
+  e->s.assign((size_t)S * W, 0.0);
+  e->t.assign(W, 0);
+  e->rng.resize(W);
+  for (int w = 0; w < W; ++w) {
+    e->rng[w] = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(w + 1) * 0xBF58476D1CE4E5B9ull;
+    reset_control(e, w);
+  }
+  *out = e;
+  return JH_OK;
+}
+
+JH_EXPORT void jh_control_destroy(jh_control* e) { delete e; }
+
+JH_EXPORT int jh_control_obs(const jh_control* e, float* h_obs) {
+  JH_ARG(e && h_obs);
+  for (size_t i = 0; i < (size_t)e->S * e->W; ++i) h_obs[i] = (float)e->s[i];
+  return JH_OK;
+}
+
+JH_EXPORT int jh_control_step(jh_control* e, const float* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done) {
+  JH_ARG(e && h_action && h_next_obs && h_reward && h_done);
+  const int S = e->S, A = e->A;
+  double nxt[64];
+  for (int w = 0; w < e->W; ++w) {
+    double* s = &e->s[(size_t)S * w];
+    const float* a = h_action + (size_t)A * w;
+    double a2 = 0.0;
+    for (int j = 0; j < A; ++j) a2 += (double)a[j] * (double)a[j];
+    for (int i = 0; i < S; ++i) {
+      double drive = 0.0;
+      for (int j = 0; j < A; ++j) drive += 0.5 * sin(1.7 * (i + 1) + 2.3 * (j + 1)) * (double)a[j];
+      nxt[i] = 0.95 * s[i] + 0.05 * drive + 0.02 * sin(s[(i + 1) % S]);
+    }
+    for (int i = 0; i < S; ++i) s[i] = nxt[i];
+    e->t[w] += 1;
+    const bool d = s[0] > 2.0 || s[0] < -2.0 || e->t[w] >= 1000;
+    for (int i = 0; i < S; ++i) h_next_obs[(size_t)S * w + i] = (float)s[i];
+    h_done[w] = d ? 1 : 0;
+    h_reward[w] = (float)(s[0] + 0.1 - 0.001 * a2);
+    if (d) reset_control(e, w);
+  }
+  return JH_OK;
+}

@@ -789,21 +789,9 @@ JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, co
 //           counter-based splitmix64 stream.
 // h_obs [W][S] and h_action [W] are ordinary host pointers; the call returns when the actions are
 // there (acting is synchronous by nature: the envs need them).  h_logits_out / h_value_out optional.
-static inline double jh_u01(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  x = x ^ (x >> 31);
-  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
-}
-
-JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs, int64_t* h_action,
-                                     float* h_logits_out, float* h_value_out, int32_t training, jh_stream stream) {
-  JH_ARG(n && h_obs && h_action);
-  JH_ARG(!n->cont);
-  JH_ARG(W > 0 && W <= n->max_act_rows);
-  hipStream_t st = jh_s(stream);
-  const int H = n->H, A = n->A;
+// raw head outputs z [W][8] (flat output order: head0[A], head1[A] (continuous), value) of W observation rows
+static int pponet_act_raw(jh_pponet* n, int32_t W, const float* h_obs, float* z_out, hipStream_t st) {
+  const int H = n->H;
   const int tiles_n = H / 16, tiles = ((W + 15) / 16) * tiles_n;
   // (tried: observations inline in the kernel-argument segment -- the 1 KB larger kernarg made every
   // launch slower than the one PCIe read it saved: 21.9 vs 18.8 us per timestep)
@@ -834,32 +822,51 @@ JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs
       if (flags[t] != seq) return jh_fail(JH_ERR_STATE, "acting kernel finished without publishing tile %d", t);
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  // ---- finish the heads on the host
+  // ---- finish the heads on the host (sum over the column tiles, tile order)
   const float* part = n->part_pin_h;
   for (int wq = 0; wq < W; ++wq) {
-    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float* z = z_out + 8 * (size_t)wq;
+    for (int o = 0; o < 8; ++o) z[o] = 0.f;
     for (int t = 0; t < tiles_n; ++t) {
       const float* p = part + ((size_t)t * n->max_act_rows + wq) * 8;
       for (int o = 0; o < n_out; ++o) z[o] += p[o];
     }
-    int act = 0;
-    float mx = z[0];
-    for (int k = 1; k < A; ++k)
-      if (z[k] > mx) { mx = z[k]; act = k; }
-    if (training) {
-      float e[8], se = 0.f;
-      for (int k = 0; k < A; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
-      const float u = (float)jh_u01(n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq) * se;
-      float c = 0.f;
-      act = A - 1;
-      for (int k = 0; k < A; ++k) {
-        c += e[k];
-        if (u < c) { act = k; break; }
-      }
-    }
-    h_action[wq] = act;
-    if (h_logits_out) memcpy(h_logits_out + (size_t)wq * A, z, sizeof(float) * A);
-    if (h_value_out) h_value_out[wq] = z[A];
+  }
+  return JH_OK;
+}
+
+JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs, int64_t* h_action,
+                                     float* h_logits_out, float* h_value_out, int32_t training, jh_stream stream) {
+  JH_ARG(n && h_obs && h_action);
+  JH_ARG(!n->cont);
+  JH_ARG(W > 0 && W <= n->max_act_rows);
+  std::vector<float> z(8 * (size_t)W);
+  int rc = pponet_act_raw(n, W, h_obs, z.data(), jh_s(stream));
+  if (rc) return rc;
+  for (int wq = 0; wq < W; ++wq) {
+    h_action[wq] = jh_sample_discrete(n, z.data() + 8 * (size_t)wq, wq, training);
+    if (h_logits_out) memcpy(h_logits_out + (size_t)wq * n->A, z.data() + 8 * (size_t)wq, sizeof(float) * n->A);
+    if (h_value_out) h_value_out[wq] = z[8 * (size_t)wq + n->A];
+  }
+  n->act_ctr += 1;
+  return JH_OK;
+}
+
+// PPO.act for a continuous policy (ppo.py:55-63): h_action [W][A] = tanh(Normal(mu, std).sample()) (tanh(mu) when
+// !training); h_mu_raw_out / h_log_std_raw_out [W][A] optional raw heads.
+JH_EXPORT int jh_pponet_act_continuous(jh_pponet* n, int32_t W, const float* h_obs, float* h_action, float* h_mu_raw_out,
+                                       float* h_log_std_raw_out, int32_t training, jh_stream stream) {
+  JH_ARG(n && h_obs && h_action);
+  JH_ARG(n->cont);
+  JH_ARG(W > 0 && W <= n->max_act_rows);
+  std::vector<float> z(8 * (size_t)W);
+  int rc = pponet_act_raw(n, W, h_obs, z.data(), jh_s(stream));
+  if (rc) return rc;
+  const int A = n->A;
+  for (int wq = 0; wq < W; ++wq) {
+    jh_sample_continuous(n, z.data() + 8 * (size_t)wq, wq, training, h_action + (size_t)wq * A);
+    if (h_mu_raw_out) memcpy(h_mu_raw_out + (size_t)wq * A, z.data() + 8 * (size_t)wq, sizeof(float) * A);
+    if (h_log_std_raw_out) memcpy(h_log_std_raw_out + (size_t)wq * A, z.data() + 8 * (size_t)wq + A, sizeof(float) * A);
   }
   n->act_ctr += 1;
   return JH_OK;

@@ -52,9 +52,13 @@ __device__ __forceinline__ void persist_poll_issue(const void* gsrc, unsigned ld
                : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
 
+// SP: observation width padded to 4 / 8 (the W1 rows of a lane's k-values live in its registers) or 12 / 16 (they
+// live in LDS: 4 x NCH x SP registers would not fit).  Up to 128 observation granules (W x S <= 128).
 template <int SP, int NCH, int D>
 __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned long long s_ring[D][64];  // poll landing slots
+  constexpr bool W1LDS = SP > 8;
+  __shared__ __attribute__((aligned(16))) unsigned long long s_ring[D][128];  // poll landing slots
+  __shared__ __attribute__((aligned(16))) float s_w1[W1LDS ? 64 * NCH * SP : 4];  // [H][SP] (W1LDS)
   __shared__ __attribute__((aligned(16))) float s_x[2][16][SP];
   __shared__ __attribute__((aligned(16))) float s_acc[2][4][64][4];
   __shared__ float s_h2[16][17];
@@ -68,7 +72,7 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
   const int r = lane & 15, kq = lane >> 4;
   const int kbeg = wid * 16 * NCH;  // H == 64 * NCH
   // ---- one-time: this lane's weight fragments into registers
-  float w2f[NCH][4], b1f[NCH][4], w1f[NCH][4][SP];
+  float w2f[NCH][4], b1f[NCH][4], w1f[NCH][4][W1LDS ? 1 : SP];
 #pragma unroll
   for (int u = 0; u < NCH; ++u) {
     const int kb = kbeg + 16 * u + 4 * kq;
@@ -76,8 +80,16 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
     for (int j = 0; j < 4; ++j) {
       w2f[u][j] = p.W2[(size_t)(n0 + r) * H + kb + j];
       b1f[u][j] = p.b1[kb + j];
+      if (!W1LDS) {
 #pragma unroll
-      for (int q = 0; q < SP; ++q) w1f[u][j][q] = q < S ? p.W1[(size_t)(kb + j) * S + q] : 0.f;
+        for (int q = 0; q < SP; ++q) w1f[u][j][q] = q < S ? p.W1[(size_t)(kb + j) * S + q] : 0.f;
+      }
+    }
+  }
+  if (W1LDS) {
+    for (int i = threadIdx.x; i < H * SP; i += 256) {
+      const int k = i / SP, q = i - k * SP;
+      s_w1[i] = q < S ? p.W1[(size_t)k * S + q] : 0.f;
     }
   }
   for (int i = threadIdx.x; i < 12 * 16; i += 256) {
@@ -87,10 +99,10 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
   if (threadIdx.x < 16) s_b2[threadIdx.x] = p.b2[n0 + threadIdx.x];
   if (threadIdx.x < 12) s_hb[threadIdx.x] = threadIdx.x < p.n_out ? *p.hbias[threadIdx.x] : 0.f;
   for (int i = threadIdx.x; i < 2 * 16 * SP; i += 256) (&s_x[0][0][0])[i] = 0.f;  // rows >= W / columns >= S stay 0
-  for (int i = threadIdx.x; i < D * 64; i += 256) (&s_ring[0][0])[i] = 0ull;
+  for (int i = threadIdx.x; i < D * 128; i += 256) (&s_ring[0][0])[i] = 0ull;
   __syncthreads();
 
-  const int n_gran = p.W * S;            // <= 64
+  const int n_gran = p.W * S;            // <= 128: lane l owns granules l and 64 + l
   const int n16 = (n_gran + 1) >> 1;     // lanes that fetch 16 bytes per poll
   const char* my_src = reinterpret_cast<const char*>(p.obs_gran) + 16 * (lane < n16 ? lane : 0);
   unsigned long long next_issue = 0;
@@ -121,12 +133,11 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
       bool ok = false;
       for (long spin = 0; spin < p.max_polls * 4; ++spin) {
         const unsigned long long gq = __hip_atomic_load(p.mbox + (lane < n_gran ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool mine = lane >= n_gran || (unsigned)(gq >> 32) == tag;
+        const unsigned long long gq1 = n_gran > 64 ? __hip_atomic_load(p.mbox + (64 + lane < n_gran ? 64 + lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const bool mine = (lane >= n_gran || (unsigned)(gq >> 32) == tag) && (64 + lane >= n_gran || (unsigned)(gq1 >> 32) == tag);
         if (__all(mine)) {
-          if (lane < n_gran) {
-            const int row = lane / S, q = lane - row * S;
-            s_x[par][row][q] = __uint_as_float((unsigned)gq);
-          }
+          if (lane < n_gran) s_x[par][lane / S][lane % S] = __uint_as_float((unsigned)gq);
+          if (64 + lane < n_gran) s_x[par][(64 + lane) / S][(64 + lane) % S] = __uint_as_float((unsigned)gq1);
           ok = true;
           break;
         }
@@ -141,14 +152,19 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
         // (a ds_read in asm: through a generic pointer hipcc emits flat_load + s_waitcnt vmcnt(0), which would wait
         // for EVERY poll in flight and serialise the ring)
-        unsigned long long gq;
-        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(gq) : "v"(ring_lane + (unsigned)slot * 512u) : "memory");
-        const bool mine = lane >= n_gran || (unsigned)(gq >> 32) == tag;
+        unsigned long long gq, gq1;
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(gq), "=&v"(gq1) : "v"(ring_lane + (unsigned)slot * 1024u) : "memory");
+        const bool mine = (lane >= n_gran || (unsigned)(gq >> 32) == tag) && (64 + lane >= n_gran || (unsigned)(gq1 >> 32) == tag);
         const bool done = __all(mine);
-        if (done && lane < n_gran) {
-          const int row = lane / S, q = lane - row * S;
-          s_x[par][row][q] = __uint_as_float((unsigned)gq);
-          if (p.mbox) __hip_atomic_store(p.mbox + lane, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: the granule is its own flag
+        if (done) {
+          if (lane < n_gran) {
+            s_x[par][lane / S][lane % S] = __uint_as_float((unsigned)gq);
+            if (p.mbox) __hip_atomic_store(p.mbox + lane, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: the granule is its own flag
+          }
+          if (64 + lane < n_gran) {
+            s_x[par][(64 + lane) / S][(64 + lane) % S] = __uint_as_float((unsigned)gq1);
+            if (p.mbox) __hip_atomic_store(p.mbox + 64 + lane, gq1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
         // re-arm the slot (the LDS read above has returned), paced so that the D polls in flight stay ~period apart
         // instead of bunching up behind the one that just landed (not when the step was just detected: nothing may
@@ -172,13 +188,10 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
     }
     // ---- layer 1 generated in registers as the A operand, straight into the MFMAs of this wave's K quarter
     float xr[SP];
-    {
-      const float4 v0 = *reinterpret_cast<const float4*>(&s_x[par][r][0]);
-      xr[0] = v0.x; xr[1] = v0.y; xr[2] = v0.z; xr[3] = v0.w;
-      if (SP > 4) {
-        const float4 v1 = *reinterpret_cast<const float4*>(&s_x[par][r][4]);
-        xr[4] = v1.x; xr[5] = v1.y; xr[6] = v1.z; xr[7] = v1.w;
-      }
+#pragma unroll
+    for (int q4 = 0; q4 < SP / 4; ++q4) {
+      const float4 v = *reinterpret_cast<const float4*>(&s_x[par][r][4 * q4]);
+      xr[4 * q4] = v.x; xr[4 * q4 + 1] = v.y; xr[4 * q4 + 2] = v.z; xr[4 * q4 + 3] = v.w;
     }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -186,8 +199,17 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float a = 0.f;
+        if (W1LDS) {
+          const float* wr = s_w1 + (size_t)(kbeg + 16 * u + 4 * kq + j) * SP;
 #pragma unroll
-        for (int q = 0; q < SP; ++q) a = fmaf(xr[q], w1f[u][j][q], a);
+          for (int q4 = 0; q4 < SP / 4; ++q4) {
+            const float4 w = *reinterpret_cast<const float4*>(wr + 4 * q4);
+            a = fmaf(xr[4 * q4], w.x, a); a = fmaf(xr[4 * q4 + 1], w.y, a); a = fmaf(xr[4 * q4 + 2], w.z, a); a = fmaf(xr[4 * q4 + 3], w.w, a);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < SP; ++q) a = fmaf(xr[q], w1f[u][j][q], a);
+        }
         a += b1f[u][j];
         a = a > 0.f ? a : 0.f;
         // two accumulators: the 16x16x4 fp32 MFMA has a 40-cycle dependent latency vs a 32-cycle issue interval
@@ -264,13 +286,13 @@ static int persist_heads(const jh_pponet* n) { return n->cont ? 2 * n->A : n->A;
 int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_ARG(n && out);
   const int H = n->H, S = n->S;
-  JH_ARG(S >= 1 && S <= 8 && (H == 64 || H == 128 || H == 256 || H == 512) && persist_heads(n) <= 12);
+  JH_ARG(S >= 1 && S <= 16 && (H == 64 || H == 128 || H == 256 || H == 512) && persist_heads(n) <= 12);
   jh_persist* p = new jh_persist();
   p->net = n;
   p->tiles = H / 16;
   p->n_out = persist_heads(n);
   p->G = (p->n_out + 2) / 3;
-  JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 64, hipHostMallocMapped));
+  JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 128, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->gran_d, p->gran_h, 0));
   const size_t part_bytes = sizeof(float4) * 16 * (size_t)p->tiles * p->G;
   JH_HIP(hipHostMalloc((void**)&p->part_h, part_bytes, hipHostMallocMapped));
@@ -278,9 +300,9 @@ int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_HIP(hipHostGetDevicePointer((void**)&p->part_d, p->part_h, 0));
   JH_HIP(hipHostMalloc((void**)&p->flag_h, sizeof(unsigned) * 16, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
-  JH_HIP(hipMalloc((void**)&p->mbox, sizeof(unsigned long long) * 64));
-  JH_HIP(hipMemset(p->mbox, 0, sizeof(unsigned long long) * 64));
-  memset(p->gran_h, 0, sizeof(unsigned long long) * 64);
+  JH_HIP(hipMalloc((void**)&p->mbox, sizeof(unsigned long long) * 128));
+  JH_HIP(hipMemset(p->mbox, 0, sizeof(unsigned long long) * 128));
+  memset(p->gran_h, 0, sizeof(unsigned long long) * 128);
   memset(p->flag_h, 0, sizeof(unsigned) * 16);
   if (getenv("JH_PERSIST_DEBUG")) {
     // timestamps go to DEVICE memory (a store to host memory would stall the wave at the next barrier
@@ -306,16 +328,15 @@ void jh_persist_destroy(jh_persist* p) {
 
 template <int SP, int NCH>
 static void persist_launch(int depth, int tiles, hipStream_t st, const PersistArgs& a) {
-  if (depth >= 8) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 8>), dim3(tiles), dim3(256), 0, st, a);
-  else if (depth >= 4) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 4>), dim3(tiles), dim3(256), 0, st, a);
+  if (depth >= 4) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 4>), dim3(tiles), dim3(256), 0, st, a);
   else if (depth >= 2) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 2>), dim3(tiles), dim3(256), 0, st, a);
   else JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 1>), dim3(tiles), dim3(256), 0, st, a);
 }
 
-// Launch the persistent kernel for T steps of W <= 16 envs (W * S <= 64 observation granules).
+// Launch the persistent kernel for T steps of W <= 16 envs (W * S <= 128 observation granules).
 int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   jh_pponet* n = p->net;
-  JH_ARG(W > 0 && W <= 16 && W * n->S <= 64 && T > 0);
+  JH_ARG(W > 0 && W <= 16 && W * n->S <= 128 && T > 0);
   PersistArgs a{};
   a.W = W; a.S = n->S; a.H = n->H; a.T = T; a.G = p->G;
   a.W1 = n->params + n->o_w1; a.b1 = n->params + n->o_b1; a.W2 = n->params + n->o_w2; a.b2 = n->params + n->o_b2;
@@ -336,9 +357,14 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.max_polls = 600000;  // x (>= 0.3 us per consumed poll) = >= 0.2 s without observations -> give up
   p->flag_h[0] = 0;
   const int nch = n->H / 64;
-  const bool sp8 = n->S > 4;
-#define JH_PERSIST_CASE(NCH) \
-  if (nch == NCH) { if (sp8) persist_launch<8, NCH>(depth, p->tiles, st, a); else persist_launch<4, NCH>(depth, p->tiles, st, a); }
+  const int sp = (n->S + 3) / 4 * 4;  // 4, 8: W1 fragments in registers; 12, 16: in LDS
+#define JH_PERSIST_CASE(NCH)                                      \
+  if (nch == NCH) {                                               \
+    if (sp == 4) persist_launch<4, NCH>(depth, p->tiles, st, a);  \
+    else if (sp == 8) persist_launch<8, NCH>(depth, p->tiles, st, a);   \
+    else if (sp == 12) persist_launch<12, NCH>(depth, p->tiles, st, a); \
+    else persist_launch<16, NCH>(depth, p->tiles, st, a);         \
+  }
   JH_PERSIST_CASE(1) else JH_PERSIST_CASE(2) else JH_PERSIST_CASE(4) else JH_PERSIST_CASE(8)
 #undef JH_PERSIST_CASE
   JH_LAUNCH_CHECK();

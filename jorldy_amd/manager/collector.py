@@ -62,12 +62,14 @@ class VecCollector:
 
 
 class NativeCollector:
-    """jh_collector_*: CartPole x native PPO (discrete) only.  `run(step)` appends W*step transitions
-    to the agent's rollout store and returns (None, 1.0); pass None to `agent.process`."""
+    """jh_collector_*: the whole T-step rollout loop in one C call for a native PPO agent on a native vectorised env:
+    ops.CartPoleVec (discrete policy) or ops.ControlVec (continuous policy, config.ppo.mujoco shapes).  `run(step)`
+    appends W*step transitions to the agent's rollout store and returns (None, 1.0); pass None to `agent.process`."""
 
     def __init__(self, env_vec, agent, num_workers=None, mode="sync"):
         assert mode == "sync"
-        assert getattr(agent, "_net", None) is not None and agent.action_type == "discrete", "needs the native PPO backend"
+        assert getattr(agent, "_net", None) is not None, "needs the native PPO backend"
+        assert agent.action_type == env_vec.action_type, "policy / env action types differ"
         self.lib = L.load()
         self.env, self.agent = env_vec, agent
         self.num_workers = env_vec.W
@@ -80,8 +82,10 @@ class NativeCollector:
 
     def _bind(self, n_rows):
         mem, W = self.agent.memory, self.env.W
-        example = {"state": np.zeros((n_rows, 4), np.float32), "action": np.zeros((n_rows, 1), np.int64), "reward": np.zeros((n_rows, 1), np.float32),
-                   "next_state": np.zeros((n_rows, 4), np.float32), "done": np.zeros((n_rows, 1), np.uint8)}
+        S, cont = self.env.state_size, self.env.action_type == "continuous"
+        action = np.zeros((n_rows, self.env.action_size), np.float32) if cont else np.zeros((n_rows, 1), np.int64)
+        example = {"state": np.zeros((n_rows, S), np.float32), "action": action, "reward": np.zeros((n_rows, 1), np.float32),
+                   "next_state": np.zeros((n_rows, S), np.float32), "done": np.zeros((n_rows, 1), np.uint8)}
         mem._ensure(example, n_rows)
         self.agent._grow_native(W)
         store, net = mem._store, self.agent._net
@@ -91,7 +95,8 @@ class NativeCollector:
             self.lib.jh_collector_destroy(self.h)
         cols = (C.c_int32 * 5)(*[store.names.index(k) for k in ("state", "action", "reward", "next_state", "done")])
         h = C.c_void_p()
-        L.check(self.lib.jh_collector_create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
+        create = self.lib.jh_collector_create_control if cont else self.lib.jh_collector_create
+        L.check(create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
         self.h, self._store_h, self._net_h = h, store.h.value, net.h.value
 
     def run(self, step=1):

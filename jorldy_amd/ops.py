@@ -508,6 +508,20 @@ def value_act(logits, v_min=0.0, v_max=0.0, eps=None, u=None, rand_action=None, 
     return act, q, q_all
 
 
+def _pponet_act_continuous(self, obs, training=True, want_heads=False):
+    """obs: numpy float32 [W, S] -> numpy float32 [W, A] in (-1, 1) (blocking); PPO.act, ppo.py:55-63."""
+    obs = np.ascontiguousarray(obs, dtype=np.float32)
+    W = int(obs.shape[0])
+    act = np.empty((W, self.A), np.float32)
+    mu = np.empty((W, self.A), np.float32) if want_heads else None
+    ls = np.empty((W, self.A), np.float32) if want_heads else None
+    L.check(self.lib.jh_pponet_act_continuous(self.h, W, L.ptr(obs), L.ptr(act), L.ptr(mu), L.ptr(ls), int(bool(training)), L.stream_ptr()))
+    return (act, mu, ls) if want_heads else act
+
+
+PPONet.act_continuous = _pponet_act_continuous
+
+
 # ============================================================================= TD / C51
 def td_loss(q, q_next_target, action, reward, done, gamma, q_next_online=None, weights=None, alpha=0.0, n_step=0, stats=None):
     """Returns (grad_q [B,A], prio [B], stats f32[4] = {loss, max_Q, mean_td, 0})."""
@@ -573,6 +587,38 @@ class CartPoleVec:
         reward = np.empty(self.W, np.float32) if reward is None else reward
         done = np.empty(self.W, np.uint8) if done is None else done
         L.check(self.lib.jh_cartpole_step(self.h, L.ptr(a), L.ptr(next_obs), L.ptr(reward), L.ptr(done)))
+        return next_obs, reward, done
+
+
+class ControlVec:
+    """W synthetic continuous-control envs (jh_control_*: stand-in for MuJoCo at config.ppo.mujoco shapes, default
+    Hopper-v3's S = 11, A = 3) stepped in one native call."""
+
+    def __init__(self, W, state_size=11, action_size=3, seed=0):
+        self.lib = L.load()
+        self.W, self.state_size, self.action_size, self.action_type = int(W), int(state_size), int(action_size), "continuous"
+        self.h = C.c_void_p()
+        L.check(self.lib.jh_control_create(self.W, self.state_size, self.action_size, C.c_uint64(int(seed)), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jh_control_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def obs(self, out=None):
+        out = np.empty((self.W, self.state_size), np.float32) if out is None else out
+        L.check(self.lib.jh_control_obs(self.h, L.ptr(out)))
+        return out
+
+    def step(self, action, next_obs=None, reward=None, done=None):
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(self.W, self.action_size)
+        next_obs = np.empty((self.W, self.state_size), np.float32) if next_obs is None else next_obs
+        reward = np.empty(self.W, np.float32) if reward is None else reward
+        done = np.empty(self.W, np.uint8) if done is None else done
+        L.check(self.lib.jh_control_step(self.h, L.ptr(a), L.ptr(next_obs), L.ptr(reward), L.ptr(done)))
         return next_obs, reward, done
 
 

@@ -603,3 +603,59 @@ class CartPoleOracle:
             if d:
                 self._reset(w)
         return nxt, rew, done
+
+
+# =============================================================================
+# synthetic continuous control (stand-in for MuJoCo at config.ppo.mujoco shapes; mirrors csrc/jh_env.hip bit for bit)
+# =============================================================================
+class ControlOracle:
+    """W envs, float64 dynamics  s'_i = 0.95 s_i + 0.05 sum_j P[i][j] a_j + 0.02 sin(s_{(i+1) mod S}),
+    P[i][j] = 0.5 sin(1.7 (i+1) + 2.3 (j+1));  reward = s'_0 + 0.1 - 0.001 |a|^2;  done when |s'_0| > 2 or after 1000
+    steps;  reset U(-0.05, 0.05)^S from a per-env splitmix64 stream;  auto-reset AFTER next_obs is taken."""
+
+    MAX_STEPS = 1000
+
+    def __init__(self, W, S=11, A=3, seed=0):
+        self.W, self.S, self.A = W, S, A
+        self.rng = np.asarray([(seed * 0x9E3779B97F4A7C15 + (w + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF for w in range(W)], dtype=np.uint64)
+        self.s = np.zeros((W, S), np.float64)
+        self.t = np.zeros(W, np.int64)
+        for w in range(W):
+            self._reset(w)
+
+    _next_u01 = CartPoleOracle._next_u01
+
+    def _reset(self, w):
+        for k in range(self.S):
+            self.s[w, k] = -0.05 + 0.1 * self._next_u01(w)
+        self.t[w] = 0
+
+    def obs(self):
+        return self.s.astype(np.float32)
+
+    def step(self, action):
+        W, S, A = self.W, self.S, self.A
+        action = np.asarray(action, dtype=np.float32).reshape(W, A)
+        nxt = np.zeros((W, S), np.float32)
+        rew = np.zeros(W, np.float32)
+        done = np.zeros(W, bool)
+        for w in range(W):
+            a = [float(v) for v in action[w]]
+            a2 = 0.0
+            for j in range(A):
+                a2 += a[j] * a[j]
+            new = [0.0] * S
+            for i in range(S):
+                drive = 0.0
+                for j in range(A):
+                    drive += 0.5 * math.sin(1.7 * (i + 1) + 2.3 * (j + 1)) * a[j]
+                new[i] = 0.95 * self.s[w, i] + 0.05 * drive + 0.02 * math.sin(self.s[w, (i + 1) % S])
+            self.s[w] = new
+            self.t[w] += 1
+            d = bool(new[0] > 2.0 or new[0] < -2.0 or self.t[w] >= self.MAX_STEPS)
+            nxt[w] = self.s[w].astype(np.float32)
+            done[w] = d
+            rew[w] = np.float32(new[0] + 0.1 - 0.001 * a2)
+            if d:
+                self._reset(w)
+        return nxt, rew, done

@@ -144,3 +144,21 @@ def test_staging_ring_many_producers_one_consumer_host_only():
     with pytest.raises(L.JhError):
         small.produce({k: v[:1] for k, v in z.items()}, timeout_ms=50)
     assert small.stats()["produced"] == 4
+
+
+def test_control_env_matches_oracle_bit_for_bit(lib):
+    """jh_control_* (synthetic continuous control at config.ppo.mujoco shapes, host code) vs oracle ControlOracle."""
+    from jorldy_amd import ops
+    from oracle.jorldy_oracle import ControlOracle
+
+    env, orc = ops.ControlVec(4, 11, 3, seed=3), ControlOracle(4, 11, 3, seed=3)
+    rng = np.random.RandomState(1)
+    n_done = 0
+    for t in range(1200):
+        assert np.array_equal(env.obs(), orc.obs())
+        a = np.tanh(rng.randn(4, 3) * 3).astype(np.float32)
+        n1, r1, d1 = env.step(a)
+        n2, r2, d2 = orc.step(a)
+        assert np.array_equal(n1, n2) and np.array_equal(r1, r2) and np.array_equal(d1.astype(bool), d2), t
+        n_done += int(d2.sum())
+    assert n_done >= 4  # the 1000-step cap at least

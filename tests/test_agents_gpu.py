@@ -546,6 +546,76 @@ def test_native_collector_matches_python_collector_layout():
     assert set(res) == {"actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob", "mean_ret"} and agent.memory.size == 0
 
 
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("H,W", [(64, 5), (512, 8)])
+def test_native_collector_continuous_policy_on_control_env(H, W, persistent, monkeypatch):
+    """jh_collector_create_control / jh_collector_run (config.ppo.mujoco shapes: S = 11, A = 3, continuous): the stored
+    worker-major transitions replayed through the oracle env reproduce states / rewards / dones bit for bit; the stored
+    actions are tanh-squashed samples of the policy (persistent acting kernel with W1 in LDS for S > 8 and 88
+    observation granules, or one launch per timestep); the learner consumes the rollout."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+    from oracle.jorldy_oracle import ControlOracle
+
+    monkeypatch.setenv("JH_COLLECT_PERSISTENT", "1" if persistent else "0")
+    S, A, T = 11, 3, 40
+    torch.manual_seed(3)
+    agent = Agent("ppo", state_size=S, action_size=A, hidden_size=H, network="continuous_policy_value", n_step=T, batch_size=50, device="cuda", backend="native", seed=5)
+    agent.memory.first_store = False
+    env = ops.ControlVec(W, S, A, seed=9)
+    col = NativeCollector(env, agent, W)
+    col.run(T)
+    torch.cuda.synchronize()
+    st = agent.memory._store
+    assert st.size == W * T
+    cols = {k: npy(st.column(k)[: W * T]) for k in ("state", "action", "reward", "next_state", "done")}
+    assert cols["action"].shape == (W * T, A) and cols["action"].dtype == np.float32 and np.all(np.abs(cols["action"]) <= 1.0)
+    orc = ControlOracle(W, S, A, seed=9)
+    a = cols["action"].reshape(W, T, A)
+    for t in range(T):
+        obs = orc.obs()
+        nxt, rew, done = orc.step(a[:, t])
+        rows = np.arange(W) * T + t  # worker-major
+        np.testing.assert_array_equal(cols["state"][rows], obs)
+        np.testing.assert_array_equal(cols["next_state"][rows], nxt)
+        np.testing.assert_array_equal(cols["reward"][rows, 0], rew)
+        np.testing.assert_array_equal(cols["done"][rows, 0].astype(bool), done)
+    # the actions are samples of THIS policy at the stored states: z = atanh(a) ~ Normal(mu, std)
+    with torch.no_grad():
+        mu, std, _ = agent.network(torch.from_numpy(cols["state"]).cuda())
+    zz = np.arctanh(np.clip(cols["action"].astype(np.float64), -1 + 1e-7, 1 - 1e-7))
+    zs = (zz - npy(mu)) / npy(std)
+    assert abs(zs.mean()) < 0.12 and 0.85 < zs.std() < 1.15, (zs.mean(), zs.std())
+    res = agent.process(None, T)
+    assert set(res) == {"actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob", "mean_ret"} and agent.memory.size == 0
+
+
+def test_native_act_continuous_distribution():
+    """PPO.act for a continuous policy on the native path (jh_pponet_act_continuous): tanh(Normal(mu, std).sample()),
+    tanh(mu) when not training (ppo.py:55-63)."""
+    from jorldy_amd.core.agent import Agent
+
+    torch.manual_seed(0)
+    agent = Agent("ppo", state_size=11, action_size=3, hidden_size=64, network="continuous_policy_value", device="cuda", backend="native")
+    with torch.no_grad():
+        agent.network.mu.bias.copy_(torch.tensor([0.3, -0.5, 0.0], device="cuda"))
+        agent.network.log_std.bias.copy_(torch.tensor([-0.5, 0.0, 0.4], device="cuda"))
+    obs = np.zeros((64, 11), np.float32)
+    zs = []
+    for _ in range(150):
+        a = agent.act(obs, training=True)["action"]
+        assert a.shape == (64, 3) and a.dtype == np.float32
+        zs.append(np.arctanh(np.clip(a.astype(np.float64), -1 + 1e-7, 1 - 1e-7)))
+    zs = np.concatenate(zs, 0)
+    with torch.no_grad():
+        mu, std, _ = agent.network(torch.zeros(1, 11, device="cuda"))
+    np.testing.assert_allclose(zs.mean(0), npy(mu)[0], atol=0.04)
+    np.testing.assert_allclose(zs.std(0), npy(std)[0], rtol=0.05)
+    g = agent.act(obs, training=False)["action"]
+    np.testing.assert_allclose(g, np.tile(np.tanh(npy(mu)), (64, 1)), rtol=1e-5, atol=1e-6)
+
+
 def test_ppo_native_data_parallel_path_single_rank_rccl():
     """The DP code path (eager native kernels + one RCCL all-reduce of the flat gradient bucket per
     minibatch) on a 1-rank nccl group: must equal the graph-replayed single-learner result."""
