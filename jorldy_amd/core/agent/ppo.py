@@ -162,6 +162,9 @@ class PPO(BaseAgent):
 
     def _learn_torch(self):
         tr = self.memory.sample()  # float32 device tensors, arrival (worker-major) order
+        if isinstance(tr["state"], list):
+            raise NotImplementedError("PPO: list-valued (multimodal) observations are stored and sampled by the buffers, but the minibatch "
+                                      "loop gathers rows of ONE state tensor; use a single observation tensor")
         state, action, reward = tr["state"], tr["action"], tr["reward"]
         next_state, done = tr["next_state"], tr["done"]
         M = reward.shape[0]

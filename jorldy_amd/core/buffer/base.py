@@ -7,14 +7,17 @@ from ... import _lib as L
 from ... import ops
 
 
-def _jh_dtype(arr):
+def _jh_dtype(arr, key=None):
     """Stored dtype of a column.  Everything becomes float32 at BaseAgent.as_tensor
     (core/agent/base.py:61-73), so floats are stored as float32 (same rounding), uint8 frames and
-    bools as one byte, integers as int64."""
+    bools as one byte.  Integer-typed arrays are kept as int64 only for the columns that are integral by
+    meaning (discrete actions, the frame-slot numbers of the de-duplicated replay); any other column whose FIRST
+    batch happens to be integer-typed (gym_env.py:78 computes `reward = -1 if done else 0.1`) is stored as
+    float32 like as_tensor would make it -- a later fractional value must not be truncated."""
     k = arr.dtype.kind
     if arr.dtype == np.uint8 or k == "b":
         return L.JH_U8
-    if k in "iu":
+    if k in "iu" and (key is None or key in ("action", "state", "next_state")):
         return L.JH_I64
     return L.JH_F32
 
@@ -72,7 +75,7 @@ class BaseBuffer(ABC):
                 a = np.asarray(a)
                 name = f"{key}#{i}" if isinstance(v, list) else key
                 shape = tuple(a.shape[1:])
-                columns.append((name, _jh_dtype(a), int(np.prod(shape)) if shape else 1, shape if shape else (1,)))
+                columns.append((name, _jh_dtype(a, key), int(np.prod(shape)) if shape else 1, shape if shape else (1,)))
                 layout.append((key, i if isinstance(v, list) else None, name))
         self._layout = layout
         self._store = ops.DeviceStore(capacity, columns, device=self.device)

@@ -33,7 +33,7 @@ class FramePool:
         self.table = {}  # content hash -> slot
         self.slot_key = [None] * self.F
         self.row_slots = np.full((self.N, 2 * self.C), -1, np.int64)  # what each transition row references
-        self._pend_frames, self._pend_slots = [], []
+        self._pend_frames, self._pend_slots, self._pend_set = [], [], set()
         self._idx_buf = {}
         self.frames_uploaded = 0
         self.frames_referenced = 0
@@ -68,6 +68,11 @@ class FramePool:
                         raise RuntimeError(f"frame pool exhausted ({self.F} frames for {self.N} transitions): raise frame_pool_factor "
                                            "(observations share fewer frames than the frame-stacking wrapper implies)")
                     s = self.free.pop()
+                    if s in self._pend_set:
+                        # the slot was released (its transitions were overwritten) while ITS upload is still queued: two
+                        # rows for one slot in one scatter launch would land in undefined order -- write the queue out first
+                        self.flush()
+                    self._pend_set.add(s)
                     self.table[key] = s
                     self.slot_key[s] = key
                     self._pend_frames.append(frame.copy())
@@ -84,7 +89,7 @@ class FramePool:
         if self._pend_slots:
             self.pool.write_rows(np.asarray(self._pend_slots, np.int64), {"frame": np.stack(self._pend_frames, 0)})
             self.frames_uploaded += len(self._pend_slots)
-            self._pend_frames, self._pend_slots = [], []
+            self._pend_frames, self._pend_slots, self._pend_set = [], [], set()
 
     def idx_buffer(self, B):
         if B not in self._idx_buf:

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -84,9 +85,11 @@ struct jh_ctx {
   static constexpr int kSlabs = 8;
   jh_pinned_slab slabs[kSlabs];
   int next_slab = 0;
-  // small device scratch for reductions (partials) -- grows on demand
+  // small device scratch for reductions (partials) -- grows on demand; outgrown blocks stay alive (captured graphs)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  std::vector<void*> retired;
+  std::mutex mu;  // slabs + scratch are shared by the threads of a process (learner, batched actors, ring producers)
 };
 
 // Get a pinned slab of at least `bytes` (waits for its previous use to drain).

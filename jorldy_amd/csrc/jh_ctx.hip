@@ -57,6 +57,7 @@ JH_EXPORT void jh_ctx_destroy(jh_ctx* ctx) {
     if (s.host) (void)hipHostFree(s.host);
   }
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  for (void* b : ctx->retired) (void)hipFree(b);
   delete ctx;
 }
 
@@ -66,7 +67,11 @@ JH_EXPORT int jh_ctx_sync(jh_ctx* ctx, jh_stream stream) {
   return JH_OK;
 }
 
+// Slabs and scratch are shared by every thread that uses this context (learner thread, batched-actor thread, ring
+// producers): the round-robin cursor and the scratch list are guarded by the context's mutex.  A slab handed out is
+// used by ONE caller until its release event has been recorded.
 int jh_ctx_slab(jh_ctx* ctx, size_t bytes, jh_pinned_slab** out) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
   jh_pinned_slab& s = ctx->slabs[ctx->next_slab];
   ctx->next_slab = (ctx->next_slab + 1) % jh_ctx::kSlabs;
   if (s.pending) {
@@ -98,15 +103,17 @@ int jh_ctx_slab_release(jh_ctx* ctx, jh_pinned_slab* slab, hipStream_t stream) {
 }
 
 int jh_ctx_scratch(jh_ctx* ctx, size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
   if (ctx->scratch_bytes < bytes) {
-    // growing is rare (first calls); the old block may still be in use by enqueued work
-    JH_HIP(hipDeviceSynchronize());
-    if (ctx->scratch) JH_HIP(hipFree(ctx->scratch));
+    // Growing is rare (first calls).  A block that was handed out is NEVER freed before the context dies: its address
+    // may be baked into a captured hipGraph (td / c51 / ppo loss partials), and nothing may hipFree / synchronise
+    // during a capture.  Old blocks are kept on a list (a few hundred KB in total).
     size_t want = 1 << 16;
     while (want < bytes) want <<= 1;
-    ctx->scratch = nullptr;
-    ctx->scratch_bytes = 0;
-    JH_HIP(hipMalloc(&ctx->scratch, want));
+    void* blk = nullptr;
+    JH_HIP(hipMalloc(&blk, want));
+    if (ctx->scratch) ctx->retired.push_back(ctx->scratch);
+    ctx->scratch = blk;
     ctx->scratch_bytes = want;
   }
   *out = ctx->scratch;

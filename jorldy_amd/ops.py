@@ -127,7 +127,10 @@ class DeviceStore:
         n = None
         arrs = []
         for name, dt, elems, _ in self.columns:
-            a = np.ascontiguousarray(np.asarray(cols[name]).reshape(len(cols[name]), -1), dtype=_NP_OF[dt])
+            src = np.asarray(cols[name]).reshape(len(cols[name]), -1)
+            a = np.ascontiguousarray(src, dtype=_NP_OF[dt])
+            if dt == L.JH_I64 and src.dtype.kind == "f" and not np.array_equal(a, src):
+                raise ValueError(f"column {name} is stored as int64 (its first batch was integer-typed) but this batch holds fractional values")
             assert a.shape[1] == elems, f"column {name}: expected {elems} elems, got {a.shape[1]}"
             n = a.shape[0] if n is None else n
             assert a.shape[0] == n
@@ -830,7 +833,10 @@ class StagingRing:
         (JhError, nothing written); timeout_ms < 0 waits forever."""
         arrs, n = [], None
         for name, dt, elems, _ in self.columns:
-            a = np.ascontiguousarray(np.asarray(cols[name]).reshape(len(cols[name]), -1), dtype=_NP_OF[dt])
+            src = np.asarray(cols[name]).reshape(len(cols[name]), -1)
+            a = np.ascontiguousarray(src, dtype=_NP_OF[dt])
+            if dt == L.JH_I64 and src.dtype.kind == "f" and not np.array_equal(a, src):
+                raise ValueError(f"column {name} is stored as int64 (its first batch was integer-typed) but this batch holds fractional values")
             assert a.shape[1] == elems, f"column {name}: expected {elems} elems, got {a.shape[1]}"
             n = a.shape[0] if n is None else n
             assert a.shape[0] == n

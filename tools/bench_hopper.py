@@ -2,10 +2,14 @@
 """Learner-side measurement at BASELINE.json configs[4] shapes (config.ppo.mujoco, Hopper-v3: S=11, A=3 continuous,
 n_step=2048, 32 workers, distributed_batch_size=2048, 10 epochs): one PPO iteration = 65 536 synthetic transitions
 (states N(0,1), actions tanh(N(0,1))) -> GAE + standardise -> 10 x 32 minibatch updates of 2048 rows
-on the native continuous policy-value net, replayed as one hipGraph.  (MuJoCo itself is not installable here, so the
-collector side of this config is not measured; `--workers W` sets the per-GPU share for data-parallel runs.)
+on the native continuous policy-value net, replayed as one hipGraph.
 
-    python tools/bench_hopper.py [--iters 10] [--workers 32]
+--e2e: the per-GPU share of the 8-GPU data-parallel layout end to end -- 32 / 8 = 4 workers and 2048 / 8 = 256 minibatch
+rows per GPU: the native collector (persistent acting kernel, continuous policy, host sampling) drives the synthetic
+control env that stands in for MuJoCo (jh_control_*, S = 11, A = 3), 4 x 2048 transitions per iteration, then 10 epochs x
+32 minibatches of 256 rows (five launches each).
+
+    python tools/bench_hopper.py [--iters 10] [--workers 32] [--e2e]
 """
 import argparse
 import json
@@ -24,7 +28,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workers", type=int, default=32)
     ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--e2e", action="store_true", help="per-GPU share of configs[4] with the native collector on the synthetic control env (4 workers, minibatch 256)")
     args = ap.parse_args()
+    if args.e2e:
+        args.workers, args.batch = 4, 256
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
 
@@ -40,10 +47,18 @@ def main():
     cols = {"state": rng.randn(M, S).astype(np.float32), "action": np.tanh(rng.randn(M, A)).astype(np.float32), "reward": rng.randn(M, 1).astype(np.float32),
             "next_state": rng.randn(M, S).astype(np.float32), "done": (rng.rand(M, 1) < 1e-3)}
     step = 0
+    collector = None
+    if args.e2e:
+        from jorldy_amd.manager import NativeCollector
+
+        collector = NativeCollector(ops.ControlVec(W, S, A, seed=1), agent, W)
 
     def iteration():
         nonlocal step
         step += T
+        if collector is not None:
+            collector.run(T)
+            return agent.process(None, step)
         return agent.process(cols, step)
 
     for _ in range(args.warmup):
@@ -75,6 +90,8 @@ def main():
         "backend": agent.backend, "learn_in_hipgraph": bool(agent._graph is not None),
         "ms_per_iteration": dt * 1e3, "learner_transitions_per_s": M / dt, "learner_updates_per_s": n_upd / dt, "minibatch_updates_per_iteration": n_upd,
         "host_to_device_MB_per_iteration": sum(v.nbytes for v in cols.values()) / 1e6,
+        "collector": (dict(kind="NativeCollector on jh_control (synthetic stand-in for MuJoCo Hopper)", **collector.stats()) if collector is not None else None),
+        "env_transitions_per_s_end_to_end": (M / dt if collector is not None else None),
         "last_result": {k: float(v) for k, v in r.items()}, "lib_kernels": kern}))
 
 
