@@ -137,6 +137,14 @@ int jh_per_update(jh_per* p, int64_t B, const int64_t* d_idx, const void* d_prio
 int jh_per_sample(jh_per* p, int64_t B, double beta, int64_t n_uniform, const int64_t* h_uniform_slot,
                   const double* h_u, int64_t* d_idx, double* d_w64, float* d_w32, double* d_stats, jh_stream stream);
 /* Blocking read-back of the scalar state (synchronises `stream`). */
+/* Sharded PER for data-parallel learners: every rank samples from its own shard with jh_per_sample;
+ * jh_per_shard_stats writes {root, count, min priority of that sample} (3 float64) for an all-gather over the ranks,
+ * jh_per_weights_sharded recomputes the IS weights of the last sample against the LOGICAL buffer (sum of roots /
+ * counts, maximum weight over the global batch = weight of the smallest gathered priority): per_buffer.py:88-94 for
+ * one tree holding all shards.  d_all3 float64[n_shards][3] in rank order.                                          */
+int jh_per_shard_stats(jh_per* p, int64_t B, double* d_out3, jh_stream stream);
+int jh_per_weights_sharded(jh_per* p, int64_t B, double beta, const double* d_all3, int32_t n_shards, double* d_w64,
+                           float* d_w32, jh_stream stream);
 int jh_per_state(jh_per* p, double* max_priority, double* root, int64_t* tree_index, int64_t* counter, jh_stream stream);
 double* jh_per_tree_ptr(jh_per* p);  /* device float64[2N-1] */
 int64_t jh_per_tree_size(const jh_per* p);

@@ -61,6 +61,8 @@ _PROTOS = {
     "jh_per_sample": (C.c_int, [_vp, _i64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_per_state": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "jh_per_tree_ptr": (_vp, [_vp]),
+    "jh_per_shard_stats": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "jh_per_weights_sharded": (C.c_int, [_vp, _i64, _f64, _vp, _i32, _vp, _vp, _vp]),
     "jh_per_tree_size": (_i64, [_vp]),
     "jh_per_load": (C.c_int, [_vp, _vp, _f64, _i64, _i64]),
     "jh_per_dump": (C.c_int, [_vp, _vp, _vp]),

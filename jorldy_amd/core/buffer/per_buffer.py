@@ -99,11 +99,20 @@ class PERBuffer(ReplayBuffer):
         self._shards = (dist, group)
 
     def _global_weights(self, beta, idx, w_out, stats):
-        from ...parallel import sharded_is_weights
-
+        """parallel.sharded_is_weights (the reference form, used by the gloo test) as two small kernels around ONE
+        all-gather of 3 float64 per rank: jh_per_shard_stats -> all_gather -> jh_per_weights_sharded."""
         dist, group = self._shards
-        w = sharded_is_weights(self._tree.view()[idx], stats[2], float(self.buffer_counter), self.uniform_sample_prob, beta, dist, group)
-        w_out.copy_(w.to(w_out.dtype))
+        G = dist.get_world_size(group)
+        if getattr(self, "_shard_bufs", None) is None or self._shard_bufs[1].numel() != 3 * G:
+            self._shard_bufs = (torch.zeros(3, dtype=torch.float64, device=self.device), torch.zeros(3 * G, dtype=torch.float64, device=self.device))
+        loc, allv = self._shard_bufs
+        B = int(idx.numel())
+        self._tree.shard_stats(B, loc)
+        if G > 1:
+            dist.all_gather_into_tensor(allv, loc, group=group)
+        else:
+            allv.copy_(loc)
+        self._tree.weights_sharded(B, beta, allv, w_out)
 
     def sample_into(self, beta, batch_size, idx_out, w_out):
         """Host RNG draws (reference order) + descent / IS weights into PREALLOCATED idx / weight tensors;

@@ -433,3 +433,57 @@ JH_EXPORT int jh_per_dump(jh_per* p, double* h_tree, jh_stream stream) {
 
 JH_EXPORT double* jh_per_tree_ptr(jh_per* p) { return p ? p->tree : nullptr; }
 JH_EXPORT int64_t jh_per_tree_size(const jh_per* p) { return p ? p->tree_size : -1; }
+
+// ------------------------------------------------------------------------------ sharded PER (data-parallel learners)
+// Every rank owns a shard (own tree) of one logical buffer; sampling is local, the IS weights are those of the single
+// logical tree (jorldy_amd/parallel.py: sharded_is_weights is the reference form of this math):
+//   jh_per_shard_stats      d_out3 = {root_g, count_g, min priority of the LAST sample}   -> all-gathered over the ranks
+//   jh_per_weights_sharded  w_i = ((1 / COUNT) / ((1 - usp) p_i / ROOT + usp / COUNT))^beta / w(min p over all ranks),
+//                           ROOT / COUNT = sums over the G gathered triples (per_buffer.py:88-94 on the logical buffer)
+__global__ void __launch_bounds__(256) jh_per_shard_stats_kernel(const double* __restrict__ tree, int64_t counter, int64_t B,
+                                                                 const double* __restrict__ prio, double* __restrict__ out3) {
+  __shared__ double s_red[16];
+  double mn = 1.7976931348623157e308;
+  for (int64_t b = threadIdx.x; b < B; b += 256) mn = fmin(mn, prio[b]);
+  mn = jh_block_reduce(mn, s_red, JhMin(), 1.7976931348623157e308);
+  if (threadIdx.x == 0) {
+    out3[0] = tree[0];
+    out3[1] = (double)counter;
+    out3[2] = mn;
+  }
+}
+
+__global__ void __launch_bounds__(256) jh_per_weights_sharded_kernel(int64_t B, double beta, double usp, const double* __restrict__ prio,
+                                                                     const double* __restrict__ all3, int G, double* __restrict__ w64,
+                                                                     float* __restrict__ w32) {
+  double root = 0.0, count = 0.0, min_p = 1.7976931348623157e308;
+  for (int g = 0; g < G; ++g) {  // rank order: the same sums on every rank
+    root += all3[3 * g];
+    count += all3[3 * g + 1];
+    min_p = fmin(min_p, all3[3 * g + 2]);
+  }
+  const double uni = 1.0 / count;
+  const double w_max = pow(uni / ((1.0 - usp) * (min_p / root) + usp * uni), beta);
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+    const double w = pow(uni / ((1.0 - usp) * (prio[b] / root) + usp * uni), beta) / w_max;
+    if (w64) w64[b] = w;
+    if (w32) w32[b] = (float)w;
+  }
+}
+
+JH_EXPORT int jh_per_shard_stats(jh_per* p, int64_t B, double* d_out3, jh_stream stream) {
+  JH_ARG(p && d_out3 && B > 0 && B <= p->ws.ws_cap);
+  JH_LAUNCH(jh_per_shard_stats_kernel, dim3(1), dim3(256), 0, jh_s(stream), p->tree, p->counter, B, p->ws.prio, d_out3);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+JH_EXPORT int jh_per_weights_sharded(jh_per* p, int64_t B, double beta, const double* d_all3, int32_t n_shards, double* d_w64,
+                                     float* d_w32, jh_stream stream) {
+  JH_ARG(p && d_all3 && n_shards > 0 && B > 0 && B <= p->ws.ws_cap && (d_w64 || d_w32));
+  int64_t nbl = (B + 255) / 256;
+  JH_LAUNCH(jh_per_weights_sharded_kernel, dim3((unsigned)(nbl < 64 ? nbl : 64)), dim3(256), 0, jh_s(stream), B, beta, p->usp, p->ws.prio,
+            d_all3, n_shards, d_w64, d_w32);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}

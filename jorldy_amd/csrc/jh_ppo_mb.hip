@@ -47,6 +47,10 @@ struct PmbFwd {
 template <int SV, bool GEN, int U>
 __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
   __shared__ float s_acc[4][64][4];
+  // GEN: each wave stages the W1 rows + biases of ITS K quarter in LDS once ([kper][S] | [kper] per wave).  Read straight
+  // from global memory, hipcc fetches them chunk by chunk behind an s_waitcnt vmcnt(0) each: eight serial L2 round
+  // trips (~5 us of the first version's 12.2 us) in front of the MFMAs
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
   const int K = g.H, tiles_n = K / 16;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
@@ -70,6 +74,27 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
       for (int s = 0; s < 8; ++s) xr[s] = s < g.S ? g.x[row * g.S + s] : 0.f;
     }
   }
+  float* w1s = s_dyn + (size_t)wid * kper * (g.S + 1);
+  float* b1s = w1s + (size_t)kper * g.S;
+  if (GEN && kend > kbeg) {
+    const int n_el = (kend - kbeg) * g.S;
+    const float* src = g.W1 + (size_t)kbeg * g.S;
+    if (SV > 0) {
+      for (int i = lane * 4; i < n_el; i += 256) *reinterpret_cast<float4*>(w1s + i) = *reinterpret_cast<const float4*>(src + i);
+    } else {
+      for (int i = lane; i < n_el; i += 64) w1s[i] = src[i];
+    }
+    for (int i = lane; i < kend - kbeg; i += 64) b1s[i] = g.b1[kbeg + i];
+    // wave-local hand-off: this wave's own ds_writes are ordered before its ds_reads
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
+  // epilogue operands (bias, head weight columns) fetched NOW: behind the split-K barrier they would be one more
+  // dependent L2 round trip on the critical path
+  const float b2 = g.b2[n];
+  float whv[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) whv[o] = o < g.n_out ? g.wh[o][n] : 0.f;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool st_h1 = GEN && g.h1_out && tn == 0;
   for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
@@ -88,7 +113,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
       const bool ok = m_ok && kb < kend;
       if (GEN) {
         // layer 1 exactly as jh_mlp_l1_kernel: fmaf chain over s from 0, + bias, relu
-        const float4 bb = *reinterpret_cast<const float4*>(g.b1 + kc);
+        const float4 bb = *reinterpret_cast<const float4*>(b1s + (kc - kbeg));
         const float bj[4] = {bb.x, bb.y, bb.z, bb.w};
         float a[4];
 #pragma unroll
@@ -97,13 +122,13 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
           if (SV > 0) {
 #pragma unroll
             for (int q = 0; q < SV; ++q) {
-              const float4 w = *reinterpret_cast<const float4*>(g.W1 + (size_t)(kc + j) * g.S + 4 * q);
+              const float4 w = *reinterpret_cast<const float4*>(w1s + (size_t)(kc - kbeg + j) * g.S + 4 * q);
               t = fmaf(xr[4 * q], w.x, t); t = fmaf(xr[4 * q + 1], w.y, t); t = fmaf(xr[4 * q + 2], w.z, t); t = fmaf(xr[4 * q + 3], w.w, t);
             }
           } else {
 #pragma unroll
             for (int s = 0; s < 8; ++s)
-              if (s < g.S) t = fmaf(xr[s], g.W1[(size_t)(kc + j) * g.S + s], t);
+              if (s < g.S) t = fmaf(xr[s], w1s[(size_t)(kc - kbeg + j) * g.S + s], t);
           }
           t += bj[j];
           a[j] = t > 0.f ? t : 0.f;
@@ -126,7 +151,6 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
   for (int i = 0; i < 4; ++i) s_acc[wid][lane][i] = acc[i];
   __syncthreads();
   if (wid != 0) return;
-  const float b2 = g.b2[n];
   float hv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -138,8 +162,10 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
     if (mm < g.M && g.h2_out) g.h2_out[(size_t)mm * K + n] = v;
   }
   // partial head outputs of this 16-column tile (reduced over the 16 lanes that share kq)
-  for (int o = 0; o < g.n_out; ++o) {
-    const float w = g.wh[o][n];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (o >= g.n_out) break;
+    const float w = whv[o];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float p = hv[i] * w;
@@ -231,6 +257,19 @@ __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s
   __syncthreads();
   const int kper = ((H + 63) / 64) * 16, kbeg = wid * kper;
   const int kend = kbeg + kper < H ? kbeg + kper : H;
+  // epilogue operands of wave 0 (relu'(h1) mask rows, observation row numbers) fetched before the main loop: behind
+  // the split-K barrier they would be dependent L2 round trips on the critical path
+  float2 hmask[4];
+  int64_t xrow[4];
+  if (wid == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mm = m0 + kq * 4 + i;
+      const int mmc = mm < g.B ? mm : g.B - 1;
+      hmask[i] = *reinterpret_cast<const float2*>(g.h1 + (size_t)mmc * H + i0 + 2 * r);
+      xrow[i] = g.x_rows ? g.x_rows[mmc] : (int64_t)mmc;
+    }
+  }
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
   for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
     float4 h2v[U];
@@ -270,17 +309,14 @@ __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s
   __syncthreads();
   if (wid != 0) return;
   float v[2][4];
-  int64_t xrow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mm = m0 + kq * 4 + i;
-    const int mmc = mm < g.B ? mm : g.B - 1;
-    const float2 hh = *reinterpret_cast<const float2*>(g.h1 + (size_t)mmc * H + i0 + 2 * r);
+    const float2 hh = hmask[i];
     const float s0 = ((s_acc[0][0][lane][i] + s_acc[1][0][lane][i]) + s_acc[2][0][lane][i]) + s_acc[3][0][lane][i];
     const float s1 = ((s_acc[0][1][lane][i] + s_acc[1][1][lane][i]) + s_acc[2][1][lane][i]) + s_acc[3][1][lane][i];
     v[0][i] = (mm < g.B && hh.x > 0.f) ? s0 : 0.f;  // relu'(h1)
     v[1][i] = (mm < g.B && hh.y > 0.f) ? s1 : 0.f;
-    xrow[i] = g.x_rows ? g.x_rows[mmc] : (int64_t)mmc;
   }
   float* slab = g.part_w1 + (size_t)tm * ((size_t)H * g.S + H);
   for (int s = 0; s < g.S; ++s) {
@@ -503,9 +539,10 @@ static int pmb_fwd_launch(const PmbFwd& g, hipStream_t st) {
   // flops: layer 1 (generated) + the H x H contraction + the heads
   const double fl = 2.0 * g.M * (double)g.H * ((GEN ? g.S : 0) + g.H + g.n_out);
   const char* nm = g.M > 1024 ? "jh_pmb_fwd_nograd" : "jh_pmb_fwd";  // the no-grad pass over [state; next_state] vs a minibatch
-  if (kper > 64) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 8>), dim3(tiles), dim3(256), 0, st, g);
-  else if (kper > 32) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 4>), dim3(tiles), dim3(256), 0, st, g);
-  else JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 2>), dim3(tiles), dim3(256), 0, st, g);
+  const size_t lds = GEN ? sizeof(float) * 4 * (size_t)kper * (g.S + 1) : 0;
+  if (kper > 64) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 8>), dim3(tiles), dim3(256), lds, st, g);
+  else if (kper > 32) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 4>), dim3(tiles), dim3(256), lds, st, g);
+  else JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 2>), dim3(tiles), dim3(256), lds, st, g);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }

@@ -277,6 +277,14 @@ class SumTree:
         L.check(self.lib.jh_per_sample(self.h, B, float(beta), int(uniform_slot.size), L.ptr(uniform_slot), L.ptr(u), L.ptr(idx), L.ptr(w64), L.ptr(w32), L.ptr(self._stats), L.stream_ptr()))
         return idx, w64, w32, self._stats
 
+    def shard_stats(self, B, out3):
+        """out3 (float64 [3], device) <- {root, count, min priority of the last sample of B}."""
+        L.check(self.lib.jh_per_shard_stats(self.h, int(B), L.ptr(out3), L.stream_ptr()))
+
+    def weights_sharded(self, B, beta, all3, w32):
+        """IS weights of the last sample against the logical buffer described by the gathered triples all3 [G, 3]."""
+        L.check(self.lib.jh_per_weights_sharded(self.h, int(B), float(beta), L.ptr(all3), int(all3.numel() // 3), None, L.ptr(w32), L.stream_ptr()))
+
     def view(self):
         """Zero-copy float64 [2N-1] torch view of the device tree (the library owns the memory)."""
         return _wrap_device(self.lib.jh_per_tree_ptr(self.h), (self.tree_size,), torch.float64, self.device, owner=self)

@@ -560,3 +560,35 @@ def test_c51_sizes_vs_oracle(ops, O, B, A, K, n):
     np.testing.assert_allclose(npy(st)[0], ro["loss"], rtol=2e-5)
     np.testing.assert_allclose(npy(g), ro["d_logit"], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(npy(st)[1], ro["max_Q"], rtol=1e-5)
+
+
+def test_sharded_per_weights_kernels_match_reference_form():
+    """jh_per_shard_stats + jh_per_weights_sharded (the data-parallel learners' IS weights against the logical buffer)
+    == parallel.sharded_is_weights, the form the world-2 gloo test pins against one big tree."""
+    from jorldy_amd import ops
+    import torch
+
+    from jorldy_amd.parallel import sharded_is_weights
+
+    N, B, beta, usp = 300, 48, 0.6, 0.01
+    tree = ops.SumTree(N, usp, device="cuda")
+    rng = np.random.RandomState(0)
+    tree.push(200, rng.rand(200) ** 2 + 0.01)
+    np.random.seed(1)
+    idx, _, w_local, stats = tree.sample(beta, np.random.randint(200, size=3), np.random.uniform(size=B - 3), want_w64=False)
+    loc = torch.zeros(3, dtype=torch.float64, device="cuda")
+    tree.shard_stats(B, loc)
+    p = tree.view()[idx]
+    assert float(loc[0]) == float(tree.view()[0]) and float(loc[1]) == 200.0 and float(loc[2]) == float(p.min())
+    # a second (virtual) shard with a bigger root and a smaller sampled priority
+    all3 = torch.stack([loc, torch.tensor([float(loc[0]) * 1.7, 333.0, float(loc[2]) * 0.4], dtype=torch.float64, device="cuda")]).contiguous()
+    w = torch.empty(B, dtype=torch.float32, device="cuda")
+    tree.weights_sharded(B, beta, all3, w)
+    root_t, count_t, min_p = float(all3[:, 0].sum()), float(all3[:, 1].sum()), float(all3[:, 2].min())
+    uni = 1.0 / count_t
+    ref = (uni / ((1 - usp) * (p / root_t) + usp * uni)) ** beta / (uni / ((1 - usp) * (min_p / root_t) + usp * uni)) ** beta
+    torch.testing.assert_close(w.double(), ref, rtol=1e-6, atol=0)
+    # one shard: identical to the sum-tree kernel's own normalisation and to the reference form
+    tree.weights_sharded(B, beta, loc.reshape(1, 3), w)
+    torch.testing.assert_close(w, w_local, rtol=1e-6, atol=0)
+    torch.testing.assert_close(w.double(), sharded_is_weights(p, loc[0], 200.0, usp, beta), rtol=1e-6, atol=0)
