@@ -328,6 +328,11 @@ int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream str
  * actions, and stepping the envs + writing the transitions.                                        */
 int jh_collector_stats(jh_collector* c, double* act_us_per_step, double* env_us_per_step, int32_t reset);
 
+/* N(0,1) draws on the device for NoisyNet layers (core/network/utils.py:58-60 draws torch.randn per forward):
+ * counter-based (element i of call c = Box-Muller on splitmix64(seed, c, i)); d_state uint64[4] = {seed, call counter,
+ * 0, 0} in DEVICE memory, advanced by the kernel itself, so a replayed hipGraph draws fresh noise every time.        */
+int jh_normal_fill(jh_ctx* ctx, int64_t n, float* d_out, uint64_t* d_state, jh_stream stream);
+
 /* ------------------------------------------------------------------ native value networks
  * The encoders of the DQN / Rainbow / Ape-X family with their learn()-side network work:
  *   kind 0  rainbow  core/network/rainbow.py:8-94: head -> l -> noisy a1|v1 -> noisy a2, v2 -> dueling over K atoms

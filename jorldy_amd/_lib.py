@@ -73,6 +73,7 @@ _PROTOS = {
     "jh_logp_continuous": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "jh_ppo_loss_discrete": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "jh_ppo_loss_continuous": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "jh_normal_fill": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "jh_value_act": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_td_loss": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "jh_c51_loss": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -165,7 +165,9 @@ class Rainbow(DQN):
         net, B = self._net, self.batch_size
         tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, as_float=self._as_float(), out=st["tr"])
         if self._noise is None:
-            st["noise"].normal_()  # three independent draws: network(s), network(s'), target_network(s') (rainbow.py:160-186)
+            if getattr(self, "_normal", None) is None:
+                self._normal = ops.NormalSource(self.device)
+            self._normal.fill(st["noise"])  # three independent draws: network(s), network(s'), target_network(s') (rainbow.py:160-186)
         else:
             for i in range(3):
                 self.network.pack_noise(self._noise[i], st["noise"][i])

@@ -232,3 +232,46 @@ JH_EXPORT int jh_ctx_local_cpulist(jh_ctx* ctx, char* out, int64_t len) {
     if (out[i] == '\n') out[i] = 0;
   return JH_OK;
 }
+
+// ------------------------------------------------------------------------------ device Gaussian draws
+// NoisyNet noise (core/network/utils.py:58-60 draws torch.randn per forward) generated on the device by a counter-based
+// generator: element i of call c = Box-Muller on splitmix64(seed, c, i).  The call counter lives in DEVICE memory and is
+// advanced by the last workgroup to finish (arrival ticket; every workgroup has read the counter before it arrives), so
+// a captured hipGraph draws fresh noise on every replay without any host involvement.
+// d_state: uint64[4] = {seed, call counter, arrival ticket, 0}.
+__global__ void __launch_bounds__(256) jh_normal_fill_kernel(int64_t n, float* __restrict__ out, unsigned long long* __restrict__ state) {
+  const unsigned long long seed = state[0], ctr = state[1];
+  const int64_t pairs = (n + 1) >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * 256) {
+    unsigned long long x = seed * 0x9E3779B97F4A7C15ull + ctr * 0xD1B54A32D192ED03ull + (unsigned long long)i * 0x8CB92BA72F3D8DD7ull;
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    const float u1 = (float)((unsigned)(x >> 40) + 1u) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)((unsigned)(x & 0xFFFFFFull)) * (1.0f / 16777216.0f);  // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.2831853071795865f * u2, &sn, &cs);
+    out[2 * i] = r * cs;
+    if (2 * i + 1 < n) out[2 * i + 1] = r * sn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = __hip_atomic_fetch_add(state + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(state + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(state + 1, ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+JH_EXPORT int jh_normal_fill(jh_ctx* ctx, int64_t n, float* d_out, uint64_t* d_state, jh_stream stream) {
+  JH_ARG(ctx && d_out && d_state && n > 0);
+  const int64_t pairs = (n + 1) / 2;
+  int64_t nb = (pairs + 255) / 256;
+  if (nb > 512) nb = 512;
+  JH_LAUNCH(jh_normal_fill_kernel, dim3((unsigned)nb), dim3(256), 0, jh_s(stream), n, d_out, (unsigned long long*)d_state);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}

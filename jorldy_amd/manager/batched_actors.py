@@ -53,6 +53,7 @@ class BatchedValueActors:
         self._act_pin = torch.empty(self.N, dtype=torch.int64, pin_memory=True)
         self._q_pin = torch.empty(self.N, dtype=torch.float32, pin_memory=True)
         self._noise = torch.empty(max(1, self.net.noise_len), dtype=torch.float32, device=self.device) if self.noisy else None
+        self._normal = ops.NormalSource(self.device) if self.noisy else None
         self._done = torch.cuda.Event()
         self.ticks = 0
         self.sync()
@@ -87,7 +88,7 @@ class BatchedValueActors:
             self._x_dev.copy_(self._x_pin, non_blocking=True)
             noise = None
             if self.noisy and training:
-                noise = self._noise.normal_()
+                noise = self._normal.fill(self._noise)
             self.net.forward(self._x_dev, which=0, noise=noise, out=self._logits)
             ops.value_act(self._logits, self.v_min, self.v_max, eps, u, ra, out=(self._act_dev, self._q_dev))
             self._act_pin.copy_(self._act_dev, non_blocking=True)

@@ -502,6 +502,24 @@ class PPONet:
         return (act, logits, val) if want_logits else act
 
 
+class NormalSource:
+    """jh_normal_fill: N(0,1) draws on the device from a counter-based generator whose call counter lives in device
+    memory (a replayed hipGraph draws fresh noise).  fill(t) overwrites the float32 CUDA tensor t in place."""
+
+    def __init__(self, device, seed=None):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.ctx = L.ctx(self.device.index)
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())  # tied to torch.manual_seed
+        self.state = torch.tensor([int(seed), 0, 0, 0], dtype=torch.int64, device=self.device)
+
+    def fill(self, t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        L.check(self.lib.jh_normal_fill(self.ctx, int(t.numel()), L.ptr(t), L.ptr(self.state), L.stream_ptr()))
+        return t
+
+
 def value_act(logits, v_min=0.0, v_max=0.0, eps=None, u=None, rand_action=None, out=None, want_q_all=False):
     """jh_value_act: network outputs [N, A, K] (K = 1: Q values) -> (action int64 [N], q_taken float32 [N], q_all | None)
     on the device.  eps / u / rand_action: numpy float32 / float64 / int64 [N] (the host's epsilon-greedy draws) or

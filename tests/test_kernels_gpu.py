@@ -592,3 +592,38 @@ def test_sharded_per_weights_kernels_match_reference_form():
     tree.weights_sharded(B, beta, loc.reshape(1, 3), w)
     torch.testing.assert_close(w, w_local, rtol=1e-6, atol=0)
     torch.testing.assert_close(w.double(), sharded_is_weights(p, loc[0], 200.0, usp, beta), rtol=1e-6, atol=0)
+
+
+def test_device_normal_source_statistics_and_graph_replay():
+    """jh_normal_fill (NoisyNet noise on the device, utils.py:58-60): N(0,1) moments, fresh values per call AND per
+    replay of a captured graph (the call counter lives in device memory), reproducible from the seed."""
+    import torch
+
+    from jorldy_amd import ops
+
+    src = ops.NormalSource("cuda:0", seed=123)
+    x = torch.empty(1_000_001, device="cuda")
+    src.fill(x)
+    m, sd = float(x.mean()), float(x.std())
+    kurt = float(((x - m) ** 4).mean() / sd**4)
+    assert abs(m) < 4e-3 and abs(sd - 1) < 4e-3 and abs(kurt - 3) < 0.05, (m, sd, kurt)
+    assert float((x.abs() > 3).float().mean()) == pytest.approx(0.0027, abs=4e-4)
+    first = x[:4096].clone()
+    src.fill(x)
+    assert not torch.equal(first, x[:4096]) and abs(float((first * x[:4096]).mean())) < 0.06  # a new, uncorrelated draw
+    again = ops.NormalSource("cuda:0", seed=123)
+    y = torch.empty(4096, device="cuda")
+    again.fill(y)
+    assert torch.equal(y, first)  # same seed, same first call
+    # inside a captured graph: every replay draws fresh noise
+    y.zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        again.fill(y)
+    outs = []
+    for _ in range(3):
+        g.replay()
+        outs.append(y.clone())
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    assert int(again.state[1]) == 4 and int(again.state[2]) == 0
