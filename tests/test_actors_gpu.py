@@ -82,3 +82,72 @@ def test_batched_actors_equal_the_agents_own_act(name, extra, S):
         np.random.random(N)
         ra = np.random.randint(0, A, size=N)
         assert np.array_equal(a[::2, 0], ra[::2]) and np.array_equal(a[1::2], greedy[1::2])
+
+
+def test_apex_async_actors_ring_learner_end_to_end():
+    """configs[3]'s structure in small: 8 actors act through ONE batched forward per tick on the acting copy (own
+    stream, synced every 25 ticks), the vectorised n-step assembler emits transitions + actor-side priorities into the
+    lock-free staging ring from the actor thread, the learner thread drains + learns (hipGraph captured while the actor
+    thread keeps issuing HIP work).  Accounting must close and the learner must see what the actors produced."""
+    import threading
+    import time
+
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import BatchedValueActors, VecNStepApeX
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    N, n = 8, 3
+    agent = Agent("ape_x", state_size=4, action_size=2, hidden_size=64, network="dueling", batch_size=32, buffer_size=2048, start_train_step=0, n_step=n,
+                  num_workers=N, target_update_period=100, run_step=100000, device="cuda")
+    assert agent.backend == "native"
+    example = {"state": np.zeros((1, 4), np.float32), "action": np.zeros((1, 1), np.int64), "reward": np.zeros((1, n, 1), np.float32),
+               "next_state": np.zeros((1, 4), np.float32), "done": np.zeros((1, n, 1), np.uint8)}
+    ring = agent.memory.make_ring(64 * N, example=example, with_priority=True)
+    env = ops.CartPoleVec(N, seed=1)
+    actors = BatchedValueActors(agent, N)
+    nstep = VecNStepApeX(N, n, agent.gamma, (4,), np.float32)
+    stop, err, ticks = threading.Event(), [], [0]
+
+    def actor_loop():
+        try:
+            torch.cuda.set_device(agent.device)
+            arng_state = np.random.RandomState(3)
+            while not stop.is_set():
+                obs = env.obs()
+                out = actors.act(obs, training=True)
+                _, rew, done = env.step(out["action"])
+                emitted = nstep.push(obs, out["action"], rew.reshape(N, 1), done.reshape(N, 1).astype(np.float32), out["q"])
+                if emitted is not None:
+                    cols, prio = emitted
+                    ring.produce(agent.memory.ring_columns(cols), prio + 1e-3, timeout_ms=2000)
+                ticks[0] += 1
+                if ticks[0] % 25 == 0:
+                    actors.sync()
+        except Exception as e:  # surfaced by the main thread
+            err.append(e)
+
+    th = threading.Thread(target=actor_loop, daemon=True)
+    th.start()
+    losses, step = [], 0
+    t_end = time.time() + 20
+    while len(losses) < 150 and time.time() < t_end and not err:
+        step += 1
+        agent.learn_period_stamp = agent.learn_period
+        r = agent.process(None, step)
+        if r:
+            losses.append(r["loss"])
+    stop.set()
+    th.join(timeout=10)
+    assert not err, err
+    assert len(losses) >= 150 and np.all(np.isfinite(losses)), (len(losses), ticks[0])
+    assert agent._graph is not None, "learn() was not captured while the actor thread was running"
+    st = ring.stats()
+    agent.process(None, step + 1)  # take what the actors published last
+    st2 = ring.stats()
+    assert st2["produced"] == st2["drained"] and st["produced"] >= N * (ticks[0] - n - 1) > 0
+    assert agent.num_transitions == st2["drained"] and agent.memory.size == min(agent.num_transitions, 2048)
+    tree = agent.memory.sum_tree
+    leaves = tree[agent.memory.first_leaf_index : agent.memory.first_leaf_index + agent.memory.size]
+    assert np.all(leaves > 0) and tree[0] == pytest.approx(leaves.sum(), rel=1e-9)
