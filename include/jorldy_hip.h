@@ -124,6 +124,8 @@ void jh_per_destroy(jh_per* p);
 /* per_buffer.py:19-40: n x add_tree_data at tree_index (wraps independently).
  * h_prio == NULL -> every new leaf gets the current max_priority (per_buffer.py:27-31). */
 int jh_per_push(jh_per* p, int64_t n, const double* h_prio, jh_stream stream);
+/* The same append with priorities that already live in HBM (float64 [n], device): jh_feed_tick's actor-side priorities. */
+int jh_per_push_device(jh_per* p, int64_t n, const double* d_prio, jh_stream stream);
 /* per_buffer.py:42-54 applied for b = 0..B-1 in order: d_idx int64[B] TREE-space indices,
  * d_prio float32[B] (prio_dtype JH_F32: the `.item()` of an fp32 tensor, per.py:68-70,
  * rainbow.py:230-231) or float64[B].  Duplicated indices behave sequentially.          */
@@ -420,6 +422,32 @@ int jh_ring_reclaim(jh_ring* r, int32_t wait);
 /* Host-side consumer (tests / CPU plumbing): rows are copied to h_out_cols and their slots recycled at once. */
 int jh_ring_consume_host(jh_ring* r, int64_t max_rows, void* const* h_out_cols, double* h_prio_out, int64_t* n_out);
 int jh_ring_stats(jh_ring* r, int64_t* produced, int64_t* drained, double* producer_wait_ms);
+
+/* ------------------------------------------------------------------ device-resident actor -> replay feed
+ * For N lockstep actors whose frame stacks are already in HBM (they were uploaded for the batched acting forward):
+ * replaces, per tick, the env wrapper's stack bookkeeping as seen by the replay (core/env/atari.py:145-149: consecutive
+ * stacks share C - 1 frames), Ape-X's per-actor n-step deque with actor-side priorities (core/agent/ape_x.py:174-199)
+ * and the transfer of both full stacks of every transition to the learner (process.py:82-97, run_mode.py:300-330).
+ * Planes go into a caller-owned plane pool [n_actors * planes_per_actor][plane_bytes] (each actor owns a private ring of
+ * planes_per_actor slots); a stack is C slot numbers.  A stack that is not its predecessor shifted by one frame (reset,
+ * frame skip glitch, ...) simply appends all C planes: the comparison is bytewise, so the stored content is always exact.
+ * window_ticks: for how many ticks a plane must survive (buffer rows / n_actors + n_step + C + in-flight ticks); when an
+ * actor allocates more than planes_per_actor planes inside that window, bit 0 of the flags word is set (jh_feed_state).
+ * jh_feed_tick: d_obs uint8 [N][C][plane_bytes] = the stacks acted on this tick, d_prev_obs = those of the previous tick
+ * (NULL on the first), d_action int64 [N] / d_q float [N] = action taken and its Q (jh_value_act), h_reward / h_done
+ * float [N] (host) = the env's answer.  From tick n_step on (*emitted = N, else 0) the outputs hold one n-step
+ * transition per actor: slot numbers of state_t and state_{t+n} int64 [N][C], action_t int64 [N], reward float [N][n],
+ * done uint8 [N][n], priority float64 [N] = |G_n - q_t| + prio_eps, all on the device, enqueued on `stream`.          */
+typedef struct jh_feed jh_feed;
+int jh_feed_create(jh_ctx* ctx, int32_t n_actors, int32_t C, int64_t plane_bytes, int32_t n_step, float gamma,
+                   int64_t planes_per_actor, int64_t window_ticks, jh_feed** out);
+void jh_feed_destroy(jh_feed* f);
+int jh_feed_tick(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_prev_obs, uint8_t* d_pool, const int64_t* d_action,
+                 const float* d_q, const float* h_reward, const float* h_done, double prio_eps, int64_t* d_state_ids,
+                 int64_t* d_next_ids, int64_t* d_action_out, float* d_reward_out, uint8_t* d_done_out, double* d_prio_out,
+                 int32_t* emitted, jh_stream stream);
+/* Blocking read of the flags word (bit 0: plane ring overrun) and the number of planes written so far. */
+int jh_feed_state(jh_feed* f, int32_t* h_flags, int64_t* h_planes_written, jh_stream stream);
 
 #ifdef __cplusplus
 }

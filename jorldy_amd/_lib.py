@@ -57,6 +57,7 @@ _PROTOS = {
     "jh_per_create": (C.c_int, [_vp, _i64, _f64, _pp]),
     "jh_per_destroy": (None, [_vp]),
     "jh_per_push": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "jh_per_push_device": (C.c_int, [_vp, _i64, _vp, _vp]),
     "jh_per_update": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp]),
     "jh_per_sample": (C.c_int, [_vp, _i64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_per_state": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_i64), _vp]),
@@ -118,6 +119,10 @@ _PROTOS = {
     "jh_ring_consume_host": (C.c_int, [_vp, _i64, _pp, _vp, C.POINTER(_i64)]),
     "jh_ring_reclaim": (C.c_int, [_vp, _i32]),
     "jh_ring_stats": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_f64)]),
+    "jh_feed_create": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _f32, _i64, _i64, _pp]),
+    "jh_feed_destroy": (None, [_vp]),
+    "jh_feed_tick": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp]),
+    "jh_feed_state": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     "jh_collector_stats": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), _i32]),
     "jh_collector_run": (C.c_int, [_vp, _i32, _i32, _vp]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),

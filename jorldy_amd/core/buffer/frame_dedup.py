@@ -105,3 +105,59 @@ class FramePool:
         return {"frames_uploaded": self.frames_uploaded, "frames_referenced": self.frames_referenced, "pool_slots": self.F,
                 "pool_in_use": self.F - len(self.free), "bytes_per_transition_plain": 2 * self.C * self.elems,
                 "bytes_uploaded_per_transition": self.frames_uploaded * self.elems / max(1, self.frames_referenced // (2 * self.C))}
+
+
+class LockstepFramePool:
+    """The device-fed counterpart of FramePool for N lockstep actors (manager/batched_actors.py: DeviceActorFeed): every
+    actor owns a private ring of `planes_per_actor` plane slots, filled by jh_feed_tick on the acting stream; transitions
+    keep 2 x C slot numbers exactly like FramePool's, so `decode` (and therefore sample / gather / checkpoints) is shared.
+    No host hashing, no host reference counts: a plane outlives every transition that can reference it because an actor
+    allocates at most `planes_per_actor` planes in `window_ticks` ticks (checked on the device, see `check`)."""
+
+    KEYS = ("state", "next_state")
+
+    def __init__(self, buffer_size, n_actors, C, frame_shape, n_step, gamma, device, pool_factor=1.5, in_flight_ticks=64):
+        self.N, self.C, self.frame_shape = int(buffer_size), int(C), tuple(int(v) for v in frame_shape)
+        self.n_actors, self.n_step = int(n_actors), int(n_step)
+        self.elems = int(np.prod(self.frame_shape))
+        live = -(-self.N // self.n_actors)  # ticks until a stored row is overwritten (every tick stores n_actors rows)
+        self.window = live + n_step + 1 + self.C + int(in_flight_ticks)
+        # one new plane per tick unless the stack is discontinuous (reset: C planes); pool_factor is the head room
+        self.R = int(np.ceil(self.window * float(pool_factor))) + 2 * self.C
+        self.F = self.n_actors * self.R
+        self.pool = ops.DeviceStore(self.F, [("frame", L.JH_U8, self.elems, self.frame_shape)], device=device)
+        self.device = self.pool.device
+        self.feed = ops.ActorFeed(self.n_actors, self.C, self.elems, self.n_step, gamma, self.R, self.window, device=self.device)
+        self.planes = self.pool.column("frame")
+        self._idx_buf = {}
+        self.rows_stored = 0
+
+    def encode(self, cols, positions):
+        raise RuntimeError("this buffer is fed on the device (attach_actor_feed): host-side store() is not available")
+
+    def flush(self):
+        pass
+
+    def idx_buffer(self, B):
+        if B not in self._idx_buf:
+            self._idx_buf[B] = torch.zeros(2 * B, self.C, dtype=torch.int64, device=self.device)
+        return self._idx_buf[B]
+
+    def decode(self, fidx, out, as_float):
+        self.pool.gather(fidx.reshape(-1), names=["frame"], as_float=as_float, out={"frame": out.view((-1,) + self.frame_shape)})
+        return out
+
+    def check(self):
+        """Raise if an actor overran its plane ring (blocking read of the device flag)."""
+        flags, written = self.feed.state()
+        if flags & 1:
+            raise RuntimeError(f"plane ring overrun: an actor wrote more than {self.R} planes within {self.window} ticks (stacks are discontinuous "
+                               "far more often than a frame-stacking wrapper implies): raise pool_factor")
+        return written
+
+    def stats(self):
+        written = self.check()
+        return {"planes_written": written, "pool_slots": self.F, "planes_per_actor": self.R, "window_ticks": self.window,
+                "bytes_per_transition_plain": 2 * self.C * self.elems,
+                "pool_bytes_per_buffer_row": self.F * self.elems / self.N,
+                "planes_per_stored_row": written / max(1, self.rows_stored)}

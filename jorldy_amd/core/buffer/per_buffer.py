@@ -38,6 +38,15 @@ class PERBuffer(ReplayBuffer):
         self._tree.push(n, None if priorities is None else np.asarray(priorities, dtype=np.float64).reshape(-1))
         return n
 
+    def store_feed_rows(self, cols, n, priorities=None):
+        """+ the rows' leaves: actor-side priorities (float64, device) or max_priority (per_buffer.py:25-30)."""
+        super().store_feed_rows(cols, n)
+        if priorities is None:
+            self._tree.push(n, None)
+        else:
+            self._tree.push_device(n, priorities)
+        return n
+
     def _defer(self, flat, n, extra=None):
         super()._defer(flat, n, self._next_prio)
 

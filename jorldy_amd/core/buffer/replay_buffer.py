@@ -80,6 +80,33 @@ class ReplayBuffer(BaseBuffer):
         self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
         return n
 
+    # ---- device-resident actor feed (frames once + slot numbers, n-step windows built in HBM) ----
+    def attach_actor_feed(self, n_actors, frame_stack_shape, n_step, gamma, pool_factor=1.5, in_flight_ticks=64):
+        """Turn this (empty) buffer into the sink of a DeviceActorFeed (manager/batched_actors.py): rows hold 2 x C plane
+        slot numbers + action + reward[n] + done[n]; planes live in a LockstepFramePool written by jh_feed_tick.
+        frame_stack_shape = (C, H, W).  Returns the pool."""
+        from .frame_dedup import LockstepFramePool
+
+        assert self._store is None and self._frames is None, "attach the actor feed to an empty buffer"
+        C = int(frame_stack_shape[0])
+        self._frames = LockstepFramePool(self.buffer_size, n_actors, C, frame_stack_shape[1:], n_step, gamma, self.device, pool_factor, in_flight_ticks)
+        self.frame_dedup = True
+        example = {"state": np.zeros((1, C), np.int64), "action": np.zeros((1, 1), np.int64), "reward": np.zeros((1, n_step, 1), np.float32),
+                   "next_state": np.zeros((1, C), np.int64), "done": np.zeros((1, n_step, 1), np.uint8)}
+        self._make_store(example, self.buffer_size)
+        self.first_store = False
+        self._feeds = []
+        return self._frames
+
+    def store_feed_rows(self, cols, n, priorities=None):
+        """Rows emitted by jh_feed_tick (device tensors, stored dtypes, slot numbers for state / next_state)."""
+        self.flush()
+        self._store.push_device(self._flat_cols(cols), n)
+        self._frames.rows_stored += n
+        self.buffer_index = (self.buffer_index + n) % self.buffer_size
+        self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
+        return n
+
     def _defer(self, flat, n, extra=None):
         # rows are copied (the caller may reuse its arrays) straight into preallocated host columns of the stored dtype:
         # no per-store allocations, no concatenate at flush time
@@ -134,9 +161,13 @@ class ReplayBuffer(BaseBuffer):
         """Learner thread: move everything the actors have published into the device ring (async copies on the
         current stream, no intermediate host copy); returns the number of transitions taken."""
         self.flush()
-        n = self._ring.drain(self._store, self._drain_tree(), max_rows)
-        self.buffer_index = (self.buffer_index + n) % self.buffer_size
-        self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
+        n = 0
+        if getattr(self, "_ring", None) is not None:
+            n = self._ring.drain(self._store, self._drain_tree(), max_rows)
+            self.buffer_index = (self.buffer_index + n) % self.buffer_size
+            self.buffer_counter = min(self.buffer_counter + n, self.buffer_size)
+        for feed in getattr(self, "_feeds", ()):  # device-resident producers (DeviceActorFeed)
+            n += feed.drain_into(self)
         return n
 
     def store(self, transitions):

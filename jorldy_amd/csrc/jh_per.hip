@@ -348,6 +348,26 @@ JH_EXPORT int jh_per_push(jh_per* p, int64_t n, const double* h_prio, jh_stream 
   return JH_OK;
 }
 
+// jh_per_push for priorities that are already in HBM (a device-side producer: jh_feed_tick's actor-side priorities).
+JH_EXPORT int jh_per_push_device(jh_per* p, int64_t n, const double* d_prio, jh_stream stream) {
+  JH_ARG(p != nullptr && n >= 0 && d_prio != nullptr);
+  hipStream_t st = jh_s(stream);
+  int64_t done = 0;
+  while (done < n) {  // same segmentation as jh_per_push
+    int64_t seg = n - done;
+    if (seg > kChunk) seg = kChunk;
+    if (p->tree_index + seg > p->tree_size) seg = p->tree_size - p->tree_index;
+    if (p->tree_index < p->deep_first && p->tree_index + seg > p->deep_first) seg = p->deep_first - p->tree_index;
+    int rc = per_apply(p, (int)seg, nullptr, p->tree_index, d_prio + done, JH_F64, PER_DISTINCT | PER_CONTIG, st);
+    if (rc) return rc;
+    p->tree_index += seg;
+    if (p->tree_index == p->tree_size) p->tree_index = p->N - 1;  // per_buffer.py:38-40
+    p->counter = p->counter + seg < p->N ? p->counter + seg : p->N;
+    done += seg;
+  }
+  return JH_OK;
+}
+
 JH_EXPORT int jh_per_update(jh_per* p, int64_t B, const int64_t* d_idx, const void* d_prio, int32_t prio_dtype,
                             jh_stream stream) {
   JH_ARG(p && d_idx && d_prio);

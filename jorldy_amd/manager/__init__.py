@@ -1,4 +1,4 @@
-from .batched_actors import BatchedValueActors, VecNStepApeX
+from .batched_actors import BatchedValueActors, DeviceActorFeed, VecNStepApeX
 from .collector import NativeCollector, VecCollector
 
-__all__ = ["VecCollector", "NativeCollector", "BatchedValueActors", "VecNStepApeX"]
+__all__ = ["VecCollector", "NativeCollector", "BatchedValueActors", "VecNStepApeX", "DeviceActorFeed"]

@@ -132,3 +132,113 @@ class VecNStepApeX:
                 "reward": np.stack([self.reward[k] for k in order[:-1]], axis=1), "next_state": self.state[oN],
                 "done": np.stack([self.done[k] for k in order[:-1]], axis=1).astype(np.uint8)}
         return cols, np.abs(tq - self.q[o0]).reshape(-1).astype(np.float64)
+
+
+class DeviceActorFeed:
+    """BatchedValueActors -> replay, without a second trip over PCIe (SURVEY.md §8f ranks 1-3 in one path).
+
+    The host pipeline (VecNStepApeX + StagingRing) copies every transition's two frame stacks three times on the host
+    and uploads them again although the same pixels were uploaded a moment ago for the batched forward.  Here the
+    tick's stacks stay where the forward read them; jh_feed_tick (csrc/jh_feed.hip) de-duplicates them into the
+    buffer's plane pool and assembles Ape-X's n-step transitions with actor-side priorities (ape_x.py:174-199) on the
+    acting stream; the learner's `memory.drain()` appends the emitted rows device-to-device and pushes their leaves.
+    Only the env's rewards and done flags (2 N floats per tick) go up a second time.
+
+        feed = DeviceActorFeed(actors, agent.memory, n_step, gamma)
+        actor thread:    out = feed.act()            # envs wrote into feed.obs_slab
+                         ... env.step(out["action"]) ...
+                         feed.push(reward, done)     # blocks while `depth` emissions wait for the learner
+        learner thread:  agent.process(None, step)   # -> memory.drain() -> feed.drain_into(memory)
+
+    Emissions are never dropped: the plane rings are sized for rows that are overwritten after buffer_size / N ticks."""
+
+    def __init__(self, actors, memory, n_step, gamma, depth=32, prio_eps=0.0, pool_factor=1.5):
+        import collections
+        import threading
+
+        assert actors.x_dtype == torch.uint8 and actors._x_dev.dim() == 4, "frame-stack observations [N, C, H, W] uint8"
+        self.actors, self.memory, self.N, self.n, self.depth, self.prio_eps = actors, memory, actors.N, int(n_step), int(depth), float(prio_eps)
+        C = actors._x_dev.shape[1]
+        self.pool = memory.attach_actor_feed(self.N, tuple(actors._x_dev.shape[1:]), n_step, gamma, pool_factor, in_flight_ticks=depth + 2)
+        memory._feeds.append(self)
+        dev = actors.device
+        self._obs = [actors._x_dev, torch.empty_like(actors._x_dev)]  # this tick's / the previous tick's stacks
+        mk = lambda shape, dt: torch.empty((self.depth + 1,) + shape, dtype=dt, device=dev)
+        self._out = {"state": mk((self.N, C), torch.int64), "next_state": mk((self.N, C), torch.int64), "action": mk((self.N, 1), torch.int64),
+                     "reward": mk((self.N, self.n, 1), torch.float32), "done": mk((self.N, self.n, 1), torch.uint8), "priority": mk((self.N,), torch.float64)}
+        self._ready = [torch.cuda.Event() for _ in range(self.depth)]     # emission e written (acting stream)
+        self._taken = [torch.cuda.Event() for _ in range(self.depth)]     # emission e stored (learner stream)
+        self._taken_valid = [False] * self.depth
+        self._free = threading.Semaphore(self.depth)
+        self._queue = collections.deque()
+        self._closed = False
+        self.ticks = self.emissions = self.stored_rows = 0
+        self.wait_s = 0.0
+
+    @property
+    def obs_slab(self):
+        return self.actors.obs_slab
+
+    def act(self, obs=None, training=True, random_actions=False):
+        a = self.actors
+        a._x_dev = self._obs[self.ticks & 1]
+        return a.act(obs, training=training, random_actions=random_actions)
+
+    def close(self):
+        """Unblock a producer waiting in push() (end of run)."""
+        self._closed = True
+        self._free.release()
+
+    def push(self, reward, done, timeout_s=None):
+        """The env's answer to the actions of the last act(): enqueue this tick's de-duplication + n-step emission.
+        Returns the number of transitions emitted (0 during the first n ticks), or -1 once close() was called."""
+        import time
+
+        a = self.actors
+        e = self.emissions % self.depth
+        will_emit = self.ticks >= self.n
+        if will_emit:
+            t0 = time.perf_counter()
+            while not self._free.acquire(timeout=0.05):
+                if self._closed or (timeout_s is not None and time.perf_counter() - t0 > timeout_s):
+                    return -1
+            self.wait_s += time.perf_counter() - t0
+            if self._closed:
+                return -1
+        slot = e if will_emit else self.depth  # warm-up ticks write their (unused) outputs to the spare slot
+        out = {k: v[slot] for k, v in self._out.items()}
+        cur, prev = self._obs[self.ticks & 1], (self._obs[(self.ticks + 1) & 1] if self.ticks > 0 else None)
+        with torch.cuda.stream(a.stream):
+            if will_emit and self._taken_valid[e]:
+                a.stream.wait_event(self._taken[e])  # the learner's copies out of this slot are done
+            flat = dict(out)
+            flat["action"], flat["reward"], flat["done"] = out["action"].view(-1), out["reward"].view(self.N, self.n), out["done"].view(self.N, self.n)
+            got = self.pool.feed.tick(cur, prev, self.pool.planes, a._act_dev, a._q_dev, reward, done, flat, self.prio_eps)
+            if got:
+                self._ready[e].record(a.stream)
+        self.ticks += 1
+        if got:
+            self.emissions += 1
+            self._queue.append(e)
+        return got
+
+    def drain_into(self, memory):
+        """Learner thread, learner stream: append every finished emission to the store (device to device) and push its
+        leaves; returns the number of rows taken."""
+        n, cur = 0, torch.cuda.current_stream(self.actors.device)
+        while self._queue:
+            e = self._queue.popleft()
+            cur.wait_event(self._ready[e])
+            cols = {k: self._out[k][e] for k in ("state", "action", "reward", "next_state", "done")}
+            memory.store_feed_rows(cols, self.N, self._out["priority"][e])
+            self._taken[e].record(cur)
+            self._taken_valid[e] = True
+            self._free.release()
+            n += self.N
+        self.stored_rows += n
+        return n
+
+    def stats(self):
+        s = self.pool.stats()
+        s.update({"ticks": self.ticks, "emissions": self.emissions, "stored_rows": self.stored_rows, "producer_wait_ms": self.wait_s * 1e3})
+        return s

@@ -227,6 +227,53 @@ def _wrap_device(ptr_value, shape, dtype, device, owner=None):
 
 
 # ============================================================================= PER sum tree
+class ActorFeed:
+    """jh_feed_*: per-tick frame-stack de-duplication + Ape-X n-step assembly with actor-side priorities for N lockstep
+    actors, entirely in HBM (core/env/atari.py:145-149 + core/agent/ape_x.py:174-199; csrc/jh_feed.hip)."""
+
+    def __init__(self, n_actors, channels, plane_bytes, n_step, gamma, planes_per_actor, window_ticks, device=None):
+        self.lib = L.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.N, self.C, self.n, self.plane = int(n_actors), int(channels), int(n_step), int(plane_bytes)
+        self.h = C.c_void_p()
+        L.check(self.lib.jh_feed_create(L.ctx(self.device.index), self.N, self.C, self.plane, self.n, float(gamma), int(planes_per_actor),
+                                        int(window_ticks), C.byref(self.h)))
+        self._rew = np.empty(self.N, np.float32)
+        self._done = np.empty(self.N, np.float32)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jh_feed_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tick(self, obs, prev_obs, pool, action, q, reward, done, out, prio_eps=0.0):
+        """obs / prev_obs uint8 [N, C, ...] (device; prev_obs None on the first tick), pool = the plane pool column
+        (device), action int64 [N] / q float32 [N] (device), reward / done: host arrays [N].  out: dict of preallocated
+        device tensors state int64 [N, C], next_state int64 [N, C], action int64 [N], reward float32 [N, n],
+        done uint8 [N, n], priority float64 [N].  Returns the number of transitions emitted (0 or N), enqueued on the
+        current stream."""
+        for t in (obs, pool, action, q):
+            assert t.is_cuda and t.is_contiguous()
+        assert obs.dtype == torch.uint8 and action.dtype == torch.int64 and q.dtype == torch.float32
+        assert out["state"].dtype == torch.int64 and out["reward"].dtype == torch.float32 and out["done"].dtype == torch.uint8 and out["priority"].dtype == torch.float64
+        np.copyto(self._rew, np.asarray(reward, dtype=np.float32).reshape(-1))
+        np.copyto(self._done, np.asarray(done, dtype=np.float32).reshape(-1))
+        emitted = C.c_int32(0)
+        L.check(self.lib.jh_feed_tick(self.h, L.ptr(obs), L.ptr(prev_obs), L.ptr(pool), L.ptr(action), L.ptr(q), L.ptr(self._rew), L.ptr(self._done),
+                                      float(prio_eps), L.ptr(out["state"]), L.ptr(out["next_state"]), L.ptr(out["action"]), L.ptr(out["reward"]),
+                                      L.ptr(out["done"]), L.ptr(out["priority"]), C.byref(emitted), L.stream_ptr()))
+        return int(emitted.value)
+
+    def state(self):
+        """(flags, planes written so far); blocking."""
+        fl, pw = C.c_int32(0), C.c_int64(0)
+        L.check(self.lib.jh_feed_state(self.h, C.byref(fl), C.byref(pw), L.stream_ptr()))
+        return int(fl.value), int(pw.value)
+
+
 class SumTree:
     """Device float64 sum tree (jh_per_*), bit-identical to per_buffer.py's numpy tree."""
 
@@ -257,6 +304,11 @@ class SumTree:
         if p is not None:
             assert p.size == n
         L.check(self.lib.jh_per_push(self.h, int(n), L.ptr(p), L.stream_ptr()))
+
+    def push_device(self, n, priorities):
+        """push() with float64 priorities that are already on the device (ActorFeed's actor-side priorities)."""
+        assert priorities.is_cuda and priorities.dtype == torch.float64 and priorities.is_contiguous() and priorities.numel() >= n
+        L.check(self.lib.jh_per_push_device(self.h, int(n), L.ptr(priorities), L.stream_ptr()))
 
     def update(self, idx, prio):
         assert idx.dtype == torch.int64 and idx.is_cuda and prio.is_cuda

@@ -151,3 +151,166 @@ def test_apex_async_actors_ring_learner_end_to_end():
     tree = agent.memory.sum_tree
     leaves = tree[agent.memory.first_leaf_index : agent.memory.first_leaf_index + agent.memory.size]
     assert np.all(leaves > 0) and tree[0] == pytest.approx(leaves.sum(), rel=1e-9)
+
+
+def _sliding_stack_env(rng, N, C, shape, p_reset):
+    """Per tick: every actor's stack slides by one new frame (core/env/atari.py:145-149), or is refilled (reset)."""
+    stacks = rng.randint(0, 256, size=(N, C) + shape).astype(np.uint8)
+    while True:
+        yield stacks.copy()
+        fresh = rng.rand(N) < p_reset
+        new = rng.randint(0, 256, size=(N,) + shape).astype(np.uint8)
+        stacks[:, :-1] = stacks[:, 1:]
+        stacks[:, -1] = new
+        if fresh.any():
+            stacks[fresh] = rng.randint(0, 256, size=(int(fresh.sum()), C) + shape).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape,N,C,n", [((12, 12), 5, 4, 3), ((5, 10), 3, 4, 1), ((7, 9), 4, 1, 2), ((84, 84), 6, 4, 3)])
+def test_device_feed_rows_and_priorities_equal_the_host_assembler(shape, N, C, n):
+    """jh_feed_tick (plane de-duplication + n-step assembly + actor-side priorities in HBM) against the host path it
+    replaces (VecNStepApeX -> PERBuffer.store_soa with full stacks): after the buffer AND the plane rings have wrapped
+    several times, every live row decodes to the same stacks / action / reward / done, and the two sum trees are
+    bit-identical.  Shapes include planes that are not a multiple of 16 bytes and C = 1."""
+    from jorldy_amd.core.buffer import PERBuffer
+    from jorldy_amd.manager import VecNStepApeX
+
+    rng = np.random.RandomState(11)
+    cap, gamma, eps, A = 8 * N, 0.99, 1e-3, 6
+    dev = torch.device("cuda")
+    host = PERBuffer(cap, 1e-3, device=dev)
+    host.first_store = False
+    fed = PERBuffer(cap, 1e-3, device=dev)
+    pool = fed.attach_actor_feed(N, (C,) + shape, n, gamma, pool_factor=1.6, in_flight_ticks=2)
+    nstep = VecNStepApeX(N, n, gamma, (C,) + shape, np.uint8)
+    env = _sliding_stack_env(rng, N, C, shape, 0.08)
+    out = {"state": torch.empty(N, C, dtype=torch.int64, device=dev), "next_state": torch.empty(N, C, dtype=torch.int64, device=dev),
+           "action": torch.empty(N, dtype=torch.int64, device=dev), "reward": torch.empty(N, n, dtype=torch.float32, device=dev),
+           "done": torch.empty(N, n, dtype=torch.uint8, device=dev), "priority": torch.empty(N, dtype=torch.float64, device=dev)}
+    obs_dev = [torch.empty((N, C) + shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+    T = 12 * (cap // N) + 7
+    for t in range(T):
+        obs = next(env)
+        action = rng.randint(0, A, size=(N, 1))
+        q = rng.randn(N, 1).astype(np.float32)
+        reward = rng.choice([-1.0, 0.0, 1.0], size=(N, 1)).astype(np.float32)
+        done = (rng.rand(N, 1) < 0.1).astype(np.float32)
+        obs_dev[t & 1].copy_(torch.from_numpy(obs))
+        got = pool.feed.tick(obs_dev[t & 1], obs_dev[(t + 1) & 1] if t else None, pool.planes, torch.from_numpy(action.reshape(-1)).to(dev),
+                             torch.from_numpy(q.reshape(-1)).to(dev), reward, done, out, eps)
+        emitted = nstep.push(obs, action, reward, done, q)
+        assert (got == N) == (emitted is not None)
+        if got:
+            cols, prio = emitted
+            host.store_soa(cols, prio + eps)
+            fed.store_feed_rows({"state": out["state"], "action": out["action"].view(N, 1), "reward": out["reward"].view(N, n, 1),
+                                 "next_state": out["next_state"], "done": out["done"].view(N, n, 1)}, N, out["priority"])
+            assert np.array_equal(out["priority"].cpu().numpy(), prio + eps)  # float32 fold, float64 leaf: bit for bit
+    assert host.buffer_index == fed.buffer_index and host.buffer_counter == fed.buffer_counter == cap
+    idx = torch.arange(cap, dtype=torch.int64, device=dev)
+    a, b = host.gather(idx, as_float=False), fed.gather(idx, as_float=False)
+    for k in ("state", "next_state", "action", "reward", "done"):
+        assert torch.equal(a[k].reshape(cap, -1).to(torch.float64), b[k].reshape(cap, -1).to(torch.float64)), k
+    assert np.array_equal(host.sum_tree, fed.sum_tree) and host.max_priority == fed.max_priority
+    st = pool.stats()  # also raises on a plane-ring overrun
+    # ~1 plane per actor and tick + C - 1 more per reset, against 2 C planes per transition stored plain
+    assert st["planes_written"] <= N * T * (1 + 0.2 * (C - 1)) + N * C
+    assert st["planes_written"] > 2 * pool.F, "the plane rings did not wrap in this test"
+
+
+def test_device_feed_reports_a_plane_ring_overrun():
+    """Stacks that are discontinuous on EVERY tick write C planes per tick: more than the ring was sized for -> the
+    device flag is raised and surfaces as an error instead of rows silently decoding to newer frames."""
+    from jorldy_amd.core.buffer import ReplayBuffer
+
+    N, C, n, shape, dev = 2, 4, 2, (4, 4), torch.device("cuda")
+    buf = ReplayBuffer(16, device=dev)
+    pool = buf.attach_actor_feed(N, (C,) + shape, n, 0.99, pool_factor=1.0, in_flight_ticks=0)
+    rng = np.random.RandomState(0)
+    out = {"state": torch.empty(N, C, dtype=torch.int64, device=dev), "next_state": torch.empty(N, C, dtype=torch.int64, device=dev),
+           "action": torch.empty(N, dtype=torch.int64, device=dev), "reward": torch.empty(N, n, dtype=torch.float32, device=dev),
+           "done": torch.empty(N, n, dtype=torch.uint8, device=dev), "priority": torch.empty(N, dtype=torch.float64, device=dev)}
+    obs = [torch.empty((N, C) + shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+    z, zq = torch.zeros(N, dtype=torch.int64, device=dev), torch.zeros(N, dtype=torch.float32, device=dev)
+    for t in range(3 * pool.window):
+        obs[t & 1].copy_(torch.from_numpy(rng.randint(0, 256, size=(N, C) + shape).astype(np.uint8)))
+        pool.feed.tick(obs[t & 1], obs[(t + 1) & 1] if t else None, pool.planes, z, zq, np.zeros(N, np.float32), np.zeros(N, np.float32), out)
+    with pytest.raises(RuntimeError, match="plane ring overrun"):
+        pool.check()
+
+
+def test_apex_device_feed_learner_end_to_end():
+    """configs[3]'s structure with the device-resident feed: 8 actors on synthetic frame-stack envs act through one
+    batched forward per tick; their stacks never leave HBM again (DeviceActorFeed: plane pool + n-step rows + actor-side
+    priorities on the acting stream); the learner thread drains device-to-device and learns (captured graph).  The
+    accounting closes, nothing is dropped, and what the learner stored decodes to what the actors saw."""
+    import threading
+    import time
+
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import BatchedValueActors, DeviceActorFeed, VecNStepApeX
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    N, n, C, shape, cap = 8, 3, 4, (44, 52), 1024
+    agent = Agent("ape_x", state_size=[C, 44, 52], action_size=4, hidden_size=64, network="dueling", head="cnn", batch_size=32, buffer_size=cap,
+                  start_train_step=0, n_step=n, num_workers=N, target_update_period=100, run_step=100000, device="cuda")
+    assert agent.backend == "native"
+    actors = BatchedValueActors(agent, N)
+    feed = DeviceActorFeed(actors, agent.memory, n, agent.gamma, depth=8, prio_eps=1e-3)
+    shadow = VecNStepApeX(N, n, agent.gamma, (C,) + shape, np.uint8)  # the host assembler, fed the same ticks
+    rng = np.random.RandomState(5)
+    env = _sliding_stack_env(rng, N, C, shape, 0.02)
+    err, ticks, log = [], [0], []
+    stop = threading.Event()
+
+    def actor_loop():
+        try:
+            torch.cuda.set_device(agent.device)
+            while not stop.is_set():
+                obs = next(env)
+                out = feed.act(obs, training=True)
+                reward = rng.choice([-1.0, 0.0, 1.0], size=(N, 1)).astype(np.float32)
+                done = (rng.rand(N, 1) < 0.01).astype(np.float32)
+                emitted = shadow.push(obs, out["action"], reward, done, out["q"])
+                got = feed.push(reward, done)
+                if got < 0:
+                    return
+                if emitted is not None:
+                    log.append(({k: np.array(v) for k, v in emitted[0].items()}, emitted[1] + 1e-3))  # copies: the assembler's outputs are views
+                    if len(log) > 4:
+                        log[len(log) - 5] = None
+                ticks[0] += 1
+                if ticks[0] % 25 == 0:
+                    actors.sync()
+        except Exception as e:
+            err.append(e)
+
+    th = threading.Thread(target=actor_loop, daemon=True)
+    th.start()
+    losses, step = [], 0
+    t_end = time.time() + 30
+    while len(losses) < 100 and time.time() < t_end and not err:
+        step += 1
+        agent.learn_period_stamp = agent.learn_period
+        r = agent.process(None, step)
+        if r:
+            losses.append(r["loss"])
+    stop.set()
+    feed.close()
+    th.join(timeout=10)
+    assert not err, err
+    assert len(losses) >= 100 and np.all(np.isfinite(losses)), (len(losses), ticks[0])
+    assert agent._graph is not None
+    agent.memory.drain()
+    st = feed.stats()
+    assert st["stored_rows"] == st["emissions"] * N == agent.memory._frames.rows_stored and st["emissions"] >= ticks[0] - n > 0
+    assert st["planes_per_stored_row"] < 2.0, st  # ~1 plane per env step (+ resets) against 8 stored plain
+    # the last rows the learner stored are the last transitions the host assembler produced from the same ticks
+    m = agent.memory
+    want_cols, want_prio = log[st["emissions"] - 1]
+    last = (m.buffer_index - N) % m.buffer_size
+    idx = (last + torch.arange(N, device=agent.device)) % m.buffer_size
+    got = m.gather(idx, as_float=False)
+    for key in ("state", "next_state", "action", "reward", "done"):
+        assert np.array_equal(got[key].cpu().numpy().reshape(N, -1).astype(np.float64), np.asarray(want_cols[key]).reshape(N, -1).astype(np.float64)), key
