@@ -224,17 +224,27 @@ class DeviceActorFeed:
 
     def drain_into(self, memory):
         """Learner thread, learner stream: append every finished emission to the store (device to device) and push its
-        leaves; returns the number of rows taken."""
-        n, cur = 0, torch.cuda.current_stream(self.actors.device)
+        leaves; returns the number of rows taken.  Emission slots are consecutive in memory, so everything that has
+        arrived goes in as one append + one tree push per contiguous run of slots (two at the slot ring's wrap)."""
+        cur = torch.cuda.current_stream(self.actors.device)
+        slots = []
         while self._queue:
-            e = self._queue.popleft()
-            cur.wait_event(self._ready[e])
-            cols = {k: self._out[k][e] for k in ("state", "action", "reward", "next_state", "done")}
-            memory.store_feed_rows(cols, self.N, self._out["priority"][e])
-            self._taken[e].record(cur)
-            self._taken_valid[e] = True
-            self._free.release()
-            n += self.N
+            slots.append(self._queue.popleft())
+        n, i = 0, 0
+        while i < len(slots):
+            j = i
+            while j + 1 < len(slots) and slots[j + 1] == slots[j] + 1:
+                j += 1
+            e0, e1, k = slots[i], slots[j], j - i + 1
+            cur.wait_event(self._ready[e1])  # recorded in stream order: the earlier ones of the run are complete too
+            cols = {key: self._out[key][e0 : e1 + 1].flatten(0, 1) for key in ("state", "action", "reward", "next_state", "done")}
+            memory.store_feed_rows(cols, k * self.N, self._out["priority"][e0 : e1 + 1].flatten(0, 1))
+            for e in range(e0, e1 + 1):
+                self._taken[e].record(cur)
+                self._taken_valid[e] = True
+                self._free.release()
+            n += k * self.N
+            i = j + 1
         self.stored_rows += n
         return n
 

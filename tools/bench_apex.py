@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--e2e", type=int, default=0, help="N > 0: END-TO-END async Ape-X with N actors that really ACT: one batched forward per tick on the GPU "
                                                        "(BatchedValueActors), synthetic Atari-shaped envs, vectorised n-step assembly with actor-side priorities, staging ring, learner")
     ap.add_argument("--sync-period", type=int, default=100, help="--e2e: actor ticks between weight syncs (config.ape_x.atari update_period)")
+    ap.add_argument("--device-feed", action="store_true", help="--e2e: the actors' stacks stay in HBM (DeviceActorFeed: plane pool + n-step assembly + "
+                                                                "actor-side priorities on the acting stream) instead of VecNStepApeX + the pinned staging ring")
     args = ap.parse_args()
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
@@ -45,6 +47,9 @@ def main():
                   uniform_sample_prob=1e-3, num_workers=64, device="cuda", backend=args.backend)
     agent.memory.first_store = False
     rng = np.random.RandomState(0)
+    if args.device_feed:
+        assert args.e2e > 0, "--device-feed is a mode of --e2e"
+        filled = 0  # the feed owns the (empty) buffer's row format: the actors fill it
 
     def synth(m):
         return {"state": rng.randint(0, 256, size=(m, 4, 84, 84), dtype=np.uint8), "action": rng.randint(0, 6, size=(m, 1)),
@@ -53,7 +58,7 @@ def main():
 
     for o in range(0, filled, 2048):
         agent.memory.store_soa(synth(2048), rng.rand(2048) ** 0.5 + 1e-3)
-    chunk, chunk_prio = synth(chunk_rows), rng.rand(chunk_rows) + 1e-3
+    chunk, chunk_prio = (synth(chunk_rows), rng.rand(chunk_rows) + 1e-3) if not args.device_feed else (None, None)
 
     def iteration():
         agent.memory.store_soa(chunk, chunk_prio)  # one actor's update_period transitions + actor-side priorities
@@ -101,12 +106,16 @@ def main():
         #   learner       (this thread) drain the ring into the device store + sum tree, one ApeX.learn() per iteration
         import threading
 
-        from jorldy_amd.manager import BatchedValueActors, VecNStepApeX
+        from jorldy_amd.manager import BatchedValueActors, DeviceActorFeed, VecNStepApeX
 
         NA = args.e2e
-        ring = agent.memory.make_ring(max(16, 64 * 100 // NA) * NA, with_priority=True)
         actors = BatchedValueActors(agent, NA)
-        nstep = VecNStepApeX(NA, n, 0.99, (4, 84, 84), np.uint8)
+        feed = ring = nstep = None
+        if args.device_feed:
+            feed = DeviceActorFeed(actors, agent.memory, n, 0.99, depth=64, prio_eps=1e-3)
+        else:
+            ring = agent.memory.make_ring(max(16, 64 * 100 // NA) * NA, with_priority=True)
+            nstep = VecNStepApeX(NA, n, 0.99, (4, 84, 84), np.uint8)
         frames = rng.randint(0, 256, size=(257, 84, 84), dtype=np.uint8)  # frame pool of the synthetic envs
         stop = threading.Event()
         counters = {"ticks": 0, "t_act": 0.0, "t_host": 0.0}
@@ -120,12 +129,17 @@ def main():
                 obs[:, c] = frames[(pos + c) % 257]
             while not stop.is_set():
                 t0 = time.perf_counter()
-                out = actors.act(None, training=True)
+                out = (feed or actors).act(None, training=True)
                 t1 = time.perf_counter()
                 # env.step for all actors: reward / done draws of SURVEY.md §8d C4, next frame stack = shift in one new frame
                 reward = arng.choice([-1.0, 0.0, 1.0], p=[0.02, 0.9, 0.08], size=(NA, 1)).astype(np.float32)
                 done = (arng.rand(NA, 1) < 1e-3).astype(np.float32)
-                emitted = nstep.push(obs, out["action"], reward, done, out["q"])
+                emitted = None
+                if feed is not None:
+                    if feed.push(reward, done) < 0:
+                        return
+                else:
+                    emitted = nstep.push(obs, out["action"], reward, done, out["q"])
                 pos = (pos + 1) % 257
                 obs[:, :3] = obs[:, 1:]
                 obs[:, 3] = frames[(pos + 3) % 257]
@@ -151,6 +165,10 @@ def main():
             agent.learn_period_stamp = agent.learn_period
             return agent.process(None, step)
 
+    if args.device_feed:  # the actors fill the empty buffer first (the other modes start from 16384 synthetic rows)
+        t_fill = time.perf_counter()
+        while agent.memory.buffer_counter < 16384 and time.perf_counter() - t_fill < 120:
+            iteration()
     for _ in range(args.warmup):
         iteration()
     torch.cuda.synchronize()
@@ -166,9 +184,15 @@ def main():
         ticks = counters["ticks"] - tick0
         e2e_stats = {"actors": args.e2e, "actor_ticks_per_s": ticks / dt, "env_steps_per_s": ticks * args.e2e / dt,
                      "act_ms_per_tick": (counters["t_act"] - tact0) / max(1, ticks) * 1e3, "host_ms_per_tick": (counters["t_host"] - thost0) / max(1, ticks) * 1e3,
-                     "ingested_transitions_per_s": (agent.num_transitions - n0) / dt, "weight_sync_every_ticks": args.sync_period, **ring.stats()}
+                     "ingested_transitions_per_s": (agent.num_transitions - n0) / dt, "weight_sync_every_ticks": args.sync_period,
+                     "path": "device feed (jh_feed_tick)" if feed is not None else "host assembler + pinned staging ring",
+                     **(ring.stats() if ring is not None else {})}
         stop.set()
+        if feed is not None:
+            feed.close()
         th.join(timeout=10)
+        if feed is not None:
+            e2e_stats.update(feed.stats())
         iteration = lambda: agent.learn()
     if args.actors > 0:
         stop.set()
