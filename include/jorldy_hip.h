@@ -268,7 +268,7 @@ int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t*
  * on the flat buckets (ppo.py:166-169).  d_norm_out: optional device float, pre-clip norm.      */
 int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_out, jh_stream stream);
 /* One whole PPO minibatch update (ppo.py:122-169: forward of `state[idx]`, clipped loss forward +
- * backward, encoder backward, clip_grad_norm_, Adam) in 5 launches (csrc/jh_ppo_mb.hip): layer 1 is
+ * backward, encoder backward, clip_grad_norm_, Adam) in 4-5 launches (csrc/jh_ppo_mb.hip): layer 1 is
  * generated in the operand fetch, the heads never exist as tensors (per-column-tile partials are summed
  * by the loss kernel), d(loss)/d(h2) is generated in the operand fetch of its two consumers, and ONE
  * backward grid produces every gradient (dh1 only as the per-row-tile partial sums of dW1 / db1).

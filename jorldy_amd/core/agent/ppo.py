@@ -71,7 +71,7 @@ class PPO(BaseAgent):
             raise ValueError("backend='native' needs head='mlp', an int state_size, Adam without weight decay and <= 8 head outputs")
         self.backend = "native" if (eligible and backend != "torch") else "torch"
         self.use_graph = use_graph
-        # five-launch minibatch update (jh_pponet_ppo_update) for minibatches < 1024 rows; JH_FUSED_UPDATE=0
+        # four- / five-launch minibatch update (jh_pponet_ppo_update) for minibatches < 1024 rows; JH_FUSED_UPDATE=0
         # keeps the forward / loss / backward / Adam calls separate (same results; used by the A/B in bench)
         self.fused_update = os.environ.get("JH_FUSED_UPDATE", "1") == "1"
         # capture the RCCL all-reduce of the data-parallel path inside the hipGraph too (falls back to
@@ -235,7 +235,7 @@ class PPO(BaseAgent):
             stats=torch.zeros(n_upd + 1, 8, dtype=torch.float32, device=self.device),
         )
         # rows of every minibatch of every epoch, gathered once per learn() (jh_ppo_minibatch_rows) when all
-        # minibatches take the five-launch update
+        # minibatches take the four- / five-launch update
         E = self.n_epoch
         if self.fused_update and all(self._net.fused_ok(min(B, M - o)) for o in range(0, M, B)):
             srcs = [st["tr"]["state"], st["tr"]["action"], st["adv"], st["ret"], st["value"], st["logp_old"]]
@@ -265,7 +265,7 @@ class PPO(BaseAgent):
         ops.mean_into(ret, st["stats"][st["n_upd"], 0:1])  # ppo.py:112
         k = 0
         if "rows" in st:
-            # x[idx] of every epoch in one launch, then forward + loss + backward (+ clip + Adam) in 5 launches per
+            # x[idx] of every epoch in one launch, then forward + loss + backward (+ clip + Adam) in 4-5 launches per
             # minibatch on consecutive rows (jh_pponet_ppo_update)
             xs, acts, advs, rets, vals, lps = st["rows"](st["idx"])
             for e in range(self.n_epoch):

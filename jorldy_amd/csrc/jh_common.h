@@ -153,6 +153,7 @@ struct jh_pponet {
   uint64_t act_seed = 0, act_ctr = 0;  // host-side counter-based sampling stream
   float* fwd_part = nullptr;      // [H/16][max_rows][8] per-column-tile partial head outputs (jh_ppo_mb.hip forward)
   float* part_w1 = nullptr;       // [min(max_rows,1024)/16][H*S + H] per-row-tile partial (dW1 | db1) sums
+  float* ssq_part = nullptr;      // [(H/32)^2 + H/32] sums of squares of the gradient tiles written by jh_pmb_bwd's workgroups
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
   float* xg = nullptr;        // [max_rows][S] gathered observation rows (B operand of dW1 on the tiled engine)

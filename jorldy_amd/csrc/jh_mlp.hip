@@ -404,14 +404,52 @@ __global__ void __launch_bounds__(256) jh_gradnorm_kernel(int64_t n, const float
   }
 }
 
+// FUSED (the four-launch minibatch update, jh_ppo_mb.hip): there is no norm kernel in front.  `partial` holds the sums
+// of squares of the gradient tiles the backward's workgroups wrote (dW2 | db2 | head weights and biases), and the
+// (dW1 | db1) head of the bucket still is `tiles_m` per-row-tile slabs in `part`: EVERY workgroup sums all slabs (in
+// row-tile order: the same bits everywhere, so all workgroups derive the same clip coefficient) for the norm, and keeps
+// the elements it is about to update.  164 KB of L2 reads per workgroup for CartPole against a 7 us launch.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       const float* __restrict__ partial, int n_partial,
                                                       const float* __restrict__ hyper, float max_norm,
-                                                      float* __restrict__ norm_out) {
+                                                      float* __restrict__ norm_out, const float* __restrict__ part,
+                                                      int tiles_m, int64_t n_head) {
   __shared__ float s_red[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t h4 = n_head >> 2;
+  if (FUSED) {
+    // tiles_m <= 16 (host).  ALL slab loads of three elements are issued before the first add (48 x 16 bytes in flight
+    // per thread; one wave per SIMD, so the registers are there): in batches of 8 this prologue was six dependent L2
+    // round trips = 6 us, as much as the norm launch it replaces.
+    const float4* part4 = reinterpret_cast<const float4*>(part);
+    constexpr int JU = 3, TU = 16;
+    for (int64_t j0 = 0; j0 * 256 < h4; j0 += JU) {
+      float4 w[JU][TU];
+#pragma unroll
+      for (int ju = 0; ju < JU; ++ju) {
+        const int64_t i = threadIdx.x + 256 * (j0 + ju);
+        const int64_t ic = i < h4 ? i : h4 - 1;
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu) w[ju][tu] = part4[(size_t)(tu < tiles_m ? tu : tiles_m - 1) * h4 + ic];
+      }
+#pragma unroll
+      for (int ju = 0; ju < JU; ++ju) {
+        const int64_t i = threadIdx.x + 256 * (j0 + ju);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu)
+          if (tu < tiles_m) { q.x += w[ju][tu].x; q.y += w[ju][tu].y; q.z += w[ju][tu].z; q.w += w[ju][tu].w; }  // row-tile order
+        if (i < h4) {
+          acc = fmaf(q.x, q.x, acc); acc = fmaf(q.y, q.y, acc); acc = fmaf(q.z, q.z, acc); acc = fmaf(q.w, q.w, acc);
+          if (j0 + ju == blockIdx.x) mine = q;  // element blockIdx.x * 256 + threadIdx.x of the update loop below
+        }
+      }
+    }
+  }
   const float total = sqrtf(jh_block_reduce(acc, s_red, JhAdd(), 0.f));
   const float bc1 = hyper[5], bc2s = hyper[6];
   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total + 1e-6), clamped to 1
@@ -433,7 +471,8 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
   const int64_t n4 = n >> 2;  // the buckets are 16-byte aligned: 16-byte accesses + <= 3 trailing elements
   float4 *p4 = reinterpret_cast<float4*>(p), *g4 = reinterpret_cast<float4*>(g), *m4 = reinterpret_cast<float4*>(m), *v4 = reinterpret_cast<float4*>(v);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    float4 gg = (FUSED && i < h4) ? mine : g4[i];  // h4 <= gridDim.x * 256 (host): a head element is met in the first pass only
     upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
     p4[i] = pp; g4[i] = gg; m4[i] = mm; v4[i] = vv;
   }
@@ -513,6 +552,7 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     JH_HIP(hipMemset(n->g_all, 0, sizeof(float) * 8 * (size_t)max_rows));
     const size_t slabs = (size_t)(((max_rows < 1024 ? max_rows : 1024) + 15) / 16);
     JH_HIP(hipMalloc((void**)&n->part_w1, sizeof(float) * slabs * ((size_t)H * S + H)));
+    JH_HIP(hipMalloc((void**)&n->ssq_part, sizeof(float) * ((size_t)(H / 32) * (H / 32) + H / 32 + 1)));
   }
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
@@ -530,7 +570,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipFree(n->g_all);
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
-  (void)hipFree(n->fwd_part); (void)hipFree(n->part_w1);
+  (void)hipFree(n->fwd_part); (void)hipFree(n->part_w1); (void)hipFree(n->ssq_part);
   (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt); (void)hipFree(n->xg);
   delete n;
 }
@@ -614,7 +654,7 @@ static int pponet_l1(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx
 }
 
 // Forward into the per-column-tile partial heads (n->fwd_part) + activations: the first launch of the
-// five-launch update and of every no-grad pass.  Layer 1 is generated in registers for S <= 8.
+// minibatch update and of every no-grad pass.  Layer 1 is generated in registers for S <= 8.
 static int pponet_forward_partials(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
   const PmbHeads hd = pmb_heads(n);
   if (n->S <= 8) return jh_pmb_forward(n, B, d_x, d_idx, hd, nullptr, true, st);
@@ -735,8 +775,25 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
 }
 
 static int pponet_adam(jh_pponet* n, float max_norm, float* d_norm_out, hipStream_t st) {
-  JH_LAUNCH(jh_adam_kernel, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
-            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out);
+  JH_LAUNCH(jh_adam_kernel<false>, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
+            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out, (const float*)nullptr, 0, (int64_t)0);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// The minibatch update's last launch when the backward left sums of squares + (dW1 | db1) slabs behind (see the kernel).
+static bool pponet_adam_fused_ok(const jh_pponet* n, int B) {
+  static const bool off = getenv("JH_PMB_NO_FUSED_ADAM") != nullptr;
+  const int64_t n_head = (int64_t)n->H * n->S + n->H;
+  const int64_t tiles_m = (B + 15) / 16;
+  // every workgroup re-reads all slabs: worth it while that is a fraction of a launch (CartPole: 2560 x 16 floats)
+  return !off && tiles_m <= 16 && n_head * tiles_m <= 65536 && n_head / 4 <= (int64_t)kNormBlocks * 256;
+}
+static int pponet_adam_fused(jh_pponet* n, int B, float max_norm, float* d_norm_out, hipStream_t st) {
+  const int t32 = n->H / 32;
+  JH_LAUNCH(jh_adam_kernel<true>, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
+            n->ssq_part, t32 * t32 + t32, n->hyper, max_norm, d_norm_out, (const float*)n->part_w1, (B + 15) / 16,
+            (int64_t)n->H * n->S + n->H);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
@@ -754,9 +811,10 @@ JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_ou
 int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows, int part_ld,
                               const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
                               const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
-                              float* d_g_all, float* d_stats, hipStream_t st);
+                              float* d_g_all, float* d_stats, float* d_hyper_advance, hipStream_t st);
 
-// One PPO minibatch update (ppo.py:122-169) in five launches (jh_ppo_mb.hip): forward into partial heads,
+// One PPO minibatch update (ppo.py:122-169) in FOUR launches when the (dW1 | db1) slabs are small enough for Adam's
+// prologue to sum them in every workgroup (B <= 256 rows, CartPole / Hopper widths), else five (jh_ppo_mb.hip): forward into partial heads,
 // loss fwd+bwd -> packed head gradients, ONE backward grid (dh1 -> dW1/db1 partials | dW2/db2 | head weights),
 // partial combine + global norm, clip + Adam.  do_adam == 0 stops after the backward with a complete gradient
 // bucket (data-parallel: all-reduce, then jh_pponet_adam_step).
@@ -770,11 +828,13 @@ JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, co
   hipStream_t st = jh_s(stream);
   int rc = pponet_forward_partials(n, B, d_x, d_idx, st);
   if (rc) return rc;
+  const bool fused = do_adam && pponet_adam_fused_ok(n, B);  // four launches: no combine + norm kernel
   rc = jh_ppo_loss_from_partials(n->ctx, n->cont, B, n->A, n->fwd_part, n->H / 16, n->max_rows, (n->cont ? 2 * n->A + 1 : n->A + 1) <= 4 ? 4 : 8, d_idx, d_action, d_adv, d_ret,
-                                 d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, n->g_all, d_stats, st);
+                                 d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, n->g_all, d_stats, fused ? n->hyper : nullptr, st);
   if (rc) return rc;
-  rc = jh_pmb_backward(n, B, d_x, d_idx, pmb_heads(n), st);
+  rc = jh_pmb_backward(n, B, d_x, d_idx, pmb_heads(n), fused, st);
   if (rc) return rc;
+  if (fused) return pponet_adam_fused(n, B, max_norm, nullptr, st);
   rc = jh_pmb_finalize(n, B, do_adam != 0, st);
   if (rc) return rc;
   return do_adam ? pponet_adam(n, max_norm, nullptr, st) : JH_OK;

@@ -299,6 +299,9 @@ struct PpoArgs {
   // sums them in tile order into LDS, which saves the separate heads kernel of the forward pass
   const float* hpart;
   int hp_tiles, hp_rows, hp_ld;  // hp_ld = floats per (tile, row): 4 when there are <= 4 head outputs, else 8
+  // optional (single-workgroup launch only): Adam's hyper block; the step advances here when the minibatch update has
+  // no norm kernel (jh_mlp.hip: four launches) -- the backward kernel must stay idempotent for the profiler's repeats
+  float* hyper_advance;
 };
 
 // z0 / z1: this row's head-0 / head-1 vectors (global memory or the LDS staging), v: value prediction
@@ -450,6 +453,12 @@ __device__ __forceinline__ void ppo_block_reduce6(float (&v)[6], float (*red)[6]
 template <bool CONT>
 __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   __shared__ float s_red6[16][6];
+  if (a.hyper_advance && threadIdx.x == blockDim.x - 1) {  // (not wave 0: it owns the final reductions)  hyper: [1] beta1 [2] beta2 [4] step [5] 1-beta1^t [6] sqrt(1-beta2^t)
+    const float t = a.hyper_advance[4] + 1.f;
+    a.hyper_advance[4] = t;
+    a.hyper_advance[5] = 1.f - powf(a.hyper_advance[1], t);
+    a.hyper_advance[6] = sqrtf(1.f - powf(a.hyper_advance[2], t));
+  }
   extern __shared__ __attribute__((aligned(16))) float s_z[];  // [B][8] when the heads come as partials
   const int i = threadIdx.x;
   const bool on = i < a.B;
@@ -625,20 +634,20 @@ JH_EXPORT int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const fl
 int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows, int part_ld,
                               const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
                               const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
-                              float* d_g_all, float* d_stats, hipStream_t st) {
+                              float* d_g_all, float* d_stats, float* d_hyper_advance, hipStream_t st) {
   JH_ARG(B > 0 && B <= 1024 && d_hpart && d_g_all);
   if (continuous) {
     PpoArgs<true> a{};
     a.B = B; a.A = A; a.idx = d_idx; a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old;
     a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef;
     a.g0 = d_g_all; a.g1 = d_g_all + A; a.gv = d_g_all + 2 * A; a.ldg = 8; a.ldv = 8;
-    a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld;
+    a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld; a.hyper_advance = d_hyper_advance;
     return ppo_launch<true>(ctx, a, st);
   }
   PpoArgs<false> a{};
   a.B = B; a.A = A; a.idx = d_idx; a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old;
   a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef;
   a.g0 = d_g_all; a.g1 = nullptr; a.gv = d_g_all + A; a.ldg = 8; a.ldv = 8;
-  a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld;
+  a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld; a.hyper_advance = d_hyper_advance;
   return ppo_launch<false>(ctx, a, st);
 }

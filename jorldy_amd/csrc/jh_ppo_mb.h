@@ -1,4 +1,4 @@
-// Internal interface of the five-launch PPO minibatch update (jh_ppo_mb.hip), driven by jh_mlp.hip.
+// Internal interface of the four- / five-launch PPO minibatch update (jh_ppo_mb.hip), driven by jh_mlp.hip.
 #pragma once
 #include "jh_common.h"
 
@@ -19,7 +19,8 @@ int jh_pmb_forward(jh_pponet* n, int M, const float* d_x, const int64_t* d_idx, 
                    bool store_act, hipStream_t st);
 int jh_pmb_heads_finish(jh_pponet* n, int M, float* d_head0, float* d_head1, float* d_value, hipStream_t st);
 // n->g_all [B][8] (+ n->h1, n->h2 of the last forward) -> gradient bucket except (W1 | b1), whose per-row-tile
-// partial sums go to n->part_w1
-int jh_pmb_backward(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, const PmbHeads& hd, hipStream_t st);
+// partial sums go to n->part_w1.  emit_ssq: every workgroup that writes gradient tiles also writes their sum of squares to
+// n->ssq_part (the fused Adam launch follows with no norm kernel in between)
+int jh_pmb_backward(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, const PmbHeads& hd, bool emit_ssq, hipStream_t st);
 // (W1 | b1) gradients <- sum of the partials; with_norm: also the global-norm partials + Adam step advance
 int jh_pmb_finalize(jh_pponet* n, int B, bool with_norm, hipStream_t st);

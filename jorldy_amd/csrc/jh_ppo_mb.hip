@@ -10,6 +10,9 @@
 //                           in the operand fetch of both consumers instead of a dh2 kernel + 2 x 512 KB round trip
 //   4 jh_pmb_norm_kernel    sums the dW1 / db1 partials in row-tile order (deterministic) + global-norm partials
 //   5 jh_adam_kernel        (jh_mlp.hip) clip + Adam
+// Minibatches of <= 256 rows skip launch 4: the backward's dW2 / head-weight workgroups also write the sum of squares of
+// their tiles, and EVERY Adam workgroup sums the 16 (dW1 | db1) slabs itself in its prologue (jh_adam_kernel<true>:
+// identical bits in all workgroups -> one clip coefficient).  Measured: Adam 6.9 -> 10.4 us, norm kernel 7.7 us gone.
 //
 // against eleven before (l1, GEMM, heads, loss, dh2, dW_heads, dW2, dh1, dW1, norm, Adam), each of which costs
 // >= 4.5 us of launch ramp / drain at these sizes whatever it computes.
@@ -228,7 +231,14 @@ struct PmbBwd {
   float* dbh[8];
   float* part_w1;  // [ceil(B/16)][H*S + H]: per-row-tile partial sums of (dW1 | db1), flat-bucket order
   int n_dh1, n_dw2;  // workgroups of the first two roles (the rest: head weight gradients)
+  float* ssq_part;   // nullable: [n_dw2 + H/32] sum of squares of what each dW2 / head-weight workgroup wrote
 };
+
+__device__ __forceinline__ float pmb_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 // ---- role: dh1 = relu'(h1) * (dh2 W2) for a 16-row x 32-column tile, reduced on the spot against the
 // observation rows into partial dW1 / db1 (dh1 never reaches HBM)
@@ -404,6 +414,7 @@ __device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s
   }
   __syncthreads();
   if (wid != 0) return;
+  float ssq = 0.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -413,13 +424,22 @@ __device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s
       out.x = ((s_acc[0][t * 2][lane][i] + s_acc[1][t * 2][lane][i]) + s_acc[2][t * 2][lane][i]) + s_acc[3][t * 2][lane][i];
       out.y = ((s_acc[0][t * 2 + 1][lane][i] + s_acc[1][t * 2 + 1][lane][i]) + s_acc[2][t * 2 + 1][lane][i]) + s_acc[3][t * 2 + 1][lane][i];
       *reinterpret_cast<float2*>(g.dW2 + (size_t)o * H + i0 + 2 * r) = out;
+      ssq = fmaf(out.x, out.x, ssq);
+      ssq = fmaf(out.y, out.y, ssq);
     }
     if (tn == 0) {
       float s = ((s_rs[0][t][lane] + s_rs[1][t][lane]) + s_rs[2][t][lane]) + s_rs[3][t][lane];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (kq == 0) g.db2[o0 + 2 * r + t] = s;
+      if (kq == 0) {
+        g.db2[o0 + 2 * r + t] = s;
+        ssq = fmaf(s, s, ssq);
+      }
     }
+  }
+  if (g.ssq_part) {
+    ssq = pmb_wave_sum(ssq);
+    if (lane == 0) g.ssq_part[blk] = ssq;
   }
 }
 
@@ -457,20 +477,31 @@ __device__ __forceinline__ void pmb_role_dwh(const PmbBwd& g, int blk, float (*s
   s_rs[wid][0][lane] = rs;
   __syncthreads();
   if (wid != 0) return;
+  float ssq = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int j = kq * 4 + i;
     if (j < g.n_out) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        g.dwh[j][c0 + 2 * r + t] = ((s_acc[0][t][lane][i] + s_acc[1][t][lane][i]) + s_acc[2][t][lane][i]) + s_acc[3][t][lane][i];
+      for (int t = 0; t < 2; ++t) {
+        const float w = ((s_acc[0][t][lane][i] + s_acc[1][t][lane][i]) + s_acc[2][t][lane][i]) + s_acc[3][t][lane][i];
+        g.dwh[j][c0 + 2 * r + t] = w;
+        ssq = fmaf(w, w, ssq);
+      }
     }
   }
   if (blk == 0) {
     float s = ((s_rs[0][0][lane] + s_rs[1][0][lane]) + s_rs[2][0][lane]) + s_rs[3][0][lane];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (kq == 0 && r < g.n_out) *g.dbh[r] = s;
+    if (kq == 0 && r < g.n_out) {
+      *g.dbh[r] = s;
+      ssq = fmaf(s, s, ssq);
+    }
+  }
+  if (g.ssq_part) {
+    ssq = pmb_wave_sum(ssq);
+    if (lane == 0) g.ssq_part[g.n_dw2 + blk] = ssq;
   }
 }
 
@@ -569,13 +600,14 @@ int jh_pmb_heads_finish(jh_pponet* n, int M, float* d_head0, float* d_head1, flo
   return JH_OK;
 }
 
-int jh_pmb_backward(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, const PmbHeads& hd, hipStream_t st) {
+int jh_pmb_backward(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, const PmbHeads& hd, bool emit_ssq, hipStream_t st) {
   PmbBwd g{};
   g.B = B; g.H = n->H; g.S = n->S; g.n_out = hd.n_out; g.x = d_x; g.x_rows = d_idx;
   g.h1 = n->h1; g.h2 = n->h2; g.g_all = n->g_all; g.W2 = n->params + n->o_w2;
   g.dW2 = n->grads + n->o_w2; g.db2 = n->grads + n->o_b2;
   for (int o = 0; o < hd.n_out; ++o) { g.wh[o] = hd.w[o]; g.dwh[o] = hd.dw[o]; g.dbh[o] = hd.db[o]; }
   g.part_w1 = n->part_w1;
+  g.ssq_part = emit_ssq ? n->ssq_part : nullptr;
   const int t32 = n->H / 32;
   g.n_dh1 = ((B + 15) / 16) * t32;
   g.n_dw2 = t32 * t32;

@@ -531,12 +531,12 @@ class PPONet:
             L.check(self.lib.jh_pponet_adam_step(self.h, float(max_norm if max_norm else 0.0), L.ptr(norm_out), L.stream_ptr()))
 
     def fused_ok(self, B):
-        """Minibatches the five-launch update (jh_pponet_ppo_update) takes: < 1024 rows (from there on the
+        """Minibatches the four- / five-launch update (jh_pponet_ppo_update) takes: < 1024 rows (from there on the
         LDS-tiled engine wins), hidden width a multiple of 32."""
         return self.H % 32 == 0 and 0 < B < 1024
 
     def ppo_update(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, max_norm, stats, do_adam=True):
-        """One whole PPO minibatch update in 5 launches (jh_pponet_ppo_update).  B = idx.numel() <= 1024."""
+        """One whole PPO minibatch update in 4 launches (5 beyond 256 rows or with do_adam=False) (jh_pponet_ppo_update).  B = idx.numel() <= 1024."""
         B = int(idx.numel()) if idx is not None else int(x.shape[0])
         L.check(self.lib.jh_pponet_ppo_update(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
                                               L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
