@@ -446,6 +446,21 @@ int jh_feed_tick(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_prev_obs, ui
                  const float* d_q, const float* h_reward, const float* h_done, double prio_eps, int64_t* d_state_ids,
                  int64_t* d_next_ids, int64_t* d_action_out, float* d_reward_out, uint8_t* d_done_out, double* d_prio_out,
                  int32_t* emitted, jh_stream stream);
+/* jh_feed_tick in two halves (the acting forward runs between them):
+ *   jh_feed_push_stacks  stack mode: the stacks as they were uploaded for the forward (what jh_feed_tick does first)
+ *   jh_feed_push_frames  frame mode: the env hands over only the NEWEST plane of every actor, d_frames uint8 [N][plane_bytes]
+ *                        (device), and h_reset uint8 [N] (host; 1 = the env was reset: the stack is that frame C times,
+ *                        core/env/atari.py:112); the stacks [N][C][plane_bytes] for the forward are rebuilt into d_stack_out
+ *                        by gather from the plane pool.  7 KB instead of 28 KB per env step over PCIe at Atari shapes,
+ *                        and the wrapper's np.concatenate of atari.py:147 has no counterpart at all.
+ *   jh_feed_emit         the second half: action / Q / reward / done -> n-step rows + priorities
+ * A feed uses ONE of the two push modes for its whole life.                                                              */
+int jh_feed_push_stacks(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_prev_obs, uint8_t* d_pool, jh_stream stream);
+int jh_feed_push_frames(jh_feed* f, const uint8_t* d_frames, const uint8_t* h_reset, uint8_t* d_pool, uint8_t* d_stack_out,
+                        jh_stream stream);
+int jh_feed_emit(jh_feed* f, const int64_t* d_action, const float* d_q, const float* h_reward, const float* h_done,
+                 double prio_eps, int64_t* d_state_ids, int64_t* d_next_ids, int64_t* d_action_out, float* d_reward_out,
+                 uint8_t* d_done_out, double* d_prio_out, int32_t* emitted, jh_stream stream);
 /* Blocking read of the flags word (bit 0: plane ring overrun) and the number of planes written so far. */
 int jh_feed_state(jh_feed* f, int32_t* h_flags, int64_t* h_planes_written, jh_stream stream);
 

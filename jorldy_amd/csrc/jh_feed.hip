@@ -29,6 +29,7 @@ struct jh_feed {
   int64_t *ids = nullptr, *cur = nullptr, *alloc_hist = nullptr, *act = nullptr;
   float *rew = nullptr, *done = nullptr, *q = nullptr;
   int32_t *neq = nullptr, *flags = nullptr;
+  bool pushed = false;  // this tick's stacks are in (jh_feed_push_*), jh_feed_emit closes the tick
 };
 
 namespace {
@@ -82,6 +83,54 @@ __global__ void __launch_bounds__(256) jh_feed_append_kernel(FeedAppend g) {
     g.alloc_hist[(size_t)a * g.Th + g.tick % g.Th] = c1;
     // every plane a stored transition can still reference was allocated during the last `window` ticks: they must all
     // fit the actor's ring, or a live row would decode to newer frames
+    const int64_t then = g.tick >= g.window ? g.alloc_hist[(size_t)a * g.Th + (g.tick - g.window) % g.Th] : 0;
+    if (c1 - then > g.R) atomicOr(g.flags, 1);
+  }
+}
+
+// Frame mode: the env hands over only the NEWEST plane of every actor (+ a reset flag).  Block (a, c) rebuilds plane c of
+// the actor's stack for the acting forward -- from the new frame (c == C - 1, or every c after a reset:
+// core/env/atari.py:112 tiles the first frame) or from the plane pool (slot numbers of the previous stack shifted by one) --
+// and block (a, C - 1) appends the new frame to the actor's plane ring.  One plane per actor and tick, always.
+struct FeedFrames {
+  const uint8_t* frames;   // [N][plane]
+  const uint8_t* reset;    // [N] (device-visible pinned memory)
+  uint8_t* pool;
+  uint8_t* stack_out;      // [N][C][plane]
+  const int64_t *cur_in, *ids_prev;
+  int64_t *cur_out, *ids_new, *alloc_hist;
+  int32_t* flags;
+  int N, C, first;
+  int64_t plane, R, window, Th, tick;
+};
+
+__global__ void __launch_bounds__(256) jh_feed_frames_kernel(FeedFrames g) {
+  const int a = blockIdx.x, c = blockIdx.y;
+  const bool fresh = g.first || g.reset[a] != 0;
+  const int64_t c0 = g.cur_in[a];
+  const int64_t slot = (int64_t)a * g.R + c0 % g.R;  // where this tick's frame goes
+  const bool from_frame = fresh || c == g.C - 1;
+  const int64_t src_slot = from_frame ? slot : g.ids_prev[(size_t)a * g.C + c + 1];
+  const uint8_t* x = from_frame ? g.frames + (size_t)a * g.plane : g.pool + (size_t)src_slot * g.plane;
+  uint8_t* y = g.stack_out + ((size_t)a * g.C + c) * g.plane;
+  uint8_t* z = c == g.C - 1 ? g.pool + (size_t)slot * g.plane : nullptr;
+  const int64_t n16 = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)(z ? z : y)) & 15) == 0) ? g.plane >> 4 : 0;
+  for (int64_t i = threadIdx.x; i < n16; i += 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+    reinterpret_cast<uint4*>(y)[i] = v;
+    if (z) reinterpret_cast<uint4*>(z)[i] = v;
+  }
+  for (int64_t i = (n16 << 4) + threadIdx.x; i < g.plane; i += 256) {
+    const uint8_t v = x[i];
+    y[i] = v;
+    if (z) z[i] = v;
+  }
+  if (threadIdx.x != 0) return;
+  g.ids_new[(size_t)a * g.C + c] = src_slot;
+  if (c == 0) {
+    const int64_t c1 = c0 + 1;
+    g.cur_out[a] = c1;
+    g.alloc_hist[(size_t)a * g.Th + g.tick % g.Th] = c1;
     const int64_t then = g.tick >= g.window ? g.alloc_hist[(size_t)a * g.Th + (g.tick - g.window) % g.Th] : 0;
     if (c1 - then > g.R) atomicOr(g.flags, 1);
   }
@@ -177,12 +226,9 @@ JH_EXPORT void jh_feed_destroy(jh_feed* f) {
   delete f;
 }
 
-JH_EXPORT int jh_feed_tick(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_prev_obs, uint8_t* d_pool, const int64_t* d_action,
-                           const float* d_q, const float* h_reward, const float* h_done, double prio_eps, int64_t* d_state_ids,
-                           int64_t* d_next_ids, int64_t* d_action_out, float* d_reward_out, uint8_t* d_done_out,
-                           double* d_prio_out, int32_t* emitted, jh_stream stream) {
-  JH_ARG(f && d_obs && d_pool && d_action && d_q && h_reward && h_done && emitted);
-  JH_ARG(d_state_ids && d_next_ids && d_action_out && d_reward_out && d_done_out && d_prio_out);
+// First half of a tick, stack mode: the actors' stacks as they were uploaded for the forward.
+JH_EXPORT int jh_feed_push_stacks(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_prev_obs, uint8_t* d_pool, jh_stream stream) {
+  JH_ARG(f && d_obs && d_pool && !f->pushed);
   JH_ARG(f->tick == 0 || d_prev_obs != nullptr);
   hipStream_t st = jh_s(stream);
   const int N = f->N, C = f->C, L = f->L;
@@ -202,6 +248,46 @@ JH_EXPORT int jh_feed_tick(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_pr
   ga.N = N; ga.C = C; ga.plane = f->plane; ga.R = f->R; ga.window = f->window; ga.Th = f->Th; ga.tick = t;
   JH_LAUNCH(jh_feed_append_kernel, dim3(N, C), dim3(256), 0, st, ga);
   JH_LAUNCH_CHECK();
+  f->pushed = true;
+  return JH_OK;
+}
+
+// First half of a tick, frame mode: only the newest plane of every actor (device) + the env's reset flags (host);
+// d_stack_out receives the rebuilt stacks [N][C][plane] for the acting forward.
+JH_EXPORT int jh_feed_push_frames(jh_feed* f, const uint8_t* d_frames, const uint8_t* h_reset, uint8_t* d_pool, uint8_t* d_stack_out,
+                                  jh_stream stream) {
+  JH_ARG(f && d_frames && h_reset && d_pool && d_stack_out && !f->pushed);
+  hipStream_t st = jh_s(stream);
+  const int N = f->N, C = f->C, L = f->L;
+  const int64_t t = f->tick;
+  jh_pinned_slab* slab = nullptr;
+  int rc = jh_ctx_slab(f->ctx, (size_t)N, &slab);
+  if (rc) return rc;
+  memcpy(slab->host, h_reset, (size_t)N);
+  const int slot = (int)(t % L), prev = (int)((t + L - 1) % L);
+  FeedFrames g{};
+  g.frames = d_frames; g.reset = static_cast<const uint8_t*>(slab->dev); g.pool = d_pool; g.stack_out = d_stack_out;
+  g.cur_in = f->cur + (size_t)(t & 1) * N; g.cur_out = f->cur + (size_t)((t + 1) & 1) * N;
+  g.ids_prev = f->ids + (size_t)prev * N * C; g.ids_new = f->ids + (size_t)slot * N * C;
+  g.alloc_hist = f->alloc_hist; g.flags = f->flags;
+  g.N = N; g.C = C; g.first = t == 0; g.plane = f->plane; g.R = f->R; g.window = f->window; g.Th = f->Th; g.tick = t;
+  JH_LAUNCH(jh_feed_frames_kernel, dim3(N, C), dim3(256), 0, st, g);
+  JH_LAUNCH_CHECK();
+  rc = jh_ctx_slab_release(f->ctx, slab, st);
+  if (rc) return rc;
+  f->pushed = true;
+  return JH_OK;
+}
+
+// Second half of a tick: the action taken / its Q (device) and the env's answer (host) -> n-step rows (see the header).
+JH_EXPORT int jh_feed_emit(jh_feed* f, const int64_t* d_action, const float* d_q, const float* h_reward, const float* h_done,
+                           double prio_eps, int64_t* d_state_ids, int64_t* d_next_ids, int64_t* d_action_out, float* d_reward_out,
+                           uint8_t* d_done_out, double* d_prio_out, int32_t* emitted, jh_stream stream) {
+  JH_ARG(f && d_action && d_q && h_reward && h_done && emitted && f->pushed);
+  JH_ARG(d_state_ids && d_next_ids && d_action_out && d_reward_out && d_done_out && d_prio_out);
+  hipStream_t st = jh_s(stream);
+  const int N = f->N, C = f->C, L = f->L;
+  const int64_t t = f->tick;
   jh_pinned_slab* slab = nullptr;
   int rc = jh_ctx_slab(f->ctx, sizeof(float) * 2 * (size_t)N, &slab);
   if (rc) return rc;
@@ -220,7 +306,18 @@ JH_EXPORT int jh_feed_tick(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_pr
   if (rc) return rc;
   *emitted = t + 1 >= L ? N : 0;
   f->tick = t + 1;
+  f->pushed = false;
   return JH_OK;
+}
+
+JH_EXPORT int jh_feed_tick(jh_feed* f, const uint8_t* d_obs, const uint8_t* d_prev_obs, uint8_t* d_pool, const int64_t* d_action,
+                           const float* d_q, const float* h_reward, const float* h_done, double prio_eps, int64_t* d_state_ids,
+                           int64_t* d_next_ids, int64_t* d_action_out, float* d_reward_out, uint8_t* d_done_out,
+                           double* d_prio_out, int32_t* emitted, jh_stream stream) {
+  int rc = jh_feed_push_stacks(f, d_obs, d_prev_obs, d_pool, stream);
+  if (rc) return rc;
+  return jh_feed_emit(f, d_action, d_q, h_reward, h_done, prio_eps, d_state_ids, d_next_ids, d_action_out, d_reward_out, d_done_out,
+                      d_prio_out, emitted, stream);
 }
 
 JH_EXPORT int jh_feed_state(jh_feed* f, int32_t* h_flags, int64_t* h_planes_written, jh_stream stream) {

@@ -71,10 +71,11 @@ class BatchedValueActors:
             self.net.params.copy_(self.agent._net.params, non_blocking=True)
 
     @torch.no_grad()
-    def act(self, obs=None, training=True, random_actions=False):
+    def act(self, obs=None, training=True, random_actions=False, upload=True):
         """obs: numpy [N, *obs_shape] (uint8 frames / float32 vectors) or None when the envs wrote into `obs_slab`.
         -> {"action": int64 [N, 1], "q": float32 [N, 1]} (blocking: the envs need the actions).
-        random_actions: the warm-up branch of Rainbow.act / the agents' `memory.size < start_train_step` phase."""
+        random_actions: the warm-up branch of Rainbow.act / the agents' `memory.size < start_train_step` phase.
+        upload=False: the observations are already in `self._x_dev` (a device-side producer on this stream)."""
         if obs is not None:
             np.copyto(self._x_pin.numpy(), obs, casting="same_kind")
         N = self.N
@@ -85,7 +86,8 @@ class BatchedValueActors:
             u = np.random.random(N)                                  # `np.random.random() < epsilon` per actor
             ra = np.random.randint(0, self.net.A, size=N)            # `np.random.randint(0, action_size)` per actor
         with torch.cuda.stream(self.stream):
-            self._x_dev.copy_(self._x_pin, non_blocking=True)
+            if upload:
+                self._x_dev.copy_(self._x_pin, non_blocking=True)
             noise = None
             if self.noisy and training:
                 noise = self._normal.fill(self._noise)
@@ -174,15 +176,48 @@ class DeviceActorFeed:
         self._closed = False
         self.ticks = self.emissions = self.stored_rows = 0
         self.wait_s = 0.0
+        self._mode, self._frames_pin, self._frames_dev = None, None, None
 
     @property
     def obs_slab(self):
         return self.actors.obs_slab
 
     def act(self, obs=None, training=True, random_actions=False):
+        """Stack mode: the envs hand over full stacks [N, C, H, W] (or wrote them into `obs_slab`)."""
+        assert self._mode in (None, "stacks"), "this feed is in frame mode"
+        self._mode = "stacks"
         a = self.actors
         a._x_dev = self._obs[self.ticks & 1]
         return a.act(obs, training=training, random_actions=random_actions)
+
+    @property
+    def frame_slab(self):
+        """Frame mode: numpy view [N, H, W] of a pinned slab for the envs' NEWEST frames (written in place)."""
+        if self._frames_pin is None:
+            shape = (self.N,) + tuple(self._obs[0].shape[2:])
+            self._frames_pin = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+            self._frames_dev = torch.empty(shape, dtype=torch.uint8, device=self.actors.device)
+        return self._frames_pin.numpy()
+
+    def act_frames(self, frames=None, reset=None, training=True, random_actions=False):
+        """Frame mode: the envs hand over only their newest frame [N, H, W] (or wrote it into `frame_slab`) and a reset
+        flag per actor (True: the env was reset, its stack is that frame C times -- core/env/atari.py:112; otherwise the
+        stack slides by one frame, :147).  The stacks for the forward are rebuilt in HBM from the plane pool: 7 KB instead
+        of 28 KB per env step over PCIe at Atari shapes, and no frame-stack bookkeeping on the host at all.  A feed uses
+        either act() or act_frames() for its whole life."""
+        a = self.actors
+        slab = self.frame_slab
+        if frames is not None:
+            np.copyto(slab, frames, casting="same_kind")
+        if reset is None:
+            reset = np.zeros(self.N, np.uint8)
+        assert self._mode in (None, "frames"), "this feed is in stack mode"
+        self._mode = "frames"
+        a._x_dev = self._obs[self.ticks & 1]
+        with torch.cuda.stream(a.stream):
+            self._frames_dev.copy_(self._frames_pin, non_blocking=True)
+            self.pool.feed.push_frames(self._frames_dev, reset, self.pool.planes, a._x_dev)
+        return a.act(None, training=training, random_actions=random_actions, upload=False)
 
     def close(self):
         """Unblock a producer waiting in push() (end of run)."""
@@ -213,7 +248,9 @@ class DeviceActorFeed:
                 a.stream.wait_event(self._taken[e])  # the learner's copies out of this slot are done
             flat = dict(out)
             flat["action"], flat["reward"], flat["done"] = out["action"].view(-1), out["reward"].view(self.N, self.n), out["done"].view(self.N, self.n)
-            got = self.pool.feed.tick(cur, prev, self.pool.planes, a._act_dev, a._q_dev, reward, done, flat, self.prio_eps)
+            if self._mode != "frames":
+                self.pool.feed.push_stacks(cur, prev, self.pool.planes)
+            got = self.pool.feed.emit(a._act_dev, a._q_dev, reward, done, flat, self.prio_eps)
             if got:
                 self._ready[e].record(a.stream)
         self.ticks += 1

@@ -267,6 +267,29 @@ class ActorFeed:
                                       L.ptr(out["done"]), L.ptr(out["priority"]), C.byref(emitted), L.stream_ptr()))
         return int(emitted.value)
 
+    def push_stacks(self, obs, prev_obs, pool):
+        """First half of a tick, stack mode (see tick)."""
+        L.check(self.lib.jh_feed_push_stacks(self.h, L.ptr(obs), L.ptr(prev_obs), L.ptr(pool), L.stream_ptr()))
+
+    def push_frames(self, frames, reset, pool, stack_out):
+        """First half of a tick, frame mode: frames uint8 [N, ...] (device) = the newest plane of every actor, reset: host
+        flags [N]; stack_out uint8 [N, C, ...] (device) <- the rebuilt stacks for the acting forward."""
+        assert frames.is_cuda and frames.is_contiguous() and frames.dtype == torch.uint8 and stack_out.is_cuda and stack_out.is_contiguous()
+        r = np.ascontiguousarray(np.asarray(reset).reshape(-1), dtype=np.uint8)
+        assert r.size == self.N
+        L.check(self.lib.jh_feed_push_frames(self.h, L.ptr(frames), L.ptr(r), L.ptr(pool), L.ptr(stack_out), L.stream_ptr()))
+
+    def emit(self, action, q, reward, done, out, prio_eps=0.0):
+        """Second half of a tick (see tick for the arguments); returns the number of transitions emitted (0 or N)."""
+        assert action.is_cuda and action.dtype == torch.int64 and q.is_cuda and q.dtype == torch.float32
+        np.copyto(self._rew, np.asarray(reward, dtype=np.float32).reshape(-1))
+        np.copyto(self._done, np.asarray(done, dtype=np.float32).reshape(-1))
+        emitted = C.c_int32(0)
+        L.check(self.lib.jh_feed_emit(self.h, L.ptr(action), L.ptr(q), L.ptr(self._rew), L.ptr(self._done), float(prio_eps), L.ptr(out["state"]),
+                                      L.ptr(out["next_state"]), L.ptr(out["action"]), L.ptr(out["reward"]), L.ptr(out["done"]), L.ptr(out["priority"]),
+                                      C.byref(emitted), L.stream_ptr()))
+        return int(emitted.value)
+
     def state(self):
         """(flags, planes written so far); blocking."""
         fl, pw = C.c_int32(0), C.c_int64(0)

@@ -314,3 +314,101 @@ def test_apex_device_feed_learner_end_to_end():
     got = m.gather(idx, as_float=False)
     for key in ("state", "next_state", "action", "reward", "done"):
         assert np.array_equal(got[key].cpu().numpy().reshape(N, -1).astype(np.float64), np.asarray(want_cols[key]).reshape(N, -1).astype(np.float64)), key
+
+
+@pytest.mark.parametrize("shape,N,C,n", [((12, 12), 5, 4, 3), ((5, 10), 3, 4, 1), ((7, 9), 4, 1, 2), ((84, 84), 6, 4, 3)])
+def test_device_feed_frame_mode_equals_host_stacking_and_assembler(shape, N, C, n):
+    """Frame mode (jh_feed_push_frames): the env hands over only its newest frame + a reset flag.  The stacks rebuilt in HBM
+    for the acting forward equal the wrapper's host stacking tick by tick (core/env/atari.py:112 np.tile on reset, :147
+    slide otherwise), and the stored rows / sum tree equal VecNStepApeX -> PERBuffer.store_soa on those host stacks."""
+    from jorldy_amd.core.buffer import PERBuffer
+    from jorldy_amd.manager import VecNStepApeX
+
+    rng = np.random.RandomState(23)
+    cap, gamma, eps, A = 8 * N, 0.99, 1e-3, 6
+    dev = torch.device("cuda")
+    host = PERBuffer(cap, 1e-3, device=dev)
+    host.first_store = False
+    fed = PERBuffer(cap, 1e-3, device=dev)
+    pool = fed.attach_actor_feed(N, (C,) + shape, n, gamma, pool_factor=1.1, in_flight_ticks=2)
+    nstep = VecNStepApeX(N, n, gamma, (C,) + shape, np.uint8)
+    out = {"state": torch.empty(N, C, dtype=torch.int64, device=dev), "next_state": torch.empty(N, C, dtype=torch.int64, device=dev),
+           "action": torch.empty(N, dtype=torch.int64, device=dev), "reward": torch.empty(N, n, dtype=torch.float32, device=dev),
+           "done": torch.empty(N, n, dtype=torch.uint8, device=dev), "priority": torch.empty(N, dtype=torch.float64, device=dev)}
+    stack_dev = torch.empty((N, C) + shape, dtype=torch.uint8, device=dev)
+    stacks = np.zeros((N, C) + shape, np.uint8)
+    T = 12 * (cap // N) + 7
+    for t in range(T):
+        frames = rng.randint(0, 256, size=(N,) + shape).astype(np.uint8)
+        reset = (rng.rand(N) < 0.1) | (t == 0)
+        for a in range(N):  # the env wrapper on the host
+            if reset[a]:
+                stacks[a] = np.tile(frames[a], (C, 1, 1))
+            else:
+                stacks[a] = np.concatenate((stacks[a][1:], frames[a][None]), axis=0)
+        pool.feed.push_frames(torch.from_numpy(frames).to(dev), reset if t else np.zeros(N, np.uint8), pool.planes, stack_dev)  # tick 0 is a reset by itself
+        assert torch.equal(stack_dev.cpu(), torch.from_numpy(stacks)), t
+        action = rng.randint(0, A, size=(N, 1))
+        q = rng.randn(N, 1).astype(np.float32)
+        reward = rng.choice([-1.0, 0.0, 1.0], size=(N, 1)).astype(np.float32)
+        done = (rng.rand(N, 1) < 0.1).astype(np.float32)
+        got = pool.feed.emit(torch.from_numpy(action.reshape(-1)).to(dev), torch.from_numpy(q.reshape(-1)).to(dev), reward, done, out, eps)
+        emitted = nstep.push(stacks, action, reward, done, q)
+        assert (got == N) == (emitted is not None)
+        if got:
+            cols, prio = emitted
+            host.store_soa(cols, prio + eps)
+            fed.store_feed_rows({"state": out["state"], "action": out["action"].view(N, 1), "reward": out["reward"].view(N, n, 1),
+                                 "next_state": out["next_state"], "done": out["done"].view(N, n, 1)}, N, out["priority"])
+    idx = torch.arange(cap, dtype=torch.int64, device=dev)
+    a, b = host.gather(idx, as_float=False), fed.gather(idx, as_float=False)
+    for k in ("state", "next_state", "action", "reward", "done"):
+        assert torch.equal(a[k].reshape(cap, -1).to(torch.float64), b[k].reshape(cap, -1).to(torch.float64)), k
+    assert np.array_equal(host.sum_tree, fed.sum_tree) and host.max_priority == fed.max_priority
+    st = pool.stats()
+    assert st["planes_written"] == N * T and st["planes_written"] > 2 * pool.F  # exactly one plane per env step; the rings wrapped
+
+
+def test_device_actor_feed_frame_mode_through_the_agent():
+    """DeviceActorFeed.act_frames / push / agent.process in one thread: the envs hand over their newest frame only; the
+    actions come from the stacks rebuilt in HBM (equal to the agent's own act() on the host-built stacks), and what the
+    learner's buffer holds afterwards is what the host wrapper + assembler produce from the same frames."""
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import BatchedValueActors, DeviceActorFeed, VecNStepApeX
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    N, n, C, shape, cap = 4, 3, 4, (44, 52), 64
+    agent = Agent("ape_x", state_size=[C, 44, 52], action_size=4, hidden_size=64, network="dueling", head="cnn", batch_size=16, buffer_size=cap,
+                  start_train_step=10**9, n_step=n, num_workers=N, target_update_period=100, run_step=100000, device="cuda")
+    actors = BatchedValueActors(agent, N, epsilons=np.zeros(N))  # greedy: comparable with the agent's own act
+    feed = DeviceActorFeed(actors, agent.memory, n, agent.gamma, depth=4, prio_eps=1e-3)
+    shadow = VecNStepApeX(N, n, agent.gamma, (C,) + shape, np.uint8)
+    rng = np.random.RandomState(9)
+    stacks = np.zeros((N, C) + shape, np.uint8)
+    last = None
+    for t in range(24):
+        frames = rng.randint(0, 256, size=(N,) + shape).astype(np.uint8)
+        reset = (rng.rand(N) < 0.15) | (t == 0)
+        for a in range(N):
+            stacks[a] = np.tile(frames[a], (C, 1, 1)) if reset[a] else np.concatenate((stacks[a][1:], frames[a][None]), axis=0)
+        out = feed.act_frames(frames, reset if t else None, training=True)
+        if t % 8 == 0:  # the stacks rebuilt on the device give the actions the agent computes from the host-built stacks
+            agent.epsilon = 0.0
+            for a in range(N):
+                assert int(agent.act(stacks[a][None], training=False)["action"][0, 0]) == int(out["action"][a, 0]), (t, a)
+        reward = rng.choice([-1.0, 0.0, 1.0], size=(N, 1)).astype(np.float32)
+        done = (rng.rand(N, 1) < 0.05).astype(np.float32)
+        emitted = shadow.push(stacks, out["action"], reward, done, out["q"])
+        assert feed.push(reward, done) == (N if emitted is not None else 0)
+        if emitted is not None:
+            last = ({k: np.array(v) for k, v in emitted[0].items()}, emitted[1] + 1e-3)
+        agent.process(None, t + 1)  # drains (start_train_step keeps learn() out of this test)
+    m = agent.memory
+    assert feed.stats()["stored_rows"] == (24 - n) * N == agent.num_transitions
+    idx = ((m.buffer_index - N) % m.buffer_size + torch.arange(N, device=agent.device)) % m.buffer_size
+    got = m.gather(idx, as_float=False)
+    for key in ("state", "next_state", "action", "reward", "done"):
+        assert np.array_equal(got[key].cpu().numpy().reshape(N, -1).astype(np.float64), np.asarray(last[0][key]).reshape(N, -1).astype(np.float64)), key
+    leaves = m.sum_tree[m.first_leaf_index + idx.cpu().numpy()]
+    assert np.array_equal(leaves, last[1])

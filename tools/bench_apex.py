@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--e2e", type=int, default=0, help="N > 0: END-TO-END async Ape-X with N actors that really ACT: one batched forward per tick on the GPU "
                                                        "(BatchedValueActors), synthetic Atari-shaped envs, vectorised n-step assembly with actor-side priorities, staging ring, learner")
     ap.add_argument("--sync-period", type=int, default=100, help="--e2e: actor ticks between weight syncs (config.ape_x.atari update_period)")
+    ap.add_argument("--frames", action="store_true", help="--device-feed: the envs hand over only their newest 84x84 frame (frame mode: the stack for the "
+                                                           "forward is rebuilt in HBM from the plane pool; 7 KB instead of 28 KB per env step over PCIe)")
     ap.add_argument("--device-feed", action="store_true", help="--e2e: the actors' stacks stay in HBM (DeviceActorFeed: plane pool + n-step assembly + "
                                                                 "actor-side priorities on the acting stream) instead of VecNStepApeX + the pinned staging ring")
     args = ap.parse_args()
@@ -127,9 +129,13 @@ def main():
             pos = arng.randint(0, 257, size=NA)
             for c in range(4):
                 obs[:, c] = frames[(pos + c) % 257]
+            frame_mode = feed is not None and args.frames
+            if frame_mode:
+                newest = feed.frame_slab
+                newest[:] = frames[(pos + 3) % 257]
             while not stop.is_set():
                 t0 = time.perf_counter()
-                out = (feed or actors).act(None, training=True)
+                out = feed.act_frames(None, None, training=True) if frame_mode else (feed or actors).act(None, training=True)
                 t1 = time.perf_counter()
                 # env.step for all actors: reward / done draws of SURVEY.md §8d C4, next frame stack = shift in one new frame
                 reward = arng.choice([-1.0, 0.0, 1.0], p=[0.02, 0.9, 0.08], size=(NA, 1)).astype(np.float32)
@@ -141,8 +147,11 @@ def main():
                 else:
                     emitted = nstep.push(obs, out["action"], reward, done, out["q"])
                 pos = (pos + 1) % 257
-                obs[:, :3] = obs[:, 1:]
-                obs[:, 3] = frames[(pos + 3) % 257]
+                if frame_mode:
+                    newest[:] = frames[(pos + 3) % 257]  # the env's new frame; the wrapper's stack bookkeeping has no counterpart
+                else:
+                    obs[:, :3] = obs[:, 1:]
+                    obs[:, 3] = frames[(pos + 3) % 257]
                 if emitted is not None:
                     cols, prio = emitted
                     try:
@@ -185,7 +194,7 @@ def main():
         e2e_stats = {"actors": args.e2e, "actor_ticks_per_s": ticks / dt, "env_steps_per_s": ticks * args.e2e / dt,
                      "act_ms_per_tick": (counters["t_act"] - tact0) / max(1, ticks) * 1e3, "host_ms_per_tick": (counters["t_host"] - thost0) / max(1, ticks) * 1e3,
                      "ingested_transitions_per_s": (agent.num_transitions - n0) / dt, "weight_sync_every_ticks": args.sync_period,
-                     "path": "device feed (jh_feed_tick)" if feed is not None else "host assembler + pinned staging ring",
+                     "path": ("device feed, frame mode (jh_feed_push_frames)" if args.frames else "device feed (jh_feed_tick)") if feed is not None else "host assembler + pinned staging ring",
                      **(ring.stats() if ring is not None else {})}
         stop.set()
         if feed is not None:
