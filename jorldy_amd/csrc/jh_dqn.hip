@@ -143,6 +143,7 @@ struct C51Args {
   const float *logit, *next_logit, *target_logit, *action, *reward, *done, *weights;
   float v_min, v_max, gamma, alpha;
   float *grad, *prio, *kl, *stats, *partial;
+  const float* wmean;  // wave-per-sample kernel: the batch mean of `weights`, computed once by jh_mean_f32 in front of it
 };
 
 // torch.linspace(v_min, v_max, K) in float32 (symmetric form used by ATen)
@@ -282,12 +283,8 @@ __global__ void __launch_bounds__(256) jh_c51_kernel(C51Args a) {
     kl = -jh_wave_sum(klp);  // rainbow.py:227
     mt_sum = jh_wave_sum(mt_sum);
     // ---- effective per-sample weight: rainbow's (B,1)*(B,) broadcast makes it the batch MEAN
-    float weff = 1.f;
-    if (a.flags & JH_C51_PER) {
-      float ws = 0.f;
-      for (int i = lane; i < a.B; i += 64) ws += a.weights[i];
-      weff = jh_wave_sum(ws) / (float)a.B;
-    }
+    // (every wave summing all B weights itself made this kernel O(B^2): 1.13 ms at B = 65 536, 2 % of the HBM roofline)
+    const float weff = (a.flags & JH_C51_PER) ? *a.wmean : 1.f;
     const float scale = weff / (float)a.B;
     for (int aa = 0; aa < a.A; ++aa) {
       float* g = a.grad + ((size_t)b * a.A + aa) * K;
@@ -513,9 +510,15 @@ JH_EXPORT int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t 
   const bool per_block = B <= 1024;  // latency regime: one workgroup per sample, softmaxes spread over its waves
   const int nb = per_block ? B : (B + 3) / 4;
   void* scratch = nullptr;
-  int rc = jh_ctx_scratch(ctx, sizeof(float) * 4 * (size_t)nb, &scratch);
+  int rc = jh_ctx_scratch(ctx, sizeof(float) * (4 * (size_t)nb + 4), &scratch);
   if (rc) return rc;
   a.partial = (float*)scratch;
+  if (!per_block && (flags & JH_C51_PER)) {
+    float* wmean = (float*)scratch + 4 * (size_t)nb;
+    rc = jh_mean_f32(ctx, B, d_weights, wmean, stream);
+    if (rc) return rc;
+    a.wmean = wmean;
+  }
   if (per_block) {
     const size_t lds = sizeof(float) * (6 * (size_t)K + (size_t)A + 12);
     JH_LAUNCH(jh_c51_block_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);

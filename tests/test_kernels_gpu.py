@@ -542,10 +542,11 @@ def test_rainbow_fixture(ops):
     np.testing.assert_allclose(npy(g), z["learn/d_logit"], rtol=1e-4, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,A,K,n", [(1, 2, 11, 1), (7, 4, 51, 3), (33, 6, 51, 3), (64, 3, 200, 2)])
+@pytest.mark.parametrize("B,A,K,n", [(1, 2, 11, 1), (7, 4, 51, 3), (33, 6, 51, 3), (64, 3, 200, 2), (1500, 4, 51, 3)])
 def test_c51_sizes_vs_oracle(ops, O, B, A, K, n):
-    """Includes K > 64 (several atoms per lane), terminal rows, and rewards that push Tz onto exact
-    atoms / outside the support."""
+    """Includes K > 64 (several atoms per lane), terminal rows, rewards that push Tz onto exact atoms / outside the
+    support, and B > 1024 (the wave-per-sample kernel with the precomputed batch-mean weight; smaller batches take the
+    workgroup-per-sample kernel)."""
     rng = np.random.RandomState(B * 100 + K)
     logit = rng.randn(B, A, K).astype(np.float32)
     nlo, tl = rng.randn(B, A, K).astype(np.float32), rng.randn(B, A, K).astype(np.float32)
