@@ -248,7 +248,13 @@ class ReplayBuffer(BaseBuffer):
         return {"buffer_size": self.buffer_size, "buffer_index": self.buffer_index, "buffer_counter": self.buffer_counter,
                 "layout": self._layout, "columns": cols}
 
+    def _refuse_load_when_fed(self):
+        if getattr(self, "_feeds", None):
+            raise RuntimeError("this buffer is the sink of a DeviceActorFeed: its rows reference the feed's plane rings; restore into a fresh "
+                               "buffer (the saved form is the portable full-stack one) -- re-attaching a feed to restored rows is not supported")
+
     def load_state_dict(self, sd):
+        self._refuse_load_when_fed()
         assert sd["buffer_size"] == self.buffer_size
         self._pending, self._pending_rows, self._pend_cols = [], 0, None
         self._frames = None
@@ -325,6 +331,7 @@ class ReplayBuffer(BaseBuffer):
         import ctypes as C
         import os
 
+        self._refuse_load_when_fed()
         assert meta["buffer_size"] == self.buffer_size
         self._pending, self._pending_rows, self._pend_cols = [], 0, None
         self._frames = self._layout = self._store = None

@@ -367,6 +367,20 @@ def test_device_feed_frame_mode_equals_host_stacking_and_assembler(shape, N, C, 
     assert np.array_equal(host.sum_tree, fed.sum_tree) and host.max_priority == fed.max_priority
     st = pool.stats()
     assert st["planes_written"] == N * T and st["planes_written"] > 2 * pool.F  # exactly one plane per env step; the rings wrapped
+    if shape == (12, 12):  # checkpoints of a fed buffer are the portable full-stack form: they restore into a plain buffer
+        import tempfile
+
+        with tempfile.TemporaryDirectory() as tmp:
+            meta = fed.save_stream(tmp)
+            plain = PERBuffer(cap, 1e-3, device=dev)
+            plain.load_stream(tmp, meta)
+            with pytest.raises(RuntimeError, match="sink of a DeviceActorFeed"):
+                fed._feeds.append(object())
+                fed.load_stream(tmp, meta)
+        c = plain.gather(idx, as_float=False)
+        for k in ("state", "next_state", "action", "reward", "done"):
+            assert torch.equal(a[k].reshape(cap, -1).to(torch.float64), c[k].reshape(cap, -1).to(torch.float64)), k
+        assert np.array_equal(host.sum_tree, plain.sum_tree) and plain.buffer_index == host.buffer_index
 
 
 def test_device_actor_feed_frame_mode_through_the_agent():
