@@ -193,7 +193,9 @@ __global__ void __launch_bounds__(256) jh_per_sample_kernel(const double* __rest
                                                             const double* __restrict__ u, int64_t counter, double usp,
                                                             double beta, int64_t* __restrict__ idx_out,
                                                             double* __restrict__ prio_ws, double* __restrict__ w_ws,
-                                                            double* __restrict__ partial) {
+                                                            double* __restrict__ partial, int fuse_norm,
+                                                            double* __restrict__ w64, float* __restrict__ w32,
+                                                            double* __restrict__ stats) {
   __shared__ double s_red[16];
   const double root = tree[0];
   const double uniform_probs = 1.0 / (double)counter;
@@ -227,6 +229,22 @@ __global__ void __launch_bounds__(256) jh_per_sample_kernel(const double* __rest
   if (threadIdx.x == 0) {
     partial[2 * blockIdx.x] = bw;
     partial[2 * blockIdx.x + 1] = bp;
+  }
+  if (fuse_norm) {
+    // B <= 256: ONE workgroup holds the whole batch, a thread's only sample is still in its registers -- the
+    // normalisation of jh_per_norm_kernel right here (same values: its max / sum over ONE partial are bw / bp), one
+    // launch less in front of every learn() of the B = 32 configurations
+    if (threadIdx.x < B) {
+      const double w = my_w / bw;  // per_buffer.py:94  (my_w = fmax(0, w) = w: the weights are positive)
+      if (w64) w64[threadIdx.x] = w;
+      if (w32) w32[threadIdx.x] = (float)w;
+    }
+    if (threadIdx.x == 0 && stats) {
+      stats[0] = bp / (double)B;
+      stats[1] = root / (double)counter;
+      stats[2] = root;
+      stats[3] = bw;
+    }
   }
 }
 
@@ -411,13 +429,16 @@ JH_EXPORT int jh_per_sample(jh_per* p, int64_t B, double beta, int64_t n_uniform
   if (B - n_uniform) memcpy((char*)slab->host + off_u, h_u, sizeof(double) * (size_t)(B - n_uniform));
   int64_t nbl = (B + 255) / 256;
   const int nb = (int)(nbl < kMaxBlocks ? nbl : kMaxBlocks);
+  const int fuse = B <= 256 ? 1 : 0;
   JH_LAUNCH(jh_per_sample_kernel, dim3(nb), dim3(256), 0, st, p->tree, p->N - 1, B, n_uniform,
                      (const int64_t*)slab->dev, (const double*)((char*)slab->dev + off_u), p->counter, p->usp, beta,
-                     d_idx, p->ws.prio, p->ws.w, p->ws.partial);
+                     d_idx, p->ws.prio, p->ws.w, p->ws.partial, fuse, d_w64, d_w32, d_stats);
   JH_LAUNCH_CHECK();
-  JH_LAUNCH(jh_per_norm_kernel, dim3(nb), dim3(256), 0, st, p->tree, B, nb, p->ws.partial, p->ws.w,
-                     p->counter, d_w64, d_w32, d_stats);
-  JH_LAUNCH_CHECK();
+  if (!fuse) {
+    JH_LAUNCH(jh_per_norm_kernel, dim3(nb), dim3(256), 0, st, p->tree, B, nb, p->ws.partial, p->ws.w,
+                       p->counter, d_w64, d_w32, d_stats);
+    JH_LAUNCH_CHECK();
+  }
   return jh_ctx_slab_release(p->ctx, slab, st);
 }
 
