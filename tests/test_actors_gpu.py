@@ -426,3 +426,58 @@ def test_device_actor_feed_frame_mode_through_the_agent():
         assert np.array_equal(got[key].cpu().numpy().reshape(N, -1).astype(np.float64), np.asarray(last[0][key]).reshape(N, -1).astype(np.float64)), key
     leaves = m.sum_tree[m.first_leaf_index + idx.cpu().numpy()]
     assert np.array_equal(leaves, last[1])
+
+
+def test_device_feed_full_size_chain_property():
+    """configs[3] shapes (64 actors, (4,84,84) frames, n = 3) at a size the host assembler is too slow to shadow in a
+    test: size-independent properties of what the feed stored.  (a) next_state of the row (tick k, actor a) is the state
+    of the row (tick k + n, actor a); (b) a state is its predecessor's shifted by one frame unless the env was reset,
+    where it is one frame C times; (c) the newest plane of every state is the frame the env handed over at that tick
+    (checked through a per-frame checksum); (d) exactly one plane per env step was written and nothing overran."""
+    from jorldy_amd.core.buffer import PERBuffer
+
+    N, C, n, shape, dev = 64, 4, 3, (84, 84), torch.device("cuda")
+    ticks_kept = 96
+    cap = N * ticks_kept
+    buf = PERBuffer(cap, 1e-3, device=dev)
+    pool = buf.attach_actor_feed(N, (C,) + shape, n, 0.99, pool_factor=1.1, in_flight_ticks=2)
+    g = torch.Generator(device=dev).manual_seed(5)
+    out = {"state": torch.empty(N, C, dtype=torch.int64, device=dev), "next_state": torch.empty(N, C, dtype=torch.int64, device=dev),
+           "action": torch.empty(N, dtype=torch.int64, device=dev), "reward": torch.empty(N, n, dtype=torch.float32, device=dev),
+           "done": torch.empty(N, n, dtype=torch.uint8, device=dev), "priority": torch.empty(N, dtype=torch.float64, device=dev)}
+    stack = torch.empty((N, C) + shape, dtype=torch.uint8, device=dev)
+    rng = np.random.RandomState(3)
+    T = 3 * ticks_kept + 11
+    sums, resets = [], []
+    zq = torch.zeros(N, dtype=torch.float32, device=dev)
+    for t in range(T):
+        frames = torch.randint(0, 256, (N,) + shape, dtype=torch.uint8, device=dev, generator=g)
+        reset = (rng.rand(N) < 0.02) | (t == 0)
+        sums.append(frames.view(N, -1).to(torch.int64).sum(1))  # checksum of the frame handed over at tick t
+        resets.append(reset.copy())
+        pool.feed.push_frames(frames, reset if t else np.zeros(N, np.uint8), pool.planes, stack)
+        act = torch.full((N,), t % 7, dtype=torch.int64, device=dev)
+        got = pool.feed.emit(act, zq, np.zeros(N, np.float32), np.zeros(N, np.float32), out, 1e-3)
+        if got:
+            buf.store_feed_rows({"state": out["state"], "action": out["action"].view(N, 1), "reward": out["reward"].view(N, n, 1),
+                                 "next_state": out["next_state"], "done": out["done"].view(N, n, 1)}, N, out["priority"])
+    st = pool.stats()
+    assert st["planes_written"] == N * T
+    # the buffer holds the emissions of ticks T - ticks_kept .. T - 1; emission e (made at tick e + n) sits in ring rows
+    # (e * N + a) % cap and describes (state of tick e, next_state of tick e + n)
+    first_e, last_e = T - n - ticks_kept, T - n - 1
+
+    def rows_of(e):
+        return ((e * N + torch.arange(N, device=dev)) % cap).to(torch.int64)
+
+    for e in (first_e, first_e + 1, (first_e + last_e) // 2, last_e - n, last_e - n - 1):
+        a = buf.gather(rows_of(e), as_float=False)
+        b = buf.gather(rows_of(e + n), as_float=False)
+        assert torch.equal(a["next_state"], b["state"]), e                                   # (a)
+        assert torch.equal(a["action"].view(-1), torch.full((N,), e % 7, device=dev, dtype=a["action"].dtype))
+        s0, s1 = buf.gather(rows_of(e), as_float=False)["state"], buf.gather(rows_of(e + 1), as_float=False)["state"]
+        r1 = torch.from_numpy(resets[e + 1]).to(dev)
+        slid = (s1[:, :-1] == s0[:, 1:]).flatten(1).all(1)
+        tiled = (s1 == s1[:, -1:].expand_as(s1)).flatten(1).all(1)
+        assert bool((slid | r1).all()) and bool((tiled | ~r1).all()), e                       # (b)
+        assert torch.equal(s1[:, -1].reshape(N, -1).to(torch.int64).sum(1), sums[e + 1]), e  # (c)
