@@ -247,7 +247,14 @@ class PPO(BaseAgent):
     def _enqueue_learn(self, st):
         """Everything between `memory.sample()` and the result read-back, as stream work only (no host
         sync, no allocation outside torch's graph-private pool): capturable."""
-        net, M, B = self._net, st["M"], self.batch_size
+        self._enqueue_pre(st)
+        self._enqueue_main(st)
+
+    def _enqueue_pre(self, st):
+        """ppo.py:83-112: everything that does NOT depend on the epoch shuffles (replay rows, the no-grad passes,
+        log pi_old, GAE, mean return).  Launched first so that the host's `np.random.shuffle` calls (ppo.py:118, ~12 us
+        each at 1024 rows) run while the GPU is busy with this."""
+        net, M = self._net, st["M"]
         cont = net.cont
         tr = st["tr"]
         self.memory._store.gather(st["arange"], as_float=True, out={k: tr[k] for k in tr})
@@ -263,6 +270,12 @@ class PPO(BaseAgent):
         adv, ret = ops.gae(tr["reward"], tr["done"], st["value"], st["next_value"], self.n_step, self.gamma, self._lambda, self.use_standardization,
                            out=(st["adv"], st["ret"]))
         ops.mean_into(ret, st["stats"][st["n_upd"], 0:1])  # ppo.py:112
+
+    def _enqueue_main(self, st):
+        """ppo.py:114-169: the minibatch updates of all epochs (needs st["idx"] = the shuffles)."""
+        net, M, B = self._net, st["M"], self.batch_size
+        cont = net.cont
+        tr, adv, ret, logp_old = st["tr"], st["adv"], st["ret"], st["logp_old"]
         k = 0
         if "rows" in st:
             # x[idx] of every epoch in one launch, then forward + loss + backward (+ clip + Adam) in 4-5 launches per
@@ -301,30 +314,50 @@ class PPO(BaseAgent):
         if self._static is None or self._static["M"] != M:
             self._static, self._graph = self._alloc_static(M), None
         st = self._static
-        # the reference's global-RNG shuffles (ppo.py:118), all epochs uploaded at once
-        idxs = np.arange(M)
-        perm = np.empty(self.n_epoch * M, np.int64)
-        for e in range(self.n_epoch):
-            np.random.shuffle(idxs)
-            perm[e * M : (e + 1) * M] = idxs
-        st["idx"].copy_(h2d_small(perm, self.device))
+
+        def shuffles():
+            # the reference's global-RNG shuffles (ppo.py:118), all epochs uploaded at once
+            idxs = np.arange(M)
+            perm = np.empty(self.n_epoch * M, np.int64)
+            for e in range(self.n_epoch):
+                np.random.shuffle(idxs)
+                perm[e * M : (e + 1) * M] = idxs
+            st["idx"].copy_(h2d_small(perm, self.device))
+
         graphable = (self.use_graph and not ops._PROF["on"] and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
                      and (self.grad_sync is None or self.graph_with_collective))
+        split = os.environ.get("JH_PPO_SPLIT_GRAPH", "1") == "1"  # pre-phase and minibatch phase as two graphs, the shuffles between their launches
         if graphable and self._graph is None and getattr(self, "_warm", False):
             try:
-                g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (batched actors, staging ring) keep issuing HIP work on their own streams
-                    self._enqueue_learn(st)
-                self._graph = g  # capture does not execute: replay below runs this iteration's update
+                if split:
+                    gp = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gp, capture_error_mode="thread_local"):
+                        self._enqueue_pre(st)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (batched actors, staging ring) keep issuing HIP work on their own streams
+                        self._enqueue_main(st)
+                    self._graph_pre, self._graph = gp, g
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._enqueue_learn(st)
+                    self._graph_pre, self._graph = None, g  # capture does not execute: replay below runs this iteration's update
             except Exception as e:  # e.g. a collective that cannot be captured: stay eager from now on
-                self._graph, self._graph_failed, graphable = None, True, False
+                self._graph, self._graph_pre, self._graph_failed, graphable = None, None, True, False
                 torch.cuda.synchronize()
                 print(f"[jorldy_amd] hipGraph capture of learn() failed ({type(e).__name__}: {e}); running eagerly")
         if graphable and self._graph is not None:
+            if getattr(self, "_graph_pre", None) is not None:
+                self._graph_pre.replay()  # the GPU works on the no-grad passes / GAE ...
+                shuffles()                # ... while the host shuffles
+            else:
+                shuffles()
             self._graph.replay()
         else:
-            self._enqueue_learn(st)
+            self._enqueue_pre(st)
+            shuffles()
+            self._enqueue_main(st)
             self._warm = True
         self.memory._store.clear()
         self._adam_steps += st["n_upd"]

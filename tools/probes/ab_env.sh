@@ -1,7 +1,14 @@
-# usage: ab_env.sh VAR  -- A/B of bench.py (PPO leg) with VAR=0 / VAR=1, two rounds
-for s in 0 1 0 1; do
-  env $1=$s timeout 120 python bench.py --no-cpu-baseline --no-roofline --no-rainbow 2>/dev/null > /tmp/ab.json
-  python -c "
-import json
-d=json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1]); print('$1=$s', round(d['value']), round(d['ms_per_step'],3), round(d['last_result']['critic_loss'],4))"
+#!/bin/bash
+# A/B an environment switch on bench.py's PPO leg:  tools/probes/ab_env.sh VAR A B [reps]
+var=$1; a=$2; b=$3; reps=${4:-3}
+for rep in $(seq $reps); do
+  for v in $a $b; do
+    env $var=$v python bench.py --steps 100 --warmup 10 --no-rainbow --no-cpu-baseline --no-roofline 2>/dev/null | grep "^{" > /tmp/l.json
+    python - $var $v <<'PY'
+import json, sys
+d = json.loads(open("/tmp/l.json").readline())
+act = d["collector_host_us_per_timestep"]["act_us_per_step"]
+print(f"{sys.argv[1]}={sys.argv[2]}", "value", round(d["value"]), "ms", round(d["ms_per_step"], 4), "act_us", round(act, 3), "learner_part_ms", round(d["ms_per_step"] - act * 0.128, 4))
+PY
+  done
 done
