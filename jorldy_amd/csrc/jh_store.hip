@@ -1,6 +1,8 @@
 // GPU-resident SoA transition store: ring push via pinned staging + async H2D, and a fused
 // multi-column gather that also performs the fp32 cast of BaseAgent.as_tensor.
 // Replaces core/buffer/replay_buffer.py:8-35, rollout_buffer.py:6-24, base.py:42-56.
+#include <stdlib.h>
+
 #include "jh_common.h"
 
 
@@ -45,6 +47,56 @@ JH_EXPORT void jh_store_destroy(jh_store* s) {
   delete s;
 }
 
+// ONE launch for a ring append of all columns (<= 8) from sources a kernel can read: device memory, or device-mapped
+// pinned memory for small appends.  A rollout commit used to be one hipMemcpyAsync per column (5-10 SDMA copies of a few
+// KB each, ~3 us apiece on the host and again on the copy engine, back to back in front of learn()).
+struct CopyCols {
+  const char* src[8];
+  char* dst[8];       // ring position of the first row
+  char* dst_wrap[8];  // column base (rows behind the ring's wrap)
+  int64_t first[8], total[8];  // bytes before the wrap / in all
+};
+__global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
+  const int c = blockIdx.y;
+  const char* src = a.src[c];
+  char* d0 = a.dst[c];
+  char* d1 = a.dst_wrap[c];
+  const int64_t first = a.first[c], total = a.total[c];
+  const bool vec = ((((uintptr_t)src | (uintptr_t)d0 | (uintptr_t)d1) & 15) == 0) && ((first & 15) == 0);
+  const int64_t nv = vec ? total >> 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = i << 4;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + o);
+    *reinterpret_cast<uint4*>(o < first ? d0 + o : d1 + (o - first)) = v;
+  }
+  for (int64_t o = (nv << 4) + (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256)
+    *(o < first ? d0 + o : d1 + (o - first)) = src[o];
+}
+
+// `cols`: device-visible sources.  Advances the ring like jh_store_append.
+static int store_append_kernel(jh_store* s, int64_t n, const void* const* cols, hipStream_t st) {
+  const int64_t first = s->capacity - s->index < n ? s->capacity - s->index : n;
+  CopyCols a{};
+  size_t most = 0;
+  for (int c = 0; c < s->n_cols; ++c) {
+    const size_t rb = s->row_bytes[c];
+    a.src[c] = (const char*)cols[c];
+    a.dst[c] = (char*)s->dev[c] + rb * (size_t)s->index;
+    a.dst_wrap[c] = (char*)s->dev[c];
+    a.first[c] = (int64_t)(rb * (size_t)first);
+    a.total[c] = (int64_t)(rb * (size_t)n);
+    if (rb * (size_t)n > most) most = rb * (size_t)n;
+  }
+  unsigned gx = (unsigned)((most + 16383) / 16384);  // 64 bytes per thread and pass
+  if (gx < 1) gx = 1;
+  if (gx > 2048) gx = 2048;
+  JH_LAUNCH(jh_store_copy_cols_kernel, dim3(gx, (unsigned)s->n_cols), dim3(256), 0, st, a);
+  JH_LAUNCH_CHECK();
+  s->index = (s->index + n) % s->capacity;
+  s->counter = s->counter + n < s->capacity ? s->counter + n : s->capacity;
+  return JH_OK;
+}
+
 JH_EXPORT int jh_store_stage_begin(jh_store* s, int64_t n, void** h_cols_out) {
   JH_ARG(s && h_cols_out);
   JH_ARG(n > 0 && n <= s->capacity);
@@ -68,6 +120,18 @@ JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) {
   if (!s->staged) return jh_fail(JH_ERR_STATE, "jh_store_stage_commit without begin");
   hipStream_t st = jh_s(stream);
   const int64_t n = s->staged_n;
+  size_t bytes = 0;
+  for (int c = 0; c < s->n_cols; ++c) bytes += s->row_bytes[c] * (size_t)n;
+  static const size_t kKernelCommitMax = getenv("JH_STORE_KERNEL_COMMIT_MAX") ? (size_t)atoll(getenv("JH_STORE_KERNEL_COMMIT_MAX")) : ((size_t)512 << 10);
+  if (s->n_cols <= 8 && bytes <= kKernelCommitMax) {
+    // small commits (a PPO rollout: 46 KB; Rainbow's 4 deferred rows: 226 KB): one kernel reads the slab in place
+    const void* src[8];
+    for (int c = 0; c < s->n_cols; ++c) src[c] = (const char*)s->staged->dev + s->staged_off[c];
+    int rc = store_append_kernel(s, n, src, st);
+    int rc2 = jh_ctx_slab_release(s->ctx, s->staged, st);
+    s->staged = nullptr;
+    return rc ? rc : rc2;
+  }
   const int64_t first = s->capacity - s->index < n ? s->capacity - s->index : n;  // rows before the wrap
   for (int c = 0; c < s->n_cols; ++c) {
     const size_t rb = s->row_bytes[c];
@@ -123,6 +187,7 @@ JH_EXPORT int jh_store_push_device(jh_store* s, int64_t n, const void* const* d_
   JH_ARG(s && d_cols);
   JH_ARG(n >= 0 && n <= s->capacity);
   if (n == 0) return JH_OK;
+  if (s->n_cols <= 8) return store_append_kernel(s, n, d_cols, jh_s(stream));  // one launch instead of a copy per column
   return jh_store_append(s, n, d_cols, hipMemcpyDeviceToDevice, jh_s(stream));
 }
 
