@@ -234,6 +234,15 @@ class PPO(BaseAgent):
             mb_h0=f(B, A), mb_h1=f(B, A) if cont else None, mb_v=f(B, 1),
             stats=torch.zeros(n_upd + 1, 8, dtype=torch.float32, device=self.device),
         )
+        if os.environ.get("JH_PPO_MAPPED_STATS", "1") == "1":
+            # the [n_upd + 1][8] statistics live in device-MAPPED pinned host memory: the loss kernels write them across
+            # PCIe themselves (32 bytes per update, flushed when the kernel ends), and learn() waits for the last row to
+            # arrive instead of for the stream -- no D2H copy, no hipStreamSynchronize wake-up, and the host is already
+            # preparing the next rollout while the last backward + Adam are still running (stream order keeps that correct)
+            pin = ops.PinnedBuffer((n_upd + 1, 8), np.float32, self.device.index)
+            pin.np[:] = 0.0
+            st["stats_pin"] = pin
+            st["stats"] = ops._wrap_device(pin.dev_ptr.value, (n_upd + 1, 8), torch.float32, self.device, owner=pin)
         # rows of every minibatch of every epoch, gathered once per learn() (jh_ppo_minibatch_rows) when all
         # minibatches take the four- / five-launch update
         E = self.n_epoch
@@ -324,6 +333,9 @@ class PPO(BaseAgent):
                 perm[e * M : (e + 1) * M] = idxs
             st["idx"].copy_(h2d_small(perm, self.device))
 
+        pin = st.get("stats_pin")
+        if pin is not None:  # arrival marker in the LAST element the last update's loss kernel writes (c2 = a mean of squares: never -1)
+            pin.np[st["n_upd"] - 1, 7] = -1.0
         graphable = (self.use_graph and not ops._PROF["on"] and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
                      and (self.grad_sync is None or self.graph_with_collective))
         split = os.environ.get("JH_PPO_SPLIT_GRAPH", "1") == "1"  # pre-phase and minibatch phase as two graphs, the shuffles between their launches
@@ -361,8 +373,28 @@ class PPO(BaseAgent):
             self._warm = True
         self.memory._store.clear()
         self._adam_steps += st["n_upd"]
-        s = self._read_stats(st["stats"])[0].astype(np.float64)  # the only host sync of learn()
+        if pin is not None:
+            s = self._await_mapped_stats(pin.np, st["n_upd"])
+        else:
+            s = self._read_stats(st["stats"])[0].astype(np.float64)  # the only host sync of learn()
         return self._result(s, st["n_upd"])
+
+    def _await_mapped_stats(self, a, n_upd):
+        """Spin until the last loss kernel's row has landed in the mapped host buffer (bounded: a stream sync after
+        2 s, which also surfaces any asynchronous error)."""
+        import time
+
+        last, spins, t0 = a[n_upd - 1], 0, None
+        while last[7] == -1.0:
+            spins += 1
+            if spins & 4095 == 0:
+                t0 = t0 or time.perf_counter()
+                if time.perf_counter() - t0 > 2.0:
+                    torch.cuda.current_stream().synchronize()
+                    if last[7] == -1.0:
+                        raise RuntimeError("PPO learn(): the statistics of the last update never arrived (failed launch?)")
+                    break
+        return a.astype(np.float64)
 
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
         super().learning_rate_decay(step, optimizers, mode)
