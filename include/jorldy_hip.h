@@ -61,6 +61,10 @@ int jh_ctx_sync(jh_ctx* ctx, jh_stream stream);  /* hipStreamSynchronize */
 /* Pinned host memory mapped into the device address space (the pinned staging of the collector:
  * observations written by the host are read in place by the acting kernels, actions come back
  * the same way).  *dev_out is the address kernels must use.                                 */
+/* Host-side wait for results that kernels write into device-mapped pinned memory (the learn() statistics: the
+ * reference reads them with .item() syncs, core/agent/ppo.py:171-184, rainbow.py:241-253): returns 0 once none of
+ * base[idx[i]], i < n, equals `sentinel` any more, 1 after timeout_s seconds.  Pure host spin, no HIP call.          */
+int jh_host_wait_marks(const float* base, const int32_t* idx, int32_t n, float sentinel, double timeout_s);
 int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void** dev_out);
 void jh_pinned_free(void* host);
 

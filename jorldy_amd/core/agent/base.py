@@ -85,6 +85,38 @@ class BaseAgent(ABC):
         torch.cuda.current_stream().synchronize()
         return [o.numpy() for o in outs]
 
+    # ---- learn() statistics in device-MAPPED pinned host memory: the loss kernels write them across PCIe themselves
+    # and learn() waits for their arrival instead of for the stream (no D2H copies, no hipStreamSynchronize wake-up, and
+    # the host goes on -- env steps, stores, the next rollout -- while the rest of the update is still running; everything
+    # it enqueues is stream-ordered behind it).  JH_MAPPED_STATS=0: device tensors + _read_stats.
+    def _mapped_stats(self, n, np_dtype=np.float32):
+        """-> (CUDA tensor aliasing the buffer for the kernels, numpy view for the host) or (device tensor, None)."""
+        import os
+
+        from ... import ops
+
+        tdt = torch.float32 if np.dtype(np_dtype) == np.float32 else torch.float64
+        if os.environ.get("JH_MAPPED_STATS", "1") != "1":
+            return torch.zeros(n, dtype=tdt, device=self.device), None
+        pin = ops.PinnedBuffer((n,), np_dtype, self.device.index)
+        pin.np[:] = 0
+        return ops._wrap_device(pin.dev_ptr.value, (n,), tdt, self.device, owner=pin), pin.np
+
+    @staticmethod
+    def _await_marks(view, marks, what="learn()"):
+        """Wait until view[m] != -1 for every m in marks (the elements the finishing kernel writes last; the caller set
+        them to -1 before launching).  The wait is jh_host_wait_marks: a C spin entered through ctypes, i.e. without
+        the GIL (a Python spin loop here cost the batched actors of an Ape-X process a third of their throughput).
+        Bounded: after 2 s a stream sync, which also surfaces asynchronous errors."""
+        from ... import _lib as L
+
+        idx = np.asarray(marks, dtype=np.int32)
+        flat = view.reshape(-1)
+        if L.load().jh_host_wait_marks(L.ptr(flat), L.ptr(idx), int(idx.size), -1.0, 2.0) != 0:
+            torch.cuda.current_stream().synchronize()
+            if any(flat[m] == -1.0 for m in marks):
+                raise RuntimeError(f"{what}: the statistics never arrived (failed launch?)")
+
     RESUME_FORMAT, RESUME_VERSION = "jorldy_amd.resume", 2
 
     def _resume_extra_attrs(self):

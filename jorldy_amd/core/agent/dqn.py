@@ -70,7 +70,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
         self.run_step = run_step
         self.lr_decay = lr_decay
         self.clip_grad_norm = None
-        self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._stats, self._stats_np = self._mapped_stats(4)
         self._static = None
         self._graph = None
         self._warm = False
@@ -203,12 +203,24 @@ class DQN(NativeValueNetMixin, BaseAgent):
             self._adam_steps += 1
         return extra
 
-    def learn(self):
+    def _learn_stats(self, view, marks, tensor):
+        """Run one learn(); -> (loss statistics, PER statistics or None) as host arrays."""
+        tree_np = getattr(getattr(self.memory, "_tree", None), "stats_np", None) if self._td["per"] else None
+        mapped = view is not None and (not self._td["per"] or tree_np is not None)
+        if mapped:
+            for m in marks:
+                view[m] = -1.0
         stats64 = self._run_learn()
+        if mapped:
+            self._await_marks(view, marks, type(self).__name__ + ".learn()")
+            # the sampling kernel ran (and ended) in front of the kernels that wrote `view`: its statistics are there too
+            return view.copy(), (tree_np.copy() if self._td["per"] else None)
         if self._td["per"]:
-            s, p = self._read_stats(self._stats, stats64)
-        else:
-            (s,) = self._read_stats(self._stats)
+            return tuple(self._read_stats(tensor, stats64))
+        return self._read_stats(tensor)[0], None
+
+    def learn(self):
+        s, p = self._learn_stats(self._stats_np, (3,), self._stats)
         result = {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1])}
         if self._td["per"]:
             result.update({"sampled_p": float(p[0]), "mean_p": float(p[1])})

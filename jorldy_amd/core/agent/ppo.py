@@ -380,20 +380,8 @@ class PPO(BaseAgent):
         return self._result(s, st["n_upd"])
 
     def _await_mapped_stats(self, a, n_upd):
-        """Spin until the last loss kernel's row has landed in the mapped host buffer (bounded: a stream sync after
-        2 s, which also surfaces any asynchronous error)."""
-        import time
-
-        last, spins, t0 = a[n_upd - 1], 0, None
-        while last[7] == -1.0:
-            spins += 1
-            if spins & 4095 == 0:
-                t0 = t0 or time.perf_counter()
-                if time.perf_counter() - t0 > 2.0:
-                    torch.cuda.current_stream().synchronize()
-                    if last[7] == -1.0:
-                        raise RuntimeError("PPO learn(): the statistics of the last update never arrived (failed launch?)")
-                    break
+        """Wait until the last loss kernel's row has landed in the mapped host buffer (BaseAgent._await_marks)."""
+        self._await_marks(a, ((n_upd - 1) * 8 + 7,), "PPO.learn()")
         return a.astype(np.float64)
 
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):

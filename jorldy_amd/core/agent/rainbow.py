@@ -22,7 +22,7 @@ class C51(DQN):
         self.v_min, self.v_max, self.num_support = v_min, v_max, num_support
         self.delta_z = (v_max - v_min) / (num_support - 1)
         self.z = torch.linspace(v_min, v_max, num_support, device=self.device).view(1, -1)
-        self._stats8 = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._stats8, self._stats8_np = self._mapped_stats(8)
 
     def logits2Q(self, logits):
         _logits = logits.view(logits.shape[0], self.action_size, self.num_support)
@@ -68,8 +68,7 @@ class C51(DQN):
         self.optimizer.step()
 
     def learn(self):
-        self._run_learn()
-        (s,) = self._read_stats(self._stats8)
+        s, _ = self._learn_stats(self._stats8_np, (5, 7), self._stats8)
         return {"loss": float(s[0]), "epsilon": self.epsilon, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3])}
 
 
@@ -134,8 +133,8 @@ class Rainbow(DQN):
         self.delta_z = (v_max - v_min) / (num_support - 1)
         self.z = torch.linspace(v_min, v_max, num_support, device=self.device).view(1, -1)
         self.epsilon = 0.0
-        self._stats8 = torch.zeros(8, dtype=torch.float32, device=self.device)
-        self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._stats8, self._stats8_np = self._mapped_stats(8)
+        self._stats, self._stats_np = self._mapped_stats(4)
         self._noise = None  # parity tests inject the Gaussian draws here (forces the eager path)
 
     def logits2Q(self, logits):
@@ -200,8 +199,7 @@ class Rainbow(DQN):
         self.optimizer.step()
 
     def learn(self):
-        stats64 = self._run_learn()
-        s, p = self._read_stats(self._stats8, stats64)
+        s, p = self._learn_stats(self._stats8_np, (5, 7), self._stats8)
         return {"loss": float(s[0]), "beta": self.beta, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3]),
                 "sampled_p": float(p[0]), "mean_p": float(p[1])}
 

@@ -308,7 +308,17 @@ class SumTree:
         self.usp = float(uniform_sample_prob)
         self.h = C.c_void_p()
         L.check(self.lib.jh_per_create(self.ctx, self.capacity, self.usp, C.byref(self.h)))
-        self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+        # {sampled_p, mean_p, root, max_w} of the last sample: device-mapped pinned memory, so that a learner can read
+        # them without a copy + stream sync once it knows the sampling kernel has finished (`stats_np`)
+        import os
+
+        if os.environ.get("JH_MAPPED_STATS", "1") == "1":
+            self._stats_pin = PinnedBuffer((4,), np.float64, self.device.index)
+            self._stats_pin.np[:] = 0
+            self._stats = _wrap_device(self._stats_pin.dev_ptr.value, (4,), torch.float64, self.device, owner=self._stats_pin)
+            self.stats_np = self._stats_pin.np
+        else:
+            self._stats, self.stats_np = torch.zeros(4, dtype=torch.float64, device=self.device), None
 
     def __del__(self):
         try:
