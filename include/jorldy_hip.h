@@ -65,6 +65,8 @@ int jh_ctx_sync(jh_ctx* ctx, jh_stream stream);  /* hipStreamSynchronize */
  * reference reads them with .item() syncs, core/agent/ppo.py:171-184, rainbow.py:241-253): returns 0 once none of
  * base[idx[i]], i < n, equals `sentinel` any more, 1 after timeout_s seconds.  Pure host spin, no HIP call.          */
 int jh_host_wait_marks(const float* base, const int32_t* idx, int32_t n, float sentinel, double timeout_s);
+/* The same on 32-bit words (e.g. the low words of int64 actions preset to -1 by the host). */
+int jh_host_wait_words(const uint32_t* base, const int32_t* idx, int32_t n, uint32_t sentinel, double timeout_s);
 int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void** dev_out);
 void jh_pinned_free(void* host);
 

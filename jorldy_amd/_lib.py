@@ -39,6 +39,7 @@ _PROTOS = {
     "jh_prof_report": (C.c_int, [C.c_char_p, _i64]),
     "jh_prof_calibrate": (C.c_int, [_i32, _vp]),
     "jh_host_wait_marks": (C.c_int, [_vp, _vp, _i32, _f32, _f64]),
+    "jh_host_wait_words": (C.c_int, [_vp, _vp, _i32, C.c_uint32, _f64]),
     "jh_pinned_alloc": (C.c_int, [_vp, _i64, _pp, _pp]),
     "jh_pinned_free": (None, [_vp]),
     "jh_store_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _pp]),

@@ -122,20 +122,26 @@ int jh_ctx_scratch(jh_ctx* ctx, size_t bytes, void** out) {
   return JH_OK;
 }
 
-// Host-side arrival wait on device-mapped pinned memory: returns 0 as soon as none of base[idx[i]] equals `sentinel`
-// any more (a finishing kernel overwrote them), 1 after timeout_s.  Pure host spin (pause between polls); callers come
-// through ctypes, i.e. WITHOUT the Python GIL -- a Python spin loop would starve the other threads of the process.
-JH_EXPORT int jh_host_wait_marks(const float* base, const int32_t* idx, int32_t n, float sentinel, double timeout_s) {
-  if (!base || !idx || n <= 0) return jh_fail(JH_ERR_ARG, "jh_host_wait_marks: bad argument");
-  const volatile float* v = base;
+// Host-side arrival wait on device-mapped pinned memory: returns 0 as soon as none of the 32-bit words base[idx[i]]
+// equals `sentinel` any more (a finishing kernel overwrote them), 1 after timeout_s.  Pure host spin (pause between polls);
+// callers come through ctypes, i.e. WITHOUT the Python GIL -- a Python spin loop would starve the other threads of the
+// process.  jh_host_wait_marks: the same for float words and a float sentinel (compared by bit pattern).
+JH_EXPORT int jh_host_wait_words(const uint32_t* base, const int32_t* idx, int32_t n, uint32_t sentinel, double timeout_s) {
+  if (!base || !idx || n <= 0) return jh_fail(JH_ERR_ARG, "jh_host_wait_words: bad argument");
+  const volatile uint32_t* v = base;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spin = 1;; ++spin) {
     bool all = true;
-    for (int i = 0; i < n; ++i) all = all && !(v[idx[i]] == sentinel);
+    for (int i = 0; i < n; ++i) all = all && v[idx[i]] != sentinel;
     if (all) return 0;
     __builtin_ia32_pause();
     if ((spin & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return 1;
   }
+}
+JH_EXPORT int jh_host_wait_marks(const float* base, const int32_t* idx, int32_t n, float sentinel, double timeout_s) {
+  uint32_t bits;
+  memcpy(&bits, &sentinel, 4);
+  return jh_host_wait_words(reinterpret_cast<const uint32_t*>(base), idx, n, bits, timeout_s);
 }
 
 // Pinned, device-mapped host memory for callers that exchange small per-step data with kernels

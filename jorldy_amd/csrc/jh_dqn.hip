@@ -572,8 +572,13 @@ __global__ void __launch_bounds__(256) jh_value_act_kernel(int N, int A, int K, 
   }
   if (lane == 0) {
     const bool explore = eps && u && u[row] < (double)eps[row];
+    // q first, the action last: a host that waits for the actions to arrive in device-mapped memory (BatchedValueActors)
+    // then finds q in place too
+    if (q_taken) {
+      q_taken[row] = explore ? q_rand : best;
+      __threadfence_system();
+    }
     action[row] = explore ? ra : best_a;
-    if (q_taken) q_taken[row] = explore ? q_rand : best;
   }
 }
 

@@ -48,10 +48,28 @@ class BatchedValueActors:
         self._x_pin = torch.empty(shape, dtype=self.x_dtype, pin_memory=True)  # the tick's observations, staged once
         self._x_dev = torch.empty(shape, dtype=self.x_dtype, device=self.device)
         self._logits = torch.empty(self.N, src.A, src.K, dtype=torch.float32, device=self.device)
-        self._act_dev = torch.empty(self.N, dtype=torch.int64, device=self.device)
-        self._q_dev = torch.empty(self.N, dtype=torch.float32, device=self.device)
-        self._act_pin = torch.empty(self.N, dtype=torch.int64, pin_memory=True)
-        self._q_pin = torch.empty(self.N, dtype=torch.float32, pin_memory=True)
+        import os
+
+        self._mapped = os.environ.get("JH_MAPPED_STATS", "1") == "1"
+        if self._mapped:
+            # actions / q of a tick in device-MAPPED pinned memory: the act kernel writes them across PCIe itself and act()
+            # waits for their arrival (jh_host_wait_words, no GIL) instead of two D2H copies + an event synchronise
+            # Two sets, alternating by tick: the consumers of a tick's outputs (DeviceActorFeed's emit kernel) are enqueued,
+            # not finished, when the next act() starts; they are finished once the NEXT tick's actions have arrived (same
+            # stream), which is before the set is marked and written again two ticks later.
+            self._maps = []
+            for _ in range(2):
+                am, qm = ops.PinnedBuffer((self.N,), np.int64, self.device.index), ops.PinnedBuffer((self.N,), np.float32, self.device.index)
+                am.np[:] = 0
+                self._maps.append((am, qm, ops._wrap_device(am.dev_ptr.value, (self.N,), torch.int64, self.device, owner=am),
+                                   ops._wrap_device(qm.dev_ptr.value, (self.N,), torch.float32, self.device, owner=qm), am.np.view(np.uint32)))
+            self._act_dev, self._q_dev = self._maps[0][2], self._maps[0][3]
+            self._act_marks = np.arange(0, 2 * self.N, 2, dtype=np.int32)  # low words of the int64 actions
+        else:
+            self._act_dev = torch.empty(self.N, dtype=torch.int64, device=self.device)
+            self._q_dev = torch.empty(self.N, dtype=torch.float32, device=self.device)
+            self._act_pin = torch.empty(self.N, dtype=torch.int64, pin_memory=True)
+            self._q_pin = torch.empty(self.N, dtype=torch.float32, pin_memory=True)
         self._noise = torch.empty(max(1, self.net.noise_len), dtype=torch.float32, device=self.device) if self.noisy else None
         self._normal = ops.NormalSource(self.device) if self.noisy else None
         self._done = torch.cuda.Event()
@@ -92,12 +110,24 @@ class BatchedValueActors:
             if self.noisy and training:
                 noise = self._normal.fill(self._noise)
             self.net.forward(self._x_dev, which=0, noise=noise, out=self._logits)
+            if self._mapped:
+                am, qm, self._act_dev, self._q_dev, words = self._maps[self.ticks & 1]
+                am.np[:] = -1  # arrival marks (actions are >= 0)
             ops.value_act(self._logits, self.v_min, self.v_max, eps, u, ra, out=(self._act_dev, self._q_dev))
-            self._act_pin.copy_(self._act_dev, non_blocking=True)
-            self._q_pin.copy_(self._q_dev, non_blocking=True)
-            self._done.record(self.stream)
-        self._done.synchronize()
+            if not self._mapped:
+                self._act_pin.copy_(self._act_dev, non_blocking=True)
+                self._q_pin.copy_(self._q_dev, non_blocking=True)
+                self._done.record(self.stream)
         self.ticks += 1
+        if self._mapped:
+            from .. import _lib as L
+
+            if L.load().jh_host_wait_words(L.ptr(words), L.ptr(self._act_marks), N, 0xFFFFFFFF, 5.0) != 0:
+                self.stream.synchronize()
+                if (am.np < 0).any():
+                    raise RuntimeError("BatchedValueActors.act(): the actions never arrived (failed launch?)")
+            return {"action": am.np.reshape(N, 1).copy(), "q": qm.np.reshape(N, 1).copy()}
+        self._done.synchronize()
         return {"action": self._act_pin.numpy().reshape(N, 1).copy(), "q": self._q_pin.numpy().reshape(N, 1).copy()}
 
 
