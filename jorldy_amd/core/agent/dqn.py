@@ -180,7 +180,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
         st = self._static
         self.memory.flush()  # held per-step stores -> HBM before anything (possibly a replayed graph) reads the ring
         extra = self._draw(st)
-        graphable = (self.use_graph and self._lr0 is not None and self._noise is None and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
+        graphable = (self.use_graph and self._lr0 is not None and (self._noise is None or isinstance(self._noise, str)) and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
                      and (self.grad_sync is None or self.graph_with_collective))
         if graphable and self._graph is None and self._warm:
             try:

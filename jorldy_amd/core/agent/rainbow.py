@@ -135,7 +135,7 @@ class Rainbow(DQN):
         self.epsilon = 0.0
         self._stats8, self._stats8_np = self._mapped_stats(8)
         self._stats, self._stats_np = self._mapped_stats(4)
-        self._noise = None  # parity tests inject the Gaussian draws here (forces the eager path)
+        self._noise = None  # parity tests inject the Gaussian draws here (a list forces the eager path; "static" = already in st["noise"], graph allowed)
 
     def logits2Q(self, logits):
         _logits = logits.view(logits.shape[0], self.action_size, self.num_support)
@@ -167,7 +167,7 @@ class Rainbow(DQN):
             if getattr(self, "_normal", None) is None:
                 self._normal = ops.NormalSource(self.device)
             self._normal.fill(st["noise"])  # three independent draws: network(s), network(s'), target_network(s') (rainbow.py:160-186)
-        else:
+        elif self._noise != "static":  # "static": the test wrote the draws into st["noise"] itself (replayable: nothing to do here)
             for i in range(3):
                 self.network.pack_noise(self._noise[i], st["noise"][i])
         lg = net.learn_forward(st["x_all"], B, st["noise"], st["logits"])

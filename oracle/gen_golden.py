@@ -426,7 +426,26 @@ def gen_dqn_family(out_dir, only=None):
     specs.append(("rainbow_cnn_atari", Rainbow, dict(n_step=3, alpha=0.5, beta=0.4, learn_period=1, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51),
                   dict(markers=specs[-2][3]["markers"], over=dict(state_size=(4, 84, 84), action_size=4, hidden_size=512, head="cnn", batch_size=32, buffer_size=64,
                                                                   optim_config={"name": "adam", "lr": 6.25e-5}), fill=60, recipe=True)))
-    big = ("rainbow_cnn", "rainbow_cnn_atari")
+    # config.dqn.cartpole exactly (BASELINE configs[0]: S=4, A=2, hidden 512, B=32, Adam 1e-4; config/dqn/cartpole.py:9-26)
+    specs.append(("dqn_h512", DQN, {}, dict(markers=["q", "target_q", "next_q", "loss"],
+                                            over=dict(state_size=4, action_size=2, hidden_size=512, batch_size=32, optim_config={"name": "adam", "lr": 1e-4}),
+                                            recipe=True, opt_state=("exp_avg", "exp_avg_sq"))))
+    # config.ape_x.atari shapes exactly (BASELINE configs[3]: dueling network + cnn head on (4,84,84) uint8 frames, A=6 = Pong,
+    # distributed_batch_size 512, n=3, alpha .6, beta .4, usp 1e-3, CENTERED RMSprop eps 1.5e-7 lr 6.25e-5, clip_grad_norm 40;
+    # config/ape_x/atari.py:16-55, learner core/agent/ape_x.py:79-133), PER of 640 slots filled by 600 env steps.
+    specs.append(("ape_x_cnn_atari", ApeX, dict(n_step=3, alpha=0.6, beta=0.4, learn_period=1, uniform_sample_prob=1e-3, num_workers=4, clip_grad_norm=40.0),
+                  dict(markers=["q", "target_q", "next_q", "next_target_q", "max_a", "td_error", "p_j", "loss", "weights", "indices", "reward", "done"], with_q=True,
+                       over=dict(state_size=(4, 84, 84), action_size=6, hidden_size=512, network="dueling", head="cnn", batch_size=512, buffer_size=640,
+                                 optim_config={"name": "rmsprop", "lr": 2.5e-4 / 4, "eps": 1.5e-7, "centered": True}),
+                       fill=600, recipe=True, opt_state=("square_avg", "grad_avg"))))
+    # the same learner on a small image with clip_grad_norm BELOW the gradient norm (at config.ape_x.atari's 40 the clip is a no-op
+    # for any sane batch: the fixture above records norm 8.9): pins clip -> centered RMSprop against the reference
+    specs.append(("ape_x_cnn_clip", ApeX, dict(n_step=3, alpha=0.6, beta=0.4, learn_period=1, uniform_sample_prob=0.05, num_workers=4, clip_grad_norm=0.5),
+                  dict(markers=specs[-1][3]["markers"], with_q=True,
+                       over=dict(state_size=(4, 44, 52), action_size=6, hidden_size=64, network="dueling", head="cnn", batch_size=8, buffer_size=64,
+                                 optim_config={"name": "rmsprop", "lr": 2.5e-4 / 4, "eps": 1.5e-7, "centered": True}),
+                       fill=40, recipe=True, opt_state=("square_avg", "grad_avg"))))
+    big = ("rainbow_cnn", "rainbow_cnn_atari", "dqn_h512", "ape_x_cnn_atari", "ape_x_cnn_clip")
     for name, cls, extra, opt in specs:
         if (only is None and name in big) or (only is not None and name != only):
             continue
@@ -470,14 +489,14 @@ def gen_dqn_family(out_dir, only=None):
             if k == "priority":
                 continue
             col = np.concatenate([agent.memory.buffer[i][k] for i in range(n)], 0)
-            if recipe and k in ("state", "next_state"):
+            if recipe and k in ("state", "next_state") and not isinstance(S, (int, np.integer)):
                 # frames: raw = [synth.raw_transition(RandomState(17), S, A) ...]; slot i holds raw[i].state and
                 # raw[i + n_step - 1].next_state (rainbow.py:294-308); the checksums pin the regenerated frames
                 out[f"buf_{k}_check"] = synth.row_checksum(col)
             else:
                 out[f"buf_{k}"] = col
         if recipe:
-            out["fill"] = np.asarray(opt["fill"])
+            out["fill"] = np.asarray(opt.get("fill", 200))
             out["fill_seed"] = np.asarray(17)
             out["recipe_seed"] = np.asarray(RECIPE_SEED)
         if is_per:
@@ -491,8 +510,12 @@ def gen_dqn_family(out_dir, only=None):
             "pre_step": (loss_line, opt["markers"] + (["action"] if recipe else ["state", "action", "next_state"])),
             "step": ("self.optimizer.step()", []),
         }
+        has_clip = "clip_grad_norm_" in inspect.getsource(cls.learn)
+        if has_clip and recipe:
+            markers["pre_clip"] = ("torch.nn.utils.clip_grad_norm_", [])
         tap = LineTap(cls.learn, markers)
         graw = {}
+        gpre = {}
         head = {}
 
         def on_step(frame):
@@ -508,6 +531,8 @@ def gen_dqn_family(out_dir, only=None):
 
         tap.on_line["step"] = on_step
         tap.on_line["pre_step"] = on_pre
+        if "pre_clip" in markers:
+            tap.on_line["pre_clip"] = lambda frame: gpre.update({k: p.grad.detach().numpy().copy() for k, p in agent.network.named_parameters()})
 
         np.random.seed(42)
         torch.manual_seed(42)
@@ -517,6 +542,9 @@ def gen_dqn_family(out_dir, only=None):
         flat("learn/", rec, out)
         flat("learn/", head, out)
         if recipe:
+            if gpre:  # gradients BEFORE clip_grad_norm_; graw (taken at optimizer.step()) holds the clipped ones
+                out["grad_clip_norm"] = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in graw.values()))
+                graw = gpre
             flat("grad_thin/", {k: synth.thin(v) for k, v in graw.items()}, out)
             out["grad_norm"] = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in graw.values()))
             for k, v in graw.items():
@@ -524,6 +552,10 @@ def gen_dqn_family(out_dir, only=None):
             flat("sd0_thin/", {k: synth.thin(v) for k, v in sd0.items()}, out)
             flat("sdt_thin/", {k: synth.thin(v) for k, v in sdt.items()}, out)
             flat("sd1_thin/", {k: synth.thin(v) for k, v in sd_to_np(agent.network.state_dict()).items()}, out)
+            # optimizer moments after the step (Adam exp_avg / exp_avg_sq, RMSprop square_avg / grad_avg), per parameter name
+            for st_key in opt.get("opt_state", ()):
+                for k, p in agent.network.named_parameters():
+                    out[f"opt1_thin/{st_key}/{k}"] = synth.thin(agent.optimizer.state[p][st_key].detach().numpy())
         else:
             flat("grad/", graw, out)
             flat("sd0/", sd0, out)
@@ -536,6 +568,7 @@ def gen_dqn_family(out_dir, only=None):
             out["maxp1"] = np.asarray(agent.memory.max_priority)
         hyper = dict(gamma=0.99, lr=kw["optim_config"]["lr"], B=B, S=np.asarray(S), A=A, H=H, np_seed=42, torch_seed=42)
         hyper.update({k: v for k, v in extra.items() if isinstance(v, (int, float))})
+        hyper.update({f"optim_{k}": v for k, v in kw["optim_config"].items() if isinstance(v, (int, float, bool))})
         for k, v in hyper.items():
             out[f"hyper/{k}"] = np.asarray(v)
         np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **out)
@@ -610,7 +643,7 @@ def main():
 
     torch.set_num_threads(1)  # deterministic reductions in the fixtures
     try:
-        todo = args.only.split(",") if args.only else ["buffers", "ppo", "dqn", "nstep"]  # + rainbow_cnn, rainbow_cnn_atari on request
+        todo = args.only.split(",") if args.only else ["buffers", "ppo", "dqn", "nstep"]  # + rainbow_cnn, rainbow_cnn_atari, dqn_h512, ape_x_cnn_atari on request
         if "buffers" in todo:
             gen_buffers(out_dir)
         if "ppo" in todo:
@@ -622,7 +655,7 @@ def main():
             gen_dqn_family(out_dir)
         if "nstep" in todo:
             gen_nstep(out_dir)
-        for nm in ("rainbow_cnn", "rainbow_cnn_atari"):
+        for nm in ("rainbow_cnn", "rainbow_cnn_atari", "dqn_h512", "ape_x_cnn_atari", "ape_x_cnn_clip"):
             if nm in todo:
                 gen_dqn_family(out_dir, only=nm)
     finally:

@@ -256,3 +256,191 @@ def test_rainbow_learn_at_atari_shapes():
         bad += int((d > 0.05 * lr).sum())
         assert float(d.max()) <= 2.1 * lr, k
     assert bad <= 0.005 * tot, (bad, tot)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# configs[0] and configs[3] at their real shapes (VERDICT r2 "missing" #2): DQN H=512 / B=32 / Adam 1e-4 and the Ape-X
+# learner = dueling CNN on (4,84,84) uint8, A=6, B=512, n=3, centered RMSprop eps 1.5e-7, clip_grad_norm 40; plus the
+# same learner on a small image with the clip ACTIVE (norm 31.8 -> 0.5).  Fixtures: runs of the unmodified reference.
+# ---------------------------------------------------------------------------------------------------------
+TD_WIDE = [("dqn_h512", "dqn"), ("ape_x_cnn_atari", "ape_x"), ("ape_x_cnn_clip", "ape_x")]
+
+
+def _td_wide_agent(z, agent_name, use_graph):
+    from jorldy_amd.core.agent import Agent
+
+    h = lambda k: z[f"hyper/{k}"].item()
+    cnn = z["hyper/S"].ndim > 0
+    S = tuple(int(v) for v in z["hyper/S"]) if cnn else int(h("S"))
+    A, H, B = int(h("A")), int(h("H")), int(h("B"))
+    oc = {"name": "rmsprop" if "hyper/optim_centered" in z.files else "adam", "lr": h("optim_lr")}
+    if oc["name"] == "rmsprop":
+        oc.update(eps=h("optim_eps"), centered=bool(h("optim_centered")))
+    extra = {k: h(k) for k in ("n_step", "alpha", "beta", "learn_period", "uniform_sample_prob", "num_workers", "clip_grad_norm") if f"hyper/{k}" in z.files}
+    for k in ("n_step", "learn_period", "num_workers"):
+        if k in extra:
+            extra[k] = int(extra[k])
+    if cnn:
+        extra.update(network="dueling", head="cnn")
+    n_rows = int(z["buf_action"].shape[0])
+    agent = Agent(agent_name, state_size=S, action_size=A, hidden_size=H, optim_config=oc, gamma=h("gamma"), buffer_size=640 if B == 512 else (64 if cnn else 256),
+                  batch_size=B, start_train_step=0, target_update_period=10000, run_step=100000, device="cuda", backend="native", use_graph=use_graph, **extra)
+    assert agent.backend == "native"
+    shapes = {k: v.shape for k, v in agent.network.state_dict().items()}
+    seed = int(z["recipe_seed"])
+    w0 = {k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, seed).items()}
+    wt = {k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, seed + 1).items()}
+    if cnn:  # slot i = (raw[i].state, raw[i + n].state): ape_x.py:174-199 (deque of n + 1, next_state = the newest STATE)
+        n = extra["n_step"]
+        rng = np.random.RandomState(int(z["fill_seed"]))
+        raw = [synth.raw_transition(rng, S, A, True) for _ in range(int(z["fill"]))]
+        assert n_rows == len(raw) - n
+        cols = {"state": np.concatenate([raw[i]["state"] for i in range(n_rows)], 0),
+                "next_state": np.concatenate([raw[i + n]["state"] for i in range(n_rows)], 0)}
+        for k in ("state", "next_state"):
+            assert np.array_equal(synth.row_checksum(cols[k]), z[f"buf_{k}_check"]), k
+    else:
+        cols = {k: z[f"buf_{k}"] for k in ("state", "next_state")}
+    for k in ("action", "reward", "done"):
+        cols[k] = z[f"buf_{k}"]
+    agent.memory.first_store = False
+    agent.memory.store_soa(cols)
+    if cnn:
+        assert agent.memory._store.column("state").dtype == torch.uint8
+    return agent, w0, wt, n_rows, oc
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("fixture,agent_name", TD_WIDE)
+def test_td_learn_at_baseline_shapes(fixture, agent_name, use_graph):
+    """One learn() of the reference (DQN.learn dqn.py:117-151; ApeX.learn ape_x.py:79-133) vs the native network + HIP TD /
+    PER kernels: sampled indices and IS weights bit-exact, q / loss / max_Q within 1e-5, every parameter gradient within
+    1e-5 of the tensor's largest entry, the optimizer's moments after the step (Adam exp_avg / exp_avg_sq; centered RMSprop
+    grad_avg / square_avg, after clip_grad_norm_).  use_graph: the third learn() (a hipGraph replay) is the one compared."""
+    from jorldy_amd.core.optimizer import Optimizer
+
+    z = load(fixture)
+    h = lambda k: z[f"hyper/{k}"].item()
+    agent, w0, wt, n_rows, oc = _td_wide_agent(z, agent_name, use_graph)
+    per = "tree0" in z.files
+    B, A = int(h("B")), int(h("A"))
+    defaults = Optimizer(**oc, params=[torch.nn.Parameter(torch.zeros(1))]).defaults
+    reps = 3 if use_graph else 1
+    for rep in range(reps):
+        agent.network.load_state_dict(w0)
+        agent.target_network.load_state_dict(wt)
+        agent._net.m.zero_()
+        agent._net.v.zero_()
+        agent._adam_steps = 0
+        agent._set_native_hyper(defaults, 0)
+        if per:
+            agent.memory._tree.load(z["tree0"], float(np.asarray(z["maxp0"]).reshape(-1)[0]), int(z["tree_index0"]), n_rows)
+        np.random.seed(int(h("np_seed")))
+        result = agent.learn()
+    if use_graph:
+        assert agent._graph is not None, "learn() was not captured"
+    _thin_cmp({k: npy(v) for k, v in w0.items()}, z, "sd0_thin/", tol=0.0, what="initial weights")
+    _thin_cmp({k: npy(v) for k, v in wt.items()}, z, "sdt_thin/", tol=0.0, what="target weights")
+    errs = {}
+    for k in ("loss", "max_Q"):
+        errs[k] = abs(result[k] - float(z[f"result/{k}"])) / (1.0 + abs(float(z[f"result/{k}"])))
+        assert errs[k] <= 1e-5, (k, result[k], float(z[f"result/{k}"]))
+    st = agent._static
+    act = z["learn/action"].astype(np.int64).reshape(-1)
+    q_all = npy(st["logits"][0]).reshape(B, A)
+    q_ref = z["learn/q"].reshape(-1)
+    errs["q_max_abs"] = float(np.abs(q_all[np.arange(B), act] - q_ref).max())
+    np.testing.assert_allclose(q_all[np.arange(B), act], q_ref, rtol=1e-5, atol=1e-5, err_msg="Q(s, a)")
+    if per:
+        assert np.array_equal(npy(st["idx"]), z["learn/indices"].astype(np.int64)), "sampled tree indices"
+        assert np.array_equal(npy(st["w"]), z["learn/weights"].astype(np.float32).reshape(-1)), "IS weights (fp32, as_tensor)"
+        np.testing.assert_allclose(result["sampled_p"], z["result/sampled_p"], rtol=1e-12)
+        assert result["mean_p"] == z["result/mean_p"].item()
+        np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=2e-5, atol=1e-6)  # our fp32 |td|^alpha written back
+    grads = {k: v.cpu().numpy() for k, v in agent._net.export_state(agent._net.grads).items()}
+    worst = _thin_cmp(grads, z, "grad_thin/", scale_of=lambda k: z[f"grad_absmax/{k}"], tol=1e-5, what="d(loss)/d")
+    norm = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
+    np.testing.assert_allclose(norm, float(z["grad_norm"]), rtol=1e-5)
+    # optimizer moments after the step (computed from the CLIPPED gradient): m = exp_avg | grad_avg, v = exp_avg_sq | square_avg
+    names = ("exp_avg", "exp_avg_sq") if oc["name"] == "adam" else ("grad_avg", "square_avg")
+    mom = {}
+    for bucket, nm in ((agent._net.m, names[0]), (agent._net.v, names[1])):
+        got = {k: v.cpu().numpy() for k, v in agent._net.export_state(bucket).items()}
+        mom[nm] = _thin_cmp(got, z, f"opt1_thin/{nm}/", tol=2e-5, what=nm)
+    if "grad_clip_norm" in z.files:
+        cn, clip = float(z["grad_clip_norm"]), h("clip_grad_norm")
+        assert (cn < clip * 1.0001) and (float(z["grad_norm"]) <= clip or abs(cn - clip) < 1e-4 * clip)
+    _report(f"{fixture}_{'graph' if use_graph else 'eager'}", {"result_err_over_1_plus_abs_ref": errs, "grad_err_rel_to_absmax": worst,
+                                                               "moment_err_rel_to_absmax": mom, "grad_norm": norm, "grad_norm_ref": float(z["grad_norm"])})
+    # updated weights: both optimizers normalise the step (Adam: lr * sign-ish; centered RMSprop's first step: lr * g / (|g| sqrt(.0099) + eps)
+    # ~ 10.05 lr), so a weight with a ~0 gradient may land a step apart: 99.5 % within 5 % of a step, none beyond the possible travel
+    lr = float(h("optim_lr"))
+    travel = lr * (1.0 if oc["name"] == "adam" else 10.06)
+    tot = bad = 0
+    for k, v in agent.network.state_dict().items():
+        d = np.abs(synth.thin(npy(v)) - z[f"sd1_thin/{k}"])
+        tot += d.size
+        bad += int((d > 0.05 * travel).sum())
+        assert float(d.max()) <= 2.1 * travel, k
+    assert bad <= 0.005 * tot, (bad, tot)
+
+
+@pytest.mark.parametrize("use_graph", [True])
+def test_rainbow_learn_at_atari_shapes_graph_replay(use_graph):
+    """The hipGraph replay of Rainbow.learn() at config.rainbow.atari shapes against the reference's fixture (the bench replays
+    this graph; the eager launch sequence is test_rainbow_learn_at_atari_shapes).  The reference's Gaussian draws are written
+    into the graph's static noise buffer before every learn() (agent._noise = "static")."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load("rainbow_cnn_atari")
+    h = lambda k: z[f"hyper/{k}"].item()
+    H, A, K, B, n = int(h("H")), int(h("A")), int(h("num_support")), int(h("B")), int(h("n_step"))
+    S = tuple(int(v) for v in z["hyper/S"])
+    agent = Agent("rainbow", state_size=S, action_size=A, hidden_size=H, head="cnn", optim_config={"name": "adam", "lr": h("lr")},
+                  gamma=h("gamma"), buffer_size=64, batch_size=B, start_train_step=0, target_update_period=10000, run_step=100000,
+                  n_step=n, alpha=h("alpha"), beta=h("beta"), learn_period=1, uniform_sample_prob=h("uniform_sample_prob"),
+                  v_min=h("v_min"), v_max=h("v_max"), num_support=K, device="cuda", backend="native", use_graph=True)
+    shapes = {k: v.shape for k, v in agent.network.state_dict().items()}
+    seed = int(z["recipe_seed"])
+    w0 = {k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, seed).items()}
+    wt = {k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, seed + 1).items()}
+    rng = np.random.RandomState(int(z["fill_seed"]))
+    raw = [synth.raw_transition(rng, S, A) for _ in range(int(z["fill"]))]
+    n_rows = len(raw) - n + 1
+    cols = {"state": np.concatenate([raw[i]["state"] for i in range(n_rows)], 0),
+            "next_state": np.concatenate([raw[i + n - 1]["next_state"] for i in range(n_rows)], 0)}
+    for k in ("action", "reward", "done"):
+        cols[k] = z[f"buf_{k}"]
+    agent.memory.first_store = False
+    agent.memory.store_soa(cols)
+    torch.manual_seed(int(h("torch_seed")))
+    noise = []
+    for _ in range(3):
+        d = {}
+        for tag, (i, o) in (("a1", (H, H)), ("v1", (H, H)), ("a2", (H, K * A)), ("v2", (H, K))):
+            d[tag] = (torch.randn(i).cuda(), torch.randn(o).cuda())
+        noise.append(d)
+    agent._noise = "static"
+    agent._static, agent._graph = agent._alloc_static(), None
+    for rep in range(3):
+        agent.network.load_state_dict(w0)
+        agent.target_network.load_state_dict(wt)
+        agent._net.m.zero_()
+        agent._net.v.zero_()
+        agent._adam_steps = 0
+        agent._net.set_hyper(h("lr"), 0.9, 0.999, 1e-8, 0)
+        agent.memory._tree.load(z["tree0"], float(np.asarray(z["maxp0"]).reshape(-1)[0]), int(z["tree_index0"]), n_rows)
+        for i in range(3):
+            agent.network.pack_noise(noise[i], agent._static["noise"][i])
+        np.random.seed(int(h("np_seed")))
+        result = agent.learn()
+    assert agent._graph is not None, "learn() was not captured"
+    for k in ("loss", "max_Q", "max_logit", "min_logit"):
+        np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
+    st = agent._static
+    assert np.array_equal(npy(st["idx"]), z["learn/indices"].astype(np.int64))
+    assert np.array_equal(npy(st["w"]), z["learn/weights"].astype(np.float32).reshape(-1))
+    np.testing.assert_allclose(npy(st["logits"][0]), z["learn/logit"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=2e-5, atol=1e-6)
+    grads = {k: v.cpu().numpy() for k, v in agent._net.export_state(agent._net.grads).items()}
+    _thin_cmp(grads, z, "grad_thin/", scale_of=lambda k: z[f"grad_absmax/{k}"], tol=1e-5, what="d(loss)/d")
