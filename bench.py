@@ -257,7 +257,7 @@ def rainbow_leg(rank, world, local_rank, dist, updates, warmup, capacity, filled
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     out = {"metric": "learner_updates_per_s (Rainbow, config.rainbow.atari shapes, B=32 per GPU)", "value": world * updates / dt, "unit": "updates/s",
@@ -297,6 +297,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("JH_FORCE_DIST") == "1"  # exercise the DP code path on a single rank (testing)
@@ -304,14 +305,17 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29577")  # the launcher (torch.distributed.run --master-port P) normally sets it
+        # JH_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses that) -- the plumbing test of tests/test_dp_two_ranks_gpu.py
+        backend = os.environ.get("JH_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
     from jorldy_amd.manager import NativeCollector, VecCollector
-    from jorldy_amd.parallel import make_grad_sync, pin_to_gpu_node, ranks_sharing_node
+    from jorldy_amd.parallel import attach_data_parallel, pin_to_gpu_node, ranks_sharing_node
 
     # "actors pinned to host cores": every rank's collector thread on the cores next to ITS GPU (two PCIe crossings per
     # timestep; the far socket costs +40 % per step); ranks whose GPUs hang off the same NUMA node split its cores
@@ -327,7 +331,7 @@ def main():
                   run_step=10_000_000, num_workers=W, device=f"cuda:{local_rank}")
     agent.memory.first_store = False
     if dist is not None:
-        agent.grad_sync = make_grad_sync(agent.network, dist)
+        attach_data_parallel(agent, dist)
     env = ops.CartPoleVec(W, seed=100 + rank)
     collector = (VecCollector if args.python_collector or agent.backend != "native" else NativeCollector)(env, agent, W)
 
@@ -358,7 +362,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -470,6 +470,31 @@ int jh_feed_emit(jh_feed* f, const int64_t* d_action, const float* d_q, const fl
 /* Blocking read of the flags word (bit 0: plane ring overrun) and the number of planes written so far. */
 int jh_feed_state(jh_feed* f, int32_t* h_flags, int64_t* h_planes_written, jh_stream stream);
 
+/* ------------------------------------------------------------------ data-parallel learners: the collective
+ * The reference has ONE learner and no collective (its "distributed" mode is Ray actors feeding that learner,
+ * manager/distributed_manager.py, process.py); BASELINE.json's north star re-expresses Ape-X's many-actor / one-learner
+ * layout as one learner per GPU that averages gradients between backward and clip_grad_norm_ / optimizer.step()
+ * (core/agent/ppo.py:164-169, ape_x.py:118-122, rainbow.py:236-238).  This is that step: one RCCL communicator per
+ * process (one rank per GPU, xGMI inside a node), bound at run time (dlopen of librccl.so.1: single-GPU users need no RCCL).
+ *   jh_comm_unique_id   rank 0 creates the 128-byte id; the caller ships it to the other ranks (any side channel:
+ *                       a file, MPI, torch.distributed's store).
+ *   jh_comm_create      collective over all ranks (ncclCommInitRank on ctx's device).
+ *   jh_comm_allreduce_mean_f32   in place, d_bucket[i] <- mean over ranks (ncclAvg), enqueued on `stream`: the flat
+ *                       gradient bucket of jh_pponet_* / jh_rbnet_* between their backward and their optimizer step.
+ *                       Capturable into a hipGraph (every rank must then replay in the same order).
+ *   jh_comm_broadcast   bytes from `root` to all (identical initial weights / optimizer moments).
+ *   jh_comm_allgather_f64   n doubles per rank -> [nranks][n] (sharded PER: {root, count, min sampled priority},
+ *                       core/buffer/per_buffer.py:88-94 evaluated for the logical buffer over all shards).          */
+#define JH_COMM_ID_BYTES 128
+typedef struct jh_comm jh_comm;
+int jh_comm_unique_id(void* h_id128);
+int jh_comm_create(jh_ctx* ctx, int32_t nranks, int32_t rank, const void* h_id128, jh_comm** out);
+void jh_comm_destroy(jh_comm* m);
+int jh_comm_info(const jh_comm* m, int32_t* nranks, int32_t* rank);
+int jh_comm_allreduce_mean_f32(jh_comm* m, float* d_bucket, int64_t n, jh_stream stream);
+int jh_comm_broadcast(jh_comm* m, void* d_buf, int64_t bytes, int32_t root, jh_stream stream);
+int jh_comm_allgather_f64(jh_comm* m, const double* d_in, double* d_out, int64_t n, jh_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

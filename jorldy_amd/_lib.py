@@ -134,6 +134,13 @@ _PROTOS = {
     "jh_cartpole_destroy": (None, [_vp]),
     "jh_cartpole_obs": (C.c_int, [_vp, _vp]),
     "jh_cartpole_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "jh_comm_unique_id": (C.c_int, [_vp]),
+    "jh_comm_create": (C.c_int, [_vp, _i32, _i32, _vp, _pp]),
+    "jh_comm_destroy": (None, [_vp]),
+    "jh_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "jh_comm_allreduce_mean_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "jh_comm_broadcast": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "jh_comm_allgather_f64": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

@@ -181,7 +181,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
         self.memory.flush()  # held per-step stores -> HBM before anything (possibly a replayed graph) reads the ring
         extra = self._draw(st)
         graphable = (self.use_graph and self._lr0 is not None and (self._noise is None or isinstance(self._noise, str)) and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
-                     and (self.grad_sync is None or self.graph_with_collective))
+                     and (self.grad_sync is None or (self.graph_with_collective and getattr(self.grad_sync, "capturable", True))))
         if graphable and self._graph is None and self._warm:
             try:
                 g = torch.cuda.CUDAGraph()

@@ -337,7 +337,7 @@ class PPO(BaseAgent):
         if pin is not None:  # arrival marker in the LAST element the last update's loss kernel writes (c2 = a mean of squares: never -1)
             pin.np[st["n_upd"] - 1, 7] = -1.0
         graphable = (self.use_graph and not ops._PROF["on"] and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
-                     and (self.grad_sync is None or self.graph_with_collective))
+                     and (self.grad_sync is None or (self.graph_with_collective and getattr(self.grad_sync, "capturable", True))))
         split = os.environ.get("JH_PPO_SPLIT_GRAPH", "1") == "1"  # pre-phase and minibatch phase as two graphs, the shuffles between their launches
         if graphable and self._graph is None and getattr(self, "_warm", False):
             try:

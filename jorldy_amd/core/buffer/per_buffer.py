@@ -101,24 +101,28 @@ class PERBuffer(ReplayBuffer):
         u = np.random.uniform(size=batch_size - n_uni)
         return uni, u
 
-    def attach_shards(self, dist, group=None):
+    def attach_shards(self, dist, group=None, transport=None):
         """Data-parallel learners (jorldy_amd.parallel.attach_data_parallel): this rank's buffer becomes one shard of
         a logical buffer of world_size x buffer_size slots; sampling stays local, the IS weights are normalised over
         the global batch against the global root / count (parallel.sharded_is_weights)."""
-        self._shards = (dist, group)
+        if transport is None:
+            from ...parallel import Transport
+
+            transport = Transport(dist, group, self.device)
+        self._shards = (dist, group, transport)
 
     def _global_weights(self, beta, idx, w_out, stats):
         """parallel.sharded_is_weights (the reference form, used by the gloo test) as two small kernels around ONE
         all-gather of 3 float64 per rank: jh_per_shard_stats -> all_gather -> jh_per_weights_sharded."""
-        dist, group = self._shards
-        G = dist.get_world_size(group)
+        dist, group, transport = self._shards
+        G = transport.world
         if getattr(self, "_shard_bufs", None) is None or self._shard_bufs[1].numel() != 3 * G:
             self._shard_bufs = (torch.zeros(3, dtype=torch.float64, device=self.device), torch.zeros(3 * G, dtype=torch.float64, device=self.device))
         loc, allv = self._shard_bufs
         B = int(idx.numel())
         self._tree.shard_stats(B, loc)
         if G > 1:
-            dist.all_gather_into_tensor(allv, loc, group=group)
+            transport.all_gather_f64_(allv, loc)
         else:
             allv.copy_(loc)
         self._tree.weights_sharded(B, beta, allv, w_out)

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -77,13 +78,15 @@ struct jh_pinned_slab {
   void* dev = nullptr;  // device-visible alias of `host`
   size_t bytes = 0;
   hipEvent_t ev = nullptr;
-  bool pending = false;
+  bool pending = false;  // release event recorded, not yet known to have fired
+  bool in_use = false;   // handed out by jh_ctx_slab, not yet released (guarded by jh_ctx::mu)
 };
 
 struct jh_ctx {
   int device = 0;
-  static constexpr int kSlabs = 8;
-  jh_pinned_slab slabs[kSlabs];
+  static constexpr int kSlabs = 8;      // initial ring; grows (never shrinks) when every slab is held by some caller
+  static constexpr int kMaxSlabs = 64;
+  std::deque<jh_pinned_slab> slabs;     // deque: growing keeps the addresses callers hold stable
   int next_slab = 0;
   // small device scratch for reductions (partials) -- grows on demand; outgrown blocks stay alive (captured graphs)
   void* scratch = nullptr;
@@ -92,7 +95,8 @@ struct jh_ctx {
   std::mutex mu;  // slabs + scratch are shared by the threads of a process (learner, batched actors, ring producers)
 };
 
-// Get a pinned slab of at least `bytes` (waits for its previous use to drain).
+// Get a pinned slab of at least `bytes` (waits for its previous use to drain).  The slab belongs to the caller -- any thread
+// of the process -- until jh_ctx_slab_release; slabs other callers still hold are skipped, a fresh one is added when all are held.
 int jh_ctx_slab(jh_ctx* ctx, size_t bytes, jh_pinned_slab** out);
 // Mark the slab busy until everything enqueued on `stream` so far has executed.
 int jh_ctx_slab_release(jh_ctx* ctx, jh_pinned_slab* slab, hipStream_t stream);

@@ -70,37 +70,65 @@ JH_EXPORT int jh_ctx_sync(jh_ctx* ctx, jh_stream stream) {
 }
 
 // Slabs and scratch are shared by every thread that uses this context (learner thread, batched-actor thread, ring
-// producers): the round-robin cursor and the scratch list are guarded by the context's mutex.  A slab handed out is
-// used by ONE caller until its release event has been recorded.
+// producers): cursor, in_use / pending flags and the scratch list are guarded by the context's mutex.  A slab handed out
+// stays with ONE caller (in_use) until jh_ctx_slab_release: a second thread that wraps the ring skips it instead of
+// overwriting -- or, on growth, freeing -- memory the first is still filling (jh_store_stage_begin holds its slab across
+// calls).  When every slab is held a new one is appended.
 int jh_ctx_slab(jh_ctx* ctx, size_t bytes, jh_pinned_slab** out) {
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  jh_pinned_slab& s = ctx->slabs[ctx->next_slab];
-  ctx->next_slab = (ctx->next_slab + 1) % jh_ctx::kSlabs;
-  if (s.pending) {
-    JH_HIP(hipEventSynchronize(s.ev));
-    s.pending = false;
+  std::unique_lock<std::mutex> lock(ctx->mu);
+  if (ctx->slabs.empty()) ctx->slabs.resize(jh_ctx::kSlabs);
+  const int n = (int)ctx->slabs.size();
+  jh_pinned_slab* pick = nullptr;
+  for (int k = 0; k < n; ++k) {
+    jh_pinned_slab& c = ctx->slabs[(ctx->next_slab + k) % n];
+    if (!c.in_use) {
+      pick = &c;
+      ctx->next_slab = (ctx->next_slab + k + 1) % n;
+      break;
+    }
   }
+  if (!pick) {
+    if (n >= jh_ctx::kMaxSlabs) return jh_fail(JH_ERR_STATE, "all %d pinned staging slabs are held (a jh_store_stage_begin without its commit?)", n);
+    ctx->slabs.emplace_back();
+    pick = &ctx->slabs.back();
+  }
+  jh_pinned_slab& s = *pick;
+  s.in_use = true;
+  const bool wait = s.pending;
+  s.pending = false;
+  lock.unlock();  // the slab is ours now: wait / (re)allocate without holding up the other threads
+  auto fail = [&](int rc) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    s.in_use = false;
+    return rc;
+  };
+  if (wait && hipEventSynchronize(s.ev) != hipSuccess) return fail(jh_fail(JH_ERR_HIP, "hipEventSynchronize on a staging slab failed"));
   if (s.bytes < bytes) {
-    if (s.host) JH_HIP(hipHostFree(s.host));
+    if (s.host && hipHostFree(s.host) != hipSuccess) return fail(jh_fail(JH_ERR_HIP, "hipHostFree of a staging slab failed"));
     size_t want = 1 << 16;
     while (want < bytes) want <<= 1;
     s.host = nullptr;
     s.bytes = 0;
     // coherent, device-mapped pinned memory: kernels may read small inputs in place,
     // hipMemcpyAsync from it is a true async DMA.
-    JH_HIP(hipHostMalloc(&s.host, want, hipHostMallocMapped));
-    JH_HIP(hipHostGetDevicePointer(&s.dev, s.host, 0));
+    if (hipHostMalloc(&s.host, want, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&s.dev, s.host, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      s.host = nullptr;
+      return fail(jh_fail(JH_ERR_HIP, "hipHostMalloc of a %zu-byte staging slab failed", want));
+    }
     s.bytes = want;
   }
-  if (!s.ev) JH_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return fail(jh_fail(JH_ERR_HIP, "hipEventCreate failed"));
   *out = &s;
   return JH_OK;
 }
 
 int jh_ctx_slab_release(jh_ctx* ctx, jh_pinned_slab* slab, hipStream_t stream) {
-  (void)ctx;
-  JH_HIP(hipEventRecord(slab->ev, stream));
-  slab->pending = true;
+  hipError_t e = hipEventRecord(slab->ev, stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  slab->pending = (e == hipSuccess);
+  slab->in_use = false;
+  if (e != hipSuccess) return jh_fail(JH_ERR_HIP, "hipEventRecord on a staging slab -> %s", hipGetErrorString(e));
   return JH_OK;
 }
 

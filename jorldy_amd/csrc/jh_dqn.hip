@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) jh_td_loss_kernel(TdArgs a) {
         a.stats[0] = s_l / (float)a.B;
         a.stats[1] = m_q;
         a.stats[2] = s_t / (float)a.B;
+        __threadfence_system();  // stats may be device-mapped host memory and [3] is the arrival mark the host spins on: payload first
         a.stats[3] = 0.f;
       }
     } else {
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(256) jh_td_finish_kernel(int nb, int B, const 
     stats[0] = l / (float)B;
     stats[1] = m;
     stats[2] = t / (float)B;
+    __threadfence_system();  // payload before the arrival mark (mapped host memory, jh_host_wait_marks)
     stats[3] = 0.f;
   }
 }
@@ -489,7 +491,9 @@ __global__ void __launch_bounds__(256) jh_c51_finish_kernel(int nb, C51Args a) {
     a.stats[2] = ml;
     a.stats[3] = nl;
     a.stats[4] = mean_kl;
-    a.stats[5] = a.stats[6] = a.stats[7] = 0.f;
+    a.stats[6] = 0.f;
+    __threadfence_system();  // payload before the arrival marks [5], [7] (mapped host memory, jh_host_wait_marks)
+    a.stats[5] = a.stats[7] = 0.f;
   }
 }
 

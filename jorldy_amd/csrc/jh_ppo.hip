@@ -418,6 +418,7 @@ __device__ __forceinline__ void ppo_finish_stats(float s_smin, float s_e1, float
     stats[4] = max_ratio;
     stats[5] = min_prob;
     stats[6] = c1;
+    __threadfence_system();  // the host waits for [7] of the last update's row (mapped host memory): payload first
     stats[7] = c2;
   }
 }

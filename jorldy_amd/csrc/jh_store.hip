@@ -43,6 +43,7 @@ JH_EXPORT void jh_store_destroy(jh_store* s) {
   if (!s) return;
   (void)hipSetDevice(s->ctx->device);
   (void)hipDeviceSynchronize();
+  if (s->staged) (void)jh_ctx_slab_release(s->ctx, s->staged, nullptr);  // a begun, never committed stage: hand the slab back
   for (void* p : s->dev) (void)hipFree(p);
   delete s;
 }

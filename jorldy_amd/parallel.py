@@ -7,14 +7,110 @@ computes the same global norm and takes the identical Adam step.
 Gradient sizes here are ~1 MB (266 755 fp32 params for PPO CartPole): the all-reduce is latency-
 bound, so a single flat bucket, in place, on the compute stream is the right shape.
 """
+import os
+
 import torch
 
 
-class FlatGradSync:
-    def __init__(self, module, dist, group=None):
+class Transport:
+    """How the ranks' collectives travel.  Three forms, chosen once per process group:
+
+      "rccl"   jh_comm_* of the C ABI (include/jorldy_hip.h): the library's own RCCL communicator, ncclAvg all-reduce in
+               place on the CURRENT stream -- the default when the process group's backend is nccl (= RCCL);
+               torch.distributed is only the side channel that ships the 128-byte unique id.  Capturable.
+      "torch"  torch.distributed collectives on device tensors (backend nccl; JH_DP_COLLECTIVE=torch, or when the
+               library's communicator cannot be created).  Capturable.
+      "host"   backend gloo: device tensors are staged through host memory around the collective.  This is the
+               two-ranks-on-one-GPU test transport (RCCL refuses two ranks on one device); never capturable."""
+
+    def __init__(self, dist, group=None, device=None):
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        backend = str(dist.get_backend(group)).lower()
+        self.kind = "host" if "gloo" in backend and "nccl" not in backend else "torch"
+        self.comm = None
+        if self.kind == "torch" and os.environ.get("JH_DP_COLLECTIVE", "rccl") != "torch" and device is not None and torch.device(device).type == "cuda":
+            try:
+                self._create_comm(torch.device(device))
+                self.kind = "rccl"
+            except Exception as e:  # e.g. librccl.so.1 not loadable: keep torch.distributed's own communicator
+                print(f"[jorldy_amd] C-ABI RCCL communicator unavailable ({type(e).__name__}: {e}); using torch.distributed collectives")
+        self.capturable = self.kind in ("rccl", "torch")
+
+    def _create_comm(self, device):
+        import ctypes as C
+
+        from . import _lib as L
+
+        lib = L.load()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            L.check(lib.jh_comm_unique_id(L.ptr(ident)))
+        ident = ident.to(device)  # the side channel: one 128-byte broadcast on the existing process group
+        self.dist.broadcast(ident, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        ident = ident.cpu()
+        h = C.c_void_p()
+        L.check(lib.jh_comm_create(L.ctx(device.index), self.world, self.rank, L.ptr(ident), C.byref(h)))
+        self.comm, self._lib, self._L = h, lib, L
+
+    def __del__(self):
+        try:
+            if self.comm is not None:
+                self._lib.jh_comm_destroy(self.comm)
+                self.comm = None
+        except Exception:
+            pass
+
+    # ---- the three collectives the learners need ----------------------------------------------------
+    def mean_(self, flat):
+        """flat (fp32, contiguous) <- mean over ranks, in place."""
+        if self.kind == "rccl":
+            self._L.check(self._lib.jh_comm_allreduce_mean_f32(self.comm, self._L.ptr(flat), int(flat.numel()), self._L.stream_ptr()))
+        elif self.kind == "torch" or not flat.is_cuda:
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+        else:
+            h = flat.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(h.div_(self.world))
+        return flat
+
+    def broadcast_(self, t, src=0):
+        if self.kind == "rccl" and t.is_contiguous():
+            self._L.check(self._lib.jh_comm_broadcast(self.comm, self._L.ptr(t), int(t.numel() * t.element_size()), int(src), self._L.stream_ptr()))
+            return t
+        gsrc = self.dist.get_global_rank(self.group, src) if self.group is not None else src
+        if self.kind != "host" or not t.is_cuda:
+            self.dist.broadcast(t, src=gsrc, group=self.group)
+        else:
+            h = t.cpu()
+            self.dist.broadcast(h, src=gsrc, group=self.group)
+            t.copy_(h)
+        return t
+
+    def all_gather_f64_(self, out, loc):
+        """out [world * n] <- the ranks' loc [n] (float64) in rank order."""
+        if self.kind == "rccl":
+            self._L.check(self._lib.jh_comm_allgather_f64(self.comm, self._L.ptr(loc), self._L.ptr(out), int(loc.numel()), self._L.stream_ptr()))
+        elif self.kind == "torch" or not loc.is_cuda:
+            self.dist.all_gather_into_tensor(out, loc, group=self.group)
+        else:
+            h = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(h, loc.cpu(), group=self.group)
+            out.copy_(h)
+        return out
+
+
+class FlatGradSync:
+    """Mean gradient over ranks for an nn.Module (the torch mirror backends): grads packed into one flat fp32
+    bucket -> Transport.mean_ -> unpacked.  The native networks' gradient already IS one flat bucket: reduce_flat."""
+
+    def __init__(self, module, dist, group=None, transport=None):
+        self.dist, self.group = dist, group
         self.params = [p for p in module.parameters() if p.requires_grad]
+        self.transport = transport or Transport(dist, group, self.params[0].device)
+        self.world = self.transport.world
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
         self.views, o = [], 0
@@ -22,26 +118,28 @@ class FlatGradSync:
             self.views.append(self.flat[o : o + p.numel()].view_as(p))
             o += p.numel()
 
+    @property
+    def capturable(self):
+        return self.transport.capturable
+
     def __call__(self):
         """Call between backward and clip/step: p.grad <- mean over ranks of p.grad."""
         torch._foreach_copy_(self.views, [p.grad for p in self.params])
-        self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(self.world)
+        self.transport.mean_(self.flat)
         torch._foreach_copy_([p.grad for p in self.params], self.views)
 
     def reduce_flat(self, flat):
         """Native-backend form: the gradient already IS one flat bucket (jh_pponet_* writes it in
         state_dict order) -> one in-place all-reduce, no packing copies."""
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world)
+        self.transport.mean_(flat)
 
     def broadcast_weights(self, src=0):
         for p in self.params:
-            self.dist.broadcast(p.data, src=src, group=self.group)
+            self.transport.broadcast_(p.data, src)
 
 
-def make_grad_sync(module, dist, group=None):
-    sync = FlatGradSync(module, dist, group)
+def make_grad_sync(module, dist, group=None, transport=None):
+    sync = FlatGradSync(module, dist, group, transport)
     sync.broadcast_weights(0)  # identical start (ncclBroadcast only at init/load)
     return sync
 
@@ -52,17 +150,21 @@ class BucketSync:
     place, one RCCL all-reduce (Rainbow Atari: 12 MB -- bandwidth- rather than latency-bound, still a single
     bucket: the backward of a B=32 batch is ~200 us, there is nothing to overlap it with)."""
 
-    def __init__(self, dist, group=None):
+    def __init__(self, dist, group=None, transport=None, device=None):
         self.dist, self.group = dist, group
-        self.world = dist.get_world_size(group)
+        self.transport = transport or Transport(dist, group, device)
+        self.world = self.transport.world
+
+    @property
+    def capturable(self):
+        return self.transport.capturable
 
     def reduce_flat(self, flat):
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world)
+        self.transport.mean_(flat)
 
     def broadcast(self, *buckets, src=0):
         for b in buckets:
-            self.dist.broadcast(b, src=src, group=self.group)
+            self.transport.broadcast_(b, src)
 
 
 def sharded_is_weights(p_sampled, root, count, usp, beta, dist=None, group=None):
@@ -102,18 +204,21 @@ def attach_data_parallel(agent, dist, group=None):
     one all-gather of {root, count, min sampled p} per learn()).  Works for PPO (native or torch), the torch-encoder DQN family and the
     native Rainbow network.  Returns the hook (also stored as agent.grad_sync)."""
     net = getattr(agent, "_net", None)
+    device = getattr(agent, "device", None)
+    transport = Transport(dist, group, device)
     if net is not None and hasattr(net, "target"):  # ops.RainbowNet
-        sync = BucketSync(dist, group)
+        sync = BucketSync(dist, group, transport)
         sync.broadcast(net.params, net.target, net.m, net.v)
     else:
-        sync = make_grad_sync(agent.network, dist, group)
+        sync = make_grad_sync(agent.network, dist, group, transport)
         if hasattr(agent, "target_network"):
             for p in agent.target_network.parameters():
-                dist.broadcast(p.data, src=0, group=group)
+                transport.broadcast_(p.data, 0)
     mem = getattr(agent, "memory", None)
     if mem is not None and hasattr(mem, "attach_shards"):  # PER: this rank's buffer is one shard of the logical buffer
-        mem.attach_shards(dist, group)
+        mem.attach_shards(dist, group, transport)
     agent.grad_sync = sync
+    agent.graph_with_collective = bool(getattr(agent, "graph_with_collective", True)) and transport.capturable
     agent._graph = None
     return sync
 

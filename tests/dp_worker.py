@@ -1,0 +1,129 @@
+"""One rank of the two-ranks-on-one-GPU data-parallel tests (tests/test_dp_two_ranks_gpu.py).  Not a test module.
+
+usage: python tests/dp_worker.py <mode: ppo|rainbow> <rank> <world> <port> <out.npz>
+RCCL refuses two ranks on one device, gloo does not: the process group is gloo, the gradient bucket is staged through
+host memory around the all-reduce (jorldy_amd.parallel.Transport kind "host"); everything else -- the native agents'
+DP branch (ppo_update(do_adam=0) -> reduce_flat -> adam_step; RainbowNet backward -> reduce_flat -> optim_step; the
+sharded PER weights) -- is the code the N-GPU RCCL run executes."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import synth  # noqa: E402  (test infrastructure: recipes for weights / rollouts)
+
+PPO_CFG = dict(S=4, A=2, H=512, W=8, T=128, B=256, E=3, lr=2.5e-4, seed=20260925)   # config.ppo.cartpole (BASELINE configs[1])
+RB_CFG = dict(S=4, A=3, H=32, K=51, B=32, N=256, fill=200, n_step=3, lr=1e-3)
+
+
+def ppo_agent(W, B, **kw):
+    from jorldy_amd.core.agent import Agent
+
+    c = PPO_CFG
+    agent = Agent("ppo", state_size=c["S"], action_size=c["A"], hidden_size=c["H"], network="discrete_policy_value", optim_config={"name": "adam", "lr": c["lr"]},
+                  batch_size=B, n_step=c["T"], n_epoch=c["E"], _lambda=0.95, epsilon_clip=0.1, vf_coef=1.0, ent_coef=0.01, clip_grad_norm=1.0, gamma=0.99,
+                  run_step=100000, num_workers=W, device="cuda", backend="native", lr_decay=False, **kw)
+    rec = synth.ppo_recipe({k: v.shape for k, v in agent.network.state_dict().items()}, c["seed"])
+    agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in rec.items()})
+    agent.memory.first_store = False
+    return agent
+
+
+def ppo_rows(rank):
+    c = PPO_CFG
+    trs = synth.ppo_rollout(np.random.RandomState(50 + rank), c["W"] * c["T"], c["S"], c["A"], False, clamp_every=0)
+    return {k: np.concatenate([t[k] for t in trs], 0) for k in ("state", "next_state", "reward", "done", "action")}
+
+
+def rainbow_agent(B, N, **kw):
+    from jorldy_amd.core.agent import Agent
+
+    c = RB_CFG
+    agent = Agent("rainbow", state_size=c["S"], action_size=c["A"], hidden_size=c["H"], optim_config={"name": "adam", "lr": c["lr"]}, buffer_size=N, batch_size=B,
+                  start_train_step=0, target_update_period=10000, run_step=100000, n_step=c["n_step"], num_support=c["K"], v_min=-1, v_max=10, alpha=0.5, beta=0.4,
+                  learn_period=1, uniform_sample_prob=0.05, device="cuda", backend="native", **kw)
+    shapes = {k: v.shape for k, v in agent.network.state_dict().items()}
+    agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, 77).items()})
+    agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, 78).items()})
+    agent.memory.first_store = False
+    return agent
+
+
+def rainbow_shard(rank):
+    """This rank's replay shard: rows + priorities (slot order)."""
+    c = RB_CFG
+    rng = np.random.RandomState(900 + rank)
+    n = c["fill"] + 17 * rank  # shards of different fill: COUNT and ROOT differ per rank
+    cols = {"state": rng.randn(n, c["S"]).astype(np.float32), "next_state": rng.randn(n, c["S"]).astype(np.float32),
+            "action": rng.randint(0, c["A"], size=(n, 1)), "reward": rng.choice([-1.0, 0.0, 1.0, 0.5], size=(n, c["n_step"], 1)),
+            "done": rng.rand(n, c["n_step"], 1) < 0.1}
+    prio = (rng.rand(n) ** 2 + 0.01).astype(np.float32).astype(np.float64) * (1.0 + rank)
+    return cols, prio
+
+
+def main():
+    mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    import torch.distributed as dist
+
+    from jorldy_amd.parallel import attach_data_parallel
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    res = {}
+    try:
+        if mode == "ppo":
+            c = PPO_CFG
+            agent = ppo_agent(c["W"], c["B"])
+            if rank == 1:  # attach must overwrite rank 1's weights with rank 0's
+                with torch.no_grad():
+                    for p in agent.network.parameters():
+                        p.add_(0.01)
+            sync = attach_data_parallel(agent, dist)
+            assert sync.transport.kind == "host" and not agent.graph_with_collective
+            perms = []
+            real_shuffle = np.random.shuffle
+
+            def recording_shuffle(x):
+                real_shuffle(x)
+                perms.append(np.array(x, copy=True))
+
+            np.random.shuffle = recording_shuffle
+            np.random.seed(200 + rank)
+            result = agent.process(ppo_rows(rank), c["T"])
+            np.random.shuffle = real_shuffle
+            torch.cuda.synchronize()
+            n_upd = c["E"] * (c["W"] * c["T"] // c["B"])
+            res = dict(params=agent._net.params.cpu().numpy(), perms=np.stack(perms), stats=np.asarray(agent._static["stats_pin"].np[: n_upd + 1]).copy(),
+                       grads=agent._net.grads.cpu().numpy(), n_upd=n_upd, **{f"result_{k}": v for k, v in result.items()})
+        else:
+            c = RB_CFG
+            agent = rainbow_agent(c["B"], c["N"], use_graph=False)
+            cols, prio = rainbow_shard(rank)
+            agent.memory.store_soa(cols, priorities=prio)
+            N = c["N"]
+            sync = attach_data_parallel(agent, dist)
+            assert sync.transport.kind == "host" and agent.memory._shards is not None
+            np.random.seed(300 + rank)
+            torch.manual_seed(40 + rank)  # the ranks draw DIFFERENT noise: the averaged gradient still gives identical weights
+            losses = []
+            for it in range(3):
+                tree_before = agent.memory.sum_tree.copy()
+                count_before = agent.memory.buffer_counter
+                losses.append(agent.learn()["loss"])
+            torch.cuda.synchronize()
+            st = agent._static
+            res = dict(params=agent._net.params.cpu().numpy(), target=agent._net.target.cpu().numpy(), idx=st["idx"].cpu().numpy(), w=st["w"].cpu().numpy(),
+                       tree_before=tree_before, count_before=count_before, beta=agent.beta, usp=agent.uniform_sample_prob, losses=np.asarray(losses), N=N)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    np.savez(out, **res)
+    print(f"dp_worker {mode} rank {rank} ok")
+
+
+if __name__ == "__main__":
+    main()
