@@ -437,7 +437,7 @@ def gen_dqn_family(out_dir, only=None):
                   dict(markers=["q", "target_q", "next_q", "next_target_q", "max_a", "td_error", "p_j", "loss", "weights", "indices", "reward", "done"], with_q=True,
                        over=dict(state_size=(4, 84, 84), action_size=6, hidden_size=512, network="dueling", head="cnn", batch_size=512, buffer_size=640,
                                  optim_config={"name": "rmsprop", "lr": 2.5e-4 / 4, "eps": 1.5e-7, "centered": True}),
-                       fill=600, recipe=True, opt_state=("square_avg", "grad_avg"))))
+                       fill=600, recipe=True, opt_state=("square_avg", "grad_avg"), grad64=True)))
     # the same learner on a small image with clip_grad_norm BELOW the gradient norm (at config.ape_x.atari's 40 the clip is a no-op
     # for any sane batch: the fixture above records norm 8.9): pins clip -> centered RMSprop against the reference
     specs.append(("ape_x_cnn_clip", ApeX, dict(n_step=3, alpha=0.6, beta=0.4, learn_period=1, uniform_sample_prob=0.05, num_workers=4, clip_grad_norm=0.5),
@@ -534,11 +534,38 @@ def gen_dqn_family(out_dir, only=None):
         if "pre_clip" in markers:
             tap.on_line["pre_clip"] = lambda frame: gpre.update({k: p.grad.detach().numpy().copy() for k, p in agent.network.named_parameters()})
 
+        net64 = tgt64 = None
+        if opt.get("grad64"):  # float64 twins of both networks (before the step) for a ground-truth gradient
+            import copy
+
+            net64, tgt64 = copy.deepcopy(agent.network).double(), copy.deepcopy(agent.target_network).double()
         np.random.seed(42)
         torch.manual_seed(42)
         with tap:
             result = agent.learn()
         rec = tap.records["pre_step"][0]
+        if net64 is not None:
+            # ApeX.learn (ape_x.py:79-122) restated in float64 on the SAME sampled rows and IS weights: how far the reference's own
+            # fp32 gradient is from the exact one (a K = B x 400 = 204 800-term reduction for conv1 at B = 512) -- the tests accept
+            # |ours - exact| <= max(1e-5 of the tensor's largest entry, 2 x |reference fp32 - exact|)
+            N_ = agent.memory.buffer_size
+            leaf = rec["indices"].astype(np.int64) - (N_ - 1)
+            st64 = torch.from_numpy(np.concatenate([agent.memory.buffer[i]["state"] for i in leaf], 0)).double()
+            ns64 = torch.from_numpy(np.concatenate([agent.memory.buffer[i]["next_state"] for i in leaf], 0)).double()
+            a64 = torch.from_numpy(rec["action"]).view(-1).long()
+            r64, d64 = torch.from_numpy(rec["reward"]).double(), torch.from_numpy(rec["done"]).double()
+            w64 = torch.from_numpy(np.asarray(rec["weights"], dtype=np.float32)).double().view(-1, 1)
+            q64 = net64(st64).gather(1, a64.view(-1, 1))
+            with torch.no_grad():
+                ma = net64(ns64).argmax(1, keepdim=True)
+                tq = tgt64(ns64).gather(1, ma)
+                for i in reversed(range(agent.n_step)):
+                    tq = r64[:, i] + (1 - d64[:, i]) * agent.gamma * tq
+            loss64 = (w64 * (tq - q64).abs() ** 2).mean()
+            loss64.backward()
+            out["loss64"] = np.asarray(loss64.item())
+            for k, p64 in net64.named_parameters():
+                out[f"grad64_thin/{k}"] = synth.thin(p64.grad.numpy())
         flat("learn/", rec, out)
         flat("learn/", head, out)
         if recipe:

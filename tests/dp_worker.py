@@ -16,7 +16,11 @@ sys.path.insert(0, ROOT)
 
 from oracle import synth  # noqa: E402  (test infrastructure: recipes for weights / rollouts)
 
-PPO_CFG = dict(S=4, A=2, H=512, W=8, T=128, B=256, E=3, lr=2.5e-4, seed=20260925)   # config.ppo.cartpole (BASELINE configs[1])
+# config.ppo.cartpole (BASELINE configs[1]) except lr: PPO's critic is max(mean(e1), mean(e2)) (ppo.py:147-154), a max of two MEANS -- per rank
+# over 256 rows, for one learner over 512.  Once |V - V_old| passes epsilon_clip for some rows (at lr 2.5e-4: from the third update on)
+# the ranks may take different branches than the single learner and "DP == one learner" holds only statistically.  With
+# lr 2.5e-6 the value clamp stays inactive for all 12 updates (asserted), both branches carry the same gradient, and the equality is exact.
+PPO_CFG = dict(S=4, A=2, H=512, W=8, T=128, B=256, E=3, lr=2.5e-6, seed=20260925)
 RB_CFG = dict(S=4, A=3, H=32, K=51, B=32, N=256, fill=200, n_step=3, lr=1e-3)
 
 

@@ -362,16 +362,42 @@ def test_td_learn_at_baseline_shapes(fixture, agent_name, use_graph):
         alpha = h("alpha")
         np.testing.assert_allclose(agent.memory.sum_tree[N - 1:] ** (1 / alpha), z["tree1"][N - 1:] ** (1 / alpha), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=2e-5, atol=2e-5)
-    grads = {k: v.cpu().numpy() for k, v in agent._net.export_state(agent._net.grads).items()}
-    worst = _thin_cmp(grads, z, "grad_thin/", scale_of=lambda k: z[f"grad_absmax/{k}"], tol=1e-5, what="d(loss)/d")
+    # after the step the bucket holds what p.grad holds in the reference: the gradient scaled in place by clip_grad_norm_
+    # (coefficient min(1, clip / (norm + 1e-6)), torch.nn.utils.clip_grad_norm_); the fixture stores the RAW gradient
+    coef = 1.0
+    if "grad_clip_norm" in z.files:
+        coef = min(1.0, h("clip_grad_norm") / (float(z["grad_norm"]) + 1e-6))
+    grads = {k: v.cpu().numpy() / np.float32(coef) for k, v in agent._net.export_state(agent._net.grads).items()}
+    vs64 = {}
+    if any(k.startswith("grad64_thin/") for k in z.files):
+        # the fixture also holds the EXACT gradient (the reference's learn() restated in float64 on the same rows): at B = 512 the
+        # reference's own fp32 conv1 gradient -- a 204 800-term reduction on the CPU -- is 2.5e-5 of the largest entry away from it.
+        # Accept |ours - exact| <= max(1e-5, 2 x |reference - exact|) per tensor, and report both distances
+        worst = {}
+        for k, v in grads.items():
+            g64, g32, scale = z[f"grad64_thin/{k}"], z[f"grad_thin/{k}"], float(z[f"grad_absmax/{k}"]) + 1e-30
+            e_ours, e_ref = float(np.abs(synth.thin(v) - g64).max()) / scale, float(np.abs(g32 - g64).max()) / scale
+            worst[k] = float(np.abs(synth.thin(v) - g32).max()) / scale
+            vs64[k] = {"ours_vs_exact": e_ours, "reference_vs_exact": e_ref}
+            assert e_ours <= max(1e-5, 2.0 * e_ref), f"d(loss)/d{k}: {e_ours:.3e} of the largest entry from the exact gradient (reference: {e_ref:.3e})"
+        _report(f"{fixture}_{'graph' if use_graph else 'eager'}_grad_vs_float64", vs64)
+    else:
+        worst = _thin_cmp(grads, z, "grad_thin/", scale_of=lambda k: z[f"grad_absmax/{k}"], tol=1e-5, what="d(loss)/d")
     norm = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
     np.testing.assert_allclose(norm, float(z["grad_norm"]), rtol=1e-5)
+    if coef < 1.0:
+        np.testing.assert_allclose(norm * coef, float(z["grad_clip_norm"]), rtol=1e-5)
     # optimizer moments after the step (computed from the CLIPPED gradient): m = exp_avg | grad_avg, v = exp_avg_sq | square_avg
     names = ("exp_avg", "exp_avg_sq") if oc["name"] == "adam" else ("grad_avg", "square_avg")
     mom = {}
     for bucket, nm in ((agent._net.m, names[0]), (agent._net.v, names[1])):
         got = {k: v.cpu().numpy() for k, v in agent._net.export_state(bucket).items()}
-        mom[nm] = _thin_cmp(got, z, f"opt1_thin/{nm}/", tol=2e-5, what=nm)
+        # where the fixture knows the reference's own fp32 distance from the exact gradient (vs64), a moment built from that
+        # gradient (m ~ g, v ~ g^2: twice the relative error) cannot be pinned tighter than that
+        mom[nm] = {}
+        for k, v in got.items():
+            tol_k = max(2e-5, 4.0 * vs64[k]["reference_vs_exact"]) if vs64 else 2e-5
+            mom[nm].update(_thin_cmp({k: v}, z, f"opt1_thin/{nm}/", tol=tol_k, what=nm))
     if "grad_clip_norm" in z.files:
         cn, clip = float(z["grad_clip_norm"]), h("clip_grad_norm")
         assert (cn < clip * 1.0001) and (float(z["grad_norm"]) <= clip or abs(cn - clip) < 1e-4 * clip)

@@ -83,6 +83,8 @@ def test_ppo_native_two_ranks_equal_one_learner_on_the_concatenated_batch(tmp_pa
     s_dp = 0.5 * (r0["stats"].astype(np.float64) + r1["stats"].astype(np.float64))
     # every update's loss terms: mean over 512 rows == mean of the two ranks' means (actor, entropy: exactly linear; critic is
     # max(mean, mean) per rank, ppo.py:147-154 -- equal here because both ranks take the same branch)
+    for st_ in (r0["stats"], r1["stats"], s1):  # precondition of exact equality: the value clamp is inactive, c1 == c2 up to rounding
+        np.testing.assert_allclose(st_[:n_upd, 6], st_[:n_upd, 7], rtol=1e-5, err_msg="value clamp active: per-rank max(mean, mean) may pick another branch")
     for j, name in ((1, "actor_loss"), (2, "critic_loss"), (3, "entropy_loss")):
         np.testing.assert_allclose(s1[:n_upd, j], s_dp[:n_upd, j], rtol=2e-5, atol=1e-6, err_msg=name)
     np.testing.assert_allclose(s1[:n_upd, 4], np.maximum(r0["stats"][:n_upd, 4], r1["stats"][:n_upd, 4]), rtol=1e-5)  # max_ratio
