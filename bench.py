@@ -337,10 +337,15 @@ def main():
 
     step = 0
 
-    def one_iteration():
+    prelaunch = hasattr(collector, "arm_prelaunch") and os.environ.get("JH_PRELAUNCH", "1") == "1"
+
+    def one_iteration(last=False):
+        """last: no acting kernel is enqueued ahead for an iteration that does not follow (the fences below would wait for it)."""
         nonlocal step
         transitions, _ = collector.run(T)
         step += T
+        if prelaunch and not last:
+            collector.arm_prelaunch(T)  # learn() enqueues the next rollout's acting kernel right behind its own launches
         result = agent.process(transitions, step)
         collector.sync(None)
         return result
@@ -351,14 +356,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_iteration()
+    for i in range(args.warmup):
+        one_iteration(last=i == args.warmup - 1)
     fence()
     if hasattr(collector, "stats"):
         collector.stats()  # reset
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = one_iteration()
+    for i in range(args.steps):
+        result = one_iteration(last=i == args.steps - 1)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -67,6 +67,12 @@ int jh_ctx_sync(jh_ctx* ctx, jh_stream stream);  /* hipStreamSynchronize */
 int jh_host_wait_marks(const float* base, const int32_t* idx, int32_t n, float sentinel, double timeout_s);
 /* The same on 32-bit words (e.g. the low words of int64 actions preset to -1 by the host). */
 int jh_host_wait_words(const uint32_t* base, const int32_t* idx, int32_t n, uint32_t sentinel, double timeout_s);
+/* The epoch shuffles of PPO.learn (core/agent/ppo.py:116-118: idxs = np.arange(M); np.random.shuffle(idxs) per epoch, cumulative)
+ * drawn IN PLACE from numpy's global MT19937 with numpy's algorithm (RandomState._shuffle_raw + random_interval), through the
+ * state address / next_uint32 / next_uint64 function pointers of BitGenerator.ctypes: h_perm_out [epochs][n] = the index list of
+ * every epoch, bit-identical to the Python calls (3 us instead of 12 us per 1024 indices).  Pure host code.                    */
+int jh_np_legacy_shuffles(void* bitgen_state, void* next_uint32_fn, void* next_uint64_fn, int64_t n, int32_t epochs,
+                          int64_t* h_perm_out);
 int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void** dev_out);
 void jh_pinned_free(void* host);
 
@@ -293,9 +299,9 @@ int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_
 int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs, int64_t* h_action, float* h_logits_out,
                            float* h_value_out, int32_t training, jh_stream stream);
 /* The continuous policy (ppo.py:55-63): h_action [W][A] = tanh(Normal(clamp(mu_raw, -5, 5), exp(tanh(log_std_raw)))
- * .sample()), tanh(mu) when training == 0; h_mu_raw_out / h_log_std_raw_out [W][A] optional.                      */
+ * .sample()), tanh(mu) when training == 0; h_mu_raw_out / h_log_std_raw_out [W][A] and h_value_out [W] optional.   */
 int jh_pponet_act_continuous(jh_pponet* n, int32_t W, const float* h_obs, float* h_action, float* h_mu_raw_out,
-                             float* h_log_std_raw_out, int32_t training, jh_stream stream);
+                             float* h_log_std_raw_out, float* h_value_out, int32_t training, jh_stream stream);
 
 /* ------------------------------------------------------------------ vectorised host collector
  * Synthetic CartPole-v1 (gym is not installable in the build image): W envs stepped in one
@@ -332,6 +338,18 @@ int jh_collector_create_control(jh_ctx* ctx, jh_pponet* net, jh_control* env, jh
                                 jh_collector** out);
 void jh_collector_destroy(jh_collector* c);
 int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream);
+/* Acting-time capture: PPO.learn opens with two no-grad passes of the network over the rollout (core/agent/ppo.py:83-94:
+ * pi, value = network(state); next_value = network(next_state)[-1]); in sync mode the actors' weights ARE the learner's, so
+ * these numbers existed when the actions were sampled.  After jh_collector_set_capture every jh_collector_run of rows = W * T
+ * transitions also delivers, in the launch that commits the rows (worker-major like the store): d_h0 [rows][A] raw policy head
+ * (logits | mu_raw), d_h1 [rows][A] log_std_raw (continuous; NULL otherwise), d_value [rows] = V(state_t), d_next_value [rows]
+ * = V(state_{t+1}) (one extra value-only query after the last step; where done_t is set the entry belongs to the reset state
+ * and is multiplied by (1 - done_t) = 0 in GAE, ppo.py:96).  d_value == NULL switches capture off.                         */
+int jh_collector_set_capture(jh_collector* c, float* d_h0, float* d_h1, float* d_value, float* d_next_value, int64_t rows);
+/* Enqueue the persistent acting kernel of the NEXT jh_collector_run(T) now, e.g. right behind the learner's last launch: it
+ * starts when the stream reaches it, reads the then-current weights and waits (bounded, ~0.2 s) for the first observations.
+ * Nothing else may be enqueued on `stream` before that run.  A kernel that timed out is replaced by the run itself.      */
+int jh_collector_prelaunch(jh_collector* c, int32_t T, jh_stream stream);
 /* Host-side timing of the collection loop (microseconds per timestep): launching + waiting for the
  * actions, and stepping the envs + writing the transitions.                                        */
 int jh_collector_stats(jh_collector* c, double* act_us_per_step, double* env_us_per_step, int32_t reset);

@@ -40,6 +40,7 @@ _PROTOS = {
     "jh_prof_calibrate": (C.c_int, [_i32, _vp]),
     "jh_host_wait_marks": (C.c_int, [_vp, _vp, _i32, _f32, _f64]),
     "jh_host_wait_words": (C.c_int, [_vp, _vp, _i32, C.c_uint32, _f64]),
+    "jh_np_legacy_shuffles": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "jh_pinned_alloc": (C.c_int, [_vp, _i64, _pp, _pp]),
     "jh_pinned_free": (None, [_vp]),
     "jh_store_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _pp]),
@@ -90,7 +91,7 @@ _PROTOS = {
     "jh_pponet_adam_step": (C.c_int, [_vp, _f32, _vp, _vp]),
     "jh_pponet_ppo_update": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "jh_pponet_act_discrete": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "jh_pponet_act_continuous": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "jh_pponet_act_continuous": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jh_control_create": (C.c_int, [_i32, _i32, _i32, C.c_uint64, _pp]),
     "jh_control_destroy": (None, [_vp]),
     "jh_control_obs": (C.c_int, [_vp, _vp]),
@@ -130,6 +131,8 @@ _PROTOS = {
     "jh_feed_state": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     "jh_collector_stats": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), _i32]),
     "jh_collector_run": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "jh_collector_set_capture": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "jh_collector_prelaunch": (C.c_int, [_vp, _i32, _vp]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),
     "jh_cartpole_destroy": (None, [_vp]),
     "jh_cartpole_obs": (C.c_int, [_vp, _vp]),

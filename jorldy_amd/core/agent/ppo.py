@@ -3,7 +3,7 @@ import os
 import numpy as np
 import torch
 
-from ... import ops
+from ... import np_rng, ops
 from ..buffer import RolloutBuffer
 from ..buffer.base import h2d_small
 from ..network import Network
@@ -81,6 +81,11 @@ class PPO(BaseAgent):
         self._graph = None
         self._static = None
         self._adam_steps = 0
+        self._captured = 0            # rows whose heads / values the collector delivered for the next learn() (jh_collector_set_capture)
+        self._post_launch_hook = None  # one-shot callable run right behind learn()'s launches (NativeCollector.arm_prelaunch)
+        self._lr_step = None          # process(): step for the lr decay that learn() applies behind its launches
+        # index lists of the next learn() drawn ahead on a copy of np.random's state (np_rng.Predraw); JH_PPO_PREDRAW=0: draw inside learn()
+        self._predraw = np_rng.Predraw() if os.environ.get("JH_PPO_PREDRAW", "1") == "1" else None
         if self.backend == "native":
             self._init_native(int(state_size), int(action_size), int(hidden_size), seed)
 
@@ -125,7 +130,7 @@ class PPO(BaseAgent):
         d = self.optimizer.defaults
         net.set_hyper(self.optimizer.param_groups[0]["lr"], d["betas"][0], d["betas"][1], d["eps"], step=float(self._adam_steps))
         torch.cuda.synchronize()
-        self._net, self._graph, self._static = net, None, None
+        self._net, self._graph, self._static, self._graphs = net, None, None, {}
 
     # ---------------------------------------------------------------------------------- act
     @torch.no_grad()
@@ -250,8 +255,37 @@ class PPO(BaseAgent):
             srcs = [st["tr"]["state"], st["tr"]["action"], st["adv"], st["ret"], st["value"], st["logp_old"]]
             st["mb"] = [f(E * M, int(t.numel() // M)) for t in srcs]
             st["rows"] = ops.MinibatchRows(srcs, st["mb"])
+        # the epochs' index lists are drawn straight into pinned memory (two buffers: the next learn()'s lists are drawn and
+        # uploaded while this one's may still be in flight)
+        st["idx_pin"] = [torch.empty(self.n_epoch * M, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        st["idx_ev"] = [None, None]
+        st["idx_k"] = 0
+        st["idx_ready"] = False  # st["idx"] already holds the (pre-drawn, uploaded) lists of the coming learn()
         self._stats = st["stats"]
         return st
+
+    def _capture_targets(self, M):
+        """Device tensors the collector's acting-time capture writes for a rollout of M rows (raw policy head(s), V(s), V(s'))."""
+        self._grow_native(2 * M if 2 * M <= 8192 else M)
+        if self._static is None or self._static["M"] != M:
+            self._static, self._graphs = self._alloc_static(M), {}
+        st = self._static
+        return st["h0"], st["h1"], st["value"], st["next_value"]
+
+    def _upload_idx(self, st, draw):
+        """draw(numpy int64 view [E * M]) fills the lists; they go to st["idx"] with one async H2D."""
+        k = st["idx_k"]
+        st["idx_k"] = 1 - k
+        if st["idx_ev"][k] is not None:
+            st["idx_ev"][k].synchronize()
+        ok = draw(st["idx_pin"][k].numpy())
+        if ok is False:
+            return False
+        st["idx"].copy_(st["idx_pin"][k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["idx_ev"][k] = ev
+        return True
 
     def _enqueue_learn(self, st):
         """Everything between `memory.sample()` and the result read-back, as stream work only (no host
@@ -259,7 +293,7 @@ class PPO(BaseAgent):
         self._enqueue_pre(st)
         self._enqueue_main(st)
 
-    def _enqueue_pre(self, st):
+    def _enqueue_pre(self, st, captured=False):
         """ppo.py:83-112: everything that does NOT depend on the epoch shuffles (replay rows, the no-grad passes,
         log pi_old, GAE, mean return).  Launched first so that the host's `np.random.shuffle` calls (ppo.py:118, ~12 us
         each at 1024 rows) run while the GPU is busy with this."""
@@ -267,7 +301,9 @@ class PPO(BaseAgent):
         cont = net.cont
         tr = st["tr"]
         self.memory._store.gather(st["arange"], as_float=True, out={k: tr[k] for k in tr})
-        if 2 * M <= min(net.max_rows, 8192):
+        if captured:
+            pass  # st["h0"] / ["h1"] / ["value"] / ["next_value"] were delivered with the rollout (acting-time capture): no forward pass
+        elif 2 * M <= min(net.max_rows, 8192):
             net.forward(st["x_all"], out=(st["h0_all"], st["h1_all"], st["v_all"]))
         else:
             net.forward(tr["next_state"], out=(st["nh0"], st["nh1"], st["next_value"]))
@@ -321,58 +357,88 @@ class PPO(BaseAgent):
         M = self.memory.size
         self._grow_native(2 * M if 2 * M <= 8192 else M)
         if self._static is None or self._static["M"] != M:
-            self._static, self._graph = self._alloc_static(M), None
+            self._static, self._graphs = self._alloc_static(M), {}
         st = self._static
+        E = self.n_epoch
+        captured = self._captured == M
+        self._captured = 0
 
         def shuffles():
-            # the reference's global-RNG shuffles (ppo.py:118), all epochs uploaded at once
-            idxs = np.arange(M)
-            perm = np.empty(self.n_epoch * M, np.int64)
-            for e in range(self.n_epoch):
-                np.random.shuffle(idxs)
-                perm[e * M : (e + 1) * M] = idxs
-            st["idx"].copy_(h2d_small(perm, self.device))
+            # the reference's global-RNG shuffles (ppo.py:118) of all epochs, drawn by numpy's own algorithm on numpy's own state
+            # (np_rng.epoch_shuffles) straight into pinned memory, uploaded at once
+            self._upload_idx(st, lambda out: np_rng.epoch_shuffles(M, E, out))
 
         pin = st.get("stats_pin")
         if pin is not None:  # arrival marker in the LAST element the last update's loss kernel writes (c2 = a mean of squares: never -1)
             pin.np[st["n_upd"] - 1, 7] = -1.0
         graphable = (self.use_graph and not ops._PROF["on"] and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
                      and (self.grad_sync is None or (self.graph_with_collective and getattr(self.grad_sync, "capturable", True))))
-        split = os.environ.get("JH_PPO_SPLIT_GRAPH", "1") == "1"  # pre-phase and minibatch phase as two graphs, the shuffles between their launches
-        if graphable and self._graph is None and getattr(self, "_warm", False):
+        # index lists: pre-drawn behind the previous learn() and already uploaded (np_rng.Predraw) when np.random has not been
+        # touched since -- then ONE graph holds the whole learn(); otherwise drawn now, between the pre-phase and the minibatch
+        # graph (the GPU works on the no-grad passes / GAE while the host shuffles)
+        have_idx = bool(st["idx_ready"]) and self._predraw is not None and self._predraw.commit(M, E)
+        st["idx_ready"] = False
+        split = not have_idx and os.environ.get("JH_PPO_SPLIT_GRAPH", "1") == "1"
+        key = ("split" if split else "one", captured)
+        graphs = getattr(self, "_graphs", None)
+        if graphs is None:
+            graphs = self._graphs = {}
+        warm = getattr(self, "_warm_keys", None)
+        if warm is None:
+            warm = self._warm_keys = set()
+        if graphable and key not in graphs and key in warm:
             try:
                 torch.cuda.synchronize()
                 if split:
                     gp = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gp, capture_error_mode="thread_local"):
-                        self._enqueue_pre(st)
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (batched actors, staging ring) keep issuing HIP work on their own streams
-                        self._enqueue_main(st)
-                    self._graph_pre, self._graph = gp, g
+                        self._enqueue_pre(st, captured)
+                    if "main" not in graphs:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (batched actors, staging ring) keep issuing HIP work on their own streams
+                            self._enqueue_main(st)
+                        graphs["main"] = g
+                    graphs[key] = gp
                 else:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._enqueue_learn(st)
-                    self._graph_pre, self._graph = None, g  # capture does not execute: replay below runs this iteration's update
+                        self._enqueue_pre(st, captured)
+                        self._enqueue_main(st)
+                    graphs[key] = g  # capture does not execute: replay below runs this iteration's update
             except Exception as e:  # e.g. a collective that cannot be captured: stay eager from now on
-                self._graph, self._graph_pre, self._graph_failed, graphable = None, None, True, False
+                graphs.clear()
+                self._graph_failed, graphable = True, False
                 torch.cuda.synchronize()
                 print(f"[jorldy_amd] hipGraph capture of learn() failed ({type(e).__name__}: {e}); running eagerly")
-        if graphable and self._graph is not None:
-            if getattr(self, "_graph_pre", None) is not None:
-                self._graph_pre.replay()  # the GPU works on the no-grad passes / GAE ...
-                shuffles()                # ... while the host shuffles
+        if graphable and key in graphs:
+            if split:
+                graphs[key].replay()  # the GPU works on the no-grad passes / GAE ...
+                shuffles()            # ... while the host shuffles
+                graphs["main"].replay()
             else:
-                shuffles()
-            self._graph.replay()
+                if not have_idx:
+                    shuffles()
+                graphs[key].replay()
+            self._graph = graphs.get("main", graphs[key])
         else:
-            self._enqueue_pre(st)
-            shuffles()
+            self._enqueue_pre(st, captured)
+            if not have_idx:
+                shuffles()
             self._enqueue_main(st)
+            warm.add(key)
             self._warm = True
         self.memory._store.clear()
         self._adam_steps += st["n_upd"]
+        # ---- behind the launches, while the GPU works: next learning rate, next index lists, the next rollout's acting kernel
+        if self._lr_step is not None:
+            if self.lr_decay:
+                self.learning_rate_decay(self._lr_step)
+            self._lr_step = None
+        if self._predraw is not None:
+            st["idx_ready"] = bool(self._upload_idx(st, lambda out: self._predraw.draw(M, E, out)))
+        hook, self._post_launch_hook = self._post_launch_hook, None
+        if hook is not None:
+            hook()
         if pin is not None:
             s = self._await_mapped_stats(pin.np, st["n_upd"])
         else:
@@ -402,9 +468,13 @@ class PPO(BaseAgent):
         self.time_t = step
         self.learn_stamp += delta_t
         if self.learn_stamp >= self.n_step:
-            result = self.learn()
-            if self.lr_decay:
-                self.learning_rate_decay(step)
+            if self._net is not None:
+                self._lr_step = step  # the native learn() applies the decay itself, right behind its launches (ppo.py:199-200)
+                result = self.learn()
+            else:
+                result = self.learn()
+                if self.lr_decay:
+                    self.learning_rate_decay(step)
             self.learn_stamp = 0
         return result
 

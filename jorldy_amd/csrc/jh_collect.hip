@@ -24,6 +24,7 @@ unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs);
 int jh_persist_collect(jh_persist* p, int W, unsigned tag, float* h_heads);
 int jh_persist_heads(const jh_persist* p);
 void jh_persist_abort(jh_persist* p);
+bool jh_persist_gave_up(const jh_persist* p);
 void jh_persist_dump_debug(jh_persist* p, int T);
 
 struct jh_collector {
@@ -40,6 +41,10 @@ struct jh_collector {
   std::vector<uint8_t> done;
   jh_persist* persist = nullptr;  // null: one launch per timestep
   int mode = 1;                   // 1: persistent acting kernel (default), 0: launch per step (JH_COLLECT_PERSISTENT=0)
+  // acting-time capture (jh_collector_set_capture): device destinations of the raw heads / values of the states acted on
+  float *cap_h0 = nullptr, *cap_h1 = nullptr, *cap_v = nullptr, *cap_nv = nullptr;
+  int64_t cap_rows = 0;
+  int prelaunched_T = 0;          // steps of a persistent kernel already enqueued by jh_collector_prelaunch (0: none)
   double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
   int64_t steps = 0;
 };
@@ -100,14 +105,78 @@ JH_EXPORT void jh_collector_destroy(jh_collector* c) {
   delete c;
 }
 
+// Acting-time capture.  PPO.learn starts with two no-grad passes of the SAME network over the rollout it was just handed
+// (core/agent/ppo.py:83-94: pi, value = network(state); next_value = network(next_state)[-1]); in sync mode the weights the
+// actors acted with are the learner's, so those numbers already existed when the actions were sampled.  With capture set the
+// collector keeps, per transition row (worker-major, like the store): the raw policy head(s) of state_t, V(state_t), and
+// V(next_state_t) = V(state_{t+1}) (the value acted on one step later; the rollout's last step gets one extra value-only
+// query).  Where done_t is set, next_state_t is the terminal observation and state_{t+1} the reset one: GAE multiplies that
+// entry by (1 - done_t) = 0 (ppo.py:96), so it never enters a result.  At the end of jh_collector_run the captured block is
+// copied to d_h0 [rows][A], d_h1 [rows][A] (continuous policies: log_std_raw; NULL otherwise), d_value [rows], d_next_value [rows]
+// in the SAME launch that commits the rollout rows.  rows must equal W * T of the runs that follow; d_value == NULL switches
+// capture off.  Values differ from the learner's own pass only by fp32 summation order (~1e-7).
+JH_EXPORT int jh_collector_set_capture(jh_collector* c, float* d_h0, float* d_h1, float* d_value, float* d_next_value, int64_t rows) {
+  JH_ARG(c != nullptr);
+  if (!d_value) { c->cap_h0 = c->cap_h1 = c->cap_v = c->cap_nv = nullptr; c->cap_rows = 0; return JH_OK; }
+  JH_ARG(d_h0 && d_next_value && rows > 0 && (!c->cont || d_h1));
+  c->cap_h0 = d_h0; c->cap_h1 = c->cont ? d_h1 : nullptr; c->cap_v = d_value; c->cap_nv = d_next_value; c->cap_rows = rows;
+  return JH_OK;
+}
+
+static int collector_steps(const jh_collector* c, int T) { return T + ((c->cap_v && c->cap_rows == (int64_t)c->W * T) ? 1 : 0); }
+
+// Enqueue the persistent acting kernel of the NEXT jh_collector_run(T) now (e.g. right behind the learner's last launch): it starts
+// when the stream reaches it, loads the then-current weights and waits for the first observations (bounded: ~0.2 s, after which it
+// exits and the run falls back to a fresh launch).  Takes the kernel's launch + start-up latency out of the host's critical path
+// between learn() and the next rollout.  Nothing else may be enqueued on `stream` until that run (it would wait for the rollout).
+JH_EXPORT int jh_collector_prelaunch(jh_collector* c, int32_t T, jh_stream stream) {
+  JH_ARG(c != nullptr && T > 0);
+  if (!c->persist || c->prelaunched_T) return JH_OK;
+  const int steps = collector_steps(c, T);
+  int rc = jh_persist_begin(c->persist, c->W, steps, jh_s(stream));
+  if (rc == JH_OK) c->prelaunched_T = steps;
+  return rc;
+}
+
 // Collect T steps from every env and append the W*T transitions (worker-major) to the store.
 JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream) {
   JH_ARG(c != nullptr && T > 0);
   const int W = c->W, S = c->S, A = c->A;
   const int64_t n = (int64_t)W * T;
+  const bool cap = c->cap_v && c->cap_rows == n;
+  const int steps = collector_steps(c, T);
   void* cols[16];
   int rc = jh_store_stage_begin(c->store, n, cols);
   if (rc) return rc;
+  // captured block in pinned, device-mapped memory: [h0 n*A | h1 n*A (continuous) | value n | next_value n]
+  jh_pinned_slab* cap_slab = nullptr;
+  float *ch0 = nullptr, *ch1 = nullptr, *cv = nullptr, *cnv = nullptr;
+  if (cap) {
+    const size_t fl = (size_t)n * A * (c->cont ? 2 : 1) + 2 * (size_t)n;
+    rc = jh_ctx_slab(c->ctx, sizeof(float) * fl, &cap_slab);
+    if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
+    ch0 = (float*)cap_slab->host;
+    ch1 = c->cont ? ch0 + (size_t)n * A : nullptr;
+    cv = ch0 + (size_t)n * A * (c->cont ? 2 : 1);
+    cnv = cv + n;
+  }
+  auto finish = [&](int rc_in) {  // commit what was staged (keeps the store consistent) and hand the capture slab back
+    int rc2;
+    if (cap && rc_in == JH_OK) {
+      const void* xs[4]; void* xd[4]; int64_t xb[4]; int k = 0;
+      const char* dev0 = (const char*)cap_slab->dev;
+      auto job = [&](const float* h, float* d, size_t floats) { xs[k] = dev0 + ((const char*)h - (const char*)cap_slab->host); xd[k] = d; xb[k] = (int64_t)(sizeof(float) * floats); ++k; };
+      job(ch0, c->cap_h0, (size_t)n * A);
+      if (c->cont) job(ch1, c->cap_h1, (size_t)n * A);
+      job(cv, c->cap_v, (size_t)n);
+      job(cnv, c->cap_nv, (size_t)n);
+      rc2 = jh_store_stage_commit_extra(c->store, k, xs, xd, xb, jh_s(stream));
+    } else {
+      rc2 = jh_store_stage_commit(c->store, stream);
+    }
+    if (cap_slab) (void)jh_ctx_slab_release(c->ctx, cap_slab, jh_s(stream));
+    return rc_in ? rc_in : rc2;
+  };
   float* st = (float*)cols[c->col_state];
   int64_t* ac_i = (int64_t*)cols[c->col_action];
   float* ac_f = (float*)cols[c->col_action];
@@ -116,10 +185,22 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
   uint8_t* dn = (uint8_t*)cols[c->col_done];
   bool persistent = c->persist != nullptr;
   if (persistent) {
-    rc = jh_persist_begin(c->persist, W, T, jh_s(stream));
-    if (rc) persistent = false;
+    const int pre = c->prelaunched_T;
+    c->prelaunched_T = 0;
+    if (pre != steps || jh_persist_gave_up(c->persist)) {  // nothing prelaunched, another length, or it timed out waiting: launch now
+      if (pre && !jh_persist_gave_up(c->persist)) {        // a live kernel of another length: stop it first
+        jh_persist_abort(c->persist);
+        JH_HIP(hipStreamSynchronize(jh_s(stream)));
+      }
+      rc = jh_persist_begin(c->persist, W, steps, jh_s(stream));
+      if (rc) persistent = false;
+    }
   }
-  for (int t = 0; t < T; ++t) {
+  const int no = c->persist ? jh_persist_heads(c->persist) : 0;  // policy heads + value
+  const int n_pol = c->cont ? 2 * A : A;
+  std::vector<float> val(W), lg((size_t)W * 2 * A);
+  for (int t = 0; t < steps; ++t) {
+    const bool extra = t == T;  // capture: one value-only query of the states the rollout ended in
     // current state of every env (reset state where it just finished)
     if (c->cart) jh_cartpole_obs(c->cart, c->obs.data());
     else jh_control_obs(c->ctl, c->obs.data());
@@ -132,23 +213,50 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
         JH_HIP(hipStreamSynchronize(jh_s(stream)));
         persistent = false;
       } else {
-        const int no = jh_persist_heads(c->persist);
         for (int w = 0; w < W; ++w) {
-          if (c->cont) jh_sample_continuous(c->net, c->heads.data() + (size_t)w * no, w, training, c->act_f.data() + (size_t)w * A);
-          else c->act_i[w] = jh_sample_discrete(c->net, c->heads.data() + (size_t)w * no, w, training);
+          const float* hz = c->heads.data() + (size_t)w * no;
+          if (!extra) {
+            if (c->cont) jh_sample_continuous(c->net, hz, w, training, c->act_f.data() + (size_t)w * A);
+            else c->act_i[w] = jh_sample_discrete(c->net, hz, w, training);
+          }
+          memcpy(lg.data() + (size_t)w * n_pol, hz, sizeof(float) * n_pol);
+          val[w] = hz[no - 1];
         }
-        c->net->act_ctr += 1;
+        if (!extra) c->net->act_ctr += 1;
       }
     }
     if (!persistent) {
-      rc = c->cont ? jh_pponet_act_continuous(c->net, W, c->obs.data(), c->act_f.data(), nullptr, nullptr, training, stream)
-                   : jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act_i.data(), nullptr, nullptr, training, stream);
-      if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
+      // (the per-step launch samples even for the value-only query; its actions are not used)
+      rc = c->cont ? jh_pponet_act_continuous(c->net, W, c->obs.data(), c->act_f.data(), lg.data(), lg.data() + (size_t)W * A, val.data(), training, stream)
+                   : jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act_i.data(), lg.data(), val.data(), training, stream);
+      if (rc) return finish(rc);
+      if (c->cont) {  // [W][A] mu | [W][A] log_std  ->  per-row [mu A | log_std A] like the persistent path
+        std::vector<float> tmp(lg);
+        for (int w = 0; w < W; ++w) {
+          memcpy(lg.data() + (size_t)w * 2 * A, tmp.data() + (size_t)w * A, sizeof(float) * A);
+          memcpy(lg.data() + (size_t)w * 2 * A + A, tmp.data() + (size_t)W * A + (size_t)w * A, sizeof(float) * A);
+        }
+      }
+    }
+    if (cap) {
+      for (int w = 0; w < W; ++w) {
+        if (t > 0) cnv[(size_t)w * T + (t - 1)] = val[w];  // V(next_state_{t-1}) = V(state_t)  (masked by done_{t-1} in GAE)
+        if (!extra) {
+          const size_t row = (size_t)w * T + t;
+          cv[row] = val[w];
+          memcpy(ch0 + row * A, lg.data() + (size_t)w * n_pol, sizeof(float) * A);
+          if (c->cont) memcpy(ch1 + row * A, lg.data() + (size_t)w * n_pol + A, sizeof(float) * A);
+        }
+      }
+    }
+    if (extra) {
+      c->t_act += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      break;
     }
     const auto t1 = std::chrono::steady_clock::now();
     rc = c->cart ? jh_cartpole_step(c->cart, c->act_i.data(), c->next_obs.data(), c->reward.data(), c->done.data())
                  : jh_control_step(c->ctl, c->act_f.data(), c->next_obs.data(), c->reward.data(), c->done.data());
-    if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
+    if (rc) return finish(rc);
     for (int w = 0; w < W; ++w) {
       const size_t row = (size_t)w * T + t;  // worker-major: w0 t0..tT-1, w1 ...  (distributed_manager.py:30)
       memcpy(st + S * row, c->obs.data() + (size_t)S * w, sizeof(float) * S);
@@ -164,7 +272,7 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
     c->steps += 1;
   }
   if (persistent && getenv("JH_PERSIST_DEBUG") && (c->steps % (64 * T)) == 0) jh_persist_dump_debug(c->persist, T);
-  return jh_store_stage_commit(c->store, stream);
+  return finish(JH_OK);
 }
 
 // Diagnostics: host seconds per timestep spent (a) launching + waiting for the actions, (b) stepping

@@ -172,6 +172,46 @@ JH_EXPORT int jh_host_wait_marks(const float* base, const int32_t* idx, int32_t 
   return jh_host_wait_words(reinterpret_cast<const uint32_t*>(base), idx, n, bits, timeout_s);
 }
 
+// The epoch shuffles of PPO.learn (core/agent/ppo.py:116-118: `idxs = np.arange(M)`, then `np.random.shuffle(idxs)` once per epoch,
+// cumulatively in place) drawn from numpy's OWN global MT19937 state, in place, with numpy's own algorithm -- so that every draw the
+// reference would make is made, in the same order, from the same generator (the minibatch index lists stay bit-identical and whatever
+// consumes np.random afterwards sees the same stream).  numpy: RandomState.shuffle -> _shuffle_raw: for i = n-1 .. 1:
+// j = random_interval(i); swap(x[i], x[j]); random_interval(max) = masked rejection sampling on next_uint32 (next_uint64 above 2^32-1).
+// `next_uint32` / `next_uint64` / `bitgen_state` are the function pointers and the state address numpy publishes through
+// BitGenerator.ctypes.  12 us per np.random.shuffle call of 1024 indices in Python -> ~3 us here; three epochs sat between the
+// two graph launches of learn() with the GPU idle.
+JH_EXPORT int jh_np_legacy_shuffles(void* bitgen_state, void* next_uint32_fn, void* next_uint64_fn, int64_t n, int32_t epochs,
+                                    int64_t* h_perm_out) {
+  if (!bitgen_state || !next_uint32_fn || !next_uint64_fn || !h_perm_out || n <= 0 || epochs <= 0)
+    return jh_fail(JH_ERR_ARG, "jh_np_legacy_shuffles: bad argument");
+  typedef uint32_t (*u32_fn)(void*);
+  typedef uint64_t (*u64_fn)(void*);
+  const u32_fn next32 = reinterpret_cast<u32_fn>(next_uint32_fn);
+  const u64_fn next64 = reinterpret_cast<u64_fn>(next_uint64_fn);
+  int64_t* x = h_perm_out;  // epoch e is shuffled in place in its own row, seeded with the previous epoch's result
+  for (int64_t i = 0; i < n; ++i) x[i] = i;
+  for (int e = 0; e < epochs; ++e) {
+    if (e > 0) {
+      memcpy(h_perm_out + (size_t)e * n, h_perm_out + (size_t)(e - 1) * n, sizeof(int64_t) * (size_t)n);
+      x = h_perm_out + (size_t)e * n;
+    }
+    for (int64_t i = n - 1; i >= 1; --i) {
+      const uint64_t max = (uint64_t)i;
+      uint64_t mask = max, value;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+      if (max <= 0xffffffffULL) {
+        while ((value = ((uint64_t)next32(bitgen_state) & mask)) > max) {}
+      } else {
+        while ((value = (next64(bitgen_state) & mask)) > max) {}
+      }
+      const int64_t t = x[i];
+      x[i] = x[value];
+      x[value] = t;
+    }
+  }
+  return JH_OK;
+}
+
 // Pinned, device-mapped host memory for callers that exchange small per-step data with kernels
 // (observations in, actions out) without a memcpy node.
 JH_EXPORT int jh_pinned_alloc(jh_ctx* ctx, int64_t bytes, void** host_out, void** dev_out) {

@@ -915,7 +915,7 @@ JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs
 // PPO.act for a continuous policy (ppo.py:55-63): h_action [W][A] = tanh(Normal(mu, std).sample()) (tanh(mu) when
 // !training); h_mu_raw_out / h_log_std_raw_out [W][A] optional raw heads.
 JH_EXPORT int jh_pponet_act_continuous(jh_pponet* n, int32_t W, const float* h_obs, float* h_action, float* h_mu_raw_out,
-                                       float* h_log_std_raw_out, int32_t training, jh_stream stream) {
+                                       float* h_log_std_raw_out, float* h_value_out, int32_t training, jh_stream stream) {
   JH_ARG(n && h_obs && h_action);
   JH_ARG(n->cont);
   JH_ARG(W > 0 && W <= n->max_act_rows);
@@ -927,6 +927,7 @@ JH_EXPORT int jh_pponet_act_continuous(jh_pponet* n, int32_t W, const float* h_o
     jh_sample_continuous(n, z.data() + 8 * (size_t)wq, wq, training, h_action + (size_t)wq * A);
     if (h_mu_raw_out) memcpy(h_mu_raw_out + (size_t)wq * A, z.data() + 8 * (size_t)wq, sizeof(float) * A);
     if (h_log_std_raw_out) memcpy(h_log_std_raw_out + (size_t)wq * A, z.data() + 8 * (size_t)wq + A, sizeof(float) * A);
+    if (h_value_out) h_value_out[wq] = z[8 * (size_t)wq + 2 * A];
   }
   n->act_ctr += 1;
   return JH_OK;

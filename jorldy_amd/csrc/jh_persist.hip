@@ -23,8 +23,8 @@
 //     {out, out, out, tag} row granules written through to pinned host memory, fire and forget; no
 //     inter-workgroup communication on the device; every poll loop is bounded and a timeout makes
 //     all workgroups exit (the host then falls back to one launch per step).
-// Heads: G = ceil(n_out / 3) granules per (tile, row): discrete A <= 9 logits, or mu / log_std of a
-// continuous policy with A <= 4 (the value head is not needed to act: ppo.py:55-69).
+// Heads: G = ceil(n_out / 3) granules per (tile, row), n_out = A logits (or mu / log_std of a continuous policy) + the value
+// head (last output; handed to the learner by the collector's capture): discrete A <= 11, continuous A <= 5.
 #include "jh_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -280,8 +280,11 @@ struct jh_persist {
   unsigned long long* mbox = nullptr;  // device: relay of the observation granules
 };
 
-// heads needed to ACT: A logits (discrete) | A mu + A log_std (continuous); the value head is not (ppo.py:55-69)
-static int persist_heads(const jh_pponet* n) { return n->cont ? 2 * n->A : n->A; }
+// heads needed to ACT: A logits (discrete) | A mu + A log_std (continuous) (ppo.py:55-69) -- plus the value head as the LAST
+// output: V(s_t) of the states acted on is exactly what PPO.learn recomputes with the same weights in its no-grad pass
+// (ppo.py:83-94; in sync mode the actors' weights ARE the learner's), so the collector can hand it over instead
+// (jh_collector_set_capture).  Discrete A = 2: the third float of the one 16-byte granule per (tile, row) was unused.
+static int persist_heads(const jh_pponet* n) { return (n->cont ? 2 * n->A : n->A) + 1; }
 
 int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_ARG(n && out);
@@ -344,6 +347,7 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   for (int k = 0; k < n->A; ++k, ++o) { a.wh[o] = n->params + n->o_wh0 + (int64_t)k * n->H; a.hbias[o] = n->params + n->o_bh0 + k; }
   if (n->cont)
     for (int k = 0; k < n->A; ++k, ++o) { a.wh[o] = n->params + n->o_wh1 + (int64_t)k * n->H; a.hbias[o] = n->params + n->o_bh1 + k; }
+  a.wh[o] = n->params + n->o_wv; a.hbias[o] = n->params + n->o_bv; ++o;  // value head last
   a.n_out = o;
   a.obs_gran = p->gran_d; a.part = p->part_d; a.abort_flag = p->flag_d;
   a.seq0 = p->seq;
@@ -435,6 +439,9 @@ void jh_persist_dump_debug(jh_persist* p, int T) {
   fprintf(stderr, "[jh_persist] per step (wall_clock64 ticks = 10 ns): wait %.1f  compute %.1f ; shader clock ~%.0f MHz\n",
           a / n, c / n, cyc / n * 100.0);
 }
+
+// Has the kernel of the last jh_persist_begin timed out waiting for observations (it sets the word to 2 and exits)?
+bool jh_persist_gave_up(const jh_persist* p) { return __atomic_load_n(p->flag_h, __ATOMIC_ACQUIRE) == 2u; }
 
 // Stop a running kernel early (error paths): it sees the word at its next abort check and exits.
 void jh_persist_abort(jh_persist* p) { __atomic_store_n(p->flag_h, 1u, __ATOMIC_RELEASE); }

@@ -51,11 +51,12 @@ JH_EXPORT void jh_store_destroy(jh_store* s) {
 // ONE launch for a ring append of all columns (<= 8) from sources a kernel can read: device memory, or device-mapped
 // pinned memory for small appends.  A rollout commit used to be one hipMemcpyAsync per column (5-10 SDMA copies of a few
 // KB each, ~3 us apiece on the host and again on the copy engine, back to back in front of learn()).
+constexpr int kCopyJobs = 12;  // store columns (<= 8) + extra plain copies riding in the same launch (the collector's captured heads / values)
 struct CopyCols {
-  const char* src[8];
-  char* dst[8];       // ring position of the first row
-  char* dst_wrap[8];  // column base (rows behind the ring's wrap)
-  int64_t first[8], total[8];  // bytes before the wrap / in all
+  const char* src[kCopyJobs];
+  char* dst[kCopyJobs];       // ring position of the first row
+  char* dst_wrap[kCopyJobs];  // column base (rows behind the ring's wrap)
+  int64_t first[kCopyJobs], total[kCopyJobs];  // bytes before the wrap / in all
 };
 __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
   const int c = blockIdx.y;
@@ -74,11 +75,19 @@ __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
     *(o < first ? d0 + o : d1 + (o - first)) = src[o];
 }
 
-// `cols`: device-visible sources.  Advances the ring like jh_store_append.
-static int store_append_kernel(jh_store* s, int64_t n, const void* const* cols, hipStream_t st) {
+// `cols`: device-visible sources.  Advances the ring like jh_store_append.  n_extra plain copies (x_src -> x_dst, x_bytes) ride along.
+static int store_append_kernel(jh_store* s, int64_t n, const void* const* cols, hipStream_t st, int n_extra = 0, const void* const* x_src = nullptr,
+                               void* const* x_dst = nullptr, const int64_t* x_bytes = nullptr) {
   const int64_t first = s->capacity - s->index < n ? s->capacity - s->index : n;
   CopyCols a{};
   size_t most = 0;
+  for (int e = 0; e < n_extra; ++e) {
+    const int c = s->n_cols + e;
+    a.src[c] = (const char*)x_src[e];
+    a.dst[c] = a.dst_wrap[c] = (char*)x_dst[e];
+    a.first[c] = a.total[c] = x_bytes[e];
+    if ((size_t)x_bytes[e] > most) most = (size_t)x_bytes[e];
+  }
   for (int c = 0; c < s->n_cols; ++c) {
     const size_t rb = s->row_bytes[c];
     a.src[c] = (const char*)cols[c];
@@ -91,7 +100,7 @@ static int store_append_kernel(jh_store* s, int64_t n, const void* const* cols, 
   unsigned gx = (unsigned)((most + 16383) / 16384);  // 64 bytes per thread and pass
   if (gx < 1) gx = 1;
   if (gx > 2048) gx = 2048;
-  JH_LAUNCH(jh_store_copy_cols_kernel, dim3(gx, (unsigned)s->n_cols), dim3(256), 0, st, a);
+  JH_LAUNCH(jh_store_copy_cols_kernel, dim3(gx, (unsigned)(s->n_cols + n_extra)), dim3(256), 0, st, a);
   JH_LAUNCH_CHECK();
   s->index = (s->index + n) % s->capacity;
   s->counter = s->counter + n < s->capacity ? s->counter + n : s->capacity;
@@ -116,10 +125,13 @@ JH_EXPORT int jh_store_stage_begin(jh_store* s, int64_t n, void** h_cols_out) {
   return JH_OK;
 }
 
-JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) {
-  JH_ARG(s != nullptr);
+JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) { return jh_store_stage_commit_extra(s, 0, nullptr, nullptr, nullptr, jh_s(stream)); }
+
+// The commit with n_extra (<= 4) plain device-visible -> device copies in the SAME launch (internal: the collector's captured
+// heads / values land next to the rollout rows without further launches or SDMA copies).
+int jh_store_stage_commit_extra(jh_store* s, int n_extra, const void* const* x_src, void* const* x_dst, const int64_t* x_bytes, hipStream_t st) {
+  JH_ARG(s != nullptr && n_extra >= 0 && n_extra <= 4);
   if (!s->staged) return jh_fail(JH_ERR_STATE, "jh_store_stage_commit without begin");
-  hipStream_t st = jh_s(stream);
   const int64_t n = s->staged_n;
   size_t bytes = 0;
   for (int c = 0; c < s->n_cols; ++c) bytes += s->row_bytes[c] * (size_t)n;
@@ -128,7 +140,7 @@ JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) {
     // small commits (a PPO rollout: 46 KB; Rainbow's 4 deferred rows: 226 KB): one kernel reads the slab in place
     const void* src[8];
     for (int c = 0; c < s->n_cols; ++c) src[c] = (const char*)s->staged->dev + s->staged_off[c];
-    int rc = store_append_kernel(s, n, src, st);
+    int rc = store_append_kernel(s, n, src, st, n_extra, x_src, x_dst, x_bytes);
     int rc2 = jh_ctx_slab_release(s->ctx, s->staged, st);
     s->staged = nullptr;
     return rc ? rc : rc2;
@@ -141,6 +153,7 @@ JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) {
     if (first < n)
       JH_HIP(hipMemcpyAsync(s->dev[c], src + rb * (size_t)first, rb * (size_t)(n - first), hipMemcpyHostToDevice, st));
   }
+  for (int e = 0; e < n_extra; ++e) JH_HIP(hipMemcpyAsync(x_dst[e], x_src[e], (size_t)x_bytes[e], hipMemcpyDefault, st));
   int rc = jh_ctx_slab_release(s->ctx, s->staged, st);
   s->staged = nullptr;
   if (rc) return rc;

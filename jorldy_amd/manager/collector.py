@@ -79,6 +79,12 @@ class NativeCollector:
         self.h = None
         self._store_h = None
         self._net_h = None
+        import os
+
+        # acting-time capture (jh_collector_set_capture): the raw heads and values the acting kernel computed anyway replace the two
+        # no-grad passes at the start of PPO.learn (ppo.py:83-94); JH_COLLECT_CAPTURE=0 switches it off
+        self.capture = os.environ.get("JH_COLLECT_CAPTURE", "1") == "1"
+        self._cap_key = None
 
     def _bind(self, n_rows):
         mem, W = self.agent.memory, self.env.W
@@ -88,8 +94,12 @@ class NativeCollector:
                    "next_state": np.zeros((n_rows, S), np.float32), "done": np.zeros((n_rows, 1), np.uint8)}
         mem._ensure(example, n_rows)
         self.agent._grow_native(W)
+        cap = self.agent._capture_targets(n_rows) if self.capture else None  # may grow the network: before its handle is read
         store, net = mem._store, self.agent._net
+        cap_key = tuple(t.data_ptr() for t in cap if t is not None) if cap else None
         if self.h is not None and self._store_h == store.h.value and self._net_h == net.h.value:
+            if cap_key != self._cap_key:
+                self._set_capture(cap, n_rows)
             return
         if self.h is not None:
             self.lib.jh_collector_destroy(self.h)
@@ -98,11 +108,34 @@ class NativeCollector:
         create = self.lib.jh_collector_create_control if cont else self.lib.jh_collector_create
         L.check(create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
         self.h, self._store_h, self._net_h = h, store.h.value, net.h.value
+        self._set_capture(cap, n_rows)
+
+    def _set_capture(self, cap, n_rows):
+        if cap is None:
+            L.check(self.lib.jh_collector_set_capture(self.h, None, None, None, None, 0))
+            self._cap_key = None
+            return
+        h0, h1, v, nv = cap
+        L.check(self.lib.jh_collector_set_capture(self.h, L.ptr(h0), L.ptr(h1), L.ptr(v), L.ptr(nv), int(n_rows)))
+        self._cap_key = tuple(t.data_ptr() for t in cap if t is not None)
 
     def run(self, step=1):
-        self._bind(self.env.W * step)
+        n_rows = self.env.W * step
+        self._bind(n_rows)
         L.check(self.lib.jh_collector_run(self.h, int(step), 1, L.stream_ptr()))
+        if self._cap_key is not None:
+            self.agent._captured = n_rows  # the coming learn() takes the heads / values of these rows as delivered (no no-grad passes)
         return None, 1.0
+
+    def arm_prelaunch(self, step):
+        """Have the coming `agent.process` enqueue the persistent acting kernel of the NEXT run(step) right behind learn()'s launches
+        (jh_collector_prelaunch): the kernel's launch and start-up leave the host's critical path between learn() and the rollout.
+        The kernel waits ~0.2 s for its first observations; nothing else may be enqueued on the stream before that run (a
+        torch.cuda.synchronize() in between waits for the timeout, after which run() simply launches afresh)."""
+        if self.h is None:
+            return
+        stream = L.stream_ptr()
+        self.agent._post_launch_hook = lambda: L.check(self.lib.jh_collector_prelaunch(self.h, int(step), stream))
 
     def stats(self, reset=True):
         a, e = C.c_double(), C.c_double()

@@ -629,7 +629,7 @@ def _pponet_act_continuous(self, obs, training=True, want_heads=False):
     act = np.empty((W, self.A), np.float32)
     mu = np.empty((W, self.A), np.float32) if want_heads else None
     ls = np.empty((W, self.A), np.float32) if want_heads else None
-    L.check(self.lib.jh_pponet_act_continuous(self.h, W, L.ptr(obs), L.ptr(act), L.ptr(mu), L.ptr(ls), int(bool(training)), L.stream_ptr()))
+    L.check(self.lib.jh_pponet_act_continuous(self.h, W, L.ptr(obs), L.ptr(act), L.ptr(mu), L.ptr(ls), None, int(bool(training)), L.stream_ptr()))
     return (act, mu, ls) if want_heads else act
 
 

@@ -220,6 +220,8 @@ def attach_data_parallel(agent, dist, group=None):
     agent.grad_sync = sync
     agent.graph_with_collective = bool(getattr(agent, "graph_with_collective", True)) and transport.capturable
     agent._graph = None
+    if hasattr(agent, "_graphs"):
+        agent._graphs = {}
     return sync
 
 

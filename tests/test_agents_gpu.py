@@ -546,6 +546,63 @@ def test_native_collector_matches_python_collector_layout():
     assert set(res) == {"actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob", "mean_ret"} and agent.memory.size == 0
 
 
+@pytest.mark.parametrize("cont", [False, True])
+@pytest.mark.parametrize("persistent", [True, False])
+def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persistent, monkeypatch):
+    """Acting-time capture (jh_collector_set_capture): the raw heads / V(s) / V(s') the acting kernel computed while collecting
+    replace the two no-grad passes at the start of PPO.learn (ppo.py:83-94).  Same weights, same inputs: the captured numbers
+    equal the learner's own pass up to fp32 summation order, next_value == V(next_state) wherever done = 0, and three
+    iterations of collect + learn (with the pre-drawn index lists and the pre-launched acting kernel) give the same losses
+    (1e-5) as the capture-free path."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+
+    monkeypatch.setenv("JH_COLLECT_PERSISTENT", "1" if persistent else "0")
+    W, T, H = 8, 64, 512 if persistent else 64
+    S, A = (11, 3) if cont else (4, 2)
+    res = {}
+    for capture in (True, False):
+        monkeypatch.setenv("JH_COLLECT_CAPTURE", "1" if capture else "0")
+        torch.manual_seed(5)
+        np.random.seed(5)
+        agent = Agent("ppo", state_size=S, action_size=A, hidden_size=H, network="continuous_policy_value" if cont else "discrete_policy_value",
+                      n_step=T, batch_size=128, n_epoch=2, device="cuda", backend="native", seed=3, lr_decay=True, run_step=10000)
+        agent.memory.first_store = False
+        env = (ops.ControlVec(W, S, A, seed=4) if cont else ops.CartPoleVec(W, seed=4))
+        col = NativeCollector(env, agent, W)
+        assert col.capture == capture
+        out = []
+        for it in range(4):
+            col.run(T)
+            if capture and it == 0:
+                torch.cuda.synchronize()
+                st, M = agent._static, W * T
+                cap = [npy(t).copy() if t is not None else None for t in (st["h0"], st["h1"], st["value"], st["next_value"])]
+                x = agent.memory._store.column("state")[:M].float()
+                nx = agent.memory._store.column("next_state")[:M].float()
+                dn = npy(agent.memory._store.column("done")[:M]).reshape(-1).astype(bool)
+                o = agent._net.forward(x)
+                own = [npy(o[0]).copy(), npy(o[1]).copy() if cont else None, npy(o[-1]).copy()]
+                own_nv = npy(agent._net.forward(nx)[-1]).copy()
+                np.testing.assert_allclose(cap[0], own[0], rtol=2e-5, atol=2e-6)
+                if cont:
+                    np.testing.assert_allclose(cap[1], own[1], rtol=2e-5, atol=2e-6)
+                np.testing.assert_allclose(cap[2].reshape(-1), own[2].reshape(-1), rtol=2e-5, atol=2e-6)
+                np.testing.assert_allclose(cap[3].reshape(-1)[~dn], own_nv.reshape(-1)[~dn], rtol=2e-5, atol=2e-6)
+                assert np.all(np.isfinite(cap[3]))
+            if it < 3:
+                col.arm_prelaunch(T)
+            out.append(agent.process(None, T * (it + 1)))
+            assert agent._captured == 0
+        torch.cuda.synchronize()
+        res[capture] = out
+        col.terminate()
+    for a, b in zip(res[True], res[False]):
+        for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
+            assert abs(a[k] - b[k]) <= 1e-5 * (1.0 + abs(b[k])), (k, a[k], b[k])
+
+
 @pytest.mark.parametrize("persistent", [True, False])
 @pytest.mark.parametrize("H,W", [(64, 5), (512, 8)])
 def test_native_collector_continuous_policy_on_control_env(H, W, persistent, monkeypatch):
