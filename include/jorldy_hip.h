@@ -353,6 +353,9 @@ int jh_collector_prelaunch(jh_collector* c, int32_t T, jh_stream stream);
 /* Host-side timing of the collection loop (microseconds per timestep): launching + waiting for the
  * actions, and stepping the envs + writing the transitions.                                        */
 int jh_collector_stats(jh_collector* c, double* act_us_per_step, double* env_us_per_step, int32_t reset);
+/* out6 = {first step's action wait per run (acting kernel start-up), value-only query per run, commit launch per run,
+ * steady-state action wait per timestep (both excluded), runs, timesteps}, microseconds; call before a resetting jh_collector_stats. */
+int jh_collector_stats_detail(jh_collector* c, double* out6);
 
 /* N(0,1) draws on the device for NoisyNet layers (core/network/utils.py:58-60 draws torch.randn per forward):
  * counter-based (element i of call c = Box-Muller on splitmix64(seed, c, i)); d_state uint64[4] = {seed, call counter,

@@ -131,6 +131,7 @@ _PROTOS = {
     "jh_feed_state": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     "jh_collector_stats": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), _i32]),
     "jh_collector_run": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "jh_collector_stats_detail": (C.c_int, [_vp, C.POINTER(_f64)]),
     "jh_collector_set_capture": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "jh_collector_prelaunch": (C.c_int, [_vp, _i32, _vp]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),

@@ -46,6 +46,8 @@ struct jh_collector {
   int64_t cap_rows = 0;
   int prelaunched_T = 0;          // steps of a persistent kernel already enqueued by jh_collector_prelaunch (0: none)
   double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
+  double t_first = 0, t_extra = 0, t_commit = 0;  // of t_act: the rollout's first step (kernel start-up) and the value-only query; the commit launch
+  int64_t runs = 0;
   int64_t steps = 0;
 };
 
@@ -230,6 +232,7 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
       rc = c->cont ? jh_pponet_act_continuous(c->net, W, c->obs.data(), c->act_f.data(), lg.data(), lg.data() + (size_t)W * A, val.data(), training, stream)
                    : jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act_i.data(), lg.data(), val.data(), training, stream);
       if (rc) return finish(rc);
+      if (extra) c->net->act_ctr -= 1;  // the value-only query must not consume a sampling step: same action stream with and without capture
       if (c->cont) {  // [W][A] mu | [W][A] log_std  ->  per-row [mu A | log_std A] like the persistent path
         std::vector<float> tmp(lg);
         for (int w = 0; w < W; ++w) {
@@ -250,10 +253,13 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
       }
     }
     if (extra) {
-      c->t_act += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      c->t_act += dt;
+      c->t_extra += dt;
       break;
     }
     const auto t1 = std::chrono::steady_clock::now();
+    if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
     rc = c->cart ? jh_cartpole_step(c->cart, c->act_i.data(), c->next_obs.data(), c->reward.data(), c->done.data())
                  : jh_control_step(c->ctl, c->act_f.data(), c->next_obs.data(), c->reward.data(), c->done.data());
     if (rc) return finish(rc);
@@ -272,7 +278,26 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
     c->steps += 1;
   }
   if (persistent && getenv("JH_PERSIST_DEBUG") && (c->steps % (64 * T)) == 0) jh_persist_dump_debug(c->persist, T);
-  return finish(JH_OK);
+  const auto tc = std::chrono::steady_clock::now();
+  rc = finish(JH_OK);
+  c->t_commit += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+  c->runs += 1;
+  return rc;
+}
+
+// More of the same: out[0..5] = per RUN microseconds {first step's action wait (kernel start-up), value-only query, commit launch},
+// steady-state action wait per timestep (first step and query excluded), runs, timesteps.
+JH_EXPORT int jh_collector_stats_detail(jh_collector* c, double* out6) {
+  JH_ARG(c && out6);
+  const double r = c->runs > 0 ? (double)c->runs : 1.0;
+  out6[0] = c->t_first / r * 1e6;
+  out6[1] = c->t_extra / r * 1e6;
+  out6[2] = c->t_commit / r * 1e6;
+  const double inner = (double)c->steps - (double)c->runs;
+  out6[3] = inner > 0 ? (c->t_act - c->t_first - c->t_extra) / inner * 1e6 : 0.0;
+  out6[4] = (double)c->runs;
+  out6[5] = (double)c->steps;
+  return JH_OK;
 }
 
 // Diagnostics: host seconds per timestep spent (a) launching + waiting for the actions, (b) stepping
@@ -282,6 +307,6 @@ JH_EXPORT int jh_collector_stats(jh_collector* c, double* act_us_per_step, doubl
   const double n = c->steps > 0 ? (double)c->steps : 1.0;
   if (act_us_per_step) *act_us_per_step = c->t_act / n * 1e6;
   if (env_us_per_step) *env_us_per_step = c->t_env / n * 1e6;
-  if (reset) { c->t_act = c->t_env = 0; c->steps = 0; }
+  if (reset) { c->t_act = c->t_env = c->t_first = c->t_extra = c->t_commit = 0; c->steps = 0; c->runs = 0; }
   return JH_OK;
 }

@@ -139,8 +139,11 @@ class NativeCollector:
 
     def stats(self, reset=True):
         a, e = C.c_double(), C.c_double()
+        d = (C.c_double * 6)()
+        L.check(self.lib.jh_collector_stats_detail(self.h, d))
         L.check(self.lib.jh_collector_stats(self.h, C.byref(a), C.byref(e), int(reset)))
-        return {"act_us_per_step": a.value, "env_us_per_step": e.value}
+        return {"act_us_per_step": a.value, "env_us_per_step": e.value, "first_step_us_per_run": d[0], "value_query_us_per_run": d[1],
+                "commit_us_per_run": d[2], "act_steady_us_per_step": d[3]}
 
     def sync(self, sync_item=None, init=False):
         return None

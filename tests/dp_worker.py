@@ -88,20 +88,13 @@ def main():
                         p.add_(0.01)
             sync = attach_data_parallel(agent, dist)
             assert sync.transport.kind == "host" and not agent.graph_with_collective
-            perms = []
-            real_shuffle = np.random.shuffle
-
-            def recording_shuffle(x):
-                real_shuffle(x)
-                perms.append(np.array(x, copy=True))
-
-            np.random.shuffle = recording_shuffle
+            agent._predraw = None  # keep this learn()'s index lists in st["idx"] (no lists of a next learn() drawn ahead)
             np.random.seed(200 + rank)
             result = agent.process(ppo_rows(rank), c["T"])
-            np.random.shuffle = real_shuffle
             torch.cuda.synchronize()
             n_upd = c["E"] * (c["W"] * c["T"] // c["B"])
-            res = dict(params=agent._net.params.cpu().numpy(), perms=np.stack(perms), stats=np.asarray(agent._static["stats_pin"].np[: n_upd + 1]).copy(),
+            perms = agent._static["idx"].cpu().numpy().reshape(c["E"], c["W"] * c["T"])  # the epochs' index lists this rank drew (np.random, seed 200 + rank)
+            res = dict(params=agent._net.params.cpu().numpy(), perms=perms, stats=np.asarray(agent._static["stats_pin"].np[: n_upd + 1]).copy(),
                        grads=agent._net.grads.cpu().numpy(), n_upd=n_upd, **{f"result_{k}": v for k, v in result.items()})
         else:
             c = RB_CFG

@@ -162,3 +162,42 @@ def test_control_env_matches_oracle_bit_for_bit(lib):
         assert np.array_equal(n1, n2) and np.array_equal(r1, r2) and np.array_equal(d1.astype(bool), d2), t
         n_done += int(d2.sum())
     assert n_done >= 4  # the 1000-step cap at least
+
+
+def test_epoch_shuffles_are_numpys_own_draws_bit_for_bit():
+    """jh_np_legacy_shuffles / np_rng.epoch_shuffles vs `idxs = np.arange(M); for e: np.random.shuffle(idxs)` (core/agent/ppo.py:116-118):
+    identical index lists AND an identical generator afterwards; np_rng.Predraw: lists drawn ahead on a copy of the state are
+    installed only when nobody touched np.random in between, and leave the stream exactly where the reference's calls would."""
+    from jorldy_amd import np_rng
+
+    for seed in range(6):
+        for M in (1, 2, 7, 64, 1000, 1024, 4096):
+            np.random.seed(seed)
+            idx, ref = np.arange(M), []
+            for _ in range(3):
+                np.random.shuffle(idx)
+                ref.append(idx.copy())
+            ref = np.concatenate(ref)
+            tail_ref = np.random.randint(1 << 30, size=5)
+            np.random.seed(seed)
+            out = np.empty(3 * M, np.int64)
+            np_rng.epoch_shuffles(M, 3, out)
+            assert np.array_equal(out, ref) and np.array_equal(np.random.randint(1 << 30, size=5), tail_ref), (seed, M)
+            # drawn ahead, nobody in between: same lists, same stream
+            np.random.seed(seed)
+            p, out2 = np_rng.Predraw(), np.empty(3 * M, np.int64)
+            assert p.draw(M, 3, out2)
+            assert p.commit(M, 3) and np.array_equal(out2, ref) and np.array_equal(np.random.randint(1 << 30, size=5), tail_ref)
+            assert not p.commit(M, 3)  # one-shot
+            # somebody drew from np.random in between: the lists are refused and the global stream is untouched by the attempt
+            np.random.seed(seed)
+            p.draw(M, 3, out2)
+            a = np.random.rand()
+            assert not p.commit(M, 3)
+            b = np.random.rand()
+            np.random.seed(seed)
+            assert (np.random.rand(), np.random.rand()) == (a, b)
+            # another shape than the one drawn for: refused
+            np.random.seed(seed)
+            p.draw(M, 3, out2)
+            assert not p.commit(M + 1, 3)

@@ -69,12 +69,14 @@ def test_ppo_native_two_ranks_equal_one_learner_on_the_concatenated_batch(tmp_pa
     for e in range(E):
         p0, p1 = r0["perms"][e], r1["perms"][e]
         perms.append(np.concatenate([np.concatenate([p0[o:o + B], M + p1[o:o + B]]) for o in range(0, M, B)]))
-    it = iter(perms)
+    from jorldy_amd import np_rng
 
-    def fixed_shuffle(x):
-        x[:] = next(it)
+    def fixed_lists(M_, E_, out):  # stands in for the np.random draws of ppo.py:116-118: the two ranks' lists side by side
+        out.reshape(-1)[:] = np.concatenate(perms)
+        return out
 
-    monkeypatch.setattr(np.random, "shuffle", fixed_shuffle)
+    agent._predraw = None
+    monkeypatch.setattr(np_rng, "epoch_shuffles", fixed_lists)
     agent.process(cols, c["T"])
     monkeypatch.undo()
     torch.cuda.synchronize()
