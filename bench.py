@@ -23,6 +23,9 @@ Extra objects on the JSON line:
   rainbow       learner updates/s at config.rainbow.atari shapes (N = 1e6 PER, uint8 frames resident in HBM),
                 its own roofline and the reference's learner (CPU port) timed on this box
   cpu_baseline  the reference's CPU path (port) on this box's host cores, sequential and 8-process variants
+  hopper        configs[4] (config.ppo.mujoco Hopper shapes): learner transitions/s, strong-scaled over the ranks
+  apex          configs[3] (config.ape_x.atari): 64 acting actors -> 1 learner GPU end to end (1-GPU runs only)
+  repeats       the timed region as consecutive chunks: median / min / max ms per step inside the one sample
 """
 import argparse
 import csv
@@ -63,6 +66,12 @@ def parse():
     ap.add_argument("--rainbow-updates", type=int, default=300)
     ap.add_argument("--rainbow-capacity", type=int, default=1_000_000, help="PER slots (config.rainbow.atari: buffer_size 1e6 = 56 GB of uint8 frames in HBM)")
     ap.add_argument("--rainbow-filled", type=int, default=131072, help="transitions in the buffer before the timed updates")
+    ap.add_argument("--no-apex", action="store_true", help="skip the Ape-X (configs[3]) end-to-end leg (rank 0 of a 1-GPU run only)")
+    ap.add_argument("--apex-actors", type=int, default=64)
+    ap.add_argument("--apex-updates", type=int, default=1200, help="learner iterations of the Ape-X leg (~2 s at ~600 updates/s)")
+    ap.add_argument("--no-hopper", action="store_true", help="skip the PPO Hopper-shaped (configs[4]) leg")
+    ap.add_argument("--hopper-iters", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="the timed steps are also reported as this many consecutive chunks (median / min / max)")
     return ap.parse_args()
 
 
@@ -115,6 +124,10 @@ def cpu_baseline(iters, W, T):
         "unit": "env_transitions/s",
         "cores": cores if best is seq else max(cores, W),
         "kind": "port",
+        # the reference tree only exists in the build container (never on a GPU box): what is timed here is the port, which
+        # tests/test_oracle_golden.py pins to the reference's own learn() (losses / weights 1e-6) and tools/cpu_reference_timing.py
+        # times side by side with the REAL reference where that tree exists (profiles/r03_cpu_reference_vs_port.json)
+        "reference_present": os.path.isdir("/root/reference"),
         "sample": f"{iters} sync iterations of config.ppo.cartpole (W={W}, T={T}, 3 epochs x 4 minibatches of 256) per variant; value = the faster "
                   f"variant ({'actor processes' if best is procs else 'sequential in-process workers'}): collect {best['collect_ms']:.1f} ms + learn {best['learn_ms']:.1f} ms per iteration",
         "learner_updates_per_s": best["learner_updates_per_s"],
@@ -146,7 +159,7 @@ def rainbow_cpu_reference(updates=8, warm=2):
     for _ in range(updates):
         ag.learn()
     dt = time.perf_counter() - t0
-    return {"value": updates / dt, "unit": "updates/s", "ms_per_update": dt / updates * 1e3, "cores": cores, "kind": "port",
+    return {"value": updates / dt, "unit": "updates/s", "ms_per_update": dt / updates * 1e3, "cores": cores, "kind": "port", "reference_present": os.path.isdir("/root/reference"),
             "sample": f"{updates} Rainbow.learn() calls (B=32, (4,84,84) uint8, N=1e6 sum tree, {fill} stored), torch CPU {cores} threads"}
 
 
@@ -291,6 +304,72 @@ def rainbow_leg(rank, world, local_rank, dist, updates, warmup, capacity, filled
     return out
 
 
+# ------------------------------------------------------------------------------------------------- configs[4] / configs[3] legs
+def _tool(name):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _dominant_mfma(kern, note):
+    """The launch with the most time among those with a flop count (tools report launches / avg_us / TFLOP/s) -> a roofline object."""
+    best = None
+    for k, v in kern.items():
+        if "TFLOP/s" in v:
+            t = v["avg_us"] * v.get("launches", 1)
+            if best is None or t > best[0]:
+                best = (t, k, v)
+    if best is None:
+        return None
+    _, k, v = best
+    return {"kernel": k, "bound": "mfma", "achieved": v["TFLOP/s"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": v["TFLOP/s"] / MFMA_F32_PEAK_TFLOPS,
+            "avg_us": v["avg_us"], "traffic": None, "note": note}
+
+
+def hopper_leg(rank, world, local_rank, dist, iters):
+    """BASELINE.json configs[4] (config.ppo.mujoco Hopper-v3 shapes: S=11, A=3 continuous, 32 workers x 2048 steps, distributed batch 2048,
+    10 epochs; "8 x MI355X data-parallel learners").  The config is split over the ranks (strong scaling: 32 / N workers and 2048 / N
+    minibatch rows per GPU, one all-reduce of the flat gradient per minibatch).  N = 1: the learner side on 65 536 synthetic transitions
+    (the persistent acting kernel serves <= 16 env rows per GPU; MuJoCo itself is not installable); N >= 2: end to end with the native
+    collector on the synthetic control env."""
+    W, B = max(1, 32 // world), max(1, 2048 // world)
+    e2e = W <= 16
+    r = _tool("bench_hopper").hopper_leg(iters=iters, warmup=2, workers=W, batch=B, e2e=e2e, dist=dist if world > 1 else None, device=f"cuda:{local_rank}")
+    note = "minibatch " + str(B) + " rows: " + ("LDS-tiled engine (jh_tgemm_ppo_*)" if B >= 1024 else "latency-oriented four / five launch update (jh_pmb_*)")
+    r = dict(metric="learner transitions/s (PPO, config.ppo.mujoco Hopper shapes)", value=r["learner_transitions_per_s"], unit="transitions/s", scaling="strong",
+             config={"workload": r.pop("workload"), "parallelism": f"dp{world}", "workers_per_gpu": W, "batch_per_gpu": B}, roofline=_dominant_mfma(r["lib_kernels"], note), **r)
+    return r
+
+
+def apex_leg(actors, updates):
+    """BASELINE.json configs[3] (config.ape_x.atari pong shapes, `actors` host actors -> 1 learner GPU) end to end in a child process:
+    batched acting on the GPU, device-resident frame / n-step feed (frame mode), learner at B = 512 with centered RMSprop, clip 40, PER with
+    actor-side priorities (tools/bench_apex.py --e2e).  -> env steps/s, learner updates/s and the dominant learner GEMM's roofline."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_apex.py"), "--e2e", str(actors), "--device-feed", "--frames", "--updates", str(updates), "--warmup", "30"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": (p.stderr or p.stdout)[-600:]}
+        r = json.loads(line[-1])
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    e2e = r.get("end_to_end") or {}
+    kern = {k: dict(v, launches=1) for k, v in r.get("lib_kernels", {}).items()}
+    return {"metric": "env steps/s + learner updates/s (Ape-X, config.ape_x.atari shapes, actors -> 1 learner GPU)", "value": e2e.get("env_steps_per_s"), "unit": "env_steps/s",
+            "learner_updates_per_s": r.get("learner_updates_per_s"), "sampled_transitions_per_s": r.get("sampled_transitions_per_s"), "ms_per_learn_only": r.get("ms_per_learn_only"),
+            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "timed_s": updates / max(1e-9, r.get("learner_updates_per_s") or 1e-9),
+            "config": {"workload": r.get("workload"), "actors": actors, "path": e2e.get("path"), "weight_sync_every_ticks": e2e.get("weight_sync_every_ticks")},
+            "end_to_end": e2e, "learn_in_hipgraph": r.get("learn_in_hipgraph"), "last_result": r.get("last_result"),
+            "roofline": _dominant_mfma(kern, "dominant learner GEMM launch at B = 512 (per-launch averages of tools/bench_apex.py's library event timers)"),
+            "lib_kernels": r.get("lib_kernels")}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -361,11 +440,19 @@ def main():
     fence()
     if hasattr(collector, "stats"):
         collector.stats()  # reset
+    # EXACTLY args.steps steps between the two fences decide `value`; host timestamps at the chunk boundaries (every iteration ends
+    # with the host holding that learn()'s statistics, i.e. in step with the GPU to ~20 us) give the spread inside the one sample
+    n_rep = max(1, min(args.repeats, args.steps))
+    marks = [(args.steps * (k + 1)) // n_rep for k in range(n_rep)]
+    stamps = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         result = one_iteration(last=i == args.steps - 1)
+        if i + 1 in marks[:-1]:
+            stamps.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    stamps.append(t0 + dt)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -395,6 +482,12 @@ def main():
         "learner_updates_per_s": world * n_updates * args.steps / dt,
         "last_result": {k: float(v) for k, v in result.items()},
     }
+    chunk_ms = [((b - a) / (m1 - m0)) * 1e3 for a, b, m0, m1 in zip([t0] + stamps[:-1], stamps, [0] + marks[:-1], marks) if m1 > m0]
+    if chunk_ms:
+        med = float(np.median(chunk_ms))
+        out["repeats"] = {"n": len(chunk_ms), "steps_each": [m1 - m0 for m0, m1 in zip([0] + marks[:-1], marks)], "ms_per_step": [round(v, 4) for v in chunk_ms],
+                          "median_ms_per_step": med, "min_ms_per_step": min(chunk_ms), "max_ms_per_step": max(chunk_ms), "median_value": world * W * T / (med * 1e-3),
+                          "note": "consecutive chunks of the ONE timed region (rank 0 host clock); `value` is the whole region"}
     act_us = None
     if hasattr(collector, "stats"):
         st = collector.stats()
@@ -451,6 +544,10 @@ def main():
         del collector, env
         out["rainbow"] = rainbow_leg(rank, world, local_rank, dist, args.rainbow_updates, 30, args.rainbow_capacity, args.rainbow_filled,
                                      not args.no_roofline, not args.no_cpu_baseline)
+    if not args.no_hopper:
+        out["hopper"] = hopper_leg(rank, world, local_rank, dist, args.hopper_iters)
+    if rank == 0 and world == 1 and not args.no_apex:
+        out["apex"] = apex_leg(args.apex_actors, args.apex_updates)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters, W, T)
     if rank == 0:

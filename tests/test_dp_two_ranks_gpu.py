@@ -128,10 +128,12 @@ def test_bench_two_ranks_on_one_gpu_plumbing(tmp_path):
 
     env = dict(os.environ, JH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-rainbow", "--no-roofline", "--no-cpu-baseline"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-rainbow", "--no-roofline", "--no-cpu-baseline", "--hopper-iters", "1"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and np.isfinite(out["last_result"]["critic_loss"])
+    hp = out["hopper"]  # configs[4] strong-scaled over the two ranks: 16 workers and 1024 minibatch rows each, collector + DP learners
+    assert hp["n_gpus"] == 2 and hp["config"]["workers_per_gpu"] == 16 and hp["config"]["batch_per_gpu"] == 1024 and hp["value"] > 0
