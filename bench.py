@@ -169,6 +169,20 @@ def _latest(pattern):
     return files[-1] if files else None
 
 
+# launch names of the grouped GEMM engine <-> kernel symbols jh_tgemm_kernel<TM, TN, ID> (csrc/jh_tgemm.h: JH_TGEMM_TAGS)
+TGEMM_TAGS = ["dense", "conv1_fwd", "conv2_fwd", "conv3_fwd", "head_fwd", "fc_fwd", "stream1_fwd", "stream2_fwd", "stream2_bwd", "stream1_bwd", "fc_bwd",
+              "head_bwd", "conv3_bwd", "conv2_bwd", "conv1_bwd", "ppo_fwd_h2", "ppo_bwd", "ppo_bwd_dW1"]
+
+
+def _kmatch(key, name):
+    """key: a substring of the kernel symbol, or a launch name "jh_tgemm_<site>" (matched through its template tag)."""
+    import re
+
+    if key.startswith("jh_tgemm_") and key[len("jh_tgemm_"):] in TGEMM_TAGS:
+        return re.search(r"jh_tgemm_kernel<\d+, ?\d+, ?%d>" % TGEMM_TAGS.index(key[len("jh_tgemm_"):]), name) is not None
+    return key in name
+
+
 def rocprof_avg_us(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
     """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command."""
     path = _latest(pattern)
@@ -177,7 +191,7 @@ def rocprof_avg_us(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
     best = None
     with open(path) as f:
         for row in csv.DictReader(f):
-            if kernel_substr in row["Name"]:
+            if _kmatch(kernel_substr, row["Name"]):
                 c = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
                 if best is None or c[0] > best[0]:
                     best = c
@@ -192,7 +206,7 @@ def pmc_traffic(kernel_substr, pattern="r*_pmc_bench.json"):
     if path is None:
         return None
     for name, v in json.load(open(path)).items():
-        if kernel_substr in name and "FETCH_SIZE_KB_mean" in v and "WRITE_SIZE_KB_mean" in v:
+        if _kmatch(kernel_substr, name) and "FETCH_SIZE_KB_mean" in v and "WRITE_SIZE_KB_mean" in v:
             return (2.0 * v["FETCH_SIZE_KB_mean"] + v["WRITE_SIZE_KB_mean"]) * 1024.0
     return None
 
@@ -280,18 +294,18 @@ def rainbow_leg(rank, world, local_rank, dist, updates, warmup, capacity, filled
                                   f"N={N} ({filled} filled, {N * 2 * 28224 / 1e9:.1f} GB of frames allocated in HBM), one store per env step, one learn() per 4",
                       "parallelism": f"dp{world}"},
            "loss": float(r["loss"])}
-    if want_roofline and rank == 0 and agent.backend == "native":
-        # same learn() work, enqueued eagerly with the library's event pairs (idempotent GEMM launches x PROF_REPEAT)
+    if want_roofline and agent.backend == "native":
+        # same learn() work, enqueued eagerly with the library's event pairs (idempotent GEMM launches x PROF_REPEAT); every rank
+        # runs it (data-parallel learners meet in the all-reduce), rank 0 reports
         ops.lib_profile(True, PROF_REPEAT)
         for _ in range(3):
             update()
         prof = ops.lib_profile_report()
         ops.lib_profile(False)
-        mf = {k: v for k, v in prof.items() if v[2] > 0}
+        mf = {k: v for k, v in prof.items() if v[2] > 0} if rank == 0 else {}
         if mf:
             name, (cnt, ms, work) = max(mf.items(), key=lambda kv: kv[1][1])
-            e = mfma_entry(name, cnt, ms, work, "jh_tgemm_kernel")
-            e.pop("rocprof_avg_us"), e.pop("rocprof_summary"), e.pop("traffic")  # grouped launches share one kernel symbol in rocprofv3
+            e = mfma_entry(name, cnt, ms, work, name)  # every call site of the grouped engine is its own kernel symbol (template tag)
             e["note"] = "dominant grouped implicit-GEMM launch of Rainbow.learn() at B=32 (latency-bound chain of 12 such launches)"
             out["roofline"] = e
             out["kernel_avg_us"] = {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
@@ -500,8 +514,9 @@ def main():
     # PROF_REPEAT times back to back inside ONE HIP event pair recorded on the launch stream inside libjorldy_hip,
     # so the average is the kernel's duration in a dependent chain (what rocprofv3's kernel trace reports) and the
     # event pair's own ~4 us is amortised instead of subtracted.
-    if rank == 0 and agent.backend == "native" and not args.no_roofline:
-        prof = {}
+    prof = {}
+    if agent.backend == "native" and not args.no_roofline:
+        # every rank runs these iterations (data-parallel learners meet in the all-reduce); rank 0 reports
         for _ in range(3):
             transitions, _ = collector.run(T)
             step += T
@@ -512,6 +527,7 @@ def main():
             for k, v in part.items():
                 p = prof.get(k, (0, 0.0, 0.0))
                 prof[k] = (p[0] + v[0], p[1] + v[1], p[2] + v[2])
+    if rank == 0 and prof:
         mf = {k: v for k, v in prof.items() if v[2] > 0}
         sym = {"jh_pmb_bwd": "jh_pmb_bwd_kernel", "jh_pmb_fwd": "jh_pmb_fwd_kernel", "jh_pmb_fwd_nograd": "jh_pmb_fwd_kernel"}
         entries = {k: mfma_entry(k, v[0], v[1], v[2], sym.get(k, k)) for k, v in mf.items()}

@@ -73,5 +73,11 @@ struct TGemmWorkspace {
   unsigned* cnt = nullptr;
   int cnt_slots = 0;
 };
+// The call sites of the engine: launch name "jh_tgemm_<NAME>" <-> kernel symbol jh_tgemm_kernel<TM, TN, ID> (what rocprofv3 sees;
+// tools/rocprof_tgemm_names.py maps the IDs back).  A launch under a name that is not listed here is refused.
+#define JH_TGEMM_TAGS(X) \
+  X(dense, 0) X(conv1_fwd, 1) X(conv2_fwd, 2) X(conv3_fwd, 3) X(head_fwd, 4) X(fc_fwd, 5) X(stream1_fwd, 6) X(stream2_fwd, 7) \
+  X(stream2_bwd, 8) X(stream1_bwd, 9) X(fc_bwd, 10) X(head_bwd, 11) X(conv3_bwd, 12) X(conv2_bwd, 13) X(conv1_bwd, 14)      \
+  X(ppo_fwd_h2, 15) X(ppo_bwd, 16) X(ppo_bwd_dW1, 17)
 // One launch for up to kMaxGroup independent problems (same tile shape, linear grid over (problem, tile, split)).
 int jh_tgemm_launch(const TGemmWorkspace& w, const char* name, TGemm* probs, int n, hipStream_t st);

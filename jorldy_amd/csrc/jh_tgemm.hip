@@ -51,7 +51,10 @@ __device__ __noinline__ float4 op_fetch4_slow(Opnd o, int x, int k, int X, int K
 // workgroup to arrive (per-tile counter) sums the partials in split order -- deterministic, no atomics on
 // data -- and runs the epilogue.
 constexpr int kTabMax = 1024;  // k-range of one split that an im2col operand can address through its LDS table
-template <int TM, int TN>
+// TAG: one kernel SYMBOL per call site (conv1_fwd, stream2_bwd, ...), so that rocprofv3's kernel trace and PMC passes
+// attribute time and traffic per layer instead of to three shared `jh_tgemm_kernel<TM,TN>` symbols; the
+// body does not depend on it.
+template <int TM, int TN, int TAG>
 __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = 36;
   __shared__ __attribute__((aligned(16))) float sA[BM * LD];
@@ -305,6 +308,14 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
 
 }  // namespace
 
+static int tgemm_tag_of(const char* name) {
+#define JH_TGEMM_NAME(NAME, ID) \
+  if (strcmp(name, "jh_tgemm_" #NAME) == 0) return ID;
+  JH_TGEMM_TAGS(JH_TGEMM_NAME)
+#undef JH_TGEMM_NAME
+  return -1;
+}
+
 int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs, int n, hipStream_t st) {
   if (n < 1 || n > kMaxGroup) return jh_fail(JH_ERR_ARG, "tgemm group of %d", n);
   int maxM = 0, maxN = 0;
@@ -312,7 +323,12 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
     if (probs[i].M > maxM) maxM = probs[i].M;
     if (probs[i].N > maxN) maxN = probs[i].N;
   }
-  const int TM = maxM <= 32 ? 1 : 2, TN = maxN <= 32 ? 1 : 2;
+  int TM = maxM <= 32 ? 1 : 2, TN = maxN <= 32 ? 1 : 2;
+  // long-K, few-tile problems (conv1's weight gradient at B = 32: M = 32, N = 256, K = 12 800): the split-K tail is the LAST
+  // ARRIVER of each tile summing all splits' partial tiles alone.  32 x 32 tiles double the number of tiles -- twice as many
+  // arrivers, each with half as many bytes to sum, at half the split count per tile
+  static const int kSmallTileK = getenv("JH_TGEMM_SMALL_TILE_K") ? atoi(getenv("JH_TGEMM_SMALL_TILE_K")) : 4096;
+  if (n == 1 && kSmallTileK > 0 && probs[0].K >= kSmallTileK && ((maxM + 32 * TM - 1) / (32 * TM)) * ((maxN + 32 * TN - 1) / (32 * TN)) <= 8) TM = TN = 1;
   const int BM = 32 * TM, BN = 32 * TN;
   int max_tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -369,10 +385,19 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   double flops = 0.0;  // profiling: 2 M N K of every problem of the group (the launch is idempotent: partial slabs are
                        // rewritten, arrival counters return to zero)
   for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * (double)probs[i].K;
-  if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2>), grid, dim3(256), 0, st, batch);
-  else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2>), grid, dim3(256), 0, st, batch);
-  else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1>), grid, dim3(256), 0, st, batch);
-  else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1>), grid, dim3(256), 0, st, batch);
+  const int tag = tgemm_tag_of(name);
+#define JH_TGEMM_CASE(NAME, ID)                                                                                          \
+  case ID:                                                                                                              \
+    if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2, ID>), grid, dim3(256), 0, st, batch);      \
+    else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2, ID>), grid, dim3(256), 0, st, batch); \
+    else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1, ID>), grid, dim3(256), 0, st, batch); \
+    else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1, ID>), grid, dim3(256), 0, st, batch);                         \
+    break;
+  switch (tag) {
+    JH_TGEMM_TAGS(JH_TGEMM_CASE)
+    default: return jh_fail(JH_ERR_ARG, "tgemm launch name %s has no kernel tag (jh_tgemm.h: JH_TGEMM_TAGS)", name);
+  }
+#undef JH_TGEMM_CASE
   JH_LAUNCH_CHECK();
   return JH_OK;
 }

@@ -83,12 +83,14 @@ def hopper_leg(iters=10, warmup=3, workers=32, batch=2048, e2e=False, dist=None,
     n_upd = E * ((M + B - 1) // B)
     cstats = collector.stats() if collector is not None else None
     kern = {}
+    # one more iteration with the library's per-kernel event timers: EVERY rank runs it (data-parallel learners meet in the all-reduce),
+    # rank 0 reports
+    ops.lib_profile(True)
+    iteration()
+    torch.cuda.synchronize()
+    prof = ops.lib_profile_report()
+    ops.lib_profile(False)
     if rank == 0:
-        ops.lib_profile(True)
-        iteration()
-        torch.cuda.synchronize()
-        prof = ops.lib_profile_report()
-        ops.lib_profile(False)
         H = 512
         fwd = 2.0 * (n_upd * B + (0 if collector is not None else 2 * M)) * H * H
         nh = 2 * A + 1
