@@ -490,6 +490,13 @@ int jh_feed_emit(jh_feed* f, const int64_t* d_action, const float* d_q, const fl
                  uint8_t* d_done_out, double* d_prio_out, int32_t* emitted, jh_stream stream);
 /* Blocking read of the flags word (bit 0: plane ring overrun) and the number of planes written so far. */
 int jh_feed_state(jh_feed* f, int32_t* h_flags, int64_t* h_planes_written, jh_stream stream);
+/* Checkpoint of the feed itself (the reference cannot resume a replay at all, core/agent/dqn.py:184-199): rolling stacks' slot
+ * numbers, plane cursors + history, rolling action / reward / done / q windows, flags, tick.  Together with the plane pool, the
+ * store's rows and the sum tree, a feed of the SAME geometry continues exactly where the saved one stood.  h buffers hold
+ * jh_feed_state_bytes(f) bytes; both calls synchronise `stream` and must not race a tick.                               */
+int64_t jh_feed_state_bytes(const jh_feed* f);
+int jh_feed_save(jh_feed* f, void* h_out, int64_t bytes, jh_stream stream);
+int jh_feed_load(jh_feed* f, const void* h_in, int64_t bytes, jh_stream stream);
 
 /* ------------------------------------------------------------------ data-parallel learners: the collective
  * The reference has ONE learner and no collective (its "distributed" mode is Ray actors feeding that learner,

@@ -129,6 +129,9 @@ _PROTOS = {
     "jh_feed_push_frames": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_feed_emit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp]),
     "jh_feed_state": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
+    "jh_feed_state_bytes": (_i64, [_vp]),
+    "jh_feed_save": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "jh_feed_load": (C.c_int, [_vp, _vp, _i64, _vp]),
     "jh_collector_stats": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), _i32]),
     "jh_collector_run": (C.c_int, [_vp, _i32, _i32, _vp]),
     "jh_collector_stats_detail": (C.c_int, [_vp, C.POINTER(_f64)]),

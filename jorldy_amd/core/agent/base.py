@@ -49,23 +49,38 @@ class BaseAgent(ABC):
     def interact_callback(self, transition):
         return transition
 
-    def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
-        """base.py:93-111."""
-        if mode == "linear":
-            weight = 1 - (step / self.run_step)
-        elif mode == "cosine":
-            weight = np.cos((np.pi / 2) * (step / self.run_step))
-        elif mode == "sqrt":
-            weight = (1 - (step / self.run_step)) ** (1 / 2)
-        else:
+    # lr(step) = lr0 * schedule(step / run_step): the reference's three annealing shapes (base.py:93-111), one table for every agent
+    _LR_SCHEDULES = {
+        "linear": lambda frac: 1.0 - frac,
+        "cosine": lambda frac: float(np.cos(0.5 * np.pi * frac)),
+        "sqrt": lambda frac: max(1.0 - frac, 0.0) ** 0.5,
+    }
+
+    def _lr_weight(self, step, mode="cosine"):
+        schedule = self._LR_SCHEDULES.get(mode)
+        if schedule is None:
             raise Exception(f"check learning rate decay mode again! => {mode}")
-        if optimizers is None:
-            optimizers = [self.optimizer]
-        if not isinstance(optimizers, list):
-            optimizers = [optimizers]
-        for optimizer in optimizers:
-            for g in optimizer.param_groups:
-                g["lr"] = optimizer.defaults["lr"] * weight
+        return schedule(step / self.run_step)
+
+    def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
+        weight = self._lr_weight(step, mode)
+        targets = optimizers if optimizers is not None else self.optimizer
+        for opt in (targets if isinstance(targets, list) else [targets]):
+            for group in opt.param_groups:
+                group["lr"] = opt.defaults["lr"] * weight
+
+    _fallback_warned = set()
+
+    def _warn_torch_backend(self, why):
+        """One line per agent class and reason when a configuration leaves the native (hand-written HIP) networks for the torch
+        mirror modules -- i.e. rocBLAS / MIOpen kernels: still correct, but not the path the benches and roofline numbers describe."""
+        key = (type(self).__name__, why)
+        if key not in BaseAgent._fallback_warned:
+            BaseAgent._fallback_warned.add(key)
+            import warnings
+
+            warnings.warn(f"[jorldy_amd] {type(self).__name__}: backend='torch' ({why}); the encoder / optimizer run on PyTorch-ROCm library kernels, "
+                          f"only buffers / losses / PER stay on libjorldy_hip.  Pass backend='torch' explicitly to silence this.", RuntimeWarning, stacklevel=3)
 
     # ---- complete checkpoint (beyond the reference's {"network", "optimizer"} ckpt) -------------------
     _RESUME_ATTRS = ("time_t", "learn_stamp", "num_learn", "epsilon", "beta", "target_update_stamp", "learn_period_stamp",

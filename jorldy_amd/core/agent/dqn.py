@@ -39,6 +39,8 @@ class DQN(NativeValueNetMixin, BaseAgent):
         can_native = native_supported(network, head, state_size, hidden_size, optim_config)
         self.backend = backend or ("native" if can_native else "torch")
         assert self.backend in ("native", "torch")
+        if backend is None and not can_native:
+            self._warn_torch_backend(f"network={network!r}, head={head!r}, hidden_size={hidden_size}, optim={optim_config.get('name', 'adam')!r} is outside the native value networks")
         if self.backend == "native" and not can_native:
             raise ValueError("backend='native' needs a discrete_q_network / dueling network, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam / RMSprop")
         mk = lambda: Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
@@ -110,8 +112,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
             return self._native_lr_decay(step, mode)
         if self._lr0 is None:
             return super().learning_rate_decay(step, optimizers, mode)
-        weight = {"linear": 1 - (step / self.run_step), "cosine": np.cos((np.pi / 2) * (step / self.run_step)),
-                  "sqrt": max(1 - (step / self.run_step), 0.0) ** 0.5}[mode]
+        weight = self._lr_weight(step, mode)
         for g in self.optimizer.param_groups:  # in place: the captured graph reads this tensor
             g["lr"].fill_(self._lr0 * float(weight))
 

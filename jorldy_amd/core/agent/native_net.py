@@ -128,9 +128,7 @@ class NativeValueNetMixin:
         return st
 
     def _native_lr_decay(self, step, mode="cosine"):
-        weight = {"linear": 1 - (step / self.run_step), "cosine": np.cos((np.pi / 2) * (step / self.run_step)),
-                  "sqrt": max(1 - (step / self.run_step), 0.0) ** 0.5}[mode]
-        self._lr_now = self._lr0 * float(weight)
+        self._lr_now = self._lr0 * float(self._lr_weight(step, mode))
         self._net.set_lr(self._lr_now)  # a device scalar: the captured graph reads it
 
     def _shadow_optimizer(self):

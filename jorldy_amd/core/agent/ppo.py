@@ -70,6 +70,8 @@ class PPO(BaseAgent):
         if backend == "native" and not eligible:
             raise ValueError("backend='native' needs head='mlp', an int state_size, Adam without weight decay and <= 8 head outputs")
         self.backend = "native" if (eligible and backend != "torch") else "torch"
+        if backend == "auto" and not eligible:
+            self._warn_torch_backend(f"network={network!r}, head={head!r}, state_size={state_size!r}, hidden_size={hidden_size}, optim={optim_config.get('name', 'adam')!r} is outside the native policy-value net")
         self.use_graph = use_graph
         # four- / five-launch minibatch update (jh_pponet_ppo_update) for minibatches < 1024 rows; JH_FUSED_UPDATE=0
         # keeps the forward / loss / backward / Adam calls separate (same results; used by the A/B in bench)

@@ -100,6 +100,8 @@ class Rainbow(DQN):
         can_native = native_supported(network, head, state_size, hidden_size, optim_config, noise_type)
         self.backend = backend or ("native" if can_native else "torch")
         assert self.backend in ("native", "torch")
+        if backend is None and not can_native:
+            self._warn_torch_backend(f"network={network!r}, head={head!r}, hidden_size={hidden_size}, noise_type={noise_type!r}, optim={optim_config.get('name', 'adam')!r} is outside the native value networks")
         if self.backend == "native" and not can_native:
             raise ValueError("backend='native' needs network='rainbow', factorized noise, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam / RMSprop")
         mk = lambda: Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head).to(self.device)

@@ -155,6 +155,38 @@ class LockstepFramePool:
                                "far more often than a frame-stacking wrapper implies): raise pool_factor")
         return written
 
+    # ---- resume: plane pool + the feed's device state; the rows / tree are the buffer's -----------------
+    def geometry(self):
+        return {"n_actors": self.n_actors, "C": self.C, "frame_shape": list(self.frame_shape), "n_step": self.n_step, "planes_per_actor": self.R,
+                "window_ticks": self.window, "pool_slots": self.F, "buffer_size": self.N}
+
+    def save_stream(self, dirpath, chunk_bytes=64 << 20):
+        """planes.bin (the pool, streamed from HBM in chunks) + feed_state.bin (jh_feed_save).  Raises on a plane-ring overrun."""
+        import os
+
+        self.check()
+        rows_per = max(1, chunk_bytes // self.elems)
+        with open(os.path.join(dirpath, "planes.bin"), "wb") as f:
+            for o in range(0, self.F, rows_per):
+                f.write(self.planes[o : o + rows_per].cpu().numpy().tobytes())
+        self.feed.save_state().tofile(os.path.join(dirpath, "feed_state.bin"))
+        return {"geometry": self.geometry(), "planes": "planes.bin", "state": "feed_state.bin", "rows_stored": int(self.rows_stored)}
+
+    def load_stream(self, dirpath, meta, chunk_bytes=64 << 20):
+        import os
+
+        if meta["geometry"] != self.geometry():
+            raise ValueError(f"the saved feed has another geometry: {meta['geometry']} vs {self.geometry()} (same buffer_size, actors, frame stack, n_step, "
+                             "pool_factor and depth are needed to continue a device-fed replay)")
+        rows_per = max(1, chunk_bytes // self.elems)
+        with open(os.path.join(dirpath, meta["planes"]), "rb") as f:
+            for o in range(0, self.F, rows_per):
+                m = min(rows_per, self.F - o)
+                a = np.frombuffer(f.read(m * self.elems), dtype=np.uint8).reshape((m,) + tuple(self.planes.shape[1:]))
+                self.planes[o : o + m].copy_(torch.from_numpy(a.copy()))
+        self.feed.load_state(np.fromfile(os.path.join(dirpath, meta["state"]), dtype=np.uint8))
+        self.rows_stored = int(meta["rows_stored"])
+
     def stats(self):
         written = self.check()
         return {"planes_written": written, "pool_slots": self.F, "planes_per_actor": self.R, "window_ticks": self.window,

@@ -250,8 +250,9 @@ class ReplayBuffer(BaseBuffer):
 
     def _refuse_load_when_fed(self):
         if getattr(self, "_feeds", None):
-            raise RuntimeError("this buffer is the sink of a DeviceActorFeed: its rows reference the feed's plane rings; restore into a fresh "
-                               "buffer (the saved form is the portable full-stack one) -- re-attaching a feed to restored rows is not supported")
+            raise RuntimeError("this buffer is the sink of a DeviceActorFeed: its rows reference the feed's plane rings.  A checkpoint written FROM a fed "
+                               "buffer (save_full / save_stream, resume format 2) carries the plane pool and the feed's state and continues in a fed buffer "
+                               "of the same geometry; the host-copy form (state_dict) and checkpoints of plain buffers restore into a plain buffer only")
 
     def load_state_dict(self, sd):
         self._refuse_load_when_fed()
@@ -296,6 +297,9 @@ class ReplayBuffer(BaseBuffer):
 
         import torch
 
+        fed = bool(getattr(self, "_feeds", None))
+        if fed:  # rows the actors have emitted but the learner has not appended yet belong to the checkpoint (actors must be paused)
+            self.drain()
         self.flush()
         meta = {"buffer_size": self.buffer_size, "buffer_index": self.buffer_index, "buffer_counter": self.buffer_counter,
                 "frame_dedup": bool(self._frames is not None), "layout": None, "columns": []}
@@ -324,14 +328,58 @@ class ReplayBuffer(BaseBuffer):
                     else:
                         chunk = col[o : o + m]
                     f.write(chunk.cpu().numpy().tobytes())
-            meta["columns"].append({"name": name, "dtype": np_dt.str, "shape": list(row_shape), "file": fn, "rows": n})
+            entry = {"name": name, "dtype": np_dt.str, "shape": list(row_shape), "file": fn, "rows": n}
+            if dec and fed:  # the raw slot numbers too: a fed buffer continues from them (plane pool below), a plain one from the stacks
+                sfn = f"col_{i}.slots.bin"
+                with open(os.path.join(dirpath, sfn), "wb") as f:
+                    f.write(col[:n].cpu().numpy().tobytes())
+                entry.update({"slots_file": sfn, "slots_shape": list(shape), "slots_dtype": np.dtype(ops._NP_OF[dt]).str})
+            meta["columns"].append(entry)
+        if fed:
+            meta["feed"] = self._frames.save_stream(dirpath, self._STREAM_CHUNK_BYTES)
+            meta["feed"]["producers"] = [fd.save_stream(dirpath, k) for k, fd in enumerate(self._feeds)]
         return meta
+
+    def _load_stream_fed(self, dirpath, meta):
+        """Continue a device-fed replay: rows with their slot numbers, plane pool, feed state (the sum tree follows in PERBuffer)."""
+        import ctypes as C
+        import os
+
+        if "feed" not in meta:
+            self._refuse_load_when_fed()
+        assert meta["buffer_size"] == self.buffer_size
+        n = int(meta["buffer_counter"])
+        self._frames.load_stream(dirpath, meta["feed"], self._STREAM_CHUNK_BYTES)
+        by_name = {c["name"]: c for c in meta["columns"]}
+        self._store.lib.jh_store_clear(self._store.h)
+        rows_per = 65536
+        files = {}
+        for name, dt, elems, shape in self._store.columns:
+            c = by_name[name]
+            raw = "slots_file" in c
+            files[name] = (open(os.path.join(dirpath, c["slots_file"] if raw else c["file"]), "rb"), np.dtype(c["slots_dtype"] if raw else c["dtype"]), int(elems))
+        try:
+            for o in range(0, n, rows_per):
+                m = min(rows_per, n - o)
+                chunk = {}
+                for name, (f, dt, elems) in files.items():
+                    chunk[name] = np.frombuffer(f.read(m * elems * dt.itemsize), dtype=dt).reshape(m, elems)
+                self._store.push(chunk)
+        finally:
+            for f, _, _ in files.values():
+                f.close()
+        self.buffer_index, self.buffer_counter = int(meta["buffer_index"]), n
+        self._store.lib.jh_store_clear(self._store.h)
+        self._store.lib.jh_store_set_position(self._store.h, C.c_int64(self.buffer_index), C.c_int64(self.buffer_counter))
+        for fd, st in zip(self._feeds, meta["feed"]["producers"]):
+            fd.load_stream(dirpath, st)
 
     def load_stream(self, dirpath, meta):
         import ctypes as C
         import os
 
-        self._refuse_load_when_fed()
+        if getattr(self, "_feeds", None):
+            return self._load_stream_fed(dirpath, meta)
         assert meta["buffer_size"] == self.buffer_size
         self._pending, self._pending_rows, self._pend_cols = [], 0, None
         self._frames = self._layout = self._store = None

@@ -18,14 +18,18 @@
 // The emitted rows are what the frame-de-duplicating replay store keeps per transition (2 C slot numbers instead of 2 C
 // planes, frame_dedup.py), so sampling rebuilds the stacks with the same row-gather kernel.  Nothing but the tick's
 // rewards and done flags (2 N floats) crosses PCIe a second time.
+#include <atomic>
+
 #include "jh_common.h"
 
 struct jh_feed {
   jh_ctx* ctx = nullptr;
   int N = 0, C = 0, n = 0, L = 0;
-  int64_t plane = 0, R = 0, window = 0, Th = 0, tick = 0;
+  int64_t plane = 0, R = 0, window = 0, Th = 0;
+  std::atomic<int64_t> tick{0};  // advanced by the producer thread (jh_feed_emit), read by jh_feed_state from others
   float gamma = 0.f;
   void* block = nullptr;
+  size_t block_bytes = 0;
   int64_t *ids = nullptr, *cur = nullptr, *alloc_hist = nullptr, *act = nullptr;
   float *rew = nullptr, *done = nullptr, *q = nullptr;
   int32_t *neq = nullptr, *flags = nullptr;
@@ -195,6 +199,7 @@ JH_EXPORT int jh_feed_create(jh_ctx* ctx, int32_t n_actors, int32_t C, int64_t p
   const size_t b_ids = sizeof(int64_t) * L * N * C, b_cur = sizeof(int64_t) * 2 * N, b_hist = sizeof(int64_t) * N * (size_t)f->Th,
                b_act = sizeof(int64_t) * L * N, b_f = sizeof(float) * L * N, b_neq = sizeof(int32_t) * N;
   const size_t total = b_ids + b_cur + b_hist + b_act + 3 * b_f + b_neq + 64;
+  f->block_bytes = total;
   hipError_t e = hipMalloc(&f->block, total);
   if (e != hipSuccess) {
     delete f;
@@ -324,11 +329,40 @@ JH_EXPORT int jh_feed_state(jh_feed* f, int32_t* h_flags, int64_t* h_planes_writ
   JH_ARG(f && h_flags && h_planes_written);
   hipStream_t st = jh_s(stream);
   std::vector<int64_t> cur(f->N);
+  const int64_t tick = f->tick.load(std::memory_order_acquire);  // ONE snapshot: another thread may be closing a tick right now
   JH_HIP(hipMemcpyAsync(h_flags, f->flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  JH_HIP(hipMemcpyAsync(cur.data(), f->cur + (size_t)(f->tick & 1) * f->N, sizeof(int64_t) * (size_t)f->N, hipMemcpyDeviceToHost, st));
+  JH_HIP(hipMemcpyAsync(cur.data(), f->cur + (size_t)(tick & 1) * f->N, sizeof(int64_t) * (size_t)f->N, hipMemcpyDeviceToHost, st));
   JH_HIP(hipStreamSynchronize(st));
   int64_t s = 0;
   for (int64_t v : cur) s += v;
   *h_planes_written = s;
+  return JH_OK;
+}
+
+// Checkpoint of the feed's own state (a resumable device-fed replay): the device block (slot numbers of the
+// rolling stacks, per-actor plane cursors and their per-tick history, the rolling action / reward / done / q windows, flags) + the
+// tick counter.  With the plane pool, the store's rows and the sum tree (saved by their owners) a feed created with the SAME
+// geometry continues exactly where this one stood.  Both calls synchronise `stream`; jh_feed_save must not race a tick.
+JH_EXPORT int64_t jh_feed_state_bytes(const jh_feed* f) { return f ? (int64_t)f->block_bytes + 16 : 0; }
+
+JH_EXPORT int jh_feed_save(jh_feed* f, void* h_out, int64_t bytes, jh_stream stream) {
+  JH_ARG(f && h_out && bytes == jh_feed_state_bytes(f));
+  if (f->pushed) return jh_fail(JH_ERR_STATE, "jh_feed_save between the two halves of a tick");
+  int64_t head[2] = {f->tick.load(), (int64_t)f->block_bytes};
+  memcpy(h_out, head, 16);
+  JH_HIP(hipMemcpyAsync((char*)h_out + 16, f->block, f->block_bytes, hipMemcpyDeviceToHost, jh_s(stream)));
+  JH_HIP(hipStreamSynchronize(jh_s(stream)));
+  return JH_OK;
+}
+
+JH_EXPORT int jh_feed_load(jh_feed* f, const void* h_in, int64_t bytes, jh_stream stream) {
+  JH_ARG(f && h_in && bytes == jh_feed_state_bytes(f));
+  int64_t head[2];
+  memcpy(head, h_in, 16);
+  if (head[1] != (int64_t)f->block_bytes) return jh_fail(JH_ERR_ARG, "jh_feed_load: the saved feed has another geometry (%lld vs %zu state bytes)", (long long)head[1], f->block_bytes);
+  JH_HIP(hipMemcpyAsync(f->block, (const char*)h_in + 16, f->block_bytes, hipMemcpyHostToDevice, jh_s(stream)));
+  JH_HIP(hipStreamSynchronize(jh_s(stream)));
+  f->tick.store(head[0]);
+  f->pushed = false;
   return JH_OK;
 }

@@ -324,11 +324,21 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
     if (probs[i].N > maxN) maxN = probs[i].N;
   }
   int TM = maxM <= 32 ? 1 : 2, TN = maxN <= 32 ? 1 : 2;
-  // long-K, few-tile problems (conv1's weight gradient at B = 32: M = 32, N = 256, K = 12 800): the split-K tail is the LAST
-  // ARRIVER of each tile summing all splits' partial tiles alone.  32 x 32 tiles double the number of tiles -- twice as many
-  // arrivers, each with half as many bytes to sum, at half the split count per tile
-  static const int kSmallTileK = getenv("JH_TGEMM_SMALL_TILE_K") ? atoi(getenv("JH_TGEMM_SMALL_TILE_K")) : 4096;
-  if (n == 1 && kSmallTileK > 0 && probs[0].K >= kSmallTileK && ((maxM + 32 * TM - 1) / (32 * TM)) * ((maxN + 32 * TN - 1) / (32 * TN)) <= 8) TM = TN = 1;
+  // long-K, few-tile groups (B = 32: conv1's weight gradient M = 32, N = 256, K = 12 800; the fc layer 96 x 512, K = 3136): the
+  // split-K tail is the LAST ARRIVER of each tile summing all splits' partial tiles alone (fc: 16 tiles x 16 splits x 16 KB).  32 x 32
+  // tiles give 2-4 x as many tiles -- as many more arrivers, each with a fraction of the bytes to sum, at a lower split count per tile.
+  // Measured (tools/probes/ab_tgemm_tiles.sh, Rainbow.learn() at config.rainbow.atari shapes): 0.428 -> 0.416 ms (K >= 4096, <= 8 tiles:
+  // conv1 wgrad only) -> 0.4065 ms (K >= 2048, <= 32 tiles); <= 64 tiles / K >= 1024: no further change
+  static const int kSmallTileK = getenv("JH_TGEMM_SMALL_TILE_K") ? atoi(getenv("JH_TGEMM_SMALL_TILE_K")) : 2048;
+  static const int kSmallTileMax = getenv("JH_TGEMM_SMALL_TILE_MAXTILES") ? atoi(getenv("JH_TGEMM_SMALL_TILE_MAXTILES")) : 32;
+  {
+    int big_tiles = 0, min_k = 1 << 30;
+    for (int i = 0; i < n; ++i) {
+      big_tiles += ((probs[i].M + 32 * TM - 1) / (32 * TM)) * ((probs[i].N + 32 * TN - 1) / (32 * TN));
+      if (probs[i].K < min_k) min_k = probs[i].K;
+    }
+    if (kSmallTileK > 0 && min_k >= kSmallTileK && big_tiles <= kSmallTileMax) TM = TN = 1;
+  }
   const int BM = 32 * TM, BN = 32 * TN;
   int max_tiles = 0;
   for (int i = 0; i < n; ++i) {

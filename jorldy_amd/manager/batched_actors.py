@@ -273,27 +273,60 @@ class DeviceActorFeed:
         slot = e if will_emit else self.depth  # warm-up ticks write their (unused) outputs to the spare slot
         out = {k: v[slot] for k, v in self._out.items()}
         cur, prev = self._obs[self.ticks & 1], (self._obs[(self.ticks + 1) & 1] if self.ticks > 0 else None)
-        with torch.cuda.stream(a.stream):
-            if will_emit and self._taken_valid[e]:
-                a.stream.wait_event(self._taken[e])  # the learner's copies out of this slot are done
-            flat = dict(out)
-            flat["action"], flat["reward"], flat["done"] = out["action"].view(-1), out["reward"].view(self.N, self.n), out["done"].view(self.N, self.n)
-            if self._mode != "frames":
-                self.pool.feed.push_stacks(cur, prev, self.pool.planes)
-            got = self.pool.feed.emit(a._act_dev, a._q_dev, reward, done, flat, self.prio_eps)
-            if got:
-                self._ready[e].record(a.stream)
+        got = 0
+        try:
+            with torch.cuda.stream(a.stream):
+                if will_emit and self._taken_valid[e]:
+                    a.stream.wait_event(self._taken[e])  # the learner's copies out of this slot are done
+                flat = dict(out)
+                flat["action"], flat["reward"], flat["done"] = out["action"].view(-1), out["reward"].view(self.N, self.n), out["done"].view(self.N, self.n)
+                if self._mode != "frames":
+                    self.pool.feed.push_stacks(cur, prev, self.pool.planes)
+                got = self.pool.feed.emit(a._act_dev, a._q_dev, reward, done, flat, self.prio_eps)
+                if got:
+                    self._ready[e].record(a.stream)
+        finally:
+            if will_emit and not got:  # the slot was not filled (an error above, or the library emitted nothing): hand the permit back
+                self._free.release()
         self.ticks += 1
         if got:
             self.emissions += 1
             self._queue.append(e)
         return got
 
+    # ---- resume: what this object knows beyond the pool's device state (tick parity of the stack buffers, mode, last stacks) ----
+    def save_stream(self, dirpath, k=0):
+        """Call with the actors paused and everything drained (ReplayBuffer.save_stream does the drain)."""
+        import os
+
+        assert not self._queue, "emissions are waiting: drain first"
+        torch.cuda.synchronize(self.actors.device)
+        fn = None
+        if self.ticks > 0:
+            fn = f"feed_{k}_last_stacks.bin"
+            self._obs[(self.ticks - 1) & 1].cpu().numpy().tofile(os.path.join(dirpath, fn))
+        return {"ticks": int(self.ticks), "mode": self._mode, "last_stacks": fn, "stored_rows": int(self.stored_rows), "N": self.N, "n_step": self.n, "depth": self.depth}
+
+    def load_stream(self, dirpath, st):
+        import os
+
+        assert (st["N"], st["n_step"]) == (self.N, self.n), "another feed geometry"
+        assert not self._queue and self.ticks == 0, "restore into a fresh feed"
+        self.ticks, self._mode, self.stored_rows, self.emissions = int(st["ticks"]), st["mode"], int(st["stored_rows"]), 0
+        if st["last_stacks"]:
+            a = np.fromfile(os.path.join(dirpath, st["last_stacks"]), dtype=np.uint8).reshape(tuple(self._obs[0].shape))
+            self._obs[(self.ticks - 1) & 1].copy_(torch.from_numpy(a))
+        self.actors._x_dev = self._obs[(self.ticks - 1) & 1] if self.ticks > 0 else self._obs[0]
+        torch.cuda.synchronize(self.actors.device)
+
     def drain_into(self, memory):
         """Learner thread, learner stream: append every finished emission to the store (device to device) and push its
         leaves; returns the number of rows taken.  Emission slots are consecutive in memory, so everything that has
         arrived goes in as one append + one tree push per contiguous run of slots (two at the slot ring's wrap)."""
         cur = torch.cuda.current_stream(self.actors.device)
+        self._drains = getattr(self, "_drains", 0) + 1
+        if self._drains % 256 == 0:  # a plane-ring overrun only raises a device flag: look at it now and then (blocking, ~20 us), not only in stats()
+            self.pool.check()
         slots = []
         while self._queue:
             slots.append(self._queue.popleft())

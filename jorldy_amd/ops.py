@@ -267,6 +267,17 @@ class ActorFeed:
                                       L.ptr(out["done"]), L.ptr(out["priority"]), C.byref(emitted), L.stream_ptr()))
         return int(emitted.value)
 
+    def save_state(self):
+        """The feed's own state (device block + tick) as bytes (jh_feed_save; synchronises the current stream)."""
+        n = int(self.lib.jh_feed_state_bytes(self.h))
+        buf = np.empty(n, np.uint8)
+        L.check(self.lib.jh_feed_save(self.h, L.ptr(buf), n, L.stream_ptr()))
+        return buf
+
+    def load_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        L.check(self.lib.jh_feed_load(self.h, L.ptr(buf), int(buf.size), L.stream_ptr()))
+
     def push_stacks(self, obs, prev_obs, pool):
         """First half of a tick, stack mode (see tick)."""
         L.check(self.lib.jh_feed_push_stacks(self.h, L.ptr(obs), L.ptr(prev_obs), L.ptr(pool), L.stream_ptr()))

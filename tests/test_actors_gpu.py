@@ -481,3 +481,92 @@ def test_device_feed_full_size_chain_property():
         tiled = (s1 == s1[:, -1:].expand_as(s1)).flatten(1).all(1)
         assert bool((slid | r1).all()) and bool((tiled | ~r1).all()), e                       # (b)
         assert torch.equal(s1[:, -1].reshape(N, -1).to(torch.int64).sum(1), sums[e + 1]), e  # (c)
+
+
+@pytest.mark.parametrize("frames", [False, True])
+def test_full_checkpoint_resumes_a_device_fed_replay_bit_identically(tmp_path, frames):
+    """SURVEY.md 8f rank 4 / VERDICT r2 "missing" #4: save_full of an Ape-X learner whose replay is fed on the device (plane rings,
+    per-actor cursors, rolling n-step windows, rows with slot numbers, sum tree) -> load_full into a FRESH agent + feed of the same
+    geometry -> the continuation (acting, feeding, draining, learning) is bit-identical to the uninterrupted run: same stored rows,
+    same decoded stacks, same float64 tree, same losses, same weights.  The buffer (96 slots) and the plane rings wrap before the
+    checkpoint."""
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import BatchedValueActors, DeviceActorFeed
+
+    N, n, C, shape, cap, T1, T2 = 6, 3, 4, (44, 52), 96, 40, 30
+    rs = np.random.RandomState(77)
+    script = []
+    stacks = rs.randint(0, 256, size=(N, C) + shape).astype(np.uint8)
+    for t in range(T1 + T2):
+        reset = (rs.rand(N) < 0.04) if t else np.ones(N, bool)
+        new = rs.randint(0, 256, size=(N,) + shape).astype(np.uint8)
+        if t:
+            stacks[:, :-1] = stacks[:, 1:]
+            stacks[:, -1] = new
+        stacks[reset] = np.repeat(new[reset][:, None], C, 1)  # a reset stack is the new frame C times (core/env/atari.py:112)
+        script.append((stacks.copy(), new.copy(), reset.astype(np.uint8), rs.choice([-1.0, 0.0, 1.0], size=(N, 1)).astype(np.float32),
+                       (rs.rand(N, 1) < 0.03).astype(np.float32)))
+
+    def mk():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        agent = Agent("ape_x", state_size=[C, 44, 52], action_size=4, hidden_size=64, network="dueling", head="cnn", batch_size=16, buffer_size=cap,
+                      start_train_step=0, n_step=n, num_workers=N, target_update_period=7, run_step=100000, device="cuda", use_graph=False)
+        actors = BatchedValueActors(agent, N)
+        return agent, actors, DeviceActorFeed(actors, agent.memory, n, agent.gamma, depth=8, prio_eps=1e-3)
+
+    def run(agent, actors, feed, t0, t1, out):
+        for t in range(t0, t1):
+            st, new, reset, reward, done = script[t]
+            act = feed.act_frames(new, reset, training=True) if frames else feed.act(st, training=True)
+            assert feed.push(reward, done) >= 0
+            if t >= 8 and t % 2 == 0:
+                agent.learn_period_stamp = agent.learn_period
+                r = agent.process(None, t)
+                if r:
+                    out.append((r["loss"], r["max_Q"], act["action"].copy()))
+            if t % 10 == 9:
+                actors.sync()
+
+    def snapshot(agent):
+        agent.memory.drain()
+        torch.cuda.synchronize()
+        m = agent.memory
+        idx = torch.arange(m.buffer_counter, device=agent.device)
+        rows = {k: v.cpu().numpy().copy() for k, v in m.gather(idx, as_float=False).items()}
+        return rows, m.sum_tree.copy(), m.buffer_index, m.buffer_counter, agent._net.params.cpu().numpy().copy(), agent._net.target.cpu().numpy().copy()
+
+    a, a_act, a_feed = mk()
+    log_a = []
+    run(a, a_act, a_feed, 0, T1, log_a)
+    a_act.sync()  # the acting copy at the checkpoint = the learner's weights (a resumed run starts from a sync)
+    a.save_full(str(tmp_path))
+    tail_a = []
+    run(a, a_act, a_feed, T1, T1 + T2, tail_a)
+    want = snapshot(a)
+    assert a.memory._frames.rows_stored > 2 * cap  # wrapped
+
+    b, b_act, b_feed = mk()
+    b.load_full(str(tmp_path))
+    b_act.sync()
+    tail_b = []
+    run(b, b_act, b_feed, T1, T1 + T2, tail_b)
+    got = snapshot(b)
+    assert len(tail_a) == len(tail_b) > 5
+    for (la, qa, aa), (lb, qb, ab) in zip(tail_a, tail_b):
+        assert la == lb and qa == qb and np.array_equal(aa, ab)
+    assert want[2:4] == got[2:4]
+    for k in want[0]:
+        assert np.array_equal(want[0][k], got[0][k]), k
+    assert np.array_equal(want[1], got[1]), "sum tree"
+    assert np.array_equal(want[4], got[4]) and np.array_equal(want[5], got[5]), "weights"
+    # a checkpoint of a plain buffer still cannot be loaded into a fed one (its rows have no planes behind them) -- and says so
+    import json
+
+    mp = os.path.join(str(tmp_path), "resume", "manifest.json")
+    man = json.load(open(mp))
+    man["memory"].pop("feed")
+    json.dump(man, open(mp, "w"))
+    c, _, _ = mk()
+    with pytest.raises(RuntimeError, match="sink of a DeviceActorFeed"):
+        c.load_full(str(tmp_path))
