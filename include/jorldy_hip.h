@@ -291,6 +291,10 @@ int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_
                          const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old,
                          float eps_clip, float vf_coef, float ent_coef, float max_norm, int32_t do_adam, float* d_stats,
                          jh_stream stream);
+/* Sampling stream of the acting calls and the collectors (counter-based: the action of env row w at acting step c is a function
+ * of (seed, c, w); the reference samples with torch.multinomial / torch.normal, ppo.py:55-69): read, or with set != 0 restore,
+ * {seed, counter} -- what a resumed run needs to continue the same action stream.                                     */
+int jh_pponet_act_rng(jh_pponet* n, uint64_t* seed, uint64_t* counter, int32_t set);
 /* PPO.act for W envs in one shot (ppo.py:55-69, discrete): ONE kernel launch computes the fused MLP
  * forward and writes per-column-tile partial head outputs + sequence words into device-mapped
  * pinned memory; the host polls them, sums the partials, and does softmax + multinomial (argmax

@@ -86,6 +86,7 @@ _PROTOS = {
     "jh_pponet_destroy": (None, [_vp]),
     "jh_pponet_set_hyper": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "jh_pponet_set_lr": (C.c_int, [_vp, _f32, _vp]),
+    "jh_pponet_act_rng": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i32]),
     "jh_pponet_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_backward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_adam_step": (C.c_int, [_vp, _f32, _vp, _vp]),

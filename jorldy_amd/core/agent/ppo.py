@@ -481,6 +481,17 @@ class PPO(BaseAgent):
         return result
 
     # ---------------------------------------------------------------------------------- checkpoint
+    def _resume_extra_attrs(self):
+        """The native sampling stream (seed, acting-step counter): a resumed run continues the same action stream."""
+        if self._net is None:
+            return {}
+        seed, ctr = self._net.act_rng()
+        return {"act_seed": str(seed), "act_ctr": str(ctr)}  # strings: uint64 does not survive JSON floats
+
+    def _resume_load_extra_attrs(self, d):
+        if self._net is not None and "act_seed" in d:
+            self._net.act_rng((int(d["act_seed"]), int(d["act_ctr"])))
+
     def _export_optim_state(self):
         """Native Adam moments -> torch.optim.Adam state, so `ckpt` keeps the reference's format
         ({"network": state_dict, "optimizer": state_dict}, reinforce.py:128-136)."""

@@ -200,6 +200,20 @@ class Rainbow(DQN):
             self.grad_sync()
         self.optimizer.step()
 
+    def _resume_extra_attrs(self):
+        """The learner's noise stream (ops.NormalSource: seed + call counter in device memory): without it a resumed run would
+        re-seed from torch's generator and draw other NoisyNet noise than the uninterrupted one."""
+        src = getattr(self, "_normal", None)
+        if src is None:
+            return {}
+        st = src.state.cpu().tolist()
+        return {"normal_source": [str(int(v)) for v in st]}
+
+    def _resume_load_extra_attrs(self, d):
+        if "normal_source" in d and self._net is not None:
+            self._normal = ops.NormalSource(self.device, seed=0)
+            self._normal.state.copy_(torch.tensor([int(v) for v in d["normal_source"]], dtype=torch.int64))
+
     def learn(self):
         s, p = self._learn_stats(self._stats8_np, (5, 7), self._stats8)
         return {"loss": float(s[0]), "beta": self.beta, "max_Q": float(s[1]), "max_logit": float(s[2]), "min_logit": float(s[3]),

@@ -575,6 +575,15 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   delete n;
 }
 
+// The host-side sampling stream of jh_pponet_act_* / the collectors (counter-based: action of env row w at acting step c =
+// f(seed, c, w)): read or (set != 0) restore {seed, counter} -- part of a complete checkpoint.
+JH_EXPORT int jh_pponet_act_rng(jh_pponet* n, uint64_t* seed, uint64_t* counter, int32_t set) {
+  JH_ARG(n && seed && counter);
+  if (set) { n->act_seed = *seed; n->act_ctr = *counter; }
+  else { *seed = n->act_seed; *counter = n->act_ctr; }
+  return JH_OK;
+}
+
 JH_EXPORT int jh_pponet_set_hyper(jh_pponet* n, float lr, float beta1, float beta2, float eps, float step,
                                   jh_stream stream) {
   JH_ARG(n != nullptr);

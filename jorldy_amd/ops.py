@@ -549,6 +549,14 @@ class PPONet:
     def set_lr(self, lr):
         L.check(self.lib.jh_pponet_set_lr(self.h, float(lr), L.stream_ptr()))
 
+    def act_rng(self, state=None):
+        """(seed, counter) of the host-side sampling stream; state=(seed, counter) restores it."""
+        s, c = C.c_uint64(0), C.c_uint64(0)
+        if state is not None:
+            s, c = C.c_uint64(int(state[0])), C.c_uint64(int(state[1]))
+        L.check(self.lib.jh_pponet_act_rng(self.h, C.byref(s), C.byref(c), int(state is not None)))
+        return int(s.value), int(c.value)
+
     def forward(self, x, idx=None, B=None, out=None):
         """x float32 [*, S]; rows gathered by idx (int64 [B]) when given.  Returns raw heads
         (logits, value) or (mu_raw, log_std_raw, value); `out` = preallocated tuple."""

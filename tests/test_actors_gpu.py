@@ -1,6 +1,8 @@
 """Batched on-GPU acting of the value-net agents: jh_value_act against torch, and
 BatchedValueActors (one forward per tick for all actors on an acting copy of the native network) against the agents'
 own act() (ape_x.py:64-77, rainbow.py:140-152, dqn.py:76-92) row by row."""
+import os
+
 import numpy as np
 import pytest
 import torch

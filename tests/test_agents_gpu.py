@@ -1135,3 +1135,53 @@ def test_rainbow_native_learns_identically_from_a_deduplicated_replay():
         if dedup:
             assert agent._graph is not None and agent.memory._frames is not None
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+def test_full_checkpoint_restores_the_native_rng_streams(tmp_path):
+    """Rainbow's learner noise (ops.NormalSource: seed + call counter in device memory) and PPO's host-side action
+    sampling stream (seed, acting-step counter) are part of resume format 2: a resumed run draws the same NoisyNet noise /
+    samples the same actions as the uninterrupted one."""
+    from jorldy_amd.core.agent import Agent
+
+    z = load("rainbow")
+    H, A, K = int(_h(z, "H")), int(_h(z, "A")), int(_h(z, "num_support"))
+
+    def mk():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        ag = Agent("rainbow", state_size=int(z["hyper/S"]), action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": 1e-3}, buffer_size=256,
+                   batch_size=int(_h(z, "B")), start_train_step=0, run_step=1000, n_step=3, num_support=K, device="cuda", backend="native", use_graph=False)
+        ag.network.load_state_dict(_sd(z, "sd0/"))
+        ag.target_network.load_state_dict(_sd(z, "sdt/"))
+        _fill_from_fixture(ag, z, True)
+        return ag
+
+    a = mk()
+    torch.manual_seed(3)
+    for _ in range(4):
+        a.learn()
+    a.save_full(str(tmp_path / "rb"))
+    want = [a.learn()["loss"] for _ in range(4)]
+    b = mk()
+    torch.manual_seed(12345)  # whatever the process' torch generator holds: the restored stream must not depend on it
+    b.load_full(str(tmp_path / "rb"))
+    got = [b.learn()["loss"] for _ in range(4)]
+    assert want == got
+    torch.testing.assert_close(a._net.params, b._net.params, rtol=0, atol=0)
+
+    def mkp():
+        torch.manual_seed(0)
+        return Agent("ppo", state_size=4, action_size=2, hidden_size=64, n_step=16, batch_size=16, device="cuda", backend="native", seed=9)
+
+    p = mkp()
+    obs = np.random.RandomState(1).randn(8, 4).astype(np.float32)
+    for _ in range(5):
+        p.act(obs, training=True)
+    os.makedirs(tmp_path / "ppo")
+    p.save_full(str(tmp_path / "ppo"))
+    want_a = [p.act(obs, training=True)["action"].copy() for _ in range(20)]
+    q = mkp()
+    q.load_full(str(tmp_path / "ppo"))
+    assert q._net.act_rng()[1] == 5
+    got_a = [q.act(obs, training=True)["action"].copy() for _ in range(20)]
+    assert all(np.array_equal(x, y) for x, y in zip(want_a, got_a)) and len({a.tobytes() for a in want_a}) > 1
