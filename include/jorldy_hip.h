@@ -291,6 +291,9 @@ int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_
                          const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old,
                          float eps_clip, float vf_coef, float ent_coef, float max_norm, int32_t do_adam, float* d_stats,
                          jh_stream stream);
+/* Device address of the optimizer's hyper block (float[8]: lr, beta1, beta2, eps, step, ...), e.g. as the destination of a
+ * jh_collector_set_ride_along copy that delivers the next decayed learning rate (base.py:93-111) without a copy of its own. */
+void* jh_pponet_hyper_ptr(jh_pponet* n);
 /* Sampling stream of the acting calls and the collectors (counter-based: the action of env row w at acting step c is a function
  * of (seed, c, w); the reference samples with torch.multinomial / torch.normal, ppo.py:55-69): read, or with set != 0 restore,
  * {seed, counter} -- what a resumed run needs to continue the same action stream.                                     */
@@ -350,6 +353,11 @@ int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream str
  * = V(state_{t+1}) (one extra value-only query after the last step; where done_t is set the entry belongs to the reset state
  * and is multiplied by (1 - done_t) = 0 in GAE, ppo.py:96).  d_value == NULL switches capture off.                         */
 int jh_collector_set_capture(jh_collector* c, float* d_h0, float* d_h1, float* d_value, float* d_next_value, int64_t rows);
+/* Two more copies (slot 0 / 1; bytes == 0 clears the slot) for the commit launch of every following run: device-visible source
+ * (device-mapped pinned memory, jh_pinned_alloc) -> device buffer, read when that launch executes (the end of the run).  For the
+ * learner's inputs that change between learn() calls and are known before the rollout ends: the coming epochs' minibatch index
+ * lists (ppo.py:116-118, drawn ahead) and the decayed learning rate (base.py:93-111).                                    */
+int jh_collector_set_ride_along(jh_collector* c, int32_t slot, const void* d_src_mapped, void* d_dst, int64_t bytes);
 /* Enqueue the persistent acting kernel of the NEXT jh_collector_run(T) now, e.g. right behind the learner's last launch: it
  * starts when the stream reaches it, reads the then-current weights and waits (bounded, ~0.2 s) for the first observations.
  * Nothing else may be enqueued on `stream` before that run.  A kernel that timed out is replaced by the run itself.      */

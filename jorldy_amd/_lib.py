@@ -86,6 +86,7 @@ _PROTOS = {
     "jh_pponet_destroy": (None, [_vp]),
     "jh_pponet_set_hyper": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "jh_pponet_set_lr": (C.c_int, [_vp, _f32, _vp]),
+    "jh_pponet_hyper_ptr": (_vp, [_vp]),
     "jh_pponet_act_rng": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i32]),
     "jh_pponet_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_backward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -138,6 +139,7 @@ _PROTOS = {
     "jh_collector_stats_detail": (C.c_int, [_vp, C.POINTER(_f64)]),
     "jh_collector_set_capture": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "jh_collector_prelaunch": (C.c_int, [_vp, _i32, _vp]),
+    "jh_collector_set_ride_along": (C.c_int, [_vp, _i32, _vp, _vp, _i64]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),
     "jh_cartpole_destroy": (None, [_vp]),
     "jh_cartpole_obs": (C.c_int, [_vp, _vp]),

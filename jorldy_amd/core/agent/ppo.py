@@ -86,6 +86,10 @@ class PPO(BaseAgent):
         self._captured = 0            # rows whose heads / values the collector delivered for the next learn() (jh_collector_set_capture)
         self._post_launch_hook = None  # one-shot callable run right behind learn()'s launches (NativeCollector.arm_prelaunch)
         self._lr_step = None          # process(): step for the lr decay that learn() applies behind its launches
+        # a NativeCollector offers its commit launch for the small per-learn() uploads (index lists, learning rate): _ride = that collector,
+        # _ride_done = a run has happened since the last learn(), _ride_wait = what was handed to it and is not known to have arrived
+        self._ride, self._ride_done, self._ride_wait = None, False, {}
+        self._lr_word = None
         # index lists of the next learn() drawn ahead on a copy of np.random's state (np_rng.Predraw); JH_PPO_PREDRAW=0: draw inside learn()
         self._predraw = np_rng.Predraw() if os.environ.get("JH_PPO_PREDRAW", "1") == "1" else None
         if self.backend == "native":
@@ -259,7 +263,8 @@ class PPO(BaseAgent):
             st["rows"] = ops.MinibatchRows(srcs, st["mb"])
         # the epochs' index lists are drawn straight into pinned memory (two buffers: the next learn()'s lists are drawn and
         # uploaded while this one's may still be in flight)
-        st["idx_pin"] = [torch.empty(self.n_epoch * M, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        st["idx_pin"] = [ops.PinnedBuffer((self.n_epoch * M,), np.int64, self.device.index) for _ in range(2)]  # device-mapped: a kernel may read them in place
+        st["idx_alias"] = [ops._wrap_device(p.dev_ptr.value, (self.n_epoch * M,), torch.int64, self.device, owner=p) for p in st["idx_pin"]]
         st["idx_ev"] = [None, None]
         st["idx_k"] = 0
         st["idx_ready"] = False  # st["idx"] already holds the (pre-drawn, uploaded) lists of the coming learn()
@@ -274,16 +279,23 @@ class PPO(BaseAgent):
         st = self._static
         return st["h0"], st["h1"], st["value"], st["next_value"]
 
-    def _upload_idx(self, st, draw):
-        """draw(numpy int64 view [E * M]) fills the lists; they go to st["idx"] with one async H2D."""
+    def _upload_idx(self, st, draw, ride=False):
+        """draw(numpy int64 view [E * M]) fills the lists in device-mapped pinned memory; they reach st["idx"] with one copy kernel now,
+        or (ride) inside the commit launch of the collector's next run."""
         k = st["idx_k"]
         st["idx_k"] = 1 - k
         if st["idx_ev"][k] is not None:
             st["idx_ev"][k].synchronize()
-        ok = draw(st["idx_pin"][k].numpy())
+            st["idx_ev"][k] = None
+        ok = draw(st["idx_pin"][k].np)
         if ok is False:
             return False
-        st["idx"].copy_(st["idx_pin"][k], non_blocking=True)
+        if ride and self._ride is not None:
+            self._ride.ride_along(0, st["idx_pin"][k].dev_ptr.value, st["idx"].data_ptr(), st["idx"].numel() * 8)
+            self._ride_wait["idx"] = k
+            return True
+        self._ride_wait.pop("idx", None)
+        st["idx"].copy_(st["idx_alias"][k])
         ev = torch.cuda.Event()
         ev.record()
         st["idx_ev"][k] = ev
@@ -364,6 +376,14 @@ class PPO(BaseAgent):
         E = self.n_epoch
         captured = self._captured == M
         self._captured = 0
+        # what was handed to the collector's commit launch has arrived iff a run happened since; otherwise deliver it now
+        rode, self._ride_done = self._ride_done, False
+        if self._ride_wait and not rode:
+            if "lr" in self._ride_wait:
+                self._net.set_lr(float(self._lr_word.np[0]))
+            if "idx" in self._ride_wait and st["idx_ready"]:
+                st["idx"].copy_(st["idx_alias"][self._ride_wait["idx"]])
+        self._ride_wait.clear()
 
         def shuffles():
             # the reference's global-RNG shuffles (ppo.py:118) of all epochs, drawn by numpy's own algorithm on numpy's own state
@@ -437,7 +457,7 @@ class PPO(BaseAgent):
                 self.learning_rate_decay(self._lr_step)
             self._lr_step = None
         if self._predraw is not None:
-            st["idx_ready"] = bool(self._upload_idx(st, lambda out: self._predraw.draw(M, E, out)))
+            st["idx_ready"] = bool(self._upload_idx(st, lambda out: self._predraw.draw(M, E, out), ride=True))
         hook, self._post_launch_hook = self._post_launch_hook, None
         if hook is not None:
             hook()
@@ -455,7 +475,16 @@ class PPO(BaseAgent):
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
         super().learning_rate_decay(step, optimizers, mode)
         if self._net is not None:
-            self._net.set_lr(self.optimizer.param_groups[0]["lr"])
+            lr = self.optimizer.param_groups[0]["lr"]
+            if self._ride is not None and self._lr_step is not None:  # from inside learn(): the next run's commit launch delivers it
+                if self._lr_word is None:
+                    self._lr_word = ops.PinnedBuffer((1,), np.float32, self.device.index)
+                self._lr_word.np[0] = lr
+                self._ride.ride_along(1, self._lr_word.dev_ptr.value, self._net.hyper_ptr(), 4)
+                self._ride_wait["lr"] = True
+            else:
+                self._ride_wait.pop("lr", None)
+                self._net.set_lr(lr)
 
     def process(self, transitions, step):
         """ppo.py:187-202.  `transitions` is the reference's List[Dict] or an SoA dict of arrays."""

@@ -44,6 +44,10 @@ struct jh_collector {
   // acting-time capture (jh_collector_set_capture): device destinations of the raw heads / values of the states acted on
   float *cap_h0 = nullptr, *cap_h1 = nullptr, *cap_v = nullptr, *cap_nv = nullptr;
   int64_t cap_rows = 0;
+  // up to two more plain copies riding in the commit launch (jh_collector_set_ride_along): device-visible source -> device
+  const void* ride_src[2] = {nullptr, nullptr};
+  void* ride_dst[2] = {nullptr, nullptr};
+  int64_t ride_bytes[2] = {0, 0};
   int prelaunched_T = 0;          // steps of a persistent kernel already enqueued by jh_collector_prelaunch (0: none)
   double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
   double t_first = 0, t_extra = 0, t_commit = 0;  // of t_act: the rollout's first step (kernel start-up) and the value-only query; the commit launch
@@ -125,6 +129,17 @@ JH_EXPORT int jh_collector_set_capture(jh_collector* c, float* d_h0, float* d_h1
   return JH_OK;
 }
 
+// Two more copies for the commit launch of every following run (slot 0 / 1; bytes == 0 clears a slot): the learner's inputs that
+// change between learn() calls but are known before the rollout ends -- the minibatch index lists of the coming epochs (drawn
+// ahead, np_rng.Predraw) and the decayed learning rate -- go from device-mapped pinned memory to their device buffers inside the
+// launch that exists anyway, instead of as hipMemcpyAsync calls of their own (SDMA hand-offs of ~10 us each between the learner's
+// last kernel and the next rollout's acting kernel).  The source is read when the commit kernel runs (end of the run).
+JH_EXPORT int jh_collector_set_ride_along(jh_collector* c, int32_t slot, const void* d_src_mapped, void* d_dst, int64_t bytes) {
+  JH_ARG(c != nullptr && slot >= 0 && slot < 2 && bytes >= 0 && (bytes == 0 || (d_src_mapped && d_dst)));
+  c->ride_src[slot] = d_src_mapped; c->ride_dst[slot] = d_dst; c->ride_bytes[slot] = bytes;
+  return JH_OK;
+}
+
 static int collector_steps(const jh_collector* c, int T) { return T + ((c->cap_v && c->cap_rows == (int64_t)c->W * T) ? 1 : 0); }
 
 // Enqueue the persistent acting kernel of the NEXT jh_collector_run(T) now (e.g. right behind the learner's last launch): it starts
@@ -164,18 +179,19 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
   }
   auto finish = [&](int rc_in) {  // commit what was staged (keeps the store consistent) and hand the capture slab back
     int rc2;
+    const void* xs[6]; void* xd[6]; int64_t xb[6]; int k = 0;
     if (cap && rc_in == JH_OK) {
-      const void* xs[4]; void* xd[4]; int64_t xb[4]; int k = 0;
       const char* dev0 = (const char*)cap_slab->dev;
       auto job = [&](const float* h, float* d, size_t floats) { xs[k] = dev0 + ((const char*)h - (const char*)cap_slab->host); xd[k] = d; xb[k] = (int64_t)(sizeof(float) * floats); ++k; };
       job(ch0, c->cap_h0, (size_t)n * A);
       if (c->cont) job(ch1, c->cap_h1, (size_t)n * A);
       job(cv, c->cap_v, (size_t)n);
       job(cnv, c->cap_nv, (size_t)n);
-      rc2 = jh_store_stage_commit_extra(c->store, k, xs, xd, xb, jh_s(stream));
-    } else {
-      rc2 = jh_store_stage_commit(c->store, stream);
     }
+    if (rc_in == JH_OK)
+      for (int r = 0; r < 2; ++r)
+        if (c->ride_bytes[r] > 0) { xs[k] = c->ride_src[r]; xd[k] = c->ride_dst[r]; xb[k] = c->ride_bytes[r]; ++k; }
+    rc2 = k ? jh_store_stage_commit_extra(c->store, k, xs, xd, xb, jh_s(stream)) : jh_store_stage_commit(c->store, stream);
     if (cap_slab) (void)jh_ctx_slab_release(c->ctx, cap_slab, jh_s(stream));
     return rc_in ? rc_in : rc2;
   };

@@ -575,6 +575,10 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   delete n;
 }
 
+// Device address of the optimizer's hyper block {lr, beta1, beta2, eps, step, ...} (8 floats): lets a caller deliver the next learning
+// rate with a copy it already makes (jh_collector_set_ride_along) instead of jh_pponet_set_lr's own H2D.
+JH_EXPORT void* jh_pponet_hyper_ptr(jh_pponet* n) { return n ? (void*)n->hyper : nullptr; }
+
 // The host-side sampling stream of jh_pponet_act_* / the collectors (counter-based: action of env row w at acting step c =
 // f(seed, c, w)): read or (set != 0) restore {seed, counter} -- part of a complete checkpoint.
 JH_EXPORT int jh_pponet_act_rng(jh_pponet* n, uint64_t* seed, uint64_t* counter, int32_t set) {

@@ -51,7 +51,7 @@ JH_EXPORT void jh_store_destroy(jh_store* s) {
 // ONE launch for a ring append of all columns (<= 8) from sources a kernel can read: device memory, or device-mapped
 // pinned memory for small appends.  A rollout commit used to be one hipMemcpyAsync per column (5-10 SDMA copies of a few
 // KB each, ~3 us apiece on the host and again on the copy engine, back to back in front of learn()).
-constexpr int kCopyJobs = 12;  // store columns (<= 8) + extra plain copies riding in the same launch (the collector's captured heads / values)
+constexpr int kCopyJobs = 14;  // store columns (<= 8) + extra plain copies riding in the same launch (the collector's captured heads / values)
 struct CopyCols {
   const char* src[kCopyJobs];
   char* dst[kCopyJobs];       // ring position of the first row
@@ -130,7 +130,7 @@ JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) { return jh_s
 // The commit with n_extra (<= 4) plain device-visible -> device copies in the SAME launch (internal: the collector's captured
 // heads / values land next to the rollout rows without further launches or SDMA copies).
 int jh_store_stage_commit_extra(jh_store* s, int n_extra, const void* const* x_src, void* const* x_dst, const int64_t* x_bytes, hipStream_t st) {
-  JH_ARG(s != nullptr && n_extra >= 0 && n_extra <= 4);
+  JH_ARG(s != nullptr && n_extra >= 0 && s->n_cols + n_extra <= kCopyJobs);
   if (!s->staged) return jh_fail(JH_ERR_STATE, "jh_store_stage_commit without begin");
   const int64_t n = s->staged_n;
   size_t bytes = 0;

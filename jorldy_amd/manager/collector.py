@@ -109,6 +109,8 @@ class NativeCollector:
         L.check(create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
         self.h, self._store_h, self._net_h = h, store.h.value, net.h.value
         self._set_capture(cap, n_rows)
+        self._rides = {}
+        self.agent._ride = self  # the agent may hand its small per-learn() uploads (index lists, learning rate) to the commit launch
 
     def _set_capture(self, cap, n_rows):
         if cap is None:
@@ -119,10 +121,19 @@ class NativeCollector:
         L.check(self.lib.jh_collector_set_capture(self.h, L.ptr(h0), L.ptr(h1), L.ptr(v), L.ptr(nv), int(n_rows)))
         self._cap_key = tuple(t.data_ptr() for t in cap if t is not None)
 
+    def ride_along(self, slot, src_dev_ptr, dst_ptr, nbytes):
+        """jh_collector_set_ride_along: the commit launch of every following run also copies nbytes from device-mapped pinned memory
+        at src_dev_ptr to the device buffer at dst_ptr (read when that launch executes, i.e. at the end of the run)."""
+        key = (int(src_dev_ptr), int(dst_ptr), int(nbytes))
+        if self._rides.get(slot) != key:
+            L.check(self.lib.jh_collector_set_ride_along(self.h, int(slot), C.c_void_p(key[0]), C.c_void_p(key[1]), key[2]))
+            self._rides[slot] = key
+
     def run(self, step=1):
         n_rows = self.env.W * step
         self._bind(n_rows)
         L.check(self.lib.jh_collector_run(self.h, int(step), 1, L.stream_ptr()))
+        self.agent._ride_done = True  # this run's commit launch carried whatever was registered with ride_along
         if self._cap_key is not None:
             self.agent._captured = n_rows  # the coming learn() takes the heads / values of these rows as delivered (no no-grad passes)
         return None, 1.0
@@ -150,6 +161,8 @@ class NativeCollector:
 
     def terminate(self):
         if self.h is not None:
+            if getattr(self.agent, "_ride", None) is self:
+                self.agent._ride = None
             self.lib.jh_collector_destroy(self.h)
             self.h = None
 

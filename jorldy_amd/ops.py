@@ -549,6 +549,9 @@ class PPONet:
     def set_lr(self, lr):
         L.check(self.lib.jh_pponet_set_lr(self.h, float(lr), L.stream_ptr()))
 
+    def hyper_ptr(self):
+        return int(self.lib.jh_pponet_hyper_ptr(self.h))
+
     def act_rng(self, state=None):
         """(seed, counter) of the host-side sampling stream; state=(seed, counter) restores it."""
         s, c = C.c_uint64(0), C.c_uint64(0)

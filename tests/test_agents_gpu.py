@@ -1160,6 +1160,7 @@ def test_full_checkpoint_restores_the_native_rng_streams(tmp_path):
     torch.manual_seed(3)
     for _ in range(4):
         a.learn()
+    os.makedirs(tmp_path / "rb")
     a.save_full(str(tmp_path / "rb"))
     want = [a.learn()["loss"] for _ in range(4)]
     b = mk()
