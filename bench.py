@@ -431,15 +431,27 @@ def main():
     step = 0
 
     prelaunch = hasattr(collector, "arm_prelaunch") and os.environ.get("JH_PRELAUNCH", "1") == "1"
+    early = hasattr(collector, "begin") and agent.backend == "native" and os.environ.get("JH_EARLY_COMMIT", "1") == "1"
 
     def one_iteration(last=False):
         """last: no acting kernel is enqueued ahead for an iteration that does not follow (the fences below would wait for it)."""
         nonlocal step
-        transitions, _ = collector.run(T)
-        step += T
-        if prelaunch and not last:
-            collector.arm_prelaunch(T)  # learn() enqueues the next rollout's acting kernel right behind its own launches
-        result = agent.process(transitions, step)
+        if early:
+            # the commit launch and the learner's launches are enqueued BEFORE the rollout's host loop (they wait on the stream behind the
+            # acting kernel / the gated commit): the learner starts the instant the rollout ends
+            collector.begin(T)
+            step += T
+            agent.process_begin(step)
+            collector.loop()
+            if prelaunch and not last:
+                collector.arm_prelaunch(T)
+            result = agent.process_end()
+        else:
+            transitions, _ = collector.run(T)
+            step += T
+            if prelaunch and not last:
+                collector.arm_prelaunch(T)  # learn() enqueues the next rollout's acting kernel right behind its own launches
+            result = agent.process(transitions, step)
         collector.sync(None)
         return result
 

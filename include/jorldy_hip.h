@@ -353,6 +353,17 @@ int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream str
  * = V(state_{t+1}) (one extra value-only query after the last step; where done_t is set the entry belongs to the reset state
  * and is multiplied by (1 - done_t) = 0 in GAE, ppo.py:96).  d_value == NULL switches capture off.                         */
 int jh_collector_set_capture(jh_collector* c, float* d_h0, float* d_h1, float* d_value, float* d_next_value, int64_t rows);
+/* jh_collector_run in two halves, the commit launch enqueued AHEAD of the host loop:
+ *   jh_collector_begin  staging, the acting kernel (unless prelaunched), then the commit launch (rows + captured block + ride-along
+ *                       copies) -- gated: its workgroups wait, bounded, for a flag word in device-mapped pinned memory.  The store's
+ *                       row count advances here: the caller may enqueue the rollout's consumer (the learner's launches) on `stream` now.
+ *   jh_collector_loop   the T-step host loop (Actor.run, manager/distributed_manager.py:76-92); its last act releases the flag.
+ * The consumer then starts the instant the rollout ends instead of after the host has returned and launched it.  Needs the persistent
+ * acting kernel (W <= 16, W * S <= 128) and a one-launch commit (<= 512 KB of rows), else the pair behaves exactly like jh_collector_run.
+ * A stalled environment (no observations for ~0.2 s) is an ERROR in this form (work is queued behind the acting kernel, the per-step
+ * fallback of jh_collector_run cannot run); the flag is released regardless so that the stream drains.                              */
+int jh_collector_begin(jh_collector* c, int32_t T, jh_stream stream);
+int jh_collector_loop(jh_collector* c, int32_t training, jh_stream stream);
 /* Two more copies (slot 0 / 1; bytes == 0 clears the slot) for the commit launch of every following run: device-visible source
  * (device-mapped pinned memory, jh_pinned_alloc) -> device buffer, read when that launch executes (the end of the run).  For the
  * learner's inputs that change between learn() calls and are known before the rollout ends: the coming epochs' minibatch index

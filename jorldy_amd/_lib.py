@@ -139,6 +139,8 @@ _PROTOS = {
     "jh_collector_stats_detail": (C.c_int, [_vp, C.POINTER(_f64)]),
     "jh_collector_set_capture": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "jh_collector_prelaunch": (C.c_int, [_vp, _i32, _vp]),
+    "jh_collector_begin": (C.c_int, [_vp, _i32, _vp]),
+    "jh_collector_loop": (C.c_int, [_vp, _i32, _vp]),
     "jh_collector_set_ride_along": (C.c_int, [_vp, _i32, _vp, _vp, _i64]),
     "jh_cartpole_create": (C.c_int, [_i32, C.c_uint64, _pp]),
     "jh_cartpole_destroy": (None, [_vp]),

@@ -368,6 +368,13 @@ class PPO(BaseAgent):
                 k += 1
 
     def _learn_native(self):
+        self._learn_launch()
+        return self._learn_finish()
+
+    def _learn_launch(self):
+        """Enqueue one learn() (everything up to and including the launches); `_learn_finish` does the host work behind them and reads
+        the statistics.  Split so that a collector can enqueue the learner BEFORE its rollout's host loop (NativeCollector.begin / loop:
+        the launches wait on the stream behind the acting kernel and the gated commit, and start the instant the rollout ends)."""
         M = self.memory.size
         self._grow_native(2 * M if 2 * M <= 8192 else M)
         if self._static is None or self._static["M"] != M:
@@ -451,6 +458,11 @@ class PPO(BaseAgent):
             self._warm = True
         self.memory._store.clear()
         self._adam_steps += st["n_upd"]
+        self._launched = (st, pin, M, E)
+
+    def _learn_finish(self):
+        st, pin, M, E = self._launched
+        self._launched = None
         # ---- behind the launches, while the GPU works: next learning rate, next index lists, the next rollout's acting kernel
         if self._lr_step is not None:
             if self.lr_decay:
@@ -485,6 +497,26 @@ class PPO(BaseAgent):
             else:
                 self._ride_wait.pop("lr", None)
                 self._net.set_lr(lr)
+
+    def process_begin(self, step):
+        """First half of `process(None, step)` for a rollout whose rows are already committed to the store -- possibly only ENQUEUED
+        (NativeCollector.begin): the bookkeeping of ppo.py:187-202 and, when a learn() is due, its launches.  `process_end` returns the result."""
+        assert self._net is not None, "process_begin / process_end are the native backend's split form of process()"
+        delta_t = step - self.time_t
+        self.time_t = step
+        self.learn_stamp += delta_t
+        self._begun = self.learn_stamp >= self.n_step
+        if self._begun:
+            self._lr_step = step
+            self._learn_launch()
+
+    def process_end(self):
+        if not getattr(self, "_begun", False):
+            return {}
+        self._begun = False
+        result = self._learn_finish()
+        self.learn_stamp = 0
+        return result
 
     def process(self, transitions, step):
         """ppo.py:187-202.  `transitions` is the reference's List[Dict] or an SoA dict of arrays."""

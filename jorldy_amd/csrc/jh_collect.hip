@@ -48,12 +48,18 @@ struct jh_collector {
   const void* ride_src[2] = {nullptr, nullptr};
   void* ride_dst[2] = {nullptr, nullptr};
   int64_t ride_bytes[2] = {0, 0};
+  void* run = nullptr;            // RunState of the run in progress (jh_collector_run, or between _begin and _loop)
+  unsigned *gate_h = nullptr, *gate_d = nullptr, gate_seq = 0;  // flag word that releases an early-enqueued commit launch
   int prelaunched_T = 0;          // steps of a persistent kernel already enqueued by jh_collector_prelaunch (0: none)
   double t_act = 0, t_env = 0, t_total = 0;  // host seconds: waiting for actions / stepping envs / whole runs
   double t_first = 0, t_extra = 0, t_commit = 0;  // of t_act: the rollout's first step (kernel start-up) and the value-only query; the commit launch
   int64_t runs = 0;
   int64_t steps = 0;
 };
+
+struct RunState;
+static void run_state_alloc(jh_collector* c);
+static void run_state_free(jh_collector* c);
 
 static int collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* cart, jh_control* ctl, jh_store* store, const int32_t* cols,
                             jh_collector** out) {
@@ -84,6 +90,7 @@ static int collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* cart, jh_c
   c->reward.resize(W);
   c->done.resize(W);
   c->heads.resize(16 * (size_t)W);
+  run_state_alloc(c);
   *out = c;
   return JH_OK;
 }
@@ -108,6 +115,8 @@ JH_EXPORT void jh_collector_destroy(jh_collector* c) {
     (void)hipDeviceSynchronize();
     jh_persist_destroy(c->persist);
   }
+  if (c->gate_h) (void)hipHostFree(c->gate_h);
+  run_state_free(c);
   delete c;
 }
 
@@ -155,65 +164,97 @@ JH_EXPORT int jh_collector_prelaunch(jh_collector* c, int32_t T, jh_stream strea
   return rc;
 }
 
-// Collect T steps from every env and append the W*T transitions (worker-major) to the store.
-JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream) {
-  JH_ARG(c != nullptr && T > 0);
-  const int W = c->W, S = c->S, A = c->A;
-  const int64_t n = (int64_t)W * T;
-  const bool cap = c->cap_v && c->cap_rows == n;
-  const int steps = collector_steps(c, T);
-  void* cols[16];
-  int rc = jh_store_stage_begin(c->store, n, cols);
-  if (rc) return rc;
-  // captured block in pinned, device-mapped memory: [h0 n*A | h1 n*A (continuous) | value n | next_value n]
+// ---- one run = prepare (staging slabs, acting kernel) -> host loop -> commit (rows + captured block + ride-along copies, ONE launch).
+// jh_collector_run does the three in that order.  jh_collector_begin / jh_collector_loop enqueue the commit launch FIRST, gated by a
+// flag word in device-mapped pinned memory that the host loop sets when its last row is written: whatever the caller enqueues next
+// (the learner's graph) then runs the instant the rollout ends, instead of after the host has returned, crossed back into Python
+// and launched it (~45 us of idle GPU per iteration at config.ppo.cartpole shapes).
+struct RunState {
+  bool active = false, cap = false, persistent = false, early = false;
+  int T = 0, steps = 0;
+  int64_t n = 0;
+  void* cols[16] = {};
   jh_pinned_slab* cap_slab = nullptr;
   float *ch0 = nullptr, *ch1 = nullptr, *cv = nullptr, *cnv = nullptr;
-  if (cap) {
-    const size_t fl = (size_t)n * A * (c->cont ? 2 : 1) + 2 * (size_t)n;
-    rc = jh_ctx_slab(c->ctx, sizeof(float) * fl, &cap_slab);
-    if (rc) { (void)jh_store_stage_commit(c->store, stream); return rc; }
-    ch0 = (float*)cap_slab->host;
-    ch1 = c->cont ? ch0 + (size_t)n * A : nullptr;
-    cv = ch0 + (size_t)n * A * (c->cont ? 2 : 1);
-    cnv = cv + n;
+};
+static RunState& run_state(jh_collector* c) { return *static_cast<RunState*>(c->run); }
+static void run_state_alloc(jh_collector* c) { c->run = new RunState(); }
+static void run_state_free(jh_collector* c) { delete static_cast<RunState*>(c->run); c->run = nullptr; }
+
+static int run_commit(jh_collector* c, RunState& r, int rc_in, const unsigned* wait_flag, unsigned wait_val, hipStream_t st) {
+  // commit what was staged (keeps the store consistent) and hand the capture slab back
+  const int A = c->A;
+  const int64_t n = r.n;
+  const void* xs[6]; void* xd[6]; int64_t xb[6]; int k = 0;
+  if (r.cap && rc_in == JH_OK) {
+    const char* dev0 = (const char*)r.cap_slab->dev;
+    auto job = [&](const float* h, float* d, size_t floats) { xs[k] = dev0 + ((const char*)h - (const char*)r.cap_slab->host); xd[k] = d; xb[k] = (int64_t)(sizeof(float) * floats); ++k; };
+    job(r.ch0, c->cap_h0, (size_t)n * A);
+    if (c->cont) job(r.ch1, c->cap_h1, (size_t)n * A);
+    job(r.cv, c->cap_v, (size_t)n);
+    job(r.cnv, c->cap_nv, (size_t)n);
   }
-  auto finish = [&](int rc_in) {  // commit what was staged (keeps the store consistent) and hand the capture slab back
-    int rc2;
-    const void* xs[6]; void* xd[6]; int64_t xb[6]; int k = 0;
-    if (cap && rc_in == JH_OK) {
-      const char* dev0 = (const char*)cap_slab->dev;
-      auto job = [&](const float* h, float* d, size_t floats) { xs[k] = dev0 + ((const char*)h - (const char*)cap_slab->host); xd[k] = d; xb[k] = (int64_t)(sizeof(float) * floats); ++k; };
-      job(ch0, c->cap_h0, (size_t)n * A);
-      if (c->cont) job(ch1, c->cap_h1, (size_t)n * A);
-      job(cv, c->cap_v, (size_t)n);
-      job(cnv, c->cap_nv, (size_t)n);
-    }
-    if (rc_in == JH_OK)
-      for (int r = 0; r < 2; ++r)
-        if (c->ride_bytes[r] > 0) { xs[k] = c->ride_src[r]; xd[k] = c->ride_dst[r]; xb[k] = c->ride_bytes[r]; ++k; }
-    rc2 = k ? jh_store_stage_commit_extra(c->store, k, xs, xd, xb, jh_s(stream)) : jh_store_stage_commit(c->store, stream);
-    if (cap_slab) (void)jh_ctx_slab_release(c->ctx, cap_slab, jh_s(stream));
-    return rc_in ? rc_in : rc2;
-  };
-  float* st = (float*)cols[c->col_state];
-  int64_t* ac_i = (int64_t*)cols[c->col_action];
-  float* ac_f = (float*)cols[c->col_action];
-  float* rw = (float*)cols[c->col_reward];
-  float* ns = (float*)cols[c->col_next];
-  uint8_t* dn = (uint8_t*)cols[c->col_done];
-  bool persistent = c->persist != nullptr;
-  if (persistent) {
+  if (rc_in == JH_OK)
+    for (int q = 0; q < 2; ++q)
+      if (c->ride_bytes[q] > 0) { xs[k] = c->ride_src[q]; xd[k] = c->ride_dst[q]; xb[k] = c->ride_bytes[q]; ++k; }
+  const int rc2 = jh_store_stage_commit_gated(c->store, k, xs, xd, xb, wait_flag, wait_val, st);
+  if (r.cap_slab) (void)jh_ctx_slab_release(c->ctx, r.cap_slab, st);
+  r.cap_slab = nullptr;
+  return rc_in ? rc_in : rc2;
+}
+
+static int run_prepare(jh_collector* c, int T, hipStream_t st) {
+  RunState& r = run_state(c);
+  const int W = c->W, A = c->A;
+  r = RunState();
+  r.T = T;
+  r.n = (int64_t)W * T;
+  r.cap = c->cap_v && c->cap_rows == r.n;
+  r.steps = collector_steps(c, T);
+  int rc = jh_store_stage_begin(c->store, r.n, r.cols);
+  if (rc) return rc;
+  // captured block in pinned, device-mapped memory: [h0 n*A | h1 n*A (continuous) | value n | next_value n]
+  if (r.cap) {
+    const size_t fl = (size_t)r.n * A * (c->cont ? 2 : 1) + 2 * (size_t)r.n;
+    rc = jh_ctx_slab(c->ctx, sizeof(float) * fl, &r.cap_slab);
+    if (rc) { (void)jh_store_stage_commit(c->store, st); return rc; }
+    r.ch0 = (float*)r.cap_slab->host;
+    r.ch1 = c->cont ? r.ch0 + (size_t)r.n * A : nullptr;
+    r.cv = r.ch0 + (size_t)r.n * A * (c->cont ? 2 : 1);
+    r.cnv = r.cv + r.n;
+  }
+  r.persistent = c->persist != nullptr;
+  if (r.persistent) {
     const int pre = c->prelaunched_T;
     c->prelaunched_T = 0;
-    if (pre != steps || jh_persist_gave_up(c->persist)) {  // nothing prelaunched, another length, or it timed out waiting: launch now
-      if (pre && !jh_persist_gave_up(c->persist)) {        // a live kernel of another length: stop it first
+    if (pre != r.steps || jh_persist_gave_up(c->persist)) {  // nothing prelaunched, another length, or it timed out waiting: launch now
+      if (pre && !jh_persist_gave_up(c->persist)) {          // a live kernel of another length: stop it first
         jh_persist_abort(c->persist);
-        JH_HIP(hipStreamSynchronize(jh_s(stream)));
+        (void)hipStreamSynchronize(st);
       }
-      rc = jh_persist_begin(c->persist, W, steps, jh_s(stream));
-      if (rc) persistent = false;
+      rc = jh_persist_begin(c->persist, W, r.steps, st);
+      if (rc) r.persistent = false;
     }
   }
+  r.active = true;
+  return JH_OK;
+}
+
+// The host loop.  Returns the first error; the caller commits either way.
+static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
+  RunState& r = run_state(c);
+  const int W = c->W, S = c->S, A = c->A, T = r.T, steps = r.steps;
+  const bool cap = r.cap;
+  jh_stream stream = (jh_stream)stream_h;
+  int rc = JH_OK;
+  float *ch0 = r.ch0, *ch1 = r.ch1, *cv = r.cv, *cnv = r.cnv;
+  float* st = (float*)r.cols[c->col_state];
+  int64_t* ac_i = (int64_t*)r.cols[c->col_action];
+  float* ac_f = (float*)r.cols[c->col_action];
+  float* rw = (float*)r.cols[c->col_reward];
+  float* ns = (float*)r.cols[c->col_next];
+  uint8_t* dn = (uint8_t*)r.cols[c->col_done];
+  bool persistent = r.persistent;
   const int no = c->persist ? jh_persist_heads(c->persist) : 0;  // policy heads + value
   const int n_pol = c->cont ? 2 * A : A;
   std::vector<float> val(W), lg((size_t)W * 2 * A);
@@ -226,9 +267,12 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
     if (persistent) {
       const unsigned tag = jh_persist_publish(c->persist, W, c->obs.data());
       rc = jh_persist_collect(c->persist, W, tag, c->heads.data());
-      if (rc) {  // the kernel gave up (it exits by itself): finish this rollout with per-step launches
+      if (rc) {  // the kernel gave up (it exits by itself)
         jh_persist_abort(c->persist);
-        JH_HIP(hipStreamSynchronize(jh_s(stream)));
+        if (r.early)  // the commit launch and the learner are already queued behind it on this stream: no per-step launches possible
+          return jh_fail(JH_ERR_STATE, "the persistent acting kernel gave up at step %d of a run whose commit was enqueued ahead (jh_collector_begin): "
+                                       "no observations for ~0.2 s; use jh_collector_run for environments that may stall", t);
+        JH_HIP(hipStreamSynchronize(stream_h));  // finish this rollout with per-step launches
         persistent = false;
       } else {
         for (int w = 0; w < W; ++w) {
@@ -244,10 +288,11 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
       }
     }
     if (!persistent) {
+      if (r.early) return jh_fail(JH_ERR_STATE, "jh_collector_begin needs the persistent acting kernel (W <= 16, W * S <= 128, JH_COLLECT_PERSISTENT != 0)");
       // (the per-step launch samples even for the value-only query; its actions are not used)
       rc = c->cont ? jh_pponet_act_continuous(c->net, W, c->obs.data(), c->act_f.data(), lg.data(), lg.data() + (size_t)W * A, val.data(), training, stream)
                    : jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act_i.data(), lg.data(), val.data(), training, stream);
-      if (rc) return finish(rc);
+      if (rc) return rc;
       if (extra) c->net->act_ctr -= 1;  // the value-only query must not consume a sampling step: same action stream with and without capture
       if (c->cont) {  // [W][A] mu | [W][A] log_std  ->  per-row [mu A | log_std A] like the persistent path
         std::vector<float> tmp(lg);
@@ -278,7 +323,7 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
     if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
     rc = c->cart ? jh_cartpole_step(c->cart, c->act_i.data(), c->next_obs.data(), c->reward.data(), c->done.data())
                  : jh_control_step(c->ctl, c->act_f.data(), c->next_obs.data(), c->reward.data(), c->done.data());
-    if (rc) return finish(rc);
+    if (rc) return rc;
     for (int w = 0; w < W; ++w) {
       const size_t row = (size_t)w * T + t;  // worker-major: w0 t0..tT-1, w1 ...  (distributed_manager.py:30)
       memcpy(st + S * row, c->obs.data() + (size_t)S * w, sizeof(float) * S);
@@ -294,10 +339,74 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
     c->steps += 1;
   }
   if (persistent && getenv("JH_PERSIST_DEBUG") && (c->steps % (64 * T)) == 0) jh_persist_dump_debug(c->persist, T);
+  return JH_OK;
+}
+
+// Collect T steps from every env and append the W*T transitions (worker-major) to the store.
+JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_stream stream) {
+  JH_ARG(c != nullptr && T > 0);
+  if (run_state(c).active) return jh_fail(JH_ERR_STATE, "jh_collector_run inside a jh_collector_begin / jh_collector_loop pair");
+  int rc = run_prepare(c, T, jh_s(stream));
+  if (rc) return rc;
+  rc = run_loop(c, training, jh_s(stream));
   const auto tc = std::chrono::steady_clock::now();
-  rc = finish(JH_OK);
+  rc = run_commit(c, run_state(c), rc, nullptr, 0, jh_s(stream));
   c->t_commit += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
   c->runs += 1;
+  run_state(c).active = false;
+  return rc;
+}
+
+// jh_collector_run in two halves with the commit launch enqueued AHEAD of the host loop:
+//   jh_collector_begin  staging slabs, the acting kernel (unless prelaunched), then the commit launch -- gated: its workgroups wait
+//                       (bounded) for a flag word in device-mapped pinned memory.  The store's row count advances here, so the caller
+//                       may enqueue the consumer of the rollout (the learner's graph) right away, behind the commit, on `stream`.
+//   jh_collector_loop   the T-step host loop; its last act is the release store of the flag.
+// Needs the persistent acting kernel and a commit small enough for the one-launch form (<= 512 KB of rows).  A stalled environment
+// (no observations for ~0.2 s) is an ERROR here -- work is already queued behind the acting kernel, so the per-step fallback of
+// jh_collector_run does not exist; the flag is still released so that the stream drains.
+JH_EXPORT int jh_collector_begin(jh_collector* c, int32_t T, jh_stream stream) {
+  JH_ARG(c != nullptr && T > 0);
+  if (run_state(c).active) return jh_fail(JH_ERR_STATE, "jh_collector_begin twice without jh_collector_loop");
+  if (!c->persist) return jh_fail(JH_ERR_STATE, "jh_collector_begin needs the persistent acting kernel (W <= 16, W * S <= 128, JH_COLLECT_PERSISTENT != 0)");
+  if (!c->gate_h) {
+    JH_HIP(hipHostMalloc((void**)&c->gate_h, 64, hipHostMallocMapped));
+    JH_HIP(hipHostGetDevicePointer((void**)&c->gate_d, c->gate_h, 0));
+    *c->gate_h = 0;
+  }
+  int rc = run_prepare(c, T, jh_s(stream));
+  if (rc) return rc;
+  RunState& r = run_state(c);
+  if (!r.persistent || !jh_store_commit_is_one_launch(c->store, r.n)) {  // behave like jh_collector_run from here (commit at the end of the loop)
+    r.early = false;
+    return JH_OK;
+  }
+  r.early = true;
+  c->gate_seq += 1;
+  const auto tc = std::chrono::steady_clock::now();
+  rc = run_commit(c, r, JH_OK, c->gate_d, c->gate_seq, jh_s(stream));
+  c->t_commit += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+  if (rc) {  // nothing is waiting on the flag that will not get it below
+    __atomic_store_n(c->gate_h, c->gate_seq, __ATOMIC_RELEASE);
+    r.active = false;
+  }
+  return rc;
+}
+
+JH_EXPORT int jh_collector_loop(jh_collector* c, int32_t training, jh_stream stream) {
+  JH_ARG(c != nullptr);
+  RunState& r = run_state(c);
+  if (!r.active) return jh_fail(JH_ERR_STATE, "jh_collector_loop without jh_collector_begin");
+  int rc = run_loop(c, training, jh_s(stream));
+  if (r.early) {
+    __atomic_store_n(c->gate_h, c->gate_seq, __ATOMIC_RELEASE);  // every row, captured value and ride-along source is written: let the commit launch go
+  } else {
+    const auto tc = std::chrono::steady_clock::now();
+    rc = run_commit(c, r, rc, nullptr, 0, jh_s(stream));
+    c->t_commit += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+  }
+  c->runs += 1;
+  r.active = false;
   return rc;
 }
 

@@ -57,8 +57,26 @@ struct CopyCols {
   char* dst[kCopyJobs];       // ring position of the first row
   char* dst_wrap[kCopyJobs];  // column base (rows behind the ring's wrap)
   int64_t first[kCopyJobs], total[kCopyJobs];  // bytes before the wrap / in all
+  const unsigned* gate;  // optional flag word (device-mapped pinned memory): every workgroup waits until it holds gate_val
+  unsigned gate_val;
 };
 __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
+  if (a.gate) {
+    // A launch enqueued BEFORE its sources are complete (jh_collector_begin): lane 0 polls the host's release store (bounded: ~2 s;
+    // the launch sits behind the acting kernel in stream order, so in practice the flag arrives within a microsecond or two), then
+    // the sources -- fine-grained host memory, never cached on the device -- are read.
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+      int ok = 0;
+      for (long spin = 0; spin < 4000000L; ++spin) {
+        if (__hip_atomic_load(a.gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == a.gate_val) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      s_ok = ok;
+    }
+    __syncthreads();
+    (void)s_ok;  // on a timeout the copy still runs (the stream must drain); the host reports the failed run
+  }
   const int c = blockIdx.y;
   const char* src = a.src[c];
   char* d0 = a.dst[c];
@@ -77,9 +95,10 @@ __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
 
 // `cols`: device-visible sources.  Advances the ring like jh_store_append.  n_extra plain copies (x_src -> x_dst, x_bytes) ride along.
 static int store_append_kernel(jh_store* s, int64_t n, const void* const* cols, hipStream_t st, int n_extra = 0, const void* const* x_src = nullptr,
-                               void* const* x_dst = nullptr, const int64_t* x_bytes = nullptr) {
+                               void* const* x_dst = nullptr, const int64_t* x_bytes = nullptr, const unsigned* gate = nullptr, unsigned gate_val = 0) {
   const int64_t first = s->capacity - s->index < n ? s->capacity - s->index : n;
   CopyCols a{};
+  a.gate = gate; a.gate_val = gate_val;
   size_t most = 0;
   for (int e = 0; e < n_extra; ++e) {
     const int c = s->n_cols + e;
@@ -130,21 +149,40 @@ JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) { return jh_s
 // The commit with n_extra (<= 4) plain device-visible -> device copies in the SAME launch (internal: the collector's captured
 // heads / values land next to the rollout rows without further launches or SDMA copies).
 int jh_store_stage_commit_extra(jh_store* s, int n_extra, const void* const* x_src, void* const* x_dst, const int64_t* x_bytes, hipStream_t st) {
+  return jh_store_stage_commit_gated(s, n_extra, x_src, x_dst, x_bytes, nullptr, 0, st);
+}
+
+static size_t store_kernel_commit_max() {
+  static const size_t v = getenv("JH_STORE_KERNEL_COMMIT_MAX") ? (size_t)atoll(getenv("JH_STORE_KERNEL_COMMIT_MAX")) : ((size_t)512 << 10);
+  return v;
+}
+// Does a commit of n staged rows take the one-launch form (the only one that can be gated)?
+bool jh_store_commit_is_one_launch(const jh_store* s, int64_t n) {
+  size_t bytes = 0;
+  for (int c = 0; c < s->n_cols; ++c) bytes += s->row_bytes[c] * (size_t)n;
+  return s->n_cols <= 8 && bytes <= store_kernel_commit_max();
+}
+
+// ... and optionally gated: the launch waits for *gate == gate_val (device-mapped pinned word) before it reads its sources, so it can be
+// enqueued before the host has filled them.  Only the one-launch form can wait: bigger commits are refused when a gate is given.
+int jh_store_stage_commit_gated(jh_store* s, int n_extra, const void* const* x_src, void* const* x_dst, const int64_t* x_bytes, const unsigned* gate,
+                                unsigned gate_val, hipStream_t st) {
   JH_ARG(s != nullptr && n_extra >= 0 && s->n_cols + n_extra <= kCopyJobs);
   if (!s->staged) return jh_fail(JH_ERR_STATE, "jh_store_stage_commit without begin");
   const int64_t n = s->staged_n;
   size_t bytes = 0;
   for (int c = 0; c < s->n_cols; ++c) bytes += s->row_bytes[c] * (size_t)n;
-  static const size_t kKernelCommitMax = getenv("JH_STORE_KERNEL_COMMIT_MAX") ? (size_t)atoll(getenv("JH_STORE_KERNEL_COMMIT_MAX")) : ((size_t)512 << 10);
+  const size_t kKernelCommitMax = store_kernel_commit_max();
   if (s->n_cols <= 8 && bytes <= kKernelCommitMax) {
     // small commits (a PPO rollout: 46 KB; Rainbow's 4 deferred rows: 226 KB): one kernel reads the slab in place
     const void* src[8];
     for (int c = 0; c < s->n_cols; ++c) src[c] = (const char*)s->staged->dev + s->staged_off[c];
-    int rc = store_append_kernel(s, n, src, st, n_extra, x_src, x_dst, x_bytes);
+    int rc = store_append_kernel(s, n, src, st, n_extra, x_src, x_dst, x_bytes, gate, gate_val);
     int rc2 = jh_ctx_slab_release(s->ctx, s->staged, st);
     s->staged = nullptr;
     return rc ? rc : rc2;
   }
+  if (gate) return jh_fail(JH_ERR_ARG, "a gated commit needs the one-launch form (<= %zu bytes of rows, <= 8 columns)", kKernelCommitMax);
   const int64_t first = s->capacity - s->index < n ? s->capacity - s->index : n;  // rows before the wrap
   for (int c = 0; c < s->n_cols; ++c) {
     const size_t rb = s->row_bytes[c];

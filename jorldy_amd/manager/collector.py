@@ -138,6 +138,26 @@ class NativeCollector:
             self.agent._captured = n_rows  # the coming learn() takes the heads / values of these rows as delivered (no no-grad passes)
         return None, 1.0
 
+    def begin(self, step=1):
+        """First half of run(step) with the commit launch enqueued AHEAD of the host loop (jh_collector_begin): after this call the
+        rollout's rows count as stored, and the learner may enqueue its launches (agent.process_begin) -- they wait on the stream behind
+        the acting kernel and the gated commit.  Then loop(), then agent.process_end():
+
+            collector.begin(T); agent.process_begin(step); collector.loop(); result = agent.process_end()
+
+        A stalled env (no observations for ~0.2 s) raises here instead of falling back to per-step launches (see the C header)."""
+        n_rows = self.env.W * step
+        self._bind(n_rows)
+        L.check(self.lib.jh_collector_begin(self.h, int(step), L.stream_ptr()))
+        if self._cap_key is not None:
+            self.agent._captured = n_rows
+        self.agent._ride_done = True
+        self._stream = L.stream_ptr()
+
+    def loop(self):
+        L.check(self.lib.jh_collector_loop(self.h, 1, self._stream))
+        return None, 1.0
+
     def arm_prelaunch(self, step):
         """Have the coming `agent.process` enqueue the persistent acting kernel of the NEXT run(step) right behind learn()'s launches
         (jh_collector_prelaunch): the kernel's launch and start-up leave the host's critical path between learn() and the rollout.

@@ -547,13 +547,14 @@ def test_native_collector_matches_python_collector_layout():
 
 
 @pytest.mark.parametrize("cont", [False, True])
-@pytest.mark.parametrize("persistent", [True, False])
-def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persistent, monkeypatch):
+@pytest.mark.parametrize("persistent,early", [(True, False), (False, False), (True, True)])
+def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persistent, early, monkeypatch):
     """Acting-time capture (jh_collector_set_capture): the raw heads / V(s) / V(s') the acting kernel computed while collecting
     replace the two no-grad passes at the start of PPO.learn (ppo.py:83-94).  Same weights, same inputs: the captured numbers
     equal the learner's own pass up to fp32 summation order, next_value == V(next_state) wherever done = 0, and three
     iterations of collect + learn (with the pre-drawn index lists and the pre-launched acting kernel) give the same losses
-    (1e-5) as the capture-free path."""
+    (1e-5) as the capture-free path.  early: the commit launch and the learner's launches are enqueued BEFORE the rollout's host
+    loop (NativeCollector.begin / agent.process_begin / loop / process_end; the commit is gated by a flag the loop sets last)."""
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
     from jorldy_amd.manager import NativeCollector
@@ -574,6 +575,16 @@ def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persiste
         assert col.capture == capture
         out = []
         for it in range(4):
+            split = early and capture and it > 0
+            if split:
+                col.begin(T)
+                agent.process_begin(T * (it + 1))
+                col.loop()
+                if it < 3:
+                    col.arm_prelaunch(T)
+                out.append(agent.process_end())
+                assert agent._captured == 0
+                continue
             col.run(T)
             if capture and it == 0:
                 torch.cuda.synchronize()
