@@ -431,12 +431,16 @@ def main():
     step = 0
 
     prelaunch = hasattr(collector, "arm_prelaunch") and os.environ.get("JH_PRELAUNCH", "1") == "1"
-    early = hasattr(collector, "begin") and agent.backend == "native" and os.environ.get("JH_EARLY_COMMIT", "1") == "1"
+    # JH_EARLY_COMMIT=1: NativeCollector.begin / loop with the commit launch and the learner's launches enqueued AHEAD of the rollout's host
+    # loop.  Measured (tools/probes/ab_multi.sh, 3 alternating pairs): the GPU-side gaps all but vanish (19 us per iteration against 114),
+    # but the host work that used to sit at the rollout's END (commit + graph launch, ~45 us with the GPU idle) now sits at its START, where
+    # the GPU is just as idle -- 1.27-1.30 ms per step against 1.23-1.27: off by default
+    early = hasattr(collector, "begin") and agent.backend == "native" and os.environ.get("JH_EARLY_COMMIT", "0") == "1"
 
     def one_iteration(last=False):
         """last: no acting kernel is enqueued ahead for an iteration that does not follow (the fences below would wait for it)."""
         nonlocal step
-        if early:
+        if early and agent.early_ready():
             # the commit launch and the learner's launches are enqueued BEFORE the rollout's host loop (they wait on the stream behind the
             # acting kernel / the gated commit): the learner starts the instant the rollout ends
             collector.begin(T)

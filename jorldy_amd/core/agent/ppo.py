@@ -371,7 +371,14 @@ class PPO(BaseAgent):
         self._learn_launch()
         return self._learn_finish()
 
-    def _learn_launch(self):
+    def early_ready(self):
+        """Is the coming learn() a pure enqueue (its whole-learn graph captured, index lists drawn ahead)?  Then a collector may take
+        the begin / process_begin / loop / process_end form; before that, process() (capturing a graph synchronises the device, which
+        must not happen while a rollout's acting kernel is waiting for this thread's observations)."""
+        st = self._static
+        return bool(st is not None and st["idx_ready"] and ("one", True) in getattr(self, "_graphs", {}) and self._predraw is not None and self._predraw.valid)
+
+    def _learn_launch(self, allow_capture=True):
         """Enqueue one learn() (everything up to and including the launches); `_learn_finish` does the host work behind them and reads
         the statistics.  Split so that a collector can enqueue the learner BEFORE its rollout's host loop (NativeCollector.begin / loop:
         the launches wait on the stream behind the acting kernel and the gated commit, and start the instant the rollout ends)."""
@@ -415,7 +422,7 @@ class PPO(BaseAgent):
         warm = getattr(self, "_warm_keys", None)
         if warm is None:
             warm = self._warm_keys = set()
-        if graphable and key not in graphs and key in warm:
+        if graphable and allow_capture and key not in graphs and key in warm:
             try:
                 torch.cuda.synchronize()
                 if split:
@@ -508,7 +515,7 @@ class PPO(BaseAgent):
         self._begun = self.learn_stamp >= self.n_step
         if self._begun:
             self._lr_step = step
-            self._learn_launch()
+            self._learn_launch(allow_capture=False)  # a capture synchronises the device: not while the acting kernel waits for this thread
 
     def process_end(self):
         if not getattr(self, "_begun", False):
