@@ -658,6 +658,89 @@ __global__ void __launch_bounds__(256) jh_rowgather_f32_kernel(int B, int S, con
   out[i] = x[(idx ? idx[b] : (int64_t)b) * S + s];
 }
 
+// dW1[h][s] = sum_b dh1[b][h] x[idx[b]][s], db1[h] = sum_b dh1[b][h] for minibatches on the tiled path (B >= 1024): K = B is long, but
+// N = S (11 for Hopper) is a sliver -- on the 32 x 32 MFMA tile engine that was 0.2-0.6 % of the fp32 matrix peak (25 us at B = 2048) plus
+// a row-gather launch.  It is a column reduction of dh1 weighted by S broadcast values per row: HBM-bound on reading dh1 once.
+//   pass 1  grid (H / 64, slabs): 256 threads = 64 h x 4 row lanes; a slab's observation rows (gathered through idx) sit in LDS;
+//           every thread walks its rows with one coalesced dh1 load + S FMAs, the 4 row lanes combine through LDS -> partial[z][h][S + 1]
+//   pass 2  out[h][s] = sum_z partial[z][h][s] in slab order (deterministic)
+template <int SP>
+__global__ void __launch_bounds__(256) jh_ppo_dw1_partial_kernel(int B, int H, int S, int rows_per, const float* __restrict__ dh1, const float* __restrict__ x,
+                                                                 const int64_t* __restrict__ idx, float* __restrict__ partial) {
+  extern __shared__ float s_dyn[];
+  float* s_x = s_dyn;                       // [rows_per][SP]
+  float* s_acc = s_dyn + (size_t)rows_per * SP;  // [4][64][SP + 1]
+  const int hl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int h = blockIdx.x * 64 + hl;
+  const int z = blockIdx.y, b0 = z * rows_per;
+  int nb = B - b0;
+  if (nb > rows_per) nb = rows_per;
+  for (int i = threadIdx.x; i < nb * SP; i += 256) {
+    const int r = i / SP, q = i - r * SP;
+    s_x[i] = q < S ? x[(idx ? idx[b0 + r] : (int64_t)(b0 + r)) * S + q] : 0.f;
+  }
+  __syncthreads();
+  float acc[SP + 1];
+#pragma unroll
+  for (int q = 0; q <= SP; ++q) acc[q] = 0.f;
+  if (h < H) {
+    for (int r = rl; r < nb; r += 4) {
+      const float g = dh1[(size_t)(b0 + r) * H + h];
+      const float* xr = s_x + (size_t)r * SP;
+#pragma unroll
+      for (int q = 0; q < SP; ++q) acc[q] = fmaf(g, xr[q], acc[q]);
+      acc[SP] += g;
+    }
+  }
+  float* mine = s_acc + ((size_t)rl * 64 + hl) * (SP + 1);
+#pragma unroll
+  for (int q = 0; q <= SP; ++q) mine[q] = acc[q];
+  __syncthreads();
+  if (rl == 0 && h < H) {
+    float* out = partial + ((size_t)z * H + h) * (S + 1);
+#pragma unroll
+    for (int q = 0; q <= SP; ++q) {
+      if (q < S || q == SP) {
+        const float v = ((s_acc[((size_t)0 * 64 + hl) * (SP + 1) + q] + s_acc[((size_t)1 * 64 + hl) * (SP + 1) + q]) + s_acc[((size_t)2 * 64 + hl) * (SP + 1) + q]) +
+                        s_acc[((size_t)3 * 64 + hl) * (SP + 1) + q];
+        out[q == SP ? S : q] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) jh_ppo_dw1_combine_kernel(int H, int S, int slabs, const float* __restrict__ partial, float* __restrict__ dW1, float* __restrict__ db1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * (S + 1)) return;
+  float v = 0.f;
+  for (int z = 0; z < slabs; ++z) v += partial[(size_t)z * H * (S + 1) + i];
+  const int h = i / (S + 1), q = i - h * (S + 1);
+  if (q < S) dW1[(size_t)h * S + q] = v;
+  else db1[h] = v;
+}
+
+static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
+  const int H = n->H, S = n->S;
+  int slabs = (B + 63) / 64;
+  if (slabs > 64) slabs = 64;  // part_w1 holds 64 slabs of H * (S + 1) floats
+  const int rows_per = (B + slabs - 1) / slabs;
+  slabs = (B + rows_per - 1) / rows_per;
+  const dim3 grid((unsigned)((H + 63) / 64), (unsigned)slabs);
+  const int sp = (S + 3) / 4 * 4;
+  const size_t lds = sizeof(float) * ((size_t)rows_per * sp + 4 * 64 * (size_t)(sp + 1));
+  if (lds > 60 * 1024) return jh_fail(JH_ERR_ARG, "dW1 reduction: %zu bytes of LDS for %d rows per slab", lds, rows_per);
+  const double flops = 2.0 * B * (double)H * (S + 1);
+  if (sp == 4) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<4>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
+  else if (sp == 8) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<8>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
+  else if (sp == 12) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<12>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
+  else if (sp == 16) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<16>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
+  else return jh_fail(JH_ERR_ARG, "dW1 reduction: observation width %d", S);
+  JH_LAUNCH_CHECK();
+  JH_LAUNCH(jh_ppo_dw1_combine_kernel, dim3((unsigned)((H * (S + 1) + 255) / 256)), dim3(256), 0, st, H, S, slabs, (const float*)n->part_w1, n->grads + n->o_w1, n->grads + n->o_b1);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
 static int pponet_l1(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
   const int64_t bh = (int64_t)B * n->H;
   JH_LAUNCH(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, n->H, d_x, d_idx,
@@ -751,6 +834,8 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
     rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd", g, ng, st);
     if (rc) return rc;
+    static const bool kDw1Gemm = getenv("JH_PPO_DW1_GEMM") && atoi(getenv("JH_PPO_DW1_GEMM")) != 0;  // A/B: round 2's tile-engine form
+    if (!kDw1Gemm && S <= 16) return pponet_dw1_reduce(n, B, d_x, d_idx, st);
     JH_LAUNCH(jh_rowgather_f32_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, st, B, S, d_x, d_idx, n->xg);
     JH_LAUNCH_CHECK();
     g[0] = mk_gemm(H, S, B, op_dense(OP_XCONT, n->dh1, H), op_dense(OP_XCONT, n->xg, S), n->grads + n->o_w1, S, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b1);

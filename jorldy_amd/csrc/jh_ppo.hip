@@ -294,6 +294,7 @@ struct PpoArgs {
   float* partial;
   float* stats;
   int nb;
+  const float* totals;  // optional [6]: the partials already reduced (jh_ppo_totals_kernel) -- many blocks: every block re-reducing all nb partials is nb^2 reads
   // optional: the heads arrive as per-column-tile PARTIAL sums straight from the encoder GEMM epilogue
   // (hpart[tile][row][8], flat output order: head0[A], head1[A] (continuous), value); the fused kernel
   // sums them in tile order into LDS, which saves the separate heads kernel of the forward pass
@@ -542,12 +543,14 @@ __global__ void __launch_bounds__(256) jh_ppo_fwd_kernel(PpoArgs<CONT> a) {
   }
 }
 
-template <bool CONT>
-__global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
-  __shared__ float s_red[16];
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = -3.4e38f, t5 = 3.4e38f;
-  for (int b = threadIdx.x; b < a.nb; b += 256) {
-    const float* p = a.partial + (size_t)b * PPO_NPART;
+// The per-block partials -> six totals, in the order every block of the backward pass would reduce them itself (same strided loop,
+// same block reduction: bit-identical).  From a few dozen blocks on, nb blocks x nb partials of re-reads cost more than this launch:
+// B = 1M rows = 4096 blocks re-read 400 MB of partials for a 44 MB problem (round 2: 14 % of the HBM roofline).
+__device__ __forceinline__ void ppo_reduce_partials(const float* __restrict__ partial, int nb, float* s_red, float& t0, float& t1, float& t2, float& t3,
+                                                    float& t4, float& t5) {
+  t0 = t1 = t2 = t3 = 0.f; t4 = -3.4e38f; t5 = 3.4e38f;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    const float* p = partial + (size_t)b * PPO_NPART;
     t0 += p[0]; t1 += p[1]; t2 += p[2]; t3 += p[3];
     t4 = fmaxf(t4, p[4]); t5 = fminf(t5, p[5]);
   }
@@ -557,6 +560,24 @@ __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
   t3 = jh_block_reduce(t3, s_red, JhAdd(), 0.f);
   t4 = jh_block_reduce(t4, s_red, JhMax(), -3.4e38f);
   t5 = jh_block_reduce(t5, s_red, JhMin(), 3.4e38f);
+}
+
+__global__ void __launch_bounds__(256) jh_ppo_totals_kernel(const float* __restrict__ partial, int nb, float* __restrict__ totals) {
+  __shared__ float s_red[16];
+  float t0, t1, t2, t3, t4, t5;
+  ppo_reduce_partials(partial, nb, s_red, t0, t1, t2, t3, t4, t5);
+  if (threadIdx.x == 0) { totals[0] = t0; totals[1] = t1; totals[2] = t2; totals[3] = t3; totals[4] = t4; totals[5] = t5; }
+}
+
+template <bool CONT>
+__global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
+  __shared__ float s_red[16];
+  float t0, t1, t2, t3, t4, t5;
+  if (a.totals) {
+    t0 = a.totals[0]; t1 = a.totals[1]; t2 = a.totals[2]; t3 = a.totals[3]; t4 = a.totals[4]; t5 = a.totals[5];
+  } else {
+    ppo_reduce_partials(a.partial, a.nb, s_red, t0, t1, t2, t3, t4, t5);
+  }
   float w1, w2;
   ppo_finish_stats(t0, t1, t2, t3, t4, t5, a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
                    (blockIdx.x == 0 && threadIdx.x == 0) ? a.stats : nullptr);
@@ -584,11 +605,17 @@ static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
   }
   a.nb = (a.B + 255) / 256;
   void* scratch = nullptr;
-  int rc = jh_ctx_scratch(ctx, sizeof(float) * PPO_NPART * (size_t)a.nb, &scratch);
+  int rc = jh_ctx_scratch(ctx, sizeof(float) * (PPO_NPART * (size_t)a.nb + 8), &scratch);
   if (rc) return rc;
   a.partial = (float*)scratch;
   JH_LAUNCH(jh_ppo_fwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
   JH_LAUNCH_CHECK();
+  if (a.nb > 64) {  // a third launch (~5 us) beats nb^2 partial reads from here on
+    float* totals = a.partial + PPO_NPART * (size_t)a.nb;
+    JH_LAUNCH(jh_ppo_totals_kernel, dim3(1), dim3(256), 0, st, a.partial, a.nb, totals);
+    JH_LAUNCH_CHECK();
+    a.totals = totals;
+  }
   JH_LAUNCH(jh_ppo_bwd_kernel<CONT>, dim3(a.nb), dim3(256), 0, st, a);
   JH_LAUNCH_CHECK();
   return JH_OK;

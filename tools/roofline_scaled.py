@@ -53,6 +53,8 @@ def main():
         kernels = kernel if isinstance(kernel, (list, tuple)) else [kernel]
         n, ms = 0, 0.0
         for k in kernels:
+            if k not in prof:
+                continue  # e.g. the totals kernel of the PPO loss only exists beyond 64 blocks
             n = max(n, prof[k][0])
             ms += prof[k][1]
         avg_s = ms / n * 1e-3
@@ -78,7 +80,7 @@ def main():
         z, vp = rnd(B, A), rnd(B, 1)
         act = torch.randint(0, A, (B, 1), device=dev, generator=g).float()
         adv, ret, vold, lpo = rnd(B, 1), rnd(B, 1), rnd(B, 1), -torch.rand(B, 1, device=dev, generator=g)
-        case(f"ppo_loss_disc_B{B}", ["jh_ppo_fwd_kernel<CONT>", "jh_ppo_bwd_kernel<CONT>"], "hbm", 44.0 * B + 32.0 * B,
+        case(f"ppo_loss_disc_B{B}", ["jh_ppo_fwd_kernel<CONT>", "jh_ppo_totals_kernel", "jh_ppo_bwd_kernel<CONT>"], "hbm", 44.0 * B + 32.0 * B,
              lambda: ops.ppo_loss_discrete(z, vp, None, act, adv, ret, vold, lpo, 0.1, 1.0, 0.01), "two-pass path: 44 B + the 8 reads of the recompute pass")
     # ---- gather: Atari-shaped uint8 rows and CartPole rows ------------------------------------------
     N = 50000
