@@ -82,6 +82,9 @@ void jh_pinned_free(void* host);
 int jh_prof_enable(int32_t on);
 int jh_prof_report(char* buf, int64_t cap);
 int jh_prof_calibrate(int32_t n, jh_stream stream); /* n empty event pairs -> "__event_pair_overhead" */
+/* Measurement aid: a streaming read of exactly `bytes` device bytes with `width` (4 / 8 / 16) bytes per lane and access -- the
+ * known byte count the rocprofv3 HBM counters are calibrated against per access width (tools/pmc_calibrate.sh).              */
+int jh_calib_stream(jh_ctx* ctx, const void* d_src, int64_t bytes, int32_t width, float* d_out, jh_stream stream);
 
 /* ------------------------------------------------------------------ transition store
  * GPU-resident struct-of-arrays ring that replaces the list-of-dicts storage of

@@ -38,6 +38,7 @@ _PROTOS = {
     "jh_prof_enable": (C.c_int, [_i32]),
     "jh_prof_report": (C.c_int, [C.c_char_p, _i64]),
     "jh_prof_calibrate": (C.c_int, [_i32, _vp]),
+    "jh_calib_stream": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "jh_host_wait_marks": (C.c_int, [_vp, _vp, _i32, _f32, _f64]),
     "jh_host_wait_words": (C.c_int, [_vp, _vp, _i32, C.c_uint32, _f64]),
     "jh_np_legacy_shuffles": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),

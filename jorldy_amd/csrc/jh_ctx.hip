@@ -231,6 +231,33 @@ JH_EXPORT void jh_pinned_free(void* host) {
   if (host) (void)hipHostFree(host);
 }
 
+// ------------------------------------------------------------------------------ PMC calibration
+// A streaming read of exactly `bytes` bytes with a chosen access width per lane (4 / 8 / 16 bytes), summed into d_out so that
+// nothing is optimised away: the known byte count that rocprofv3's FETCH_SIZE / TCC_EA0_RDREQ* are calibrated against
+// (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own access pattern"; tools/pmc_calibrate.sh).
+template <typename V>
+__global__ void __launch_bounds__(256) jh_calib_stream_kernel(const V* __restrict__ src, int64_t n, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const V v = src[i];
+    const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(V) / 4); ++k) acc += f[k];
+  }
+  if (acc == 123.456f) out[0] = acc;  // never true for the calibration data; keeps the loads alive
+}
+
+JH_EXPORT int jh_calib_stream(jh_ctx* ctx, const void* d_src, int64_t bytes, int32_t width, float* d_out, jh_stream stream) {
+  JH_ARG(ctx && d_src && d_out && bytes > 0 && (width == 4 || width == 8 || width == 16) && bytes % width == 0);
+  const int64_t n = bytes / width;
+  const unsigned grid = 2048;
+  if (width == 4) JH_LAUNCH_NAMED("jh_calib_stream_kernel<4>", jh_calib_stream_kernel<float>, dim3(grid), dim3(256), 0, jh_s(stream), (const float*)d_src, n, d_out);
+  else if (width == 8) JH_LAUNCH_NAMED("jh_calib_stream_kernel<8>", jh_calib_stream_kernel<float2>, dim3(grid), dim3(256), 0, jh_s(stream), (const float2*)d_src, n, d_out);
+  else JH_LAUNCH_NAMED("jh_calib_stream_kernel<16>", jh_calib_stream_kernel<float4>, dim3(grid), dim3(256), 0, jh_s(stream), (const float4*)d_src, n, d_out);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
 // ------------------------------------------------------------------------------ kernel profiler
 #include <map>
 bool g_jh_prof_on = false;
