@@ -42,7 +42,6 @@ struct PersistArgs {
   unsigned long long* dbg;             // optional [T][8]: per-step timestamps of workgroup 0 (diagnostics)
   int period;                          // spacing of the polls in flight, wall_clock64 ticks (10 ns)
   unsigned long long* mbox;            // device memory [64] granules: relay of the observations (null: every workgroup polls the host)
-  int head_mfma;                       // 1: head partials on the MFMA even for <= 4 outputs (JH_PERSIST_HEAD_MFMA=1: round 2's form, for A/B)
 };
 
 // One poll: lanes 0..n16-1 of the calling wave each fetch 16 bytes (two granules) of the observation area
@@ -230,44 +229,6 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
         v += s_b2[r];
         hv[i] = v > 0.f ? v : 0.f;
       }
-      if (p.n_out <= 4 && !p.head_mfma) {
-        // <= 4 head outputs (discrete A <= 3 + value): the partials part[row][o] = sum_col h2[row][col] * Wh[o][n0 + col] are a sum over
-        // the 16 lanes r of one DPP row (lane = kq * 16 + r holds column r of rows kq * 4 + i): four row_ror adds per value put the total
-        // into EVERY lane of the row, so lane (kq, r) builds the 16-byte granule of env row kq * 4 + (r & 3) itself -- no LDS round trips,
-        // no second MFMA chain (the 16 x 16 x 16 product below costs ~0.3 us of dependent ds_read / MFMA latency for 3 useful columns)
-        float tot[4][4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          const float w = s_wh[o][r];  // 0 for o >= n_out
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float v = hv[i] * w;
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));  // row_ror:4
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false));  // row_ror:2
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));  // row_ror:1
-            tot[o][i] = v + (tile == 0 ? s_hb[o] : 0.f);
-          }
-        }
-        const int ii = r & 3, g = r >> 2, row = kq * 4 + ii;
-        if (g < p.G && row < p.W) {
-          const int o0 = 3 * g;  // G == 1 for n_out <= 3, 2 for n_out == 4: outputs o0 .. o0 + 2 (o0 + k < 4 always holds for k <= 3 - o0)
-          float ov[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            float x = 0.f;
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (o == o0 + k && i == ii) x = tot[o][i];
-            ov[k] = x;
-          }
-          const f32x4 gq = (f32x4){ov[0], ov[1], ov[2], __uint_as_float(tag)};
-          float4* dst = p.part + ((size_t)tile * p.G + g) * 16 + row;
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
-        }
-      } else {
       // h2 tile -> LDS in A-operand order; the head partials part[row][o] = sum_col h2[row][col] * Wh[o][n0 + col]
       // are one more 16x16x16 product on the MFMA (4 steps)
 #pragma unroll
@@ -298,7 +259,6 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
         // track asm stores: the s_nop keeps the data registers intact until the store has read them (CDNA guide §5.7)
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
       }
-      }  // n_out > 4
     }
     // no end-of-step barrier: s_x / s_acc alternate by step parity, s_h2 / s_out belong to wave 0
     if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 4] = wall_clock64(); p.dbg[(t - 1) * 8 + 5] = __builtin_readcyclecounter(); }
@@ -398,8 +358,6 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.period = depth > 1 ? period : 0;
   static const int relay = getenv("JH_PERSIST_RELAY") ? atoi(getenv("JH_PERSIST_RELAY")) : 1;
   a.mbox = relay ? p->mbox : nullptr;
-  static const int head_mfma = getenv("JH_PERSIST_HEAD_MFMA") ? atoi(getenv("JH_PERSIST_HEAD_MFMA")) : 0;
-  a.head_mfma = head_mfma;
   a.max_polls = 600000;  // x (>= 0.3 us per consumed poll) = >= 0.2 s without observations -> give up
   p->flag_h[0] = 0;
   const int nch = n->H / 64;
