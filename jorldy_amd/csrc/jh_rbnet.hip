@@ -776,10 +776,11 @@ JH_EXPORT int jh_rbnet_optim_step(jh_rbnet* n, int32_t optimizer, float max_norm
     JH_LAUNCH(jh_rb_gradnorm_kernel, dim3(256), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial);
     JH_LAUNCH_CHECK();
   }
+  static const unsigned kOptGrid = getenv("JH_RB_OPTIM_GRID") ? (unsigned)atoi(getenv("JH_RB_OPTIM_GRID")) : 512u;
   if (optimizer == 0) {
-    JH_LAUNCH(jh_rb_optim_kernel<0>, dim3(512), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
+    JH_LAUNCH(jh_rb_optim_kernel<0>, dim3(kOptGrid), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
   } else {
-    JH_LAUNCH(jh_rb_optim_kernel<1>, dim3(512), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
+    JH_LAUNCH(jh_rb_optim_kernel<1>, dim3(kOptGrid), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
   }
   JH_LAUNCH_CHECK();
   return JH_OK;
