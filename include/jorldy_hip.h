@@ -451,6 +451,10 @@ int jh_rbnet_adam_step(jh_rbnet* n, jh_stream stream);
 int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* d_a, int32_t lda, int32_t a_kcont, const float* d_b,
                    int32_t ldb, int32_t b_kcont, float* d_c, int32_t ldc, int32_t epi, const float* d_bias, const float* d_aux,
                    int32_t ldaux, float* d_rowsum, jh_stream stream);
+/* Test entry: n (<= 6) independent problems C_j [M][N] = A_j [M][K] B_j [N][K]^T as ONE grouped launch (the shape of the value
+ * networks' forward launches: online and target trunks side by side); d_a / d_b / d_c are host arrays of n device pointers.  */
+int jh_tgemm_dense_group(jh_ctx* ctx, int32_t n, int32_t M, int32_t N, int32_t K, const float* const* d_a, const float* const* d_b,
+                         float* const* d_c, jh_stream stream);
 
 /* ------------------------------------------------------------------ asynchronous actor -> learner staging
  * Replaces the async path's transport (run_mode.py:212-363 async_distributed_train: Ray actors -> manager

@@ -39,6 +39,132 @@ __device__ __noinline__ float4 op_fetch4_slow(Opnd o, int x, int k, int X, int K
   return r;
 }
 
+// Everything behind a tile's MFMA loop, shared by the register-staged and the LDS-DMA kernel: split-K hand-off (partials + ticket,
+// the last arriver sums them in split order), epilogue, stores.
+struct TileCtx {
+  int z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn;
+};
+template <int TM, int TN>
+__device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f32x4 (&acc)[TM][TN], float (&rs)[TM], bool want_rs, int* s_last_p) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  const int z = c.z, tiles = c.tiles, tile = c.tile, m0 = c.m0, n0 = c.n0, t = c.t, lane = c.lane, wid = c.wid, r = c.r, kq = c.kq, wm = c.wm, wn = c.wn;
+  int& s_last = *s_last_p;
+  auto epilogue = [&](float v, int m, int n) -> float {
+    if (g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU) v += g.bias[n];
+    if (g.epi == TEPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+    if (g.epi == TEPI_MASK) v = g.aux[(size_t)m * g.ldaux + n] > 0.f ? v : 0.f;
+    return v;
+  };
+
+  if (g.splitk > 1) {
+    // Split-K hand-off without __threadfence(): on a multi-XCD part an agent-scope fence writes back / invalidates
+    // the whole per-XCD L2, which costs more than the GEMM.  Partials are written and read with sc1 (agent-coherent)
+    // 16-byte accesses instead; s_waitcnt vmcnt(0) makes sure this wave's partial stores have completed before its
+    // workgroup takes a ticket.  Partials are stored fragment-major ([wave][tile i][tile j][lane][4]): a lane's
+    // accumulator registers are one 16-byte store, and the last workgroup to arrive rebuilds ITS accumulators as
+    // the sum over all splits in split order (deterministic) and falls through to the common epilogue.
+    constexpr int PSTRIDE = BM * BN + BM;
+    float* mine = g.ws + ((size_t)z * tiles + tile) * PSTRIDE;
+    const int frag0 = (wid * TM * TN * 64 + lane) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* dst = mine + frag0 + (i * TN + j) * 256;
+        // s_nop 1: a 16-byte store reads its data registers over several cycles and the compiler does not know that, so
+        // whatever it schedules next (the v_accvgpr_read of the next fragment into the same temporaries) must not land on them.
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+      }
+      if (want_rs && wn == 0 && kq == 0)
+        __hip_atomic_store(mine + BM * BN + wm * 16 * TM + 16 * i + r, rs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == (unsigned)g.splitk - 1;
+      if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* base = g.ws + (size_t)tile * PSTRIDE;
+    const size_t zstride = (size_t)tiles * PSTRIDE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int UNR = 4;  // UNR x TM x TN 16-byte loads in flight per lane
+    for (int sp = 0; sp < g.splitk; sp += UNR) {
+      // The loads of one round and their wait are ONE asm statement with early-clobber outputs: an asm load's destination
+      // counts as written when the statement ends, so with the wait in a later statement the compiler is free to copy or
+      // reuse the registers while the data is still in flight (seen as 32 wrong elements in one fragment, once in a few
+      // thousand launches, under the LDS-DMA kernel's register allocation).
+      f32x4 part[UNR][TM * TN];
+      const float* src[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) src[u] = base + (sp + u < g.splitk ? sp + u : g.splitk - 1) * zstride + frag0;  // clamped: uniform control flow
+      static_assert(UNR == 4, "the asm below names four address registers");
+#define JH_LD(d, a, off) "global_load_dwordx4 %" #d ", %" #a ", off offset:" #off " sc1\n\t"
+      if constexpr (TM * TN == 1) {
+        asm volatile(JH_LD(0, 4, 0) JH_LD(1, 5, 0) JH_LD(2, 6, 0) JH_LD(3, 7, 0) "s_waitcnt vmcnt(0)"
+                     : "=&v"(part[0][0]), "=&v"(part[1][0]), "=&v"(part[2][0]), "=&v"(part[3][0])
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3])
+                     : "memory");
+      } else if constexpr (TM * TN == 2) {
+        asm volatile(JH_LD(0, 8, 0) JH_LD(1, 8, 1024) JH_LD(2, 9, 0) JH_LD(3, 9, 1024) JH_LD(4, 10, 0) JH_LD(5, 10, 1024) JH_LD(6, 11, 0)
+                         JH_LD(7, 11, 1024) "s_waitcnt vmcnt(0)"
+                     : "=&v"(part[0][0]), "=&v"(part[0][1]), "=&v"(part[1][0]), "=&v"(part[1][1]), "=&v"(part[2][0]), "=&v"(part[2][1]),
+                       "=&v"(part[3][0]), "=&v"(part[3][1])
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3])
+                     : "memory");
+      } else {
+        static_assert(TM * TN == 4, "fragment counts 1, 2 and 4 are spelled out");
+        asm volatile(JH_LD(0, 16, 0) JH_LD(1, 16, 1024) JH_LD(2, 16, 2048) JH_LD(3, 16, 3072) JH_LD(4, 17, 0) JH_LD(5, 17, 1024)
+                         JH_LD(6, 17, 2048) JH_LD(7, 17, 3072) JH_LD(8, 18, 0) JH_LD(9, 18, 1024) JH_LD(10, 18, 2048) JH_LD(11, 18, 3072)
+                             JH_LD(12, 19, 0) JH_LD(13, 19, 1024) JH_LD(14, 19, 2048) JH_LD(15, 19, 3072) "s_waitcnt vmcnt(0)"
+                     : "=&v"(part[0][0]), "=&v"(part[0][1]), "=&v"(part[0][2]), "=&v"(part[0][3]), "=&v"(part[1][0]), "=&v"(part[1][1]),
+                       "=&v"(part[1][2]), "=&v"(part[1][3]), "=&v"(part[2][0]), "=&v"(part[2][1]), "=&v"(part[2][2]), "=&v"(part[2][3]),
+                       "=&v"(part[3][0]), "=&v"(part[3][1]), "=&v"(part[3][2]), "=&v"(part[3][3])
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3])
+                     : "memory");
+      }
+#undef JH_LD
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q)
+          if (sp + u < g.splitk) acc[q / TN][q % TN] += part[u][q];
+      }
+    }
+    if (want_rs && wn == 0 && kq == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v = 0.f;
+        for (int sp = 0; sp < g.splitk; ++sp)
+          v += __hip_atomic_load(base + sp * zstride + BM * BN + wm * 16 * TM + 16 * i + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rs[i] = v;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 16 * TN + 16 * j + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+        const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
+        if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(acc[i][j][q], m, n);
+      }
+    }
+    if (want_rs && wn == 0 && kq == 0) {
+      const int m = m0 + wm * 16 * TM + 16 * i + r;
+      if (m < g.M) g.rowsum[m] = rs[i];
+    }
+  }
+}
+
 // C[M][N] = sum_k A(m, k) B(k, n), workgroup tile (32 TM) x (32 TN), BK = 32, 4 waves as 2 x 2.
 // LDS tiles are [x][k] with a 36-float row stride: a lane's MFMA operands for 4 consecutive k are ONE
 // 16-byte LDS read (the k order inside a 16-wide block is permuted identically for A and B, which a
@@ -213,100 +339,152 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
     }
   }
 
-  auto epilogue = [&](float v, int m, int n) -> float {
-    if (g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU) v += g.bias[n];
-    if (g.epi == TEPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-    if (g.epi == TEPI_MASK) v = g.aux[(size_t)m * g.ldaux + n] > 0.f ? v : 0.f;
-    return v;
-  };
+  TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
+  tgemm_finish<TM, TN>(g, tc, acc, rs, want_rs, &s_last);
+}
 
-  if (g.splitk > 1) {
-    // Split-K hand-off without __threadfence(): on a multi-XCD part an agent-scope fence writes back / invalidates
-    // the whole per-XCD L2, which costs more than the GEMM.  Partials are written and read with sc1 (agent-coherent)
-    // 16-byte accesses instead; s_waitcnt vmcnt(0) makes sure this wave's partial stores have completed before its
-    // workgroup takes a ticket.  Partials are stored fragment-major ([wave][tile i][tile j][lane][4]): a lane's
-    // accumulator registers are one 16-byte store, and the last workgroup to arrive rebuilds ITS accumulators as
-    // the sum over all splits in split order (deterministic) and falls through to the common epilogue.
-    constexpr int PSTRIDE = BM * BN + BM;
-    float* mine = g.ws + ((size_t)z * tiles + tile) * PSTRIDE;
-    const int frag0 = (wid * TM * TN * 64 + lane) * 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float* dst = mine + frag0 + (i * TN + j) * 256;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
-      }
-      if (want_rs && wn == 0 && kq == 0)
-        __hip_atomic_store(mine + BM * BN + wm * 16 * TM + 16 * i + r, rs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) {
-      const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = old == (unsigned)g.splitk - 1;
-      if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const float* base = g.ws + (size_t)tile * PSTRIDE;
-    const size_t zstride = (size_t)tiles * PSTRIDE;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int UNR = 4;  // UNR x TM x TN 16-byte loads in flight per lane
-    for (int sp = 0; sp < g.splitk; sp += UNR) {
-      f32x4 part[UNR][TM * TN];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int spc = sp + u < g.splitk ? sp + u : g.splitk - 1;  // clamped: uniform control flow around the asm loads
-#pragma unroll
-        for (int q = 0; q < TM * TN; ++q) {
-          const float* src = base + spc * zstride + frag0 + q * 256;
-          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[u][q]) : "v"(src) : "memory");
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-        for (int q = 0; q < TM * TN; ++q) {
-          asm volatile("" : "+v"(part[u][q]));  // the values are only valid after the wait above
-          if (sp + u < g.splitk) acc[q / TN][q % TN] += part[u][q];
-        }
-      }
-    }
-    if (want_rs && wn == 0 && kq == 0) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float v = 0.f;
-        for (int sp = 0; sp < g.splitk; ++sp)
-          v += __hip_atomic_load(base + sp * zstride + BM * BN + wm * 16 * TM + 16 * i + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rs[i] = v;
-      }
-    }
-  }
+// ---- the same 64 x 64 tile with its operands DMA-ed straight from global memory into LDS (global_load_lds_dwordx4: 16 bytes per lane,
+// no VGPR destination, no ds_write issue slots) for launches whose operands are all k-contiguous fp32 (dense KCONT, NHWC im2col with
+// C % 4 == 0) and K % 32 == 0: the forward GEMMs of the value networks at B >= 64 rows, the PPO net's 2048-row forward.
+// Round 2's SQ counters (profiles/r02_apex_pmc_tgemm.json): these launches live on occupancy -- waves parked in s_waitcnt / barriers
+// 40-57 % of their cycles -- and every variant that took registers or LDS from the co-resident workgroups lost.  This one gives both
+// back: 16 staging VGPRs and 4 ds_write_b128 per chunk and wave are gone, and with them the wait for the registers to fill before the
+// LDS store; two 16 KB buffers (A | B, 32 k each) so the next chunk's DMA flies under this chunk's MFMAs.
+// LDS tiles are UNPADDED [row][32 k] (the DMA writes lane-linear: 64 lanes x 16 bytes = 8 rows); the 16-byte k-blocks of a row are
+// XOR-swizzled with (row & 7) on the GLOBAL side (lane p of an instruction fetches block (p & 7) ^ (row & 7) and lands in block p & 7),
+// which spreads a wave's ds_read_b128 of one k over all bank groups the way the 36-float row stride of the staged kernel does.
+// The DMA is inline asm on purpose: with __builtin_amdgcn_global_load_lds hipcc puts s_waitcnt vmcnt(0) in front of every s_barrier
+// while a DMA is pending, so the next chunk never flies under this chunk's MFMAs (measured at Ape-X B = 512: stream1_fwd 150 us with
+// the builtin, 121 us with the asm; conv2_fwd 111 -> 92, conv3_fwd 84 -> 66).  With asm the compiler does not count these loads at
+// all; the kernel waits for them itself (vmcnt(0) before the first issue, then vmcnt(TM + TN) = "all but the chunk just issued").
+__device__ __forceinline__ void tgemm_dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
 
+template <int TAG>
+__global__ void __launch_bounds__(256, 2) jh_tgemm_dma_kernel(TGemmBatch batch) {
+  constexpr int TM = 2, TN = 2, BM = 64, BN = 64, BK = 32;
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) float sB[2][BN * BK];
+  __shared__ int sTabA[kTabMax], sTabB[kTabMax];
+  __shared__ int s_last;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.p[i].wg_begin) pi = i;
+  const TGemm& g = batch.p[pi];
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int local = blockIdx.x - g.wg_begin;
+  const int z = local / tiles, tile = local - z * tiles;
+  const int tm_blk = tile / g.tiles_n, tn_blk = tile - tm_blk * g.tiles_n;
+  const int m0 = tm_blk * BM, n0 = tn_blk * BN;
+  const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, kq = lane >> 4, wm = wid & 1, wn = wid >> 1;
+  const int nchunks = g.K / BK, per = (nchunks + g.splitk - 1) / g.splitk;
+  const int kbeg = z * per * BK;
+  int kend = kbeg + per * BK;
+  if (kend > g.K) kend = g.K;
+  const bool a_conv = g.a.mode >= OP_NHWC_K, b_conv = g.b.mode >= OP_NHWC_K;
+  if (a_conv)
+    for (int i = t; i < kend - kbeg; i += 256) sTabA[i] = g.a.tap_tab[kbeg + i];
+  if (b_conv)
+    for (int i = t; i < kend - kbeg; i += 256) sTabB[i] = g.b.tap_tab[kbeg + i];
+  // piece (slot i of this lane): p = (i * 4 + wid) * 64 + lane in [0, 512): row p >> 3 of the tile, LDS k-block p & 7 <- global k-block (p & 7) ^ (row & 7)
+  const float* a_src[TM];
+  const float* b_src[TN];
+  int a_kb[TM], b_kb[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int p = (i * 4 + wid) * 64 + lane, row = p >> 3;
+    a_kb[i] = 4 * ((p & 7) ^ (row & 7));
+    const int x = m0 + row, xc = x < g.M ? x : g.M - 1;  // rows beyond M fetch a valid row: their results are never stored
+    a_src[i] = (const float*)g.a.p + (a_conv ? (size_t)g.a.pix_tab[xc] : (size_t)xc * g.a.ld + kbeg + a_kb[i]);
+  }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * 16 * TN + 16 * j + r;
+  for (int i = 0; i < TN; ++i) {
+    const int p = (i * 4 + wid) * 64 + lane, row = p >> 3;
+    b_kb[i] = 4 * ((p & 7) ^ (row & 7));
+    const int x = n0 + row, xc = x < g.N ? x : g.N - 1;
+    b_src[i] = (const float*)g.b.p + (b_conv ? (size_t)g.b.pix_tab[xc] : (size_t)xc * g.b.ld + kbeg + b_kb[i]);
+  }
+  if (a_conv || b_conv) __syncthreads();
+  const unsigned ldsA = (unsigned)(uintptr_t)&sA[0][0], ldsB = (unsigned)(uintptr_t)&sB[0][0];
+  auto issue = [&](int c) {  // chunk c of this split -> buffer c & 1
+    const int kc = c * BK;
+    const float* sa0 = a_conv ? a_src[0] + sTabA[kc + a_kb[0]] : a_src[0] + kc;
+    const float* sa1 = a_conv ? a_src[1] + sTabA[kc + a_kb[1]] : a_src[1] + kc;
+    const float* sb0 = b_conv ? b_src[0] + sTabB[kc + b_kb[0]] : b_src[0] + kc;
+    const float* sb1 = b_conv ? b_src[1] + sTabB[kc + b_kb[1]] : b_src[1] + kc;
+    const unsigned bo = (unsigned)(c & 1) * (unsigned)(BM * BK * 4) + (unsigned)wid * 1024u;  // the wave's 1 KB piece: 64 lanes x 16 bytes
+    tgemm_dma16(sa0, ldsA + bo);
+    tgemm_dma16(sa1, ldsA + bo + 4096u);
+    tgemm_dma16(sb0, ldsB + bo);
+    tgemm_dma16(sb1, ldsB + bo + 4096u);
+  };
+  f32x4 acc[TM][TN];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
-        const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
-        if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(acc[i][j][q], m, n);
-      }
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rs[TM] = {0.f, 0.f};
+  const int nc = (kend - kbeg) / BK;
+  // (the compiler's own loads so far -- tables, operand descriptors -- must not be counted by the vmcnt arithmetic below)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  if (nc > 0) issue(0);
+#pragma unroll 1
+  for (int c = 0; c < nc; ++c) {
+    if (c > 0) __syncthreads();  // every wave is done with chunk c - 1: its buffer may be refilled
+    if (c + 1 < nc) {
+      issue(c + 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM + TN) : "memory");  // this wave's pieces of chunk c have landed (chunk c + 1 stays in flight)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (want_rs && wn == 0 && kq == 0) {
-      const int m = m0 + wm * 16 * TM + 16 * i + r;
-      if (m < g.M) g.rowsum[m] = rs[i];
+    __syncthreads();  // ... and everybody else's
+    const float* A = &sA[c & 1][0];
+    const float* B = &sB[c & 1][0];
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 16) {
+      float a[TM][4], b[TN][4];
+      const int blk = (((kb >> 2) + kq) ^ (r & 7)) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 q = *reinterpret_cast<const float4*>(A + (wm * 32 + 16 * i + r) * BK + blk);
+        a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(B + (wn * 32 + 16 * j + r) * BK + blk);
+        b[j][0] = q.x; b[j][1] = q.y; b[j][2] = q.z; b[j][3] = q.w;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][cc], b[j][cc], acc[i][j], 0, 0, 0);
     }
   }
+  TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
+  tgemm_finish<TM, TN>(g, tc, acc, rs, false, &s_last);
 }
 
 }  // namespace
+
+// Can every problem of a launch take the LDS-DMA kernel?  k-contiguous fp32 operands with 16-byte pieces, K a multiple of the chunk,
+// no bias-gradient row sums (those ride on x-contiguous weight-gradient operands anyway).
+static bool tgemm_dma_ok(const TGemm* probs, int n) {
+  static const bool off = getenv("JH_TGEMM_DMA") && atoi(getenv("JH_TGEMM_DMA")) == 0;
+  if (off) return false;
+  for (int i = 0; i < n; ++i) {
+    const TGemm& g = probs[i];
+    auto ok = [](const Opnd& o) { return (o.mode == OP_KCONT || o.mode == OP_NHWC_K) && o.vec && !o.u8; };
+    if (!ok(g.a) || !ok(g.b) || (g.K & 31) || g.rowsum) return false;
+    if ((g.a.mode == OP_KCONT && (g.a.ld & 3)) || (g.b.mode == OP_KCONT && (g.b.ld & 3))) return false;
+  }
+  return true;
+}
 
 static int tgemm_tag_of(const char* name) {
 #define JH_TGEMM_NAME(NAME, ID) \
@@ -339,6 +517,9 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
     }
     if (kSmallTileK > 0 && min_k >= kSmallTileK && big_tiles <= kSmallTileMax) TM = TN = 1;
   }
+  static const long kDmaMask = getenv("JH_TGEMM_DMA_MASK") ? atol(getenv("JH_TGEMM_DMA_MASK")) : -1L;  // bit per call-site tag (debugging)
+  const int tag_early = tgemm_tag_of(name);
+  const bool use_dma = TM == 2 && TN == 2 && tgemm_dma_ok(probs, n) && tag_early >= 0 && ((kDmaMask >> tag_early) & 1L);
   const int BM = 32 * TM, BN = 32 * TN;
   int max_tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -396,6 +577,17 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
                        // rewritten, arrival counters return to zero)
   for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * (double)probs[i].K;
   const int tag = tgemm_tag_of(name);
+  if (use_dma) {
+#define JH_TGEMM_DMA_CASE(NAME, ID) \
+  case ID: JH_LAUNCH_IDEM(name, flops, (jh_tgemm_dma_kernel<ID>), grid, dim3(256), 0, st, batch); break;
+    switch (tag) {
+      JH_TGEMM_TAGS(JH_TGEMM_DMA_CASE)
+      default: return jh_fail(JH_ERR_ARG, "tgemm launch name %s has no kernel tag (jh_tgemm.h: JH_TGEMM_TAGS)", name);
+    }
+#undef JH_TGEMM_DMA_CASE
+    JH_LAUNCH_CHECK();
+    return JH_OK;
+  }
 #define JH_TGEMM_CASE(NAME, ID)                                                                                          \
   case ID:                                                                                                              \
     if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2, ID>), grid, dim3(256), 0, st, batch);      \
@@ -441,4 +633,23 @@ JH_EXPORT int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const
   TGemm g = mk_gemm(M, N, K, op_dense(a_kcont ? OP_KCONT : OP_XCONT, d_a, lda), op_dense(b_kcont ? OP_KCONT : OP_XCONT, d_b, ldb), d_c, ldc, epi, d_bias, d_aux, ldaux,
                     d_rowsum);
   return jh_tgemm_launch(w, "jh_tgemm_dense", &g, 1, jh_s(stream));
+}
+
+// Test entry: `n` (<= 6) independent k-contiguous problems C_j [M][N] = A_j [M][K] B_j [N][K]^T as ONE grouped launch (the shape of the
+// value networks' forward launches: online / target trunks side by side).
+JH_EXPORT int jh_tgemm_dense_group(jh_ctx* ctx, int32_t n, int32_t M, int32_t N, int32_t K, const float* const* d_a, const float* const* d_b, float* const* d_c,
+                                   jh_stream stream) {
+  JH_ARG(ctx && d_a && d_b && d_c && n >= 1 && n <= kMaxGroup && M > 0 && N > 0 && K > 0);
+  JH_HIP(hipSetDevice(ctx->device));
+  TGemmWorkspace& w = g_dense_ws.w;
+  if (!w.ws) {
+    w.ws_floats = (size_t)4 << 20;
+    w.cnt_slots = 4096;
+    JH_HIP(hipMalloc((void**)&w.ws, sizeof(float) * w.ws_floats));
+    JH_HIP(hipMalloc((void**)&w.cnt, sizeof(unsigned) * (size_t)w.cnt_slots));
+    JH_HIP(hipMemset(w.cnt, 0, sizeof(unsigned) * (size_t)w.cnt_slots));
+  }
+  TGemm g[kMaxGroup];
+  for (int j = 0; j < n; ++j) g[j] = mk_gemm(M, N, K, op_dense(OP_KCONT, d_a[j], K), op_dense(OP_KCONT, d_b[j], K), d_c[j], N, TEPI_NONE);
+  return jh_tgemm_launch(w, "jh_tgemm_stream1_fwd", g, n, jh_s(stream));
 }

@@ -1023,3 +1023,18 @@ def tgemm_dense(a, b, a_kcont=True, b_kcont=True, epi=0, bias=None, aux=None, ro
     L.check(lib.jh_tgemm_dense(L.ctx(a.device.index), int(M), int(N), int(K), pa, int(a.stride(0)), int(bool(a_kcont)), pb, int(b.stride(0)), int(bool(b_kcont)),
                                L.ptr(c), int(c.stride(0)), int(epi), L.ptr(bias), L.ptr(aux), int(aux.stride(0)) if aux is not None else 0, L.ptr(rs), L.stream_ptr()))
     return (c, rs) if rowsum else c
+
+
+def tgemm_dense_group(a_list, b_list):
+    """jh_tgemm_dense_group: C_j = A_j B_j^T for up to six same-shape problems (A_j [M, K], B_j [N, K], contiguous) as ONE grouped
+    launch -- the shape of the value networks' forward launches (online and target trunks side by side)."""
+    lib = L.load()
+    n = len(a_list)
+    M, K = a_list[0].shape
+    N = b_list[0].shape[0]
+    for a, b in zip(a_list, b_list):
+        assert a.shape == (M, K) and b.shape == (N, K) and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype == torch.float32
+    cs = [torch.empty(M, N, dtype=torch.float32, device=a_list[0].device) for _ in range(n)]
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    L.check(lib.jh_tgemm_dense_group(L.ctx(a_list[0].device.index), n, int(M), int(N), int(K), arr(a_list), arr(b_list), arr(cs), L.stream_ptr()))
+    return cs

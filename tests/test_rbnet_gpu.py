@@ -245,6 +245,27 @@ def test_value_net_adam_with_clip_and_eval_forward():
     _close(nat.forward(x, which=0)[:, :, 0], ref(x).detach(), what="acting forward")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,M,N,K", [(3, 64, 1024, 3136), (2, 512, 512, 3136), (1, 2048, 256, 64), (4, 96, 64, 4096)])
+def test_tgemm_grouped_split_k_is_exact_launch_after_launch(n, M, N, K):
+    """Grouped launches on the LDS-DMA operand path with split-K hand-offs (the Ape-X / R2D2 forward shapes), many times over fresh
+    operands: the hand-off between the splits (sc1 partial stores, ticket, last arriver's sum) went wrong once in a few hundred
+    launches -- 32 elements of one accumulator fragment -- until its asm loads carried their wait and its asm stores their s_nop."""
+    import torch
+    from jorldy_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + M)
+    for _ in range(40):
+        As = [torch.randn(M, K, device="cuda", generator=g) for _ in range(n)]
+        Bs = [torch.randn(N, K, device="cuda", generator=g) for _ in range(n)]
+        Cs = ops.tgemm_dense_group(As, Bs)
+        torch.cuda.synchronize()
+        for a, b, c in zip(As, Bs, Cs):
+            want = a.double() @ b.double().t()
+            err = ((c.double() - want).abs() / want.abs().max())
+            assert int((~(err < 1e-5)).sum()) == 0, float(err.max())
+
+
 def test_tgemm_dense_random_shapes_modes_and_epilogues_match_torch():
     """The GEMM engine under every value-network layer, on 80 random problems: ragged M / N / K (not multiples of
     the 64 x 64 x 32 tile, of 4, or of anything), all four dense operand layouts, row strides that do and do not
