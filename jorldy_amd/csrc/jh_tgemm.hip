@@ -344,31 +344,155 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
 }
 
 // ---- the same 64 x 64 tile with its operands DMA-ed straight from global memory into LDS (global_load_lds_dwordx4: 16 bytes per lane,
-// no VGPR destination, no ds_write issue slots) for launches whose operands are all k-contiguous fp32 (dense KCONT, NHWC im2col with
-// C % 4 == 0) and K % 32 == 0: the forward GEMMs of the value networks at B >= 64 rows, the PPO net's 2048-row forward.
+// no VGPR destination, no ds_write issue slots) for launches whose operands are all fp32 in 16-byte pieces -- dense k- or x-contiguous,
+// NHWC im2col with C % 4 == 0 in either orientation -- and K % 32 == 0: the value networks' forward GEMMs, their data and weight
+// gradients from conv2 up, the PPO net's 2048-row forward.
 // Round 2's SQ counters (profiles/r02_apex_pmc_tgemm.json): these launches live on occupancy -- waves parked in s_waitcnt / barriers
 // 40-57 % of their cycles -- and every variant that took registers or LDS from the co-resident workgroups lost.  This one gives both
-// back: 16 staging VGPRs and 4 ds_write_b128 per chunk and wave are gone, and with them the wait for the registers to fill before the
-// LDS store; two 16 KB buffers (A | B, 32 k each) so the next chunk's DMA flies under this chunk's MFMAs.
-// LDS tiles are UNPADDED [row][32 k] (the DMA writes lane-linear: 64 lanes x 16 bytes = 8 rows); the 16-byte k-blocks of a row are
-// XOR-swizzled with (row & 7) on the GLOBAL side (lane p of an instruction fetches block (p & 7) ^ (row & 7) and lands in block p & 7),
-// which spreads a wave's ds_read_b128 of one k over all bank groups the way the 36-float row stride of the staged kernel does.
+// back: 16 staging VGPRs and 4 ds_write_b128 (16 ds_write_b32 for an x-contiguous operand) per chunk and wave are gone, and with them
+// the wait for the registers to fill before the LDS store; kDmaBufs 16 KB buffers (A | B, 32 k each) keep kDmaBufs - 1 chunks in flight
+// under the MFMAs, with ONE barrier per chunk.
+// LDS tiles are UNPADDED and lane-linear (the DMA writes 64 lanes x 16 bytes back to back):
+//   k-contiguous operand  [x][32 k]: the 16-byte k-blocks of a row are XOR-swizzled with (x & 7) on the GLOBAL side (lane p of an
+//     instruction fetches block (p & 7) ^ (x & 7) and lands in block p & 7), which spreads a wave's ds_read_b128 of one k over all
+//     bank groups the way the 36-float row stride of the staged kernel does;
+//   x-contiguous operand  [32 k][64 x]: the 16-byte x-blocks of a k row are XOR-swizzled with ((k >> 2) & 3) << 2; MFMA step c of a
+//     16-wide k block takes k = 4 kq + c from lane group kq (the same order the k-contiguous float4 gives), so the four lane groups
+//     read rows 4 apart, the swizzle is the per-lane constant kq << 2 and the 64 ds_read_b32 of a step hit 64 distinct banks.
 // The DMA is inline asm on purpose: with __builtin_amdgcn_global_load_lds hipcc puts s_waitcnt vmcnt(0) in front of every s_barrier
 // while a DMA is pending, so the next chunk never flies under this chunk's MFMAs (measured at Ape-X B = 512: stream1_fwd 150 us with
 // the builtin, 121 us with the asm; conv2_fwd 111 -> 92, conv3_fwd 84 -> 66).  With asm the compiler does not count these loads at
-// all; the kernel waits for them itself (vmcnt(0) before the first issue, then vmcnt(TM + TN) = "all but the chunk just issued").
+// all; the kernel waits for them itself (vmcnt(0) before the first issue, then "all but the chunks issued after this one").
 __device__ __forceinline__ void tgemm_dma16(const void* gsrc, unsigned lds_base) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
 
+// Measured at Ape-X B = 512 and Rainbow B = 32 (tools/probes/ab_apex_lib.sh, ab_rb_lib.sh): 2 and 3 buffers are the same to the
+// noise WHEN three workgroups share a CU either way (3 x (48 + 4) KB still fit); 3 buffers at two workgroups per CU lose 5 %.
+#ifndef JH_TGEMM_DMA_BUFS
+#define JH_TGEMM_DMA_BUFS 2
+#endif
+constexpr int kDmaBufs = JH_TGEMM_DMA_BUFS;
+
+// One operand's two 16-byte pieces per lane and chunk: piece p = (i * 4 + wave) * 64 + lane of the 512 that make a 64 x 32 tile.
+struct DmaOp {
+  const float* src[2];  // address of the piece in chunk 0 (im2col: without the term that follows k)
+  int kin[2];           // im2col: index of that term in the split's LDS table
+  size_t step;          // dense: floats from one chunk to the next
+  const int* tab;       // im2col: the LDS table (taps for k-contiguous, pixels for x-contiguous), else nullptr
+};
+__device__ __forceinline__ DmaOp tgemm_dma_operand(const Opnd& o, int X, int x0, int kbeg, const int* tab, int wid, int lane) {
+  DmaOp d;
+  const bool xfast = o.mode & 1, conv = o.mode >= OP_NHWC_K;
+  d.tab = conv ? tab : nullptr;
+  d.step = xfast ? (size_t)32 * o.ld : 32;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = (i * 4 + wid) * 64 + lane;
+    if (!xfast) {
+      const int row = p >> 3, kb = 4 * ((p & 7) ^ (row & 7));
+      const int x = x0 + row, xc = x < X ? x : X - 1;  // rows beyond the matrix fetch a valid row: their results are never stored
+      d.kin[i] = kb;
+      d.src[i] = (const float*)o.p + (conv ? (size_t)o.pix_tab[xc] : (size_t)xc * o.ld + kbeg + kb);
+    } else {
+      const int kk = p >> 4, xb = (p & 15) ^ (((kk >> 2) & 3) << 2);
+      const int x = x0 + 4 * xb, xc = x + 3 < X ? x : X - 4;  // X % 4 == 0: a piece is wholly inside or wholly outside
+      d.kin[i] = kk;
+      d.src[i] = (const float*)o.p + (conv ? (size_t)o.tap_tab[xc] : (size_t)(kbeg + kk) * o.ld + xc);
+    }
+  }
+  return d;
+}
+__device__ __forceinline__ void tgemm_dma_issue(const DmaOp& d, int c, unsigned lds) {  // chunk c -> the wave's two 1 KB pieces at lds
+  const float* s0 = d.tab ? d.src[0] + d.tab[c * 32 + d.kin[0]] : d.src[0] + c * d.step;
+  const float* s1 = d.tab ? d.src[1] + d.tab[c * 32 + d.kin[1]] : d.src[1] + c * d.step;
+  tgemm_dma16(s0, lds);
+  tgemm_dma16(s1, lds + 4096u);
+}
+
+template <bool AX, bool BX>
+__device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float* sB, const DmaOp& da, const DmaOp& db, int nc, int wid, int r, int kq, int wm,
+                                                   int wn, f32x4 (&acc)[2][2], float (&rs)[2], bool want_rs) {
+  constexpr int TM = 2, TN = 2, BK = 32, TILE = 64 * BK;
+  const unsigned ldsA = (unsigned)(uintptr_t)sA + (unsigned)wid * 1024u, ldsB = (unsigned)(uintptr_t)sB + (unsigned)wid * 1024u;
+  // read offsets (floats) of this lane inside a tile; see the layouts above
+  int ao[TM], bo[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int x = wm * 32 + 16 * i + r;
+    ao[i] = AX ? 4 * kq * 64 + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int x = wn * 32 + 16 * j + r;
+    bo[j] = BX ? 4 * kq * 64 + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
+  }
+  // (the compiler's own loads so far -- tables, operand descriptors -- must not be counted by the vmcnt arithmetic below)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int c = 0; c < kDmaBufs - 1 && c < nc; ++c) {
+    tgemm_dma_issue(da, c, ldsA + (unsigned)c * (TILE * 4));
+    tgemm_dma_issue(db, c, ldsB + (unsigned)c * (TILE * 4));
+  }
+  int buf = 0, nbuf = kDmaBufs - 1;  // buffer of chunk c, buffer of chunk c + kDmaBufs - 1 (the one chunk c - 1 just left)
+#pragma unroll 1
+  for (int c = 0; c < nc; ++c) {
+    // this wave's pieces of chunk c have landed once at most the chunks issued after it (4 loads each) are outstanding
+    const int after = nc - 1 - c < kDmaBufs - 2 ? nc - 1 - c : kDmaBufs - 2;
+    if (kDmaBufs >= 4 && after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kDmaBufs >= 3 && after >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // ... and everybody else's; every wave is done with chunk c - 1, so its buffer may be refilled
+    if (c + kDmaBufs - 1 < nc) {
+      tgemm_dma_issue(da, c + kDmaBufs - 1, ldsA + (unsigned)nbuf * (TILE * 4));
+      tgemm_dma_issue(db, c + kDmaBufs - 1, ldsB + (unsigned)nbuf * (TILE * 4));
+    }
+    const float* A = sA + buf * TILE;
+    const float* B = sB + buf * TILE;
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 16) {
+      float a[TM][4], b[TN][4];
+      const int blk = (((kb >> 2) + kq) ^ (r & 7)) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (AX) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) a[i][cc] = A[ao[i] + (kb + cc) * 64];
+        } else {
+          const float4 q = *reinterpret_cast<const float4*>(A + ao[i] + blk);
+          a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
+        }
+        if (want_rs && wn == 0) rs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (BX) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) b[j][cc] = B[bo[j] + (kb + cc) * 64];
+        } else {
+          const float4 q = *reinterpret_cast<const float4*>(B + bo[j] + blk);
+          b[j][0] = q.x; b[j][1] = q.y; b[j][2] = q.z; b[j][3] = q.w;
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][cc], b[j][cc], acc[i][j], 0, 0, 0);
+    }
+    buf = buf + 1 == kDmaBufs ? 0 : buf + 1;
+    nbuf = nbuf + 1 == kDmaBufs ? 0 : nbuf + 1;
+  }
+}
+
 template <int TAG>
-__global__ void __launch_bounds__(256, 2) jh_tgemm_dma_kernel(TGemmBatch batch) {
+__global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) {
   constexpr int TM = 2, TN = 2, BM = 64, BN = 64, BK = 32;
-  __shared__ __attribute__((aligned(16))) float sA[2][BM * BK];
-  __shared__ __attribute__((aligned(16))) float sB[2][BN * BK];
-  __shared__ int sTabA[kTabMax], sTabB[kTabMax];
+  __shared__ __attribute__((aligned(16))) float sA[kDmaBufs * BM * BK];
+  __shared__ __attribute__((aligned(16))) float sB[kDmaBufs * BN * BK];
+  __shared__ int sTab[kTabMax];  // at most one operand of a problem is an im2col view; 48 + 4 KB lets three workgroups share a CU
   __shared__ int s_last;
   int pi = 0;
 #pragma unroll
@@ -385,103 +509,63 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_dma_kernel(TGemmBatch batch) 
   const int kbeg = z * per * BK;
   int kend = kbeg + per * BK;
   if (kend > g.K) kend = g.K;
+  const bool a_x = g.a.mode & 1, b_x = g.b.mode & 1;
   const bool a_conv = g.a.mode >= OP_NHWC_K, b_conv = g.b.mode >= OP_NHWC_K;
-  if (a_conv)
-    for (int i = t; i < kend - kbeg; i += 256) sTabA[i] = g.a.tap_tab[kbeg + i];
-  if (b_conv)
-    for (int i = t; i < kend - kbeg; i += 256) sTabB[i] = g.b.tap_tab[kbeg + i];
-  // piece (slot i of this lane): p = (i * 4 + wid) * 64 + lane in [0, 512): row p >> 3 of the tile, LDS k-block p & 7 <- global k-block (p & 7) ^ (row & 7)
-  const float* a_src[TM];
-  const float* b_src[TN];
-  int a_kb[TM], b_kb[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int p = (i * 4 + wid) * 64 + lane, row = p >> 3;
-    a_kb[i] = 4 * ((p & 7) ^ (row & 7));
-    const int x = m0 + row, xc = x < g.M ? x : g.M - 1;  // rows beyond M fetch a valid row: their results are never stored
-    a_src[i] = (const float*)g.a.p + (a_conv ? (size_t)g.a.pix_tab[xc] : (size_t)xc * g.a.ld + kbeg + a_kb[i]);
+  // im2col operands: the offset term that follows k (taps for k-contiguous, pixels for x-contiguous) is staged in LDS for this
+  // split's whole k range, as in the staged kernel
+  if (a_conv) {
+    const int* ktab = a_x ? g.a.pix_tab : g.a.tap_tab;
+    for (int i = t; i < kend - kbeg; i += 256) sTab[i] = ktab[kbeg + i];
   }
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int p = (i * 4 + wid) * 64 + lane, row = p >> 3;
-    b_kb[i] = 4 * ((p & 7) ^ (row & 7));
-    const int x = n0 + row, xc = x < g.N ? x : g.N - 1;
-    b_src[i] = (const float*)g.b.p + (b_conv ? (size_t)g.b.pix_tab[xc] : (size_t)xc * g.b.ld + kbeg + b_kb[i]);
+  if (b_conv) {
+    const int* ktab = b_x ? g.b.pix_tab : g.b.tap_tab;
+    for (int i = t; i < kend - kbeg; i += 256) sTab[i] = ktab[kbeg + i];
   }
+  const DmaOp da = tgemm_dma_operand(g.a, g.M, m0, kbeg, sTab, wid, lane);
+  const DmaOp db = tgemm_dma_operand(g.b, g.N, n0, kbeg, sTab, wid, lane);
   if (a_conv || b_conv) __syncthreads();
-  const unsigned ldsA = (unsigned)(uintptr_t)&sA[0][0], ldsB = (unsigned)(uintptr_t)&sB[0][0];
-  auto issue = [&](int c) {  // chunk c of this split -> buffer c & 1
-    const int kc = c * BK;
-    const float* sa0 = a_conv ? a_src[0] + sTabA[kc + a_kb[0]] : a_src[0] + kc;
-    const float* sa1 = a_conv ? a_src[1] + sTabA[kc + a_kb[1]] : a_src[1] + kc;
-    const float* sb0 = b_conv ? b_src[0] + sTabB[kc + b_kb[0]] : b_src[0] + kc;
-    const float* sb1 = b_conv ? b_src[1] + sTabB[kc + b_kb[1]] : b_src[1] + kc;
-    const unsigned bo = (unsigned)(c & 1) * (unsigned)(BM * BK * 4) + (unsigned)wid * 1024u;  // the wave's 1 KB piece: 64 lanes x 16 bytes
-    tgemm_dma16(sa0, ldsA + bo);
-    tgemm_dma16(sa1, ldsA + bo + 4096u);
-    tgemm_dma16(sb0, ldsB + bo);
-    tgemm_dma16(sb1, ldsB + bo + 4096u);
-  };
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float rs[TM] = {0.f, 0.f};
+  const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
   const int nc = (kend - kbeg) / BK;
-  // (the compiler's own loads so far -- tables, operand descriptors -- must not be counted by the vmcnt arithmetic below)
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  if (nc > 0) issue(0);
-#pragma unroll 1
-  for (int c = 0; c < nc; ++c) {
-    if (c > 0) __syncthreads();  // every wave is done with chunk c - 1: its buffer may be refilled
-    if (c + 1 < nc) {
-      issue(c + 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM + TN) : "memory");  // this wave's pieces of chunk c have landed (chunk c + 1 stays in flight)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();  // ... and everybody else's
-    const float* A = &sA[c & 1][0];
-    const float* B = &sB[c & 1][0];
+  if (a_x) {
+    if (b_x) tgemm_dma_mainloop<true, true>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
+    else tgemm_dma_mainloop<true, false>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
+  } else {
+    if (b_x) tgemm_dma_mainloop<false, true>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
+    else tgemm_dma_mainloop<false, false>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
+  }
+  if (want_rs && wn == 0) {
 #pragma unroll
-    for (int kb = 0; kb < BK; kb += 16) {
-      float a[TM][4], b[TN][4];
-      const int blk = (((kb >> 2) + kq) ^ (r & 7)) * 4;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const float4 q = *reinterpret_cast<const float4*>(A + (wm * 32 + 16 * i + r) * BK + blk);
-        a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float4 q = *reinterpret_cast<const float4*>(B + (wn * 32 + 16 * j + r) * BK + blk);
-        b[j][0] = q.x; b[j][1] = q.y; b[j][2] = q.z; b[j][3] = q.w;
-      }
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][cc], b[j][cc], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) {
+      rs[i] += __shfl_xor(rs[i], 16, 64);
+      rs[i] += __shfl_xor(rs[i], 32, 64);
     }
   }
   TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
-  tgemm_finish<TM, TN>(g, tc, acc, rs, false, &s_last);
+  tgemm_finish<TM, TN>(g, tc, acc, rs, want_rs, &s_last);
 }
 
 }  // namespace
 
-// Can every problem of a launch take the LDS-DMA kernel?  k-contiguous fp32 operands with 16-byte pieces, K a multiple of the chunk,
-// no bias-gradient row sums (those ride on x-contiguous weight-gradient operands anyway).
+// Can every problem of a launch take the LDS-DMA kernel?  fp32 operands in 16-byte pieces (dense either way, NHWC im2col either way),
+// K a multiple of the chunk, x-contiguous operands with an extent that is a multiple of 4.
 static bool tgemm_dma_ok(const TGemm* probs, int n) {
   static const bool off = getenv("JH_TGEMM_DMA") && atoi(getenv("JH_TGEMM_DMA")) == 0;
   if (off) return false;
   for (int i = 0; i < n; ++i) {
     const TGemm& g = probs[i];
-    auto ok = [](const Opnd& o) { return (o.mode == OP_KCONT || o.mode == OP_NHWC_K) && o.vec && !o.u8; };
-    if (!ok(g.a) || !ok(g.b) || (g.K & 31) || g.rowsum) return false;
-    if ((g.a.mode == OP_KCONT && (g.a.ld & 3)) || (g.b.mode == OP_KCONT && (g.b.ld & 3))) return false;
+    auto ok = [](const Opnd& o, int X) {
+      if (o.mode > OP_NHWC_X || !o.vec || o.u8) return false;
+      if (o.mode <= OP_XCONT && (o.ld & 3)) return false;
+      return !(o.mode & 1) || (X >= 4 && !(X & 3));
+    };
+    if (!ok(g.a, g.M) || !ok(g.b, g.N) || (g.K & 31)) return false;
+    if (g.a.mode >= OP_NHWC_K && g.b.mode >= OP_NHWC_K) return false;  // one LDS table
   }
   return true;
 }

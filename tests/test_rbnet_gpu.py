@@ -305,6 +305,47 @@ def test_tgemm_dense_random_shapes_modes_and_epilogues_match_torch():
         assert rs_err < 2e-6, (case, M, N, K, "rowsum", rs_err)
 
 
+@pytest.mark.gpu
+def test_tgemm_dense_lds_dma_shapes_all_layouts_match_torch():
+    """Problems the LDS-DMA kernel takes (K % 32 == 0, 16-byte pieces, x-contiguous extents % 4 == 0; tiles that are and are not
+    full, K ranges that do and do not split, one to three chunk buffers' worth of K) in all four dense layouts, with every epilogue
+    and the fused row sums."""
+    import torch
+    from jorldy_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rng = np.random.RandomState(1)
+    for case in range(64):
+        a_kc, b_kc = bool(case & 1), bool(case & 2)
+        M = int(rng.choice([64, 65, 100, 512, 777] if a_kc else [64, 68, 132, 512, 1000]))
+        N = int(rng.choice([64, 100, 129, 512] if b_kc else [64, 68, 260, 512]))
+        K = int(rng.choice([32, 64, 96, 128, 512, 1024, 3136, 6400]))
+        pad = 4 * int(rng.randint(2))
+        A = torch.randn((M, K + pad) if a_kc else (K, M + pad), device="cuda", generator=g)
+        Bm = torch.randn((N, K + pad) if b_kc else (K, N + pad), device="cuda", generator=g)
+        a_v = A[:, :K] if a_kc else A[:, :M]
+        b_v = Bm[:, :K] if b_kc else Bm[:, :N]
+        a2 = a_v if a_kc else a_v.t()
+        b2 = b_v.t() if b_kc else b_v
+        epi = (case >> 2) % 4
+        bias = torch.randn(N, device="cuda", generator=g) if epi in (1, 2) else None
+        aux = torch.randn(M, N, device="cuda", generator=g) if epi == 3 else None
+        want = a2.double() @ b2.double()
+        if epi in (1, 2):
+            want = want + bias.double()
+        if epi == 2:
+            want = want.clamp_min(0)
+        if epi == 3:
+            want = torch.where(aux > 0, want, torch.zeros_like(want))
+        for rep in range(3):
+            got, rs = ops.tgemm_dense(a_v, b_v, a_kcont=a_kc, b_kcont=b_kc, epi=epi, bias=bias, aux=aux, rowsum=True, M=M, N=N, K=K)
+            scale = float(a2.abs().double().matmul(b2.abs().double()).max()) + 1e-9
+            err = float((got.double() - want).abs().max()) / scale
+            assert err < 2e-6, (case, rep, M, N, K, a_kc, b_kc, epi, err)
+            rs_err = float((rs.double() - a2.double().sum(1)).abs().max()) / (float(a2.abs().double().sum(1).max()) + 1e-9)
+            assert rs_err < 2e-6, (case, rep, M, N, K, "rowsum", rs_err)
+
+
 def test_rbnet_independent_noise_matches_torch():
     """noise_type="independent" (utils.py:72-79: one Gaussian draw per weight): three forwards + backward."""
     import torch
