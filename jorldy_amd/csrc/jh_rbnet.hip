@@ -178,6 +178,217 @@ __global__ void __launch_bounds__(256) jh_rb_col2im_kernel(const float* __restri
   *reinterpret_cast<float4*>(dact + (size_t)pix * C + c) = acc;
 }
 
+// ---------------------------------------------------------------------------------- conv1 forward on uint8 frames
+// act1[(b, oy, ox)][oc] = relu(b1[oc] + sum over taps of x[b][c][4 oy + ky][4 ox + kx] / 255 * W1[oc][c][ky][kx]) for the head's first layer.
+// As a GEMM: M = pixels, N = 32, K = 64 Cin -- half a tile wide and eight chunks deep on the tile engine, whose uint8 operand goes
+// global -> VGPR -> convert -> LDS one dword per lane (170 us for 3 x 512 frames, 38 % of the MFMA peak; 24 us at B = 32).  Here a
+// workgroup keeps W1 (32 KB, row stride + 4 floats) in LDS and walks 16-pixel tiles of ITS frame, one tile per wave and turn:
+//   A[m = pixel r][k]   lane group kq of step s loads the dword of taps (c, ky, 4 h .. 4 h + 3), (c, ky, h) = bits of 4 s + kq, straight
+//                       from the frame: byte j is the lane's k element of MFMA j of that step (the float4 trick of the tile engine)
+//   B[k][n = oc r]      the matching float4 of W1 row oc: one ds_read_b128 per step and 16-channel tile
+// all 4 Cin dwords of a tile are in flight before its first MFMA; no barriers after the weight staging.
+struct C1Job {
+  const uint8_t* x;
+  const float *W, *bias;
+  float* out;
+  int wg_begin;
+};
+struct C1Fwd {
+  C1Job j[2];
+  int nj, H, W, OW, P, tiles_per_img, tiles_per_wg, wgs_per_img;
+  float inv_ow;
+};
+template <int CIN>
+__global__ void __launch_bounds__(256) jh_rb_conv1_fwd_kernel(C1Fwd a) {
+  constexpr int K = CIN * 64, LDW = K + 4, NS = CIN * 4;
+  __shared__ __attribute__((aligned(16))) float sW[32 * LDW];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 15, kq = lane >> 4;
+  const C1Job& J = a.j[(a.nj > 1 && (int)blockIdx.x >= a.j[1].wg_begin) ? 1 : 0];
+  const int local = blockIdx.x - J.wg_begin;
+  const int img = local / a.wgs_per_img, part = local - img * a.wgs_per_img;
+  for (int i = t; i < 32 * (K / 4); i += 256) {
+    const int oc = i / (K / 4), k4 = i - oc * (K / 4);
+    *reinterpret_cast<float4*>(&sW[oc * LDW + 4 * k4]) = *reinterpret_cast<const float4*>(J.W + (size_t)oc * K + 4 * k4);
+  }
+  __syncthreads();
+  const float bias0 = J.bias[r], bias1 = J.bias[16 + r];
+  const int t0 = part * a.tiles_per_wg;
+  int t1 = t0 + a.tiles_per_wg;
+  if (t1 > a.tiles_per_img) t1 = a.tiles_per_img;
+  const uint8_t* frame = J.x + (size_t)img * CIN * a.H * a.W;
+  float* out = J.out + (size_t)img * a.P * 32;
+  for (int tile = t0 + wid; tile < t1; tile += 4) {
+    const int p = tile * 16 + r, pc = p < a.P ? p : a.P - 1;
+    const int oy = (int)(((float)pc + 0.5f) * a.inv_ow), ox = pc - oy * a.OW;
+    const uint8_t* base = frame + (size_t)(4 * oy) * a.W + 4 * ox;
+    uint32_t xw[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int q = 4 * s + kq, c = q >> 4, ky = (q >> 1) & 7, h = q & 1;
+      xw[s] = *reinterpret_cast<const uint32_t*>(base + (size_t)(c * a.H + ky) * a.W + 4 * h);
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float af[4] = {u8_unit(xw[s] & 255u), u8_unit((xw[s] >> 8) & 255u), u8_unit((xw[s] >> 16) & 255u), u8_unit(xw[s] >> 24)};
+      const float4 w0 = *reinterpret_cast<const float4*>(&sW[r * LDW + 4 * (4 * s + kq)]);
+      const float4 w1 = *reinterpret_cast<const float4*>(&sW[(16 + r) * LDW + 4 * (4 * s + kq)]);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], w0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], w1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], w0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], w1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], w0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], w1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], w0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], w1.w, acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // C fragment: rows (pixels) 4 kq + q, column (channel) r
+      const int m = tile * 16 + 4 * kq + q;
+      if (m < a.P) {
+        const float v0 = acc[0][q] + bias0, v1 = acc[1][q] + bias1;
+        out[(size_t)m * 32 + r] = v0 > 0.f ? v0 : 0.f;
+        out[(size_t)m * 32 + 16 + r] = v1 > 0.f ? v1 : 0.f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- conv1 weight gradient on uint8 frames
+// dW1[oc][c][ky][kx] = sum over (b, oy, ox) of dY[(b, oy, ox)][oc] * x[b][c][4 oy + ky][4 ox + kx] / 255 for the head's first layer
+// (8 x 8 kernel, stride 4, 32 output channels, uint8 NCHW frames: core/network/head.py:37-47 CNN).  As a GEMM this is M = 32,
+// N = 64 Cin, K = B * OH * OW (12 800 at B = 32, 204 800 at B = 512): four 64 x 64 output tiles for the whole chip, so the tile engine
+// splits K 64 ways and its last arrivers sum 64 partial tiles each, alone -- 33 us at B = 32, 140 us at B = 512 (15 % of the MFMA peak).
+// Here the K range is the parallel dimension: workgroup g takes a contiguous run of 4-pixel groups, wave w the input channels
+// w, w + 4, ..., and a wave keeps the whole 32 x 64 block of ITS channel in 8 accumulator tiles:
+//   A[m = oc][k = pixel kq]   two dwords of dY per lane and group (oc = r, r + 16)
+//   B[k = pixel kq][n = r]    tile j holds the taps 4 r + j, i.e. (ky = r >> 1, kx = 4 (r & 1) + j): ONE aligned dword of the frame per
+//                             lane and group is the B operand of all four tiles, unpacked with v_cvt_f32_ubyte0..3
+// (the permutation of the taps is undone by the store: a lane ends up with 4 consecutive kx of one (oc, c, ky) -> one 16-byte store).
+// UN groups' loads (3 dwords each) are in flight before the first MFMA of a round, and a workgroup is SIXTEEN waves -- four K slices
+// of its run x four channels -- so that every SIMD has four independent load -> MFMA chains to interleave (with one wave per SIMD the
+// kernel sat at 4 x its MFMA time: 86 us at B = 512); slices 1..3 hand their accumulators to slice 0 through LDS, added in slice order.
+// Every workgroup writes its partial [32][64 Cin] (+ 32 bias sums) and jh_rb_parts_sum_kernel adds the partials in workgroup order:
+// deterministic.
+template <int UN>
+__global__ void __launch_bounds__(1024) jh_rb_conv1_wgrad_kernel(const uint8_t* __restrict__ x, const float* __restrict__ dY, float* __restrict__ part, int Cin,
+                                                                 int H, int W, int OW, int P, float inv_ow, int groups_per_img, int total_groups,
+                                                                 int groups_per_wg) {
+  __shared__ float s_acc[3][4][34][64];  // [slice - 1][channel wave][32 accumulator registers + 2 row sums][lane]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int cw = wid & 3, slice = wid >> 2;
+  const int per_slice = groups_per_wg / 4;  // the host keeps groups_per_wg a multiple of 4 UN
+  const int g0 = blockIdx.x * groups_per_wg + slice * per_slice;
+  int g1 = g0 + per_slice;
+  if (g1 > total_groups) g1 = total_groups;
+  const int NW = Cin * 64, n_all = 32 * NW + 32;
+  float* mine = part + (size_t)blockIdx.x * n_all;
+  const int ky = r >> 1, kx0 = 4 * (r & 1);
+  for (int c = cw; c < Cin; c += 4) {
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float rs[2] = {0.f, 0.f};
+#pragma unroll 1
+    for (int gi = g0; gi < g1; gi += UN) {
+      float a[UN][2];
+      uint32_t xw[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int g = gi + u < g1 ? gi + u : g1 - 1;  // clamped: uniform control flow, the operand is zeroed instead
+        const int b = g / groups_per_img;
+        const int p = (g - b * groups_per_img) * 4 + kq, pc = p < P ? p : P - 1;
+        const int oy = (int)(((float)pc + 0.5f) * inv_ow), ox = pc - oy * OW;
+        const float* dy = dY + ((size_t)b * P + pc) * 32 + r;
+        const bool ok = gi + u < g1 && p < P;
+        const float a0 = dy[0], a1 = dy[16];
+        a[u][0] = ok ? a0 : 0.f;
+        a[u][1] = ok ? a1 : 0.f;
+        xw[u] = *reinterpret_cast<const uint32_t*>(x + (((size_t)b * Cin + c) * H + 4 * oy + ky) * W + 4 * ox + kx0);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const float bf[4] = {u8_unit(xw[u] & 255u), u8_unit((xw[u] >> 8) & 255u), u8_unit((xw[u] >> 16) & 255u), u8_unit(xw[u] >> 24)};
+        rs[0] += a[u][0];
+        rs[1] += a[u][1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (slice > 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s_acc[slice - 1][cw][(i * 4 + j) * 4 + q][lane] = acc[i][j][q];
+        s_acc[slice - 1][cw][32 + i][lane] = rs[i];
+      }
+    }
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] += s_acc[sl][cw][(i * 4 + j) * 4 + q][lane];
+          rs[i] += s_acc[sl][cw][32 + i][lane];
+        }
+      // C fragment: a lane holds rows 4 kq + q, column r of every tile: tile j is tap 4 r + j
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(mine + (size_t)(16 * i + 4 * kq + q) * NW + c * 64 + 4 * r) =
+              make_float4(acc[i][0][q], acc[i][1][q], acc[i][2][q], acc[i][3][q]);
+      if (c == 0) {  // bias gradient = sum over this workgroup's pixels of dY
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v = rs[i];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (kq == 0) mine[32 * NW + 16 * i + r] = v;
+        }
+      }
+    }
+    __syncthreads();  // s_acc is reused by the next channel round
+  }
+}
+
+// out[e] = sum over g < G of part[g][e] in g order (8 interleaved runs, then those in order): 32 elements x 8 runs per workgroup
+__global__ void __launch_bounds__(256) jh_rb_parts_sum_kernel(const float* __restrict__ part, float* __restrict__ out_w, float* __restrict__ out_b, int n_w,
+                                                              int n_all, int G) {
+  __shared__ float s[8][32];
+  const int el = threadIdx.x & 31, run = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  float acc = 0.f;
+  if (e < n_all) {
+    int g = run;
+    for (; g + 24 < G; g += 32) {
+      const float v0 = part[(size_t)g * n_all + e], v1 = part[(size_t)(g + 8) * n_all + e], v2 = part[(size_t)(g + 16) * n_all + e],
+                  v3 = part[(size_t)(g + 24) * n_all + e];
+      acc = (((acc + v0) + v1) + v2) + v3;
+    }
+    for (; g < G; g += 8) acc += part[(size_t)g * n_all + e];
+  }
+  s[run][el] = acc;
+  __syncthreads();
+  if (run == 0 && e < n_all) {
+    float v = s[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += s[k][el];
+    if (e < n_w) out_w[e] = v;
+    else out_b[e - n_w] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------- optimizers
 // hyper (device): {lr, beta1 | alpha, beta2, eps, step, centered}.  The step counter advances inside: every
 // workgroup derives what it needs from step + 1 at its start; the last one to finish stores the new step.
@@ -266,6 +477,7 @@ enum {
   SEG_MU_V2, SEG_SIG_V2, SEG_MUB_V2, SEG_SIGB_V2, SEG_COUNT
 };
 
+constexpr int kC1Parts = 256;  // conv1 weight gradient: at most this many K slices (workgroups)
 struct jh_rbnet {
   jh_ctx* ctx = nullptr;
   int cnn = 0, Cin = 0, Hin = 0, Win = 0, hidden = 0, A = 0, K = 0, NA = 0, maxB = 0, F = 0;
@@ -293,6 +505,7 @@ struct jh_rbnet {
   size_t ws_floats = 0;
   unsigned* cnt = nullptr;
   int cnt_slots = 0;
+  float* c1_part = nullptr;    // conv1 weight-gradient partials [kC1Parts][32 * 64 Cin + 32]
   const void* last_x = nullptr;  // input of the last learn_forward (backward of layer 1 reads it again)
   int last_x_u8 = 0, last_B = 0;
   const float* last_noise = nullptr;
@@ -425,6 +638,7 @@ JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t kind, int32_t head_cnn, int32
     size_t dc = B * n->P3 * 576;
     if (B * n->P2 * 512 > dc) dc = B * n->P2 * 512;
     A4(&n->dcol, dc); A4(&n->dact2, B * n->P2 * 64); A4(&n->dact1, B * n->P1 * 32);
+    A4(&n->c1_part, (size_t)kC1Parts * (32 * n->Cin * 64 + 32), false);
   }
   if (n->cnn && !rc) {
     ConvGeom* gs[3] = {&n->c1, &n->c2, &n->c3};
@@ -528,7 +742,30 @@ static int rb_trunk(jh_rbnet* n, const TrunkJob* jobs, int nj, int x_u8, hipStre
       g[j] = mk_gemm(J.rows * n->P1, 32, n->Cin * 64, op_conv(OP_NCHW_K, J.x, x_u8, n->c1), op_dense(OP_KCONT, J.P + n->seg_off[SEG_W1], n->Cin * 64),
                      n->act1[J.slot], 32, TEPI_BIAS_RELU, J.P + n->seg_off[SEG_B1]);
     }
-    int rc = launch_tgemm(n, "jh_tgemm_conv1_fwd", g, nj, st);
+    // uint8 frames in the head's own geometry: the dedicated kernel (jh_rb_conv1_fwd_kernel); anything else is a GEMM like the other layers
+    static const bool kC1Own = !(getenv("JH_RB_CONV1_FWD") && atoi(getenv("JH_RB_CONV1_FWD")) == 0);
+    const ConvGeom& c1 = n->c1;
+    int rc = JH_OK;
+    if (kC1Own && x_u8 && c1.KH == 8 && c1.KW == 8 && c1.S == 4 && c1.W % 4 == 0 && n->Cin == 4 && n->P1 < (1 << 20)) {
+      C1Fwd a{};
+      int imgs = 0;
+      for (int j = 0; j < nj; ++j) imgs += jobs[j].rows;
+      a.nj = nj; a.H = c1.H; a.W = c1.W; a.OW = c1.OW; a.P = n->P1; a.inv_ow = 1.0f / (float)c1.OW;
+      a.tiles_per_img = (n->P1 + 15) / 16;
+      a.wgs_per_img = imgs >= 512 ? 1 : (imgs >= 192 ? 2 : (imgs >= 64 ? 3 : 6));  // >= 256 workgroups once there are 43 frames
+      a.tiles_per_wg = (a.tiles_per_img + a.wgs_per_img - 1) / a.wgs_per_img;
+      a.wgs_per_img = (a.tiles_per_img + a.tiles_per_wg - 1) / a.tiles_per_wg;
+      int wgs = 0;
+      for (int j = 0; j < nj; ++j) {
+        const TrunkJob& J = jobs[j];
+        a.j[j] = C1Job{(const uint8_t*)J.x, J.P + n->seg_off[SEG_W1], J.P + n->seg_off[SEG_B1], n->act1[J.slot], wgs};
+        wgs += J.rows * a.wgs_per_img;
+      }
+      JH_LAUNCH(jh_rb_conv1_fwd_kernel<4>, dim3(wgs), dim3(256), 0, st, a);
+      JH_LAUNCH_CHECK();
+    } else {
+      rc = launch_tgemm(n, "jh_tgemm_conv1_fwd", g, nj, st);
+    }
     if (rc) return rc;
     for (int j = 0; j < nj; ++j) {
       const TrunkJob& J = jobs[j];
@@ -762,6 +999,24 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
     JH_LAUNCH(jh_rb_col2im_kernel, dim3((unsigned)(((int64_t)n_pix * 8 + 255) / 256)), dim3(256), 0, st, n->dcol, n->act1[0], n->dact1, n_pix, 32, n->c2.H,
               n->c2.W, n->c2.OH, n->c2.OW, 4, 4, 2);
     JH_LAUNCH_CHECK();
+  }
+  // uint8 frames in the head's own geometry: the dedicated K-parallel kernel (above); anything else is a GEMM like the other layers
+  static const bool kC1Own = !(getenv("JH_RB_CONV1_WGRAD") && atoi(getenv("JH_RB_CONV1_WGRAD")) == 0);
+  const ConvGeom& c1 = n->c1;
+  const int64_t c1_groups = (int64_t)B * ((n->P1 + 3) / 4);
+  if (kC1Own && n->last_x_u8 && c1.KH == 8 && c1.KW == 8 && c1.S == 4 && c1.W % 4 == 0 && n->Cin % 4 == 0 && c1_groups < (1 << 20)) {
+    constexpr int UN = 5;
+    const int gpi = (n->P1 + 3) / 4, total = (int)c1_groups;
+    int per = (total + kC1Parts - 1) / kC1Parts;
+    per = ((per + 4 * UN - 1) / (4 * UN)) * (4 * UN);  // four K slices per workgroup, whole rounds of UN groups each
+    const int parts = (total + per - 1) / per;
+    const int n_w = 32 * n->Cin * 64, n_all = n_w + 32;
+    JH_LAUNCH(jh_rb_conv1_wgrad_kernel<UN>, dim3(parts), dim3(1024), 0, st, (const uint8_t*)n->last_x, n->dact1, n->c1_part, n->Cin, c1.H, c1.W, c1.OW, n->P1,
+              1.0f / (float)c1.OW, gpi, total, per);
+    JH_LAUNCH_CHECK();
+    JH_LAUNCH(jh_rb_parts_sum_kernel, dim3((n_all + 31) / 32), dim3(256), 0, st, n->c1_part, G + n->seg_off[SEG_W1], G + n->seg_off[SEG_B1], n_w, n_all, parts);
+    JH_LAUNCH_CHECK();
+    return JH_OK;
   }
   g[0] = mk_gemm(32, n->Cin * 64, B * n->P1, op_dense(OP_XCONT, n->dact1, 32), op_conv(OP_NCHW_X, n->last_x, n->last_x_u8, n->c1), G + n->seg_off[SEG_W1],
                  n->Cin * 64, TEPI_NONE, nullptr, nullptr, 0, G + n->seg_off[SEG_B1]);

@@ -40,6 +40,14 @@ struct TGemmBatch {
   int n;
 };
 
+// uint8 / 255 correctly rounded without a division: q = b * (1/255), one Newton correction with exact
+// remainders (verified == b / 255.0f for all 256 byte values; tests compare against the fp32-frame path)
+__device__ __forceinline__ static float u8_unit(uint32_t b) {
+  const float x = (float)b, r = 1.0f / 255.0f;
+  const float q = x * r;
+  return fmaf(fmaf(-q, 255.0f, x), r, q);
+}
+
 // ---- host-side helpers
 inline Opnd op_dense(int mode, const float* p, int ld) {
   Opnd o{};

@@ -8,14 +8,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// uint8 / 255 correctly rounded without a division: q = b * (1/255), one Newton correction with exact
-// remainders (verified == b / 255.0f for all 256 byte values; tests compare against the fp32-frame path)
-__device__ __forceinline__ float u8_unit(uint32_t b) {
-  const float x = (float)b, r = 1.0f / 255.0f;
-  const float q = x * r;
-  return fmaf(fmaf(-q, 255.0f, x), r, q);
-}
-
 __device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
   if (o.mode == OP_KCONT) return ((const float*)o.p)[(size_t)x * o.ld + k];
   if (o.mode == OP_XCONT) return ((const float*)o.p)[(size_t)k * o.ld + x];
