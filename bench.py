@@ -169,7 +169,7 @@ def _latest(pattern):
     return files[-1] if files else None
 
 
-# launch names of the grouped GEMM engine <-> kernel symbols jh_tgemm_kernel<TM, TN, ID> (csrc/jh_tgemm.h: JH_TGEMM_TAGS)
+# launch names of the grouped GEMM engine <-> kernel symbols jh_tgemm_kernel<TM, TN, ID> / jh_tgemm_dma_kernel<ID> (csrc/jh_tgemm.h: JH_TGEMM_TAGS)
 TGEMM_TAGS = ["dense", "conv1_fwd", "conv2_fwd", "conv3_fwd", "head_fwd", "fc_fwd", "stream1_fwd", "stream2_fwd", "stream2_bwd", "stream1_bwd", "fc_bwd",
               "head_bwd", "conv3_bwd", "conv2_bwd", "conv1_bwd", "ppo_fwd_h2", "ppo_bwd", "ppo_bwd_dW1"]
 
@@ -179,7 +179,8 @@ def _kmatch(key, name):
     import re
 
     if key.startswith("jh_tgemm_") and key[len("jh_tgemm_"):] in TGEMM_TAGS:
-        return re.search(r"jh_tgemm_kernel<\d+, ?\d+, ?%d>" % TGEMM_TAGS.index(key[len("jh_tgemm_"):]), name) is not None
+        tag = TGEMM_TAGS.index(key[len("jh_tgemm_"):])  # staged kernel <TM, TN, TAG> or LDS-DMA kernel <TAG>
+        return re.search(r"jh_tgemm_kernel<\d+, ?\d+, ?%d>|jh_tgemm_dma_kernel<%d>" % (tag, tag), name) is not None
     return key in name
 
 

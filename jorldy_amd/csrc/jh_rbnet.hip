@@ -761,7 +761,7 @@ static int rb_trunk(jh_rbnet* n, const TrunkJob* jobs, int nj, int x_u8, hipStre
         a.j[j] = C1Job{(const uint8_t*)J.x, J.P + n->seg_off[SEG_W1], J.P + n->seg_off[SEG_B1], n->act1[J.slot], wgs};
         wgs += J.rows * a.wgs_per_img;
       }
-      JH_LAUNCH(jh_rb_conv1_fwd_kernel<4>, dim3(wgs), dim3(256), 0, st, a);
+      JH_LAUNCH_IDEM("jh_rb_conv1_fwd_kernel", 2.0 * 32 * 256 * (double)imgs * n->P1, jh_rb_conv1_fwd_kernel<4>, dim3(wgs), dim3(256), 0, st, a);
       JH_LAUNCH_CHECK();
     } else {
       rc = launch_tgemm(n, "jh_tgemm_conv1_fwd", g, nj, st);
@@ -1011,7 +1011,7 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
     per = ((per + 4 * UN - 1) / (4 * UN)) * (4 * UN);  // four K slices per workgroup, whole rounds of UN groups each
     const int parts = (total + per - 1) / per;
     const int n_w = 32 * n->Cin * 64, n_all = n_w + 32;
-    JH_LAUNCH(jh_rb_conv1_wgrad_kernel<UN>, dim3(parts), dim3(1024), 0, st, (const uint8_t*)n->last_x, n->dact1, n->c1_part, n->Cin, c1.H, c1.W, c1.OW, n->P1,
+    JH_LAUNCH_IDEM("jh_rb_conv1_wgrad_kernel", 2.0 * 32 * n->Cin * 64 * (double)B * n->P1, jh_rb_conv1_wgrad_kernel<UN>, dim3(parts), dim3(1024), 0, st, (const uint8_t*)n->last_x, n->dact1, n->c1_part, n->Cin, c1.H, c1.W, c1.OW, n->P1,
               1.0f / (float)c1.OW, gpi, total, per);
     JH_LAUNCH_CHECK();
     JH_LAUNCH(jh_rb_parts_sum_kernel, dim3((n_all + 31) / 32), dim3(256), 0, st, n->c1_part, G + n->seg_off[SEG_W1], G + n->seg_off[SEG_B1], n_w, n_all, parts);

@@ -572,6 +572,27 @@ static int tgemm_tag_of(const char* name) {
 
 int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs, int n, hipStream_t st) {
   if (n < 1 || n > kMaxGroup) return jh_fail(JH_ERR_ARG, "tgemm group of %d", n);
+  // A group whose heavy problems could take the LDS-DMA kernel but for some small ones that cannot (the PPO net's backward at 2048
+  // rows: dW2 and dh1 at 1.07 GFLOP each next to three head weight gradients with M = 1 / 3 rows of the [B][8] loss gradient) goes as
+  // two launches, heavy ones first: the second launch's ramp is cheaper than staging 2 GFLOP of operands through registers.
+  if (n > 1) {
+    static const double kSplitFlops = getenv("JH_TGEMM_SPLIT_GFLOP") ? atof(getenv("JH_TGEMM_SPLIT_GFLOP")) * 1e9 : 0.5e9;
+    TGemm fast[kMaxGroup], rest[kMaxGroup];
+    int nf = 0, nr = 0;
+    double fast_flops = 0.0;
+    for (int i = 0; i < n; ++i) {
+      if (probs[i].M > 32 && probs[i].N > 32 && tgemm_dma_ok(&probs[i], 1)) {
+        fast[nf++] = probs[i];
+        fast_flops += 2.0 * probs[i].M * (double)probs[i].N * (double)probs[i].K;
+      } else {
+        rest[nr++] = probs[i];
+      }
+    }
+    if (nf > 0 && nr > 0 && kSplitFlops > 0.0 && fast_flops >= kSplitFlops) {
+      const int rc = jh_tgemm_launch(net_w, name, fast, nf, st);
+      return rc ? rc : jh_tgemm_launch(net_w, name, rest, nr, st);
+    }
+  }
   int maxM = 0, maxN = 0;
   for (int i = 0; i < n; ++i) {
     if (probs[i].M > maxM) maxM = probs[i].M;

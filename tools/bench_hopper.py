@@ -99,8 +99,8 @@ def hopper_leg(iters=10, warmup=3, workers=32, batch=2048, e2e=False, dist=None,
                  "jh_pmb_fwd": 2.0 * n_upd * B * H * (S + H + nh), "jh_pmb_bwd": 2.0 * n_upd * B * H * (2 * H + 3 * nh + S)}
         for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]:
             kern[k] = {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2)}
-            if k in flops:
-                tf = flops[k] / (v[1] * 1e-3) / 1e12
+            if v[2] > 0 or k in flops:  # the grouped GEMM engine declares its own flops per launch; the minibatch kernels are counted here
+                tf = (v[2] if v[2] > 0 else flops[k]) / (v[1] * 1e-3) / 1e12
                 kern[k].update({"TFLOP/s": round(tf, 1), "frac_of_157.3_f32_mfma_peak": round(tf / 157.3, 3)})
     return {
         "workload": f"config.ppo.mujoco Hopper-shaped (BASELINE.json configs[4]), synthetic: S=11, A=3 continuous, W={W} x T=2048 = {M} transitions/iteration/GPU, "
