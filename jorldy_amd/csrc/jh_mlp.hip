@@ -27,20 +27,48 @@ constexpr int kNormBlocks = 256;
 }
 
 // ============================================================================ layer 1 (K = S, tiny)
-// h1[b][j] = relu(sum_s x[r(b)][s] * W1[j][s] + b1[j]);  one lane per (b, j), j fastest.
+// h1[b][j] = relu(sum_s x[r(b)][s] * W1[j][s] + b1[j]).  A lane owns one hidden unit j for kL1Rows rows: its W1 row (S <= 16 floats,
+// 44-byte stride between lanes at S = 11) is fetched ONCE into registers; the workgroup's kL1Rows observation rows are gathered into
+// LDS first (index -> row: two dependent round trips per workgroup instead of per row), the store is coalesced.  One lane per (b, j)
+// re-read the strided W1 row for every output: 13.5-19 us at B = 2048, S = 11 (4 MB of h1 written; a tenth of that is the store).
+constexpr int kL1Rows = 16;
 __global__ void __launch_bounds__(256) jh_mlp_l1_kernel(int B, int S, int H, const float* __restrict__ x,
                                                         const int64_t* __restrict__ idx, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, float* __restrict__ h1) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)B * H) return;
-  const int b = (int)(i / H), j = (int)(i - (int64_t)b * H);
-  const int64_t r = idx ? idx[b] : (int64_t)b;
-  const float* xr = x + r * S;
-  const float* w = W1 + (size_t)j * S;
-  float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc = fmaf(xr[s], w[s], acc);
-  acc += b1[j];
-  h1[i] = acc > 0.f ? acc : 0.f;
+  __shared__ float sx[kL1Rows][16];
+  const int jb = (H + 255) / 256;  // column blocks of 256 hidden units
+  const int rb = blockIdx.x / jb, j = (blockIdx.x - rb * jb) * 256 + threadIdx.x;
+  const int b0 = rb * kL1Rows, nb = b0 + kL1Rows < B ? kL1Rows : B - b0;
+  const bool lds_rows = S <= 16;
+  if (lds_rows) {
+    const int rr = threadIdx.x >> 4, sc = threadIdx.x & 15;  // 256 lanes = 16 rows x 16 columns
+    float v = 0.f;
+    if (rr < nb && sc < S) {
+      const int64_t r = idx ? idx[b0 + rr] : (int64_t)(b0 + rr);
+      v = x[r * S + sc];
+    }
+    sx[rr][sc] = v;
+  }
+  const int jc = j < H ? j : H - 1;
+  float w[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) w[s] = s < S ? W1[(size_t)jc * S + s] : 0.f;
+  const float bias = b1[jc];
+  __syncthreads();
+  if (j >= H) return;
+  for (int rr = 0; rr < nb; ++rr) {
+    float acc = 0.f;
+    if (lds_rows) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (s < S) acc = fmaf(sx[rr][s], w[s], acc);
+    } else {
+      const int64_t r = idx ? idx[b0 + rr] : (int64_t)(b0 + rr);
+      for (int s = 0; s < S; ++s) acc = fmaf(x[r * S + s], W1[(size_t)j * S + s], acc);
+    }
+    acc += bias;
+    h1[(size_t)(b0 + rr) * H + j] = acc > 0.f ? acc : 0.f;
+  }
 }
 
 // ============================================================================ MFMA GEMM
@@ -742,8 +770,8 @@ static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_
 }
 
 static int pponet_l1(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
-  const int64_t bh = (int64_t)B * n->H;
-  JH_LAUNCH(jh_mlp_l1_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, n->S, n->H, d_x, d_idx,
+  const unsigned grid = (unsigned)(((B + kL1Rows - 1) / kL1Rows) * ((n->H + 255) / 256));
+  JH_LAUNCH(jh_mlp_l1_kernel, dim3(grid), dim3(256), 0, st, B, n->S, n->H, d_x, d_idx,
             n->params + n->o_w1, n->params + n->o_b1, n->h1);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -768,7 +796,10 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   JH_ARG(!n->cont || d_head1);
   hipStream_t st = jh_s(stream);
   const int H = n->H;
-  if (jh_pmb_eligible(n, B) && B <= 8192) {
+  // below kFwdTiledRows rows the fused forward (layer 2 + head partials in one latency-oriented launch) wins; from there on layer 2
+  // belongs on the tile engine's LDS-DMA kernel (B = 2048: 41 + 6 us fused + finish vs GEMM + heads kernel, tools/bench_hopper.py)
+  static const int kFwdTiledRows = getenv("JH_PPO_FWD_TILED_ROWS") ? atoi(getenv("JH_PPO_FWD_TILED_ROWS")) : 2048;
+  if (jh_pmb_eligible(n, B) && B < kFwdTiledRows) {
     int rc = pponet_forward_partials(n, B, d_x, d_idx, st);
     if (rc) return rc;
     return jh_pmb_heads_finish(n, B, d_head0, d_head1, d_value, st);
