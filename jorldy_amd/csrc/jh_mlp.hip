@@ -579,7 +579,7 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     JH_HIP(hipMemset(n->fwd_part, 0, part_bytes));  // head slots >= n_out are never written: they must read as 0
     JH_HIP(hipMemset(n->g_all, 0, sizeof(float) * 8 * (size_t)max_rows));
     const size_t slabs = (size_t)(((max_rows < 1024 ? max_rows : 1024) + 15) / 16);
-    JH_HIP(hipMalloc((void**)&n->part_w1, sizeof(float) * slabs * ((size_t)H * S + H)));
+    JH_HIP(hipMalloc((void**)&n->part_w1, sizeof(float) * slabs * ((size_t)H * S + H + 8 * (size_t)H)));
     JH_HIP(hipMalloc((void**)&n->ssq_part, sizeof(float) * ((size_t)(H / 32) * (H / 32) + H / 32 + 1)));
   }
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
@@ -689,15 +689,23 @@ __global__ void __launch_bounds__(256) jh_rowgather_f32_kernel(int B, int S, con
 // dW1[h][s] = sum_b dh1[b][h] x[idx[b]][s], db1[h] = sum_b dh1[b][h] for minibatches on the tiled path (B >= 1024): K = B is long, but
 // N = S (11 for Hopper) is a sliver -- on the 32 x 32 MFMA tile engine that was 0.2-0.6 % of the fp32 matrix peak (25 us at B = 2048) plus
 // a row-gather launch.  It is a column reduction of dh1 weighted by S broadcast values per row: HBM-bound on reading dh1 once.
-//   pass 1  grid (H / 64, slabs): 256 threads = 64 h x 4 row lanes; a slab's observation rows (gathered through idx) sit in LDS;
-//           every thread walks its rows with one coalesced dh1 load + S FMAs, the 4 row lanes combine through LDS -> partial[z][h][S + 1]
-//   pass 2  out[h][s] = sum_z partial[z][h][s] in slab order (deterministic)
+// The head weight gradients dWh[o][h] = sum_b g_all[b][o] h2[b][h] are the same shape (a column reduction of h2 weighted by the <= 8
+// packed head gradients of the row; on the tile engine: an unaligned [B][8] operand on the element-wise fetch path, 19 us at B = 2048)
+// and ride in the same two launches when h2 is given.
+//   pass 1  grid (H / 64, slabs): 256 threads = 64 h x 4 row lanes; a slab's observation rows (gathered through idx) and head-gradient
+//           rows sit in LDS; every thread walks its rows with one coalesced dh1 (+ h2) load + S (+ 8) FMAs, the 4 row lanes combine
+//           through LDS -> partial[z][h][S + 1 (+ 8)]
+//   pass 2  out[h][s] = sum_z partial[z][h][s] in slab order (deterministic); head bias gradients = column sums of g_all (last workgroup)
 template <int SP>
 __global__ void __launch_bounds__(256) jh_ppo_dw1_partial_kernel(int B, int H, int S, int rows_per, const float* __restrict__ dh1, const float* __restrict__ x,
-                                                                 const int64_t* __restrict__ idx, float* __restrict__ partial) {
+                                                                 const int64_t* __restrict__ idx, float* __restrict__ partial, const float* __restrict__ h2,
+                                                                 const float* __restrict__ g8) {
   extern __shared__ float s_dyn[];
-  float* s_x = s_dyn;                       // [rows_per][SP]
-  float* s_acc = s_dyn + (size_t)rows_per * SP;  // [4][64][SP + 1]
+  const bool heads = h2 != nullptr;
+  constexpr int NA = SP + 1 + 8;                               // accumulators per thread: S taps | row sum | 8 head columns
+  float* s_x = s_dyn;                                          // [rows_per][SP]
+  float* s_g = s_dyn + (size_t)rows_per * SP;                  // [rows_per][8]
+  float* s_acc = s_g + (size_t)rows_per * 8;                   // [4][64][NA]
   const int hl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int h = blockIdx.x * 64 + hl;
   const int z = blockIdx.y, b0 = z * rows_per;
@@ -707,10 +715,12 @@ __global__ void __launch_bounds__(256) jh_ppo_dw1_partial_kernel(int B, int H, i
     const int r = i / SP, q = i - r * SP;
     s_x[i] = q < S ? x[(idx ? idx[b0 + r] : (int64_t)(b0 + r)) * S + q] : 0.f;
   }
+  if (heads)
+    for (int i = threadIdx.x; i < nb * 8; i += 256) s_g[i] = g8[(size_t)b0 * 8 + i];
   __syncthreads();
-  float acc[SP + 1];
+  float acc[NA];
 #pragma unroll
-  for (int q = 0; q <= SP; ++q) acc[q] = 0.f;
+  for (int q = 0; q < NA; ++q) acc[q] = 0.f;
   if (h < H) {
     for (int r = rl; r < nb; r += 4) {
       const float g = dh1[(size_t)(b0 + r) * H + h];
@@ -718,53 +728,95 @@ __global__ void __launch_bounds__(256) jh_ppo_dw1_partial_kernel(int B, int H, i
 #pragma unroll
       for (int q = 0; q < SP; ++q) acc[q] = fmaf(g, xr[q], acc[q]);
       acc[SP] += g;
+      if (heads) {
+        const float a2 = h2[(size_t)(b0 + r) * H + h];
+        const float* gr = s_g + (size_t)r * 8;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[SP + 1 + o] = fmaf(a2, gr[o], acc[SP + 1 + o]);
+      }
     }
   }
-  float* mine = s_acc + ((size_t)rl * 64 + hl) * (SP + 1);
+  float* mine = s_acc + ((size_t)rl * 64 + hl) * NA;
 #pragma unroll
-  for (int q = 0; q <= SP; ++q) mine[q] = acc[q];
+  for (int q = 0; q < NA; ++q) mine[q] = acc[q];
   __syncthreads();
   if (rl == 0 && h < H) {
-    float* out = partial + ((size_t)z * H + h) * (S + 1);
+    const int PS = S + 1 + (heads ? 8 : 0);
+    float* out = partial + ((size_t)z * H + h) * PS;
 #pragma unroll
-    for (int q = 0; q <= SP; ++q) {
-      if (q < S || q == SP) {
-        const float v = ((s_acc[((size_t)0 * 64 + hl) * (SP + 1) + q] + s_acc[((size_t)1 * 64 + hl) * (SP + 1) + q]) + s_acc[((size_t)2 * 64 + hl) * (SP + 1) + q]) +
-                        s_acc[((size_t)3 * 64 + hl) * (SP + 1) + q];
-        out[q == SP ? S : q] = v;
+    for (int q = 0; q < NA; ++q) {
+      if (q < S || q == SP || (heads && q > SP)) {
+        const float v = ((s_acc[((size_t)0 * 64 + hl) * NA + q] + s_acc[((size_t)1 * 64 + hl) * NA + q]) + s_acc[((size_t)2 * 64 + hl) * NA + q]) +
+                        s_acc[((size_t)3 * 64 + hl) * NA + q];
+        out[q < S ? q : (q == SP ? S : S + 1 + (q - SP - 1))] = v;
       }
     }
   }
 }
 
-__global__ void __launch_bounds__(256) jh_ppo_dw1_combine_kernel(int H, int S, int slabs, const float* __restrict__ partial, float* __restrict__ dW1, float* __restrict__ db1) {
+struct HeadGradOut {
+  float* dw[8];   // row o of the head weight gradients ([H] each), nullptr beyond n_out
+  float* db[8];
+  const float* g8;  // [B][8] packed head gradients (bias gradients = its column sums)
+  int n_out, B;
+};
+__global__ void __launch_bounds__(256) jh_ppo_dw1_combine_kernel(int H, int S, int slabs, const float* __restrict__ partial, float* __restrict__ dW1,
+                                                                 float* __restrict__ db1, HeadGradOut hg) {
+  const int PS = S + 1 + (hg.n_out > 0 ? 8 : 0);
+  const int n_main = (H * PS + 255) / 256;
+  if ((int)blockIdx.x >= n_main) {  // head bias gradients: 8 columns x 32 row lanes, combined in lane order
+    __shared__ float s_b[32][8];
+    const int o = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    float v = 0.f;
+    for (int b = rl; b < hg.B; b += 32) v += hg.g8[(size_t)b * 8 + o];
+    s_b[rl][o] = v;
+    __syncthreads();
+    if (threadIdx.x < 8 && threadIdx.x < hg.n_out) {
+      float t = s_b[0][threadIdx.x];
+      for (int k = 1; k < 32; ++k) t += s_b[k][threadIdx.x];
+      *hg.db[threadIdx.x] = t;
+    }
+    return;
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * (S + 1)) return;
+  if (i >= H * PS) return;
   float v = 0.f;
-  for (int z = 0; z < slabs; ++z) v += partial[(size_t)z * H * (S + 1) + i];
-  const int h = i / (S + 1), q = i - h * (S + 1);
+#pragma unroll 8
+  for (int z = 0; z < slabs; ++z) v += partial[(size_t)z * H * PS + i];
+  const int h = i / PS, q = i - h * PS;
   if (q < S) dW1[(size_t)h * S + q] = v;
-  else db1[h] = v;
+  else if (q == S) db1[h] = v;
+  else if (q - S - 1 < hg.n_out) hg.dw[q - S - 1][h] = v;
 }
 
-static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
+static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, bool heads, hipStream_t st) {
   const int H = n->H, S = n->S;
   int slabs = (B + 63) / 64;
-  if (slabs > 64) slabs = 64;  // part_w1 holds 64 slabs of H * (S + 1) floats
+  if (slabs > 64) slabs = 64;  // part_w1 holds 64 slabs of H * (S + 1 + 8) floats
   const int rows_per = (B + slabs - 1) / slabs;
   slabs = (B + rows_per - 1) / rows_per;
   const dim3 grid((unsigned)((H + 63) / 64), (unsigned)slabs);
   const int sp = (S + 3) / 4 * 4;
-  const size_t lds = sizeof(float) * ((size_t)rows_per * sp + 4 * 64 * (size_t)(sp + 1));
+  const size_t lds = sizeof(float) * ((size_t)rows_per * (sp + 8) + 4 * 64 * (size_t)(sp + 1 + 8));
   if (lds > 60 * 1024) return jh_fail(JH_ERR_ARG, "dW1 reduction: %zu bytes of LDS for %d rows per slab", lds, rows_per);
-  const double flops = 2.0 * B * (double)H * (S + 1);
-  if (sp == 4) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<4>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
-  else if (sp == 8) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<8>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
-  else if (sp == 12) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<12>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
-  else if (sp == 16) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<16>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1);
+  HeadGradOut hg{};
+  const float* h2 = nullptr;
+  if (heads) {
+    const float* w[8]; const float* b[8];
+    hg.n_out = head_rows(n, w, hg.dw, b, hg.db);
+    hg.g8 = n->g_all; hg.B = B;
+    h2 = n->h2;
+  }
+  const double flops = 2.0 * B * (double)H * (S + 1 + (heads ? hg.n_out : 0));
+  if (sp == 4) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<4>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
+  else if (sp == 8) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<8>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
+  else if (sp == 12) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<12>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
+  else if (sp == 16) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<16>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
   else return jh_fail(JH_ERR_ARG, "dW1 reduction: observation width %d", S);
   JH_LAUNCH_CHECK();
-  JH_LAUNCH(jh_ppo_dw1_combine_kernel, dim3((unsigned)((H * (S + 1) + 255) / 256)), dim3(256), 0, st, H, S, slabs, (const float*)n->part_w1, n->grads + n->o_w1, n->grads + n->o_b1);
+  const int PS = S + 1 + (heads ? 8 : 0);
+  JH_LAUNCH(jh_ppo_dw1_combine_kernel, dim3((unsigned)((H * PS + 255) / 256 + (heads ? 1 : 0))), dim3(256), 0, st, H, S, slabs, (const float*)n->part_w1, n->grads + n->o_w1,
+            n->grads + n->o_b1, hg);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
@@ -853,20 +905,24 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     g[ng++] = mk_gemm(H, H, B, op_dense(OP_XCONT, n->dh2, H), op_dense(OP_XCONT, n->h1, H), n->grads + n->o_w2, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b2);
     // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]
     g[ng++] = mk_gemm(B, H, H, op_dense(OP_KCONT, n->dh2, H), op_dense(OP_XCONT, n->params + n->o_w2, H), n->dh1, H, TEPI_MASK, nullptr, n->h1, H);
-    // head weight gradients: g_all is [B][8] = (head0 A cols | head1 A cols (continuous) | value)
-    g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh0, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh0);
-    int col = A;
-    if (n->cont) {
-      g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh1, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh1);
-      col += A;
+    // head weight gradients (g_all is [B][8] = head0 A cols | head1 A cols (continuous) | value): with the dW1 column reduction below
+    // when that runs, else three more problems of this group
+    static const bool kDw1Gemm = getenv("JH_PPO_DW1_GEMM") && atoi(getenv("JH_PPO_DW1_GEMM")) != 0;  // A/B: round 2's tile-engine form
+    const bool reduce = !kDw1Gemm && S <= 16;
+    if (!reduce) {
+      g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh0, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh0);
+      int col = A;
+      if (n->cont) {
+        g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh1, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh1);
+        col += A;
+      }
+      g[ng++] = mk_gemm(1, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wv, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bv);
     }
-    g[ng++] = mk_gemm(1, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wv, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bv);
     TGemmWorkspace tw;
     tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
     rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd", g, ng, st);
     if (rc) return rc;
-    static const bool kDw1Gemm = getenv("JH_PPO_DW1_GEMM") && atoi(getenv("JH_PPO_DW1_GEMM")) != 0;  // A/B: round 2's tile-engine form
-    if (!kDw1Gemm && S <= 16) return pponet_dw1_reduce(n, B, d_x, d_idx, st);
+    if (reduce) return pponet_dw1_reduce(n, B, d_x, d_idx, true, st);
     JH_LAUNCH(jh_rowgather_f32_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, st, B, S, d_x, d_idx, n->xg);
     JH_LAUNCH_CHECK();
     g[0] = mk_gemm(H, S, B, op_dense(OP_XCONT, n->dh1, H), op_dense(OP_XCONT, n->xg, S), n->grads + n->o_w1, S, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b1);
