@@ -396,8 +396,27 @@ __global__ void __launch_bounds__(256) jh_rb_parts_sum_kernel(const float* __res
 // to the gradient in place like the reference): `partial` holds per-workgroup sums of squares.
 __global__ void __launch_bounds__(256) jh_rb_gradnorm_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ partial) {
   __shared__ float s_red[16];
-  float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+  // 16-byte loads, four of them in flight per lane and round (13 MB of gradients at Ape-X: 18 us with one dword per lane and round)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * 256;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+    a0 = fmaf(v0.x, v0.x, a0); a0 = fmaf(v0.y, v0.y, a0); a0 = fmaf(v0.z, v0.z, a0); a0 = fmaf(v0.w, v0.w, a0);
+    a1 = fmaf(v1.x, v1.x, a1); a1 = fmaf(v1.y, v1.y, a1); a1 = fmaf(v1.z, v1.z, a1); a1 = fmaf(v1.w, v1.w, a1);
+    a2 = fmaf(v2.x, v2.x, a2); a2 = fmaf(v2.y, v2.y, a2); a2 = fmaf(v2.z, v2.z, a2); a2 = fmaf(v2.w, v2.w, a2);
+    a3 = fmaf(v3.x, v3.x, a3); a3 = fmaf(v3.y, v3.y, a3); a3 = fmaf(v3.z, v3.z, a3); a3 = fmaf(v3.w, v3.w, a3);
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = g4[i];
+    a0 = fmaf(v.x, v.x, a0); a0 = fmaf(v.y, v.y, a0); a0 = fmaf(v.z, v.z, a0); a0 = fmaf(v.w, v.w, a0);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
+    const float v = g[4 * n4 + threadIdx.x];
+    a0 = fmaf(v, v, a0);
+  }
+  float acc = (a0 + a1) + (a2 + a3);
   acc = jh_block_reduce(acc, s_red, JhAdd(), 0.f);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
