@@ -125,7 +125,7 @@ def cpu_baseline(iters, W, T):
         "cores": cores if best is seq else max(cores, W),
         "kind": "port",
         # the reference tree only exists in the build container (never on a GPU box): what is timed here is the port, which
-        # tests/test_oracle_golden.py pins to the reference's own learn() (losses / weights 1e-6) and tools/cpu_reference_timing.py
+        # tests/test_oracle_golden.py pins to the reference's own learn() (losses / weights 1e-6) and oracle/time_reference_vs_port.py
         # times side by side with the REAL reference where that tree exists (profiles/r03_cpu_reference_vs_port.json)
         "reference_present": os.path.isdir("/root/reference"),
         "sample": f"{iters} sync iterations of config.ppo.cartpole (W={W}, T={T}, 3 epochs x 4 minibatches of 256) per variant; value = the faster "

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""The REAL reference vs the port on the same host cores (build container only: needs /root/reference; no GPU).
+"""The REAL reference vs the port on the same host cores (build container only: needs /root/reference; no GPU).  Test infrastructure like the rest of oracle/: not imported by the product.
 
 bench.py's `cpu_baseline` times oracle/ppo_port.py (kind "port") because the reference tree does not exist on the GPU box.
 This script shows what that stands for: PPO.learn of the unmodified reference (config.ppo.cartpole: 1024 transitions, 3 epochs x 4
 minibatches of 256, hidden 512) and PPOPort.process on the same transitions, same torch thread count, alternating; and
 Rainbow.learn (config.rainbow.atari shapes) vs RainbowPort.learn.  -> JSON (committed as profiles/r03_cpu_reference_vs_port.json).
 
-    python tools/cpu_reference_timing.py [--threads 8] [--iters 10]
+    python oracle/time_reference_vs_port.py [--threads 8] [--iters 10]
 """
 import argparse
 import json
