@@ -404,9 +404,11 @@ __device__ __forceinline__ void tgemm_dma_issue(const DmaOp& d, int c, unsigned 
   tgemm_dma16(s1, lds + 4096u);
 }
 
-template <bool AX, bool BX>
+// RS: this wave accumulates the row sums of A (bias gradients).  A template parameter, not a run-time flag: as a flag hipcc computes
+// the sums in every wave and selects (36 VALU instructions per chunk next to 32 MFMAs: the forward launches lost 8 % to it).
+template <bool AX, bool BX, bool RS>
 __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float* sB, const DmaOp& da, const DmaOp& db, int nc, int wid, int r, int kq, int wm,
-                                                   int wn, f32x4 (&acc)[2][2], float (&rs)[2], bool want_rs) {
+                                                   int wn, f32x4 (&acc)[2][2], float (&rs)[2]) {
   constexpr int TM = 2, TN = 2, BK = 32, TILE = 64 * BK;
   const unsigned ldsA = (unsigned)(uintptr_t)sA + (unsigned)wid * 1024u, ldsB = (unsigned)(uintptr_t)sB + (unsigned)wid * 1024u;
   // read offsets (floats) of this lane inside a tile; see the layouts above
@@ -455,7 +457,7 @@ __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float*
           const float4 q = *reinterpret_cast<const float4*>(A + ao[i] + blk);
           a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
         }
-        if (want_rs && wn == 0) rs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
+        if (RS) rs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -524,13 +526,15 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
   float rs[TM] = {0.f, 0.f};
   const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
   const int nc = (kend - kbeg) / BK;
-  if (a_x) {
-    if (b_x) tgemm_dma_mainloop<true, true>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
-    else tgemm_dma_mainloop<true, false>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
+#define JH_DMA_LOOP(AX, BX, RS) tgemm_dma_mainloop<AX, BX, RS>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs)
+  if (want_rs && wn == 0) {  // wave-uniform
+    if (a_x) { if (b_x) JH_DMA_LOOP(true, true, true); else JH_DMA_LOOP(true, false, true); }
+    else { if (b_x) JH_DMA_LOOP(false, true, true); else JH_DMA_LOOP(false, false, true); }
   } else {
-    if (b_x) tgemm_dma_mainloop<false, true>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
-    else tgemm_dma_mainloop<false, false>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, want_rs);
+    if (a_x) { if (b_x) JH_DMA_LOOP(true, true, false); else JH_DMA_LOOP(true, false, false); }
+    else { if (b_x) JH_DMA_LOOP(false, true, false); else JH_DMA_LOOP(false, false, false); }
   }
+#undef JH_DMA_LOOP
   if (want_rs && wn == 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {

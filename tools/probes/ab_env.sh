@@ -3,7 +3,7 @@
 var=$1; a=$2; b=$3; reps=${4:-3}
 for rep in $(seq $reps); do
   for v in $a $b; do
-    env $var=$v python bench.py --steps 100 --warmup 10 --no-rainbow --no-cpu-baseline --no-roofline 2>/dev/null | grep "^{" > /tmp/l.json
+    env $var=$v python bench.py --steps 100 --warmup 10 --no-rainbow --no-cpu-baseline --no-roofline --no-hopper --no-apex 2>/dev/null | grep "^{" > /tmp/l.json
     python - $var $v <<'PY'
 import json, sys
 d = json.loads(open("/tmp/l.json").readline())

@@ -5,7 +5,7 @@ reps=$1; shift
 for rep in $(seq $reps); do
   for spec in "$@"; do
     name=${spec%%:*}; envs=${spec#*:}
-    env $envs python bench.py --steps 100 --warmup 10 --no-rainbow --no-cpu-baseline --no-roofline 2>/dev/null | grep "^{" > /tmp/l.json
+    env $envs python bench.py --steps 100 --warmup 10 --no-rainbow --no-cpu-baseline --no-roofline --no-hopper --no-apex 2>/dev/null | grep "^{" > /tmp/l.json
     python - "$name" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/l.json").readline())
