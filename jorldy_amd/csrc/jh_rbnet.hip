@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(1024) jh_rb_conv1_wgrad_kernel(const uint8_t* 
                                                                  int H, int W, int OW, int P, float inv_ow, int groups_per_img, int total_groups,
                                                                  int groups_per_wg) {
   __shared__ float s_acc[3][4][34][64];  // [slice - 1][channel wave][32 accumulator registers + 2 row sums][lane]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
   const int cw = wid & 3, slice = wid >> 2;
   const int per_slice = groups_per_wg / 4;  // the host keeps groups_per_wg a multiple of 4 UN
   const int g0 = blockIdx.x * groups_per_wg + slice * per_slice;
@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(1024) jh_rb_conv1_wgrad_kernel(const uint8_t* 
   const int NW = Cin * 64, n_all = 32 * NW + 32;
   float* mine = part + (size_t)blockIdx.x * n_all;
   const int ky = r >> 1, kx0 = 4 * (r & 1);
+  const size_t CHW = (size_t)Cin * H * W;
   for (int c = cw; c < Cin; c += 4) {
     f32x4 acc[2][4];
 #pragma unroll
@@ -291,33 +292,52 @@ __global__ void __launch_bounds__(1024) jh_rb_conv1_wgrad_kernel(const uint8_t* 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float rs[2] = {0.f, 0.f};
+    // The walk over (frame b, 4-pixel group pg) is incremental: one division per wave and channel, then adds and two compares per
+    // group (P % 4 == 0 and OW >= 4: the host checks).  Addresses as (b, pixel) -> offsets took 370 VALU instructions per round of 5
+    // groups next to 40 MFMAs; the kernel ran at the VALU's pace (62 us at B = 512), not the matrix core's.
+    int b = g0 / groups_per_img, pg = g0 - b * groups_per_img;  // uniform
+    int oy, ox;                                                 // this lane's pixel (kq-th of the group)
+    {
+      const int p = pg * 4 + kq;
+      oy = (int)(((float)p + 0.5f) * inv_ow);
+      ox = p - oy * OW;
+    }
+    const uint8_t* xl = x + (size_t)c * H * W + (size_t)ky * W + kx0;  // lane-constant part of the frame address
+    const float* dyl = dY + (size_t)kq * 32 + r;
+    auto fetch = [&](float (&a)[2], uint32_t& xw) {
+      const float* dy = dyl + ((size_t)b * P + (size_t)pg * 4) * 32;
+      a[0] = dy[0];
+      a[1] = dy[16];
+      xw = *reinterpret_cast<const uint32_t*>(xl + (size_t)b * CHW + (size_t)(4 * oy) * W + 4 * ox);
+      ox += 4;
+      if (ox >= OW) { ox -= OW; oy += 1; }
+      if (++pg == groups_per_img) { pg = 0; ++b; oy = 0; ox = kq; }
+    };
+    auto consume = [&](const float (&a)[2], uint32_t xw) {
+      const float bf[4] = {u8_unit(xw & 255u), u8_unit((xw >> 8) & 255u), u8_unit((xw >> 16) & 255u), u8_unit(xw >> 24)};
+      rs[0] += a[0];
+      rs[1] += a[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    int gi = g0;
 #pragma unroll 1
-    for (int gi = g0; gi < g1; gi += UN) {
+    for (; gi + UN <= g1; gi += UN) {
       float a[UN][2];
       uint32_t xw[UN];
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int g = gi + u < g1 ? gi + u : g1 - 1;  // clamped: uniform control flow, the operand is zeroed instead
-        const int b = g / groups_per_img;
-        const int p = (g - b * groups_per_img) * 4 + kq, pc = p < P ? p : P - 1;
-        const int oy = (int)(((float)pc + 0.5f) * inv_ow), ox = pc - oy * OW;
-        const float* dy = dY + ((size_t)b * P + pc) * 32 + r;
-        const bool ok = gi + u < g1 && p < P;
-        const float a0 = dy[0], a1 = dy[16];
-        a[u][0] = ok ? a0 : 0.f;
-        a[u][1] = ok ? a1 : 0.f;
-        xw[u] = *reinterpret_cast<const uint32_t*>(x + (((size_t)b * Cin + c) * H + 4 * oy + ky) * W + 4 * ox + kx0);
-      }
+      for (int u = 0; u < UN; ++u) fetch(a[u], xw[u]);
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const float bf[4] = {u8_unit(xw[u] & 255u), u8_unit((xw[u] >> 8) & 255u), u8_unit((xw[u] >> 16) & 255u), u8_unit(xw[u] >> 24)};
-        rs[0] += a[u][0];
-        rs[1] += a[u][1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], bf[j], acc[i][j], 0, 0, 0);
-      }
+      for (int u = 0; u < UN; ++u) consume(a[u], xw[u]);
+    }
+#pragma unroll 1
+    for (; gi < g1; ++gi) {  // ragged end of the last workgroup's run
+      float a[2];
+      uint32_t xw;
+      fetch(a, xw);
+      consume(a, xw);
     }
     if (slice > 0) {
 #pragma unroll
@@ -1023,7 +1043,7 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
   static const bool kC1Own = !(getenv("JH_RB_CONV1_WGRAD") && atoi(getenv("JH_RB_CONV1_WGRAD")) == 0);
   const ConvGeom& c1 = n->c1;
   const int64_t c1_groups = (int64_t)B * ((n->P1 + 3) / 4);
-  if (kC1Own && n->last_x_u8 && c1.KH == 8 && c1.KW == 8 && c1.S == 4 && c1.W % 4 == 0 && n->Cin % 4 == 0 && c1_groups < (1 << 20)) {
+  if (kC1Own && n->last_x_u8 && c1.KH == 8 && c1.KW == 8 && c1.S == 4 && c1.W % 4 == 0 && n->Cin % 4 == 0 && n->P1 % 4 == 0 && c1.OW >= 4 && c1_groups < (1 << 20)) {
     constexpr int UN = 5;
     const int gpi = (n->P1 + 3) / 4, total = (int)c1_groups;
     int per = (total + kC1Parts - 1) / kC1Parts;
