@@ -470,20 +470,34 @@ __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
     if (on) {
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const bool wide = a.hp_ld == 8;
-      for (int t0 = 0; t0 < a.hp_tiles; t0 += 8) {  // tile order: deterministic; 8-16 loads in flight per batch
-        float4 q0[8], q1[8];
+      if (!wide) {  // <= 4 head outputs (CartPole: 2 logits + value): 16 tiles' float4 per round trip, sums in tile order
+        for (int t0 = 0; t0 < a.hp_tiles; t0 += 16) {
+          float4 q0[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = t0 + u < a.hp_tiles ? t0 + u : a.hp_tiles - 1;
-          const float4* q = reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * a.hp_ld);
-          q0[u] = q[0];
-          if (wide) q1[u] = q[1];
+          for (int u = 0; u < 16; ++u) {
+            const int t = t0 + u < a.hp_tiles ? t0 + u : a.hp_tiles - 1;
+            q0[u] = *reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (t0 + u < a.hp_tiles) { z[0] += q0[u].x; z[1] += q0[u].y; z[2] += q0[u].z; z[3] += q0[u].w; }
         }
+      } else {
+        for (int t0 = 0; t0 < a.hp_tiles; t0 += 8) {  // tile order: deterministic; 16 loads in flight per batch
+          float4 q0[8], q1[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (t0 + u < a.hp_tiles) {
-            z[0] += q0[u].x; z[1] += q0[u].y; z[2] += q0[u].z; z[3] += q0[u].w;
-            if (wide) { z[4] += q1[u].x; z[5] += q1[u].y; z[6] += q1[u].z; z[7] += q1[u].w; }
+          for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u < a.hp_tiles ? t0 + u : a.hp_tiles - 1;
+            const float4* q = reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * 8);
+            q0[u] = q[0];
+            q1[u] = q[1];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (t0 + u < a.hp_tiles) {
+              z[0] += q0[u].x; z[1] += q0[u].y; z[2] += q0[u].z; z[3] += q0[u].w;
+              z[4] += q1[u].x; z[5] += q1[u].y; z[6] += q1[u].z; z[7] += q1[u].w;
+            }
           }
         }
       }

@@ -4,7 +4,7 @@ reps=${1:-3}
 for rep in $(seq $reps); do
   for v in old new; do
     cp ab/lib_$v.so jorldy_amd/csrc/libjorldy_hip.so
-    python bench.py --steps 100 --warmup 10 --no-rainbow --no-cpu-baseline 2>/dev/null | grep "^{" > /tmp/l.json
+    python bench.py --steps 100 --warmup 10 --no-rainbow --no-cpu-baseline --no-hopper --no-apex 2>/dev/null | grep "^{" > /tmp/l.json
     python - $v <<'PY'
 import json, sys
 d = json.loads(open("/tmp/l.json").readline())
