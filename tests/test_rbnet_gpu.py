@@ -54,6 +54,8 @@ CASES = [
     ("mlp", 6, 2, 11, 64, 5),           # S not a multiple of 4, ragged batch
     ("cnn", (4, 44, 52), 3, 51, 32, 8),  # non-square image, 2x3 feature map
     ("cnn", (4, 84, 84), 4, 51, 512, 32),  # config.rainbow.atari shapes
+    ("cnn", (4, 48, 52), 2, 7, 32, 6),   # 11 x 12 = 132 conv1 pixels: not a multiple of the forward kernel's 16-pixel tiles
+    ("cnn", (4, 44, 48), 2, 7, 32, 5),   # 10 x 11 = 110 conv1 pixels: not a multiple of 4 -> conv1 weight gradient on the tile engine
 ]
 
 
