@@ -789,15 +789,26 @@ __global__ void __launch_bounds__(256) jh_ppo_dw1_combine_kernel(int H, int S, i
   else if (q - S - 1 < hg.n_out) hg.dw[q - S - 1][h] = v;
 }
 
-static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, bool heads, hipStream_t st) {
-  const int H = n->H, S = n->S;
+// slabs / rows per slab / dynamic LDS bytes of the column reduction for B rows (part_w1 holds 64 slabs of H * (S + 1 + 8) floats)
+static size_t pponet_dw1_plan(int B, int S, int* slabs_out, int* rows_per_out) {
   int slabs = (B + 63) / 64;
-  if (slabs > 64) slabs = 64;  // part_w1 holds 64 slabs of H * (S + 1 + 8) floats
+  if (slabs > 64) slabs = 64;
   const int rows_per = (B + slabs - 1) / slabs;
   slabs = (B + rows_per - 1) / rows_per;
+  const int sp = (S + 3) / 4 * 4;
+  if (slabs_out) *slabs_out = slabs;
+  if (rows_per_out) *rows_per_out = rows_per;
+  return sizeof(float) * ((size_t)rows_per * (sp + 8) + 4 * 64 * (size_t)(sp + 1 + 8));
+}
+// the reduction keeps a slab's observation and head-gradient rows in LDS: beyond ~24 k rows the tile engine takes over again
+static bool pponet_dw1_reduce_fits(int B, int S) { return S <= 16 && pponet_dw1_plan(B, S, nullptr, nullptr) <= 60 * 1024; }
+
+static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, bool heads, hipStream_t st) {
+  const int H = n->H, S = n->S;
+  int slabs, rows_per;
+  const size_t lds = pponet_dw1_plan(B, S, &slabs, &rows_per);
   const dim3 grid((unsigned)((H + 63) / 64), (unsigned)slabs);
   const int sp = (S + 3) / 4 * 4;
-  const size_t lds = sizeof(float) * ((size_t)rows_per * (sp + 8) + 4 * 64 * (size_t)(sp + 1 + 8));
   if (lds > 60 * 1024) return jh_fail(JH_ERR_ARG, "dW1 reduction: %zu bytes of LDS for %d rows per slab", lds, rows_per);
   HeadGradOut hg{};
   const float* h2 = nullptr;
@@ -908,7 +919,7 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     // head weight gradients (g_all is [B][8] = head0 A cols | head1 A cols (continuous) | value): with the dW1 column reduction below
     // when that runs, else three more problems of this group
     static const bool kDw1Gemm = getenv("JH_PPO_DW1_GEMM") && atoi(getenv("JH_PPO_DW1_GEMM")) != 0;  // A/B: round 2's tile-engine form
-    const bool reduce = !kDw1Gemm && S <= 16;
+    const bool reduce = !kDw1Gemm && pponet_dw1_reduce_fits(B, S);
     if (!reduce) {
       g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh0, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh0);
       int col = A;
