@@ -345,9 +345,10 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
 // the wait for the registers to fill before the LDS store; kDmaBufs 16 KB buffers (A | B, 32 k each) keep kDmaBufs - 1 chunks in flight
 // under the MFMAs, with ONE barrier per chunk.
 // LDS tiles are UNPADDED and lane-linear (the DMA writes 64 lanes x 16 bytes back to back):
-//   k-contiguous operand  [x][32 k]: the 16-byte k-blocks of a row are XOR-swizzled with (x & 7) on the GLOBAL side (lane p of an
-//     instruction fetches block (p & 7) ^ (x & 7) and lands in block p & 7), which spreads a wave's ds_read_b128 of one k over all
-//     bank groups the way the 36-float row stride of the staged kernel does;
+//   k-contiguous operand  [x][32 k]: the 16-byte k-blocks of a row are XOR-swizzled with (x >> 1) & 7 on the GLOBAL side (lane p of an
+//     instruction fetches block (p & 7) ^ ((x >> 1) & 7) and lands in block p & 7).  A ds_read_b128 is served 16 lanes = 16 rows at a
+//     time from 16 slots of 16 bytes; with 128-byte rows, row x sits in slot 8 (x & 1) + block: the key (x >> 1) & 7 gives the 16 rows of
+//     a group 16 distinct slots.  (The first version keyed on x & 7: rows x and x + 8 shared a slot -- every read 2-way conflicted.)
 //   x-contiguous operand  [32 k][64 x]: the 16-byte x-blocks of a k row are XOR-swizzled with ((k >> 2) & 3) << 2; MFMA step c of a
 //     16-wide k block takes k = 4 kq + c from lane group kq (the same order the k-contiguous float4 gives), so the four lane groups
 //     read rows 4 apart, the swizzle is the per-lane constant kq << 2 and the 64 ds_read_b32 of a step hit 64 distinct banks.
@@ -384,7 +385,7 @@ __device__ __forceinline__ DmaOp tgemm_dma_operand(const Opnd& o, int X, int x0,
   for (int i = 0; i < 2; ++i) {
     const int p = (i * 4 + wid) * 64 + lane;
     if (!xfast) {
-      const int row = p >> 3, kb = 4 * ((p & 7) ^ (row & 7));
+      const int row = p >> 3, kb = 4 * ((p & 7) ^ ((row >> 1) & 7));
       const int x = x0 + row, xc = x < X ? x : X - 1;  // rows beyond the matrix fetch a valid row: their results are never stored
       d.kin[i] = kb;
       d.src[i] = (const float*)o.p + (conv ? (size_t)o.pix_tab[xc] : (size_t)xc * o.ld + kbeg + kb);
@@ -447,7 +448,7 @@ __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float*
 #pragma unroll
     for (int kb = 0; kb < BK; kb += 16) {
       float a[TM][4], b[TN][4];
-      const int blk = (((kb >> 2) + kq) ^ (r & 7)) * 4;
+      const int blk = (((kb >> 2) + kq) ^ ((r >> 1) & 7)) * 4;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (AX) {
