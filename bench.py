@@ -385,6 +385,38 @@ def apex_leg(actors, updates):
             "lib_kernels": r.get("lib_kernels")}
 
 
+class _Ahead:
+    """A second host thread for work that only ENQUEUES (JH_EARLY_COMMIT=2): one callable at a time, errors re-raised in join()."""
+
+    def __init__(self, device):
+        import threading
+
+        self.req, self.done, self.fn, self.err = threading.Event(), threading.Event(), None, None
+        threading.Thread(target=self._run, args=(device,), daemon=True).start()
+
+    def _run(self, device):
+        torch.cuda.set_device(device)  # the device is per thread
+        while True:
+            self.req.wait()
+            self.req.clear()
+            try:
+                self.fn()
+            except BaseException as e:  # noqa: BLE001 -- handed to the submitting thread
+                self.err = e
+            self.done.set()
+
+    def submit(self, fn):
+        self.fn = fn
+        self.done.clear()
+        self.req.set()
+
+    def join(self):
+        self.done.wait()
+        if self.err is not None:
+            err, self.err = self.err, None
+            raise err
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -436,7 +468,12 @@ def main():
     # loop.  Measured (tools/probes/ab_multi.sh, 3 alternating pairs): the GPU-side gaps all but vanish (19 us per iteration against 114),
     # but the host work that used to sit at the rollout's END (commit + graph launch, ~45 us with the GPU idle) now sits at its START, where
     # the GPU is just as idle -- 1.27-1.30 ms per step against 1.23-1.27: off by default
-    early = hasattr(collector, "begin") and agent.backend == "native" and os.environ.get("JH_EARLY_COMMIT", "0") == "1"
+    early_mode = os.environ.get("JH_EARLY_COMMIT", "0")
+    early = hasattr(collector, "begin") and agent.backend == "native" and early_mode in ("1", "2")
+    # JH_EARLY_COMMIT=2: the learner's launches are enqueued by a SECOND host thread while this one is already inside the rollout's host
+    # loop (both the graph launch and jh_collector_loop release the GIL; the loop makes no HIP calls): the ~45 us move off the critical
+    # path instead of from its end to its start
+    ahead = _Ahead(local_rank) if early and early_mode == "2" else None
 
     def one_iteration(last=False):
         """last: no acting kernel is enqueued ahead for an iteration that does not follow (the fences below would wait for it)."""
@@ -446,8 +483,13 @@ def main():
             # acting kernel / the gated commit): the learner starts the instant the rollout ends
             collector.begin(T)
             step += T
-            agent.process_begin(step)
-            collector.loop()
+            if ahead is not None:
+                ahead.submit(lambda s=step: agent.process_begin(s))
+                collector.loop()
+                ahead.join()
+            else:
+                agent.process_begin(step)
+                collector.loop()
             if prelaunch and not last:
                 collector.arm_prelaunch(T)
             result = agent.process_end()
