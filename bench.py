@@ -417,8 +417,27 @@ class _Ahead:
             raise err
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher (RANK unset): re-exec under torch.distributed.run, one rank per GPU, rendezvous
+    on 127.0.0.1 at a free port -- the same command line the driver's launcher form uses (the old assert died before
+    touching a GPU when the driver issued `--gpus 8` the way it issues `--gpus 1`)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's hosts only support dmabuf IPC (RCCL needs it across processes)
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        _self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -436,7 +455,8 @@ def main():
         backend = os.environ.get("JH_DIST_BACKEND", "nccl")
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; pass --gpus {world} (or run `python bench.py --gpus N` and let it launch itself)")
 
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
@@ -459,7 +479,7 @@ def main():
     if dist is not None:
         attach_data_parallel(agent, dist)
     env = ops.CartPoleVec(W, seed=100 + rank)
-    collector = (VecCollector if args.python_collector or agent.backend != "native" else NativeCollector)(env, agent, W)
+    collector = (VecCollector if args.python_collector else NativeCollector)(env, agent, W)
 
     step = 0
 

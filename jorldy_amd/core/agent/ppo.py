@@ -5,10 +5,14 @@ import torch
 
 from ... import np_rng, ops
 from ..buffer import RolloutBuffer
-from ..buffer.base import h2d_small
 from ..network import Network
 from ..optimizer import Optimizer
 from .base import BaseAgent
+
+
+NATIVE_ELIGIBLE = ("PPO runs on libjorldy_hip only: network in {discrete_policy_value, continuous_policy_value}, head='mlp', int state_size, "
+                   "hidden_size % 16 == 0, optim_config name 'adam' without weight_decay / amsgrad, and action_size + 1 (discrete) or "
+                   "2 * action_size + 1 (continuous) <= 8 head outputs (config.ppo.cartpole, config.ppo.mujoco and their shapes)")
 
 
 class PPO(BaseAgent):
@@ -23,19 +27,17 @@ class PPO(BaseAgent):
         Adam on flat buckets            [backend "native"]
       the 5 `.item()` syncs per minibatch                  one D2H of a [n_updates, 8] stats array
 
-    backend = "native": everything above is hand-written kernels; the whole learn() is captured in
-              one hipGraph after the first call (single-GPU).  Needs head="mlp", an int state_size
-              and the Adam optimizer (what configs ppo.cartpole / ppo.mujoco use).
-    backend = "torch":  encoder fwd/bwd, clip and the optimizer are torch ops on the same stream
-              (any head / optimizer); losses, GAE and buffers are still the HIP kernels.
-    backend = "auto" (default): native when eligible.
+    Everything above is hand-written kernels; the whole learn() is captured in one hipGraph after the first call.
+    There is ONE backend (libjorldy_hip): head="mlp", an int state_size, Adam without weight decay / amsgrad and <= 8 head
+    outputs -- what configs ppo.cartpole / ppo.mujoco use.  Any other configuration raises (NATIVE_ELIGIBLE below) instead of
+    silently switching to library kernels; the reference agent keeps working for those.
     Constructor arguments, `act`, `process`, result keys, checkpoint format are the reference's.
     """
 
     def __init__(self, state_size, action_size, hidden_size=512, network="discrete_policy_value", head="mlp",
                  optim_config={"name": "adam"}, gamma=0.99, use_standardization=True, run_step=1e6, lr_decay=True,
                  device=None, batch_size=32, n_step=128, n_epoch=3, _lambda=0.95, epsilon_clip=0.1, vf_coef=1.0,
-                 ent_coef=0.01, clip_grad_norm=1.0, num_workers=1, backend="auto", use_graph=True, seed=0, **kwargs):
+                 ent_coef=0.01, clip_grad_norm=1.0, num_workers=1, backend=None, use_graph=True, seed=0, **kwargs):
         self.device = self._require_gpu(device)
         self.action_type = network.split("_")[0]
         assert self.action_type in ["continuous", "discrete"]
@@ -66,12 +68,12 @@ class PPO(BaseAgent):
             and not self.optimizer.defaults.get("amsgrad", False) and self.optimizer.defaults.get("weight_decay", 0) == 0
             and (2 * action_size + 1 if self.action_type == "continuous" else action_size + 1) <= 8
         )
-        assert backend in ("auto", "native", "torch")
-        if backend == "native" and not eligible:
-            raise ValueError("backend='native' needs head='mlp', an int state_size, Adam without weight decay and <= 8 head outputs")
-        self.backend = "native" if (eligible and backend != "torch") else "torch"
-        if backend == "auto" and not eligible:
-            self._warn_torch_backend(f"network={network!r}, head={head!r}, state_size={state_size!r}, hidden_size={hidden_size}, optim={optim_config.get('name', 'adam')!r} is outside the native policy-value net")
+        if backend not in (None, "auto", "native"):
+            raise ValueError(f"backend={backend!r}: jorldy_amd has one backend (libjorldy_hip); the torch mirror of round 1-3 is test infrastructure now (tests/mirror)")
+        if not eligible:
+            raise ValueError(f"{NATIVE_ELIGIBLE}; got network={network!r}, head={head!r}, state_size={state_size!r}, hidden_size={hidden_size}, "
+                             f"optim_config={optim_config!r}, action_size={action_size}")
+        self.backend = "native"
         self.use_graph = use_graph
         # four- / five-launch minibatch update (jh_pponet_ppo_update) for minibatches < 1024 rows; JH_FUSED_UPDATE=0
         # keeps the forward / loss / backward / Adam calls separate (same results; used by the A/B in bench)
@@ -92,8 +94,7 @@ class PPO(BaseAgent):
         self._lr_word = None
         # index lists of the next learn() drawn ahead on a copy of np.random's state (np_rng.Predraw); JH_PPO_PREDRAW=0: draw inside learn()
         self._predraw = np_rng.Predraw() if os.environ.get("JH_PPO_PREDRAW", "1") == "1" else None
-        if self.backend == "native":
-            self._init_native(int(state_size), int(action_size), int(hidden_size), seed)
+        self._init_native(int(state_size), int(action_size), int(hidden_size), seed)
 
     # ---------------------------------------------------------------------------------- native engine
     def _init_native(self, S, A, H, seed, max_rows=4096):
@@ -141,25 +142,16 @@ class PPO(BaseAgent):
     # ---------------------------------------------------------------------------------- act
     @torch.no_grad()
     def act(self, state, training=True):
-        if self._net is not None and not isinstance(state, list):
-            self._grow_native(len(state))
-            obs = np.asarray(state, dtype=np.float32)
-            return {"action": self._net.act_discrete(obs, training) if self.action_type == "discrete" else self._net.act_continuous(obs, training)}
-        self.network.train(training)
-        if self.action_type == "continuous":
-            mu, std, _ = self.network(self.as_tensor(state))
-            z = torch.normal(mu, std) if training else mu
-            action = torch.tanh(z)
-        else:
-            pi, _ = self.network(self.as_tensor(state))
-            action = torch.multinomial(pi, 1) if training else torch.argmax(pi, dim=-1, keepdim=True)
-        return {"action": action.cpu().numpy()}
+        """ppo.py:55-69 on the native acting kernels (sampling included: Philox stream `seed`)."""
+        if isinstance(state, list):
+            raise NotImplementedError("PPO: list-valued (multimodal) observations are outside the native policy-value net")
+        self._grow_native(len(state))
+        obs = np.asarray(state, dtype=np.float32)
+        return {"action": self._net.act_discrete(obs, training) if self.action_type == "discrete" else self._net.act_continuous(obs, training)}
 
     # ---------------------------------------------------------------------------------- learn
     def learn(self):
-        if self._net is not None:
-            return self._learn_native()
-        return self._learn_torch()
+        return self._learn_native()
 
     def _result(self, s, n_upd):
         return {
@@ -170,58 +162,6 @@ class PPO(BaseAgent):
             "min_prob": float(s[:n_upd, 5].min()),
             "mean_ret": float(s[n_upd, 0]),
         }
-
-    def _learn_torch(self):
-        tr = self.memory.sample()  # float32 device tensors, arrival (worker-major) order
-        if isinstance(tr["state"], list):
-            raise NotImplementedError("PPO: list-valued (multimodal) observations are stored and sampled by the buffers, but the minibatch "
-                                      "loop gathers rows of ONE state tensor; use a single observation tensor")
-        state, action, reward = tr["state"], tr["action"], tr["reward"]
-        next_state, done = tr["next_state"], tr["done"]
-        M = reward.shape[0]
-        cont = self.action_type == "continuous"
-        with torch.no_grad():  # ppo.py:83-110
-            if cont:
-                mu_raw, ls_raw, value = self.network.raw(state)
-                log_prob_old = ops.logp_continuous(mu_raw, ls_raw, action)
-            else:
-                logits, value = self.network.raw(state)
-                log_prob_old = ops.logp_discrete(logits, action)
-            next_value = self.network.raw(next_state)[-1]
-            adv, ret = ops.gae(reward, done, value, next_value, self.n_step, self.gamma, self._lambda, self.use_standardization)
-            value = value.contiguous()
-            mean_ret_t = ret.mean()
-        n_mb = (M + self.batch_size - 1) // self.batch_size
-        n_upd = self.n_epoch * n_mb
-        if self._stats is None or self._stats.shape[0] < n_upd + 1:
-            self._stats = torch.zeros(n_upd + 1, 8, dtype=torch.float32, device=self.device)
-        stats = self._stats
-        idxs = np.arange(M)
-        k = 0
-        for _ in range(self.n_epoch):
-            np.random.shuffle(idxs)  # ppo.py:118 -- same global-RNG call as the reference
-            idxs_d = h2d_small(idxs.astype(np.int64), self.device)
-            for offset in range(0, M, self.batch_size):
-                idx = idxs_d[offset : offset + self.batch_size]
-                _state = state.index_select(0, idx)
-                if cont:
-                    mu_raw, ls_raw, value_pred = self.network.raw(_state)
-                    g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu_raw.detach(), ls_raw.detach(), value_pred.detach(), idx, action, adv, ret, value, log_prob_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=stats[k])
-                    outs, grads = [mu_raw, ls_raw, value_pred], [g_mu, g_ls, g_v]
-                else:
-                    logits, value_pred = self.network.raw(_state)
-                    g_z, g_v, _ = ops.ppo_loss_discrete(logits.detach(), value_pred.detach(), idx, action, adv, ret, value, log_prob_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=stats[k])
-                    outs, grads = [logits, value_pred], [g_z, g_v]
-                self.optimizer.zero_grad(set_to_none=True)
-                torch.autograd.backward(outs, grads)
-                if self.grad_sync is not None:
-                    self.grad_sync()
-                torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.clip_grad_norm)
-                self.optimizer.step()
-                k += 1
-        stats[n_upd, 0] = mean_ret_t
-        s = stats[: n_upd + 1].cpu().numpy().astype(np.float64)  # the only host sync of learn()
-        return self._result(s, n_upd)
 
     # -- native: static buffers so that the whole update sequence can be replayed as one hipGraph ----
     def _alloc_static(self, M):
@@ -538,13 +478,8 @@ class PPO(BaseAgent):
         self.time_t = step
         self.learn_stamp += delta_t
         if self.learn_stamp >= self.n_step:
-            if self._net is not None:
-                self._lr_step = step  # the native learn() applies the decay itself, right behind its launches (ppo.py:199-200)
-                result = self.learn()
-            else:
-                result = self.learn()
-                if self.lr_decay:
-                    self.learning_rate_decay(step)
+            self._lr_step = step  # learn() applies the decay itself, right behind its launches (ppo.py:199-200)
+            result = self.learn()
             self.learn_stamp = 0
         return result
 

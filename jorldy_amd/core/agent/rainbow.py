@@ -7,9 +7,8 @@ import torch
 from ... import ops
 from ..buffer import PERBuffer
 from ..network import Network
-from ..optimizer import Optimizer
 from .dqn import DQN
-from .native_net import native_supported
+from .native_net import require_native
 
 
 class C51(DQN):
@@ -44,28 +43,15 @@ class C51(DQN):
 
     def _learn_body(self, st):
         B, A, K = self.batch_size, self.action_size, self.num_support
-        if self._net is not None:  # q-network with A*K outputs on the native engine
-            net = self._net
-            tr = self.memory.gather(st["idx"], as_float=self._as_float(), out=st["tr"])
-            lg = net.learn_forward(st["x_all"], B, None, st["logits"])
-            g, _, _, _ = ops.c51_loss(lg[0].view(B, A, K), lg[2].view(B, A, K), tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max, self.gamma,
-                                      shift_max=True, stats=self._stats8)
-            net.backward(g.view(B, A * K))
-            if self.grad_sync is not None:
-                self.grad_sync.reduce_flat(net.grads)
-            net.optim_step(self._opt_name, self.clip_grad_norm)
-            return
-        tr = self.memory.gather(st["idx"], out=st["tr"])
-        logit = self.network(tr["state"])
-        with torch.no_grad():
-            target_logit = self.target_network(tr["next_state"])
-        g, _, _, _ = ops.c51_loss(logit.detach().view(B, A, K), target_logit.view(B, A, K), tr["action"], tr["reward"], tr["done"],
-                                  self.v_min, self.v_max, self.gamma, shift_max=True, stats=self._stats8)
-        self.optimizer.zero_grad(set_to_none=True)
-        logit.backward(g.view_as(logit))
+        net = self._net  # q-network with A*K outputs on the native engine
+        tr = self.memory.gather(st["idx"], as_float=self._as_float(), out=st["tr"])
+        lg = net.learn_forward(st["x_all"], B, None, st["logits"])
+        g, _, _, _ = ops.c51_loss(lg[0].view(B, A, K), lg[2].view(B, A, K), tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max, self.gamma,
+                                  shift_max=True, stats=self._stats8)
+        net.backward(g.view(B, A * K))
         if self.grad_sync is not None:
-            self.grad_sync()
-        self.optimizer.step()
+            self.grad_sync.reduce_flat(net.grads)
+        net.optim_step(self._opt_name, self.clip_grad_norm)
 
     def learn(self):
         s, _ = self._learn_stats(self._stats8_np, (5, 7), self._stats8)
@@ -77,12 +63,10 @@ class Rainbow(DQN):
     with priorities KL^alpha.  The projection + KL + backward-to-logits + priorities are one HIP
     kernel (jh_c51_loss); priorities go straight into the device sum tree (no B `.item()` syncs).
 
-    backend="native" (default when the configuration allows it: factorised noise, mlp / cnn head, Adam):
-    the network itself runs on libjorldy_hip (ops.RainbowNet): convolutions as implicit GEMMs on the fp32
-    MFMA reading the uint8 frames straight out of the replay store, the three forwards of learn() share
-    their launches, backward + Adam are native; ~30 launches per learn(), replayed as one hipGraph.
-    backend="torch": the PyTorch mirror of the reference modules (MIOpen / hipBLASLt) around the same
-    HIP loss / PER kernels."""
+    The network itself runs on libjorldy_hip (ops.RainbowNet; factorised or independent noise, mlp / cnn head, plain Adam /
+    RMSprop): convolutions as implicit GEMMs on the fp32 MFMA reading the uint8 frames straight out of the replay store, the
+    three forwards of learn() share their launches, backward + Adam are native; one hipGraph per learn().  One backend: any
+    other configuration raises (native_net.NATIVE_ELIGIBLE)."""
 
     def __init__(self, state_size, action_size, hidden_size=512, network="rainbow", head="mlp",
                  optim_config={"name": "adam"}, gamma=0.99, buffer_size=50000, batch_size=64, start_train_step=2000,
@@ -97,21 +81,11 @@ class Rainbow(DQN):
         self._td = dict(double=True, per=True, n_step=1)
         self.action_size = action_size
         self.action_type = "discrete"
-        can_native = native_supported(network, head, state_size, hidden_size, optim_config, noise_type)
-        self.backend = backend or ("native" if can_native else "torch")
-        assert self.backend in ("native", "torch")
-        if backend is None and not can_native:
-            self._warn_torch_backend(f"network={network!r}, head={head!r}, hidden_size={hidden_size}, noise_type={noise_type!r}, optim={optim_config.get('name', 'adam')!r} is outside the native value networks")
-        if self.backend == "native" and not can_native:
-            raise ValueError("backend='native' needs network='rainbow', factorized noise, an mlp/cnn head, hidden_size % 4 == 0 and plain Adam / RMSprop")
-        mk = lambda: Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head).to(self.device)
+        require_native(backend, network, head, state_size, hidden_size, optim_config, noise_type)
+        self.backend = "native"
         self._net = None
-        if self.backend == "native":
-            self._init_native(network, state_size, action_size, num_support, hidden_size, head, batch_size, optim_config, mk(), noise_type=noise_type)
-        else:
-            self.network, self.target_network = mk(), mk()
-            self.target_network.load_state_dict(self.network.state_dict())
-            self.optimizer = self._make_optimizer(optim_config, self.network.parameters())
+        self._init_native(network, state_size, action_size, num_support, hidden_size, head, batch_size, optim_config,
+                          Network(network, state_size, action_size, num_support, noise_type, D_hidden=hidden_size, head=head), noise_type=noise_type)
         self.gamma = gamma
         self.batch_size = batch_size
         self.start_train_step = start_train_step
@@ -161,8 +135,8 @@ class Rainbow(DQN):
     def _idx_offset(self):
         return self.memory.first_leaf_index
 
-    # ---- native backend (plumbing: native_net.NativeValueNetMixin via DQN) -------------------
-    def _learn_body_native(self, st):
+    # ---- plumbing: native_net.NativeValueNetMixin via DQN -------------------
+    def _learn_body(self, st):
         net, B = self._net, self.batch_size
         tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, as_float=self._as_float(), out=st["tr"])
         if self._noise is None:
@@ -180,25 +154,6 @@ class Rainbow(DQN):
         if self.grad_sync is not None:  # data-parallel learners: one all-reduce of the flat gradient bucket
             self.grad_sync.reduce_flat(net.grads)
         net.optim_step(self._opt_name, self.clip_grad_norm)
-
-    def _learn_body(self, st):
-        if self._net is not None:
-            return self._learn_body_native(st)
-        tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, out=st["tr"])
-        nz = self._noise or [None, None, None]
-        logit = self.network(tr["state"], True, nz[0])  # [B, A, K]
-        with torch.no_grad():
-            next_logit = self.network(tr["next_state"], True, nz[1])
-            target_logit = self.target_network(tr["next_state"], True, nz[2])
-        g, prio, _, _ = ops.c51_loss(logit.detach(), target_logit, tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max,
-                                     self.gamma, next_logit_online=next_logit, weights=st["w"], alpha=self.alpha,
-                                     n_step=self.n_step, stats=self._stats8)
-        self.memory.update_priorities(st["idx"], prio)  # rainbow.py:230-231
-        self.optimizer.zero_grad(set_to_none=True)
-        logit.backward(g)
-        if self.grad_sync is not None:
-            self.grad_sync()
-        self.optimizer.step()
 
     def _resume_extra_attrs(self):
         """The learner's noise stream (ops.NormalSource: seed + call counter in device memory): without it a resumed run would

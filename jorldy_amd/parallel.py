@@ -31,28 +31,60 @@ class Transport:
         self.kind = "host" if "gloo" in backend and "nccl" not in backend else "torch"
         self.comm = None
         if self.kind == "torch" and os.environ.get("JH_DP_COLLECTIVE", "rccl") != "torch" and device is not None and torch.device(device).type == "cuda":
-            try:
-                self._create_comm(torch.device(device))
+            # a COLLECTIVE decision: every rank runs the same sequence of collectives whatever fails locally, and all ranks
+            # end on the same transport (a per-rank try/except left ranks on different transports / off-by-one collectives)
+            if self._create_comm(torch.device(device)):
                 self.kind = "rccl"
-            except Exception as e:  # e.g. librccl.so.1 not loadable: keep torch.distributed's own communicator
-                print(f"[jorldy_amd] C-ABI RCCL communicator unavailable ({type(e).__name__}: {e}); using torch.distributed collectives")
         self.capturable = self.kind in ("rccl", "torch")
 
     def _create_comm(self, device):
+        """-> True when EVERY rank holds a working jh_comm communicator; otherwise nothing is left behind on any rank.
+        Sequence on every rank, unconditionally: broadcast(128-byte id from rank 0; all zeros = rank 0 could not make one),
+        [jh_comm_create], all_reduce(MIN) of the local success flag.  JH_COMM_INJECT=id|create makes the named step fail
+        (tests of the fallback)."""
         import ctypes as C
 
-        from . import _lib as L
+        inject = os.environ.get("JH_COMM_INJECT", "")
+        lib = L = None
+        err = None
+        try:
+            from . import _lib as L
 
-        lib = L.load()
+            lib = L.load()
+        except Exception as e:
+            err = e
         ident = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            L.check(lib.jh_comm_unique_id(L.ptr(ident)))
+        if self.rank == 0 and lib is not None:
+            try:
+                if inject == "id":
+                    raise RuntimeError("injected: jh_comm_unique_id")
+                L.check(lib.jh_comm_unique_id(L.ptr(ident)))
+            except Exception as e:
+                err = e
+                ident.zero_()
         ident = ident.to(device)  # the side channel: one 128-byte broadcast on the existing process group
         self.dist.broadcast(ident, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         ident = ident.cpu()
-        h = C.c_void_p()
-        L.check(lib.jh_comm_create(L.ctx(device.index), self.world, self.rank, L.ptr(ident), C.byref(h)))
+        h, ok = None, 0
+        if lib is not None and bool(ident.any()):
+            try:
+                if inject == "create":
+                    raise RuntimeError("injected: jh_comm_create")
+                h = C.c_void_p()
+                L.check(lib.jh_comm_create(L.ctx(device.index), self.world, self.rank, L.ptr(ident), C.byref(h)))
+                ok = 1
+            except Exception as e:
+                err, h = e, None
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            if h is not None:
+                lib.jh_comm_destroy(h)
+            why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"
+            print(f"[jorldy_amd] rank {self.rank}: C-ABI RCCL communicator unavailable ({why}); ALL ranks use torch.distributed collectives")
+            return False
         self.comm, self._lib, self._L = h, lib, L
+        return True
 
     def __del__(self):
         try:
@@ -103,8 +135,9 @@ class Transport:
 
 
 class FlatGradSync:
-    """Mean gradient over ranks for an nn.Module (the torch mirror backends): grads packed into one flat fp32
-    bucket -> Transport.mean_ -> unpacked.  The native networks' gradient already IS one flat bucket: reduce_flat."""
+    """Mean gradient over ranks for a list of parameter tensors: grads packed into one flat fp32 bucket -> Transport.mean_ ->
+    unpacked.  The agents' networks live in ONE flat bucket already and use BucketSync / reduce_flat; this packing form is kept
+    for callers that hold separate tensors (and for the CPU collective tests)."""
 
     def __init__(self, module, dist, group=None, transport=None):
         self.dist, self.group = dist, group
@@ -201,19 +234,14 @@ def attach_data_parallel(agent, dist, group=None):
     every rank keeps its own actors and its own replay shard / sum tree (no data-path collective), samples
     its own minibatch of `batch_size`, and the gradients are averaged before the optimizer step so all
     ranks hold identical weights.  PER: the IS weights are those of the single logical buffer (sharded_is_weights:
-    one all-gather of {root, count, min sampled p} per learn()).  Works for PPO (native or torch), the torch-encoder DQN family and the
-    native Rainbow network.  Returns the hook (also stored as agent.grad_sync)."""
+    one all-gather of {root, count, min sampled p} per learn()).  Works for PPO and the DQN / Rainbow / Ape-X family.
+    Returns the hook (also stored as agent.grad_sync)."""
     net = getattr(agent, "_net", None)
     device = getattr(agent, "device", None)
+    assert net is not None, "attach_data_parallel needs a jorldy_amd agent (its network lives in libjorldy_hip's flat buckets)"
     transport = Transport(dist, group, device)
-    if net is not None and hasattr(net, "target"):  # ops.RainbowNet
-        sync = BucketSync(dist, group, transport)
-        sync.broadcast(net.params, net.target, net.m, net.v)
-    else:
-        sync = make_grad_sync(agent.network, dist, group, transport)
-        if hasattr(agent, "target_network"):
-            for p in agent.target_network.parameters():
-                transport.broadcast_(p.data, 0)
+    sync = BucketSync(dist, group, transport)  # ops.PPONet / ops.RainbowNet: the gradient already IS one flat bucket
+    sync.broadcast(net.params, net.m, net.v, *([net.target] if hasattr(net, "target") else []))  # identical start (ncclBroadcast only at init/load)
     mem = getattr(agent, "memory", None)
     if mem is not None and hasattr(mem, "attach_shards"):  # PER: this rank's buffer is one shard of the logical buffer
         mem.attach_shards(dist, group, transport)

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+import margins
 from tests.util import cu, f32, load, npy
 
 pytestmark = pytest.mark.gpu
@@ -30,8 +31,8 @@ def _cmp_sd(net, gold, lr, n_updates, atol=2e-5):
         tot += d.size
         bad += int((d > atol).sum())
         worst = max(worst, float(d.max()))
-    assert bad <= 0.005 * tot, f"{bad}/{tot} weights differ by more than {atol}"
-    assert worst <= 2.1 * lr * n_updates, f"worst weight diff {worst}"
+    margins.leq(bad / tot, 0.005, f"fraction of weights further than {atol} from the reference's")
+    margins.leq(worst, 2.1 * lr * n_updates, "worst weight difference vs the possible travel")
 
 
 PPO_CASES = ["ppo_disc_small", "ppo_disc_cartpole", "ppo_cont_small", "ppo_cont_hopper"]
@@ -52,7 +53,7 @@ def _drift(name, s, z, n_upd, later):
     with open(os.path.join(d, f"parity_drift_{name}.json"), "w") as f:
         json.dump({"per_update_max_err_over_1_plus_abs_ref": drift}, f, indent=1)
     for i, e in enumerate(drift):
-        assert e <= (1e-5 if i == 0 else later), f"{name} update {i}: {e:.3e}  (all: {['%.1e' % v for v in drift]})"
+        margins.leq(e, 1e-5 if i == 0 else later, f"{name} update {i} loss scalars (all: {['%.1e' % v for v in drift]})")
 
 
 @pytest.mark.parametrize("name", PPO_CASES)
@@ -104,11 +105,10 @@ def _h(z, k):
     return z[f"hyper/{k}"].item()
 
 
-@pytest.mark.parametrize("backend", ["native", "torch"])
 @pytest.mark.parametrize("name", ["dqn", "double", "multistep", "per", "ape_x"])
-def test_td_agents_learn_matches_reference(name, backend):
-    """backend native = the q-network / dueling encoder, its backward and the optimizer on libjorldy_hip
-    (jh_rbnet_*), torch = the PyTorch mirror modules; both around the same HIP loss / PER kernels."""
+def test_td_agents_learn_matches_reference(name):
+    """The q-network / dueling encoder, its backward and the optimizer on libjorldy_hip (jh_rbnet_*) around the HIP loss / PER
+    kernels, against the reference's own learn() (fixture)."""
     from jorldy_amd.core.agent import Agent
 
     z = load(name)
@@ -117,9 +117,8 @@ def test_td_agents_learn_matches_reference(name, backend):
         if f"hyper/{k}" in z.files:
             extra[k] = _h(z, k)
     agent = Agent(name, state_size=int(_h(z, "S")), action_size=int(_h(z, "A")), hidden_size=int(_h(z, "H")), optim_config={"name": "adam", "lr": _h(z, "lr")},
-                  gamma=_h(z, "gamma"), buffer_size=256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=100000, device="cuda",
-                  backend=backend, **extra)
-    assert agent.backend == backend
+                  gamma=_h(z, "gamma"), buffer_size=256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=100000, device="cuda", **extra)
+    assert agent.backend == "native"
     agent.network.load_state_dict(_sd(z, "sd0/"))
     agent.target_network.load_state_dict(_sd(z, "sdt/"))
     per = name in ("per", "ape_x")
@@ -153,12 +152,11 @@ def test_c51_agent_learn_matches_reference():
     _cmp_sd(agent.network, _sd(z, "sd1/"), _h(z, "lr"), 1)
 
 
-@pytest.mark.parametrize("fixture,backend", [("rainbow", "native"), ("rainbow", "torch"), ("rainbow_cnn", "native"), ("rainbow_cnn", "torch")])
-def test_rainbow_agent_learn_matches_reference(fixture, backend):
+@pytest.mark.parametrize("fixture", ["rainbow", "rainbow_cnn"])
+def test_rainbow_agent_learn_matches_reference(fixture):
     """The reference draws NoisyNet noise with the CPU generator inside forward (utils.py:58-60); the
     same draws are regenerated here (same seed, same order) and injected so the whole update is
-    comparable.  backend native = the network itself on libjorldy_hip (jh_rbnet_*), torch = the PyTorch
-    mirror modules; rainbow_cnn = Nature-CNN head on uint8 frames."""
+    comparable.  rainbow_cnn = Nature-CNN head on uint8 frames."""
     from jorldy_amd.core.agent import Agent
 
     z = load(fixture)
@@ -169,8 +167,8 @@ def test_rainbow_agent_learn_matches_reference(fixture, backend):
                   optim_config={"name": "adam", "lr": _h(z, "lr")},
                   gamma=_h(z, "gamma"), buffer_size=64 if cnn else 256, batch_size=int(_h(z, "B")), start_train_step=0, target_update_period=10000, run_step=100000,
                   n_step=int(_h(z, "n_step")), alpha=_h(z, "alpha"), beta=_h(z, "beta"), learn_period=1, uniform_sample_prob=_h(z, "uniform_sample_prob"),
-                  v_min=_h(z, "v_min"), v_max=_h(z, "v_max"), num_support=K, device="cuda", backend=backend)
-    assert agent.backend == backend
+                  v_min=_h(z, "v_min"), v_max=_h(z, "v_max"), num_support=K, device="cuda")
+    assert agent.backend == "native"
     agent.network.load_state_dict(_sd(z, "sd0/"))
     agent.target_network.load_state_dict(_sd(z, "sdt/"))
     n = _fill_from_fixture(agent, z, True)
@@ -190,15 +188,14 @@ def test_rainbow_agent_learn_matches_reference(fixture, backend):
         np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=1e-5, err_msg=k)
     np.testing.assert_allclose(result["sampled_p"], z["result/sampled_p"], rtol=1e-12)
     np.testing.assert_allclose(agent.memory.sum_tree, z["tree1"], rtol=1e-4 if cnn else 2e-5, atol=1e-6)
-    if backend == "native":  # gradients of every parameter against the reference's autograd
-        grads = agent._net.export_state(agent._net.grads)
-        for k, v in grads.items():
-            ref = z[f"grad/{k}"]
-            assert float(np.abs(v.cpu().numpy() - ref).max()) <= 5e-5 * (float(np.abs(ref).max()) + 1e-12) + 1e-9, k
+    grads = agent._net.export_state(agent._net.grads)  # gradients of every parameter against the reference's autograd
+    for k, v in grads.items():
+        ref = z[f"grad/{k}"]
+        margins.leq(float(np.abs(v.cpu().numpy() - ref).max()), 5e-5 * (float(np.abs(ref).max()) + 1e-12) + 1e-9, f"grad {k}")
     _cmp_sd(agent.network, _sd(z, "sd1/"), _h(z, "lr"), 1)
 
 
-def test_rainbow_native_graph_replay_equals_eager_and_torch_backend_statistics():
+def test_rainbow_native_graph_replay_equals_eager():
     """Native learn() as one hipGraph == the same launches issued eagerly (same device RNG stream)."""
     from jorldy_amd.core.agent import Agent
 
@@ -231,34 +228,39 @@ def test_rainbow_native_graph_replay_equals_eager_and_torch_backend_statistics()
     np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
-def test_rainbow_native_checkpoint_interchanges_with_torch_backend(tmp_path):
-    """ckpt written by the native backend = the reference's format: loads into the torch-mirror agent (and
-    back) with parameters and Adam moments intact."""
+def test_rainbow_native_checkpoint_interchanges_with_torch_modules(tmp_path):
+    """ckpt written by the agent = the reference's format ({"network": state_dict, "optimizer": torch.optim state_dict},
+    rainbow.py / dqn.py:184-199): loads into the reference-shaped torch module + torch.optim.Adam (tests/mirror) and back
+    with parameters and Adam moments intact."""
     from jorldy_amd.core.agent import Agent
+    from mirror.networks import Network
 
     z = load("rainbow")
     H, A, K = int(_h(z, "H")), int(_h(z, "A")), int(_h(z, "num_support"))
-    mk = lambda backend: Agent("rainbow", state_size=int(z["hyper/S"]), action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": 1e-3}, buffer_size=256,
-                               batch_size=int(_h(z, "B")), start_train_step=0, run_step=1000, n_step=3, num_support=K, device="cuda", backend=backend, use_graph=False)
-    a = mk("native")
+    mk = lambda: Agent("rainbow", state_size=int(z["hyper/S"]), action_size=A, hidden_size=H, optim_config={"name": "adam", "lr": 1e-3}, buffer_size=256,
+                       batch_size=int(_h(z, "B")), start_train_step=0, run_step=1000, n_step=3, num_support=K, device="cuda", use_graph=False)
+    a = mk()
     a.network.load_state_dict(_sd(z, "sd0/"))
     _fill_from_fixture(a, z, True)
     np.random.seed(1)
     for _ in range(3):
         a.learn()
     a.save(str(tmp_path))
-    b = mk("torch")
-    b.load(str(tmp_path))
-    for (k, v1), (_, v2) in zip(a.network.state_dict().items(), b.network.state_dict().items()):
-        assert torch.equal(v1, v2), k
-    st = b.optimizer.state_dict()["state"]
-    assert len(st) == len(list(b.network.parameters())) and all(int(float(s["step"])) == 3 for s in st.values())
+    ck = torch.load(str(tmp_path / "ckpt"), map_location="cpu", weights_only=False)
+    mod = Network("rainbow", int(z["hyper/S"]), A, K, "factorized", D_hidden=H, head="mlp")
+    mod.load_state_dict(ck["network"])  # strict: same keys, same shapes
+    opt = torch.optim.Adam(mod.parameters(), lr=1e-3)
+    opt.load_state_dict(ck["optimizer"])
+    for (k, v1), (_, v2) in zip(a.network.state_dict().items(), mod.state_dict().items()):
+        assert torch.equal(v1.cpu(), v2), k
+    st = opt.state_dict()["state"]
+    assert len(st) == len(list(mod.parameters())) and all(int(float(s["step"])) == 3 for s in st.values())
     m_nat = a._net.export_state(a._net.m)
-    for (k, v), s in zip(m_nat.items(), st.values()):
-        assert torch.equal(v, s["exp_avg"].to(v.device)), k
+    for (k, v), s_ in zip(m_nat.items(), st.values()):
+        assert torch.equal(v.cpu(), s_["exp_avg"]), k
     (tmp_path / "b").mkdir()
-    b.save(str(tmp_path / "b"))
-    c = mk("native")
+    torch.save({"network": mod.state_dict(), "optimizer": opt.state_dict()}, str(tmp_path / "b" / "ckpt"))  # what the reference's save() writes
+    c = mk()
     c.load(str(tmp_path / "b"))
     assert c._adam_steps == 3
     assert torch.equal(c._net.params, a._net.params) and torch.equal(c._net.m, a._net.m) and torch.equal(c._net.v, a._net.v)
@@ -328,52 +330,83 @@ def test_reference_bookkeeping_asserts(name, extra, check, tmp_path):
 
 
 # ---- native backend (hand-written MLP fwd/bwd + clip + Adam) ---------------------------------------
-def test_pponet_forward_backward_adam_vs_torch():
-    """jh_pponet_* against torch autograd + torch.optim.Adam on the same flat parameters."""
+def _unflat(flat, module):
+    """flat bucket (state_dict order) -> {name: tensor shaped like the module's parameter}."""
+    out, o = {}, 0
+    for k, p in module.named_parameters():
+        out[k] = flat[o : o + p.numel()].view_as(p)
+        o += p.numel()
+    return out
+
+
+def _policy64(agent, name, S, A, H):
+    """The agent's CURRENT policy as the reference's module in float64 on the CPU (tests/mirror): what `agent.network(x)` meant
+    when the product still carried a torch forward."""
+    from mirror.networks import Network
+
+    m = Network(name, S, A, D_hidden=H).double()
+    m.load_state_dict({k: v.detach().cpu().double() for k, v in agent.network.state_dict().items()})
+    return m
+
+
+def test_pponet_forward_backward_adam_vs_float64():
+    """jh_pponet_* against the reference's module + torch.optim.Adam evaluated in float64 on the CPU (tests/fp64_truth.py), with
+    torch-CPU fp32 beside it: heads, every gradient, the clip norm, Adam's moments and the stepped weights, three teacher-forced steps."""
+    import fp64_truth as T
     from jorldy_amd import ops
-    from jorldy_amd.core.network import Network
+    from mirror.networks import Network
 
     for cont, S, H, A, B in ((False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8)):
         torch.manual_seed(0)
-        ref = Network("continuous_policy_value" if cont else "discrete_policy_value", S, A, D_hidden=H).cuda()
+        ref64 = Network("continuous_policy_value" if cont else "discrete_policy_value", S, A, D_hidden=H).double()
         with torch.no_grad():
-            for p in ref.parameters():
+            for p in ref64.parameters():
                 p.add_(0.05 * torch.randn_like(p))
+        T.round_to_fp32_(ref64)
+        ref32 = T.as32(ref64)
         net = ops.PPONet(S, H, A, cont, 1024, "cuda:0")
-        flat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
-        assert flat.numel() == net.n_params
-        net.params.copy_(flat)
+        assert sum(p.numel() for p in ref64.parameters()) == net.n_params
         lr = 1e-3
-        net.set_hyper(lr, 0.9, 0.999, 1e-8, step=0.0)
-        opt = torch.optim.Adam(ref.parameters(), lr=lr)
-        x_all = torch.randn(300, S, device="cuda")
+        truth = T.OptimTruth(ref64, ref32, lambda ps: torch.optim.Adam(ps, lr=lr), lr, ("exp_avg", "exp_avg_sq"))
+        g = torch.Generator().manual_seed(1)
+        x_all = torch.randn(300, S, generator=g)
+        x_dev = x_all.cuda()
+        flat = lambda d: torch.cat([d[k].reshape(-1) for k, _ in ref64.named_parameters()]).cuda()
         for it in range(3):
-            idx = torch.randperm(300, device="cuda")[:B]
-            outs = net.forward(x_all, idx=idx)
-            routs = ref.raw(x_all[idx])
-            for a, b in zip(outs, routs):
-                torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
-            gs = [torch.randn_like(o) / B for o in routs]
-            opt.zero_grad(set_to_none=True)
-            torch.autograd.backward(list(routs), gs)
-            if cont:
-                net.backward(x_all, idx, gs[0], gs[1], gs[2])
+            params, m, v = truth.teacher_force()
+            net.params.copy_(flat(params))
+            if m is None:
+                net.m.zero_()
+                net.v.zero_()
             else:
-                net.backward(x_all, idx, gs[0], None, gs[1])
-            gref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
-            torch.testing.assert_close(net.grads, gref, rtol=1e-3, atol=1e-6)
-            norm_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
-            opt.step()
+                net.m.copy_(flat(m))
+                net.v.copy_(flat(v))
+            net.set_hyper(lr, 0.9, 0.999, 1e-8, step=float(it))
+            idx = torch.randperm(300, generator=g)[:B]
+            outs = net.forward(x_dev, idx=idx.cuda())
+            r64, r32 = ref64.raw(x_all[idx].double()), ref32.raw(x_all[idx])
+            for nm, a, b, c in zip(("mu", "log_std", "value") if cont else ("logits", "value"), outs, r64, r32):
+                T.vs_exact(a, b, c, 1e-5, f"cont={cont} step {it} {nm}")
+            gs = [torch.randn(o.shape, generator=g) / B for o in r64]
+            truth.opt64.zero_grad(set_to_none=True)
+            truth.opt32.zero_grad(set_to_none=True)
+            torch.autograd.backward(list(r64), [t.double() for t in gs])
+            torch.autograd.backward(list(r32), gs)
+            gd = [t.cuda() for t in gs]
+            if cont:
+                net.backward(x_dev, idx.cuda(), gd[0], gd[1], gd[2])
+            else:
+                net.backward(x_dev, idx.cuda(), gd[0], None, gd[1])
+            ours_g = _unflat(net.grads, ref64)
+            p32 = dict(ref32.named_parameters())
+            for k, p in ref64.named_parameters():
+                T.vs_exact(ours_g[k], p.grad, p32[k].grad, 1e-5, f"cont={cont} step {it} grad {k}")
+            ours_raw = {k: v.clone() for k, v in ours_g.items()}  # adam_step clips the bucket in place
+            norm64 = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ours_raw.values())))  # float64 norm of OUR gradient
             norm = torch.zeros(1, device="cuda")
             net.adam_step(0.5, norm)
-            torch.testing.assert_close(norm[0], norm_ref, rtol=1e-4, atol=1e-7)
-            pref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
-            # Adam normalises the update: weights with ~0 gradient may differ by a step
-            d = (net.params - pref).abs()
-            assert float((d > 2e-5).float().mean()) < 0.005 and float(d.max()) <= 2.1 * lr * (it + 1)
-            net.params.copy_(pref)  # keep both trajectories aligned for the next iteration
-            net.m.copy_(torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref.parameters()]))
-            net.v.copy_(torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ref.parameters()]))
+            margins.close(float(norm[0]), norm64, rtol=1e-5, what=f"cont={cont} step {it} grad norm")
+            truth.step(0.5, ours_raw, _unflat(net.params, ref64), _unflat(net.m, ref64), _unflat(net.v, ref64), tag=f"cont={cont} adam step {it}")
 
 
 @pytest.mark.parametrize("cont,S,H,A,B", [(False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8), (False, 8, 64, 3, 250), (True, 3, 96, 2, 1000)])
@@ -415,15 +448,16 @@ def test_ppo_update_five_launches_equal_separate_calls(cont, S, H, A, B):
     st1, st2 = torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda")
     n1.ppo_update(x, idx, action, adv, ret, vold, logp_old, eps, vf, ent, clip, st1, do_adam=False)
     scale = float(raw.abs().max())
-    assert float((n1.grads - raw).abs().max()) <= 1e-5 * scale, "raw gradient bucket"
+    margins.leq(float((n1.grads - raw).abs().max()), 1e-5 * scale, "raw gradient bucket")
     torch.testing.assert_close(st1, st0, rtol=1e-5, atol=1e-6)
     n1.adam_step(clip)
     n2.ppo_update(x, idx, action, adv, ret, vold, logp_old, eps, vf, ent, clip, st2, do_adam=True)
     torch.testing.assert_close(st2, st1, rtol=0, atol=0)  # same kernels, same bits
     for n in (n1, n2):
-        assert float((n.grads - n0.grads).abs().max()) <= 1e-5 * float(n0.grads.abs().max()), "clipped gradient bucket"
+        margins.leq(float((n.grads - n0.grads).abs().max()), 1e-5 * float(n0.grads.abs().max()), "clipped gradient bucket")
         d = (n.params - n0.params).abs()
-        assert float((d > 2e-5).float().mean()) < 0.005 and float(d.max()) <= 2.1e-3
+        margins.lt(float((d > 2e-5).float().mean()), 0.005, "fraction of weights > 2e-5 apart")
+        margins.leq(float(d.max()), 2.1e-3, "worst weight difference")
     torch.testing.assert_close(n2.params, n1.params, rtol=0, atol=1e-7)
 
 
@@ -504,7 +538,8 @@ def test_native_act_discrete_distribution():
         a = agent.act(obs, training=True)["action"]
         assert a.shape == (64, 1) and a.dtype == np.int64
         counts += np.bincount(a.reshape(-1), minlength=3)
-    pi, _ = agent.network(torch.zeros(1, 4, device="cuda"))
+    with torch.no_grad():
+        pi, _ = _policy64(agent, "discrete_policy_value", 4, 3, 32)(torch.zeros(1, 4, dtype=torch.float64))
     p = npy(pi)[0]
     np.testing.assert_allclose(counts / counts.sum(), p, atol=0.015)
     g = agent.act(obs, training=False)["action"]
@@ -611,7 +646,7 @@ def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persiste
         col.terminate()
     for a, b in zip(res[True], res[False]):
         for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
-            assert abs(a[k] - b[k]) <= 1e-5 * (1.0 + abs(b[k])), (k, a[k], b[k])
+            margins.leq(abs(a[k] - b[k]), 1e-5 * (1.0 + abs(b[k])), f"result {k}")
 
 
 @pytest.mark.parametrize("persistent", [True, False])
@@ -651,7 +686,7 @@ def test_native_collector_continuous_policy_on_control_env(H, W, persistent, mon
         np.testing.assert_array_equal(cols["done"][rows, 0].astype(bool), done)
     # the actions are samples of THIS policy at the stored states: z = atanh(a) ~ Normal(mu, std)
     with torch.no_grad():
-        mu, std, _ = agent.network(torch.from_numpy(cols["state"]).cuda())
+        mu, std, _ = _policy64(agent, "continuous_policy_value", S, A, H)(torch.from_numpy(cols["state"]).double())
     zz = np.arctanh(np.clip(cols["action"].astype(np.float64), -1 + 1e-7, 1 - 1e-7))
     zs = (zz - npy(mu)) / npy(std)
     assert abs(zs.mean()) < 0.12 and 0.85 < zs.std() < 1.15, (zs.mean(), zs.std())
@@ -677,7 +712,7 @@ def test_native_act_continuous_distribution():
         zs.append(np.arctanh(np.clip(a.astype(np.float64), -1 + 1e-7, 1 - 1e-7)))
     zs = np.concatenate(zs, 0)
     with torch.no_grad():
-        mu, std, _ = agent.network(torch.zeros(1, 11, device="cuda"))
+        mu, std, _ = _policy64(agent, "continuous_policy_value", 11, 3, 64)(torch.zeros(1, 11, dtype=torch.float64))
     np.testing.assert_allclose(zs.mean(0), npy(mu)[0], atol=0.04)
     np.testing.assert_allclose(zs.std(0), npy(std)[0], rtol=0.05)
     g = agent.act(obs, training=False)["action"]
@@ -692,7 +727,7 @@ def test_ppo_native_data_parallel_path_single_rank_rccl():
     import torch.distributed as dist
 
     from jorldy_amd.core.agent import Agent
-    from jorldy_amd.parallel import make_grad_sync
+    from jorldy_amd.parallel import attach_data_parallel
 
     z = load("ppo_disc_cartpole")
     S, A, H, W, T, B, E, cont = [int(x) for x in z["cfg"]]
@@ -711,14 +746,15 @@ def test_ppo_native_data_parallel_path_single_rank_rccl():
             agent.network.load_state_dict(_sd(z, "sd0/"))
             agent.memory.first_store = False
             if dp:
-                agent.grad_sync = make_grad_sync(agent.network, dist)
+                attach_data_parallel(agent, dist)
             np.random.seed(int(z["np_seed"]))
             agent.process(cols, T)
             outs.append(agent._net.params.clone())
         # same kernels except the global norm (fused per-GEMM partials vs the gradnorm pass after the
         # all-reduce): equal up to the rounding of that one reduction
         d = (outs[0] - outs[1]).abs()
-        assert float((d > 2e-6).float().mean()) < 0.005 and float(d.max()) <= 2.1 * lr * int(z["n_minibatch"])
+        margins.lt(float((d > 2e-6).float().mean()), 0.005, "fraction of weights > 2e-6 apart (DP hook vs none)")
+        margins.leq(float(d.max()), 2.1 * lr * int(z["n_minibatch"]), "worst weight difference (DP hook vs none)")
         _cmp_sd(agent.network, _sd(z, "sd1/"), lr, int(z["n_minibatch"]), atol=3e-5)
     finally:
         dist.destroy_process_group()

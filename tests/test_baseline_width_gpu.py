@@ -16,6 +16,8 @@ import json
 import os
 
 import numpy as np
+
+import margins
 import pytest
 import torch
 
@@ -45,7 +47,7 @@ def _thin_cmp(ours, z, prefix, scale_of=None, tol=1e-5, what=""):
         scale = float(scale_of(k)) if scale_of else float(np.abs(ref).max())
         err = float(np.abs(got - ref).max()) / (scale + 1e-30)
         worst[k] = err
-        assert err <= tol, f"{what} {k}: max |diff| = {err:.3e} x the tensor's largest entry (allowed {tol:.1e})"
+        margins.leq(err, tol, f"{what} {k}: max |diff| / the tensor's largest entry")
     return worst
 
 
@@ -124,7 +126,7 @@ def test_ppo_first_minibatch_forward_loss_backward(name):
         np.testing.assert_allclose(s[j], z[f"mb0/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
     for tag, g in heads.items():
         ref = z[f"mb0/head/d_{tag}"]
-        assert float(np.abs(npy(g) - ref).max()) <= 1e-5 * float(np.abs(ref).max()), tag
+        margins.leq(float(np.abs(npy(g) - ref).max()), 1e-5 * float(np.abs(ref).max()), tag)
     grads = {k: npy(p.grad) for k, p in agent.network.named_parameters()}
     worst = _thin_cmp(grads, z, "mb0/grad_raw/", scale_of=lambda k: z[f"mb0/grad_raw_absmax/{k}"], tol=1e-5, what="d(loss)/d")
     norm = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
@@ -164,7 +166,7 @@ def test_ppo_learn_at_baseline_width(name, graph):
             drift.append(e)
         _report(f"{name}_{'graph' if graph else 'eager'}", {"per_update_max_err_over_1_plus_abs_ref": drift, "bound": [_bound(i) for i in range(n_upd)]})
         for i, e in enumerate(drift):
-            assert e <= _bound(i), f"{name} rep {rep} update {i}: {e:.3e} > {_bound(i):.1e}  (all: {['%.1e' % d for d in drift]})"
+            margins.leq(e, _bound(i), f"{name} rep {rep} update {i} loss scalars")
         for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
             np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=2e-5, atol=2e-5, err_msg=k)
         np.testing.assert_allclose(agent.optimizer.param_groups[0]["lr"], z["lr_after"], rtol=1e-12)
@@ -181,7 +183,8 @@ def test_ppo_learn_at_baseline_width(name, graph):
             tot += d.size
             bad += int((d > 2e-5).sum())
             worst = max(worst, float(d.max()))
-        assert bad <= 0.005 * tot and worst <= 2.1 * lr * n_upd, (bad, tot, worst)
+        margins.leq(bad / tot, 0.005, "fraction of weights off")
+        margins.leq(worst, 2.1 * lr * n_upd, "worst weight difference vs travel")
 
 
 def test_rainbow_learn_at_atari_shapes():
@@ -254,8 +257,8 @@ def test_rainbow_learn_at_atari_shapes():
         d = np.abs(synth.thin(npy(v)) - z[f"sd1_thin/{k}"])
         tot += d.size
         bad += int((d > 0.05 * lr).sum())
-        assert float(d.max()) <= 2.1 * lr, k
-    assert bad <= 0.005 * tot, (bad, tot)
+        margins.leq(float(d.max()), 2.1 * lr, f"worst weight difference {k}")
+    margins.leq(bad / tot, 0.005, "fraction of weights off")
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -344,7 +347,7 @@ def test_td_learn_at_baseline_shapes(fixture, agent_name, use_graph):
     errs = {}
     for k in ("loss", "max_Q"):
         errs[k] = abs(result[k] - float(z[f"result/{k}"])) / (1.0 + abs(float(z[f"result/{k}"])))
-        assert errs[k] <= 1e-5, (k, result[k], float(z[f"result/{k}"]))
+        margins.leq(errs[k], 1e-5, f"result {k}")
     st = agent._static
     act = z["learn/action"].astype(np.int64).reshape(-1)
     q_all = npy(st["logits"][0]).reshape(B, A)
@@ -379,7 +382,7 @@ def test_td_learn_at_baseline_shapes(fixture, agent_name, use_graph):
             e_ours, e_ref = float(np.abs(synth.thin(v) - g64).max()) / scale, float(np.abs(g32 - g64).max()) / scale
             worst[k] = float(np.abs(synth.thin(v) - g32).max()) / scale
             vs64[k] = {"ours_vs_exact": e_ours, "reference_vs_exact": e_ref}
-            assert e_ours <= max(1e-5, 2.0 * e_ref), f"d(loss)/d{k}: {e_ours:.3e} of the largest entry from the exact gradient (reference: {e_ref:.3e})"
+            margins.leq(e_ours, max(1e-5, 2.0 * e_ref), f"d(loss)/d{k} vs the exact gradient, of the largest entry (reference: {e_ref:.3e})")
         _report(f"{fixture}_{'graph' if use_graph else 'eager'}_grad_vs_float64", vs64)
     else:
         worst = _thin_cmp(grads, z, "grad_thin/", scale_of=lambda k: z[f"grad_absmax/{k}"], tol=1e-5, what="d(loss)/d")
@@ -412,8 +415,8 @@ def test_td_learn_at_baseline_shapes(fixture, agent_name, use_graph):
         d = np.abs(synth.thin(npy(v)) - z[f"sd1_thin/{k}"])
         tot += d.size
         bad += int((d > 0.05 * travel).sum())
-        assert float(d.max()) <= 2.1 * travel, k
-    assert bad <= 0.005 * tot, (bad, tot)
+        margins.leq(float(d.max()), 2.1 * travel, f"worst weight difference {k}")
+    margins.leq(bad / tot, 0.005, "fraction of weights off by > 5 % of a step")
 
 
 @pytest.mark.parametrize("use_graph", [True])

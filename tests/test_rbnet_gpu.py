@@ -1,39 +1,65 @@
-"""GPU parity tests of the native Rainbow network (jh_rbnet_*: implicit-GEMM convolutions, noisy
-dueling heads, backward, Adam) against the plain PyTorch fp32 mirror of the reference modules
-(jorldy_amd/core/network = core/network/rainbow.py:8-94, head.py:6-61) with the same parameters,
-inputs and NoisyNet draws.  fp32 tolerance: 2e-5 relative to the tensor's max magnitude (the MFMA
-accumulates K in a different order than rocBLAS / MIOpen)."""
+"""GPU parity tests of the native value networks (jh_rbnet_*: implicit-GEMM convolutions, noisy dueling heads, backward, Adam /
+centered RMSprop) against FLOAT64 ground truth: the reference's modules (core/network/rainbow.py:8-94, dueling.py:8-35,
+q_network.py:8-20, head.py:6-61; restated in tests/mirror) evaluated on the CPU in float64 with the same parameters, inputs and
+NoisyNet draws, and torch-CPU float32 (the oracle's arithmetic) beside it.  Criterion: tests/fp64_truth.py --
+|ours - exact| <= max(1e-5, 2 x |torch_cpu_fp32 - exact|) per tensor for values / gradients; an optimizer step is checked as
+arithmetic (float64 torch.optim fed OUR gradient must give our weights / moments up to fp32 rounding).  No GPU library (MIOpen / rocBLAS) is a comparator anywhere in this file."""
+import copy
+
 import numpy as np
 import pytest
 
+import fp64_truth as T
+import margins
+
 pytestmark = pytest.mark.gpu
 
+TOL = 1e-5  # north star: 1e-5 in fp32, relative to the tensor's largest entry
 
-def _mk(head, state_size, A, K, H, B, seed=0):
+
+def _net64(name, *args, seed=0, **kw):
+    """The reference module in float64 with fp32-representable, slightly de-symmetrised parameters, and its float32 twin."""
     import torch
-    from jorldy_amd import ops
-    from jorldy_amd.core.network import Network
+    from mirror.networks import Network
 
     torch.manual_seed(seed)
-    ref = Network("rainbow", state_size, A, K, "factorized", D_hidden=H, head=head).cuda()
-    tgt = Network("rainbow", state_size, A, K, "factorized", D_hidden=H, head=head).cuda()
+    m = Network(name, *args, **kw).double()
     with torch.no_grad():
-        for net in (ref, tgt):
-            for p in net.parameters():
-                p.add_(0.05 * torch.randn_like(p))
-    nat = ops.RainbowNet(state_size, A, K, H, head, B, "cuda:0")
-    nat.import_state(ref.state_dict(), nat.params)
-    nat.import_state(tgt.state_dict(), nat.target)
-    return ref, tgt, nat
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    T.round_to_fp32_(m)
+    return m, T.as32(m)
 
 
-def _noise_dicts(nat, noise):
-    """flat noise set -> the {tag: (e_in, e_out)} dict the torch mirror takes."""
-    H, NA, K = nat.H, nat.A * nat.K, nat.K
+def _mk(head, state_size, A, K, H, B, seed=0, noise_type="factorized"):
+    from jorldy_amd import ops
+
+    ref64, ref32 = _net64("rainbow", state_size, A, K, noise_type, D_hidden=H, head=head, seed=seed)
+    tgt64, tgt32 = _net64("rainbow", state_size, A, K, noise_type, D_hidden=H, head=head, seed=seed + 100)
+    nat = ops.RainbowNet(state_size, A, K, H, head, B, "cuda:0", noise_type=noise_type)
+    nat.import_state(ref32.state_dict(), nat.params)
+    nat.import_state(tgt32.state_dict(), nat.target)
+    return (ref64, ref32), (tgt64, tgt32), nat
+
+
+def _inputs(head, S, rows, g):
+    """-> (device tensor for the native net: uint8 frames / fp32 vectors, the same values as float64 on the CPU)."""
+    import torch
+
+    if head == "cnn":
+        x = torch.randint(0, 256, (rows,) + tuple(S), dtype=torch.uint8, generator=g)
+    else:
+        x = torch.randn(rows, S, generator=g)
+    return x.cuda(), x.double()
+
+
+def _noise_dicts(nat, noise, dtype):
+    """flat noise set -> the {tag: (e_in, e_out)} dict the mirror modules take."""
+    H, NA = nat.H, nat.A * nat.K
     out = []
     for s in range(noise.shape[0]):
-        e, o, d = noise[s], 0, {}
-        for tag, n_out in (("a1", H), ("v1", H), ("a2", NA), ("v2", K)):
+        e, o, d = noise[s].to(dtype), 0, {}
+        for tag, n_out in (("a1", H), ("v1", H), ("a2", NA), ("v2", nat.K)):
             d[tag] = (e[o : o + H], e[o + H : o + H + n_out])
             o += H + n_out
         assert o == nat.noise_len
@@ -41,12 +67,13 @@ def _noise_dicts(nat, noise):
     return out
 
 
-def _close(a, b, tol=2e-5, what=""):
-    import torch
-
-    scale = float(b.abs().max()) + 1e-12
-    err = float((a - b).abs().max()) / scale
-    assert err <= tol, f"{what}: max err {err:.3e} relative to max |ref| {scale:.3e}"
+def _grads_vs_exact(nat, m64, m32, tol=TOL, tag=""):
+    """-> our raw gradient {name: tensor} (checked against float64)."""
+    grads = nat.export_state(nat.grads)
+    p32 = dict(m32.named_parameters())
+    for k, p in m64.named_parameters():
+        T.vs_exact(grads[k], p.grad, p32[k].grad, tol, f"{tag}grad {k}")
+    return grads
 
 
 CASES = [
@@ -60,117 +87,125 @@ CASES = [
 
 
 @pytest.mark.parametrize("head,S,A,K,H,B", CASES)
-def test_rbnet_three_forwards_and_backward_match_torch(head, S, A, K, H, B):
+def test_rbnet_three_forwards_and_backward_match_float64(head, S, A, K, H, B):
     import torch
 
-    ref, tgt, nat = _mk(head, S, A, K, H, B)
-    g = torch.Generator(device="cuda").manual_seed(1)
-    if head == "cnn":
-        x_all = torch.randint(0, 256, (2 * B,) + tuple(S), dtype=torch.uint8, device="cuda", generator=g)
-    else:
-        x_all = torch.randn(2 * B, S, device="cuda", generator=g)
-    noise = torch.randn(3, nat.noise_len, device="cuda", generator=g)
+    (ref64, ref32), (tgt64, tgt32), nat = _mk(head, S, A, K, H, B)
+    g = torch.Generator().manual_seed(1)
+    x_dev, x64 = _inputs(head, S, 2 * B, g)
+    noise = torch.randn(3, nat.noise_len, generator=g)
     out = torch.empty(3, B, A, K, device="cuda")
-    nat.learn_forward(x_all, B, noise, out)
-    nd = _noise_dicts(nat, noise)
-    xf = x_all.float()
-    l0 = ref(xf[:B], True, nd[0])
+    noise_dev = noise.cuda()  # stays alive until after backward(): the sigma gradients re-read the draws
+    nat.learn_forward(x_dev, B, noise_dev, out)
+    nd64, nd32 = _noise_dicts(nat, noise, torch.float64), _noise_dicts(nat, noise, torch.float32)
+    x32 = x64.float()
+    l0, l0_32 = ref64(x64[:B], True, nd64[0]), ref32(x32[:B], True, nd32[0])
     with torch.no_grad():
-        l1 = ref(xf[B:], True, nd[1])
-        l2 = tgt(xf[B:], True, nd[2])
-    _close(out[0], l0.detach(), what="online(state)")
-    _close(out[1], l1, what="online(next_state)")
-    _close(out[2], l2, what="target(next_state)")
-    gl = torch.randn(B, A, K, device="cuda", generator=g) / B
-    ref.zero_grad()
-    l0.backward(gl)
-    nat.backward(gl.contiguous())
+        l1, l1_32 = ref64(x64[B:], True, nd64[1]), ref32(x32[B:], True, nd32[1])
+        l2, l2_32 = tgt64(x64[B:], True, nd64[2]), tgt32(x32[B:], True, nd32[2])
+    T.vs_exact(out[0], l0, l0_32, TOL, "online(state)")
+    T.vs_exact(out[1], l1, l1_32, TOL, "online(next_state)")
+    T.vs_exact(out[2], l2, l2_32, TOL, "target(next_state)")
+    gl = torch.randn(B, A, K, generator=g) / B
+    l0.backward(gl.double())
+    l0_32.backward(gl)
+    nat.backward(gl.cuda().contiguous())
     torch.cuda.synchronize()
-    grads = nat.export_state(nat.grads)
-    for k, p in ref.named_parameters():
-        _close(grads[k], p.grad, tol=5e-5, what=f"grad {k}")
+    _grads_vs_exact(nat, ref64, ref32)
 
 
 @pytest.mark.parametrize("head,S,A,K,H,B", CASES[:3])
 def test_rbnet_eval_forward_and_uint8_vs_float_input(head, S, A, K, H, B):
     import torch
 
-    ref, tgt, nat = _mk(head, S, A, K, H, B, seed=3)
-    if head == "cnn":
-        x = torch.randint(0, 256, (B,) + tuple(S), dtype=torch.uint8, device="cuda")
-    else:
-        x = torch.randn(B, S, device="cuda")
+    (ref64, ref32), (tgt64, tgt32), nat = _mk(head, S, A, K, H, B, seed=3)
+    g = torch.Generator().manual_seed(4)
+    x_dev, x64 = _inputs(head, S, B, g)
     rows = max(1, B - 3)
-    got = nat.forward(x[:rows].contiguous(), which=1, noise=None)
+    got = nat.forward(x_dev[:rows].contiguous(), which=1, noise=None)
     with torch.no_grad():
-        want = tgt(x[:rows].float(), False)
-    _close(got, want, what="target eval forward")
+        want, want32 = tgt64(x64[:rows], False), tgt32(x64[:rows].float(), False)
+    T.vs_exact(got, want, want32, TOL, "target eval forward")
     if head == "cnn":  # fp32 frames (the reference's as_tensor path) give the same numbers as uint8 frames: the operands are the
         # same fp32 values (byte / 255 correctly rounded), only the summation order of layer 1 differs (dedicated uint8 kernel)
-        got_f = nat.forward(x[:rows].float().contiguous(), which=1, noise=None)
-        _close(got, got_f, tol=2e-6, what="uint8 vs fp32 frames")
+        got_f = nat.forward(x_dev[:rows].float().contiguous(), which=1, noise=None)
+        T.vs_exact(got_f, want, want32, TOL, "target eval forward from fp32 frames")
 
 
-def test_rbnet_adam_matches_torch_adam_over_several_steps():
+def _native_state(nat):
+    return nat.export_state(), nat.export_state(nat.m), nat.export_state(nat.v)
+
+
+def _force(nat, truth, set_hyper, it):
+    params, m, v = truth.teacher_force()
+    nat.import_state(params, nat.params)
+    if m is not None:
+        nat.import_state(m, nat.m)
+    else:
+        nat.m.zero_()
+    if v is not None:
+        nat.import_state(v, nat.v)
+    else:
+        nat.v.zero_()
+    set_hyper(it)
+
+
+def test_rbnet_adam_matches_float64_adam_over_several_steps():
+    """Adam (eps 1.5e-4 as config.rainbow.atari), a learning-rate change in the middle; four teacher-forced steps."""
     import torch
 
-    ref, tgt, nat = _mk("mlp", 4, 3, 11, 32, 16, seed=5)
-    opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1.5e-4)
-    nat.set_hyper(3e-4, 0.9, 0.999, 1.5e-4, 0)
-    g = torch.Generator(device="cuda").manual_seed(2)
+    (ref64, ref32), _, nat = _mk("mlp", 4, 3, 11, 32, 16, seed=5)
+    lr = [3e-4]
+    truth = T.OptimTruth(ref64, ref32, lambda ps: torch.optim.Adam(ps, lr=lr[0], eps=1.5e-4), lr[0], ("exp_avg", "exp_avg_sq"))
+    g = torch.Generator().manual_seed(2)
     for it in range(4):
-        x_all = torch.randn(32, 4, device="cuda", generator=g)
-        noise = torch.randn(3, nat.noise_len, device="cuda", generator=g)
+        _force(nat, truth, lambda step: nat.set_hyper(lr[0], 0.9, 0.999, 1.5e-4, step), it)
+        x_dev, x64 = _inputs("mlp", 4, 32, g)
+        noise = torch.randn(3, nat.noise_len, generator=g)
         out = torch.empty(3, 16, 3, 11, device="cuda")
-        nat.learn_forward(x_all, 16, noise, out)
-        gl = torch.randn(16, 3, 11, device="cuda", generator=g)
-        l0 = ref(x_all[:16], True, _noise_dicts(nat, noise)[0])
-        opt.zero_grad()
-        l0.backward(gl)
-        opt.step()
-        nat.backward(gl)
+        noise_dev = noise.cuda()  # alive until after backward()
+        nat.learn_forward(x_dev, 16, noise_dev, out)
+        gl = torch.randn(16, 3, 11, generator=g)
+        for m, opt, dt in ((ref64, truth.opt64, torch.float64), (ref32, truth.opt32, torch.float32)):
+            opt.zero_grad()
+            m(x64[:16].to(dt), True, _noise_dicts(nat, noise, dt)[0]).backward(gl.to(dt))
+        nat.backward(gl.cuda())
+        raw = _grads_vs_exact(nat, ref64, ref32, tag=f"step {it} ")
         nat.adam_step()
+        truth.step(None, raw, *_native_state(nat), tag=f"adam step {it}")
         if it == 1:
-            nat.set_lr(1e-4)
-            opt.param_groups[0]["lr"] = 1e-4
-    sd = nat.export_state()
-    for k, p in ref.state_dict().items():
-        assert float((sd[k] - p).abs().max()) <= 2e-6, k  # a handful of lr-sized steps
+            lr[0] = 1e-4
+            truth.lr = 1e-4
+            for opt in (truth.opt64, truth.opt32):
+                opt.param_groups[0]["lr"] = 1e-4
 
 
 def test_rbnet_state_dict_roundtrip_and_target_sync():
     import torch
 
-    ref, tgt, nat = _mk("cnn", (4, 44, 52), 3, 51, 32, 4, seed=7)
+    (ref64, ref32), _, nat = _mk("cnn", (4, 44, 52), 3, 51, 32, 4, seed=7)
     sd = nat.export_state()
-    assert list(sd.keys()) == list(ref.state_dict().keys())
-    for k, v in ref.state_dict().items():
-        assert sd[k].shape == v.shape and torch.equal(sd[k], v), k
+    assert list(sd.keys()) == list(ref32.state_dict().keys())
+    for k, v in ref32.state_dict().items():
+        assert sd[k].shape == v.shape and torch.equal(sd[k].cpu(), v), k
     nat.sync_target()
     sdt = nat.export_state(nat.target)
-    for k, v in ref.state_dict().items():
-        assert torch.equal(sdt[k], v), k
+    for k, v in ref32.state_dict().items():
+        assert torch.equal(sdt[k].cpu(), v), k
 
 
 # ------------------------------------------------------------------ dueling / q-network kinds (Ape-X, DQN family)
 def _mk_kind(kind, head, S, A, H, B, seed=0):
-    import torch
     from jorldy_amd import ops
-    from jorldy_amd.core.network import Network
 
-    torch.manual_seed(seed)
     name = {"dueling": "dueling", "q": "discrete_q_network"}[kind]
-    ref = Network(name, S, A, D_hidden=H, head=head).cuda()
-    tgt = Network(name, S, A, D_hidden=H, head=head).cuda()
-    with torch.no_grad():
-        for net in (ref, tgt):
-            for p in net.parameters():
-                p.add_(0.05 * torch.randn_like(p))
+    ref64, ref32 = _net64(name, S, A, D_hidden=H, head=head, seed=seed)
+    tgt64, tgt32 = _net64(name, S, A, D_hidden=H, head=head, seed=seed + 100)
     nat = ops.RainbowNet(S, A, 1, H, head, B, "cuda:0", kind=kind)
-    nat.import_state(ref.state_dict(), nat.params)
-    nat.import_state(tgt.state_dict(), nat.target)
-    assert list(nat.export_state().keys()) == list(ref.state_dict().keys())
-    return ref, tgt, nat
+    nat.import_state(ref32.state_dict(), nat.params)
+    nat.import_state(tgt32.state_dict(), nat.target)
+    assert list(nat.export_state().keys()) == list(ref32.state_dict().keys())
+    return (ref64, ref32), (tgt64, tgt32), nat
 
 
 KIND_CASES = [
@@ -183,210 +218,104 @@ KIND_CASES = [
 
 
 @pytest.mark.parametrize("kind,head,S,A,H,B", KIND_CASES)
-def test_value_net_kinds_forward_backward_and_rmsprop_match_torch(kind, head, S, A, H, B):
+def test_value_net_kinds_forward_backward_and_rmsprop_match_float64(kind, head, S, A, H, B):
+    """Three teacher-forced steps of config.ape_x.atari's optimizer (centered RMSprop, alpha 0.95, eps 1.5e-7; clip_grad_norm_ 0.5
+    on the first step so that the clip bites, 40 = the config's afterwards): forward values, every parameter gradient, grad_avg /
+    square_avg and the stepped weights against float64."""
     import torch
 
-    ref, tgt, nat = _mk_kind(kind, head, S, A, H, B)
-    opt = torch.optim.RMSprop(ref.parameters(), lr=2.5e-4, alpha=0.95, eps=1.5e-7, centered=True)
-    nat.set_hyper(2.5e-4, 0.95, 0.0, 1.5e-7, 0, centered=True)
-    g = torch.Generator(device="cuda").manual_seed(1)
+    (ref64, ref32), (tgt64, tgt32), nat = _mk_kind(kind, head, S, A, H, B)
+    lr = 2.5e-4
+    truth = T.OptimTruth(ref64, ref32, lambda ps: torch.optim.RMSprop(ps, lr=lr, alpha=0.95, eps=1.5e-7, centered=True), lr, ("grad_avg", "square_avg"))
+    g = torch.Generator().manual_seed(1)
     for it in range(3):
-        if head == "cnn":
-            x_all = torch.randint(0, 256, (2 * B,) + tuple(S), dtype=torch.uint8, device="cuda", generator=g)
-        else:
-            x_all = torch.randn(2 * B, S, device="cuda", generator=g)
+        _force(nat, truth, lambda step: nat.set_hyper(lr, 0.95, 0.0, 1.5e-7, step, centered=True), it)
+        x_dev, x64 = _inputs(head, S, 2 * B, g)
         out = torch.empty(3, B, A, 1, device="cuda")
-        nat.learn_forward(x_all, B, None, out)
-        xf = x_all.float()
-        q0 = ref(xf[:B])
+        nat.learn_forward(x_dev, B, None, out)
+        x32 = x64.float()
+        q0, q0_32 = ref64(x64[:B]), ref32(x32[:B])
         with torch.no_grad():
-            q1, q2 = ref(xf[B:]), tgt(xf[B:])
-        if it == 0:
-            _close(out[0, :, :, 0], q0.detach(), what="online(state)")
-            _close(out[1, :, :, 0], q1, what="online(next_state)")
-            _close(out[2, :, :, 0], q2, what="target(next_state)")
-        gl = torch.randn(B, A, device="cuda", generator=g)
-        opt.zero_grad()
-        q0.backward(gl)
-        nat.backward(gl.contiguous())
-        if it == 0:
-            grads = nat.export_state(nat.grads)
-            for k, p in ref.named_parameters():
-                _close(grads[k], p.grad, tol=5e-5, what=f"grad {k}")
-        norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 40.0 if it else 0.5)  # 0.5: the clip bites
-        opt.step()
-        nat.optim_step("rmsprop", 40.0 if it else 0.5)
-    sd = nat.export_state()
-    for k, p in ref.state_dict().items():
-        # centered RMSprop divides by sqrt(E[g^2] - E[g]^2): ill-conditioned in the first steps, so compare the
-        # travel of every weight (<= a few lr) rather than demanding bit-close updates
-        assert float((sd[k] - p).abs().max()) <= 3e-5, k
+            q1, q1_32, q2, q2_32 = ref64(x64[B:]), ref32(x32[B:]), tgt64(x64[B:]), tgt32(x32[B:])
+        T.vs_exact(out[0, :, :, 0], q0, q0_32, TOL, f"step {it} online(state)")
+        T.vs_exact(out[1, :, :, 0], q1, q1_32, TOL, f"step {it} online(next_state)")
+        T.vs_exact(out[2, :, :, 0], q2, q2_32, TOL, f"step {it} target(next_state)")
+        gl = torch.randn(B, A, generator=g)
+        truth.opt64.zero_grad()
+        truth.opt32.zero_grad()
+        q0.backward(gl.double())
+        q0_32.backward(gl)
+        nat.backward(gl.cuda().contiguous())
+        raw = _grads_vs_exact(nat, ref64, ref32, tag=f"step {it} ")
+        clip = 40.0 if it else 0.5  # 0.5: the clip bites
+        nat.optim_step("rmsprop", clip)
+        truth.step(clip, raw, *_native_state(nat), tag=f"rmsprop step {it}")
 
 
 def test_value_net_adam_with_clip_and_eval_forward():
     import torch
 
-    ref, tgt, nat = _mk_kind("dueling", "mlp", 5, 4, 32, 16, seed=9)
-    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
-    nat.set_hyper(1e-3, 0.9, 0.999, 1e-8, 0)
-    g = torch.Generator(device="cuda").manual_seed(2)
+    (ref64, ref32), _, nat = _mk_kind("dueling", "mlp", 5, 4, 32, 16, seed=9)
+    lr = 1e-3
+    truth = T.OptimTruth(ref64, ref32, lambda ps: torch.optim.Adam(ps, lr=lr), lr, ("exp_avg", "exp_avg_sq"))
+    g = torch.Generator().manual_seed(2)
     for it in range(3):
-        x_all = torch.randn(32, 5, device="cuda", generator=g)
+        _force(nat, truth, lambda step: nat.set_hyper(lr, 0.9, 0.999, 1e-8, step), it)
+        x_dev, x64 = _inputs("mlp", 5, 32, g)
         out = torch.empty(3, 16, 4, 1, device="cuda")
-        nat.learn_forward(x_all, 16, None, out)
-        gl = torch.randn(16, 4, device="cuda", generator=g)
-        opt.zero_grad()
-        ref(x_all[:16]).backward(gl)
-        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
-        opt.step()
-        nat.backward(gl)
+        nat.learn_forward(x_dev, 16, None, out)
+        gl = torch.randn(16, 4, generator=g)
+        truth.opt64.zero_grad()
+        truth.opt32.zero_grad()
+        ref64(x64[:16]).backward(gl.double())
+        ref32(x64[:16].float()).backward(gl)
+        nat.backward(gl.cuda())
+        raw = _grads_vs_exact(nat, ref64, ref32, tag=f"step {it} ")
         nat.optim_step("adam", 1.0)
-    sd = nat.export_state()
-    for k, p in ref.state_dict().items():
-        assert float((sd[k] - p).abs().max()) <= 3e-6, k
-    x = torch.randn(7, 5, device="cuda", generator=g)
-    _close(nat.forward(x, which=0)[:, :, 0], ref(x).detach(), what="acting forward")
+        truth.step(1.0, raw, *_native_state(nat), tag=f"adam+clip step {it}")
+    x_dev, x64 = _inputs("mlp", 5, 7, g)
+    T.round_to_fp32_(ref64)
+    nat.import_state({k: v.float() for k, v in ref64.state_dict().items()}, nat.params)
+    with torch.no_grad():
+        T.vs_exact(nat.forward(x_dev, which=0)[:, :, 0], ref64(x64), T.as32(ref64)(x64.float()), TOL, "acting forward")
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("n,M,N,K", [(3, 64, 1024, 3136), (2, 512, 512, 3136), (1, 2048, 256, 64), (4, 96, 64, 4096)])
-def test_tgemm_grouped_split_k_is_exact_launch_after_launch(n, M, N, K):
-    """Grouped launches on the LDS-DMA operand path with split-K hand-offs (the Ape-X / R2D2 forward shapes), many times over fresh
-    operands: the hand-off between the splits (sc1 partial stores, ticket, last arriver's sum) went wrong once in a few hundred
-    launches -- 32 elements of one accumulator fragment -- until its asm loads carried their wait and its asm stores their s_nop."""
-    import torch
-    from jorldy_amd import ops
-
-    g = torch.Generator(device="cuda").manual_seed(n * 1000 + M)
-    for _ in range(40):
-        As = [torch.randn(M, K, device="cuda", generator=g) for _ in range(n)]
-        Bs = [torch.randn(N, K, device="cuda", generator=g) for _ in range(n)]
-        Cs = ops.tgemm_dense_group(As, Bs)
-        torch.cuda.synchronize()
-        for a, b, c in zip(As, Bs, Cs):
-            want = a.double() @ b.double().t()
-            err = ((c.double() - want).abs() / want.abs().max())
-            assert int((~(err < 1e-5)).sum()) == 0, float(err.max())
-
-
-def test_tgemm_dense_random_shapes_modes_and_epilogues_match_torch():
-    """The GEMM engine under every value-network layer, on 80 random problems: ragged M / N / K (not multiples of
-    the 64 x 64 x 32 tile, of 4, or of anything), all four dense operand layouts, row strides that do and do not
-    allow 16-byte loads, every epilogue, fused row sums, shapes that do and do not split K."""
-    import torch
-    from jorldy_amd import ops
-
-    g = torch.Generator(device="cuda").manual_seed(0)
-    rng = np.random.RandomState(0)
-    dims = [1, 2, 3, 4, 5, 7, 8, 11, 16, 31, 32, 33, 51, 64, 65, 100, 127, 128, 204, 256, 512, 777, 1024, 3136]
-    for case in range(80):
-        M, N = int(rng.choice(dims[:-3])), int(rng.choice(dims[:-3]))
-        K = int(rng.choice(dims)) if case % 5 else int(rng.choice([2048, 3136, 12800]))
-        a_kc, b_kc = bool(rng.randint(2)), bool(rng.randint(2))
-        pad_a, pad_b = int(rng.choice([0, 0, 1, 4])), int(rng.choice([0, 0, 3, 4]))
-        A = torch.randn((M, K + pad_a) if a_kc else (K, M + pad_a), device="cuda", generator=g)
-        Bm = torch.randn((N, K + pad_b) if b_kc else (K, N + pad_b), device="cuda", generator=g)
-        a_v = A[:, :K] if a_kc else A[:, :M]
-        b_v = Bm[:, :K] if b_kc else Bm[:, :N]
-        a2 = a_v if a_kc else a_v.t()       # [M, K]
-        b2 = b_v.t() if b_kc else b_v       # [K, N]
-        epi = case % 4
-        bias = torch.randn(N, device="cuda", generator=g) if epi in (1, 2) else None
-        aux = torch.randn(M, N, device="cuda", generator=g) if epi == 3 else None
-        want = a2.double() @ b2.double()
-        if epi in (1, 2):
-            want = want + bias.double()
-        if epi == 2:
-            want = want.clamp_min(0)
-        if epi == 3:
-            want = torch.where(aux > 0, want, torch.zeros_like(want))
-        got, rs = ops.tgemm_dense(a_v, b_v, a_kcont=a_kc, b_kcont=b_kc, epi=epi, bias=bias, aux=aux, rowsum=True, M=M, N=N, K=K)
-        scale = float(a2.abs().double().matmul(b2.abs().double()).max()) + 1e-9  # fp32 accumulation error scales with sum |a||b|
-        err = float((got.double() - want).abs().max()) / scale
-        assert err < 2e-6, (case, M, N, K, a_kc, b_kc, epi, err)
-        rs_err = float((rs.double() - a2.double().sum(1)).abs().max()) / (float(a2.abs().double().sum(1).max()) + 1e-9)
-        assert rs_err < 2e-6, (case, M, N, K, "rowsum", rs_err)
-
-
-@pytest.mark.gpu
-def test_tgemm_dense_lds_dma_shapes_all_layouts_match_torch():
-    """Problems the LDS-DMA kernel takes (K % 32 == 0, 16-byte pieces, x-contiguous extents % 4 == 0; tiles that are and are not
-    full, K ranges that do and do not split, one to three chunk buffers' worth of K) in all four dense layouts, with every epilogue
-    and the fused row sums."""
-    import torch
-    from jorldy_amd import ops
-
-    g = torch.Generator(device="cuda").manual_seed(1)
-    rng = np.random.RandomState(1)
-    for case in range(64):
-        a_kc, b_kc = bool(case & 1), bool(case & 2)
-        M = int(rng.choice([64, 65, 100, 512, 777] if a_kc else [64, 68, 132, 512, 1000]))
-        N = int(rng.choice([64, 100, 129, 512] if b_kc else [64, 68, 260, 512]))
-        K = int(rng.choice([32, 64, 96, 128, 512, 1024, 3136, 6400]))
-        pad = 4 * int(rng.randint(2))
-        A = torch.randn((M, K + pad) if a_kc else (K, M + pad), device="cuda", generator=g)
-        Bm = torch.randn((N, K + pad) if b_kc else (K, N + pad), device="cuda", generator=g)
-        a_v = A[:, :K] if a_kc else A[:, :M]
-        b_v = Bm[:, :K] if b_kc else Bm[:, :N]
-        a2 = a_v if a_kc else a_v.t()
-        b2 = b_v.t() if b_kc else b_v
-        epi = (case >> 2) % 4
-        bias = torch.randn(N, device="cuda", generator=g) if epi in (1, 2) else None
-        aux = torch.randn(M, N, device="cuda", generator=g) if epi == 3 else None
-        want = a2.double() @ b2.double()
-        if epi in (1, 2):
-            want = want + bias.double()
-        if epi == 2:
-            want = want.clamp_min(0)
-        if epi == 3:
-            want = torch.where(aux > 0, want, torch.zeros_like(want))
-        for rep in range(3):
-            got, rs = ops.tgemm_dense(a_v, b_v, a_kcont=a_kc, b_kcont=b_kc, epi=epi, bias=bias, aux=aux, rowsum=True, M=M, N=N, K=K)
-            scale = float(a2.abs().double().matmul(b2.abs().double()).max()) + 1e-9
-            err = float((got.double() - want).abs().max()) / scale
-            assert err < 2e-6, (case, rep, M, N, K, a_kc, b_kc, epi, err)
-            rs_err = float((rs.double() - a2.double().sum(1)).abs().max()) / (float(a2.abs().double().sum(1).max()) + 1e-9)
-            assert rs_err < 2e-6, (case, rep, M, N, K, "rowsum", rs_err)
-
-
-def test_rbnet_independent_noise_matches_torch():
+def test_rbnet_independent_noise_matches_float64():
     """noise_type="independent" (utils.py:72-79: one Gaussian draw per weight): three forwards + backward."""
     import torch
-    from jorldy_amd import ops
-    from jorldy_amd.core.network import Network
 
     S, A, K, H, B = 5, 3, 11, 32, 8
-    torch.manual_seed(0)
-    ref = Network("rainbow", S, A, K, "independent", D_hidden=H, head="mlp").cuda()
-    with torch.no_grad():
-        for p in ref.parameters():
-            p.add_(0.05 * torch.randn_like(p))
-    nat = ops.RainbowNet(S, A, K, H, "mlp", B, "cuda:0", noise_type="independent")
-    nat.import_state(ref.state_dict(), nat.params)
-    nat.import_state(ref.state_dict(), nat.target)
-    g = torch.Generator(device="cuda").manual_seed(1)
-    x_all = torch.randn(2 * B, S, device="cuda", generator=g)
-    noise = torch.randn(3, nat.noise_len, device="cuda", generator=g)
+    (ref64, ref32), _, nat = _mk("mlp", S, A, K, H, B, noise_type="independent")
+    nat.import_state(ref32.state_dict(), nat.target)
+    g = torch.Generator().manual_seed(1)
+    x_dev, x64 = _inputs("mlp", S, 2 * B, g)
+    noise = torch.randn(3, nat.noise_len, generator=g)
     assert nat.noise_len == 2 * (H * H + H) + H * A * K + A * K + H * K + K
-    nd = []
-    for s in range(3):
-        e, o, d = noise[s], 0, {}
-        for tag, n_out in (("a1", H), ("v1", H), ("a2", A * K), ("v2", K)):
-            d[tag] = (e[o : o + H * n_out].view(H, n_out), e[o + H * n_out : o + H * n_out + n_out])
-            o += H * n_out + n_out
-        nd.append(d)
+
+    def dicts(dtype):
+        nd = []
+        for s in range(3):
+            e, o, d = noise[s].to(dtype), 0, {}
+            for tag, n_out in (("a1", H), ("v1", H), ("a2", A * K), ("v2", K)):
+                d[tag] = (e[o : o + H * n_out].view(H, n_out), e[o + H * n_out : o + H * n_out + n_out])
+                o += H * n_out + n_out
+            nd.append(d)
+        return nd
+
+    nd64, nd32 = dicts(torch.float64), dicts(torch.float32)
     out = torch.empty(3, B, A, K, device="cuda")
-    nat.learn_forward(x_all, B, noise, out)
-    l0 = ref(x_all[:B], True, nd[0])
+    noise_dev = noise.cuda()  # stays alive until after backward(): the sigma gradients re-read the draws
+    nat.learn_forward(x_dev, B, noise_dev, out)
+    x32 = x64.float()
+    l0, l0_32 = ref64(x64[:B], True, nd64[0]), ref32(x32[:B], True, nd32[0])
     with torch.no_grad():
-        l1, l2 = ref(x_all[B:], True, nd[1]), ref(x_all[B:], True, nd[2])
-    _close(out[0], l0.detach(), what="online(state)")
-    _close(out[1], l1, what="online(next_state)")
-    _close(out[2], l2, what="target(next_state)")
-    gl = torch.randn(B, A, K, device="cuda", generator=g) / B
-    ref.zero_grad()
-    l0.backward(gl)
-    nat.backward(gl.contiguous())
-    grads = nat.export_state(nat.grads)
-    for k, p in ref.named_parameters():
-        _close(grads[k], p.grad, tol=5e-5, what=f"grad {k}")
+        l1, l1_32 = ref64(x64[B:], True, nd64[1]), ref32(x32[B:], True, nd32[1])
+        l2, l2_32 = ref64(x64[B:], True, nd64[2]), ref32(x32[B:], True, nd32[2])
+    T.vs_exact(out[0], l0, l0_32, TOL, "online(state)")
+    T.vs_exact(out[1], l1, l1_32, TOL, "online(next_state)")
+    T.vs_exact(out[2], l2, l2_32, TOL, "target(next_state)")
+    gl = torch.randn(B, A, K, generator=g) / B
+    l0.backward(gl.double())
+    l0_32.backward(gl)
+    nat.backward(gl.cuda().contiguous())
+    _grads_vs_exact(nat, ref64, ref32)

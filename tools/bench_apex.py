@@ -7,7 +7,7 @@ One learner iteration = ingest one actor chunk (update_period=100 n-step transit
 coalesced ring append + one sum-tree push) and one ApeX.learn() (PER sample -> gather -> 3 CNN forwards +
 backward + clip + RMSprop on jh_rbnet_* -> jh_td_loss -> priority write-back), replayed as one hipGraph.
 
-    python tools/bench_apex.py [--updates 100] [--backend native|torch]
+    python tools/bench_apex.py [--updates 100]
 """
 import argparse
 import json
@@ -25,7 +25,6 @@ def main():
     ap.add_argument("--buffer", type=int, default=200000)
     ap.add_argument("--updates", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--backend", default="native", choices=["native", "torch"])
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--actors", type=int, default=0, help="N > 0: N host actor threads publish chunks into the staging ring while the learner runs")
     ap.add_argument("--actor-hz", type=float, default=0.0, help="env steps/s per actor (0: as fast as the ring takes them = ingestion capacity)")
@@ -46,7 +45,7 @@ def main():
     agent = Agent("ape_x", state_size=[4, 84, 84], action_size=6, hidden_size=512, network="dueling", head="cnn",
                   optim_config={"name": "rmsprop", "eps": 1.5e-7, "lr": 2.5e-4 / 4, "centered": True}, gamma=0.99, buffer_size=N, batch_size=B,
                   clip_grad_norm=40.0, start_train_step=0, target_update_period=2500, run_step=30_000_000, n_step=n, alpha=0.6, beta=0.4,
-                  uniform_sample_prob=1e-3, num_workers=64, device="cuda", backend=args.backend)
+                  uniform_sample_prob=1e-3, num_workers=64, device="cuda")
     agent.memory.first_store = False
     rng = np.random.RandomState(0)
     if args.device_feed:
@@ -228,7 +227,7 @@ def main():
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
     out = {
         "workload": f"config.ape_x.atari pong-shaped (BASELINE.json configs[3]), synthetic uint8 (4,84,84), A=6, B={B}, n=3, dueling CNN, centered RMSprop, clip 40, "
-                    f"PER N={N} ({filled} filled), backend {args.backend}",
+                    f"PER N={N} ({filled} filled)",
         "learner_updates_per_s": args.updates / dt,
         "sampled_transitions_per_s": B * args.updates / dt,
         "ingested_transitions_per_s": (async_stats or e2e_stats)["ingested_transitions_per_s"] if (async_stats or e2e_stats) else chunk_rows * args.updates / dt,

@@ -4,7 +4,7 @@ mode): learner-side hot path at Atari shapes with synthetic transitions (SURVEY.
 uint8 (4,84,84) frames, A=4, n_step=3, K=51, B=32, PER alpha .5, buffer N slots.
 
 Per env step: PERBuffer.store of one transition; every `learn_period`=4 steps one Rainbow.learn()
-(PER sample -> gather -> 3 CNN forwards + backward (jh_rbnet_*, or torch/MIOpen with --backend torch) -> jh_c51_loss ->
+(PER sample -> gather -> 3 CNN forwards + backward (jh_rbnet_*) -> jh_c51_loss ->
 priority write-back -> Adam).  Reports learner updates/s and the implied env-steps/s ceiling
 (learn_period x updates/s), next to the same loop on the CPU reference port when --cpu is given.
 
@@ -26,7 +26,6 @@ def main():
     ap.add_argument("--buffer", type=int, default=100000)
     ap.add_argument("--updates", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--backend", default="native", choices=["native", "torch"])
     ap.add_argument("--stream", action="store_true", help="frame-stack stream (consecutive transitions share frames, as the Atari wrapper produces) instead of i.i.d. stacks")
     ap.add_argument("--frame-dedup", action="store_true", help="store single frames + slot numbers (implies --stream)")
     args = ap.parse_args()
@@ -38,7 +37,7 @@ def main():
     N, B, n = args.buffer, 32, 3
     agent = Agent("rainbow", state_size=[4, 84, 84], action_size=4, hidden_size=512, head="cnn", optim_config={"name": "adam", "lr": 6.25e-5},
                   gamma=0.99, buffer_size=N, batch_size=B, start_train_step=0, target_update_period=10000, run_step=30_000_000, n_step=n,
-                  alpha=0.5, beta=0.4, learn_period=4, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51, device="cuda", backend=args.backend,
+                  alpha=0.5, beta=0.4, learn_period=4, uniform_sample_prob=1e-3, v_min=-1, v_max=10, num_support=51, device="cuda",
                   frame_dedup=args.frame_dedup)
     agent.memory.first_store = False
     rng = np.random.RandomState(0)
@@ -114,8 +113,8 @@ def main():
     torch.cuda.synchronize()
     dt_learn = (time.perf_counter() - t0) / 40
     out = {
-        "workload": f"config.rainbow.atari breakout-shaped, synthetic uint8 (4,84,84), B=32, n=3, K=51, PER N={N} ({filled} filled), network backend {args.backend}",
-        "backend": args.backend,
+        "workload": f"config.rainbow.atari breakout-shaped, synthetic uint8 (4,84,84), B=32, n=3, K=51, PER N={N} ({filled} filled)",
+        "backend": "native",
         "stream": stream,
         "frame_dedup": agent.memory._frames.stats() if agent.memory._frames is not None else None,
         "learner_updates_per_s": args.updates / dt,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """learn() latency of the TD-family agents at CartPole shapes (BASELINE.json configs[0]: S=4, A=2, hidden 512, B=32;
-config/dqn/cartpole.py) on both network backends: "native" (jh_rbnet_*: q-network / dueling / noisy categorical
-net, backward and optimizer on libjorldy_hip) vs "torch" (PyTorch mirror modules); both replay learn() as one hipGraph.
+config/dqn/cartpole.py): q-network / dueling / noisy categorical net, backward and optimizer on libjorldy_hip (jh_rbnet_*), learn()
+replayed as one hipGraph.
 Prints microseconds per learn().    python tools/bench_td_mlp.py"""
 import sys, time, json
 import os
@@ -10,10 +10,10 @@ import numpy as np, torch
 from jorldy_amd.core.agent import Agent
 out = {}
 for name, extra in (("dqn", {}), ("per", dict(learn_period=1)), ("ape_x", dict(num_workers=8, n_step=3)), ("rainbow", dict(n_step=3))):
-    for backend in ("native", "torch"):
+    for backend in ("native",):
         torch.manual_seed(0); np.random.seed(0)
         kw = dict(state_size=4, action_size=2, hidden_size=512, optim_config={"name": "adam", "lr": 1e-4}, buffer_size=50000, batch_size=32, start_train_step=0,
-                  run_step=10**7, device="cuda", backend=backend)
+                  run_step=10**7, device="cuda")
         kw.update(extra)
         a = Agent(name, **kw)
         a.memory.first_store = False
