@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define JH_ABI_VERSION 1
+#define JH_ABI_VERSION 2
 
 typedef enum {
   JH_OK = 0,
@@ -267,9 +267,11 @@ int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int32_t conti
 void jh_pponet_destroy(jh_pponet* n);
 /* Adam hyper-parameters live in device memory (a captured graph can be replayed while the host
  * anneals lr, core/agent/base.py:93-111).  step >= 0 sets Adam's step counter (checkpoint restore),
- * step < 0 keeps it.                                                                            */
-int jh_pponet_set_hyper(jh_pponet* n, float lr, float beta1, float beta2, float eps, float step, jh_stream stream);
-int jh_pponet_set_lr(jh_pponet* n, float lr, jh_stream stream);
+ * step < 0 keeps it.  Hyper-parameters are DOUBLES: torch.optim derives (1 - beta) and the bias
+ * corrections 1 - beta^t in Python double arithmetic before its fp32 kernels see them, and so does this
+ * library ((1.f - 0.999f) would be off by 1.3e-5 relative, visible in exp_avg_sq).                */
+int jh_pponet_set_hyper(jh_pponet* n, double lr, double beta1, double beta2, double eps, double step, jh_stream stream);
+int jh_pponet_set_lr(jh_pponet* n, double lr, jh_stream stream);
 /* Forward of B rows of d_x [*, S] (gathered through d_idx int64[B] when non-NULL: the `state[idx]`
  * of ppo.py:122).  Writes the RAW heads: d_head0 = logits | mu_raw [B][A], d_head1 = log_std_raw
  * (continuous only), d_value [B].  Activations stay in the net for a following backward.     */
@@ -424,9 +426,9 @@ int jh_rbnet_segment(const jh_rbnet* n, int32_t i, int64_t* offset, int32_t* row
  * kind 3: per layer [eps_w (in x out, row-major like the reference's mu_w)][eps_b (out)]                   */
 int64_t jh_rbnet_noise_len(const jh_rbnet* n);
 /* Adam: (lr, beta1, beta2, eps).  RMSprop: (lr, alpha, unused, eps) + centered.  step = optimizer step counter. */
-int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1_or_alpha, float beta2, float eps, int64_t step, int32_t centered,
+int jh_rbnet_set_hyper(jh_rbnet* n, double lr, double beta1_or_alpha, double beta2, double eps, int64_t step, int32_t centered,
                        jh_stream stream);
-int jh_rbnet_set_lr(jh_rbnet* n, float lr, jh_stream stream);
+int jh_rbnet_set_lr(jh_rbnet* n, double lr, jh_stream stream);
 /* update_target (dqn.py:162-163, rainbow.py:270-271): target <- online                                  */
 int jh_rbnet_sync_target(jh_rbnet* n, jh_stream stream);
 /* network(x[, is_train]): rows <= max_batch observations (JH_U8 or JH_F32; NCHW images or [rows][S]),

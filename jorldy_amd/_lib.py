@@ -85,8 +85,8 @@ _PROTOS = {
     "jh_pponet_param_count": (_i64, [_i32, _i32, _i32, _i32]),
     "jh_pponet_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.c_uint64, _pp]),
     "jh_pponet_destroy": (None, [_vp]),
-    "jh_pponet_set_hyper": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _f32, _vp]),
-    "jh_pponet_set_lr": (C.c_int, [_vp, _f32, _vp]),
+    "jh_pponet_set_hyper": (C.c_int, [_vp, _f64, _f64, _f64, _f64, _f64, _vp]),
+    "jh_pponet_set_lr": (C.c_int, [_vp, _f64, _vp]),
     "jh_pponet_hyper_ptr": (_vp, [_vp]),
     "jh_pponet_act_rng": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i32]),
     "jh_pponet_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -109,9 +109,9 @@ _PROTOS = {
     "jh_rbnet_segment_count": (_i32, []),
     "jh_rbnet_segment": (C.c_int, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)]),
     "jh_rbnet_noise_len": (_i64, [_vp]),
-    "jh_rbnet_set_hyper": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _i64, _i32, _vp]),
+    "jh_rbnet_set_hyper": (C.c_int, [_vp, _f64, _f64, _f64, _f64, _i64, _i32, _vp]),
     "jh_rbnet_optim_step": (C.c_int, [_vp, _i32, _f32, _vp]),
-    "jh_rbnet_set_lr": (C.c_int, [_vp, _f32, _vp]),
+    "jh_rbnet_set_lr": (C.c_int, [_vp, _f64, _vp]),
     "jh_rbnet_sync_target": (C.c_int, [_vp, _vp]),
     "jh_rbnet_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "jh_rbnet_learn_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
@@ -175,8 +175,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError -> header / library out of sync: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.jh_abi_version() != 1:
-        raise JhError(f"ABI mismatch: library reports {lib.jh_abi_version()}, binding expects 1")
+    if lib.jh_abi_version() != 2:
+        raise JhError(f"ABI mismatch: library reports {lib.jh_abi_version()}, binding expects 2")
     _lib = lib
     return lib
 

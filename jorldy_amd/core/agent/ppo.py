@@ -385,7 +385,9 @@ class PPO(BaseAgent):
                 graphs.clear()
                 self._graph_failed, graphable = True, False
                 torch.cuda.synchronize()
-                print(f"[jorldy_amd] hipGraph capture of learn() failed ({type(e).__name__}: {e}); running eagerly")
+                import traceback
+
+                print(f"[jorldy_amd] hipGraph capture of learn() failed ({type(e).__name__}: {e}); running eagerly\n{traceback.format_exc()}")
         if graphable and key in graphs:
             if split:
                 graphs[key].replay()  # the GPU works on the no-grad passes / GAE ...

@@ -22,6 +22,7 @@ void jh_persist_destroy(jh_persist* p);
 int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st);
 unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs);
 int jh_persist_collect(jh_persist* p, int W, unsigned tag, float* h_heads);
+int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned tag, float* h_heads);
 int jh_persist_heads(const jh_persist* p);
 void jh_persist_abort(jh_persist* p);
 bool jh_persist_gave_up(const jh_persist* p);
@@ -41,6 +42,10 @@ struct jh_collector {
   std::vector<uint8_t> done;
   jh_persist* persist = nullptr;  // null: one launch per timestep
   int mode = 1;                   // 1: persistent acting kernel (default), 0: launch per step (JH_COLLECT_PERSISTENT=0)
+  // lookahead = 2 (discrete two-action envs that can be forked on the host, 3 W <= 32 rows): every PCIe round trip carries each
+  // env's state AND both successor states, and serves two timesteps (run_loop_lookahead).  1: one timestep per round trip.
+  int lookahead = 1;
+  jh_cartpole *spec = nullptr, *spec2 = nullptr, *spec3 = nullptr;  // 2 W / 4 W / 8 W scratch envs: successors one, two and three steps ahead
   // acting-time capture (jh_collector_set_capture): device destinations of the raw heads / values of the states acted on
   float *cap_h0 = nullptr, *cap_h1 = nullptr, *cap_v = nullptr, *cap_nv = nullptr;
   int64_t cap_rows = 0;
@@ -83,6 +88,13 @@ static int collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* cart, jh_c
   if (c->mode == 1 && W <= 16 && W * S <= 128) {
     if (jh_persist_create(net, &c->persist) != JH_OK) c->persist = nullptr;  // unsupported width: one launch per step
   }
+  if (c->persist && cart && A == 2 && 3 * W <= 32 && 3 * W * S <= 128) {
+    const char* e = getenv("JH_COLLECT_LOOKAHEAD");
+    c->lookahead = e ? (atoi(e) >= 2 ? 2 : 1) : 2;
+    if (c->lookahead == 2 && (jh_cartpole_create(2 * W, 0, &c->spec) != JH_OK || jh_cartpole_create(4 * W, 0, &c->spec2) != JH_OK ||
+                              jh_cartpole_create(8 * W, 0, &c->spec3) != JH_OK))
+      c->lookahead = 1;
+  }
   c->obs.resize((size_t)S * W);
   c->next_obs.resize((size_t)S * W);
   c->act_i.resize(W);
@@ -116,6 +128,9 @@ JH_EXPORT void jh_collector_destroy(jh_collector* c) {
     jh_persist_destroy(c->persist);
   }
   if (c->gate_h) (void)hipHostFree(c->gate_h);
+  if (c->spec) jh_cartpole_destroy(c->spec);
+  if (c->spec2) jh_cartpole_destroy(c->spec2);
+  if (c->spec3) jh_cartpole_destroy(c->spec3);
   run_state_free(c);
   delete c;
 }
@@ -149,7 +164,12 @@ JH_EXPORT int jh_collector_set_ride_along(jh_collector* c, int32_t slot, const v
   return JH_OK;
 }
 
-static int collector_steps(const jh_collector* c, int T) { return T + ((c->cap_v && c->cap_rows == (int64_t)c->W * T) ? 1 : 0); }
+// exchanges with the acting kernel per run: T timesteps (two per exchange with lookahead) + the value-only query of a capturing run
+static int collector_steps(const jh_collector* c, int T) {
+  const int extra = (c->cap_v && c->cap_rows == (int64_t)c->W * T) ? 1 : 0;
+  return (c->lookahead == 2 ? (T + 1) / 2 : T) + extra;
+}
+static int collector_rows(const jh_collector* c) { return c->lookahead == 2 ? 3 * c->W : c->W; }
 
 // Enqueue the persistent acting kernel of the NEXT jh_collector_run(T) now (e.g. right behind the learner's last launch): it starts
 // when the stream reaches it, loads the then-current weights and waits for the first observations (bounded: ~0.2 s, after which it
@@ -159,7 +179,7 @@ JH_EXPORT int jh_collector_prelaunch(jh_collector* c, int32_t T, jh_stream strea
   JH_ARG(c != nullptr && T > 0);
   if (!c->persist || c->prelaunched_T) return JH_OK;
   const int steps = collector_steps(c, T);
-  int rc = jh_persist_begin(c->persist, c->W, steps, jh_s(stream));
+  int rc = jh_persist_begin(c->persist, collector_rows(c), steps, jh_s(stream));
   if (rc == JH_OK) c->prelaunched_T = steps;
   return rc;
 }
@@ -232,7 +252,7 @@ static int run_prepare(jh_collector* c, int T, hipStream_t st) {
         jh_persist_abort(c->persist);
         (void)hipStreamSynchronize(st);
       }
-      rc = jh_persist_begin(c->persist, W, r.steps, st);
+      rc = jh_persist_begin(c->persist, collector_rows(c), r.steps, st);
       if (rc) r.persistent = false;
     }
   }
@@ -240,11 +260,20 @@ static int run_prepare(jh_collector* c, int T, hipStream_t st) {
   return JH_OK;
 }
 
+static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_h, int* t_done);
+
 // The host loop.  Returns the first error; the caller commits either way.
 static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
   RunState& r = run_state(c);
-  const int W = c->W, S = c->S, A = c->A, T = r.T, steps = r.steps;
+  const int W = c->W, S = c->S, A = c->A, T = r.T, steps = T + (r.cap ? 1 : 0);
   const bool cap = r.cap;
+  int t_begin = 0;
+  if (r.persistent && c->lookahead == 2) {
+    const int rc_la = run_loop_lookahead(c, training, stream_h, &t_begin);
+    if (rc_la != JH_OK || t_begin >= steps) return rc_la;
+    // the acting kernel gave up in the middle of the run: finish the remaining timesteps with one launch per step (below)
+    r.persistent = false;
+  }
   jh_stream stream = (jh_stream)stream_h;
   int rc = JH_OK;
   float *ch0 = r.ch0, *ch1 = r.ch1, *cv = r.cv, *cnv = r.cnv;
@@ -258,7 +287,7 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
   const int no = c->persist ? jh_persist_heads(c->persist) : 0;  // policy heads + value
   const int n_pol = c->cont ? 2 * A : A;
   std::vector<float> val(W), lg((size_t)W * 2 * A);
-  for (int t = 0; t < steps; ++t) {
+  for (int t = t_begin; t < steps; ++t) {
     const bool extra = t == T;  // capture: one value-only query of the states the rollout ended in
     // current state of every env (reset state where it just finished)
     if (c->cart) jh_cartpole_obs(c->cart, c->obs.data());
@@ -338,7 +367,186 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
     c->t_env += std::chrono::duration<double>(t2 - t1).count();
     c->steps += 1;
   }
-  if (persistent && getenv("JH_PERSIST_DEBUG") && (c->steps % (64 * T)) == 0) jh_persist_dump_debug(c->persist, T);
+  if (persistent && getenv("JH_PERSIST_DEBUG") && (c->runs % 16) == 15) jh_persist_dump_debug(c->persist, T);
+  return JH_OK;
+}
+
+
+// ---- lookahead = 2: two timesteps per exchange with the acting kernel.
+// An acting step is latency: the host's observations cross PCIe (the GPU polls host memory: ~1.7 us), are relayed on the chip, go
+// through ~1.6 us of kernel and come back as partial heads (~0.7 us) -- ~5 us per timestep of which the MFMA work is 0.4 us
+// (DESIGN §9.1).  The envs are host objects with two actions: the collector steps COPIES of every env with both actions first and
+// publishes three rows per env -- the state s_t and its two possible successors -- in ONE exchange (24 rows x 4 floats = 96 of the
+// 128 granules for config.ppo.cartpole's 8 workers; the second 16-row tile is a second set of workgroups, jh_persist.hip).  When the
+// heads come back, a_t is sampled from pi(.|s_t) exactly as before, the env takes the successor that action leads to (already
+// computed, reward / done / reset included), and a_{t+1} is sampled at once from the heads of THAT row.
+// While the GPU works on an exchange the host has nothing to do but poll, so it runs the env model further ahead in that window:
+// the four two-step successors of every env and their eight successors (12 env steps per env, ~1.8 us for 8 envs inside a ~6 us
+// wait).  When the heads arrive, the next exchange's 24 rows are picked from what is already computed: no env step is left on the
+// critical path between two exchanges.
+// Same policy evaluations at the visited states (the row position inside an MFMA tile does not change a row's arithmetic:
+// bit-identical heads), same counter-based sampling stream, same env RNG streams (one per env, and a fork copies it) -> the
+// rollout, the captured heads / values and every stored transition are bit-identical to the one-step-per-exchange path
+// (tests/test_agents_gpu.py: lookahead vs JH_COLLECT_LOOKAHEAD=1); what changes is that the GPU also evaluates the successor that
+// was not taken (8 wasted rows per exchange) and the host steps env copies that are thrown away.
+// *t_done: timesteps (incl. the value-only query) completed; < steps only when the kernel gave up.
+namespace {
+struct Level {  // 2^k W forked envs: row 2 i + a = env i of the level above after action a
+  jh_cartpole* env = nullptr;
+  std::vector<float> next, obs, rw;
+  std::vector<uint8_t> dn;
+  std::vector<int64_t> act;
+  void init(int rows) {
+    next.resize((size_t)4 * rows); obs.resize((size_t)4 * rows); rw.resize(rows); dn.resize(rows); act.resize(rows);
+    for (int i = 0; i < rows; ++i) act[i] = i & 1;
+  }
+};
+inline void copy_env(jh_cartpole* d, int di, const jh_cartpole* s_, int si) {
+  memcpy(&d->s[4 * (size_t)di], &s_->s[4 * (size_t)si], sizeof(double) * 4);
+  d->t[di] = s_->t[si];
+  d->rng[di] = s_->rng[si];
+}
+// dst rows 2 i + a <- src row i stepped with action a (auto-reset included: the row then holds the reset state)
+inline void fork_step(Level& dst, const jh_cartpole* src, int n_src) {
+  for (int i = 0; i < n_src; ++i) { copy_env(dst.env, 2 * i, src, i); copy_env(dst.env, 2 * i + 1, src, i); }
+  jh_cartpole_step_rows(dst.env, 0, 2 * n_src, dst.act.data(), dst.next.data(), dst.rw.data(), dst.dn.data());
+  jh_cartpole_obs_rows(dst.env, 0, 2 * n_src, dst.obs.data());
+}
+inline void copy_level_row(Level& d, int di, const Level& s_, int si) {
+  copy_env(d.env, di, s_.env, si);
+  memcpy(&d.next[4 * (size_t)di], &s_.next[4 * (size_t)si], 16);
+  memcpy(&d.obs[4 * (size_t)di], &s_.obs[4 * (size_t)si], 16);
+  d.rw[di] = s_.rw[si];
+  d.dn[di] = s_.dn[si];
+}
+}  // namespace
+
+static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_h, int* t_done) {
+  RunState& r = run_state(c);
+  const int W = c->W, S = c->S, T = r.T, steps = T + (r.cap ? 1 : 0);
+  const bool cap = r.cap;
+  jh_cartpole* e = c->cart;
+  float *ch0 = r.ch0, *cv = r.cv, *cnv = r.cnv;
+  float* st = (float*)r.cols[c->col_state];
+  int64_t* ac_i = (int64_t*)r.cols[c->col_action];
+  float* rw = (float*)r.cols[c->col_reward];
+  float* ns = (float*)r.cols[c->col_next];
+  uint8_t* dn = (uint8_t*)r.cols[c->col_done];
+  const int no = jh_persist_heads(c->persist);  // A logits + value
+  const int A = c->A;
+  Level L1, L2, L3;
+  L1.env = c->spec; L2.env = c->spec2; L3.env = c->spec3;
+  L1.init(2 * W); L2.init(4 * W); L3.init(8 * W);
+  std::vector<float> pub((size_t)3 * W * S), hz((size_t)W * no), hz2((size_t)W * no);
+  std::vector<int> pick(W);
+  std::vector<int64_t> a0(W), a1(W);
+  int t = 0;
+  *t_done = 0;
+  fork_step(L1, e, W);  // the successors of the states the run starts in
+  while (t < steps) {
+    const bool extra = t == T;
+    const bool two = !extra && t + 1 < T;
+    // rows 0 .. W-1: the envs' current states; rows W + 2 w + a: the state env w acts on next if it takes action a now
+    jh_cartpole_obs(e, pub.data());
+    memcpy(pub.data() + (size_t)W * S, L1.obs.data(), sizeof(float) * (size_t)2 * W * S);
+    const auto t0 = std::chrono::steady_clock::now();
+    const unsigned tag = jh_persist_publish(c->persist, 3 * W, pub.data());
+    if (!extra) {  // the GPU is busy for ~5 us: run the env model two levels further meanwhile
+      fork_step(L2, L1.env, 2 * W);
+      if (two) fork_step(L3, L2.env, 4 * W);
+    }
+    int rc = jh_persist_collect_rows(c->persist, nullptr, W, tag, hz.data());
+    if (rc) {  // the kernel gave up (it exits by itself)
+      jh_persist_abort(c->persist);
+      if (r.early)
+        return jh_fail(JH_ERR_STATE, "the persistent acting kernel gave up at step %d of a run whose commit was enqueued ahead (jh_collector_begin): "
+                                     "no observations for ~0.2 s; use jh_collector_run for environments that may stall", t);
+      JH_HIP(hipStreamSynchronize(stream_h));
+      *t_done = t;
+      return JH_OK;  // the caller finishes the run with one launch per step
+    }
+    for (int w = 0; w < W; ++w) {
+      const float* z = hz.data() + (size_t)w * no;
+      if (!extra) a0[w] = jh_sample_discrete(c->net, z, w, training);
+      if (cap) {
+        if (t > 0) cnv[(size_t)w * T + (t - 1)] = z[no - 1];  // V(next_state_{t-1}) = V(state_t)  (masked by done_{t-1} in GAE)
+        if (!extra) {
+          const size_t row = (size_t)w * T + t;
+          cv[row] = z[no - 1];
+          memcpy(ch0 + row * A, z, sizeof(float) * A);
+        }
+      }
+    }
+    if (extra) {
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      c->t_act += dt;
+      c->t_extra += dt;
+      t += 1;
+      break;
+    }
+    c->net->act_ctr += 1;
+    for (int w = 0; w < W; ++w) pick[w] = W + 2 * w + (int)a0[w];
+    if (two) {  // timestep t + 1: the heads of the chosen successors arrived with the same exchange
+      rc = jh_persist_collect_rows(c->persist, pick.data(), W, tag, hz2.data());
+      if (rc) return rc;  // (the kernel answers a tag for all rows or for none)
+      for (int w = 0; w < W; ++w) {
+        const float* z = hz2.data() + (size_t)w * no;
+        a1[w] = jh_sample_discrete(c->net, z, w, training);
+        if (cap) {
+          const size_t row = (size_t)w * T + (t + 1);
+          cnv[row - 1] = z[no - 1];
+          cv[row] = z[no - 1];
+          memcpy(ch0 + row * A, z, sizeof(float) * A);
+        }
+      }
+      c->net->act_ctr += 1;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
+    // the transitions, and the envs move on to states that are already computed
+    for (int w = 0; w < W; ++w) {
+      const int k1 = 2 * w + (int)a0[w];
+      size_t row = (size_t)w * T + t;  // worker-major (distributed_manager.py:30)
+      memcpy(st + S * row, pub.data() + (size_t)S * w, sizeof(float) * S);
+      memcpy(ns + S * row, &L1.next[(size_t)S * k1], sizeof(float) * S);
+      ac_i[row] = a0[w];
+      rw[row] = L1.rw[k1];
+      dn[row] = L1.dn[k1];
+      if (two) {
+        const int k2 = 2 * k1 + (int)a1[w];
+        row += 1;
+        memcpy(st + S * row, &L1.obs[(size_t)S * k1], sizeof(float) * S);
+        memcpy(ns + S * row, &L2.next[(size_t)S * k2], sizeof(float) * S);
+        ac_i[row] = a1[w];
+        rw[row] = L2.rw[k2];
+        dn[row] = L2.dn[k2];
+        copy_env(e, w, L2.env, k2);
+        copy_level_row(L1, 2 * w, L3, 2 * k2);
+        copy_level_row(L1, 2 * w + 1, L3, 2 * k2 + 1);
+      } else {
+        copy_env(e, w, L1.env, k1);
+        // (L1's rows 2 w, 2 w + 1 are read above before they are overwritten: k1 is one of them -- copy through temporaries)
+      }
+    }
+    if (!two) {  // a one-step exchange (odd T): the next successors come from L2, two rows per env
+      Level tmp;
+      tmp.env = L3.env;  // scratch: L3 is not in use in a one-step exchange
+      tmp.init(2 * W);
+      for (int w = 0; w < W; ++w) {
+        const int k1 = 2 * w + (int)a0[w];
+        copy_level_row(tmp, 2 * w, L2, 2 * k1);
+        copy_level_row(tmp, 2 * w + 1, L2, 2 * k1 + 1);
+      }
+      for (int i = 0; i < 2 * W; ++i) copy_level_row(L1, i, tmp, i);
+    }
+    c->steps += two ? 2 : 1;
+    const auto t2 = std::chrono::steady_clock::now();
+    c->t_act += std::chrono::duration<double>(t1 - t0).count();
+    c->t_env += std::chrono::duration<double>(t2 - t1).count();
+    t += two ? 2 : 1;
+  }
+  *t_done = t;
+  if (getenv("JH_PERSIST_DEBUG") && (c->runs % 16) == 15) jh_persist_dump_debug(c->persist, collector_steps(c, T));
   return JH_OK;
 }
 

@@ -424,12 +424,7 @@ __global__ void __launch_bounds__(256) jh_gradnorm_kernel(int64_t n, const float
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
   acc = jh_block_reduce(acc, s_red, JhAdd(), 0.f);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // advance Adam's step (nobody reads hyper in this kernel)
-    const float t = hyper[4] + 1.f;
-    hyper[4] = t;
-    hyper[5] = 1.f - powf(hyper[1], t);
-    hyper[6] = sqrtf(1.f - powf(hyper[2], t));
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) jh_adam_advance(hyper);  // nobody reads hyper in this kernel
 }
 
 // FUSED (the four-launch minibatch update, jh_ppo_mb.hip): there is no norm kernel in front.  `partial` holds the sums
@@ -484,13 +479,14 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  const float lr = hyper[JH_HY_LR], b2 = hyper[JH_HY_B2], eps = hyper[JH_HY_EPS];
+  const float omb1 = hyper[JH_HY_OMB1], omb2 = hyper[JH_HY_OMB2];  // (float)(1.0 - beta): torch derives them in double
   const float step_size = lr / bc1;
   auto upd = [&](float& pi, float& gi_, float& mi_, float& vi_) {
     const float gi = gi_ * coef;
-    gi_ = gi;                                        // clip is in place, like the reference
-    const float mi = mi_ + (1.f - b1) * (gi - mi_);  // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = vi_ * b2 + (1.f - b2) * gi * gi;
+    gi_ = gi;                                   // clip is in place, like the reference
+    const float mi = mi_ + omb1 * (gi - mi_);  // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = vi_ * b2 + omb2 * gi * gi;
     mi_ = mi;
     vi_ = vi;
     const float denom = sqrtf(vi) / bc2s + eps;
@@ -583,8 +579,9 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     JH_HIP(hipMalloc((void**)&n->ssq_part, sizeof(float) * ((size_t)(H / 32) * (H / 32) + H / 32 + 1)));
   }
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
-  JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * 8));
-  const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
+  JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * JH_HY_FLOATS));
+  float hy[JH_HY_FLOATS];
+  jh_hyper_fill(hy, 1e-3, 0.9, 0.999, 1e-8, 0.0);
   JH_HIP(hipMemcpy(n->hyper, hy, sizeof(hy), hipMemcpyHostToDevice));
   *out = n;
   return JH_OK;
@@ -616,25 +613,31 @@ JH_EXPORT int jh_pponet_act_rng(jh_pponet* n, uint64_t* seed, uint64_t* counter,
   return JH_OK;
 }
 
-JH_EXPORT int jh_pponet_set_hyper(jh_pponet* n, float lr, float beta1, float beta2, float eps, float step,
+JH_EXPORT int jh_pponet_set_hyper(jh_pponet* n, double lr, double beta1, double beta2, double eps, double step,
                                   jh_stream stream) {
   JH_ARG(n != nullptr);
-  // staged through a pinned slab so the copy is a true async H2D that a later graph launch sees
+  // staged through a pinned slab so the copy is a true async H2D that a later graph launch sees.  step < 0: the step counter (and
+  // the bias corrections derived from it) stay as they are -- two copies around them
   jh_pinned_slab* slab = nullptr;
   int rc = jh_ctx_slab(n->ctx, 64, &slab);
   if (rc) return rc;
   float* h = (float*)slab->host;
-  h[0] = lr; h[1] = beta1; h[2] = beta2; h[3] = eps; h[4] = step;
-  JH_HIP(hipMemcpyAsync(n->hyper, h, sizeof(float) * (step >= 0.f ? 5 : 4), hipMemcpyHostToDevice, jh_s(stream)));
+  jh_hyper_fill(h, lr, beta1, beta2, eps, step < 0 ? 0.0 : step);
+  if (step >= 0) {
+    JH_HIP(hipMemcpyAsync(n->hyper, h, sizeof(float) * JH_HY_FLOATS, hipMemcpyHostToDevice, jh_s(stream)));
+  } else {
+    JH_HIP(hipMemcpyAsync(n->hyper, h, sizeof(float) * 4, hipMemcpyHostToDevice, jh_s(stream)));
+    JH_HIP(hipMemcpyAsync(n->hyper + JH_HY_OMB1, h + JH_HY_OMB1, sizeof(float) * (JH_HY_FLOATS - JH_HY_OMB1), hipMemcpyHostToDevice, jh_s(stream)));
+  }
   return jh_ctx_slab_release(n->ctx, slab, jh_s(stream));
 }
 
-JH_EXPORT int jh_pponet_set_lr(jh_pponet* n, float lr, jh_stream stream) {
+JH_EXPORT int jh_pponet_set_lr(jh_pponet* n, double lr, jh_stream stream) {
   JH_ARG(n != nullptr);
   jh_pinned_slab* slab = nullptr;
   int rc = jh_ctx_slab(n->ctx, 64, &slab);
   if (rc) return rc;
-  *(float*)slab->host = lr;
+  *(float*)slab->host = (float)lr;
   JH_HIP(hipMemcpyAsync(n->hyper, slab->host, sizeof(float), hipMemcpyHostToDevice, jh_s(stream)));
   return jh_ctx_slab_release(n->ctx, slab, jh_s(stream));
 }

@@ -23,8 +23,15 @@
 //     {out, out, out, tag} row granules written through to pinned host memory, fire and forget; no
 //     inter-workgroup communication on the device; every poll loop is bounded and a timeout makes
 //     all workgroups exit (the host then falls back to one launch per step).
+// Round 4: up to 32 rows per step (RT = 2 row tiles of 16).  The rows need not be 32 ENVIRONMENTS: the native collector's
+// lookahead form (jh_collect.hip) publishes, for W <= 10 discrete-action envs, each env's current state AND the two states its two
+// actions lead to (the envs are host objects that can be forked), so that one PCIe round trip serves TWO timesteps: the host samples
+// a_t from the root row, picks that child and samples a_{t+1} from the child's row, which is already there.  The second row tile
+// is a second set of 32 workgroups (grid = column tiles x row tiles): a step's compute stays the one-tile 1.65 us.
 // Heads: G = ceil(n_out / 3) granules per (tile, row), n_out = A logits (or mu / log_std of a continuous policy) + the value
 // head (last output; handed to the learner by the collector's capture): discrete A <= 11, continuous A <= 5.
+#include <emmintrin.h>
+
 #include "jh_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,7 +42,8 @@ struct PersistArgs {
   const float* wh[12];
   const float* hbias[12];
   const unsigned long long* obs_gran;  // pinned: [W*S] granules {tag << 32 | float bits}
-  float4* part;                        // pinned: [tiles][G][16] row granules {out, out, out, tag bits}
+  float4* part;                        // pinned: [tiles][G][rows_ld] row granules {out, out, out, tag bits}
+  int rows_ld;                         // 16 x row tiles
   unsigned* abort_flag;                // pinned: set by the kernel on timeout / by the host to stop early
   unsigned seq0;                       // tag of the first step (tags are seq0+1 .. seq0+T)
   long max_polls;
@@ -68,7 +76,11 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
   __shared__ int s_go[2];
   const int H = p.H, S = p.S;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: an SGPR
-  const int tile = blockIdx.x, n0 = tile * 16;
+  // grid = (H / 16 column tiles) x (row tiles of 16): workgroup (tile, rt) owns rows 16 rt .. 16 rt + 15 of column tile `tile`.
+  // Splitting the ROWS over workgroups (instead of a second accumulator set per wave: 411 VGPRs, +1.2 us of compute per step)
+  // keeps a step's compute at the one-tile 1.65 us whatever the number of rows
+  const int tiles_n = H / 16;
+  const int tile = blockIdx.x % tiles_n, rt = blockIdx.x / tiles_n, n0 = tile * 16;
   const int r = lane & 15, kq = lane >> 4;
   const int kbeg = wid * 16 * NCH;  // H == 64 * NCH
   // ---- one-time: this lane's weight fragments into registers
@@ -136,8 +148,8 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
         const unsigned long long gq1 = n_gran > 64 ? __hip_atomic_load(p.mbox + (64 + lane < n_gran ? 64 + lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         const bool mine = (lane >= n_gran || (unsigned)(gq >> 32) == tag) && (64 + lane >= n_gran || (unsigned)(gq1 >> 32) == tag);
         if (__all(mine)) {
-          if (lane < n_gran) s_x[par][lane / S][lane % S] = __uint_as_float((unsigned)gq);
-          if (64 + lane < n_gran) s_x[par][(64 + lane) / S][(64 + lane) % S] = __uint_as_float((unsigned)gq1);
+          if (lane < n_gran && (lane / S) >> 4 == rt) s_x[par][(lane / S) & 15][lane % S] = __uint_as_float((unsigned)gq);
+          if (64 + lane < n_gran && ((64 + lane) / S) >> 4 == rt) s_x[par][((64 + lane) / S) & 15][(64 + lane) % S] = __uint_as_float((unsigned)gq1);
           ok = true;
           break;
         }
@@ -158,11 +170,11 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
         const bool done = __all(mine);
         if (done) {
           if (lane < n_gran) {
-            s_x[par][lane / S][lane % S] = __uint_as_float((unsigned)gq);
+            if ((lane / S) >> 4 == rt) s_x[par][(lane / S) & 15][lane % S] = __uint_as_float((unsigned)gq);
             if (p.mbox) __hip_atomic_store(p.mbox + lane, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: the granule is its own flag
           }
           if (64 + lane < n_gran) {
-            s_x[par][(64 + lane) / S][(64 + lane) % S] = __uint_as_float((unsigned)gq1);
+            if (((64 + lane) / S) >> 4 == rt) s_x[par][((64 + lane) / S) & 15][(64 + lane) % S] = __uint_as_float((unsigned)gq1);
             if (p.mbox) __hip_atomic_store(p.mbox + 64 + lane, gq1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
@@ -252,9 +264,9 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
       // 16-byte row granules {out 3g, out 3g+1, out 3g+2, tag}: the partial IS its own flag.  Lanes (g, row) store
       // W consecutive granules per g with ONE instruction; fire and forget (no fence, no acknowledgement wait)
       const int g = lane >> 4, row = lane & 15;
-      if (g < p.G && row < p.W) {
+      if (g < p.G && 16 * rt + row < p.W) {
         const f32x4 gq = (f32x4){s_out[row][3 * g], s_out[row][3 * g + 1], s_out[row][3 * g + 2], __uint_as_float(tag)};
-        float4* dst = p.part + ((size_t)tile * p.G + g) * 16 + row;
+        float4* dst = p.part + ((size_t)tile * p.G + g) * p.rows_ld + 16 * rt + row;
         // write-through system-scope 16-byte store (a plain store lingers in L2 for milliseconds); hipcc does not
         // track asm stores: the s_nop keeps the data registers intact until the store has read them (CDNA guide §5.7)
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
@@ -276,6 +288,7 @@ struct jh_persist {
   unsigned *flag_h = nullptr, *flag_d = nullptr;  // abort word
   unsigned seq = 0;
   int tiles = 0, n_out = 0, G = 0;
+  int rows_ld = 16;  // rows per (tile, g) block of `part` in the running kernel: 16 RT
   unsigned long long *dbg_h = nullptr, *dbg_d = nullptr;
   unsigned long long* mbox = nullptr;  // device: relay of the observation granules
 };
@@ -297,7 +310,7 @@ int jh_persist_create(jh_pponet* n, jh_persist** out) {
   p->G = (p->n_out + 2) / 3;
   JH_HIP(hipHostMalloc((void**)&p->gran_h, sizeof(unsigned long long) * 128, hipHostMallocMapped));
   JH_HIP(hipHostGetDevicePointer((void**)&p->gran_d, p->gran_h, 0));
-  const size_t part_bytes = sizeof(float4) * 16 * (size_t)p->tiles * p->G;
+  const size_t part_bytes = sizeof(float4) * 32 * (size_t)p->tiles * p->G;  // room for two row tiles
   JH_HIP(hipHostMalloc((void**)&p->part_h, part_bytes, hipHostMallocMapped));
   memset(p->part_h, 0, part_bytes);
   JH_HIP(hipHostGetDevicePointer((void**)&p->part_d, p->part_h, 0));
@@ -330,16 +343,16 @@ void jh_persist_destroy(jh_persist* p) {
 }
 
 template <int SP, int NCH>
-static void persist_launch(int depth, int tiles, hipStream_t st, const PersistArgs& a) {
-  if (depth >= 4) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 4>), dim3(tiles), dim3(256), 0, st, a);
-  else if (depth >= 2) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 2>), dim3(tiles), dim3(256), 0, st, a);
-  else JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 1>), dim3(tiles), dim3(256), 0, st, a);
+static void persist_launch(int depth, int grid, hipStream_t st, const PersistArgs& a) {
+  if (depth >= 4) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 4>), dim3(grid), dim3(256), 0, st, a);
+  else if (depth >= 2) JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 2>), dim3(grid), dim3(256), 0, st, a);
+  else JH_LAUNCH_NAMED("jh_act_persist_kernel", (jh_act_persist_kernel<SP, NCH, 1>), dim3(grid), dim3(256), 0, st, a);
 }
 
-// Launch the persistent kernel for T steps of W <= 16 envs (W * S <= 128 observation granules).
+// Launch the persistent kernel for T steps of W <= 32 rows (W * S <= 128 observation granules).
 int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   jh_pponet* n = p->net;
-  JH_ARG(W > 0 && W <= 16 && W * n->S <= 128 && T > 0);
+  JH_ARG(W > 0 && W <= 32 && W * n->S <= 128 && T > 0);
   PersistArgs a{};
   a.W = W; a.S = n->S; a.H = n->H; a.T = T; a.G = p->G;
   a.W1 = n->params + n->o_w1; a.b1 = n->params + n->o_b1; a.W2 = n->params + n->o_w2; a.b2 = n->params + n->o_b2;
@@ -362,12 +375,16 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   p->flag_h[0] = 0;
   const int nch = n->H / 64;
   const int sp = (n->S + 3) / 4 * 4;  // 4, 8: W1 fragments in registers; 12, 16: in LDS
-#define JH_PERSIST_CASE(NCH)                                      \
-  if (nch == NCH) {                                               \
-    if (sp == 4) persist_launch<4, NCH>(depth, p->tiles, st, a);  \
-    else if (sp == 8) persist_launch<8, NCH>(depth, p->tiles, st, a);   \
-    else if (sp == 12) persist_launch<12, NCH>(depth, p->tiles, st, a); \
-    else persist_launch<16, NCH>(depth, p->tiles, st, a);         \
+  const int rt = W > 16 ? 2 : 1;  // row tiles = workgroups per column tile
+  p->rows_ld = 16 * rt;
+  a.rows_ld = p->rows_ld;
+  const int grid = p->tiles * rt;
+#define JH_PERSIST_CASE(NCH)                                   \
+  if (nch == NCH) {                                            \
+    if (sp == 4) persist_launch<4, NCH>(depth, grid, st, a);   \
+    else if (sp == 8) persist_launch<8, NCH>(depth, grid, st, a);   \
+    else if (sp == 12) persist_launch<12, NCH>(depth, grid, st, a); \
+    else persist_launch<16, NCH>(depth, grid, st, a);          \
   }
   JH_PERSIST_CASE(1) else JH_PERSIST_CASE(2) else JH_PERSIST_CASE(4) else JH_PERSIST_CASE(8)
 #undef JH_PERSIST_CASE
@@ -387,38 +404,53 @@ unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs) {
   return tag;
 }
 
-// Wait until every tile's granules of all W rows carry `tag`, then sum the per-tile partials in tile order:
-// h_heads [W][n_out] raw head outputs (logits | mu_raw, log_std_raw).  JH_ERR_STATE if the kernel gave up.
-int jh_persist_collect(jh_persist* p, int W, unsigned tag, float* h_heads) {
-  const int n_out = p->n_out, G = p->G;
+// Wait until every tile's granules of the listed rows (rows == NULL: rows 0 .. n_rows-1) carry `tag`, then sum the per-tile partials
+// in tile order: h_heads [n_rows][n_out] raw head outputs (logits | mu_raw, log_std_raw; value last).  JH_ERR_STATE if the kernel gave up.
+int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned tag, float* h_heads) {
+  const int n_out = p->n_out, G = p->G, ld = p->rows_ld, tiles = p->tiles;
   volatile unsigned* abort_w = p->flag_h;
-  const volatile unsigned* part = reinterpret_cast<const volatile unsigned*>(p->part_h);  // [tiles][G][16][4 words]
-  bool all = false;
-  for (long spin = 0; spin < 40000000L && !all; ++spin) {
-    all = true;
-    for (int t = 0; t < p->tiles * G && all; ++t)
-      for (int wq = 0; wq < W; ++wq)
-        if (part[((size_t)t * 16 + wq) * 4 + 3] != tag) { all = false; break; }
-    if (!all) {
+  // [tiles][G][ld] granules of 16 bytes {out, out, out, tag}: ONE 16-byte load per granule serves the tag check and the sum (the
+  // device's 16-byte store is one PCIe write: tag and payload arrive together); a row is summed tile by tile as its granules are
+  // found, and only the missing rows are re-polled
+  const __m128i* part = reinterpret_cast<const __m128i*>(p->part_h);
+  float z[32][12];
+  unsigned char have[32];
+  JH_ARG(n_rows <= 32);
+  int missing = n_rows;
+  for (int k = 0; k < n_rows; ++k) have[k] = 0;
+  for (long spin = 0; spin < 40000000L && missing; ++spin) {
+    for (int k = 0; k < n_rows; ++k) {
+      if (have[k]) continue;
+      const int wq = rows ? rows[k] : k;
+      float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      bool ok = true;
+      for (int t = 0; t < tiles && ok; ++t)
+        for (int g = 0; g < G; ++g) {
+          const __m128i q = _mm_load_si128(part + ((size_t)t * G + g) * ld + wq);
+          alignas(16) unsigned w4[4];
+          _mm_store_si128(reinterpret_cast<__m128i*>(w4), q);
+          if (w4[3] != tag) { ok = false; break; }
+          float f3[3];
+          memcpy(f3, w4, 12);
+          acc[3 * g] += f3[0]; acc[3 * g + 1] += f3[1]; acc[3 * g + 2] += f3[2];  // tile order: the same bits as the device-side reduce would give
+        }
+      if (ok) {
+        memcpy(z[k], acc, sizeof(acc));
+        have[k] = 1;
+        --missing;
+      }
+    }
+    if (missing) {
       if ((spin & 1023) == 1023 && *abort_w == 2u) break;  // the kernel timed out
       __builtin_ia32_pause();
     }
   }
-  if (!all) return jh_fail(JH_ERR_STATE, "persistent acting kernel did not answer step tag %u", tag);
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  for (int wq = 0; wq < W; ++wq) {
-    float z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = 0; t < p->tiles; ++t)
-      for (int o = 0; o < n_out; ++o) {
-        const unsigned bits = part[(((size_t)t * G + o / 3) * 16 + wq) * 4 + o % 3];
-        float v;
-        memcpy(&v, &bits, 4);
-        z[o] += v;
-      }
-    memcpy(h_heads + (size_t)wq * n_out, z, sizeof(float) * n_out);
-  }
+  if (missing) return jh_fail(JH_ERR_STATE, "persistent acting kernel did not answer step tag %u", tag);
+  for (int k = 0; k < n_rows; ++k) memcpy(h_heads + (size_t)k * n_out, z[k], sizeof(float) * n_out);
   return JH_OK;
 }
+
+int jh_persist_collect(jh_persist* p, int W, unsigned tag, float* h_heads) { return jh_persist_collect_rows(p, nullptr, W, tag, h_heads); }
 
 int jh_persist_heads(const jh_persist* p) { return p->n_out; }
 

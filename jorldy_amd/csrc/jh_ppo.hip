@@ -455,12 +455,7 @@ __device__ __forceinline__ void ppo_block_reduce6(float (&v)[6], float (*red)[6]
 template <bool CONT>
 __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   __shared__ float s_red6[16][6];
-  if (a.hyper_advance && threadIdx.x == blockDim.x - 1) {  // (not wave 0: it owns the final reductions)  hyper: [1] beta1 [2] beta2 [4] step [5] 1-beta1^t [6] sqrt(1-beta2^t)
-    const float t = a.hyper_advance[4] + 1.f;
-    a.hyper_advance[4] = t;
-    a.hyper_advance[5] = 1.f - powf(a.hyper_advance[1], t);
-    a.hyper_advance[6] = sqrtf(1.f - powf(a.hyper_advance[2], t));
-  }
+  if (a.hyper_advance && threadIdx.x == blockDim.x - 1) jh_adam_advance(a.hyper_advance);  // (not wave 0: it owns the final reductions)
   extern __shared__ __attribute__((aligned(16))) float s_z[];  // [B][8] when the heads come as partials
   const int i = threadIdx.x;
   const bool on = i < a.B;

@@ -552,12 +552,7 @@ __global__ void __launch_bounds__(256) jh_pmb_norm_kernel(int64_t n, float* __re
   }
   acc = jh_block_reduce(acc, s_red, JhAdd(), 0.f);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // advance Adam's step (nobody reads hyper in this kernel)
-    const float t = hyper[4] + 1.f;
-    hyper[4] = t;
-    hyper[5] = 1.f - powf(hyper[1], t);
-    hyper[6] = sqrtf(1.f - powf(hyper[2], t));
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) jh_adam_advance(hyper);  // nobody reads hyper in this kernel
 }
 
 // ============================================================================ host side

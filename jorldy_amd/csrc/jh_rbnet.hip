@@ -446,6 +446,9 @@ __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __re
                                                           float* __restrict__ v, float* __restrict__ hyper, unsigned* __restrict__ ticket,
                                                           const float* __restrict__ partial, int n_partial, float max_norm) {
   __shared__ float s_red[16];
+  __shared__ float s_bc[2];
+  const float t_new = hyper[JH_HY_STEP] + 1.f;
+  if (OPT == 0 && threadIdx.x == 0) jh_adam_bias_corrections(hyper, t_new, s_bc[0], s_bc[1]);  // in double, like torch (jh_common.h)
   float coef = 1.f;
   if (max_norm > 0.f) {
     float acc = 0.f;
@@ -453,26 +456,24 @@ __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __re
     const float total = sqrtf(jh_block_reduce(acc, s_red, JhAdd(), 0.f));
     coef = fminf(max_norm / (total + 1e-6f), 1.f);
   }
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
-  const float t_new = hyper[4] + 1.f;
-  const bool centered = hyper[5] != 0.f;
+  __syncthreads();
+  const float lr = hyper[JH_HY_LR], b1 = hyper[JH_HY_B1], b2 = hyper[JH_HY_B2], eps = hyper[JH_HY_EPS];
+  const float omb1 = hyper[JH_HY_OMB1], omb2 = hyper[JH_HY_OMB2];  // (float)(1.0 - beta | alpha): torch derives them in double
+  const bool centered = hyper[JH_HY_BC1] != 0.f;
   float bc1 = 1.f, bc2s = 1.f;
-  if (OPT == 0) {
-    bc1 = 1.f - powf(b1, t_new);
-    bc2s = sqrtf(1.f - powf(b2, t_new));
-  }
+  if (OPT == 0) { bc1 = s_bc[0]; bc2s = s_bc[1]; }
   const float step_size = lr / bc1;
   auto update = [&](float& pi, float& gi, float& mi, float& vi) {
     if (max_norm > 0.f) gi *= coef;
     if (OPT == 0) {
-      mi = mi + (1.f - b1) * (gi - mi);  // exp_avg.lerp_(grad, 1 - beta1)
-      vi = vi * b2 + (1.f - b2) * gi * gi;
+      mi = mi + omb1 * (gi - mi);  // exp_avg.lerp_(grad, 1 - beta1)
+      vi = vi * b2 + omb2 * gi * gi;
       pi = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
     } else {
-      vi = vi * b1 + (1.f - b1) * gi * gi;  // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
+      vi = vi * b1 + omb1 * gi * gi;  // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
       float avg;
       if (centered) {
-        mi = mi + (1.f - b1) * (gi - mi);   // grad_avg.lerp_(grad, 1 - alpha)
+        mi = mi + omb1 * (gi - mi);   // grad_avg.lerp_(grad, 1 - alpha)
         avg = sqrtf(vi - mi * mi) + eps;    // square_avg.addcmul(grad_avg, grad_avg, value=-1).sqrt_().add_(eps)
       } else {
         avg = sqrtf(vi) + eps;
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __re
     const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tk == gridDim.x - 1) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      hyper[4] = t_new;
+      hyper[JH_HY_STEP] = t_new;
     }
   }
 }
@@ -658,7 +659,7 @@ JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t kind, int32_t head_cnn, int32
   const int H = hidden;
   const size_t B = (size_t)max_batch;
   auto A4 = [&](float** p, size_t floats, bool zero = true) { if (!rc) rc = rb_alloc(n, (void**)p, floats * sizeof(float), zero); };
-  A4(&n->hyper, 8);
+  A4(&n->hyper, JH_HY_FLOATS);
   A4(&n->norm_partial, 256);
   if (!rc) rc = rb_alloc(n, (void**)&n->ticket, 16, true);
   A4(&n->weff, 3 * (size_t)d.set_stride);
@@ -717,7 +718,8 @@ JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t kind, int32_t head_cnn, int32
     delete n;
     return rc;
   }
-  const float hy[8] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f, 0.f};
+  float hy[JH_HY_FLOATS];
+  jh_hyper_fill(hy, 1e-3, 0.9, 0.999, 1e-8, 0.0);
   JH_HIP(hipMemcpy(n->hyper, hy, sizeof(hy), hipMemcpyHostToDevice));
   JH_HIP(hipDeviceSynchronize());
   *out = n;
@@ -741,22 +743,23 @@ JH_EXPORT int jh_rbnet_segment(const jh_rbnet* n, int32_t i, int64_t* offset, in
 }
 JH_EXPORT int64_t jh_rbnet_noise_len(const jh_rbnet* n) { return n ? n->nd.noise_len : -1; }
 
-JH_EXPORT int jh_rbnet_set_hyper(jh_rbnet* n, float lr, float beta1, float beta2, float eps, int64_t step, int32_t centered, jh_stream stream) {
+JH_EXPORT int jh_rbnet_set_hyper(jh_rbnet* n, double lr, double beta1, double beta2, double eps, int64_t step, int32_t centered, jh_stream stream) {
   JH_ARG(n != nullptr);
   jh_pinned_slab* slab = nullptr;
-  int rc = jh_ctx_slab(n->ctx, 32, &slab);
+  int rc = jh_ctx_slab(n->ctx, 64, &slab);
   if (rc) return rc;
   float* h = (float*)slab->host;
-  h[0] = lr; h[1] = beta1; h[2] = beta2; h[3] = eps; h[4] = (float)step; h[5] = centered ? 1.f : 0.f;
-  JH_HIP(hipMemcpyAsync(n->hyper, slab->dev, 6 * sizeof(float), hipMemcpyDeviceToDevice, jh_s(stream)));
+  jh_hyper_fill(h, lr, beta1, beta2, eps, (double)step);
+  h[JH_HY_BC1] = centered ? 1.f : 0.f;
+  JH_HIP(hipMemcpyAsync(n->hyper, slab->dev, JH_HY_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, jh_s(stream)));
   return jh_ctx_slab_release(n->ctx, slab, jh_s(stream));
 }
-JH_EXPORT int jh_rbnet_set_lr(jh_rbnet* n, float lr, jh_stream stream) {
+JH_EXPORT int jh_rbnet_set_lr(jh_rbnet* n, double lr, jh_stream stream) {
   JH_ARG(n != nullptr);
   jh_pinned_slab* slab = nullptr;
   int rc = jh_ctx_slab(n->ctx, 16, &slab);
   if (rc) return rc;
-  *(float*)slab->host = lr;
+  *(float*)slab->host = (float)lr;
   JH_HIP(hipMemcpyAsync(n->hyper, slab->dev, sizeof(float), hipMemcpyDeviceToDevice, jh_s(stream)));
   return jh_ctx_slab_release(n->ctx, slab, jh_s(stream));
 }

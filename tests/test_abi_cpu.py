@@ -34,7 +34,7 @@ def test_library_exports_every_header_symbol(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/jorldy_hip.h but not exported"
     assert set(syms) == set(_lib.exported_names()), "ctypes binding table out of sync with the header"
-    assert lib.jh_abi_version() == 1
+    assert lib.jh_abi_version() == 2
 
 
 def test_header_cites_reference_lines():

@@ -581,6 +581,47 @@ def test_native_collector_matches_python_collector_layout():
     assert set(res) == {"actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob", "mean_ret"} and agent.memory.size == 0
 
 
+@pytest.mark.parametrize("T,H", [(16, 64), (17, 64), (128, 512)])
+def test_collector_lookahead_two_timesteps_per_exchange_is_bit_identical(T, H, monkeypatch):
+    """jh_collect.hip run_loop_lookahead: for two-action envs the collector publishes every env's state AND both successor states
+    in one exchange with the persistent acting kernel and takes TWO timesteps from it.  Same policy evaluations at the visited
+    states, same sampling counters, same per-env RNG streams: stored transitions, the captured heads / values and the envs
+    themselves must equal the one-timestep-per-exchange path (JH_COLLECT_LOOKAHEAD=1) BIT FOR BIT -- over several runs (the
+    persistent kernel is relaunched per run), even and odd T (an odd run ends on a one-step exchange), with episode ends
+    (random policy: ~22-step episodes, so resets happen inside looked-ahead successors), and through learn() updates in between."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+
+    W = 8
+    res = {}
+    for la in (1, 2):
+        monkeypatch.setenv("JH_COLLECT_LOOKAHEAD", str(la))
+        torch.manual_seed(5)
+        np.random.seed(5)
+        agent = Agent("ppo", state_size=4, action_size=2, hidden_size=H, n_step=T, batch_size=64, n_epoch=1, device="cuda", seed=3, lr_decay=False)
+        agent.memory.first_store = False
+        env = ops.CartPoleVec(W, seed=4)
+        col = NativeCollector(env, agent, W)
+        out = []
+        for it in range(3):
+            col.run(T)
+            torch.cuda.synchronize()
+            st, M = agent._static, W * T
+            store = agent.memory._store
+            rec = {k: npy(store.column(k)[:M]).copy() for k in ("state", "action", "reward", "next_state", "done")}
+            rec.update(h0=npy(st["h0"]).copy(), value=npy(st["value"]).copy(), next_value=npy(st["next_value"]).copy(), obs=env.obs().copy())
+            out.append(rec)
+            r = agent.process(None, T * (it + 1))  # a learn() between the runs: the next run acts with updated weights
+            rec["loss"] = (r["actor_loss"], r["critic_loss"], r["entropy_loss"])
+        assert any(o["done"].any() for o in out), "no episode ended: the reset path was not exercised"
+        res[la] = out
+        col.terminate()
+    for a, b in zip(res[1], res[2]):
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
 @pytest.mark.parametrize("cont", [False, True])
 @pytest.mark.parametrize("persistent,early", [(True, False), (False, False), (True, True)])
 def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persistent, early, monkeypatch):
