@@ -208,6 +208,18 @@ int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const float* d_mu_
                            const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip,
                            float vf_coef, float ent_coef, float* d_grad_mu_raw, float* d_grad_log_std_raw,
                            float* d_grad_value, float* d_stats, jh_stream stream);
+/* The same loss for DATA-PARALLEL learners with the critic of ppo.py:147-154 exact over the global minibatch (see
+ * jh_pponet_ppo_update_dp_begin): both critic branches' value gradients are kept (d_grad_value | d_dv2 float32[B]), d_critic_sums
+ * float32[2] <- this rank's {sum e1, sum e2}, d_stats_local float32[8] <- this rank's statistics.  After the caller's all-reduce (MEAN
+ * over the ranks) of d_critic_sums, jh_ppo_critic_select_rows mixes d_grad_value in place with the global branch weights and writes
+ * d_stats (actor / entropy terms of this rank, critic terms of the global minibatch).                                            */
+int jh_ppo_loss_deferred(jh_ctx* ctx, int32_t continuous, int32_t B, int32_t A, const float* d_head0, const float* d_head1,
+                         const float* d_value_pred, const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
+                         const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
+                         float* d_grad_head0, float* d_grad_head1, float* d_grad_value, float* d_dv2, float* d_critic_sums,
+                         float* d_stats_local, jh_stream stream);
+int jh_ppo_critic_select_rows(jh_ctx* ctx, int32_t B, const float* d_critic_sums, float vf_coef, float ent_coef, float* d_grad_value,
+                              const float* d_dv2, const float* d_stats_local, float* d_stats, jh_stream stream);
 
 /* ------------------------------------------------------------------ TD losses (DQN family)
  * One kernel for dqn.py:128-141, double.py:28-39, multistep.py:41-50, per.py:54-74,
@@ -296,6 +308,17 @@ int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_
                          const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old,
                          float eps_clip, float vf_coef, float ent_coef, float max_norm, int32_t do_adam, float* d_stats,
                          jh_stream stream);
+/* jh_pponet_ppo_update for DATA-PARALLEL learners with the reference's critic exactly: core/agent/ppo.py:147-154 takes
+ * max(mean(e1), mean(e2)) over the WHOLE minibatch -- a max of two means, so with the minibatch sharded over ranks the branch is
+ * only known after {sum e1, sum e2} have been reduced.  _begin: forward + loss of this rank's B rows; d_critic_sums float32[2] <- this
+ * rank's sums.  The caller all-reduces d_critic_sums (MEAN over ranks; every rank holds B rows).  _end: branch weights from the
+ * reduced sums, value gradients, backward -> a complete gradient bucket (then: all-reduce MEAN of the bucket, jh_pponet_adam_step).
+ * d_stats float32[8] as in jh_ppo_loss_*: actor / entropy terms of this rank's rows, critic terms of the global minibatch.       */
+int jh_pponet_ppo_update_dp_begin(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action, const float* d_adv,
+                                  const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef,
+                                  float ent_coef, float* d_critic_sums, jh_stream stream);
+int jh_pponet_ppo_update_dp_end(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_critic_sums, float vf_coef,
+                                float ent_coef, float* d_stats, jh_stream stream);
 /* Device address of the optimizer's hyper block (float[8]: lr, beta1, beta2, eps, step, ...), e.g. as the destination of a
  * jh_collector_set_ride_along copy that delivers the next decayed learning rate (base.py:93-111) without a copy of its own. */
 void* jh_pponet_hyper_ptr(jh_pponet* n);

@@ -60,7 +60,11 @@ class PPO(BaseAgent):
         self.time_t = 0
         self.learn_stamp = 0
         self._stats = None
-        self.grad_sync = None  # data-parallel hook: jorldy_amd.parallel.FlatGradSync (RCCL all-reduce)
+        self.grad_sync = None  # data-parallel hook: jorldy_amd.parallel.BucketSync (RCCL all-reduce)
+        # data-parallel learners: the critic's max(mean, mean) (ppo.py:147-154) taken over the GLOBAL minibatch (one more 8-byte all-reduce per
+        # minibatch, between loss and backward) = exactly one learner on the concatenated batch.  JH_DP_EXACT_CRITIC=0: every rank's own max
+        # (round 3's form: equal only while the value clamp is inactive)
+        self.dp_exact_critic = os.environ.get("JH_DP_EXACT_CRITIC", "1") == "1"
 
         eligible = (
             head == "mlp" and isinstance(state_size, (int, np.integer)) and optim_config.get("name", "adam").lower() == "adam"
@@ -137,6 +141,7 @@ class PPO(BaseAgent):
         d = self.optimizer.defaults
         net.set_hyper(self.optimizer.param_groups[0]["lr"], d["betas"][0], d["betas"][1], d["eps"], step=float(self._adam_steps))
         torch.cuda.synchronize()
+        self._drop_rides()
         self._net, self._graph, self._static, self._graphs = net, None, None, {}
 
     # ---------------------------------------------------------------------------------- act
@@ -215,9 +220,19 @@ class PPO(BaseAgent):
         """Device tensors the collector's acting-time capture writes for a rollout of M rows (raw policy head(s), V(s), V(s'))."""
         self._grow_native(2 * M if 2 * M <= 8192 else M)
         if self._static is None or self._static["M"] != M:
+            self._drop_rides()
             self._static, self._graphs = self._alloc_static(M), {}
         st = self._static
         return st["h0"], st["h1"], st["value"], st["next_value"]
+
+    def _drop_rides(self):
+        """The static buffers (index lists) or the network (hyper block) are about to be replaced: whatever was handed to the collector's
+        commit launch and has not been delivered must not be delivered any more (dangling ride-along pointers)."""
+        if self._ride is not None:
+            self._ride.clear_rides()
+        self._ride_wait.clear()
+        if self._static is not None:
+            self._static["idx_ready"] = False
 
     def _upload_idx(self, st, draw, ride=False):
         """draw(numpy int64 view [E * M]) fills the lists in device-mapped pinned memory; they reach st["idx"] with one copy kernel now,
@@ -231,7 +246,7 @@ class PPO(BaseAgent):
         if ok is False:
             return False
         if ride and self._ride is not None:
-            self._ride.ride_along(0, st["idx_pin"][k].dev_ptr.value, st["idx"].data_ptr(), st["idx"].numel() * 8)
+            self._ride.ride_along(0, st["idx_pin"][k].dev_ptr.value, st["idx"].data_ptr(), st["idx"].numel() * 8, keep=(st["idx_pin"][k], st["idx"]))
             self._ride_wait["idx"] = k
             return True
         self._ride_wait.pop("idx", None)
@@ -280,27 +295,45 @@ class PPO(BaseAgent):
             # x[idx] of every epoch in one launch, then forward + loss + backward (+ clip + Adam) in 4-5 launches per
             # minibatch on consecutive rows (jh_pponet_ppo_update)
             xs, acts, advs, rets, vals, lps = st["rows"](st["idx"])
+            exact = self.grad_sync is not None and self.dp_exact_critic
+            if exact and "critic_sums" not in st:
+                st["critic_sums"] = torch.zeros(st["n_upd"], 2, dtype=torch.float32, device=self.device)
             for e in range(self.n_epoch):
                 for offset in range(0, M, B):
                     o0, o1 = e * M + offset, e * M + min(offset + B, M)
-                    net.ppo_update(xs[o0:o1], None, acts[o0:o1], advs[o0:o1], rets[o0:o1], vals[o0:o1], lps[o0:o1], self.epsilon_clip, self.vf_coef,
-                                   self.ent_coef, self.clip_grad_norm, st["stats"][k], do_adam=self.grad_sync is None)
+                    if exact:  # critic = max(mean(e1), mean(e2)) over the GLOBAL minibatch: 8 more bytes on the wire, before the backward
+                        net.ppo_update_dp(xs[o0:o1], None, acts[o0:o1], advs[o0:o1], rets[o0:o1], vals[o0:o1], lps[o0:o1], self.epsilon_clip, self.vf_coef,
+                                          self.ent_coef, st["stats"][k], self.grad_sync.reduce_flat, st["critic_sums"][k])
+                    else:
+                        net.ppo_update(xs[o0:o1], None, acts[o0:o1], advs[o0:o1], rets[o0:o1], vals[o0:o1], lps[o0:o1], self.epsilon_clip, self.vf_coef,
+                                       self.ent_coef, self.clip_grad_norm, st["stats"][k], do_adam=self.grad_sync is None)
                     if self.grad_sync is not None:
                         self.grad_sync.reduce_flat(net.grads)
                         net.adam_step(self.clip_grad_norm)
                     k += 1
             return
+        exact = self.grad_sync is not None and self.dp_exact_critic
+        if exact and "dp_work" not in st:
+            st["dp_work"] = torch.zeros(st["n_upd"], B + 16, dtype=torch.float32, device=self.device)
         for e in range(self.n_epoch):
             for offset in range(0, M, B):
                 b = min(B, M - offset)
                 idx = st["idx"][e * M + offset : e * M + offset + b]
                 if cont:
                     mu, ls, vp = net.forward(tr["state"], idx=idx, out=(st["mb_h0"][:b], st["mb_h1"][:b], st["mb_v"][:b]))
-                    g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu, ls, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])
+                    if exact:
+                        g_mu, g_ls, g_v = ops.ppo_loss_dp(mu, ls, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef,
+                                                          st["stats"][k], self.grad_sync.reduce_flat, st["dp_work"][k])
+                    else:
+                        g_mu, g_ls, g_v, _ = ops.ppo_loss_continuous(mu, ls, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])
                     net.backward(tr["state"], idx, g_mu, g_ls, g_v)
                 else:
                     z, vp = net.forward(tr["state"], idx=idx, out=(st["mb_h0"][:b], None, st["mb_v"][:b]))
-                    g_z, g_v, _ = ops.ppo_loss_discrete(z, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])
+                    if exact:
+                        g_z, g_v = ops.ppo_loss_dp(z, None, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef,
+                                                   st["stats"][k], self.grad_sync.reduce_flat, st["dp_work"][k])
+                    else:
+                        g_z, g_v, _ = ops.ppo_loss_discrete(z, vp, idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, stats=st["stats"][k])
                     net.backward(tr["state"], idx, g_z, None, g_v)
                 if self.grad_sync is not None:
                     self.grad_sync.reduce_flat(net.grads)
@@ -325,6 +358,7 @@ class PPO(BaseAgent):
         M = self.memory.size
         self._grow_native(2 * M if 2 * M <= 8192 else M)
         if self._static is None or self._static["M"] != M:
+            self._drop_rides()
             self._static, self._graphs = self._alloc_static(M), {}
         st = self._static
         E = self.n_epoch
@@ -441,10 +475,11 @@ class PPO(BaseAgent):
                 if self._lr_word is None:
                     self._lr_word = ops.PinnedBuffer((1,), np.float32, self.device.index)
                 self._lr_word.np[0] = lr
-                self._ride.ride_along(1, self._lr_word.dev_ptr.value, self._net.hyper_ptr(), 4)
+                self._ride.ride_along(1, self._lr_word.dev_ptr.value, self._net.hyper_ptr(), 4, keep=(self._lr_word, self._net))
                 self._ride_wait["lr"] = True
-            else:
-                self._ride_wait.pop("lr", None)
+            else:  # set directly (load(), an external schedule): nothing older may be delivered on top of it later
+                if self._ride_wait.pop("lr", None) and self._ride is not None:
+                    self._ride.ride_along(1, 0, 0, 0)
                 self._net.set_lr(lr)
 
     def process_begin(self, step):
@@ -517,6 +552,8 @@ class PPO(BaseAgent):
                 steps = int(float(stt["step"]))
         self._adam_steps = steps
         d = self.optimizer.defaults
+        if self._ride_wait.pop("lr", None) and self._ride is not None:  # a learning rate still riding with the next commit launch would overwrite this one
+            self._ride.ride_along(1, 0, 0, 0)
         self._net.set_hyper(self.optimizer.param_groups[0]["lr"], d["betas"][0], d["betas"][1], d["eps"], step=float(steps))
 
     def save(self, path):

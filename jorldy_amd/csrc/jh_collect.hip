@@ -153,7 +153,8 @@ JH_EXPORT int jh_collector_set_capture(jh_collector* c, float* d_h0, float* d_h1
   return JH_OK;
 }
 
-// Two more copies for the commit launch of every following run (slot 0 / 1; bytes == 0 clears a slot): the learner's inputs that
+// Two more copies for the commit launch of the NEXT run only (slot 0 / 1; one-shot: the launch that performs a copy clears its
+// slot; bytes == 0 clears a slot before that): the learner's inputs that
 // change between learn() calls but are known before the rollout ends -- the minibatch index lists of the coming epochs (drawn
 // ahead, np_rng.Predraw) and the decayed learning rate -- go from device-mapped pinned memory to their device buffers inside the
 // launch that exists anyway, instead of as hipMemcpyAsync calls of their own (SDMA hand-offs of ~10 us each between the learner's
@@ -214,9 +215,12 @@ static int run_commit(jh_collector* c, RunState& r, int rc_in, const unsigned* w
     job(r.cv, c->cap_v, (size_t)n);
     job(r.cnv, c->cap_nv, (size_t)n);
   }
-  if (rc_in == JH_OK)
-    for (int q = 0; q < 2; ++q)
-      if (c->ride_bytes[q] > 0) { xs[k] = c->ride_src[q]; xd[k] = c->ride_dst[q]; xb[k] = c->ride_bytes[q]; ++k; }
+  // ride-along copies are ONE-SHOT: consumed by this commit launch (a registration that persisted across runs kept
+  // pointing at index-list buffers the agent had meanwhile reallocated, and re-delivered a stale learning rate)
+  for (int q = 0; q < 2; ++q) {
+    if (rc_in == JH_OK && c->ride_bytes[q] > 0) { xs[k] = c->ride_src[q]; xd[k] = c->ride_dst[q]; xb[k] = c->ride_bytes[q]; ++k; }
+    c->ride_src[q] = nullptr; c->ride_dst[q] = nullptr; c->ride_bytes[q] = 0;
+  }
   const int rc2 = jh_store_stage_commit_gated(c->store, k, xs, xd, xb, wait_flag, wait_val, st);
   if (r.cap_slab) (void)jh_ctx_slab_release(c->ctx, r.cap_slab, st);
   r.cap_slab = nullptr;
@@ -434,26 +438,27 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
   uint8_t* dn = (uint8_t*)r.cols[c->col_done];
   const int no = jh_persist_heads(c->persist);  // A logits + value
   const int A = c->A;
-  Level L1, L2, L3;
+  Level L1, L2, L3, tmp;
   L1.env = c->spec; L2.env = c->spec2; L3.env = c->spec3;
   L1.init(2 * W); L2.init(4 * W); L3.init(8 * W);
-  std::vector<float> pub((size_t)3 * W * S), hz((size_t)W * no), hz2((size_t)W * no);
+  std::vector<float> pub((size_t)3 * W * S), pub_next((size_t)3 * W * S), hz((size_t)W * no), hz2((size_t)W * no);
   std::vector<int> pick(W);
   std::vector<int64_t> a0(W), a1(W);
   int t = 0;
   *t_done = 0;
-  fork_step(L1, e, W);  // the successors of the states the run starts in
+  // rows 0 .. W-1: the envs' current states; rows W + 2 w + a: the state env w acts on next if it takes action a now
+  fork_step(L1, e, W);
+  jh_cartpole_obs(e, pub.data());
+  memcpy(pub.data() + (size_t)W * S, L1.obs.data(), sizeof(float) * (size_t)2 * W * S);
+  auto t0 = std::chrono::steady_clock::now();
+  unsigned tag = jh_persist_publish(c->persist, 3 * W, pub.data());
   while (t < steps) {
     const bool extra = t == T;
     const bool two = !extra && t + 1 < T;
-    // rows 0 .. W-1: the envs' current states; rows W + 2 w + a: the state env w acts on next if it takes action a now
-    jh_cartpole_obs(e, pub.data());
-    memcpy(pub.data() + (size_t)W * S, L1.obs.data(), sizeof(float) * (size_t)2 * W * S);
-    const auto t0 = std::chrono::steady_clock::now();
-    const unsigned tag = jh_persist_publish(c->persist, 3 * W, pub.data());
+    const int t_next = t + (two ? 2 : 1);
     if (!extra) {  // the GPU is busy for ~5 us: run the env model two levels further meanwhile
       fork_step(L2, L1.env, 2 * W);
-      if (two) fork_step(L3, L2.env, 4 * W);
+      if (two && t_next < steps) fork_step(L3, L2.env, 4 * W);
     }
     int rc = jh_persist_collect_rows(c->persist, nullptr, W, tag, hz.data());
     if (rc) {  // the kernel gave up (it exits by itself)
@@ -465,45 +470,65 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
       *t_done = t;
       return JH_OK;  // the caller finishes the run with one launch per step
     }
-    for (int w = 0; w < W; ++w) {
-      const float* z = hz.data() + (size_t)w * no;
-      if (!extra) a0[w] = jh_sample_discrete(c->net, z, w, training);
-      if (cap) {
+    if (!extra) {
+      for (int w = 0; w < W; ++w) {
+        a0[w] = jh_sample_discrete(c->net, hz.data() + (size_t)w * no, w, training);
+        pick[w] = W + 2 * w + (int)a0[w];
+      }
+      c->net->act_ctr += 1;
+      if (two) {  // timestep t + 1: the heads of the chosen successors arrived with the same exchange
+        rc = jh_persist_collect_rows(c->persist, pick.data(), W, tag, hz2.data());
+        if (rc) return rc;  // (the kernel answers a tag for all rows or for none)
+        for (int w = 0; w < W; ++w) a1[w] = jh_sample_discrete(c->net, hz2.data() + (size_t)w * no, w, training);
+        c->net->act_ctr += 1;
+      }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    // ---- the next exchange first: its rows are already computed; everything else happens while the GPU works on it
+    unsigned tag_next = 0;
+    auto t0_next = t1;
+    if (!extra && t_next < steps) {
+      for (int w = 0; w < W; ++w) {
+        const int k1 = 2 * w + (int)a0[w];
+        if (two) {
+          const int k2 = 2 * k1 + (int)a1[w];
+          memcpy(&pub_next[(size_t)S * w], &L2.obs[(size_t)S * k2], sizeof(float) * S);
+          memcpy(&pub_next[(size_t)S * (W + 2 * w)], &L3.obs[(size_t)S * 2 * k2], sizeof(float) * 2 * S);
+        } else {
+          memcpy(&pub_next[(size_t)S * w], &L1.obs[(size_t)S * k1], sizeof(float) * S);
+          memcpy(&pub_next[(size_t)S * (W + 2 * w)], &L2.obs[(size_t)S * 2 * k1], sizeof(float) * 2 * S);
+        }
+      }
+      t0_next = std::chrono::steady_clock::now();
+      tag_next = jh_persist_publish(c->persist, 3 * W, pub_next.data());
+    }
+    // ---- bookkeeping of this exchange: captured heads / values, transitions, the envs move on
+    if (cap) {
+      for (int w = 0; w < W; ++w) {
+        const float* z = hz.data() + (size_t)w * no;
         if (t > 0) cnv[(size_t)w * T + (t - 1)] = z[no - 1];  // V(next_state_{t-1}) = V(state_t)  (masked by done_{t-1} in GAE)
         if (!extra) {
           const size_t row = (size_t)w * T + t;
           cv[row] = z[no - 1];
           memcpy(ch0 + row * A, z, sizeof(float) * A);
+          if (two) {
+            const float* z2 = hz2.data() + (size_t)w * no;
+            cnv[row] = z2[no - 1];
+            cv[row + 1] = z2[no - 1];
+            memcpy(ch0 + (row + 1) * A, z2, sizeof(float) * A);
+          }
         }
       }
     }
     if (extra) {
-      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const double dt = std::chrono::duration<double>(t1 - t0).count();
       c->t_act += dt;
       c->t_extra += dt;
-      t += 1;
+      t = t_next;
       break;
     }
-    c->net->act_ctr += 1;
-    for (int w = 0; w < W; ++w) pick[w] = W + 2 * w + (int)a0[w];
-    if (two) {  // timestep t + 1: the heads of the chosen successors arrived with the same exchange
-      rc = jh_persist_collect_rows(c->persist, pick.data(), W, tag, hz2.data());
-      if (rc) return rc;  // (the kernel answers a tag for all rows or for none)
-      for (int w = 0; w < W; ++w) {
-        const float* z = hz2.data() + (size_t)w * no;
-        a1[w] = jh_sample_discrete(c->net, z, w, training);
-        if (cap) {
-          const size_t row = (size_t)w * T + (t + 1);
-          cnv[row - 1] = z[no - 1];
-          cv[row] = z[no - 1];
-          memcpy(ch0 + row * A, z, sizeof(float) * A);
-        }
-      }
-      c->net->act_ctr += 1;
-    }
-    const auto t1 = std::chrono::steady_clock::now();
     if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
-    // the transitions, and the envs move on to states that are already computed
+    if (!two) { tmp.env = L3.env; tmp.init(2 * W); }  // one-step exchange: L3 is free, the successors move up through it
     for (int w = 0; w < W; ++w) {
       const int k1 = 2 * w + (int)a0[w];
       size_t row = (size_t)w * T + t;  // worker-major (distributed_manager.py:30)
@@ -521,29 +546,26 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
         rw[row] = L2.rw[k2];
         dn[row] = L2.dn[k2];
         copy_env(e, w, L2.env, k2);
-        copy_level_row(L1, 2 * w, L3, 2 * k2);
-        copy_level_row(L1, 2 * w + 1, L3, 2 * k2 + 1);
+        if (t_next < steps) {  // (L1's rows of env w are read above before they are overwritten)
+          copy_level_row(L1, 2 * w, L3, 2 * k2);
+          copy_level_row(L1, 2 * w + 1, L3, 2 * k2 + 1);
+        }
       } else {
         copy_env(e, w, L1.env, k1);
-        // (L1's rows 2 w, 2 w + 1 are read above before they are overwritten: k1 is one of them -- copy through temporaries)
-      }
-    }
-    if (!two) {  // a one-step exchange (odd T): the next successors come from L2, two rows per env
-      Level tmp;
-      tmp.env = L3.env;  // scratch: L3 is not in use in a one-step exchange
-      tmp.init(2 * W);
-      for (int w = 0; w < W; ++w) {
-        const int k1 = 2 * w + (int)a0[w];
         copy_level_row(tmp, 2 * w, L2, 2 * k1);
         copy_level_row(tmp, 2 * w + 1, L2, 2 * k1 + 1);
       }
-      for (int i = 0; i < 2 * W; ++i) copy_level_row(L1, i, tmp, i);
     }
+    if (!two)
+      for (int i = 0; i < 2 * W; ++i) copy_level_row(L1, i, tmp, i);
     c->steps += two ? 2 : 1;
     const auto t2 = std::chrono::steady_clock::now();
     c->t_act += std::chrono::duration<double>(t1 - t0).count();
     c->t_env += std::chrono::duration<double>(t2 - t1).count();
-    t += two ? 2 : 1;
+    t = t_next;
+    tag = tag_next;
+    t0 = t0_next;
+    pub.swap(pub_next);
   }
   *t_done = t;
   if (getenv("JH_PERSIST_DEBUG") && (c->runs % 16) == 15) jh_persist_dump_debug(c->persist, collector_steps(c, T));

@@ -153,6 +153,8 @@ struct jh_pponet {
   // owned workspaces
   float *h1 = nullptr, *h2 = nullptr, *dh1 = nullptr, *dh2 = nullptr;
   float* g_all = nullptr;     // [max_rows][8] packed head gradients (A-operand of the dW_heads GEMM)
+  float* dv2 = nullptr;       // [min(max_rows, 1024)] value gradients of the critic's second branch (data-parallel exact critic) + 8 floats:
+  float* stats_tmp = nullptr; // the loss kernel's local statistics row between jh_pponet_ppo_update_dp_begin and _end
   int max_act_rows = 0;
   // acting exchange area: pinned host memory mapped into the device address space
   float *obs_pin_h = nullptr, *obs_pin_d = nullptr;        // [max_act_rows][S] observations (host writes, kernel reads)

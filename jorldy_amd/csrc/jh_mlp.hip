@@ -574,6 +574,8 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     JH_HIP(hipMalloc((void**)&n->fwd_part, part_bytes));
     JH_HIP(hipMemset(n->fwd_part, 0, part_bytes));  // head slots >= n_out are never written: they must read as 0
     JH_HIP(hipMemset(n->g_all, 0, sizeof(float) * 8 * (size_t)max_rows));
+    JH_HIP(hipMalloc((void**)&n->dv2, sizeof(float) * ((size_t)(max_rows < 1024 ? max_rows : 1024) + 8)));
+    n->stats_tmp = n->dv2 + (max_rows < 1024 ? max_rows : 1024);
     const size_t slabs = (size_t)(((max_rows < 1024 ? max_rows : 1024) + 15) / 16);
     JH_HIP(hipMalloc((void**)&n->part_w1, sizeof(float) * slabs * ((size_t)H * S + H + 8 * (size_t)H)));
     JH_HIP(hipMalloc((void**)&n->ssq_part, sizeof(float) * ((size_t)(H / 32) * (H / 32) + H / 32 + 1)));
@@ -594,7 +596,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipFree(n->h1); (void)hipFree(n->h2); (void)hipFree(n->dh1); (void)hipFree(n->dh2);
   (void)hipFree(n->g_all);
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
-  (void)hipFree(n->norm_partial); (void)hipFree(n->hyper);
+  (void)hipFree(n->norm_partial); (void)hipFree(n->hyper); (void)hipFree(n->dv2);
   (void)hipFree(n->fwd_part); (void)hipFree(n->part_w1); (void)hipFree(n->ssq_part);
   (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt); (void)hipFree(n->xg);
   delete n;
@@ -1010,7 +1012,9 @@ JH_EXPORT int jh_pponet_adam_step(jh_pponet* n, float max_norm, float* d_norm_ou
 int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows, int part_ld,
                               const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
                               const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
-                              float* d_g_all, float* d_stats, float* d_hyper_advance, hipStream_t st);
+                              float* d_g_all, float* d_stats, float* d_hyper_advance, float* d_defer_dv2, float* d_critic_sums, hipStream_t st);
+int jh_ppo_critic_select(int B, const float* d_sums, float vf, float ent, float* d_gv, int ldv, const float* d_dv2, const float* d_stats_local,
+                         float* d_stats_out, hipStream_t st);
 
 // One PPO minibatch update (ppo.py:122-169) in FOUR launches when the (dW1 | db1) slabs are small enough for Adam's
 // prologue to sum them in every workgroup (B <= 256 rows, CartPole / Hopper widths), else five (jh_ppo_mb.hip): forward into partial heads,
@@ -1029,7 +1033,7 @@ JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, co
   if (rc) return rc;
   const bool fused = do_adam && pponet_adam_fused_ok(n, B);  // four launches: no combine + norm kernel
   rc = jh_ppo_loss_from_partials(n->ctx, n->cont, B, n->A, n->fwd_part, n->H / 16, n->max_rows, (n->cont ? 2 * n->A + 1 : n->A + 1) <= 4 ? 4 : 8, d_idx, d_action, d_adv, d_ret,
-                                 d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, n->g_all, d_stats, fused ? n->hyper : nullptr, st);
+                                 d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, n->g_all, d_stats, fused ? n->hyper : nullptr, nullptr, nullptr, st);
   if (rc) return rc;
   rc = jh_pmb_backward(n, B, d_x, d_idx, pmb_heads(n), fused, st);
   if (rc) return rc;
@@ -1037,6 +1041,41 @@ JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, co
   rc = jh_pmb_finalize(n, B, do_adam != 0, st);
   if (rc) return rc;
   return do_adam ? pponet_adam(n, max_norm, nullptr, st) : JH_OK;
+}
+
+// ---- the same update for DATA-PARALLEL learners with the reference's exact critic.  The critic of ppo.py:147-154 is
+// max(mean(e1), mean(e2)) over the whole minibatch; with the minibatch sharded over ranks each rank's own max picks ITS branch and the
+// averaged gradient is no longer one learner's once the value clamp binds.  Two halves around an 8-byte all-reduce:
+//   jh_pponet_ppo_update_dp_begin   forward + loss: policy / entropy gradients complete, BOTH critic branches' value gradients kept
+//                                   (g_all's value column | n->dv2), d_critic_sums[2] = this rank's {sum e1, sum e2}
+//   (caller)                        all-reduce MEAN of d_critic_sums over the ranks
+//   jh_pponet_ppo_update_dp_end     branch weights from the reduced sums (identical on every rank) -> value gradients -> the backward
+//                                   grid + (dW1 | db1) combine: a complete gradient bucket.  d_stats: this rank's actor / entropy terms,
+//                                   the GLOBAL critic terms.  Then: all-reduce MEAN of the bucket, jh_pponet_adam_step.
+JH_EXPORT int jh_pponet_ppo_update_dp_begin(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action, const float* d_adv,
+                                            const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef,
+                                            float ent_coef, float* d_critic_sums, jh_stream stream) {
+  JH_ARG(n && d_x && d_action && d_adv && d_ret && d_value_old && d_logp_old && d_critic_sums);
+  JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
+  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update_dp_begin needs hidden_size %% 32 == 0 (H = %d)", n->H);
+  hipStream_t st = jh_s(stream);
+  int rc = pponet_forward_partials(n, B, d_x, d_idx, st);
+  if (rc) return rc;
+  return jh_ppo_loss_from_partials(n->ctx, n->cont, B, n->A, n->fwd_part, n->H / 16, n->max_rows, (n->cont ? 2 * n->A + 1 : n->A + 1) <= 4 ? 4 : 8, d_idx, d_action, d_adv,
+                                   d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, n->g_all, n->stats_tmp, nullptr, n->dv2, d_critic_sums, st);
+}
+
+JH_EXPORT int jh_pponet_ppo_update_dp_end(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_critic_sums, float vf_coef,
+                                          float ent_coef, float* d_stats, jh_stream stream) {
+  JH_ARG(n && d_x && d_critic_sums);
+  JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
+  hipStream_t st = jh_s(stream);
+  const int vcol = n->cont ? 2 * n->A : n->A;  // the value head's column of g_all [B][8]
+  int rc = jh_ppo_critic_select(B, d_critic_sums, vf_coef, ent_coef, n->g_all + vcol, 8, n->dv2, n->stats_tmp, d_stats, st);
+  if (rc) return rc;
+  rc = jh_pmb_backward(n, B, d_x, d_idx, pmb_heads(n), false, st);
+  if (rc) return rc;
+  return jh_pmb_finalize(n, B, false, st);
 }
 
 // Batched acting for W envs (PPO.act, ppo.py:55-69, discrete): ONE launch + host finish.

@@ -303,6 +303,12 @@ struct PpoArgs {
   // optional (single-workgroup launch only): Adam's hyper block; the step advances here when the minibatch update has
   // no norm kernel (jh_mlp.hip: four launches) -- the backward kernel must stay idempotent for the profiler's repeats
   float* hyper_advance;
+  // optional, data-parallel learners (exact critic): the critic is max(mean(e1), mean(e2)) over the WHOLE minibatch (ppo.py:147-154), a
+  // max of two means -- which of the two carries the gradient is known only after the ranks' sums have been reduced.  With defer_dv2
+  // the kernel writes gv = d(vf mean(e1))/dv for every row and defer_dv2[i] = d(vf mean(e2))/dv, and critic_sums = {sum e1, sum e2} of
+  // THIS rank's rows; jh_ppo_critic_select_kernel mixes the two with the branch weights of the reduced sums.
+  float* defer_dv2;
+  float* critic_sums;
 };
 
 // z0 / z1: this row's head-0 / head-1 vectors (global memory or the LDS staging), v: value prediction
@@ -350,8 +356,13 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
   const float d_ratio = -invB * (rc.g1 * rc.adv + (rc.in_clip ? rc.g2 * rc.adv : 0.f));
   const float d_logp = d_ratio * rc.ratio;
   // critic = max(c1, c2): weights w1/w2 (ties split); clamp passes grad inside [-eps, eps]
-  const float dv = a.vf * (w1 * 2.f * (rc.v - rc.ret) * invB + (rc.in_v ? w2 * 2.f * (rc.vclip - rc.ret) * invB : 0.f));
-  a.gv[(size_t)i * a.ldv] = dv;
+  if (a.defer_dv2) {
+    a.gv[(size_t)i * a.ldv] = a.vf * (2.f * (rc.v - rc.ret) * invB);
+    a.defer_dv2[i] = rc.in_v ? a.vf * (2.f * (rc.vclip - rc.ret) * invB) : 0.f;
+  } else {
+    const float dv = a.vf * (w1 * 2.f * (rc.v - rc.ret) * invB + (rc.in_v ? w2 * 2.f * (rc.vclip - rc.ret) * invB : 0.f));
+    a.gv[(size_t)i * a.ldv] = dv;
+  }
   if (!CONT) {
     const float* z = z0;
     const float ce = a.ent * invB;  // loss += ent_coef * (-mean(H)) = ent_coef/B * sum pn*lg
@@ -523,6 +534,7 @@ __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   float w1, w2;
   ppo_finish_stats(v6[0], v6[1], v6[2], v6[3], v6[4], v6[5], a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
                    threadIdx.x == 0 ? a.stats : nullptr);
+  if (a.critic_sums && threadIdx.x == 0) { a.critic_sums[0] = v6[1]; a.critic_sums[1] = v6[2]; }
   if (on) ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2);
 }
 
@@ -590,6 +602,7 @@ __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
   float w1, w2;
   ppo_finish_stats(t0, t1, t2, t3, t4, t5, a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
                    (blockIdx.x == 0 && threadIdx.x == 0) ? a.stats : nullptr);
+  if (a.critic_sums && blockIdx.x == 0 && threadIdx.x == 0) { a.critic_sums[0] = t1; a.critic_sums[1] = t2; }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.B) return;
   RowCommon rc;
@@ -665,13 +678,78 @@ JH_EXPORT int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const fl
   return ppo_launch<true>(ctx, a, jh_s(stream));
 }
 
+// Exact critic for data-parallel learners, second half (see PpoArgs::defer_dv2).  sums = the ranks' {sum e1, sum e2} averaged over the
+// ranks (one 8-byte all-reduce), B = rows per rank: c1 = sums[0] / B and c2 = sums[1] / B are then the means over the GLOBAL minibatch,
+// every rank takes the same branch, and after the gradient all-reduce the update equals one learner's on the concatenated batch.
+// stats_local: the loss kernel's row for this rank; stats_out gets it with the critic terms replaced by the global ones (written in the
+// order ppo_finish_stats uses: [7] last, behind a system fence -- it is the arrival marker of the mapped statistics).
+__global__ void __launch_bounds__(256) jh_ppo_critic_select_kernel(int B, const float* __restrict__ sums, float vf, float ent, float* __restrict__ gv, int ldv,
+                                                                   const float* __restrict__ dv2, const float* __restrict__ stats_local,
+                                                                   float* __restrict__ stats_out) {
+  const float c1 = sums[0] / (float)B, c2 = sums[1] / (float)B;
+  const float w1 = c1 > c2 ? 1.f : (c1 == c2 ? 0.5f : 0.f), w2 = 1.f - w1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B) gv[(size_t)i * ldv] = w1 * gv[(size_t)i * ldv] + w2 * dv2[i];
+  if (i == 0 && stats_out) {
+    const float critic = fmaxf(c1, c2);
+    stats_out[0] = stats_local[1] + vf * critic + ent * stats_local[3];
+    stats_out[1] = stats_local[1];
+    stats_out[2] = critic;
+    stats_out[3] = stats_local[3];
+    stats_out[4] = stats_local[4];
+    stats_out[5] = stats_local[5];
+    stats_out[6] = c1;
+    __threadfence_system();
+    stats_out[7] = c2;
+  }
+}
+
+int jh_ppo_critic_select(int B, const float* d_sums, float vf, float ent, float* d_gv, int ldv, const float* d_dv2, const float* d_stats_local,
+                         float* d_stats_out, hipStream_t st) {
+  JH_LAUNCH(jh_ppo_critic_select_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, d_sums, vf, ent, d_gv, ldv, d_dv2, d_stats_local, d_stats_out);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// Public form of the two halves for minibatches that do not take jh_pponet_ppo_update_dp_* (>= 1024 rows per rank): the loss with both
+// critic branches kept (d_dv2 [B], d_critic_sums [2] = this rank's {sum e1, sum e2}, d_stats_local [8]), then -- after the caller's
+// all-reduce (mean) of d_critic_sums -- jh_ppo_critic_select mixes d_grad_value in place and writes the final statistics row.
+JH_EXPORT int jh_ppo_loss_deferred(jh_ctx* ctx, int32_t continuous, int32_t B, int32_t A, const float* d_head0, const float* d_head1,
+                                   const float* d_value_pred, const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
+                                   const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
+                                   float* d_grad_head0, float* d_grad_head1, float* d_grad_value, float* d_dv2, float* d_critic_sums,
+                                   float* d_stats_local, jh_stream stream) {
+  JH_ARG(ctx && d_head0 && d_value_pred && d_action && d_adv && d_ret && d_value_old && d_logp_old);
+  JH_ARG(d_grad_head0 && d_grad_value && d_dv2 && d_critic_sums && B > 0 && A > 0 && (!continuous || (d_head1 && d_grad_head1)));
+  if (continuous) {
+    PpoArgs<true> a{};
+    a.B = B; a.A = A; a.h0 = d_head0; a.h1 = d_head1; a.value_pred = d_value_pred; a.idx = d_idx;
+    a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+    a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_head0; a.g1 = d_grad_head1; a.gv = d_grad_value;
+    a.ldg = A; a.ldv = 1; a.stats = d_stats_local; a.defer_dv2 = d_dv2; a.critic_sums = d_critic_sums;
+    return ppo_launch<true>(ctx, a, jh_s(stream));
+  }
+  PpoArgs<false> a{};
+  a.B = B; a.A = A; a.h0 = d_head0; a.h1 = nullptr; a.value_pred = d_value_pred; a.idx = d_idx;
+  a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+  a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_head0; a.g1 = nullptr; a.gv = d_grad_value;
+  a.ldg = A; a.ldv = 1; a.stats = d_stats_local; a.defer_dv2 = d_dv2; a.critic_sums = d_critic_sums;
+  return ppo_launch<false>(ctx, a, jh_s(stream));
+}
+
+JH_EXPORT int jh_ppo_critic_select_rows(jh_ctx* ctx, int32_t B, const float* d_critic_sums, float vf_coef, float ent_coef, float* d_grad_value,
+                                        const float* d_dv2, const float* d_stats_local, float* d_stats, jh_stream stream) {
+  JH_ARG(ctx && B > 0 && d_critic_sums && d_grad_value && d_dv2 && d_stats_local);
+  return jh_ppo_critic_select(B, d_critic_sums, vf_coef, ent_coef, d_grad_value, 1, d_dv2, d_stats_local, d_stats, jh_s(stream));
+}
+
 // Internal entry (jh_mlp.hip): same losses with the heads given as encoder partial sums (jh_pmb_fwd_kernel) and
 // the head gradients written PACKED, d_g_all [B][8] = (d head0 [A] | d head1 [A] (continuous) | d value | zeros):
 // the operand layout of the backward grid (jh_pmb_bwd_kernel).
 int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const float* d_hpart, int tiles, int part_rows, int part_ld,
                               const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
                               const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
-                              float* d_g_all, float* d_stats, float* d_hyper_advance, hipStream_t st) {
+                              float* d_g_all, float* d_stats, float* d_hyper_advance, float* d_defer_dv2, float* d_critic_sums, hipStream_t st) {
   JH_ARG(B > 0 && B <= 1024 && d_hpart && d_g_all);
   if (continuous) {
     PpoArgs<true> a{};
@@ -679,6 +757,7 @@ int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const f
     a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef;
     a.g0 = d_g_all; a.g1 = d_g_all + A; a.gv = d_g_all + 2 * A; a.ldg = 8; a.ldv = 8;
     a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld; a.hyper_advance = d_hyper_advance;
+    a.defer_dv2 = d_defer_dv2; a.critic_sums = d_critic_sums;
     return ppo_launch<true>(ctx, a, st);
   }
   PpoArgs<false> a{};
@@ -686,5 +765,6 @@ int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const f
   a.logp_old = d_logp_old; a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef;
   a.g0 = d_g_all; a.g1 = nullptr; a.gv = d_g_all + A; a.ldg = 8; a.ldv = 8;
   a.stats = d_stats; a.hpart = d_hpart; a.hp_tiles = tiles; a.hp_rows = part_rows; a.hp_ld = part_ld; a.hyper_advance = d_hyper_advance;
+  a.defer_dv2 = d_defer_dv2; a.critic_sums = d_critic_sums;
   return ppo_launch<false>(ctx, a, st);
 }

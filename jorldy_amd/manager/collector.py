@@ -85,6 +85,7 @@ class NativeCollector:
         # no-grad passes at the start of PPO.learn (ppo.py:83-94); JH_COLLECT_CAPTURE=0 switches it off
         self.capture = os.environ.get("JH_COLLECT_CAPTURE", "1") == "1"
         self._cap_key = None
+        self._rides, self._rides_prev = {}, {}
 
     def _bind(self, n_rows):
         mem, W = self.agent.memory, self.env.W
@@ -121,22 +122,36 @@ class NativeCollector:
         L.check(self.lib.jh_collector_set_capture(self.h, L.ptr(h0), L.ptr(h1), L.ptr(v), L.ptr(nv), int(n_rows)))
         self._cap_key = tuple(t.data_ptr() for t in cap if t is not None)
 
-    def ride_along(self, slot, src_dev_ptr, dst_ptr, nbytes):
-        """jh_collector_set_ride_along: the commit launch of every following run also copies nbytes from device-mapped pinned memory
-        at src_dev_ptr to the device buffer at dst_ptr (read when that launch executes, i.e. at the end of the run)."""
-        key = (int(src_dev_ptr), int(dst_ptr), int(nbytes))
-        if self._rides.get(slot) != key:
-            L.check(self.lib.jh_collector_set_ride_along(self.h, int(slot), C.c_void_p(key[0]), C.c_void_p(key[1]), key[2]))
-            self._rides[slot] = key
+    def ride_along(self, slot, src_dev_ptr, dst_ptr, nbytes, keep=None):
+        """jh_collector_set_ride_along: the commit launch of the NEXT run also copies nbytes from device-mapped pinned memory at
+        src_dev_ptr to the device buffer at dst_ptr (read when that launch executes, i.e. at the end of the run).  One-shot: the
+        launch consumes the registration.  `keep`: objects that own the two buffers -- held here until the slot is consumed or
+        cleared, so that a reallocation on the agent's side cannot leave the registration dangling."""
+        if self.h is None:
+            return
+        L.check(self.lib.jh_collector_set_ride_along(self.h, int(slot), C.c_void_p(int(src_dev_ptr)), C.c_void_p(int(dst_ptr)), int(nbytes)))
+        self._rides[slot] = keep
+
+    def clear_rides(self):
+        """Drop whatever is registered (the agent reallocated its buffers, or set the learning rate directly)."""
+        if self.h is not None:
+            for slot in (0, 1):
+                L.check(self.lib.jh_collector_set_ride_along(self.h, slot, None, None, 0))
+        self._rides = {}
 
     def run(self, step=1):
         n_rows = self.env.W * step
         self._bind(n_rows)
         L.check(self.lib.jh_collector_run(self.h, int(step), 1, L.stream_ptr()))
+        self._rides_consumed()
         self.agent._ride_done = True  # this run's commit launch carried whatever was registered with ride_along
         if self._cap_key is not None:
             self.agent._captured = n_rows  # the coming learn() takes the heads / values of these rows as delivered (no no-grad passes)
         return None, 1.0
+
+    def _rides_consumed(self):
+        # the commit launch is enqueued: the buffers must live until it has executed (stream order) -- one more generation
+        self._rides_prev, self._rides = self._rides, {}
 
     def begin(self, step=1):
         """First half of run(step) with the commit launch enqueued AHEAD of the host loop (jh_collector_begin): after this call the
@@ -149,6 +164,7 @@ class NativeCollector:
         n_rows = self.env.W * step
         self._bind(n_rows)
         L.check(self.lib.jh_collector_begin(self.h, int(step), L.stream_ptr()))
+        self._rides_consumed()
         if self._cap_key is not None:
             self.agent._captured = n_rows
         self.agent._ride_done = True

@@ -494,6 +494,29 @@ def ppo_loss_continuous(mu_raw, log_std_raw, value_pred, idx, action, adv, ret, 
     return g_mu, g_ls, g_v.view(-1, 1), stats
 
 
+def ppo_loss_dp(head0, head1, value_pred, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, stats, reduce_mean, work):
+    """ppo_loss_discrete (head1 None) / ppo_loss_continuous for data-parallel learners with the global critic branch (jh_ppo_loss_deferred ->
+    reduce_mean(critic sums) -> jh_ppo_critic_select_rows).  work: fp32 device tensor of >= B + 16 elements (second branch's value gradients,
+    the two sums, the local statistics row).  Returns the head gradients like the plain functions."""
+    lib = L.load()
+    cont = head1 is not None
+    h0, v = _f32(head0), _f32(value_pred).reshape(-1)
+    h1 = _f32(head1) if cont else None
+    B, A = h0.shape
+    g0 = torch.empty_like(h0)
+    g1 = torch.empty_like(h1) if cont else None
+    g_v = torch.empty(B, dtype=torch.float32, device=h0.device)
+    dv2, sums, local = work[:B], work[B : B + 2], work[B + 8 : B + 16]
+    ctx = L.ctx(_dev(h0))
+    L.check(lib.jh_ppo_loss_deferred(ctx, int(cont), B, A, L.ptr(h0), L.ptr(h1), L.ptr(v), L.ptr(idx), L.ptr(_f32(action) if cont else _f32(action).reshape(-1)),
+                                     L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)), L.ptr(_f32(value_old).reshape(-1)),
+                                     L.ptr(_f32(logp_old) if cont else _f32(logp_old).reshape(-1)), float(eps_clip), float(vf_coef), float(ent_coef),
+                                     L.ptr(g0), L.ptr(g1), L.ptr(g_v), L.ptr(dv2), L.ptr(sums), L.ptr(local), L.stream_ptr()))
+    reduce_mean(sums)
+    L.check(lib.jh_ppo_critic_select_rows(ctx, B, L.ptr(sums), float(vf_coef), float(ent_coef), L.ptr(g_v), L.ptr(dv2), L.ptr(local), L.ptr(stats), L.stream_ptr()))
+    return (g0, g1, g_v.view(-1, 1)) if cont else (g0, g_v.view(-1, 1))
+
+
 # ============================================================================= native policy-value MLP
 class PinnedBuffer:
     """Pinned host memory mapped into the device address space (jh_pinned_alloc): `.np` is the host
@@ -596,6 +619,17 @@ class PPONet:
         L.check(self.lib.jh_pponet_ppo_update(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
                                               L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
                                               float(max_norm if max_norm else 0.0), int(bool(do_adam)), L.ptr(stats), L.stream_ptr()))
+
+    def ppo_update_dp(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, stats, reduce_mean, critic_sums):
+        """The minibatch update for data-parallel learners with the reference's critic exactly (jh_pponet_ppo_update_dp_begin / _end around
+        an 8-byte all-reduce): reduce_mean(t) all-reduces a small fp32 device tensor to its mean over the ranks, in place, on the current
+        stream.  Leaves a complete gradient bucket; the caller reduces it and calls adam_step."""
+        B = int(idx.numel()) if idx is not None else int(x.shape[0])
+        L.check(self.lib.jh_pponet_ppo_update_dp_begin(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
+                                                       L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
+                                                       L.ptr(critic_sums), L.stream_ptr()))
+        reduce_mean(critic_sums)
+        L.check(self.lib.jh_pponet_ppo_update_dp_end(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(critic_sums), float(vf_coef), float(ent_coef), L.ptr(stats), L.stream_ptr()))
 
     # ---- acting (one launch; partial heads come back through device-mapped pinned memory) ---------
     def act_discrete(self, obs, training=True, want_logits=False):

@@ -1,6 +1,7 @@
 """One rank of the two-ranks-on-one-GPU data-parallel tests (tests/test_dp_two_ranks_gpu.py).  Not a test module.
 
-usage: python tests/dp_worker.py <mode: ppo|rainbow> <rank> <world> <port> <out.npz>
+usage: python tests/dp_worker.py <mode: ppo|rainbow> <rank> <world> <port> <out.npz> [gloo|nccl]
+nccl (= RCCL): rank r on GPU r -- the form the N-GPU bench runs; needs >= world GPUs (the driver's 8-GPU node).
 RCCL refuses two ranks on one device, gloo does not: the process group is gloo, the gradient bucket is staged through
 host memory around the all-reduce (jorldy_amd.parallel.Transport kind "host"); everything else -- the native agents'
 DP branch (ppo_update(do_adam=0) -> reduce_flat -> adam_step; RainbowNet backward -> reduce_flat -> optim_step; the
@@ -16,11 +17,11 @@ sys.path.insert(0, ROOT)
 
 from oracle import synth  # noqa: E402  (test infrastructure: recipes for weights / rollouts)
 
-# config.ppo.cartpole (BASELINE configs[1]) except lr: PPO's critic is max(mean(e1), mean(e2)) (ppo.py:147-154), a max of two MEANS -- per rank
-# over 256 rows, for one learner over 512.  Once |V - V_old| passes epsilon_clip for some rows (at lr 2.5e-4: from the third update on)
-# the ranks may take different branches than the single learner and "DP == one learner" holds only statistically.  With
-# lr 2.5e-6 the value clamp stays inactive for all 12 updates (asserted), both branches carry the same gradient, and the equality is exact.
-PPO_CFG = dict(S=4, A=2, H=512, W=8, T=128, B=256, E=3, lr=2.5e-6, seed=20260925)
+# config.ppo.cartpole (BASELINE configs[1]) at its own learning rate.  PPO's critic is max(mean(e1), mean(e2)) (ppo.py:147-154), a max of two MEANS
+# over the whole minibatch; from the third update on |V - V_old| passes epsilon_clip for some rows and the two means differ.  Round 3 let every
+# rank take the max of ITS means (equal to one learner only while the clamp is inactive: the test ran at lr 2.5e-6 and asserted that); round 4
+# reduces {sum e1, sum e2} over the ranks before the backward (jh_pponet_ppo_update_dp_begin / _end), so DP == one learner with the clamp active.
+PPO_CFG = dict(S=4, A=2, H=512, W=8, T=128, B=256, E=3, lr=2.5e-4, seed=20260925)
 RB_CFG = dict(S=4, A=3, H=32, K=51, B=32, N=256, fill=200, n_step=3, lr=1e-3)
 
 
@@ -71,12 +72,16 @@ def rainbow_shard(rank):
 
 def main():
     mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    backend = sys.argv[6] if len(sys.argv) > 6 else "gloo"
     import torch.distributed as dist
 
     from jorldy_amd.parallel import attach_data_parallel
 
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rccl = backend == "nccl"
+    torch.cuda.set_device(rank if rccl else 0)
+    kw = {"device_id": torch.device("cuda", rank)} if rccl else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
+    kinds = ("rccl", "torch") if rccl else ("host",)
     res = {}
     try:
         if mode == "ppo":
@@ -87,7 +92,7 @@ def main():
                     for p in agent.network.parameters():
                         p.add_(0.01)
             sync = attach_data_parallel(agent, dist)
-            assert sync.transport.kind == "host" and not agent.graph_with_collective
+            assert sync.transport.kind in kinds and (rccl or not agent.graph_with_collective)
             agent._predraw = None  # keep this learn()'s index lists in st["idx"] (no lists of a next learn() drawn ahead)
             np.random.seed(200 + rank)
             result = agent.process(ppo_rows(rank), c["T"])
@@ -103,7 +108,7 @@ def main():
             agent.memory.store_soa(cols, priorities=prio)
             N = c["N"]
             sync = attach_data_parallel(agent, dist)
-            assert sync.transport.kind == "host" and agent.memory._shards is not None
+            assert sync.transport.kind in kinds and agent.memory._shards is not None
             np.random.seed(300 + rank)
             torch.manual_seed(40 + rank)  # the ranks draw DIFFERENT noise: the averaged gradient still gives identical weights
             losses = []
@@ -119,7 +124,7 @@ def main():
     finally:
         dist.destroy_process_group()
     np.savez(out, **res)
-    print(f"dp_worker {mode} rank {rank} ok")
+    print(f"dp_worker {mode} rank {rank} ok (transport {sync.transport.kind})")
 
 
 if __name__ == "__main__":

@@ -4,7 +4,8 @@ B = 32, each rank with its own rollout / replay shard and its own index lists.
 
   (a) after the updates the ranks' parameter buckets are bit-identical;
   (b) PPO == ONE learner on the concatenated batch fed the same per-rank index lists (the reference shuffles globally,
-      core/agent/ppo.py:116-120; here: 16 workers x 128 steps, minibatch 512 = [rank 0's 256 rows; rank 1's 256 rows]);
+      core/agent/ppo.py:116-120; here: 16 workers x 128 steps, minibatch 512 = [rank 0's 256 rows; rank 1's 256 rows]) at the config's
+      own learning rate, i.e. with the value clamp active: the critic's max(mean, mean) is taken over the global minibatch;
   (c) the sharded PER importance weights == those of a single logical sum tree over both shards (per_buffer.py:88-94);
   (d) `bench.py --gpus 2` runs 3 steps through the same launch / pinning / barrier plumbing.
 """
@@ -35,11 +36,11 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, tmp_path, world=2):
+def _run_ranks(mode, tmp_path, world=2, backend="gloo", extra_env=None):
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JH_NO_PIN="1")
-    outs = [str(tmp_path / f"{mode}_{r}.npz") for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), mode, str(r), str(world), str(port), outs[r]], env=env, cwd=ROOT,
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JH_NO_PIN="1", **(extra_env or {}))
+    outs = [str(tmp_path / f"{mode}_{backend}_{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), mode, str(r), str(world), str(port), outs[r], backend], env=env, cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -56,7 +57,52 @@ def _run_ranks(mode, tmp_path, world=2):
 
 
 def test_ppo_native_two_ranks_equal_one_learner_on_the_concatenated_batch(tmp_path, monkeypatch):
-    r0, r1 = _run_ranks("ppo", tmp_path)
+    _check_ppo_two_ranks(_run_ranks("ppo", tmp_path), monkeypatch)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need two GPUs (the driver's 8-GPU node; the builder's box has one)")
+@pytest.mark.parametrize("inject", ["", "create"])
+def test_ppo_native_two_ranks_over_rccl_equal_one_learner(tmp_path, monkeypatch, inject):
+    """The same equality with rank r on GPU r over RCCL: the library's own communicator (jh_comm_create from a torch-broadcast id,
+    the all-reduces of the gradient bucket and of the critic sums captured into the learn() graph) before the bench meets it.
+    inject = create: jh_comm_create fails on every rank -> all ranks fall back to torch.distributed's collectives TOGETHER."""
+    _check_ppo_two_ranks(_run_ranks("ppo", tmp_path, backend="nccl", extra_env={"JH_COMM_INJECT": inject} if inject else None), monkeypatch)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need two GPUs")
+def test_rainbow_native_two_ranks_over_rccl_identical_weights(tmp_path):
+    r0, r1 = _run_ranks("rainbow", tmp_path, backend="nccl")
+    assert np.array_equal(r0["params"], r1["params"]) and np.array_equal(r0["target"], r1["target"])
+    assert np.all(np.isfinite(r0["losses"])) and np.all(np.isfinite(r1["losses"]))
+
+
+@pytest.mark.parametrize("inject,kind", [("", "rccl"), ("id", "torch"), ("create", "torch")])
+def test_rccl_communicator_fallback_is_decided_collectively(inject, kind, monkeypatch):
+    """jorldy_amd.parallel.Transport on a 1-rank RCCL group: the library's communicator when everything works; when rank 0 cannot make a
+    unique id (a ZERO id is broadcast: every rank still runs the same collectives) or jh_comm_create fails, the all-reduced success flag
+    puts ALL ranks on torch.distributed's collectives (a per-rank try/except left ranks on different transports)."""
+    import torch.distributed as dist
+
+    from jorldy_amd.parallel import Transport
+
+    if inject:
+        monkeypatch.setenv("JH_COMM_INJECT", inject)
+    else:
+        monkeypatch.delenv("JH_COMM_INJECT", raising=False)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tr = Transport(dist, None, torch.device("cuda", 0))
+        assert tr.kind == kind and tr.capturable
+        t = torch.arange(8, dtype=torch.float32, device="cuda")
+        tr.mean_(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_ppo_two_ranks(ranks, monkeypatch):
+    r0, r1 = ranks
     # (a) identical weights on both ranks, bit for bit
     assert np.array_equal(r0["params"], r1["params"]), "ranks diverged"
     assert np.array_equal(r0["grads"], r1["grads"])
@@ -85,10 +131,15 @@ def test_ppo_native_two_ranks_equal_one_learner_on_the_concatenated_batch(tmp_pa
     one = npy(agent._net.params)
     s1 = np.asarray(agent._static["stats_pin"].np[: n_upd + 1], dtype=np.float64)
     s_dp = 0.5 * (r0["stats"].astype(np.float64) + r1["stats"].astype(np.float64))
-    # every update's loss terms: mean over 512 rows == mean of the two ranks' means (actor, entropy: exactly linear; critic is
-    # max(mean, mean) per rank, ppo.py:147-154 -- equal here because both ranks take the same branch)
-    for st_ in (r0["stats"], r1["stats"], s1):  # precondition of exact equality: the value clamp is inactive, c1 == c2 up to rounding
-        np.testing.assert_allclose(st_[:n_upd, 6], st_[:n_upd, 7], rtol=1e-5, err_msg="value clamp active: per-rank max(mean, mean) may pick another branch")
+    # every update's loss terms: mean over 512 rows == mean of the two ranks' means (actor, entropy: exactly linear); the critic is
+    # max(mean(e1), mean(e2)) over the GLOBAL minibatch (ppo.py:147-154): both ranks report it (exact DP critic) and it must be
+    # the single learner's -- with the value clamp ACTIVE (config's own lr: the branches differ from the third update on)
+    for st_ in (r0["stats"], r1["stats"]):
+        np.testing.assert_array_equal(st_[:n_upd, 6:8], r0["stats"][:n_upd, 6:8])  # the same global c1 / c2 on every rank, bit for bit
+    gap = np.abs(s1[:n_upd, 6] - s1[:n_upd, 7]) / np.maximum(s1[:n_upd, 6], 1e-12)
+    assert (gap > 1e-3).sum() >= n_upd // 2, f"the value clamp never became active (relative |c1 - c2| per update: {gap}): the test would not see a wrong branch"
+    for j in (6, 7):
+        np.testing.assert_allclose(s1[:n_upd, j], r0["stats"][:n_upd, j], rtol=2e-5, atol=1e-7, err_msg="global c1 / c2 vs one learner")
     for j, name in ((1, "actor_loss"), (2, "critic_loss"), (3, "entropy_loss")):
         np.testing.assert_allclose(s1[:n_upd, j], s_dp[:n_upd, j], rtol=2e-5, atol=1e-6, err_msg=name)
     np.testing.assert_allclose(s1[:n_upd, 4], np.maximum(r0["stats"][:n_upd, 4], r1["stats"][:n_upd, 4]), rtol=1e-5)  # max_ratio
