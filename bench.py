@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workers", type=int, default=8, help="sync workers per GPU (config: train.num_workers 8)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling of the PPO leg (SURVEY.md 8e): the config's 8 workers and its minibatch of 256 are SPLIT over "
+                                                         "the ranks (W / G workers, B / G rows per rank) instead of replicated per GPU (weak, the default)")
     ap.add_argument("--cpu-baseline-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -68,7 +70,9 @@ def parse():
     ap.add_argument("--rainbow-filled", type=int, default=131072, help="transitions in the buffer before the timed updates")
     ap.add_argument("--no-apex", action="store_true", help="skip the Ape-X (configs[3]) end-to-end leg (rank 0 of a 1-GPU run only)")
     ap.add_argument("--apex-actors", type=int, default=64)
-    ap.add_argument("--apex-updates", type=int, default=1200, help="learner iterations of the Ape-X leg (~2 s at ~600 updates/s)")
+    ap.add_argument("--apex-updates", type=int, default=3600, help="learner iterations of the Ape-X leg (>= 3 s at ~1000 updates/s)")
+    ap.add_argument("--apex-buffer", type=int, default=2_000_000, help="config.ape_x.atari buffer_size")
+    ap.add_argument("--apex-prefill", type=int, default=50_000, help="config.ape_x.atari start_train_step: transitions in the buffer before the first learn()")
     ap.add_argument("--no-hopper", action="store_true", help="skip the PPO Hopper-shaped (configs[4]) leg")
     ap.add_argument("--hopper-iters", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="the timed steps are also reported as this many consecutive chunks (median / min / max)")
@@ -184,7 +188,7 @@ def _kmatch(key, name):
     return key in name
 
 
-def rocprof_avg_us(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
+def rocprof_avg_us(kernel_substr, pattern="r*_bench_kernel_stats.csv"):  # other commands' summaries: pattern="r*_apex_kernel_stats.csv"
     """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command."""
     path = _latest(pattern)
     if path is None:
@@ -329,8 +333,10 @@ def _tool(name):
     return mod
 
 
-def _dominant_mfma(kern, note):
-    """The launch with the most time among those with a flop count (tools report launches / avg_us / TFLOP/s) -> a roofline object."""
+def _dominant_mfma(kern, note, stats_pattern=None, pmc_pattern=None):
+    """The launch with the most time among those with a flop count (tools report launches / avg_us / TFLOP/s) -> a roofline object.
+    stats_pattern / pmc_pattern: committed rocprofv3 summaries of the tool's command under profiles/ (tools/profile_cmd.sh): the same
+    kernel's average duration and HBM traffic per launch from there."""
     best = None
     for k, v in kern.items():
         if "TFLOP/s" in v:
@@ -340,8 +346,13 @@ def _dominant_mfma(kern, note):
     if best is None:
         return None
     _, k, v = best
-    return {"kernel": k, "bound": "mfma", "achieved": v["TFLOP/s"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": v["TFLOP/s"] / MFMA_F32_PEAK_TFLOPS,
-            "avg_us": v["avg_us"], "traffic": None, "note": note}
+    e = {"kernel": k, "bound": "mfma", "achieved": v["TFLOP/s"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": v["TFLOP/s"] / MFMA_F32_PEAK_TFLOPS,
+         "avg_us": v["avg_us"], "traffic": None, "note": note}
+    if stats_pattern:
+        e["rocprof_avg_us"], e["rocprof_summary"] = rocprof_avg_us(k, stats_pattern)
+    if pmc_pattern:
+        e["traffic"] = pmc_traffic(k, pmc_pattern)
+    return e
 
 
 def hopper_leg(rank, world, local_rank, dist, iters):
@@ -359,13 +370,14 @@ def hopper_leg(rank, world, local_rank, dist, iters):
     return r
 
 
-def apex_leg(actors, updates):
+def apex_leg(actors, updates, buffer=2_000_000, prefill=50_000):
     """BASELINE.json configs[3] (config.ape_x.atari pong shapes, `actors` host actors -> 1 learner GPU) end to end in a child process:
     batched acting on the GPU, device-resident frame / n-step feed (frame mode), learner at B = 512 with centered RMSprop, clip 40, PER with
     actor-side priorities (tools/bench_apex.py --e2e).  -> env steps/s, learner updates/s and the dominant learner GEMM's roofline."""
     import subprocess
 
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_apex.py"), "--e2e", str(actors), "--device-feed", "--frames", "--updates", str(updates), "--warmup", "30"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_apex.py"), "--e2e", str(actors), "--device-feed", "--frames", "--updates", str(updates), "--warmup", "30",
+           "--buffer", str(buffer), "--prefill", str(prefill)]
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -378,10 +390,12 @@ def apex_leg(actors, updates):
     kern = {k: dict(v, launches=1) for k, v in r.get("lib_kernels", {}).items()}
     return {"metric": "env steps/s + learner updates/s (Ape-X, config.ape_x.atari shapes, actors -> 1 learner GPU)", "value": e2e.get("env_steps_per_s"), "unit": "env_steps/s",
             "learner_updates_per_s": r.get("learner_updates_per_s"), "sampled_transitions_per_s": r.get("sampled_transitions_per_s"), "ms_per_learn_only": r.get("ms_per_learn_only"),
-            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "timed_s": updates / max(1e-9, r.get("learner_updates_per_s") or 1e-9),
+            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "timed_s": r.get("timed_s"), "prefill": r.get("prefill"),
             "config": {"workload": r.get("workload"), "actors": actors, "path": e2e.get("path"), "weight_sync_every_ticks": e2e.get("weight_sync_every_ticks")},
             "end_to_end": e2e, "learn_in_hipgraph": r.get("learn_in_hipgraph"), "last_result": r.get("last_result"),
-            "roofline": _dominant_mfma(kern, "dominant learner GEMM launch at B = 512 (per-launch averages of tools/bench_apex.py's library event timers)"),
+            "roofline": _dominant_mfma(kern, "dominant learner GEMM launch at B = 512 (achieved: per-launch averages of tools/bench_apex.py's library event timers, live; "
+                                             "rocprof_avg_us / traffic: the committed rocprofv3 summaries of the same command, tools/profile_cmd.sh)",
+                                       "r*_apex_kernel_stats.csv", "r*_apex_pmc.json"),
             "lib_kernels": r.get("lib_kernels")}
 
 
@@ -469,10 +483,14 @@ def main():
     cores = pin_to_gpu_node(local_rank, local_rank=slot, ranks_on_node=n_on_node)
 
     W, T = args.workers, 128
+    batch = 256
+    if args.strong:  # envs and minibatch rows sharded over the ranks, one learner's worth of work in total
+        assert args.workers % world == 0 and batch % world == 0, f"--strong: {args.workers} workers / minibatch {batch} do not split over {world} ranks"
+        W, batch = args.workers // world, batch // world
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)  # identical initial weights on every rank
     agent = Agent("ppo", state_size=4, action_size=2, hidden_size=512, network="discrete_policy_value",
-                  optim_config={"name": "adam", "lr": 2.5e-4}, gamma=0.99, batch_size=256, n_step=T, n_epoch=3, _lambda=0.95,
+                  optim_config={"name": "adam", "lr": 2.5e-4}, gamma=0.99, batch_size=batch, n_step=T, n_epoch=3, _lambda=0.95,
                   epsilon_clip=0.1, vf_coef=1.0, ent_coef=0.01, clip_grad_norm=1.0, use_standardization=True, lr_decay=True,
                   run_step=10_000_000, num_workers=W, device=f"cuda:{local_rank}")
     agent.memory.first_store = False
@@ -551,11 +569,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    n_mb = (W * T + 255) // 256
+    n_mb = (W * T + batch - 1) // batch
     n_updates = 3 * n_mb
     ms_per_step = dt / args.steps * 1e3
     out = {
-        "metric": "env_steps_per_s (PPO CartPole sync, W=8 workers/GPU, T=128)",
+        "metric": f"env_steps_per_s (PPO CartPole sync, W={W} workers/GPU, T=128)",
         "value": world * W * T * args.steps / dt,
         "unit": "env_transitions/s",
         "n_gpus": world,
@@ -563,13 +581,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "config.ppo.cartpole --sync --train.num_workers 8 (BASELINE.json configs[1]): synthetic CartPole-v1, "
-                               "W=8 x T=128 = 1024 transitions/iteration/GPU, MLP 4-512-512-{2,1}, 3 epochs x 4 minibatches of 256",
-                   "workers_per_gpu": W, "n_step": T, "batch_size": 256, "n_epoch": 3, "parallelism": f"dp{world}",
+                               f"W={W} x T=128 = {W * T} transitions/iteration/GPU, MLP 4-512-512-{{2,1}}, 3 epochs x {n_mb} minibatches of {batch}"
+                               + (f" per rank ({args.workers} workers / minibatch 256 split over {world} ranks)" if args.strong else ""),
+                   "workers_per_gpu": W, "n_step": T, "batch_size": batch, "n_epoch": 3, "parallelism": f"dp{world}",
                    "backend": agent.backend, "hipgraph": bool(agent._graph is not None), "collector": type(collector).__name__,
                    "host_cores_per_rank": len(cores) if cores else None},
         "learner_updates_per_s": world * n_updates * args.steps / dt,
@@ -634,7 +653,9 @@ def main():
         rp, src = rocprof_avg_us("jh_act_persist_kernel")
         out["acting"] = {"kernel": "jh_act_persist_kernel", "launches_per_step": 1, "host_us_per_timestep": act_us, "us_per_step": act_us * T,
                          "share_of_step": act_us * T / (ms_per_step * 1e3), "rocprof_avg_us": rp,
-                         "bound": "PCIe round trip per timestep (host env.step between two crossings); in-kernel compute ~1.6 us of it (JH_PERSIST_DEBUG=1)"}
+                         "timesteps_per_exchange": 2 if os.environ.get("JH_COLLECT_LOOKAHEAD", "2") != "1" else 1,
+                         "bound": "PCIe round trip per EXCHANGE (host envs between two crossings); one exchange carries every env's state and both successor states "
+                                  "and serves two timesteps (jh_collect.hip run_loop_lookahead); in-kernel compute ~1.6 us of an exchange (JH_PERSIST_DEBUG=1)"}
     if not args.no_rainbow:
         del collector, env
         out["rainbow"] = rainbow_leg(rank, world, local_rank, dist, args.rainbow_updates, 30, args.rainbow_capacity, args.rainbow_filled,
@@ -642,10 +663,15 @@ def main():
     if not args.no_hopper:
         out["hopper"] = hopper_leg(rank, world, local_rank, dist, args.hopper_iters)
     if rank == 0 and world == 1 and not args.no_apex:
-        out["apex"] = apex_leg(args.apex_actors, args.apex_updates)
+        out["apex"] = apex_leg(args.apex_actors, args.apex_updates, args.apex_buffer, args.apex_prefill)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters, W, T)
     if rank == 0:
+        # the secondary legs' headline numbers once more, compact and LAST on the line: a truncated tail still carries them
+        leg = lambda k, f: (out.get(k) or {}).get(f)
+        out["legs"] = {"ppo_env_transitions_s": out["value"], "ppo_ms_per_step": ms_per_step, "ppo_x_cpu_baseline": (out["value"] / out["cpu_baseline"]["value"]) if out.get("cpu_baseline") else None,
+                       "rainbow_updates_s": leg("rainbow", "value"), "apex_env_steps_s": leg("apex", "value"), "apex_updates_s": leg("apex", "learner_updates_per_s"),
+                       "hopper_transitions_s": leg("hopper", "value")}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -70,11 +70,130 @@ __global__ void __launch_bounds__(256) jh_gae_kernel(int W, int T, float gamma, 
   for (int t = lane; t < T; t += 64) adv[base + t] = (adv[base + t] - mean) * inv;
 }
 
+// Long rows (config.ppo.mujoco: T = 2048): one WORKGROUP of up to 16 waves per row instead of one wave walking T / 64 tiles serially
+// (W = 32, T = 2048 ran on 32 waves of a 256-CU GPU: 46.8 us).  Every wave scans its tiles with the same 6-step shuffle scan,
+// the tiles' aggregates (A_k, B_k) = f_{64k} o ... o f_{64k+63} go to LDS, wave 0 scans THOSE (the maps compose: the same associative
+// operator one level up, <= 128 tiles = two passes of 64), and every element finishes as x = b + a * carry[tile + 1] from registers.
+// E = elements per thread (T <= 1024 E).  Standardisation from registers too: two block reductions, no re-read of adv.
+template <int E>
+__global__ void __launch_bounds__(1024) jh_gae_long_kernel(int T, int nw, float gamma, float lambda, const float* __restrict__ reward,
+                                                           const float* __restrict__ done, const float* __restrict__ value,
+                                                           const float* __restrict__ next_value, float* __restrict__ adv, float* __restrict__ ret,
+                                                           int standardize) {
+  __shared__ float s_A[16 * E], s_B[16 * E], s_carry[16 * E + 1];
+  __shared__ float s_red[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const size_t base = (size_t)blockIdx.x * (size_t)T;
+  const int ntiles = (T + 63) >> 6;
+  float a[E], b[E], v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {  // all loads of the thread in flight first
+    const int k = wid + nw * e, t = k * 64 + lane;
+    a[e] = 1.f; b[e] = 0.f; v[e] = 0.f;
+    if (k < ntiles && t < T) {
+      const float r = reward[base + t], d = done[base + t], vn = next_value[base + t];
+      v[e] = value[base + t];
+      const float nd_g = (1.f - d) * gamma;    // ((1-done)*gamma) first, as in ppo.py:95,99-100
+      b[e] = r + nd_g * vn - v[e];             // delta
+      a[e] = (t == T - 1) ? 0.f : nd_g * lambda;  // no bootstrap across the row end (ppo.py:98)
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float a2 = __shfl_down(a[e], off, 64);
+      const float b2 = __shfl_down(b[e], off, 64);
+      if (lane + off < 64) {
+        b[e] = b[e] + a[e] * b2;
+        a[e] = a[e] * a2;
+      }
+    }
+    const int k = wid + nw * e;
+    if (lane == 0 && k < ntiles) { s_A[k] = a[e]; s_B[k] = b[e]; }
+  }
+  __syncthreads();
+  if (wid == 0) {  // carry[k] = adv at the first element of tile k = (F_k o F_{k+1} o ... o F_last)(0): suffix scan of the tile aggregates
+    float cin = 0.f;
+    for (int h = (ntiles - 1) >> 6; h >= 0; --h) {
+      const int k = h * 64 + lane;
+      float ta = k < ntiles ? s_A[k] : 1.f, tb = k < ntiles ? s_B[k] : 0.f;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float a2 = __shfl_down(ta, off, 64);
+        const float b2 = __shfl_down(tb, off, 64);
+        if (lane + off < 64) {
+          tb = tb + ta * b2;
+          ta = ta * a2;
+        }
+      }
+      const float x = tb + ta * cin;
+      if (k < ntiles) s_carry[k] = x;
+      cin = __shfl(x, 0, 64);
+    }
+    if (lane == 0) s_carry[ntiles] = 0.f;
+  }
+  __syncthreads();
+  float x[E], sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = wid + nw * e, t = k * 64 + lane;
+    x[e] = 0.f;
+    if (k < ntiles && t < T) {
+      x[e] = b[e] + a[e] * s_carry[k + 1];
+      ret[base + t] = x[e] + v[e];  // ppo.py:103
+      sum += x[e];
+    }
+  }
+  if (!standardize) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = wid + nw * e, t = k * 64 + lane;
+      if (k < ntiles && t < T) adv[base + t] = x[e];
+    }
+    return;
+  }
+  // per-row (adv - mean) / (std_unbiased + 1e-7)   ppo.py:105-108
+  const float mean = jh_block_reduce(sum, s_red, JhAdd(), 0.f) / (float)T;
+  float ssq = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = wid + nw * e, t = k * 64 + lane;
+    if (k < ntiles && t < T) {
+      const float c = x[e] - mean;
+      ssq += c * c;
+    }
+  }
+  const float var = jh_block_reduce(ssq, s_red, JhAdd(), 0.f) / (float)(T - 1);
+  const float inv = 1.f / (sqrtf(var) + 1e-7f);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = wid + nw * e, t = k * 64 + lane;
+    if (k < ntiles && t < T) adv[base + t] = (x[e] - mean) * inv;
+  }
+}
+
 JH_EXPORT int jh_gae(jh_ctx* ctx, int32_t W, int32_t T, float gamma, float lambda, const float* d_reward,
                      const float* d_done, const float* d_value, const float* d_next_value, float* d_adv, float* d_ret,
                      int32_t standardize, jh_stream stream) {
   JH_ARG(ctx && d_reward && d_done && d_value && d_next_value && d_adv && d_ret);
   JH_ARG(W > 0 && T > 0);
+  static const int kLongFrom = getenv("JH_GAE_LONG_FROM") ? atoi(getenv("JH_GAE_LONG_FROM")) : 257;  // rows of > 4 tiles: a workgroup per row
+  const int ntiles = (T + 63) / 64;
+  if (T >= kLongFrom && ntiles <= 128) {
+    const int nw = ntiles < 16 ? ntiles : 16;
+    const int e = (ntiles + nw - 1) / nw;
+#define JH_GAE_LONG(E)                                                                                                                          \
+    JH_LAUNCH_NAMED("jh_gae_long_kernel", (jh_gae_long_kernel<E>), dim3(W), dim3(64 * nw), 0, jh_s(stream), T, nw, gamma, lambda, d_reward, d_done, \
+                    d_value, d_next_value, d_adv, d_ret, standardize)
+    if (e <= 1) JH_GAE_LONG(1);
+    else if (e <= 2) JH_GAE_LONG(2);
+    else if (e <= 4) JH_GAE_LONG(4);
+    else JH_GAE_LONG(8);
+#undef JH_GAE_LONG
+    JH_LAUNCH_CHECK();
+    return JH_OK;
+  }
   JH_LAUNCH(jh_gae_kernel, dim3((W + 3) / 4), dim3(256), 0, jh_s(stream), W, T, gamma, lambda, d_reward, d_done,
                      d_value, d_next_value, d_adv, d_ret, standardize);
   JH_LAUNCH_CHECK();

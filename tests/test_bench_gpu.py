@@ -47,3 +47,10 @@ def test_bench_emits_one_contract_json_line():
     ax = d["apex"]
     assert "error" not in ax, ax
     assert "configs[3]" in ax["config"]["workload"] and ax["value"] > 0 and ax["learner_updates_per_s"] > 0 and 0 < ax["roofline"]["frac"] < 1
+    # config.ape_x.atari at its own replay size: buffer_size 2e6, nothing learned before start_train_step = 50000 transitions
+    assert "N=2000000" in ax["config"]["workload"] and ax["prefill"]["transitions"] >= 50000
+    # the headline numbers of every leg once more, LAST on the line (a truncated tail still carries them)
+    assert lines[0].rstrip().endswith("}}") and list(d)[-1] == "legs"
+    lg = d["legs"]
+    assert lg["ppo_env_transitions_s"] == d["value"] and lg["rainbow_updates_s"] == rb["value"] and lg["apex_env_steps_s"] == ax["value"] and lg["hopper_transitions_s"] == hp["value"]
+    assert d["acting"]["timesteps_per_exchange"] == 2

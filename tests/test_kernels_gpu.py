@@ -270,7 +270,8 @@ def test_gae_vs_reference_fixture(ops, name):
     np.testing.assert_allclose(npy(adv), z["gae/adv"], rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("W,T", [(1, 1), (3, 2), (5, 63), (4, 64), (7, 65), (8, 128), (32, 2048), (1000, 130)])
+@pytest.mark.parametrize("W,T", [(1, 1), (3, 2), (5, 63), (4, 64), (7, 65), (8, 128), (32, 2048), (1000, 130),
+                                 (2, 257), (3, 1000), (5, 4097), (2, 8192), (1, 8193), (300, 320)])  # > 256: one workgroup per row (jh_gae_long_kernel); 8193: 129 tiles -> wave per row
 def test_gae_shapes_vs_oracle(ops, O, W, T):
     rng = np.random.RandomState(W * 1000 + T)
     M = W * T

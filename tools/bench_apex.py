@@ -22,7 +22,9 @@ import torch
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--buffer", type=int, default=200000)
+    ap.add_argument("--buffer", type=int, default=2_000_000, help="PER slots (config.ape_x.atari: buffer_size 2e6; frame mode: ~21 GB of de-duplicated 84x84 planes "
+                                                                    "in HBM, plain rows would be 113 GB of uint8 stacks -- both fit the 288 GB)")
+    ap.add_argument("--prefill", type=int, default=50_000, help="transitions in the buffer before the first learn() (config.ape_x.atari: start_train_step 50000)")
     ap.add_argument("--updates", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512)
@@ -41,7 +43,7 @@ def main():
 
     torch.manual_seed(0)
     np.random.seed(0)
-    N, B, n, chunk_rows, filled = args.buffer, args.batch, 3, 100, 16384
+    N, B, n, chunk_rows, filled = args.buffer, args.batch, 3, 100, min(args.prefill, 16384)  # (host-synthesised rows: 115 MB of randint per 2048)
     agent = Agent("ape_x", state_size=[4, 84, 84], action_size=6, hidden_size=512, network="dueling", head="cnn",
                   optim_config={"name": "rmsprop", "eps": 1.5e-7, "lr": 2.5e-4 / 4, "centered": True}, gamma=0.99, buffer_size=N, batch_size=B,
                   clip_grad_norm=40.0, start_train_step=0, target_update_period=2500, run_step=30_000_000, n_step=n, alpha=0.6, beta=0.4,
@@ -173,10 +175,13 @@ def main():
             agent.learn_period_stamp = agent.learn_period
             return agent.process(None, step)
 
-    if args.device_feed:  # the actors fill the empty buffer first (the other modes start from 16384 synthetic rows)
+    if args.device_feed:  # the actors fill the empty buffer up to start_train_step first, the learner only ingests (ape_x.py:150-153)
         t_fill = time.perf_counter()
-        while agent.memory.buffer_counter < 16384 and time.perf_counter() - t_fill < 120:
-            iteration()
+        while agent.memory.buffer_counter < args.prefill and time.perf_counter() - t_fill < 300:
+            agent.num_transitions += agent.memory.drain()
+            time.sleep(0.0005)
+        filled = int(agent.memory.buffer_counter)
+        prefill_s = time.perf_counter() - t_fill
     for _ in range(args.warmup):
         iteration()
     torch.cuda.synchronize()
@@ -228,6 +233,8 @@ def main():
     out = {
         "workload": f"config.ape_x.atari pong-shaped (BASELINE.json configs[3]), synthetic uint8 (4,84,84), A=6, B={B}, n=3, dueling CNN, centered RMSprop, clip 40, "
                     f"PER N={N} ({filled} filled)",
+        "timed_s": dt,
+        "prefill": {"transitions": filled, "seconds": round(prefill_s, 2)} if args.device_feed else {"transitions": filled},
         "learner_updates_per_s": args.updates / dt,
         "sampled_transitions_per_s": B * args.updates / dt,
         "ingested_transitions_per_s": (async_stats or e2e_stats)["ingested_transitions_per_s"] if (async_stats or e2e_stats) else chunk_rows * args.updates / dt,

@@ -40,7 +40,7 @@ def main():
     cases = []
 
     def case(name, kernel, bound, work_per_launch, fn, note=""):
-        if args.only and args.only != name:
+        if args.only and not name.startswith(args.only):
             return
         for _ in range(3):
             fn()
@@ -68,12 +68,12 @@ def main():
         print(json.dumps(row), flush=True)
 
     # ---- GAE: 24 B / transition -------------------------------------------------------------------
-    for W, T in ((8192, 128), (64, 2048), (65536, 128)):
+    for W, T in ((8192, 128), (32, 2048), (64, 2048), (65536, 128)):  # (32, 2048): config.ppo.mujoco's own shape (rows > 256 steps: a workgroup per row)
         M = W * T
         r, v, vn = rnd(M, 1), rnd(M, 1), rnd(M, 1)
         d = (torch.rand(M, 1, device=dev, generator=g) < 0.02).float()
-        case(f"gae_W{W}_T{T}", "jh_gae_kernel", "hbm", 24.0 * M, lambda: ops.gae(r, d, v, vn, T, 0.99, 0.95, False), "24 B/transition, no standardise")
-        case(f"gae_std_W{W}_T{T}", "jh_gae_kernel", "hbm", 36.0 * M, lambda: ops.gae(r, d, v, vn, T, 0.99, 0.95, True), "24 + 12 B/transition (standardise re-reads hit L2)")
+        case(f"gae_W{W}_T{T}", ["jh_gae_kernel", "jh_gae_long_kernel"], "hbm", 24.0 * M, lambda: ops.gae(r, d, v, vn, T, 0.99, 0.95, False), "24 B/transition, no standardise")
+        case(f"gae_std_W{W}_T{T}", ["jh_gae_kernel", "jh_gae_long_kernel"], "hbm", 36.0 * M, lambda: ops.gae(r, d, v, vn, T, 0.99, 0.95, True), "24 + 12 B/transition (standardise re-reads hit L2)")
     # ---- PPO loss: discrete A=2 44 B/sample (+8 B idx); continuous A=3 88 B ---------------------------
     for B in (1 << 20,):
         A = 2
