@@ -320,14 +320,29 @@ __global__ void __launch_bounds__(256) jh_logp_discrete_kernel(int64_t M, int A,
   logp[i] = logf(pi);                            // pi.gather(1, a).log()  ppo.py:92
 }
 
+// The continuous head's per-element terms in DOUBLE.  d(loss)/d(log_std_raw) cancels (z - mu)^2 / (var std) against 1 / std, and
+// (1 - tanh^2) against 1: with the fp32 device transcendentals (1-2 ulp) the head gradient sat 8.5e-6 of its largest entry from the
+// float64 gradient, the reference's own torch-CPU fp32 3.3e-6 (round 4's float64 criterion, tests/test_baseline_width_gpu.py).  The
+// terms are a handful of operations per (row, action dimension) of a latency-bound kernel: evaluating them in double costs nothing
+// measurable and puts the kernel closer to the exact gradient than either fp32 evaluation.
+struct NormalD {
+  double mu, std, z, th, lp;
+};
+__device__ __forceinline__ NormalD normal_terms(float mu_raw, float ls_raw, float act) {
+  NormalD n;
+  n.mu = fmin(fmax((double)mu_raw, -5.0), 5.0);  // policy_value.py:54
+  n.th = tanh((double)ls_raw);
+  n.std = exp(n.th);                              // policy_value.py:55-56
+  const float a = fminf(fmaxf(act, JH_ATANH_LO), JH_ATANH_HI);  // the reference clamps the fp32 action tensor (ppo.py:87)
+  n.z = atanh((double)a);
+  const double dm = n.z - n.mu;
+  n.lp = -(dm * dm) / (2.0 * n.std * n.std) - log(n.std) - 0.91893853320467274178;  // Normal.log_prob
+  return n;
+}
 __device__ __forceinline__ float normal_logp(float mu_raw, float ls_raw, float act, float& mu, float& std, float& z) {
-  mu = fminf(fmaxf(mu_raw, -5.f), 5.f);  // policy_value.py:54
-  std = expf(tanhf(ls_raw));             // policy_value.py:55-56
-  const float a = fminf(fmaxf(act, JH_ATANH_LO), JH_ATANH_HI);
-  z = atanhf(a);
-  const float var = std * std;
-  const float dm = z - mu;
-  return -(dm * dm) / (2.f * var) - logf(std) - JH_HALF_LOG_2PI;  // Normal.log_prob
+  const NormalD n = normal_terms(mu_raw, ls_raw, act);
+  mu = (float)n.mu; std = (float)n.std; z = (float)n.z;
+  return (float)n.lp;
 }
 
 __global__ void __launch_bounds__(256) jh_logp_continuous_kernel(int64_t MA, const float* __restrict__ mu_raw,
@@ -454,16 +469,16 @@ __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, const
     rc = row_common(logp - a.logp_old[r], adv, v, vold, ret, a.eps);
     minp_row = expf(logp);
   } else {
-    float lsum = 0.f, ent = 0.f, minp = 3.4e38f;
+    double lsum = 0.0, ent = 0.0;
+    float minp = 3.4e38f;
     for (int k = 0; k < a.A; ++k) {
-      float mu, std, z;
-      const float lp = normal_logp(z0[k], z1[k], a.action[r * a.A + k], mu, std, z);
-      lsum += lp - a.logp_old[r * a.A + k];
-      ent += 0.5f + JH_HALF_LOG_2PI + logf(std);  // Normal.entropy
-      minp = fminf(minp, expf(lp));
+      const NormalD n = normal_terms(z0[k], z1[k], a.action[r * a.A + k]);
+      lsum += n.lp - (double)a.logp_old[r * a.A + k];
+      ent += 0.5 + 0.91893853320467274178 + n.th;  // Normal.entropy = 1/2 + log sqrt(2 pi) + log(std), log(std) = tanh(log_std_raw)
+      minp = fminf(minp, (float)exp(n.lp));
     }
-    ent_row = ent;  // summed over dims; the mean is over B*A elements (ppo.py:156)
-    rc = row_common(lsum, adv, v, vold, ret, a.eps);
+    ent_row = (float)ent;  // summed over dims; the mean is over B*A elements (ppo.py:156)
+    rc = row_common((float)lsum, adv, v, vold, ret, a.eps);
     minp_row = minp;
   }
 }
@@ -516,18 +531,17 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
     }
   } else {
     const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
-    const float ce = -a.ent / (float)(a.B * a.A);  // d(ent_coef * -mean(H)) / d log(std)
+    const double ce = -(double)a.ent / (double)(a.B * a.A);  // d(ent_coef * -mean(H)) / d log(std)
+    const double dlp = (double)d_logp;
     for (int k = 0; k < a.A; ++k) {
       const float mr = z0[k], lr = z1[k];
-      float mu, std, z;
-      (void)normal_logp(mr, lr, a.action[r * a.A + k], mu, std, z);
-      const float var = std * std, dm = z - mu;
-      const float d_mu = d_logp * dm / var;
-      float d_std = d_logp * ((dm * dm) / (var * std) - 1.f / std);
-      d_std += ce / std;
-      const float th = tanhf(lr);
-      a.g0[(size_t)i * a.ldg + k] = (mr >= -5.f && mr <= 5.f) ? d_mu : 0.f;
-      a.g1[(size_t)i * a.ldg + k] = d_std * std * (1.f - th * th);
+      const NormalD n = normal_terms(mr, lr, a.action[r * a.A + k]);
+      const double var = n.std * n.std, dm = n.z - n.mu;
+      const double d_mu = dlp * dm / var;
+      // d/d(std): d_logp ((dm^2 - var) / (var std)) + ce / std; then std' = std (1 - th^2) through exp(tanh(.))
+      const double d_std = dlp * ((dm * dm - var) / (var * n.std)) + ce / n.std;
+      a.g0[(size_t)i * a.ldg + k] = (mr >= -5.f && mr <= 5.f) ? (float)d_mu : 0.f;
+      a.g1[(size_t)i * a.ldg + k] = (float)(d_std * n.std * (1.0 - n.th * n.th));
     }
   }
 }

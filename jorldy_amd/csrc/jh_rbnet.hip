@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(1024) jh_rb_conv1_wgrad_kernel(const uint8_t* 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float rs[2] = {0.f, 0.f};
+    double rs[2] = {0.0, 0.0};  // bias gradient = a 200 000-term sum of dY at Ape-X shapes: double running sums cost two adds next to eight MFMAs
     // The walk over (frame b, 4-pixel group pg) is incremental: one division per wave and channel, then adds and two compares per
     // group (P % 4 == 0 and OW >= 4: the host checks).  Addresses as (b, pixel) -> offsets took 370 VALU instructions per round of 5
     // groups next to 40 MFMAs; the kernel ran at the VALU's pace (62 us at B = 512), not the matrix core's.
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(1024) jh_rb_conv1_wgrad_kernel(const uint8_t* 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) s_acc[slice - 1][cw][(i * 4 + j) * 4 + q][lane] = acc[i][j][q];
-        s_acc[slice - 1][cw][32 + i][lane] = rs[i];
+        s_acc[slice - 1][cw][32 + i][lane] = (float)rs[i];
       }
     }
     __syncthreads();
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(1024) jh_rb_conv1_wgrad_kernel(const uint8_t* 
       if (c == 0) {  // bias gradient = sum over this workgroup's pixels of dY
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          float v = rs[i];
+          float v = (float)rs[i];
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
           if (kq == 0) mine[32 * NW + 16 * i + r] = v;

@@ -747,7 +747,7 @@ def test_native_act_continuous_distribution():
         agent.network.log_std.bias.copy_(torch.tensor([-0.5, 0.0, 0.4], device="cuda"))
     obs = np.zeros((64, 11), np.float32)
     zs = []
-    for _ in range(150):
+    for _ in range(600):  # 38 400 samples per dimension: the mean's sampling error is ~0.0075 against atol 0.04
         a = agent.act(obs, training=True)["action"]
         assert a.shape == (64, 3) and a.dtype == np.float32
         zs.append(np.arctanh(np.clip(a.astype(np.float64), -1 + 1e-7, 1 - 1e-7)))

@@ -75,6 +75,36 @@ def _ppo_agent(z, **kw):
 PPO_WIDE = ["ppo_disc_cartpole_h512", "ppo_cont_hopper_real"]
 
 
+def _ppo_head_grads_float64(z, cont, eps, vf, ent, actions, heads=None):
+    """d(loss)/d(raw heads) of minibatch 0 in float64: core/agent/ppo.py:125-165 restated with torch autograd on the CPU, fed the
+    reference's own head values (or `heads`: {name: array}) and upstream quantities from the fixture (test infrastructure: the comparator,
+    not the product)."""
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    hv = lambda k: t(heads[k] if heads is not None else z[f"mb0/head/{k}"])
+    idx = z["mb0/idx"].astype(np.int64)
+    adv, ret, v_old, lp_old = (t(z[f"gae/{k}"])[idx] for k in ("adv", "ret", "value", "log_prob_old"))
+    action = t(actions)[idx]
+    v = hv("v").reshape(-1, 1).requires_grad_(True)
+    if cont:
+        mu_raw, ls_raw = hv("mu_raw").requires_grad_(True), hv("log_std_raw").requires_grad_(True)
+        m = torch.distributions.Normal(torch.clamp(mu_raw, -5.0, 5.0), torch.tanh(ls_raw).exp())  # policy_value.py:52-56
+        log_prob = m.log_prob(torch.atanh(torch.clamp(action, -1 + 1e-7, 1 - 1e-7)))
+        leaves = {"mu_raw": mu_raw, "log_std_raw": ls_raw, "v": v}
+    else:
+        logits = hv("logits").requires_grad_(True)
+        pi = torch.exp(torch.log_softmax(logits, dim=-1))
+        m = torch.distributions.Categorical(pi)
+        log_prob = m.log_prob(action.squeeze(-1).long()).unsqueeze(-1)
+        leaves = {"logits": logits, "v": v}
+    ratio = (log_prob - lp_old).sum(1, keepdim=True).exp()
+    actor = -torch.min(ratio * adv, torch.clamp(ratio, 1 - eps, 1 + eps) * adv).mean()
+    v_clip = v_old + torch.clamp(v - v_old, -eps, eps)
+    critic = torch.max(torch.nn.functional.mse_loss(v, ret), torch.nn.functional.mse_loss(v_clip, ret))
+    loss = actor + vf * critic + ent * (-m.entropy().mean())
+    loss.backward()
+    return {k: x.grad.numpy() for k, x in leaves.items()}
+
+
 @pytest.mark.parametrize("name", PPO_WIDE)
 def test_ppo_first_minibatch_forward_loss_backward(name):
     """Minibatch 0 of the reference's run, step by step through the C ABI: no-grad passes + GAE, the minibatch
@@ -124,9 +154,29 @@ def test_ppo_first_minibatch_forward_loss_backward(name):
     s = npy(stats)
     for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")):
         np.testing.assert_allclose(s[j], z[f"mb0/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
+    # The loss kernel by ITSELF, fed the reference's own head values (the fixture's) -- d(loss)/d(log_std_raw) cancels (z - mu)^2 / (var std)
+    # against 1 / std, so a head value off by 1e-6 (ours vs the reference's forward) moves it by 1e-5 of its largest entry: an input
+    # difference, not the kernel's.  Truth: ppo.py:125-165 re-evaluated with torch autograd in float64 on the same head values; the
+    # reference's fp32 gradient (fixture) is itself 3e-6 from it.  |ours - exact| <= max(1e-5, 2 x |reference - exact|) of the largest entry.
+    exact = _ppo_head_grads_float64(z, cont, eps, vf, ent, cols["action"])
+    st2 = torch.zeros(8, device="cuda")
+    if cont:
+        iso = ops.ppo_loss_continuous(dev(z["mb0/head/mu_raw"]), dev(z["mb0/head/log_std_raw"]), dev(z["mb0/head/v"]), idx, action, adv_r, ret_r, v_r, lp_r, eps, vf, ent, stats=st2)
+        iso = {"mu_raw": iso[0], "log_std_raw": iso[1], "v": iso[2]}
+    else:
+        iso = ops.ppo_loss_discrete(dev(z["mb0/head/logits"]), dev(z["mb0/head/v"]), idx, action, adv_r, ret_r, v_r, lp_r, eps, vf, ent, stats=st2)
+        iso = {"logits": iso[0], "v": iso[1]}
+    for tag, g in iso.items():
+        ref, ex = z[f"mb0/head/d_{tag}"], exact[tag]
+        scale = float(np.abs(ex).max())
+        e_ref = float(np.abs(ref.reshape(ex.shape) - ex).max()) / scale
+        margins.leq(float(np.abs(npy(g).reshape(ex.shape) - ex).max()) / scale, max(1e-5, 2.0 * e_ref), f"loss kernel alone: d(loss)/d({tag}) vs float64 (reference's own fp32: {e_ref:.2e})")
+    # ... and inside the pipeline, where its inputs are OUR forward's heads: against the float64 gradient AT THOSE heads
+    ours_heads = {"mu_raw": npy(mu), "log_std_raw": npy(ls), "v": npy(vp)} if cont else {"logits": npy(zz), "v": npy(vp)}
+    exact_ours = _ppo_head_grads_float64(z, cont, eps, vf, ent, cols["action"], heads=ours_heads)
     for tag, g in heads.items():
-        ref = z[f"mb0/head/d_{tag}"]
-        margins.leq(float(np.abs(npy(g) - ref).max()), 1e-5 * float(np.abs(ref).max()), tag)
+        ex = exact_ours[tag]
+        margins.leq(float(np.abs(npy(g).reshape(ex.shape) - ex).max()) / float(np.abs(ex).max()), 1e-5, f"pipeline: d(loss)/d({tag}) vs float64 at our own heads")
     grads = {k: npy(p.grad) for k, p in agent.network.named_parameters()}
     worst = _thin_cmp(grads, z, "mb0/grad_raw/", scale_of=lambda k: z[f"mb0/grad_raw_absmax/{k}"], tol=1e-5, what="d(loss)/d")
     norm = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
