@@ -612,7 +612,8 @@ JH_EXPORT int jh_collector_begin(jh_collector* c, int32_t T, jh_stream stream) {
     return JH_OK;
   }
   r.early = true;
-  c->gate_seq += 1;
+  c->gate_seq = (c->gate_seq + 1) & 0x7fffffffu;  // the top bit marks an aborted run
+  if (c->gate_seq == 0) c->gate_seq = 1;
   const auto tc = std::chrono::steady_clock::now();
   rc = run_commit(c, r, JH_OK, c->gate_d, c->gate_seq, jh_s(stream));
   c->t_commit += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
@@ -629,7 +630,11 @@ JH_EXPORT int jh_collector_loop(jh_collector* c, int32_t training, jh_stream str
   if (!r.active) return jh_fail(JH_ERR_STATE, "jh_collector_loop without jh_collector_begin");
   int rc = run_loop(c, training, jh_s(stream));
   if (r.early) {
-    __atomic_store_n(c->gate_h, c->gate_seq, __ATOMIC_RELEASE);  // every row, captured value and ride-along source is written: let the commit launch go
+    // every row, captured value and ride-along source is written: let the commit launch go.  After an ERROR the staging rows are half
+    // filled: the abort value makes the launch copy nothing.  The learner's launches that the caller enqueued behind it still
+    // run -- on whatever the store held before -- so the agent's weights are NOT trustworthy after this error; the caller must treat the
+    // run as failed (the Python collectors raise).
+    __atomic_store_n(c->gate_h, rc == JH_OK ? c->gate_seq : (c->gate_seq | 0x80000000u), __ATOMIC_RELEASE);
   } else {
     const auto tc = std::chrono::steady_clock::now();
     rc = run_commit(c, r, rc, nullptr, 0, jh_s(stream));

@@ -65,17 +65,21 @@ __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
     // A launch enqueued BEFORE its sources are complete (jh_collector_begin): lane 0 polls the host's release store (bounded: ~2 s;
     // the launch sits behind the acting kernel in stream order, so in practice the flag arrives within a microsecond or two), then
     // the sources -- fine-grained host memory, never cached on the device -- are read.
+    // The host ABORTS a run by storing gate_val | 0x80000000 (jh_collector_loop after an error: half-filled staging rows must not reach
+    // the store): the launch then copies nothing.  On a timeout nothing is copied either; the stream drains, the host reports the failed run.
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
       int ok = 0;
       for (long spin = 0; spin < 4000000L; ++spin) {
-        if (__hip_atomic_load(a.gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == a.gate_val) { ok = 1; break; }
+        const unsigned v = __hip_atomic_load(a.gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == a.gate_val) { ok = 1; break; }
+        if (v == (a.gate_val | 0x80000000u)) break;
         __builtin_amdgcn_s_sleep(8);
       }
       s_ok = ok;
     }
     __syncthreads();
-    (void)s_ok;  // on a timeout the copy still runs (the stream must drain); the host reports the failed run
+    if (!s_ok) return;
   }
   const int c = blockIdx.y;
   const char* src = a.src[c];

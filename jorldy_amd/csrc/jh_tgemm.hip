@@ -714,7 +714,7 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
 struct jh_tgemm_ws_holder {
   TGemmWorkspace w;
 };
-static thread_local jh_tgemm_ws_holder g_dense_ws;
+static thread_local jh_tgemm_ws_holder g_dense_ws[16];  // per calling thread AND per device (one process-global workspace served every device)
 
 JH_EXPORT int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* d_a, int32_t lda, int32_t a_kcont, const float* d_b, int32_t ldb,
                              int32_t b_kcont, float* d_c, int32_t ldc, int32_t epi, const float* d_bias, const float* d_aux, int32_t ldaux, float* d_rowsum,
@@ -724,7 +724,8 @@ JH_EXPORT int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const
   JH_ARG((epi != 1 && epi != 2) || d_bias);
   JH_ARG(epi != 3 || d_aux);
   JH_HIP(hipSetDevice(ctx->device));
-  TGemmWorkspace& w = g_dense_ws.w;
+  JH_ARG(ctx->device >= 0 && ctx->device < 16);
+  TGemmWorkspace& w = g_dense_ws[ctx->device].w;
   if (!w.ws) {  // one lazily created workspace per calling thread (split-K partials + arrival counters)
     w.ws_floats = (size_t)4 << 20;
     w.cnt_slots = 4096;
@@ -743,7 +744,8 @@ JH_EXPORT int jh_tgemm_dense_group(jh_ctx* ctx, int32_t n, int32_t M, int32_t N,
                                    jh_stream stream) {
   JH_ARG(ctx && d_a && d_b && d_c && n >= 1 && n <= kMaxGroup && M > 0 && N > 0 && K > 0);
   JH_HIP(hipSetDevice(ctx->device));
-  TGemmWorkspace& w = g_dense_ws.w;
+  JH_ARG(ctx->device >= 0 && ctx->device < 16);
+  TGemmWorkspace& w = g_dense_ws[ctx->device].w;
   if (!w.ws) {
     w.ws_floats = (size_t)4 << 20;
     w.cnt_slots = 4096;

@@ -35,6 +35,12 @@ def _global_mt():
         return None
 
 
+def _lock():
+    """numpy serialises every draw of the global generator with this lock; taking it around our raw reads / writes of the MT19937 state
+    keeps another thread's np.random call from running in the middle of them."""
+    return np.random.mtrand._rand._bit_generator.lock
+
+
 def _fn_ptrs(ct):
     return C.cast(ct.next_uint32, C.c_void_p), C.cast(ct.next_uint64, C.c_void_p)
 
@@ -53,7 +59,8 @@ def epoch_shuffles(M, n_epoch, out):
         return out
     ct, addr = g
     f32, f64 = _fn_ptrs(ct)
-    L.check(L.load().jh_np_legacy_shuffles(C.c_void_p(addr), f32, f64, int(M), int(n_epoch), C.c_void_p(flat.ctypes.data)))
+    with _lock():
+        L.check(L.load().jh_np_legacy_shuffles(C.c_void_p(addr), f32, f64, int(M), int(n_epoch), C.c_void_p(flat.ctypes.data)))
     return out
 
 
@@ -73,7 +80,8 @@ class Predraw:
         if g is None:
             return False
         ct, addr = g
-        self._s0 = C.string_at(addr, _MT_BYTES)
+        with _lock():
+            self._s0 = C.string_at(addr, _MT_BYTES)
         C.memmove(self._scratch, self._s0, _MT_BYTES)
         f32, f64 = _fn_ptrs(ct)
         flat = out.reshape(-1)
@@ -92,7 +100,8 @@ class Predraw:
         if g is None:
             return False
         _, addr = g
-        if C.string_at(addr, _MT_BYTES) != self._s0:
-            return False
-        C.memmove(addr, self._s1, _MT_BYTES)
+        with _lock():  # compare and install atomically with respect to other threads' draws
+            if C.string_at(addr, _MT_BYTES) != self._s0:
+                return False
+            C.memmove(addr, self._s1, _MT_BYTES)
         return True
