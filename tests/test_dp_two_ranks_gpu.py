@@ -174,19 +174,29 @@ def test_rainbow_native_two_ranks_identical_weights_and_single_tree_is_weights(t
     assert np.all(np.isfinite(r0["losses"])) and np.all(np.isfinite(r1["losses"]))
 
 
-def test_bench_two_ranks_on_one_gpu_plumbing(tmp_path):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), backend gloo so that both
-    ranks may share cuda:0: launch, per-rank pinning, attach_data_parallel, barrier + max-over-ranks timing, one JSON line."""
+@pytest.mark.parametrize("launcher,strong", [("torchrun", False), ("self", True)])
+def test_bench_two_ranks_on_one_gpu_plumbing(tmp_path, launcher, strong):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank) AND launching itself (`python bench.py
+    --gpus 2` with no RANK in the environment: VERDICT r3 #4), backend gloo so that both ranks may share cuda:0: launch, per-rank pinning,
+    attach_data_parallel (exact critic: two collectives per minibatch), barrier + max-over-ranks timing, one JSON line.  strong: the config's
+    8 workers and minibatch of 256 split over the ranks (4 workers, 128 rows each)."""
     import json
 
     env = dict(os.environ, JH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-rainbow", "--no-roofline", "--no-cpu-baseline", "--hopper-iters", "1"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-rainbow", "--no-roofline", "--no-cpu-baseline", "--hopper-iters", "1"] + (["--strong"] if strong else [])
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["parallelism"] == "dp2"
-    assert out["value"] > 0 and np.isfinite(out["last_result"]["critic_loss"])
+    assert out["scaling"] == ("strong" if strong else "weak") and out["config"]["workers_per_gpu"] == (4 if strong else 8) and out["config"]["batch_size"] == (128 if strong else 256)
+    assert out["value"] > 0 and np.isfinite(out["last_result"]["critic_loss"]) and list(out)[-1] == "legs"
     hp = out["hopper"]  # configs[4] strong-scaled over the two ranks: 16 workers and 1024 minibatch rows each, collector + DP learners
     assert hp["n_gpus"] == 2 and hp["config"]["workers_per_gpu"] == 16 and hp["config"]["batch_per_gpu"] == 1024 and hp["value"] > 0
