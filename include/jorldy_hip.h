@@ -462,6 +462,15 @@ int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int32_t x_dtyp
  * NULL) -> d_logits [3][B][A][K] = online(state), online(next_state), target(next_state)                */
 int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits,
                            jh_stream stream);
+/* jh_rbnet_learn_forward in two halves + the part that does not depend on the batch (rainbow.py:160-186: the three forwards of learn()):
+ *   jh_rbnet_prepare_noise  W = mu + sig * eps of the three noisy weight sets (network/utils.py:55-86) for the draw d_noise [3][noise_len]
+ *                           -- may run on another stream while the trunk runs (a 12-us launch off the critical path)
+ *   jh_rbnet_learn_trunk    head + l of [state; next_state] (online) and next_state (target)
+ *   jh_rbnet_learn_heads    the noisy dueling heads of the three forwards -> d_logits [3][B][A][K]; uses the prepared sets when
+ *                           jh_rbnet_prepare_noise ran for the same d_noise, else materialises them itself                          */
+int jh_rbnet_prepare_noise(jh_rbnet* n, const float* d_noise, jh_stream stream);
+int jh_rbnet_learn_trunk(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, jh_stream stream);
+int jh_rbnet_learn_heads(jh_rbnet* n, int32_t B, const float* d_noise, float* d_logits, jh_stream stream);
 /* loss.backward() given d(loss)/d(online(state) output) [B][A][K] (from jh_c51_loss / jh_td_loss); fills d_grads */
 int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream);
 /* [clip_grad_norm_(max_norm) when max_norm > 0 (ape_x.py:128),] optimizer.step(): optimizer 0 torch.optim.Adam,

@@ -119,6 +119,9 @@ _PROTOS = {
     "jh_rbnet_sync_target": (C.c_int, [_vp, _vp]),
     "jh_rbnet_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "jh_rbnet_learn_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "jh_rbnet_prepare_noise": (C.c_int, [_vp, _vp, _vp]),
+    "jh_rbnet_learn_trunk": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "jh_rbnet_learn_heads": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "jh_rbnet_backward": (C.c_int, [_vp, _vp, _vp]),
     "jh_rbnet_adam_step": (C.c_int, [_vp, _vp]),
     "jh_tgemm_dense": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),

@@ -65,6 +65,12 @@ class DQN(NativeValueNetMixin, BaseAgent):
         self._graph = None
         self._warm = False
         self._noise = None
+        # JH_LEARN_OVERLAP=1 (opt-in, measured SLOWER): learn() as a graph with BRANCHES -- work that nothing on the critical path waits for on
+        # a side stream forked from / joined to the learner's stream inside the captured body: the PER priority write-back (per_delta + tree
+        # climb: 25 us at B = 32, 45 us at B = 512) next to the backward pass + optimizer, Rainbow's noisy weight sets (17 us) next to the
+        # trunk.  On this stack a fork / join inside a hipGraph costs more than the 42 us it hides: Rainbow 2 969 -> 2 655 updates/s, Ape-X
+        # 988 -> 967 (two alternating pairs each, round 4).  Default: one stream, one chain.
+        self._overlap = os.environ.get("JH_LEARN_OVERLAP", "0") == "1"
 
     @torch.no_grad()
     def act(self, state, training=True):
@@ -95,6 +101,26 @@ class DQN(NativeValueNetMixin, BaseAgent):
     def _idx_offset(self):
         return 0
 
+    def _fork(self):
+        """(main, side): the side stream, made to wait for everything enqueued on the current stream so far (the fork of a graph branch)."""
+        main = torch.cuda.current_stream()
+        side = self.__dict__.get("_side_stream")
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.device)
+        side.wait_stream(main)
+        return main, side
+
+    def _write_back_priorities(self, st, prio):
+        """per.py:67-70 without the B `.item()` syncs; on a side branch when overlapping: nothing before the next sample reads the tree.
+        -> the side stream to join at the end of the body, or None."""
+        if not self._overlap:
+            self.memory.update_priorities(st["idx"], prio)
+            return None
+        main, side = self._fork()
+        with torch.cuda.stream(side):
+            self.memory.update_priorities(st["idx"], prio)
+        return side
+
     def _learn_body(self, st):
         net, B, A = self._net, self.batch_size, self.action_size
         tr = self.memory.gather(st["idx"], idx_offset=self._idx_offset(), as_float=self._as_float(), out=st["tr"])
@@ -103,12 +129,13 @@ class DQN(NativeValueNetMixin, BaseAgent):
         g, prio, _ = ops.td_loss(q, next_target_q, tr["action"], tr["reward"], tr["done"], self.gamma, q_next_online=next_q if self._td["double"] else None,
                                  weights=st["w"] if self._td["per"] else None, alpha=getattr(self, "alpha", 0.0),
                                  n_step=self._td["n_step"] and self.n_step, stats=self._stats)
-        if self._td["per"]:
-            self.memory.update_priorities(st["idx"], prio)  # per.py:67-70 without the B `.item()` syncs
+        side = self._write_back_priorities(st, prio) if self._td["per"] else None
         net.backward(g)
         if self.grad_sync is not None:  # data-parallel learners: one all-reduce of the flat gradient bucket
             self.grad_sync.reduce_flat(net.grads)
         net.optim_step(self._opt_name, self.clip_grad_norm)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)  # join: the next sample / store sees the updated tree
 
     def _run_learn(self):
         """Sample on the host (eager), then run the body: eagerly the first time, captured into a hipGraph the second time,

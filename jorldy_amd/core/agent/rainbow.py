@@ -78,6 +78,7 @@ class Rainbow(DQN):
         self.grad_sync = None  # data-parallel hook (jorldy_amd.parallel.attach_data_parallel)
         self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
         self._static, self._graph, self._warm, self.clip_grad_norm = None, None, False, None
+        self._overlap = os.environ.get("JH_LEARN_OVERLAP", "0") == "1"  # opt-in graph branches (dqn.py: measured slower): noise sets || trunk, PER write-back || backward
         self._td = dict(double=True, per=True, n_step=1)
         self.action_size = action_size
         self.action_type = "discrete"
@@ -136,24 +137,40 @@ class Rainbow(DQN):
         return self.memory.first_leaf_index
 
     # ---- plumbing: native_net.NativeValueNetMixin via DQN -------------------
-    def _learn_body(self, st):
-        net, B = self._net, self.batch_size
-        tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, as_float=self._as_float(), out=st["tr"])
+    def _draw_noise(self, st):
+        """Three independent draws: network(s), network(s'), target_network(s') (rainbow.py:160-186) -> st["noise"]."""
         if self._noise is None:
             if getattr(self, "_normal", None) is None:
                 self._normal = ops.NormalSource(self.device)
-            self._normal.fill(st["noise"])  # three independent draws: network(s), network(s'), target_network(s') (rainbow.py:160-186)
+            self._normal.fill(st["noise"])
         elif self._noise != "static":  # "static": the test wrote the draws into st["noise"] itself (replayable: nothing to do here)
             for i in range(3):
                 self.network.pack_noise(self._noise[i], st["noise"][i])
-        lg = net.learn_forward(st["x_all"], B, st["noise"], st["logits"])
+
+    def _learn_body(self, st):
+        net, B = self._net, self.batch_size
+        if self._overlap:
+            # branch 1: the noise draw and the three noisy weight sets (normal fill 5 us + a 12-us launch) beside gather + trunk
+            main, side = self._fork()
+            with torch.cuda.stream(side):
+                self._draw_noise(st)
+                net.prepare_noise(st["noise"])
+        else:
+            self._draw_noise(st)
+        tr = self.memory.gather(st["idx"], idx_offset=self.memory.first_leaf_index, as_float=self._as_float(), out=st["tr"])
+        net.learn_trunk(st["x_all"], B)
+        if self._overlap:
+            main.wait_stream(side)
+        lg = net.learn_heads(B, st["noise"], st["logits"])
         g, prio, _, _ = ops.c51_loss(lg[0], lg[2], tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max, self.gamma,
                                      next_logit_online=lg[1], weights=st["w"], alpha=self.alpha, n_step=self.n_step, stats=self._stats8)
-        self.memory.update_priorities(st["idx"], prio)  # rainbow.py:230-231
+        side = self._write_back_priorities(st, prio)  # rainbow.py:230-231; branch 2: beside the backward pass + optimizer
         net.backward(g)
         if self.grad_sync is not None:  # data-parallel learners: one all-reduce of the flat gradient bucket
             self.grad_sync.reduce_flat(net.grads)
         net.optim_step(self._opt_name, self.clip_grad_norm)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def _resume_extra_attrs(self):
         """The learner's noise stream (ops.NormalSource: seed + call counter in device memory): without it a resumed run would

@@ -549,6 +549,7 @@ struct jh_rbnet {
   const void* last_x = nullptr;  // input of the last learn_forward (backward of layer 1 reads it again)
   int last_x_u8 = 0, last_B = 0;
   const float* last_noise = nullptr;
+  const float* prepared_noise = nullptr;  // jh_rbnet_prepare_noise materialised the three learn() weight sets for this draw already
   std::vector<void*> owned;
 };
 
@@ -868,7 +869,9 @@ struct HeadJob {
 static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t st) {
   const int H = n->hidden, NA = n->NA, K = n->K, in1 = n->in1;
   const NoisyDims& d = n->nd;
-  if (n->noisy) {
+  const bool prepared = n->noisy && nj == 3 && n->prepared_noise != nullptr && n->prepared_noise == jobs[0].noise;
+  n->prepared_noise = nullptr;
+  if (n->noisy && !prepared) {
     NoiseSets ns{};
     ns.n_sets = nj;
     for (int j = 0; j < nj; ++j) {
@@ -932,18 +935,45 @@ JH_EXPORT int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int3
 //   d_x = [state (B rows); next_state (B rows)]  (one contiguous batch of 2B observations)
 //   logits[0] = online(state; noise 0)   logits[1] = online(next_state; noise 1)   logits[2] = target(next_state; noise 2)
 // The online trunk runs once over all 2B rows; the target trunk shares the launches (grouped GEMMs).
-JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
-  JH_ARG(n && d_x && d_logits);
-  JH_ARG(d_noise || !n->noisy);
+// The two halves separately, so that a caller can run what does not depend on the batch on ANOTHER stream meanwhile (round 4: the
+// NoisyNet weight sets W = mu + sig * eps of the three forwards only need the noise draw; materialising them costs a 12-us launch that
+// used to sit in front of the trunk): jh_rbnet_prepare_noise (any stream) || jh_rbnet_learn_trunk; join; jh_rbnet_learn_heads.
+JH_EXPORT int jh_rbnet_prepare_noise(jh_rbnet* n, const float* d_noise, jh_stream stream) {
+  JH_ARG(n != nullptr);
+  if (!n->noisy) return JH_OK;
+  JH_ARG(d_noise != nullptr);
+  const NoisyDims& d = n->nd;
+  const int64_t L = d.noise_len;
+  NoiseSets ns{};
+  ns.n_sets = 3;
+  const float* P[3] = {n->params, n->params, n->target};
+  for (int j = 0; j < 3; ++j) { ns.params[j] = P[j]; ns.noise[j] = d_noise + j * L; ns.weff[j] = n->weff + (size_t)j * d.set_stride; }
+  int64_t blocks = (n->n_noisy + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  JH_LAUNCH(jh_rb_noise_kernel, dim3((unsigned)blocks, 3), dim3(256), 0, jh_s(stream), d, ns, n->n_noisy);
+  JH_LAUNCH_CHECK();
+  n->prepared_noise = d_noise;
+  return JH_OK;
+}
+
+JH_EXPORT int jh_rbnet_learn_trunk(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, jh_stream stream) {
+  JH_ARG(n && d_x);
   JH_ARG(B > 0 && B <= n->maxB);
   JH_ARG(x_dtype == JH_U8 || x_dtype == JH_F32);
-  hipStream_t st = jh_s(stream);
   const size_t row_elems = n->cnn ? (size_t)n->Cin * n->Hin * n->Win : (size_t)n->Cin;
   const size_t esz = x_dtype == JH_U8 ? 1 : 4;
   const void* x_next = (const char*)d_x + (size_t)B * row_elems * esz;
   TrunkJob tj[2] = {{n->params, d_x, 2 * B, 0}, {n->target, x_next, B, 1}};
-  int rc = rb_trunk(n, tj, 2, x_dtype == JH_U8, st);
+  int rc = rb_trunk(n, tj, 2, x_dtype == JH_U8, jh_s(stream));
   if (rc) return rc;
+  n->last_x = d_x; n->last_x_u8 = x_dtype == JH_U8; n->last_B = B;
+  return JH_OK;
+}
+
+JH_EXPORT int jh_rbnet_learn_heads(jh_rbnet* n, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
+  JH_ARG(n && d_logits);
+  JH_ARG(d_noise || !n->noisy);
+  JH_ARG(B > 0 && B == n->last_B);
   const int64_t L = n->noisy ? n->nd.noise_len : 0;
   const size_t lsz = (size_t)B * n->NA;
   const float* nz = n->noisy ? d_noise : nullptr;
@@ -951,10 +981,18 @@ JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dty
   HeadJob hj[3] = {{n->params, nz, sin[0], d_logits},
                    {n->params, nz ? nz + L : nullptr, sin[0] + (size_t)B * n->in1, d_logits + lsz},
                    {n->target, nz ? nz + 2 * L : nullptr, sin[1], d_logits + 2 * lsz}};
-  rc = rb_heads(n, hj, 3, B, st);
+  int rc = rb_heads(n, hj, 3, B, jh_s(stream));
   if (rc) return rc;
-  n->last_x = d_x; n->last_x_u8 = x_dtype == JH_U8; n->last_B = B; n->last_noise = d_noise;
+  n->last_noise = d_noise;
   return JH_OK;
+}
+
+JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
+  JH_ARG(n && d_x && d_logits);
+  JH_ARG(d_noise || !n->noisy);
+  int rc = jh_rbnet_learn_trunk(n, d_x, x_dtype, B, stream);
+  if (rc) return rc;
+  return jh_rbnet_learn_heads(n, B, d_noise, d_logits, stream);
 }
 
 // Backward of logits[0] of the last jh_rbnet_learn_forward: d_g = d(loss)/d(logits) [B][A][K]; fills the

@@ -953,6 +953,19 @@ class RainbowNet:
         L.check(self.lib.jh_rbnet_learn_forward(self.h, L.ptr(x_all), self._xdt(x_all), int(B), L.ptr(noise), L.ptr(out), L.stream_ptr()))
         return out
 
+    def prepare_noise(self, noise):
+        """The three noisy weight sets of learn()'s forwards for the draw `noise` [3, noise_len], on the CURRENT stream (may be a side stream)."""
+        L.check(self.lib.jh_rbnet_prepare_noise(self.h, L.ptr(noise), L.stream_ptr()))
+
+    def learn_trunk(self, x_all, B):
+        assert x_all.is_contiguous() and int(x_all.shape[0]) == 2 * B
+        L.check(self.lib.jh_rbnet_learn_trunk(self.h, L.ptr(x_all), self._xdt(x_all), int(B), L.stream_ptr()))
+
+    def learn_heads(self, B, noise, out):
+        assert (noise is None or noise.is_contiguous()) and out.is_contiguous()
+        L.check(self.lib.jh_rbnet_learn_heads(self.h, int(B), L.ptr(noise), L.ptr(out), L.stream_ptr()))
+        return out
+
     def backward(self, g):
         assert g.is_contiguous() and g.dtype == torch.float32
         L.check(self.lib.jh_rbnet_backward(self.h, L.ptr(g), L.stream_ptr()))
