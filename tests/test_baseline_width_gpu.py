@@ -459,6 +459,12 @@ def test_td_learn_at_baseline_shapes(fixture, agent_name, use_graph):
     # updated weights: both optimizers normalise the step (Adam: lr * sign-ish; centered RMSprop's first step: lr * g / (|g| sqrt(.0099) + eps)
     # ~ 10.05 lr), so a weight with a ~0 gradient may land a step apart: 99.5 % within 5 % of a step, none beyond the possible travel
     lr = float(h("optim_lr"))
+    # ... and the step itself as ARITHMETIC (the statistical criterion below would not notice an eps or a bias correction
+    # that is a few per cent off): float64 torch.optim from the fixture's w0 and zero state, fed our (clipped) gradient, must land on our weights
+    import fp64_truth as T64
+
+    clipped = {k: v for k, v in agent._net.export_state(agent._net.grads).items()}
+    T64.check_first_step_from_our_gradient(w0, clipped, agent.network.state_dict(), lambda ps: Optimizer(**oc, params=ps), lr, f"{fixture} first step")
     travel = lr * (1.0 if oc["name"] == "adam" else 10.06)
     tot = bad = 0
     for k, v in agent.network.state_dict().items():
