@@ -370,27 +370,47 @@ struct HeadPtrs {
   int groups;
 };
 
-// forward: one wave per row; lanes split H, one shuffle reduction per output
+// forward: one wave per row; lanes split H.  All (<= 8) outputs' lane-partial dot products first, then their shuffle reductions
+// INTERLEAVED (the same tree per output as one reduction after the other: identical bits; seven dependent 6-step chains one after the
+// other were most of the kernel's 9-11 us at B = 2048)
 __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, const float* __restrict__ h2, HeadPtrs hp) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const float* hr = h2 + (size_t)b * H;
-  for (int g = 0; g < hp.groups; ++g) {
-    for (int o = 0; o < hp.n[g]; ++o) {
-      const float* w = hp.w[g] + (size_t)o * H;
-      float acc = 0.f;
-      for (int k = lane * 4; k < H; k += 256) {
-        const float4 hv = *reinterpret_cast<const float4*>(hr + k);
-        const float4 wv = *reinterpret_cast<const float4*>(w + k);
-        acc = fmaf(hv.x, wv.x, acc);
-        acc = fmaf(hv.y, wv.y, acc);
-        acc = fmaf(hv.z, wv.z, acc);
-        acc = fmaf(hv.w, wv.w, acc);
-      }
-      acc = jh_wave_sum(acc);
-      if (lane == 0) hp.out[g][(size_t)b * hp.n[g] + o] = acc + hp.b[g][o];
+  const float* wrow[8];
+  float* dst[8];
+  float bias[8];
+  int n_out = 0;
+  for (int g = 0; g < hp.groups; ++g)
+    for (int o = 0; o < hp.n[g] && n_out < 8; ++o, ++n_out) {
+      wrow[n_out] = hp.w[g] + (size_t)o * H;
+      dst[n_out] = hp.out[g] + (size_t)b * hp.n[g] + o;
+      bias[n_out] = hp.b[g][o];
     }
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = lane * 4; k < H; k += 256) {
+    const float4 hv = *reinterpret_cast<const float4*>(hr + k);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      if (o < n_out) {
+        const float4 wv = *reinterpret_cast<const float4*>(wrow[o] + k);
+        acc[o] = fmaf(hv.x, wv.x, acc[o]);
+        acc[o] = fmaf(hv.y, wv.y, acc[o]);
+        acc[o] = fmaf(hv.z, wv.z, acc[o]);
+        acc[o] = fmaf(hv.w, wv.w, acc[o]);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] += __shfl_xor(acc[o], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < n_out) *dst[o] = acc[o] + bias[o];
   }
 }
 
@@ -399,20 +419,25 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, con
 __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, const float* __restrict__ h2,
                                                                   float* __restrict__ dh2, float* __restrict__ g_all,
                                                                   HeadPtrs hp) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)B * H) return;
-  const int b = (int)(i / H), k = (int)(i - (int64_t)b * H);
-  float acc = 0.f;
+  // four consecutive hidden units per thread (H % 4 == 0: 16-byte loads of h2 / the head weight rows, one 16-byte store of dh2);
+  // the sum over the outputs runs in the same order per element as one thread per element did
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int h4 = H >> 2;
+  if (i4 >= (int64_t)B * h4) return;
+  const int b = (int)(i4 / h4), k = 4 * (int)(i4 - (int64_t)b * h4);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float mine[4] = {0.f, 0.f, 0.f, 0.f};
   int o_flat = 0;
-  float mine = 0.f;
   for (int g = 0; g < hp.groups; ++g)
     for (int o = 0; o < hp.n[g]; ++o, ++o_flat) {
       const float gv = hp.g[g][(size_t)b * hp.n[g] + o];
-      acc = fmaf(gv, hp.w[g][(size_t)o * H + k], acc);
-      if (o_flat == k) mine = gv;
+      const float4 w = *reinterpret_cast<const float4*>(hp.w[g] + (size_t)o * H + k);
+      acc[0] = fmaf(gv, w.x, acc[0]); acc[1] = fmaf(gv, w.y, acc[1]); acc[2] = fmaf(gv, w.z, acc[2]); acc[3] = fmaf(gv, w.w, acc[3]);
+      if (o_flat >= k && o_flat < k + 4) mine[o_flat - k] = gv;
     }
-  dh2[i] = h2[i] > 0.f ? acc : 0.f;
-  if (k < 8) g_all[(size_t)b * 8 + k] = mine;  // zero for k >= number of head outputs
+  const float4 hv = *reinterpret_cast<const float4*>(h2 + (size_t)b * H + k);
+  *reinterpret_cast<float4*>(dh2 + (size_t)b * H + k) = make_float4(hv.x > 0.f ? acc[0] : 0.f, hv.y > 0.f ? acc[1] : 0.f, hv.z > 0.f ? acc[2] : 0.f, hv.w > 0.f ? acc[3] : 0.f);
+  if (k < 8) *reinterpret_cast<float4*>(g_all + (size_t)b * 8 + k) = make_float4(mine[0], mine[1], mine[2], mine[3]);  // zero beyond the head outputs
 }
 
 // ============================================================================ clip_grad_norm_ + Adam
@@ -727,17 +752,31 @@ __global__ void __launch_bounds__(256) jh_ppo_dw1_partial_kernel(int B, int H, i
 #pragma unroll
   for (int q = 0; q < NA; ++q) acc[q] = 0.f;
   if (h < H) {
-    for (int r = rl; r < nb; r += 4) {
-      const float g = dh1[(size_t)(b0 + r) * H + h];
-      const float* xr = s_x + (size_t)r * SP;
+    // four of this thread's rows per round, their dh1 / h2 loads issued before the first FMA (one row per round left the thread waiting
+    // for a dependent HBM round trip sixteen times: 14-16 us at B = 2048 for 8 MB of reads); the FMA order per accumulator is unchanged
+    constexpr int RU = 4;
+    for (int r0 = rl; r0 < nb; r0 += 4 * RU) {
+      float g[RU], a2[RU];
 #pragma unroll
-      for (int q = 0; q < SP; ++q) acc[q] = fmaf(g, xr[q], acc[q]);
-      acc[SP] += g;
-      if (heads) {
-        const float a2 = h2[(size_t)(b0 + r) * H + h];
-        const float* gr = s_g + (size_t)r * 8;
+      for (int u = 0; u < RU; ++u) {
+        const int r = r0 + 4 * u;
+        const int rc = r < nb ? r : nb - 1;
+        g[u] = dh1[(size_t)(b0 + rc) * H + h];
+        a2[u] = heads ? h2[(size_t)(b0 + rc) * H + h] : 0.f;
+      }
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc[SP + 1 + o] = fmaf(a2, gr[o], acc[SP + 1 + o]);
+      for (int u = 0; u < RU; ++u) {
+        const int r = r0 + 4 * u;
+        if (r >= nb) break;
+        const float* xr = s_x + (size_t)r * SP;
+#pragma unroll
+        for (int q = 0; q < SP; ++q) acc[q] = fmaf(g[u], xr[q], acc[q]);
+        acc[SP] += g[u];
+        if (heads) {
+          const float* gr = s_g + (size_t)r * 8;
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc[SP + 1 + o] = fmaf(a2[u], gr[o], acc[SP + 1 + o]);
+        }
       }
     }
   }
@@ -905,7 +944,7 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
   const int H = n->H, S = n->S;
   const int64_t bh = (int64_t)B * H;
   HeadPtrs hp = head_ptrs(n, nullptr, nullptr, nullptr, d_g_head0, d_g_head1, d_g_value);
-  JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
+  JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh / 4 + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
             n->g_all, hp);
   JH_LAUNCH_CHECK();
   const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];

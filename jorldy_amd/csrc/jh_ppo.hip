@@ -275,8 +275,13 @@ struct RowFwd {
 };
 
 // ---- discrete head -----------------------------------------------------------------------------
+struct NormalD {
+  double mu, std, z, th, lp;
+};
+constexpr int kContCache = 4;  // action dimensions whose double-precision terms the forward half of a row hands to its backward half
 struct DiscRow {
   float m, lse, s;  // row max, log-sum-exp of (z-m), sum of p (re-normalisation by Categorical)
+  NormalD n[kContCache];  // continuous policies only (dead code for discrete ones)
 };
 
 __device__ __forceinline__ DiscRow disc_prepare(const float* __restrict__ z, int A) {
@@ -325,9 +330,6 @@ __global__ void __launch_bounds__(256) jh_logp_discrete_kernel(int64_t M, int A,
 // float64 gradient, the reference's own torch-CPU fp32 3.3e-6 (round 4's float64 criterion, tests/test_baseline_width_gpu.py).  The
 // terms are a handful of operations per (row, action dimension) of a latency-bound kernel: evaluating them in double costs nothing
 // measurable and puts the kernel closer to the exact gradient than either fp32 evaluation.
-struct NormalD {
-  double mu, std, z, th, lp;
-};
 __device__ __forceinline__ NormalD normal_terms(float mu_raw, float ls_raw, float act) {
   NormalD n;
   n.mu = fmin(fmax((double)mu_raw, -5.0), 5.0);  // policy_value.py:54
@@ -473,6 +475,7 @@ __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, const
     float minp = 3.4e38f;
     for (int k = 0; k < a.A; ++k) {
       const NormalD n = normal_terms(z0[k], z1[k], a.action[r * a.A + k]);
+      if (k < kContCache) dr.n[k] = n;
       lsum += n.lp - (double)a.logp_old[r * a.A + k];
       ent += 0.5 + 0.91893853320467274178 + n.th;  // Normal.entropy = 1/2 + log sqrt(2 pi) + log(std), log(std) = tanh(log_std_raw)
       minp = fminf(minp, (float)exp(n.lp));
@@ -535,7 +538,7 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
     const double dlp = (double)d_logp;
     for (int k = 0; k < a.A; ++k) {
       const float mr = z0[k], lr = z1[k];
-      const NormalD n = normal_terms(mr, lr, a.action[r * a.A + k]);
+      const NormalD n = k < kContCache ? dr.n[k] : normal_terms(mr, lr, a.action[r * a.A + k]);  // (the forward half evaluated them: ~10 double transcendentals per dimension)
       const double var = n.std * n.std, dm = n.z - n.mu;
       const double d_mu = dlp * dm / var;
       // d/d(std): d_logp ((dm^2 - var) / (var std)) + ce / std; then std' = std (1 - th^2) through exp(tanh(.))
