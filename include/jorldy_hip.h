@@ -49,6 +49,10 @@ typedef void* jh_stream;
 
 /* ------------------------------------------------------------------ library / context */
 int jh_abi_version(void);
+/* End a stream capture that was invalidated and abandoned by its owner (hipStreamEndCapture + destroy whatever graph comes back) and clear
+ * the sticky error: 1 = there was a capture to end, 0 = the stream was not capturing.  The host side calls it when torch.cuda.graph raises
+ * out of capture_end(), which leaves the capture stream current and still capturing.                                                  */
+int jh_stream_abort_capture(jh_stream stream);
 const char* jh_last_error(void);
 int jh_device_count(void);                       /* 0 when no GPU is visible (never an error) */
 int jh_ctx_create(int device, jh_ctx** out);     /* binds the device, allocates pinned staging */
@@ -471,8 +475,27 @@ int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_
 int jh_rbnet_prepare_noise(jh_rbnet* n, const float* d_noise, jh_stream stream);
 int jh_rbnet_learn_trunk(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, jh_stream stream);
 int jh_rbnet_learn_heads(jh_rbnet* n, int32_t B, const float* d_noise, float* d_logits, jh_stream stream);
-/* loss.backward() given d(loss)/d(online(state) output) [B][A][K] (from jh_c51_loss / jh_td_loss); fills d_grads */
+/* loss.backward() given d(loss)/d(online(state) output) [B][A][K] (from jh_c51_loss / jh_td_loss; NULL after jh_rbnet_c51_step); fills d_grads */
 int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream);
+/* Rainbow.learn()'s loss step on the network's own stream outputs (rainbow.py:160-235), three launches where the separate calls
+ * (jh_rbnet_learn_heads' combine, jh_c51_loss x 2, jh_per_update x 2, jh_rbnet_backward's first kernel) take six:
+ *   jh_rbnet_learn_heads_raw  = jh_rbnet_learn_heads up to the advantage / value streams (network/rainbow.py:76-87); no logits yet
+ *   jh_rbnet_c51_step         launch 1: dueling combine of the three forwards (rainbow.py:88-93 -> d_logits [3][B][A][K], bit-identical
+ *                             to jh_rbnet_learn_heads) + double-Q action + n-step projection + KL + priorities KL^alpha (-> d_prio, d_kl)
+ *                             + the gradient pulled back through the combine (kept in the network);
+ *                             launch 2: batch statistics (d_stats as jh_c51_loss) + priorities into the leaves d_tree_idx of `per`
+ *                             (per_buffer.py:42-54); launch 3: the climb.  per NULL: no write-back.  flags: JH_C51_DOUBLE required.
+ *   jh_rbnet_backward(n, NULL, ..) continues from the gradient jh_rbnet_c51_step left.                                               */
+int jh_rbnet_learn_heads_raw(jh_rbnet* n, int32_t B, const float* d_noise, jh_stream stream);
+int jh_rbnet_c51_step(jh_rbnet* n, jh_per* per, int32_t B, int32_t n_step, int32_t flags, const float* d_action, const float* d_reward,
+                      const float* d_done, const float* d_weights, const int64_t* d_tree_idx, float v_min, float v_max, float gamma,
+                      float alpha, float* d_logits, float* d_prio, float* d_kl, float* d_stats, jh_stream stream);
+/* jh_rbnet_backward that leaves two elementwise tails undone -- d(sigma) = d(mu) * eps of the noisy layers (network/utils.py:60-70) and
+ * the sum of conv1's weight-gradient partials -- for jh_rbnet_optim_step to do inside the optimizer's own pass (no clipping) or as the
+ * launches they were (clipping).  jh_rbnet_flush_grads completes the gradient bucket for anybody who reads it before the optimizer step
+ * (a data-parallel all-reduce).                                                                                                       */
+int jh_rbnet_backward_deferred(jh_rbnet* n, const float* d_g, jh_stream stream);
+int jh_rbnet_flush_grads(jh_rbnet* n, jh_stream stream);
 /* [clip_grad_norm_(max_norm) when max_norm > 0 (ape_x.py:128),] optimizer.step(): optimizer 0 torch.optim.Adam,
  * 1 torch.optim.RMSprop (momentum 0, centered per set_hyper); advances the step counter                 */
 int jh_rbnet_optim_step(jh_rbnet* n, int32_t optimizer, float max_norm, jh_stream stream);

@@ -29,6 +29,7 @@ _pp = C.POINTER(C.c_void_p)
 # name -> (restype, argtypes).  Status-returning functions use c_int and are checked.
 _PROTOS = {
     "jh_abi_version": (C.c_int, []),
+    "jh_stream_abort_capture": (C.c_int, [_vp]),
     "jh_last_error": (C.c_char_p, []),
     "jh_device_count": (C.c_int, []),
     "jh_ctx_create": (C.c_int, [C.c_int, _pp]),
@@ -123,6 +124,10 @@ _PROTOS = {
     "jh_rbnet_learn_trunk": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "jh_rbnet_learn_heads": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "jh_rbnet_backward": (C.c_int, [_vp, _vp, _vp]),
+    "jh_rbnet_backward_deferred": (C.c_int, [_vp, _vp, _vp]),
+    "jh_rbnet_flush_grads": (C.c_int, [_vp, _vp]),
+    "jh_rbnet_learn_heads_raw": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "jh_rbnet_c51_step": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "jh_rbnet_adam_step": (C.c_int, [_vp, _vp]),
     "jh_tgemm_dense": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "jh_tgemm_dense_group": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -151,7 +151,7 @@ class DQN(NativeValueNetMixin, BaseAgent):
             try:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (batched actors, staging ring) keep issuing HIP work on their own streams
+                with ops.graph_capture(g):  # thread_local capture, garbage collector held off, stream restored if it fails
                     self._learn_body(st)
                 self._graph = g
             except Exception as e:

@@ -401,17 +401,17 @@ class PPO(BaseAgent):
                 torch.cuda.synchronize()
                 if split:
                     gp = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gp, capture_error_mode="thread_local"):
+                    with ops.graph_capture(gp):
                         self._enqueue_pre(st, captured)
                     if "main" not in graphs:
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (batched actors, staging ring) keep issuing HIP work on their own streams
+                        with ops.graph_capture(g):  # thread_local: other threads (batched actors, staging ring) keep issuing HIP work on their own streams
                             self._enqueue_main(st)
                         graphs["main"] = g
                     graphs[key] = gp
                 else:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    with ops.graph_capture(g):
                         self._enqueue_pre(st, captured)
                         self._enqueue_main(st)
                     graphs[key] = g  # capture does not execute: replay below runs this iteration's update

@@ -79,6 +79,7 @@ class Rainbow(DQN):
         self.graph_with_collective = os.environ.get("JH_GRAPH_DP", "1") == "1"
         self._static, self._graph, self._warm, self.clip_grad_norm = None, None, False, None
         self._overlap = os.environ.get("JH_LEARN_OVERLAP", "0") == "1"  # opt-in graph branches (dqn.py: measured slower): noise sets || trunk, PER write-back || backward
+        self._fused_step = os.environ.get("JH_RB_FUSED_STEP", "1") == "1"  # jh_rbnet_c51_step + deferred backward tails (0: the separate calls, an A/B switch)
         self._td = dict(double=True, per=True, n_step=1)
         self.action_size = action_size
         self.action_type = "discrete"
@@ -161,6 +162,19 @@ class Rainbow(DQN):
         net.learn_trunk(st["x_all"], B)
         if self._overlap:
             main.wait_stream(side)
+        if self._fused_step and not self._overlap and B <= 1024:
+            # rainbow.py:160-235 in three launches (jh_rbnet_c51_step): the dueling combine of the three forwards and the gradient back through it
+            # live inside the loss kernel, the priorities' leaf write-back (rainbow.py:230-231) inside the statistics kernel, then the climb
+            net.learn_heads_raw(B, st["noise"])
+            self.memory.flush()
+            net.c51_step(self.memory._tree, st["idx"], tr["action"], tr["reward"], tr["done"], st["w"], self.v_min, self.v_max, self.gamma, self.alpha,
+                         self.n_step, st["logits"], stats=self._stats8)
+            # d(sigma) = d(mu) * eps and conv1's partial sums ride in the optimizer's pass unless somebody reads the bucket first
+            net.backward(None, defer=self.grad_sync is None)
+            if self.grad_sync is not None:
+                self.grad_sync.reduce_flat(net.grads)
+            net.optim_step(self._opt_name, self.clip_grad_norm)
+            return
         lg = net.learn_heads(B, st["noise"], st["logits"])
         g, prio, _, _ = ops.c51_loss(lg[0], lg[2], tr["action"], tr["reward"], tr["done"], self.v_min, self.v_max, self.gamma,
                                      next_logit_online=lg[1], weights=st["w"], alpha=self.alpha, n_step=self.n_step, stats=self._stats8)

@@ -102,7 +102,12 @@ int jh_ctx_slab(jh_ctx* ctx, size_t bytes, jh_pinned_slab** out) {
     s.in_use = false;
     return rc;
   };
-  if (wait && hipEventSynchronize(s.ev) != hipSuccess) return fail(jh_fail(JH_ERR_HIP, "hipEventSynchronize on a staging slab failed"));
+  if (wait) {
+    hipError_t se = hipEventSynchronize(s.ev);
+    if (se != hipSuccess) {
+      return fail(jh_fail(JH_ERR_HIP, "hipEventSynchronize on a staging slab failed: %s", hipGetErrorString(se)));
+    }
+  }
   if (s.bytes < bytes) {
     if (s.host && hipHostFree(s.host) != hipSuccess) return fail(jh_fail(JH_ERR_HIP, "hipHostFree of a staging slab failed"));
     size_t want = 1 << 16;
@@ -130,6 +135,23 @@ int jh_ctx_slab_release(jh_ctx* ctx, jh_pinned_slab* slab, hipStream_t stream) {
   slab->in_use = false;
   if (e != hipSuccess) return jh_fail(JH_ERR_HIP, "hipEventRecord on a staging slab -> %s", hipGetErrorString(e));
   return JH_OK;
+}
+
+// A stream capture that failed (hipErrorStreamCaptureInvalidated) leaves its stream in the capture until somebody ends it; a caller whose
+// framework gave up half way (torch.cuda.graph.__exit__ raises out of capture_end) calls this before it reuses or abandons the stream.
+// Returns 1 when there was a capture to end, 0 when the stream was not capturing; the sticky error of the failed capture is cleared.
+JH_EXPORT int jh_stream_abort_capture(jh_stream stream) {
+  hipStream_t st = jh_s(stream);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  int ended = 0;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(st, &g);
+    if (g) (void)hipGraphDestroy(g);
+    ended = 1;
+  }
+  (void)hipGetLastError();
+  return ended;
 }
 
 int jh_ctx_scratch(jh_ctx* ctx, size_t bytes, void** out) {

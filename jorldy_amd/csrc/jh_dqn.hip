@@ -7,6 +7,7 @@
 // Both are latency/HBM-bound (B = 32..512 rows): one lane per row (TD) / one wave per row with
 // atoms across lanes and LDS staging of the per-sample projection operands (C51).
 #include "jh_common.h"
+#include "jh_fused.h"
 
 // ============================================================================ TD losses
 struct TdArgs {
@@ -140,14 +141,6 @@ JH_EXPORT int jh_td_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t n_step, int3
 }
 
 // ============================================================================ C51 / Rainbow
-struct C51Args {
-  int B, A, K, n, flags;
-  const float *logit, *next_logit, *target_logit, *action, *reward, *done, *weights;
-  float v_min, v_max, gamma, alpha;
-  float *grad, *prio, *kl, *stats, *partial;
-  const float* wmean;  // wave-per-sample kernel: the batch mean of `weights`, computed once by jh_mean_f32 in front of it
-};
-
 // torch.linspace(v_min, v_max, K) in float32 (symmetric form used by ATen)
 __device__ __forceinline__ float support_z(int k, int K, float v_min, float v_max) {
   const float step = (v_max - v_min) / (float)(K - 1);
@@ -156,14 +149,11 @@ __device__ __forceinline__ float support_z(int k, int K, float v_min, float v_ma
 
 // softmax over the K atoms of one action row: lane j owns atoms j, j+64, ...  (K <= 256: <= 4 per lane)
 // returns this lane's probabilities in p[0..3] and the expectation sum_k z_k p_k (all lanes).
-__device__ __forceinline__ float atom_softmax(const float* __restrict__ row, int K, int lane, float v_min, float v_max,
-                                              float p[4], float& row_max, float& row_min) {
-  float z[4];
+__device__ __forceinline__ float atom_softmax_z(const float z[4], int K, int lane, float v_min, float v_max, float p[4], float& row_max, float& row_min) {
   float m = -3.4e38f, mn = 3.4e38f;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int k = lane + 64 * s;
-    z[s] = k < K ? row[k] : -3.4e38f;
     m = fmaxf(m, z[s]);
     if (k < K) mn = fminf(mn, z[s]);
   }
@@ -185,20 +175,104 @@ __device__ __forceinline__ float atom_softmax(const float* __restrict__ row, int
   row_min = mn;
   return jh_wave_sum(q);
 }
+__device__ __forceinline__ float atom_softmax(const float* __restrict__ row, int K, int lane, float v_min, float v_max,
+                                              float p[4], float& row_max, float& row_min) {
+  float z[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = lane + 64 * s;
+    z[s] = k < K ? row[k] : -3.4e38f;
+  }
+  return atom_softmax_z(z, K, lane, v_min, v_max, p, row_max, row_min);
+}
 
-// 4 waves per block, one wave per sample.  Dynamic LDS: per wave 5*K floats
-// (l, u as float, wl, wu, target_p of the chosen action).
+// Dueling combine of one (set, sample): this lane's share of mean_a xa[b][a][k] (the sum runs over a in order, like
+// jh_rb_duel_fwd_kernel), and one action's logits (xa - mean) + xv, written to the set's logits as a side effect.
+__device__ __forceinline__ void duel_mean(const C51Duel& d, int set, int b, int A, int K, int lane, float mean[4]) {
+  const float* xa = d.xa[set] + (size_t)b * d.ld_a;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = lane + 64 * s;
+    float sum = 0.f;
+    if (k < K)
+      for (int a = 0; a < A; ++a) sum += xa[a * K + k];
+    mean[s] = sum / (float)A;
+  }
+}
+// one action's row: the loads (issued with the mean's loads, in front of any store), then combine + store
+__device__ __forceinline__ void duel_row_load(const C51Duel& d, int set, int b, int aa, int K, int lane, float ra[4], float rv[4]) {
+  const float* __restrict__ xa = d.xa[set] + (size_t)b * d.ld_a + (size_t)aa * K;
+  const float* __restrict__ xv = d.xv[set] + (size_t)b * d.ld_v;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = lane + 64 * s;
+    ra[s] = k < K ? xa[k] : 0.f;
+    rv[s] = k < K ? xv[k] : 0.f;
+  }
+}
+__device__ __forceinline__ void duel_row_put(const C51Duel& d, int set, int b, int aa, int A, int K, int lane, const float ra[4], const float rv[4],
+                                             const float mean[4], float z[4]) {
+  float* o = d.out[set] + ((size_t)b * A + aa) * K;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = lane + 64 * s;
+    z[s] = -3.4e38f;
+    if (k < K) {
+      z[s] = (ra[s] - mean[s]) + rv[s];
+      o[k] = z[s];
+    }
+  }
+}
+
+// The projection's sum over source atoms (rainbow.py:212-217) for the atoms this lane owns: m_k = d0 * mean_j [l_j == k == u_j] + ... in
+// ASCENDING source atom j like the reference's sum over dim 1.  Source atom j = 64 s + i lives in lane i's registers (slot s); it reaches all
+// lanes through v_readlane (j is wave-uniform: a scalar broadcast, a few cycles) instead of five LDS reads per j -- at K = 51 that loop
+// was 5.9 of the block kernel's 14.4 us (in-kernel clock).  Same operations in the same order as the LDS form: bit-identical results.
+__device__ __forceinline__ float bcast_lane(float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); }
+template <int NS>  // NS = ceil(K / 64) slots in use: no per-slot branches inside the loop over source atoms
+__device__ __forceinline__ void c51_project_ns(const float l[4], const float u[4], const float wl[4], const float wu[4], const float tp[4], int K, int lane, float d0,
+                                               float m[4], float& msum) {
+  float term[NS], non[NS], kf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { term[s] = 0.f; non[s] = 0.f; kf[s] = (float)(lane + 64 * s); }
+#pragma unroll
+  for (int sj = 0; sj < NS; ++sj) {
+    const int nj = K - 64 * sj < 64 ? K - 64 * sj : 64;
+    for (int i = 0; i < nj; ++i) {
+      const float lj = bcast_lane(l[sj], i), uj = bcast_lane(u[sj], i), wlj = bcast_lane(wl[sj], i), wuj = bcast_lane(wu[sj], i), tpj = bcast_lane(tp[sj], i);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float val = (lj == kf[s] ? wlj : 0.f) + (uj == kf[s] ? wuj : 0.f);
+        term[s] += ((lj == kf[s] && uj == kf[s]) ? 1.f : 0.f) + val;  // rainbow.py:212-214
+        non[s] += tpj * val;                                          // rainbow.py:215-217
+      }
+    }
+  }
+  msum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    m[s] = 0.f;
+    if (s < NS) {
+      const bool own = lane + 64 * s < K;
+      m[s] = own ? d0 * (term[s] / (float)K) + (1.f - d0) * non[s] : 0.f;  // torch.mean over the source atoms
+    }
+    msum += m[s];
+  }
+}
+__device__ __forceinline__ void c51_project(const float l[4], const float u[4], const float wl[4], const float wu[4], const float tp[4], int K, int lane, float d0,
+                                            float m[4], float& msum) {
+  if (K <= 64) c51_project_ns<1>(l, u, wl, wu, tp, K, lane, d0, m, msum);
+  else if (K <= 128) c51_project_ns<2>(l, u, wl, wu, tp, K, lane, d0, m, msum);
+  else if (K <= 192) c51_project_ns<3>(l, u, wl, wu, tp, K, lane, d0, m, msum);
+  else c51_project_ns<4>(l, u, wl, wu, tp, K, lane, d0, m, msum);
+}
+
+// 4 waves per block, one wave per sample.
 __global__ void __launch_bounds__(256) jh_c51_kernel(C51Args a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float s_part[4][4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + wid;
   const int K = a.K;
-  float* s_l = smem + (size_t)wid * 5 * K;
-  float* s_u = s_l + K;
-  float* s_wl = s_u + K;
-  float* s_wu = s_wl + K;
-  float* s_tp = s_wu + K;
   float kl = 0.f, maxq = -3.4e38f, maxl = -3.4e38f, minl = 3.4e38f;
   if (b < a.B) {
     int act = (int)a.action[b];
@@ -230,9 +304,11 @@ __global__ void __launch_bounds__(256) jh_c51_kernel(C51Args a) {
     // ---- n-step Bellman image of every atom and its two neighbours on the support
     const float range = a.v_max - a.v_min;
     const float dz = (float)(((double)a.v_max - (double)a.v_min) / (double)(K - 1));
+    float pl[4], pu[4], pwl[4], pwu[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int j = lane + 64 * s;
+      pl[s] = pu[s] = -1.f; pwl[s] = pwu[s] = 0.f;
       if (j < K) {
         float Tz = support_z(j, K, a.v_min, a.v_max);
         for (int i = a.n - 1; i >= 0; --i) {  // rainbow.py:188-193
@@ -240,36 +316,16 @@ __global__ void __launch_bounds__(256) jh_c51_kernel(C51Args a) {
           Tz = r + (1.f - d) * a.gamma * Tz;
         }
         const float bb = fminf(fmaxf(Tz - a.v_min, 0.f), range) / dz;  // rainbow.py:195
-        const float l = floorf(bb), u = ceilf(bb);
-        s_l[j] = l;
-        s_u[j] = u;
-        s_wl[j] = u - bb;  // mass to l;  integral b -> l == u -> both weights 0 (quirk kept)
-        s_wu[j] = bb - l;
-        s_tp[j] = tp[s];
+        pl[s] = floorf(bb);
+        pu[s] = ceilf(bb);
+        pwl[s] = pu[s] - bb;  // mass to l;  integral b -> l == u -> both weights 0 (quirk kept)
+        pwu[s] = bb - pl[s];
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
     const float d0 = a.done[(size_t)b * a.n];  // terminal branch keyed on done[:,0]  rainbow.py:212
     float m[4];
-    float msum = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k = lane + 64 * s;
-      float term = 0.f, non = 0.f;
-      if (k < K) {
-        const float kf = (float)k;
-        for (int j = 0; j < K; ++j) {  // ascending source atom, like the sum over dim 1
-          const float l = s_l[j], u = s_u[j];
-          const float val = (l == kf ? s_wl[j] : 0.f) + (u == kf ? s_wu[j] : 0.f);
-          term += ((l == kf && u == kf) ? 1.f : 0.f) + val;  // rainbow.py:212-214
-          non += s_tp[j] * val;                              // rainbow.py:215-217
-        }
-        term = term / (float)K;  // torch.mean over the source atoms
-      }
-      m[s] = k < K ? d0 * term + (1.f - d0) * non : 0.f;
-      msum += m[s];
-    }
+    float msum;
+    c51_project(pl, pu, pwl, pwu, tp, K, lane, d0, m, msum);
     msum = jh_wave_sum(msum);
     const float norm = fmaxf(msum, 1e-8f);  // rainbow.py:218-220
     float klp = 0.f, mt_sum = 0.f;
@@ -327,27 +383,62 @@ __global__ void __launch_bounds__(256) jh_c51_kernel(C51Args a) {
 // on a single wave -- at B = 32 that chain, not bandwidth, is the whole cost.  Every value is computed by the same
 // instruction sequence as above (one wave per softmax row, same shuffle trees, same source-atom order in the
 // projection), so the results are bit-identical.
-// Dynamic LDS: [K] p_act, [K] l, u, wl, wu, tp, [A] selector Q, [4][3] per-wave stats.
-__global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a) {
+// Dynamic LDS: [K] p_act, [A] selector Q, [4][3] per-wave stats (+ [A][K] target logits in the dueling form).
+// DUEL (Rainbow's own step, jh_rbnet_c51_step): the logits do not exist yet -- the kernel reads the advantage / value streams
+// of the three forwards, forms (xa - mean_a xa) + xv per row as jh_rb_duel_fwd_kernel would (same expression, same order: the
+// logits it leaves in d.out are bit-identical) and hands back d(loss)/d(xa), d(loss)/d(xv) instead of d(loss)/d(logits).
+template <bool DUEL>
+__global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a, C51Duel d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x, K = a.K;
   float* s_pact = smem;
-  float* s_l = s_pact + K;
-  float* s_u = s_l + K;
-  float* s_wl = s_u + K;
-  float* s_wu = s_wl + K;
-  float* s_tp = s_wu + K;
-  float* s_qsel = s_tp + K;       // [A]
+  float* s_qsel = s_pact + K;     // [A]
   float* s_stat = s_qsel + a.A;   // [4][3]: max Q, max logit, min logit of the rows this wave saw
+  float* s_z2 = s_stat + 12;      // DUEL: [A][K] the target net's combined logits (wave 0 picks the greedy action's row from here)
   int act = (int)a.action[b];
   act = act < 0 ? 0 : (act >= a.A ? a.A - 1 : act);
+  // what wave 0 needs after the barrier, requested now so that it arrives under the softmaxes instead of as three more dependent round
+  // trips: the n-step rewards / dones (lane i holds step i) and this lane's share of the batch's IS weights (summed in the old order)
+  const bool pre = a.n <= 64;
+  float pre_r = 0.f, pre_d = 0.f, pre_ws = 0.f;
+  if (wid == 0) {
+    if (pre && lane < a.n) { pre_r = a.reward[(size_t)b * a.n + lane]; pre_d = a.done[(size_t)b * a.n + lane]; }
+    if (a.flags & JH_C51_PER)
+      for (int i = lane; i < a.B; i += 64) pre_ws += a.weights[i];
+  }
   // ---- phase 1: online softmaxes (stats + the taken action's distribution) and the selector's Q, actions strided over waves
   float maxq = -3.4e38f, maxl = -3.4e38f, minl = 3.4e38f;
   const float* sel = (a.flags & JH_C51_DOUBLE) ? a.next_logit : a.target_logit;
+  const int sel_set = (a.flags & JH_C51_DOUBLE) ? 1 : 2;
+  float mean0[4], mean1[4], mean2[4];
+  float ra[3][4], rv[3][4];
+  if (DUEL) {
+    // this wave's first row of the three sets and everything the means need: one batch of loads, one wait
+    if (wid < a.A)
+      for (int j = 0; j < 3; ++j) duel_row_load(d, j, b, wid, K, lane, ra[j], rv[j]);
+    duel_mean(d, 0, b, a.A, K, lane, mean0);
+    duel_mean(d, 1, b, a.A, K, lane, mean1);
+    duel_mean(d, 2, b, a.A, K, lane, mean2);
+  }
   for (int aa = wid; aa < a.A; aa += 4) {
-    float p[4], rmx, rmn;
-    const float q = atom_softmax(a.logit + ((size_t)b * a.A + aa) * K, K, lane, a.v_min, a.v_max, p, rmx, rmn);
+    float p[4], rmx, rmn, q, q2, p2[4];
+    if (DUEL) {
+      float z0[4], z1[4], z2[4];
+      if (aa != wid)
+        for (int j = 0; j < 3; ++j) duel_row_load(d, j, b, aa, K, lane, ra[j], rv[j]);
+      duel_row_put(d, 0, b, aa, a.A, K, lane, ra[0], rv[0], mean0, z0);
+      duel_row_put(d, 1, b, aa, a.A, K, lane, ra[1], rv[1], mean1, z1);  // every row of every set is written: the logits are an output
+      duel_row_put(d, 2, b, aa, a.A, K, lane, ra[2], rv[2], mean2, z2);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (lane + 64 * s < K) s_z2[aa * K + lane + 64 * s] = z2[s];
+      q = atom_softmax_z(z0, K, lane, a.v_min, a.v_max, p, rmx, rmn);
+      float r2x, r2n;
+      q2 = atom_softmax_z(sel_set == 1 ? z1 : z2, K, lane, a.v_min, a.v_max, p2, r2x, r2n);
+    } else {
+      q = atom_softmax(a.logit + ((size_t)b * a.A + aa) * K, K, lane, a.v_min, a.v_max, p, rmx, rmn);
+    }
     maxq = fmaxf(maxq, q);
     maxl = fmaxf(maxl, rmx);
     minl = fminf(minl, rmn);
@@ -356,13 +447,13 @@ __global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a) {
       for (int s = 0; s < 4; ++s)
         if (lane + 64 * s < K) s_pact[lane + 64 * s] = p[s];
     }
-    float p2[4];
-    const float q2 = atom_softmax(sel + ((size_t)b * a.A + aa) * K, K, lane, a.v_min, a.v_max, p2, rmx, rmn);
+    if (!DUEL) q2 = atom_softmax(sel + ((size_t)b * a.A + aa) * K, K, lane, a.v_min, a.v_max, p2, rmx, rmn);
     if (lane == 0) s_qsel[aa] = q2;
   }
   if (lane == 0) { s_stat[wid * 3 + 0] = maxq; s_stat[wid * 3 + 1] = maxl; s_stat[wid * 3 + 2] = minl; }
   __syncthreads();
   if (wid != 0) {
+    if (DUEL) return;  // the gradient rows of the other actions are -mean_a g: wave 0 writes them with the taken action's row
     // ---- the other waves only write the zero gradient rows of the actions that were not taken (phase 4 needs nothing from them)
     for (int aa = wid - 1; aa < a.A; aa += 3) {
       if (aa == act) continue;
@@ -379,53 +470,41 @@ __global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a) {
     if (q > bq) { bq = q; best = aa; }
   }
   float tp[4], rmx, rmn;
-  (void)atom_softmax(a.target_logit + ((size_t)b * a.A + best) * K, K, lane, a.v_min, a.v_max, tp, rmx, rmn);
+  if (DUEL) {
+    float zt[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) zt[s] = (lane + 64 * s < K) ? s_z2[best * K + lane + 64 * s] : -3.4e38f;  // what phase 1 wrote for this row
+    (void)atom_softmax_z(zt, K, lane, a.v_min, a.v_max, tp, rmx, rmn);
+  } else {
+    (void)atom_softmax(a.target_logit + ((size_t)b * a.A + best) * K, K, lane, a.v_min, a.v_max, tp, rmx, rmn);
+  }
   float p_act[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) p_act[s] = (lane + 64 * s < K) ? s_pact[lane + 64 * s] : 0.f;
   // ---- n-step Bellman image of every atom and its two neighbours on the support
   const float range = a.v_max - a.v_min;
   const float dz = (float)(((double)a.v_max - (double)a.v_min) / (double)(K - 1));
+  float Tzs[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) Tzs[s] = support_z(lane + 64 * s, K, a.v_min, a.v_max);
+  for (int i = a.n - 1; i >= 0; --i) {  // rainbow.py:188-193 (every atom sees the same operations in the same order as one loop per atom)
+    const float r = pre ? __shfl(pre_r, i, 64) : a.reward[(size_t)b * a.n + i], dn = pre ? __shfl(pre_d, i, 64) : a.done[(size_t)b * a.n + i];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Tzs[s] = r + (1.f - dn) * a.gamma * Tzs[s];
+  }
+  float pl[4], pu[4], pwl[4], pwu[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int j = lane + 64 * s;
-    if (j < K) {
-      float Tz = support_z(j, K, a.v_min, a.v_max);
-      for (int i = a.n - 1; i >= 0; --i) {  // rainbow.py:188-193
-        const float r = a.reward[(size_t)b * a.n + i], d = a.done[(size_t)b * a.n + i];
-        Tz = r + (1.f - d) * a.gamma * Tz;
-      }
-      const float bb = fminf(fmaxf(Tz - a.v_min, 0.f), range) / dz;  // rainbow.py:195
-      const float l = floorf(bb), u = ceilf(bb);
-      s_l[j] = l;
-      s_u[j] = u;
-      s_wl[j] = u - bb;  // mass to l;  integral b -> l == u -> both weights 0 (quirk kept)
-      s_wu[j] = bb - l;
-      s_tp[j] = tp[s];
-    }
+    const float bb = fminf(fmaxf(Tzs[s] - a.v_min, 0.f), range) / dz;  // rainbow.py:195
+    pl[s] = floorf(bb);
+    pu[s] = ceilf(bb);
+    pwl[s] = pu[s] - bb;  // mass to l;  integral b -> l == u -> both weights 0 (quirk kept)
+    pwu[s] = bb - pl[s];
   }
-  __builtin_amdgcn_wave_barrier();
-  __threadfence_block();
-  const float d0 = a.done[(size_t)b * a.n];  // terminal branch keyed on done[:,0]  rainbow.py:212
+  const float d0 = pre ? __shfl(pre_d, 0, 64) : a.done[(size_t)b * a.n];  // terminal branch keyed on done[:,0]  rainbow.py:212
   float m[4];
-  float msum = 0.f;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int k = lane + 64 * s;
-    float term = 0.f, non = 0.f;
-    if (k < K) {
-      const float kf = (float)k;
-      for (int j = 0; j < K; ++j) {  // ascending source atom, like the sum over dim 1
-        const float l = s_l[j], u = s_u[j];
-        const float val = (l == kf ? s_wl[j] : 0.f) + (u == kf ? s_wu[j] : 0.f);
-        term += ((l == kf && u == kf) ? 1.f : 0.f) + val;  // rainbow.py:212-214
-        non += s_tp[j] * val;                              // rainbow.py:215-217
-      }
-      term = term / (float)K;  // torch.mean over the source atoms
-    }
-    m[s] = k < K ? d0 * term + (1.f - d0) * non : 0.f;
-    msum += m[s];
-  }
+  float msum;
+  c51_project(pl, pu, pwl, pwu, tp, K, lane, d0, m, msum);
   msum = jh_wave_sum(msum);
   const float norm = fmaxf(msum, 1e-8f);  // rainbow.py:218-220
   float klp = 0.f, mt_sum = 0.f;
@@ -441,17 +520,29 @@ __global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a) {
   const float kl = -jh_wave_sum(klp);  // rainbow.py:227
   mt_sum = jh_wave_sum(mt_sum);
   float weff = 1.f;  // rainbow's (B,1)*(B,) broadcast makes the per-sample weight the batch MEAN
-  if (a.flags & JH_C51_PER) {
-    float ws = 0.f;
-    for (int i = lane; i < a.B; i += 64) ws += a.weights[i];
-    weff = jh_wave_sum(ws) / (float)a.B;
-  }
+  if (a.flags & JH_C51_PER) weff = jh_wave_sum(pre_ws) / (float)a.B;
   const float scale = weff / (float)a.B;
-  float* g = a.grad + ((size_t)b * a.A + act) * K;
+  if (DUEL) {
+    // g is zero outside the taken action's row: sum_a g = that row (jh_rb_duel_bwd_kernel's sum of A terms, A - 1 of them 0.f)
+    float* dxa = d.dxa + (size_t)b * d.ld_a;
+    float* dxv = d.dxv + (size_t)b * d.ld_v;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int k = lane + 64 * s;
-    if (k < K) g[k] = (-mt[s] + p_act[s] * mt_sum) * scale;
+    for (int s = 0; s < 4; ++s) {
+      const int k = lane + 64 * s;
+      if (k < K) {
+        const float gv = (-mt[s] + p_act[s] * mt_sum) * scale;
+        const float mean = gv / (float)a.A;
+        dxv[k] = gv;
+        for (int aa = 0; aa < a.A; ++aa) dxa[aa * K + k] = (aa == act ? gv : 0.f) - mean;
+      }
+    }
+  } else {
+    float* g = a.grad + ((size_t)b * a.A + act) * K;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = lane + 64 * s;
+      if (k < K) g[k] = (-mt[s] + p_act[s] * mt_sum) * scale;
+    }
   }
   if (lane == 0) {
     if (a.kl) a.kl[b] = kl;
@@ -468,8 +559,17 @@ __global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a) {
   }
 }
 
-__global__ void __launch_bounds__(256) jh_c51_finish_kernel(int nb, C51Args a) {
+// PER: the same launch writes the new priorities a.prio into the tree's leaves (jh_per_delta_body; the climb follows).
+template <bool PER>
+__global__ void __launch_bounds__(256) jh_c51_finish_kernel(int nb, C51Args a, PerDeltaArgs pa) {
   __shared__ float s_red[16];
+  if (PER && blockIdx.x == 1) {  // a workgroup of its own beside the statistics: neither waits for the other
+    __shared__ unsigned long long s_key[kPerChunk];
+    __shared__ double s_new[kPerChunk];
+    __shared__ double s_redd[16];
+    jh_per_delta_body(pa, a.B, s_key, s_new, s_redd);
+    return;
+  }
   float sk = 0.f, mq = -3.4e38f, ml = -3.4e38f, nl = 3.4e38f, ws = 0.f;
   for (int b = threadIdx.x; b < nb; b += 256) {
     sk += a.partial[4 * b];
@@ -497,6 +597,36 @@ __global__ void __launch_bounds__(256) jh_c51_finish_kernel(int nb, C51Args a) {
   }
 }
 
+int jh_c51_run(jh_ctx* ctx, C51Args a, const C51Duel* duel, const PerDeltaArgs* per, hipStream_t st) {
+  const int B = a.B, K = a.K;
+  const bool per_block = B <= 1024;  // latency regime: one workgroup per sample, softmaxes spread over its waves
+  if (duel && !per_block) return jh_fail(JH_ERR_ARG, "jh_c51_run: the fused dueling form is the block kernel's (B <= 1024)");
+  if (per && B > kPerChunk) return jh_fail(JH_ERR_ARG, "jh_c51_run: fused priority write-back takes B <= %d", kPerChunk);
+  const int nb = per_block ? B : (B + 3) / 4;
+  void* scratch = nullptr;
+  int rc = jh_ctx_scratch(ctx, sizeof(float) * (4 * (size_t)nb + 4), &scratch);
+  if (rc) return rc;
+  a.partial = (float*)scratch;
+  if (!per_block && (a.flags & JH_C51_PER)) {
+    float* wmean = (float*)scratch + 4 * (size_t)nb;
+    rc = jh_mean_f32(ctx, B, a.weights, wmean, (jh_stream)st);
+    if (rc) return rc;
+    a.wmean = wmean;
+  }
+  if (per_block) {
+    const size_t lds = sizeof(float) * ((size_t)K + (size_t)a.A + 12 + (duel ? (size_t)a.A * K : 0));
+    if (duel) JH_LAUNCH(jh_c51_block_kernel<true>, dim3(nb), dim3(256), lds, st, a, *duel);
+    else JH_LAUNCH(jh_c51_block_kernel<false>, dim3(nb), dim3(256), lds, st, a, C51Duel{});
+  } else {
+    JH_LAUNCH(jh_c51_kernel, dim3(nb), dim3(256), 0, st, a);
+  }
+  JH_LAUNCH_CHECK();
+  if (per) JH_LAUNCH(jh_c51_finish_kernel<true>, dim3(2), dim3(256), 0, st, nb, a, *per);
+  else JH_LAUNCH(jh_c51_finish_kernel<false>, dim3(1), dim3(256), 0, st, nb, a, PerDeltaArgs{});
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
 JH_EXPORT int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t n_step, int32_t flags,
                           const float* d_logit, const float* d_next_logit_online, const float* d_target_logit,
                           const float* d_action, const float* d_reward, const float* d_done, const float* d_weights,
@@ -511,29 +641,7 @@ JH_EXPORT int jh_c51_loss(jh_ctx* ctx, int32_t B, int32_t A, int32_t K, int32_t 
   a.logit = d_logit; a.next_logit = d_next_logit_online; a.target_logit = d_target_logit; a.action = d_action;
   a.reward = d_reward; a.done = d_done; a.weights = d_weights; a.v_min = v_min; a.v_max = v_max; a.gamma = gamma;
   a.alpha = alpha; a.grad = d_grad_logit; a.prio = d_prio; a.kl = d_kl; a.stats = d_stats;
-  const bool per_block = B <= 1024;  // latency regime: one workgroup per sample, softmaxes spread over its waves
-  const int nb = per_block ? B : (B + 3) / 4;
-  void* scratch = nullptr;
-  int rc = jh_ctx_scratch(ctx, sizeof(float) * (4 * (size_t)nb + 4), &scratch);
-  if (rc) return rc;
-  a.partial = (float*)scratch;
-  if (!per_block && (flags & JH_C51_PER)) {
-    float* wmean = (float*)scratch + 4 * (size_t)nb;
-    rc = jh_mean_f32(ctx, B, d_weights, wmean, stream);
-    if (rc) return rc;
-    a.wmean = wmean;
-  }
-  if (per_block) {
-    const size_t lds = sizeof(float) * (6 * (size_t)K + (size_t)A + 12);
-    JH_LAUNCH(jh_c51_block_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);
-  } else {
-    const size_t lds = sizeof(float) * 4 * 5 * (size_t)K;
-    JH_LAUNCH(jh_c51_kernel, dim3(nb), dim3(256), lds, jh_s(stream), a);
-  }
-  JH_LAUNCH_CHECK();
-  JH_LAUNCH(jh_c51_finish_kernel, dim3(1), dim3(256), 0, jh_s(stream), nb, a);
-  JH_LAUNCH_CHECK();
-  return JH_OK;
+  return jh_c51_run(ctx, a, nullptr, nullptr, jh_s(stream));
 }
 
 // ============================================================================ batched acting of the value-net agents

@@ -15,9 +15,10 @@
 // The descent (per_buffer.py:56-68) is a dependent chain of ~log2(N) 8-byte loads per sample:
 // latency-bound, one lane per sample, `num <= left` goes left.
 #include "jh_common.h"
+#include "jh_fused.h"
 
 namespace {
-constexpr int kChunk = 2048;  // items per kernel pass, a power of two <= 4096 (LDS: 2048 * (8+8) B = 32 KiB)
+constexpr int kChunk = kPerChunk;  // items per kernel pass (jh_fused.h)
 
 struct PerWs {
   double* delta = nullptr;   // [kChunk]
@@ -45,86 +46,12 @@ struct jh_per {
 // ----------------------------------------------------------------------------- kernels
 __device__ __forceinline__ int node_depth(int64_t i) { return 63 - __clzll((unsigned long long)(i + 1)); }
 
-// mode bits
-#define PER_DISTINCT 1  // caller guarantees all leaves distinct (push of consecutive leaves)
-#define PER_CONTIG 2    // caller guarantees each node's items are contiguous in batch order
-
-// In-LDS bitonic sort of n (power of two, <= kChunk) 64-bit keys by 256 threads.  Keys are
-// (node << 12 | batch position): equal nodes become one contiguous run ordered by batch position,
-// which is exactly the order in which the reference applies its `+= delta` to that node.
-__device__ __forceinline__ void jh_bitonic_sort(unsigned long long* keys, int n) {
-  for (int k = 2; k <= n; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < n; t += 256) {
-        const int ixj = t ^ j;
-        if (ixj > t) {
-          const unsigned long long a = keys[t], b = keys[ixj];
-          const bool up = (t & k) == 0;
-          if ((a > b) == up) { keys[t] = b; keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-__device__ __forceinline__ int jh_pow2_ge(int n) {
-  int p = 1;
-  while (p < n) p <<= 1;
-  return p;
-}
-
-__global__ void __launch_bounds__(256) jh_per_delta_kernel(double* __restrict__ tree, double* __restrict__ maxp, int B,
-                                                           const int64_t* __restrict__ idx, int64_t push_start,
-                                                           const void* __restrict__ prio, int prio_dt, int mode,
-                                                           int64_t tree_size, int64_t first_leaf,
-                                                           double* __restrict__ delta_out) {
+// leaf write-back: the body lives in jh_fused.h (the fused C51 statistics kernel of jh_dqn.hip runs it too)
+__global__ void __launch_bounds__(256) jh_per_delta_kernel(PerDeltaArgs a, int B) {
   __shared__ unsigned long long s_key[kChunk];  // (leaf << 12) | i, sorted unless PER_DISTINCT
   __shared__ double s_new[kChunk];
   __shared__ double s_red[16];
-  const double cur_max = *maxp;
-  const int n2 = jh_pow2_ge(B);
-  double my_max = cur_max;
-  for (int i = threadIdx.x; i < n2; i += 256) {
-    if (i < B) {
-      int64_t ix = idx ? idx[i] : push_start + i;
-      // a bad index must not corrupt internal nodes: clamp into the leaf range
-      ix = ix < first_leaf ? first_leaf : (ix >= tree_size ? tree_size - 1 : ix);
-      double p;
-      if (!prio) p = cur_max;
-      else if (prio_dt == JH_F32) p = (double)((const float*)prio)[i];  // fp32 tensor .item() -> python float
-      else p = ((const double*)prio)[i];
-      s_key[i] = ((unsigned long long)ix << 12) | (unsigned long long)i;
-      s_new[i] = p;
-      my_max = fmax(my_max, p);
-    } else {
-      s_key[i] = ~0ull;
-    }
-  }
-  __syncthreads();
-  if (!(mode & PER_DISTINCT)) jh_bitonic_sort(s_key, n2);
-  // sorted position q holds item i = key & 4095 of leaf key >> 12.  Within a run of equal leaves the
-  // reference sees: old = tree[leaf] for the first write, the previous write's value afterwards, and
-  // the leaf ends up with the last write (per_buffer.py:42-46 applied in batch order).
-  for (int q = threadIdx.x; q < B; q += 256) {
-    const unsigned long long kq = s_key[q];
-    const int i = (int)(kq & 4095ull);
-    const int64_t leaf = (int64_t)(kq >> 12);
-    const bool head = q == 0 || (s_key[q - 1] >> 12) != (unsigned long long)leaf;
-    const bool tail = q == B - 1 || (s_key[q + 1] >> 12) != (unsigned long long)leaf;
-    const double oldp = head ? tree[leaf] : s_new[(int)(s_key[q - 1] & 4095ull)];
-    delta_out[i] = s_new[i] - oldp;
-    (void)tail;  // the leaf itself is written by the run tail, after the barrier below
-  }
-  __syncthreads();  // all leaf reads are done before any leaf is overwritten
-  for (int q = threadIdx.x; q < B; q += 256) {
-    const unsigned long long kq = s_key[q];
-    const int64_t leaf = (int64_t)(kq >> 12);
-    const bool tail = q == B - 1 || (s_key[q + 1] >> 12) != (unsigned long long)leaf;
-    if (tail) tree[leaf] = s_new[(int)(kq & 4095ull)];
-  }
-  const double m = jh_block_reduce(my_max, s_red, JhMax(), 0.0);
-  if (threadIdx.x == 0) *maxp = m;  // max(max_priority, new...) per_buffer.py:48
+  jh_per_delta_body(a, B, s_key, s_new, s_red);
 }
 
 __global__ void __launch_bounds__(256) jh_per_climb_kernel(double* __restrict__ tree, int B,
@@ -320,11 +247,14 @@ JH_EXPORT void jh_per_destroy(jh_per* p) {
   delete p;
 }
 
-static int per_apply(jh_per* p, int B, const int64_t* d_idx, int64_t push_start, const void* prio, int prio_dt, int mode,
-                     hipStream_t st) {
-  JH_LAUNCH(jh_per_delta_kernel, dim3(1), dim3(256), 0, st, p->tree, p->maxp, B, d_idx, push_start, prio,
-                     prio_dt, mode, p->tree_size, p->N - 1, p->ws.delta);
-  JH_LAUNCH_CHECK();
+static PerDeltaArgs per_delta_args(jh_per* p, const int64_t* d_idx, int64_t push_start, const void* prio, int prio_dt, int mode) {
+  PerDeltaArgs a{};
+  a.tree = p->tree; a.maxp = p->maxp; a.idx = d_idx; a.push_start = push_start; a.prio = prio; a.prio_dt = prio_dt; a.mode = mode;
+  a.tree_size = p->tree_size; a.first_leaf = p->N - 1; a.delta_out = p->ws.delta;
+  return a;
+}
+
+static int per_climb(jh_per* p, int B, const int64_t* d_idx, int64_t push_start, int mode, hipStream_t st) {
   if (p->depth_max > 0) {
     JH_LAUNCH(jh_per_climb_kernel, dim3(p->depth_max), dim3(256), 0, st, p->tree, B, d_idx, push_start,
                        p->ws.delta, mode, p->tree_size, p->N - 1);
@@ -332,6 +262,22 @@ static int per_apply(jh_per* p, int B, const int64_t* d_idx, int64_t push_start,
   }
   return JH_OK;
 }
+
+static int per_apply(jh_per* p, int B, const int64_t* d_idx, int64_t push_start, const void* prio, int prio_dt, int mode,
+                     hipStream_t st) {
+  JH_LAUNCH(jh_per_delta_kernel, dim3(1), dim3(256), 0, st, per_delta_args(p, d_idx, push_start, prio, prio_dt, mode), B);
+  JH_LAUNCH_CHECK();
+  return per_climb(p, B, d_idx, push_start, mode, st);
+}
+
+// the two halves for a caller that folds the leaf write-back into a kernel of its own (jh_fused.h)
+int jh_per_delta_args(jh_per* p, int B, const int64_t* d_idx, const void* d_prio, int prio_dt, PerDeltaArgs* out) {
+  JH_ARG(p && d_idx && d_prio && out);
+  JH_ARG(B > 0 && B <= kChunk && (prio_dt == JH_F32 || prio_dt == JH_F64));
+  *out = per_delta_args(p, d_idx, 0, d_prio, prio_dt, 0);
+  return JH_OK;
+}
+int jh_per_climb(jh_per* p, int B, const int64_t* d_idx, hipStream_t st) { return per_climb(p, B, d_idx, 0, 0, st); }
 
 JH_EXPORT int jh_per_push(jh_per* p, int64_t n, const double* h_prio, jh_stream stream) {
   JH_ARG(p != nullptr && n >= 0);

@@ -18,6 +18,7 @@
 //   linear / noisy weights [out][in] (the reference keeps noisy weights as [in][out])
 //   a1 | v1 noisy layers stacked into one [2H][H] matrix (one GEMM feeds both streams)
 #include "jh_tgemm.h"
+#include "jh_fused.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -441,10 +442,18 @@ __global__ void __launch_bounds__(256) jh_rb_gradnorm_kernel(int64_t n, const fl
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// A tail of the backward pass that rides in the optimizer's launch (jh_rbnet_backward_deferred; only without clipping: the global norm would
+// need the finished gradient first): the sum of conv1's weight-gradient partials.  The bucket still ends up holding the complete gradient.
+struct OptFuse {
+  int n_c1;              // > 0: elements [0, n_c1) = conv1's weight + bias gradient, still `parts` partial sums in c1_part (n_c1 % 32 == 0)
+  int parts;
+  const float* c1_part;
+  int extra_wgs;         // workgroups at the end of the grid that only do the conv1 part (beside the others' pass, not in front of it)
+};
 template <int OPT>  // 0 torch.optim.Adam, 1 torch.optim.RMSprop (momentum 0, optionally centered); no weight decay
 __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, float* __restrict__ hyper, unsigned* __restrict__ ticket,
-                                                          const float* __restrict__ partial, int n_partial, float max_norm) {
+                                                          const float* __restrict__ partial, int n_partial, float max_norm, OptFuse f) {
   __shared__ float s_red[16];
   __shared__ float s_bc[2];
   const float t_new = hyper[JH_HY_STEP] + 1.f;
@@ -481,9 +490,39 @@ __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __re
       pi = pi - lr * (gi / avg);
     }
   };
+  // conv1's gradient still in partials: 32 elements per workgroup and round, summed in jh_rb_parts_sum_kernel's order (8 interleaved runs,
+  // then those in order), written to the bucket, and stepped right here
+  const int main_wgs = (int)gridDim.x - f.extra_wgs;
+  if (f.n_c1 > 0 && (int)blockIdx.x >= main_wgs) {
+    __shared__ float s_ps[8][32];
+    const int el = threadIdx.x & 31, run = threadIdx.x >> 5;
+    for (int e0 = ((int)blockIdx.x - main_wgs) * 32; e0 < f.n_c1; e0 += f.extra_wgs * 32) {
+      const int e = e0 + el;
+      float acc = 0.f;
+      int q = run;
+      for (; q + 24 < f.parts; q += 32) {
+        const float v0 = f.c1_part[(size_t)q * f.n_c1 + e], v1 = f.c1_part[(size_t)(q + 8) * f.n_c1 + e], v2 = f.c1_part[(size_t)(q + 16) * f.n_c1 + e],
+                    v3 = f.c1_part[(size_t)(q + 24) * f.n_c1 + e];
+        acc = (((acc + v0) + v1) + v2) + v3;
+      }
+      for (; q < f.parts; q += 8) acc += f.c1_part[(size_t)q * f.n_c1 + e];
+      s_ps[run][el] = acc;
+      __syncthreads();
+      if (run == 0) {
+        float gi = s_ps[0][el];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) gi += s_ps[k][el];
+        float pi = p[e], mi = m[e], vi = v[e];
+        update(pi, gi, mi, vi);
+        p[e] = pi; g[e] = gi; v[e] = vi;
+        if (OPT == 0 || centered) m[e] = mi;
+      }
+      __syncthreads();
+    }
+  }
   // 16-byte accesses: the buckets are 16-byte aligned and n is a multiple of 4 (segment offsets are)
   const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)(f.n_c1 >> 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4 && (int)blockIdx.x < main_wgs; i += (int64_t)main_wgs * 256) {
     float4 p4 = reinterpret_cast<float4*>(p)[i], g4 = reinterpret_cast<float4*>(g)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
     update(p4.x, g4.x, m4.x, v4.x);
     update(p4.y, g4.y, m4.y, v4.y);
@@ -494,7 +533,7 @@ __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __re
     if (OPT == 0 || centered) reinterpret_cast<float4*>(m)[i] = m4;
     reinterpret_cast<float4*>(v)[i] = v4;
   }
-  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n && (int)blockIdx.x < main_wgs; i += (int64_t)main_wgs * 256) {
     float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
     update(pi, gi, mi, vi);
     p[i] = pi; g[i] = gi; m[i] = mi; v[i] = vi;
@@ -550,6 +589,9 @@ struct jh_rbnet {
   int last_x_u8 = 0, last_B = 0;
   const float* last_noise = nullptr;
   const float* prepared_noise = nullptr;  // jh_rbnet_prepare_noise materialised the three learn() weight sets for this draw already
+  int raw_heads = 0;    // the last learn_heads left xa / xv uncombined (jh_rbnet_learn_heads_raw): jh_rbnet_c51_step combines them
+  int dx_ready = 0;     // dxa / dxv already hold the gradient pulled through the dueling combine (jh_rbnet_c51_step)
+  int pend_parts = 0;   // conv1 weight-gradient partials not yet summed into the bucket (jh_rbnet_backward_deferred): their count
   std::vector<void*> owned;
 };
 
@@ -866,7 +908,7 @@ struct HeadJob {
   const float* h;  // [B][H]
   float* logits;   // [B][A][K]
 };
-static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t st) {
+static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t st, bool raw = false) {
   const int H = n->hidden, NA = n->NA, K = n->K, in1 = n->in1;
   const NoisyDims& d = n->nd;
   const bool prepared = n->noisy && nj == 3 && n->prepared_noise != nullptr && n->prepared_noise == jobs[0].noise;
@@ -905,7 +947,7 @@ static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t
   }
   rc = launch_tgemm(n, "jh_tgemm_stream2_fwd", g, ng, st);
   if (rc) return rc;
-  if (!n->dueling) return JH_OK;
+  if (!n->dueling || raw) return JH_OK;
   DuelSets ds{};
   for (int j = 0; j < nj; ++j) {
     ds.xa[j] = n->xa + j * B_ * n->NA4; ds.xv[j] = n->xv + j * B_ * n->K4; ds.out[j] = jobs[j].logits;
@@ -970,10 +1012,11 @@ JH_EXPORT int jh_rbnet_learn_trunk(jh_rbnet* n, const void* d_x, int32_t x_dtype
   return JH_OK;
 }
 
-JH_EXPORT int jh_rbnet_learn_heads(jh_rbnet* n, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
-  JH_ARG(n && d_logits);
+static int rb_learn_heads(jh_rbnet* n, int32_t B, const float* d_noise, float* d_logits, bool raw, jh_stream stream) {
+  JH_ARG(n && (d_logits || raw));
   JH_ARG(d_noise || !n->noisy);
   JH_ARG(B > 0 && B == n->last_B);
+  if (raw && !n->dueling) return jh_fail(JH_ERR_ARG, "jh_rbnet_learn_heads_raw: a dueling network's call");
   const int64_t L = n->noisy ? n->nd.noise_len : 0;
   const size_t lsz = (size_t)B * n->NA;
   const float* nz = n->noisy ? d_noise : nullptr;
@@ -981,10 +1024,59 @@ JH_EXPORT int jh_rbnet_learn_heads(jh_rbnet* n, int32_t B, const float* d_noise,
   HeadJob hj[3] = {{n->params, nz, sin[0], d_logits},
                    {n->params, nz ? nz + L : nullptr, sin[0] + (size_t)B * n->in1, d_logits + lsz},
                    {n->target, nz ? nz + 2 * L : nullptr, sin[1], d_logits + 2 * lsz}};
-  int rc = rb_heads(n, hj, 3, B, jh_s(stream));
+  int rc = rb_heads(n, hj, 3, B, jh_s(stream), raw);
   if (rc) return rc;
   n->last_noise = d_noise;
+  n->raw_heads = raw;
+  n->dx_ready = 0;
   return JH_OK;
+}
+JH_EXPORT int jh_rbnet_learn_heads(jh_rbnet* n, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
+  return rb_learn_heads(n, B, d_noise, d_logits, false, stream);
+}
+// ... the same up to the advantage / value streams of the three forwards (xa, xv stay inside the network): jh_rbnet_c51_step forms the
+// logits in the loss kernel (one launch less, and the gradient comes back already pulled through the combine: one more)
+JH_EXPORT int jh_rbnet_learn_heads_raw(jh_rbnet* n, int32_t B, const float* d_noise, jh_stream stream) {
+  return rb_learn_heads(n, B, d_noise, nullptr, true, stream);
+}
+
+// Rainbow.learn's loss step (rainbow.py:160-235) on the network's own stream outputs, after jh_rbnet_learn_trunk + jh_rbnet_learn_heads_raw:
+//   launch 1  dueling combine of the three forwards (-> d_logits [3][B][A][K], bit-identical to jh_rbnet_learn_heads) + double-Q action +
+//             n-step projection + KL + priorities KL^alpha + d(loss)/d(xa), d(loss)/d(xv)   (jh_c51_block_kernel<true>)
+//   launch 2  batch statistics (d_stats, as jh_c51_loss) + the new priorities written into the sum tree's leaves at d_tree_idx
+//   launch 3  the tree climb (jh_per.hip) -- per == null: launch 2 is statistics only, no launch 3
+// Six launches before (heads' combine, loss, statistics, leaf write-back, climb, gradient through the combine).  jh_rbnet_backward(n, null)
+// continues from the gradient left in the network.
+JH_EXPORT int jh_rbnet_c51_step(jh_rbnet* n, jh_per* per, int32_t B, int32_t n_step, int32_t flags, const float* d_action, const float* d_reward,
+                                const float* d_done, const float* d_weights, const int64_t* d_tree_idx, float v_min, float v_max, float gamma,
+                                float alpha, float* d_logits, float* d_prio, float* d_kl, float* d_stats, jh_stream stream) {
+  JH_ARG(n && d_action && d_reward && d_done && d_logits && d_prio);
+  JH_ARG(n->dueling && n->K > 1 && n->K <= 256);
+  JH_ARG(B > 0 && B <= 1024 && B == n->last_B && n_step >= 0);
+  JH_ARG((flags & JH_C51_DOUBLE) != 0);
+  JH_ARG(!(flags & JH_C51_PER) || d_weights);
+  JH_ARG(!per || d_tree_idx);
+  if (!n->raw_heads) return jh_fail(JH_ERR_STATE, "jh_rbnet_c51_step without a preceding jh_rbnet_learn_heads_raw");
+  hipStream_t st = jh_s(stream);
+  const size_t B_ = (size_t)n->maxB, lsz = (size_t)B * n->NA;
+  C51Args a{};
+  a.B = B; a.A = n->A; a.K = n->K; a.n = n_step > 0 ? n_step : 1; a.flags = flags;
+  a.action = d_action; a.reward = d_reward; a.done = d_done; a.weights = d_weights; a.v_min = v_min; a.v_max = v_max; a.gamma = gamma;
+  a.alpha = alpha; a.prio = d_prio; a.kl = d_kl; a.stats = d_stats;
+  C51Duel d{};
+  for (int j = 0; j < 3; ++j) { d.xa[j] = n->xa + j * B_ * n->NA4; d.xv[j] = n->xv + j * B_ * n->K4; d.out[j] = d_logits + j * lsz; }
+  d.dxa = n->dxa; d.dxv = n->dxv; d.ld_a = n->NA4; d.ld_v = n->K4;
+  PerDeltaArgs pa{};
+  int rc;
+  if (per) {
+    rc = jh_per_delta_args(per, B, d_tree_idx, d_prio, JH_F32, &pa);
+    if (rc) return rc;
+  }
+  rc = jh_c51_run(n->ctx, a, &d, per ? &pa : nullptr, st);
+  if (rc) return rc;
+  n->raw_heads = 0;
+  n->dx_ready = 1;
+  return per ? jh_per_climb(per, B, d_tree_idx, st) : JH_OK;
 }
 
 JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits, jh_stream stream) {
@@ -995,12 +1087,36 @@ JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dty
   return jh_rbnet_learn_heads(n, B, d_noise, d_logits, stream);
 }
 
+static int rb_noisy_grad(jh_rbnet* n, hipStream_t st) {
+  int64_t blocks = (n->n_noisy + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  JH_LAUNCH(jh_rb_noisy_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n->nd, n->last_noise, n->grads, n->n_noisy);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+static int rb_parts_sum(jh_rbnet* n, int parts, hipStream_t st) {
+  const int n_w = 32 * n->Cin * 64, n_all = n_w + 32;
+  float* G = n->grads;
+  JH_LAUNCH(jh_rb_parts_sum_kernel, dim3((n_all + 31) / 32), dim3(256), 0, st, n->c1_part, G + n->seg_off[SEG_W1], G + n->seg_off[SEG_B1], n_w, n_all, parts);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+// what a deferred backward left undone (the gradient bucket is complete afterwards)
+static int rb_flush_grads(jh_rbnet* n, hipStream_t st) {
+  int rc = JH_OK;
+  if (n->pend_parts) rc = rb_parts_sum(n, n->pend_parts, st);
+  n->pend_parts = 0;
+  return rc;
+}
+
 // Backward of logits[0] of the last jh_rbnet_learn_forward: d_g = d(loss)/d(logits) [B][A][K]; fills the
 // gradient bucket (same layout as the parameters).  Effective weights of noise set 0 and all online
 // activations of the `state` rows are still in place.
-JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream) {
-  JH_ARG(n && d_g);
+static int rb_backward(jh_rbnet* n, const float* d_g, bool defer, jh_stream stream) {
+  JH_ARG(n != nullptr);
   if (!n->last_x) return jh_fail(JH_ERR_STATE, "jh_rbnet_backward without a preceding jh_rbnet_learn_forward");
+  if (!d_g && !n->dx_ready) return jh_fail(JH_ERR_STATE, "jh_rbnet_backward(null gradient) without a preceding jh_rbnet_c51_step");
+  n->pend_parts = 0;
   hipStream_t st = jh_s(stream);
   const int B = n->last_B, H = n->hidden, NA = n->NA, K = n->K, F = n->F, in1 = n->in1;
   const StreamW w0 = stream_w(n, n->params, 0);  // noise set 0 / the online parameters
@@ -1011,23 +1127,37 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
   const float* dxa = d_g;
   int ld_dxa = NA;
   if (n->dueling) {
-    JH_LAUNCH(jh_rb_duel_bwd_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, d_g, B, n->A, K, n->dxa, n->NA4, n->dxv, n->K4);
-    JH_LAUNCH_CHECK();
+    if (d_g) {
+      JH_LAUNCH(jh_rb_duel_bwd_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, d_g, B, n->A, K, n->dxa, n->NA4, n->dxv, n->K4);
+      JH_LAUNCH_CHECK();
+    }  // else: jh_rbnet_c51_step left the gradient in dxa / dxv
     dxa = n->dxa;
     ld_dxa = n->NA4;
   }
+  n->dx_ready = 0;
   TGemm g[4];
   int ng = 0, rc;
   // last stream layer(s): weight gradients (+ bias gradients as row sums) and data gradients (+ relu')
   const float* in_a = n->has_av1 ? hav0 : sin0;
   const int ld_in = n->has_av1 ? 2 * H : H;
   float* d_in = n->has_av1 ? n->dhav : dsin;
+  // factorised NoisyNet layers: d(sig) = d(mu) * f(e_in) f(e_out)^T and d(sig_b) = d(mu_b) * f(e_out) leave the weight-gradient GEMMs' epilogues
+  // beside d(mu), d(mu_b) (jh_tgemm.h: C2 / rowsum2).  Noise set 0 = [ei_a1 H][ej_a1 H][ei_v1 H][ej_v1 H][ei_a2 H][ej_a2 NA][ei_v2 H][ej_v2 K].
+  const bool sig_epi = n->noisy && !n->noise_independent;
+  const float* e0 = n->last_noise;
+  auto with_sigma = [&](TGemm& t, int seg_sig, int seg_sigb, const float* ej, const float* ei, int split, const float* ej2, const float* ei2) {
+    if (!sig_epi) return;
+    t.C2 = G + n->seg_off[seg_sig]; t.rowsum2 = G + n->seg_off[seg_sigb];
+    t.nz_m = ej; t.nz_n = ei; t.nz_split = split; t.nz_m2 = ej2; t.nz_n2 = ei2;
+  };
   g[ng++] = mk_gemm(NA, H, B, op_dense(OP_XCONT, dxa, ld_dxa), op_dense(OP_XCONT, in_a, ld_in), G + n->seg_off[SEG_MU_A2], H, TEPI_NONE, nullptr, nullptr, 0,
                     G + n->seg_off[SEG_MUB_A2]);
+  with_sigma(g[ng - 1], SEG_SIG_A2, SEG_SIGB_A2, e0 + 5 * H, e0 + 4 * H, NA, nullptr, nullptr);
   g[ng++] = mk_gemm(B, H, NA, op_dense(OP_KCONT, dxa, ld_dxa), op_dense(OP_XCONT, w0.a2, H), d_in, ld_in, TEPI_MASK, nullptr, in_a, ld_in);
   if (n->dueling) {
     g[ng++] = mk_gemm(K, H, B, op_dense(OP_XCONT, n->dxv, n->K4), op_dense(OP_XCONT, in_a + H, ld_in), G + n->seg_off[SEG_MU_V2], H, TEPI_NONE, nullptr, nullptr, 0,
                       G + n->seg_off[SEG_MUB_V2]);
+    with_sigma(g[ng - 1], SEG_SIG_V2, SEG_SIGB_V2, e0 + 6 * H + NA, e0 + 5 * H + NA, K, nullptr, nullptr);
     g[ng++] = mk_gemm(B, H, K, op_dense(OP_KCONT, n->dxv, n->K4), op_dense(OP_XCONT, w0.v2, H), d_in + H, ld_in, TEPI_MASK, nullptr, in_a + H, ld_in);
   }
   rc = launch_tgemm(n, "jh_tgemm_stream2_bwd", g, ng, st);
@@ -1035,15 +1165,15 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
   if (n->has_av1) {  // first stream layer (a1 | v1 stacked)
     g[0] = mk_gemm(2 * H, in1, B, op_dense(OP_XCONT, n->dhav, 2 * H), op_dense(OP_XCONT, sin0, in1), G + n->seg_off[SEG_MU_AV1], in1, TEPI_NONE, nullptr, nullptr, 0,
                    G + n->seg_off[SEG_MUB_AV1]);
+    // rows m < H are a1 (e_out at H + m, e_in at k), rows m >= H are v1 (e_out at 3H + (m - H) = 2H + m, e_in at 2H + k)
+    with_sigma(g[0], SEG_SIG_AV1, SEG_SIGB_AV1, e0 + H, e0, H, e0 + 2 * H, e0 + 2 * H);
     g[1] = mk_gemm(B, in1, 2 * H, op_dense(OP_KCONT, n->dhav, 2 * H), op_dense(OP_XCONT, w0.av1, in1), dsin, in1, TEPI_MASK, nullptr, sin0, in1);
     rc = launch_tgemm(n, "jh_tgemm_stream1_bwd", g, 2, st);
     if (rc) return rc;
   }
-  if (n->noisy) {
-    int64_t blocks = (n->n_noisy + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    JH_LAUNCH(jh_rb_noisy_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n->nd, n->last_noise, G, n->n_noisy);
-    JH_LAUNCH_CHECK();
+  if (n->noisy && !sig_epi) {  // independent noise (utils.py:73-76): eps is a matrix of its own, the elementwise kernel forms d(sig)
+    rc = rb_noisy_grad(n, st);
+    if (rc) return rc;
   }
   if (n->has_l) {  // l: F -> H
     g[0] = mk_gemm(H, F, B, op_dense(OP_XCONT, n->dh, H), op_dense(OP_XCONT, n->feat[0], F), G + n->seg_off[SEG_WL], F, TEPI_NONE, nullptr, nullptr, 0,
@@ -1094,28 +1224,47 @@ JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream)
     JH_LAUNCH_IDEM("jh_rb_conv1_wgrad_kernel", 2.0 * 32 * n->Cin * 64 * (double)B * n->P1, jh_rb_conv1_wgrad_kernel<UN>, dim3(parts), dim3(1024), 0, st, (const uint8_t*)n->last_x, n->dact1, n->c1_part, n->Cin, c1.H, c1.W, c1.OW, n->P1,
               1.0f / (float)c1.OW, gpi, total, per);
     JH_LAUNCH_CHECK();
-    JH_LAUNCH(jh_rb_parts_sum_kernel, dim3((n_all + 31) / 32), dim3(256), 0, st, n->c1_part, G + n->seg_off[SEG_W1], G + n->seg_off[SEG_B1], n_w, n_all, parts);
-    JH_LAUNCH_CHECK();
-    return JH_OK;
+    if (defer && n->seg_off[SEG_W1] == 0 && n->seg_off[SEG_B1] == n_w && n->seg_off[SEG_W2] == n_all) {
+      n->pend_parts = parts;
+      return JH_OK;
+    }
+    return rb_parts_sum(n, parts, st);
   }
   g[0] = mk_gemm(32, n->Cin * 64, B * n->P1, op_dense(OP_XCONT, n->dact1, 32), op_conv(OP_NCHW_X, n->last_x, n->last_x_u8, n->c1), G + n->seg_off[SEG_W1],
                  n->Cin * 64, TEPI_NONE, nullptr, nullptr, 0, G + n->seg_off[SEG_B1]);
   return launch_tgemm(n, "jh_tgemm_conv1_bwd", g, 1, st);
+}
+JH_EXPORT int jh_rbnet_backward(jh_rbnet* n, const float* d_g, jh_stream stream) { return rb_backward(n, d_g, false, stream); }
+// The same, but one tail stays undone -- the sum of conv1's weight-gradient partials -- for jh_rbnet_optim_step to do inside the optimizer's
+// launch (which it does when no clipping is asked for; otherwise, and in jh_rbnet_flush_grads, it runs as the launch it was).  Whoever reads
+// the gradient bucket before the optimizer step (a data-parallel all-reduce, a test) calls jh_rbnet_flush_grads first or uses jh_rbnet_backward.
+JH_EXPORT int jh_rbnet_backward_deferred(jh_rbnet* n, const float* d_g, jh_stream stream) { return rb_backward(n, d_g, true, stream); }
+JH_EXPORT int jh_rbnet_flush_grads(jh_rbnet* n, jh_stream stream) {
+  JH_ARG(n != nullptr);
+  return rb_flush_grads(n, jh_s(stream));
 }
 
 JH_EXPORT int jh_rbnet_optim_step(jh_rbnet* n, int32_t optimizer, float max_norm, jh_stream stream) {
   JH_ARG(n != nullptr);
   JH_ARG(optimizer == 0 || optimizer == 1);
   hipStream_t st = jh_s(stream);
+  static const bool kFuse = !(getenv("JH_RB_OPTIM_FUSE") && atoi(getenv("JH_RB_OPTIM_FUSE")) == 0);
+  OptFuse f{};
+  if (max_norm <= 0.f && kFuse && n->pend_parts) {  // (the norm needs the finished gradient)
+    f.n_c1 = 32 * n->Cin * 64 + 32; f.parts = n->pend_parts; f.c1_part = n->c1_part; f.extra_wgs = (f.n_c1 + 31) / 32;
+    n->pend_parts = 0;
+  }
+  int rc = rb_flush_grads(n, st);  // whatever is still pending runs as the launch it was
+  if (rc) return rc;
   if (max_norm > 0.f) {
     JH_LAUNCH(jh_rb_gradnorm_kernel, dim3(256), dim3(256), 0, st, n->n_params, n->grads, n->norm_partial);
     JH_LAUNCH_CHECK();
   }
   static const unsigned kOptGrid = getenv("JH_RB_OPTIM_GRID") ? (unsigned)atoi(getenv("JH_RB_OPTIM_GRID")) : 512u;
   if (optimizer == 0) {
-    JH_LAUNCH(jh_rb_optim_kernel<0>, dim3(kOptGrid), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
+    JH_LAUNCH(jh_rb_optim_kernel<0>, dim3(kOptGrid + f.extra_wgs), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm, f);
   } else {
-    JH_LAUNCH(jh_rb_optim_kernel<1>, dim3(kOptGrid), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm);
+    JH_LAUNCH(jh_rb_optim_kernel<1>, dim3(kOptGrid + f.extra_wgs), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v, n->hyper, n->ticket, n->norm_partial, 256, max_norm, f);
   }
   JH_LAUNCH_CHECK();
   return JH_OK;

@@ -29,6 +29,13 @@ struct TGemm {
   const float* aux;    // MASK: forward activation, same indexing as C
   int ldaux;
   float* rowsum;       // optional [M]: sum_k A(m, k)  (bias gradients)
+  // optional second output for the weight gradient of a NoisyNet layer with factorised noise (network/utils.py:60-70: W = mu + sig * f(e_in) f(e_out)^T):
+  //   C2[m][n] = C[m][n] * (f(nz_n[n]) * f(nz_m[m]))   = d(sig) beside d(mu),     rowsum2[m] = rowsum[m] * f(nz_m[m])   = d(sig_b) beside d(mu_b)
+  // rows m >= nz_split take the second pair of noise vectors (two layers stacked into one matrix: a1 | v1)
+  float* C2;
+  float* rowsum2;
+  const float *nz_m, *nz_n, *nz_m2, *nz_n2;
+  int nz_split;
   int splitk, tiles_m, tiles_n;
   int wg_begin;        // first workgroup of this problem in the linear grid (tiles x splits workgroups each)
   float* ws;           // split-K partials [splitk][tiles][BM*BN + BM]
@@ -47,6 +54,8 @@ __device__ __forceinline__ static float u8_unit(uint32_t b) {
   const float q = x * r;
   return fmaf(fmaf(-q, 255.0f, x), r, q);
 }
+
+__device__ __forceinline__ static float jh_noise_f(float e) { return copysignf(sqrtf(fabsf(e)), e); }  // utils.py:66-67 (sign(0) = 0 either way)
 
 // ---- host-side helpers
 inline Opnd op_dense(int mode, const float* p, int ld) {

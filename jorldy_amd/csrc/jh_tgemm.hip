@@ -147,12 +147,22 @@ __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f
 #pragma unroll
       for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
         const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
-        if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = epilogue(acc[i][j][q], m, n);
+        if (m < g.M && n < g.N) {
+          const float v = epilogue(acc[i][j][q], m, n);
+          g.C[(size_t)m * g.ldc + n] = v;
+          if (g.C2) {  // d(sig) = d(mu) * eps, eps = f(e_in[n]) * f(e_out[m]) (jh_rb_noisy_grad_kernel's expression)
+            const bool second = m >= g.nz_split;
+            g.C2[(size_t)m * g.ldc + n] = v * (jh_noise_f((second ? g.nz_n2 : g.nz_n)[n]) * jh_noise_f((second ? g.nz_m2 : g.nz_m)[m]));
+          }
+        }
       }
     }
     if (want_rs && wn == 0 && kq == 0) {
       const int m = m0 + wm * 16 * TM + 16 * i + r;
-      if (m < g.M) g.rowsum[m] = rs[i];
+      if (m < g.M) {
+        g.rowsum[m] = rs[i];
+        if (g.rowsum2) g.rowsum2[m] = rs[i] * jh_noise_f((m >= g.nz_split ? g.nz_m2 : g.nz_m)[m]);
+      }
     }
   }
 }

@@ -3,6 +3,7 @@
 Every function enqueues HIP kernels from libjorldy_hip.so on torch's current stream and
 returns torch tensors that alias the outputs.  Nothing here computes on the CPU.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -709,6 +710,44 @@ def td_loss(q, q_next_target, action, reward, done, gamma, q_next_online=None, w
     return g, prio, stats
 
 
+@contextlib.contextmanager
+def graph_capture(g):
+    """`with torch.cuda.graph(g, capture_error_mode="thread_local")` plus the two things this torch build leaves to the caller:
+
+    * garbage collection.  torch.cuda.graph.__enter__ only collects when torch.compiler.config.force_cudagraph_gc is set (it is not): a dead
+      reference cycle left by an EARLIER agent (agent <-> collector, owning device buffers, pinned memory, events) is then finalized by
+      whichever Python allocation happens to trip the cyclic collector -- and if that is one inside the capture, the hipFree / hipHostFree /
+      hipEventDestroy comes from the capturing thread and invalidates the capture (hipErrorStreamCaptureInvalidated at the next launch;
+      seen in ~1 of 8 runs of the GPU suite, always in a test that follows many agent + collector pairs, never in that test alone).
+      So: one full collection in front, the automatic collector off while capturing.
+    * a failed capture.  torch.cuda.graph.__exit__ raises out of capture_end() BEFORE it restores the stream: the capture stream -- torch's
+      process-wide default one -- stays current and stays capturing, and everything enqueued afterwards fails.  Here the previous stream
+      is made current again, the abandoned capture is ended, and torch is given a fresh default capture stream; the caller's eager
+      fallback then runs on a healthy stream."""
+    import gc
+
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    prev = torch.cuda.current_stream()
+    cm = torch.cuda.graph(g, capture_error_mode="thread_local")  # other threads (batched actors, staging ring, collector) keep issuing HIP work on their own streams
+    try:
+        with cm:
+            yield
+    except BaseException:
+        try:
+            torch.cuda.set_stream(prev)
+            L.load().jh_stream_abort_capture(C.c_void_p(cm.capture_stream.cuda_stream))
+            if torch.cuda.graph.default_capture_stream is cm.capture_stream:
+                torch.cuda.graph.default_capture_stream = None
+        except Exception:
+            pass
+        raise
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 def c51_loss(logit, target_logit, action, reward, done, v_min, v_max, gamma, next_logit_online=None, weights=None, alpha=0.0, n_step=0, shift_max=False, stats=None):
     """logit/target_logit/next_logit_online [B,A,K].  Returns (grad_logit, prio [B], kl [B], stats f32[8])."""
     lib = L.load()
@@ -966,9 +1005,42 @@ class RainbowNet:
         L.check(self.lib.jh_rbnet_learn_heads(self.h, int(B), L.ptr(noise), L.ptr(out), L.stream_ptr()))
         return out
 
-    def backward(self, g):
-        assert g.is_contiguous() and g.dtype == torch.float32
-        L.check(self.lib.jh_rbnet_backward(self.h, L.ptr(g), L.stream_ptr()))
+    def learn_heads_raw(self, B, noise):
+        """learn_heads up to the advantage / value streams; `c51_step` forms the logits inside the loss kernel."""
+        assert noise is None or noise.is_contiguous()
+        L.check(self.lib.jh_rbnet_learn_heads_raw(self.h, int(B), L.ptr(noise), L.stream_ptr()))
+
+    def c51_step(self, tree, idx, action, reward, done, weights, v_min, v_max, gamma, alpha, n_step, logits, stats=None):
+        """Rainbow.learn()'s loss step in three launches (jh_rbnet_c51_step): dueling combine of the three forwards (-> logits [3, B, A, K])
+        + double-Q projection + KL + the gradient back through the combine (stays in the network: `backward(None)`); statistics + the
+        priorities KL^alpha into the leaves `idx` (tree space, int64) of `tree` (ops.SumTree or None); the climb.  -> (prio [B], kl [B], stats f32[8])."""
+        lib = self.lib
+        B = int(logits.shape[1])
+        assert logits.is_contiguous() and logits.dtype == torch.float32 and tuple(logits.shape) == (3, B, self.A, self.K)
+        prio = torch.empty(B, dtype=torch.float32, device=self.device)
+        kl = torch.empty(B, dtype=torch.float32, device=self.device)
+        if stats is None:
+            stats = torch.empty(8, dtype=torch.float32, device=self.device)
+        r, d = _f32(reward).reshape(B, -1), _f32(done).reshape(B, -1)
+        assert r.shape[1] == max(n_step, 1) and d.shape == r.shape
+        flags = L.JH_C51_DOUBLE | (L.JH_C51_PER if weights is not None else 0)
+        if tree is not None:
+            assert idx.dtype == torch.int64 and idx.is_cuda and idx.is_contiguous() and idx.numel() == B
+        L.check(lib.jh_rbnet_c51_step(self.h, None if tree is None else tree.h, B, int(n_step), flags, L.ptr(_f32(action).reshape(-1)), L.ptr(r), L.ptr(d),
+                                      L.ptr(None if weights is None else _f32(weights).reshape(-1)), L.ptr(None if tree is None else idx), float(v_min), float(v_max),
+                                      float(gamma), float(alpha), L.ptr(logits), L.ptr(prio), L.ptr(kl), L.ptr(stats), L.stream_ptr()))
+        return prio, kl, stats
+
+    def backward(self, g, defer=False):
+        """g = d(loss)/d(logits of online(state)), or None after `c51_step`.  defer: leave d(sigma) = d(mu) * eps and the sum of conv1's
+        weight-gradient partials to `optim_step` (it folds them into the optimizer pass when there is no clipping); `flush_grads`
+        completes the bucket for a reader in between."""
+        assert g is None or (g.is_contiguous() and g.dtype == torch.float32)
+        fn = self.lib.jh_rbnet_backward_deferred if defer else self.lib.jh_rbnet_backward
+        L.check(fn(self.h, L.ptr(g), L.stream_ptr()))
+
+    def flush_grads(self):
+        L.check(self.lib.jh_rbnet_flush_grads(self.h, L.stream_ptr()))
 
     def adam_step(self):
         L.check(self.lib.jh_rbnet_adam_step(self.h, L.stream_ptr()))

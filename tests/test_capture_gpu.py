@@ -1,0 +1,109 @@
+"""hipGraph capture hygiene of the agents' learn() (jorldy_amd.ops.graph_capture).
+
+Round 4 chased an intermittent failure of the GPU suite (about 1 run in 8): the capture of PPO.learn() in a test that follows many
+agent + collector pairs died with hipErrorStreamCaptureInvalidated between two launches that have nothing but Python between them,
+and every later test failed because torch.cuda.graph.__exit__ had raised before restoring the stream.  Cause: this torch build does
+not garbage-collect when a capture begins (torch.compiler.config.force_cudagraph_gc is False), so a dead agent <-> collector cycle
+of an earlier test was finalized by the cyclic collector INSIDE the capture, and its hipFree from the capturing thread invalidates a
+thread_local capture.  The tests below reproduce the mechanism deterministically and pin the two remedies."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Owner:
+    """A HIP-resource owner inside a reference cycle: only the cyclic collector can free it (like agent <-> collector)."""
+
+    def __init__(self):
+        from jorldy_amd import ops
+
+        self.tree = ops.SumTree(64, 1e-3, device="cuda:0")  # jh_per_destroy -> hipFree
+        self.me = self
+
+
+def test_a_finalizer_inside_a_raw_capture_invalidates_it_and_graph_capture_prevents_that():
+    from jorldy_amd import ops
+
+    x = torch.randn(1024, device="cuda")
+    out = torch.zeros(1, device="cuda")
+    ops.mean_into(x, out)  # warm (scratch sizes, lazy module state)
+    torch.cuda.synchronize()
+
+    # --- the mechanism: garbage that owns device memory, collected while a thread_local capture is open
+    gc.collect()
+    _Owner()  # unreachable at once, but only the cyclic collector can see that
+    g = torch.cuda.CUDAGraph()
+    prev = torch.cuda.current_stream()
+    failed = False
+    try:
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            ops.mean_into(x, out)
+            gc.collect()  # what any allocation may trigger: jh_per_destroy -> hipFree on the capturing thread
+            ops.mean_into(x, out)
+    except Exception:
+        failed = True
+    finally:
+        # leave the process healthy whatever happened (this is what ops.graph_capture does on failure)
+        import ctypes as C
+
+        from jorldy_amd import _lib as L
+
+        cap = torch.cuda.graph.default_capture_stream
+        torch.cuda.set_stream(prev)
+        if cap is not None:
+            L.load().jh_stream_abort_capture(C.c_void_p(cap.cuda_stream))
+            torch.cuda.graph.default_capture_stream = None
+    torch.cuda.synchronize()
+    assert failed, "a hipFree from the capturing thread no longer invalidates a thread_local capture: the precaution in ops.graph_capture can go"
+
+    # --- the remedy: the same garbage, the same body, through ops.graph_capture
+    _Owner()  # collected by the helper before the capture begins
+    held = [_Owner()]
+    made_inside = []
+    g2 = torch.cuda.CUDAGraph()
+    with ops.graph_capture(g2):
+        assert not gc.isenabled()
+        ops.mean_into(x, out)
+        held.clear()  # garbage born inside the capture (a cycle: no refcount free) stays until the capture is over
+        made_inside.append([[i] for i in range(20000)])  # allocation churn that would trip the automatic collector
+        ops.mean_into(x, out)
+    assert gc.isenabled()
+    out.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(out), float(x.mean()), rtol=1e-5)
+    gc.collect()
+    torch.cuda.synchronize()
+
+
+def test_b_failed_capture_leaves_a_healthy_stream_behind():
+    from jorldy_amd import ops
+
+    x = torch.randn(256, device="cuda")
+    out = torch.zeros(1, device="cuda")
+    ops.mean_into(x, out)
+    torch.cuda.synchronize()
+    before = torch.cuda.current_stream()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(Exception):
+        with ops.graph_capture(g):
+            ops.mean_into(x, out)
+            torch.cuda.synchronize()  # not allowed while capturing: invalidates
+            ops.mean_into(x, out)
+    assert torch.cuda.current_stream() == before and gc.isenabled()
+    # eager work and a new capture both run
+    out.zero_()
+    ops.mean_into(x, out)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(out), float(x.mean()), rtol=1e-5)
+    g2 = torch.cuda.CUDAGraph()
+    with ops.graph_capture(g2):
+        ops.mean_into(x, out)
+    out.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(out), float(x.mean()), rtol=1e-5)

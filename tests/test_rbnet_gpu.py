@@ -319,3 +319,89 @@ def test_rbnet_independent_noise_matches_float64():
     l0_32.backward(gl)
     nat.backward(gl.cuda().contiguous())
     _grads_vs_exact(nat, ref64, ref32)
+
+
+@pytest.mark.parametrize("head,S,A,K,H,B", [("mlp", 4, 3, 51, 32, 32), ("cnn", (4, 84, 84), 6, 51, 64, 8), ("mlp", 6, 5, 21, 16, 33)])
+def test_rainbow_fused_step_is_bit_identical_to_the_separate_calls(head, S, A, K, H, B):
+    """jh_rbnet_c51_step (dueling combine + C51 + gradient through the combine in one launch; statistics + PER leaf write-back in one;
+    climb) followed by the deferred backward (d(sigma) and conv1's partial sums folded into the optimizer pass) against the calls it
+    replaces -- jh_rbnet_learn_heads, jh_c51_loss, jh_per_update, jh_rbnet_backward, jh_rbnet_optim_step: every output byte for byte
+    (logits of the three forwards, priorities, KL, statistics, the whole sum tree with duplicate leaves in the batch, the gradient
+    bucket, weights and both Adam moments after the step)."""
+    import torch
+    from jorldy_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    (r64, r32), _, nat_a = _mk(head, S, A, K, H, B, seed=5)
+    _, _, nat_b = _mk(head, S, A, K, H, B, seed=5)
+    x_dev, _ = _inputs(head, S, 2 * B, g)
+    noise = torch.randn(3, nat_a.noise_len, generator=g).cuda()
+    n_step, N = 3, 64
+    action = torch.randint(0, A, (B, 1), generator=g).float().cuda()
+    reward = torch.randn(B, n_step, generator=g).cuda()
+    done = (torch.rand(B, n_step, generator=g) < 0.2).float().cuda()
+    w = (torch.rand(B, generator=g) + 0.1).cuda()
+    idx = (torch.randint(0, N, (B,), generator=g) + (N - 1)).cuda()  # tree space; B > distinct leaves in places: duplicates
+    idx[1] = idx[0]
+    trees = []
+    for _ in range(2):
+        t = ops.SumTree(N, 1e-3, device="cuda:0")
+        t.push(N, (np.arange(N, dtype=np.float64) % 7 + 0.5))
+        trees.append(t)
+    out = {}
+    for tag, nat, tree in (("sep", nat_a, trees[0]), ("fused", nat_b, trees[1])):
+        nat.set_hyper(1e-3, 0.9, 0.999, 1e-8, 0)
+        nat.m.zero_(); nat.v.zero_()
+        logits = torch.empty(3, B, A, K, device="cuda")
+        stats = torch.zeros(8, device="cuda")
+        for it in range(2):  # two steps: the second runs on moments / weights the first produced
+            nat.learn_trunk(x_dev, B)
+            if tag == "sep":
+                lg = nat.learn_heads(B, noise, logits)
+                gl, prio, kl, _ = ops.c51_loss(lg[0], lg[2], action, reward, done, -2.0, 3.0, 0.99, next_logit_online=lg[1], weights=w, alpha=0.6, n_step=n_step, stats=stats)
+                tree.update(idx, prio)
+                nat.backward(gl)
+            else:
+                nat.learn_heads_raw(B, noise)
+                prio, kl, _ = nat.c51_step(tree, idx, action, reward, done, w, -2.0, 3.0, 0.99, 0.6, n_step, logits, stats=stats)
+                nat.backward(None, defer=True)
+            nat.optim_step("adam", None)
+        torch.cuda.synchronize()
+        out[tag] = dict(logits=logits.cpu(), prio=prio.cpu(), kl=kl.cpu(), stats=stats.cpu()[:5], tree=torch.from_numpy(tree.dump()), maxp=torch.tensor(tree.state()["max_priority"]),
+                        grads=nat.grads.cpu().clone(), params=nat.params.cpu().clone(), m=nat.m.cpu().clone(), v=nat.v.cpu().clone())
+    for k in out["sep"]:
+        a, b = out["sep"][k], out["fused"][k]
+        assert torch.equal(a, b), (k, float((a.double() - b.double()).abs().max()))
+    assert float(out["fused"]["grads"].abs().max()) > 0 and float(out["fused"]["prio"].max()) > 0
+
+
+def test_rainbow_deferred_backward_with_clipping_and_flush():
+    """The deferred tails run as their own launches when clipping needs the finished gradient first (jh_rbnet_optim_step, max_norm > 0)
+    and in jh_rbnet_flush_grads (what a data-parallel learner calls in front of its all-reduce): same bytes as jh_rbnet_backward."""
+    import torch
+    from jorldy_amd import ops
+
+    head, S, A, K, H, B = "cnn", (4, 84, 84), 4, 51, 32, 6
+    g = torch.Generator().manual_seed(3)
+    nets = [_mk(head, S, A, K, H, B, seed=9)[2] for _ in range(3)]
+    x_dev, _ = _inputs(head, S, 2 * B, g)
+    noise = torch.randn(3, nets[0].noise_len, generator=g).cuda()
+    gl = (torch.randn(B, A, K, generator=g) * 0.05).cuda()
+    res = []
+    for mode, nat in zip(("plain", "deferred_clip", "deferred_flush"), nets):
+        nat.set_hyper(1e-3, 0.9, 0.999, 1e-8, 0)
+        nat.m.zero_(); nat.v.zero_()
+        logits = torch.empty(3, B, A, K, device="cuda")
+        nat.learn_trunk(x_dev, B)
+        nat.learn_heads(B, noise, logits)
+        nat.backward(gl, defer=mode != "plain")
+        if mode == "deferred_flush":
+            nat.flush_grads()
+            g_mid = nat.grads.cpu().clone()
+        nat.optim_step("adam", 0.5)
+        torch.cuda.synchronize()
+        res.append(dict(grads=nat.grads.cpu().clone(), params=nat.params.cpu().clone(), m=nat.m.cpu().clone(), v=nat.v.cpu().clone()))
+    for r in res[1:]:
+        for k in r:
+            assert torch.equal(res[0][k], r[k]), k
+    assert float(g_mid.abs().max()) > 0
