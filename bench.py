@@ -363,7 +363,7 @@ def hopper_leg(rank, world, local_rank, dist, iters):
     collector on the synthetic control env."""
     W, B = max(1, 32 // world), max(1, 2048 // world)
     e2e = W <= 16
-    r = _tool("bench_hopper").hopper_leg(iters=iters, warmup=2, workers=W, batch=B, e2e=e2e, dist=dist if world > 1 else None, device=f"cuda:{local_rank}")
+    r = _tool("bench_hopper").hopper_leg(iters=iters, warmup=4, workers=W, batch=B, e2e=e2e, dist=dist if world > 1 else None, device=f"cuda:{local_rank}")
     note = "minibatch " + str(B) + " rows: " + ("LDS-tiled engine (jh_tgemm_ppo_*)" if B >= 1024 else "latency-oriented four / five launch update (jh_pmb_*)")
     r = dict(metric="learner transitions/s (PPO, config.ppo.mujoco Hopper shapes)", value=r["learner_transitions_per_s"], unit="transitions/s", scaling="strong",
              config={"workload": r.pop("workload"), "parallelism": f"dp{world}", "workers_per_gpu": W, "batch_per_gpu": B}, roofline=_dominant_mfma(r["lib_kernels"], note), **r)

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 
-def hopper_leg(iters=10, warmup=3, workers=32, batch=2048, e2e=False, dist=None, device="cuda"):
+def hopper_leg(iters=10, warmup=4, workers=32, batch=2048, e2e=False, dist=None, device="cuda"):
     """One measurement at config.ppo.mujoco shapes -> dict (bench.py embeds it as its `hopper` object).  dist: torch.distributed with
     an initialised process group -> data-parallel learners (one flat all-reduce of the gradient bucket per minibatch)."""
     from jorldy_amd import ops
@@ -116,7 +116,7 @@ def hopper_leg(iters=10, warmup=3, workers=32, batch=2048, e2e=False, dist=None,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=4, help="untimed iterations: 1 eager, 2 captures the split graphs, 3 eager with pre-drawn lists, 4 captures the whole-learn graph")
     ap.add_argument("--workers", type=int, default=32)
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--e2e", action="store_true", help="per-GPU share of configs[4] with the native collector on the synthetic control env (4 workers, minibatch 256)")
