@@ -167,6 +167,30 @@ def rainbow_cpu_reference(updates=8, warm=2):
             "sample": f"{updates} Rainbow.learn() calls (B=32, (4,84,84) uint8, N=1e6 sum tree, {fill} stored), torch CPU {cores} threads"}
 
 
+def hopper_cpu_reference(W=32, T=2048, B=2048, epochs=10):
+    """The reference's PPO.learn on this box's host cores at config.ppo.mujoco's Hopper shapes (port: oracle/ppo_port.py, the learner the
+    cartpole baseline uses, continuous heads): ONE learn() over the 65 536 transitions of a 32-worker x 2048-step rollout -- np.stack of
+    the per-transition dicts, the two no-grad passes, the Python GAE loop, 10 epochs x 32 minibatches of 2048 -- torch CPU, 8 threads.
+    The learner side only, like the `hopper` leg's N = 1 value it stands beside (VERDICT r3 weak #11)."""
+    from oracle import ppo_port as P
+
+    cores = min(8, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    S, A, M = 11, 3, W * T
+    ag = P.PPOPort(S, A, 512, True, 3e-4, 0.99, B, T, epochs, 0.95, 0.2, 0.5, 0.0, 0.5, run_step=1e6)
+    rng = np.random.RandomState(0)
+    st, ac, rw = rng.randn(M, S).astype(np.float32), np.tanh(rng.randn(M, A)).astype(np.float32), rng.randn(M, 1).astype(np.float32)
+    ns, dn = rng.randn(M, S).astype(np.float32), rng.rand(M, 1) < 1e-3
+    ag.memory.store([{"state": st[i : i + 1], "action": ac[i : i + 1], "reward": rw[i : i + 1], "next_state": ns[i : i + 1], "done": dn[i : i + 1]} for i in range(M)])
+    t0 = time.perf_counter()
+    ag.learn()
+    dt = time.perf_counter() - t0
+    return {"value": M / dt, "unit": "transitions/s", "s_per_learn": dt, "cores": cores, "kind": "port", "reference_present": os.path.isdir("/root/reference"),
+            "sample": f"one PPO.learn() over {M} transitions (W={W}, T={T}), {epochs} epochs x {M // B} minibatches of {B}, S=11, A=3 continuous, hidden 512, torch CPU {cores} threads"}
+
+
 # ------------------------------------------------------------------------------------------------- profiles/
 def _latest(pattern):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
@@ -666,12 +690,18 @@ def main():
         out["apex"] = apex_leg(args.apex_actors, args.apex_updates, args.apex_buffer, args.apex_prefill)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters, W, T)
+        if "hopper" in out:  # CPU work last: nothing on the GPU legs' host side shares the cores with it
+            try:
+                out["hopper"]["cpu_reference"] = hopper_cpu_reference(epochs=10 if args.cpu_baseline_iters >= 3 else 1)
+            except Exception as e:
+                out["hopper"]["cpu_reference"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         # the secondary legs' headline numbers once more, compact and LAST on the line: a truncated tail still carries them
         leg = lambda k, f: (out.get(k) or {}).get(f)
         out["legs"] = {"ppo_env_transitions_s": out["value"], "ppo_ms_per_step": ms_per_step, "ppo_x_cpu_baseline": (out["value"] / out["cpu_baseline"]["value"]) if out.get("cpu_baseline") else None,
                        "rainbow_updates_s": leg("rainbow", "value"), "apex_env_steps_s": leg("apex", "value"), "apex_updates_s": leg("apex", "learner_updates_per_s"),
-                       "hopper_transitions_s": leg("hopper", "value")}
+                       "hopper_transitions_s": leg("hopper", "value"),
+                       "hopper_x_cpu_reference": (leg("hopper", "value") / out["hopper"]["cpu_reference"]["value"]) if (out.get("hopper") or {}).get("cpu_reference", {}).get("value") else None}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

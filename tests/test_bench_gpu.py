@@ -54,3 +54,7 @@ def test_bench_emits_one_contract_json_line():
     lg = d["legs"]
     assert lg["ppo_env_transitions_s"] == d["value"] and lg["rainbow_updates_s"] == rb["value"] and lg["apex_env_steps_s"] == ax["value"] and lg["hopper_transitions_s"] == hp["value"]
     assert d["acting"]["timesteps_per_exchange"] == 2
+    # the Hopper leg has the reference's learner on the box's host cores beside it
+    hc = hp["cpu_reference"]
+    assert "error" not in hc, hc
+    assert hc["kind"] == "port" and hc["unit"] == hp["unit"] and hc["value"] > 0 and abs(lg["hopper_x_cpu_reference"] - hp["value"] / hc["value"]) < 1e-6 * lg["hopper_x_cpu_reference"]
