@@ -8,6 +8,7 @@ B = 32, each rank with its own rollout / replay shard and its own index lists.
       own learning rate, i.e. with the value clamp active: the critic's max(mean, mean) is taken over the global minibatch;
   (c) the sharded PER importance weights == those of a single logical sum tree over both shards (per_buffer.py:88-94);
   (d) `bench.py --gpus 2` runs 3 steps through the same launch / pinning / barrier plumbing.
+The same checks with rank r on GPU r over RCCL live in tests/test_zz_rccl_two_gpus_gpu.py (they need two GPUs, and run last).
 """
 import os
 import socket
@@ -58,22 +59,6 @@ def _run_ranks(mode, tmp_path, world=2, backend="gloo", extra_env=None):
 
 def test_ppo_native_two_ranks_equal_one_learner_on_the_concatenated_batch(tmp_path, monkeypatch):
     _check_ppo_two_ranks(_run_ranks("ppo", tmp_path), monkeypatch)
-
-
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need two GPUs (the driver's 8-GPU node; the builder's box has one)")
-@pytest.mark.parametrize("inject", ["", "create"])
-def test_ppo_native_two_ranks_over_rccl_equal_one_learner(tmp_path, monkeypatch, inject):
-    """The same equality with rank r on GPU r over RCCL: the library's own communicator (jh_comm_create from a torch-broadcast id,
-    the all-reduces of the gradient bucket and of the critic sums captured into the learn() graph) before the bench meets it.
-    inject = create: jh_comm_create fails on every rank -> all ranks fall back to torch.distributed's collectives TOGETHER."""
-    _check_ppo_two_ranks(_run_ranks("ppo", tmp_path, backend="nccl", extra_env={"JH_COMM_INJECT": inject} if inject else None), monkeypatch)
-
-
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need two GPUs")
-def test_rainbow_native_two_ranks_over_rccl_identical_weights(tmp_path):
-    r0, r1 = _run_ranks("rainbow", tmp_path, backend="nccl")
-    assert np.array_equal(r0["params"], r1["params"]) and np.array_equal(r0["target"], r1["target"])
-    assert np.all(np.isfinite(r0["losses"])) and np.all(np.isfinite(r1["losses"]))
 
 
 @pytest.mark.parametrize("inject,kind", [("", "rccl"), ("id", "torch"), ("create", "torch")])
