@@ -621,7 +621,7 @@ def test_device_normal_source_statistics_and_graph_replay():
     y.zero_()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):  # garbage collector held off while capturing
         again.fill(y)
     outs = []
     for _ in range(3):
