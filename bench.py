@@ -212,19 +212,34 @@ def _kmatch(key, name):
     return key in name
 
 
-def rocprof_avg_us(kernel_substr, pattern="r*_bench_kernel_stats.csv"):  # other commands' summaries: pattern="r*_apex_kernel_stats.csv"
-    """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command."""
+def rocprof_rows(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
+    """Every row of the committed rocprofv3 --kernel-trace --stats summary of this command whose symbol matches:
+    [(symbol, calls, avg_us)], summary path."""
     path = _latest(pattern)
     if path is None:
-        return None, None
-    best = None
+        return [], None
+    rows = []
     with open(path) as f:
         for row in csv.DictReader(f):
             if _kmatch(kernel_substr, row["Name"]):
-                c = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
-                if best is None or c[0] > best[0]:
-                    best = c
-    return (best[1] if best else None), os.path.relpath(path, ROOT)
+                rows.append((row["Name"][:96], int(row["Calls"]), float(row["AverageNs"]) / 1e3))
+    return rows, os.path.relpath(path, ROOT)
+
+
+def rocprof_avg_us(kernel_substr, pattern="r*_bench_kernel_stats.csv", live_avg_us=None):  # other commands' summaries: pattern="r*_apex_kernel_stats.csv"
+    """Average duration of a kernel in the committed rocprofv3 summary.  One launch NAME can be several SYMBOLS (the grouped GEMM
+    engine's staged `jh_tgemm_kernel<TM,TN,TAG>` and LDS-DMA `jh_tgemm_dma_kernel<TAG>` forms of one call site: the Ape-X leg's
+    acting copy runs the first at B = 64, its learner the second at B = 512).  Round 4 kept the row with the most CALLS -- the acting
+    copy's -- next to the learner's live average.  Now: with a live average, the row closest to it (ratio);
+    without one, the row with the most total time.  The caller gets every candidate row too (`rocprof_rows`)."""
+    rows, src = rocprof_rows(kernel_substr, pattern)
+    if not rows:
+        return None, src
+    if live_avg_us:
+        best = min(rows, key=lambda r: abs(np.log(max(r[2], 1e-9) / live_avg_us)))
+    else:
+        best = max(rows, key=lambda r: r[1] * r[2])
+    return best[2], src
 
 
 def pmc_traffic(kernel_substr, pattern="r*_pmc_bench.json"):
@@ -244,7 +259,7 @@ def mfma_entry(name, n, ms, work, rocprof_key):
     avg_s = ms / n * 1e-3
     per_launch = work / n
     achieved = per_launch / avg_s / 1e12
-    rp, src = rocprof_avg_us(rocprof_key)
+    rp, src = rocprof_avg_us(rocprof_key, live_avg_us=avg_s * 1e6)
     e = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
          "traffic": pmc_traffic(rocprof_key), "launches": n, "avg_us": avg_s * 1e6, "flops_per_launch": per_launch, "rocprof_avg_us": rp, "rocprof_summary": src}
     return e
@@ -373,7 +388,10 @@ def _dominant_mfma(kern, note, stats_pattern=None, pmc_pattern=None):
     e = {"kernel": k, "bound": "mfma", "achieved": v["TFLOP/s"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": v["TFLOP/s"] / MFMA_F32_PEAK_TFLOPS,
          "avg_us": v["avg_us"], "traffic": None, "note": note}
     if stats_pattern:
-        e["rocprof_avg_us"], e["rocprof_summary"] = rocprof_avg_us(k, stats_pattern)
+        e["rocprof_avg_us"], e["rocprof_summary"] = rocprof_avg_us(k, stats_pattern, live_avg_us=v["avg_us"])
+        rows, _ = rocprof_rows(k, stats_pattern)
+        if len(rows) > 1:  # one launch name, several symbols (staged / LDS-DMA forms, acting copy / learner): all of them, the chosen one above
+            e["rocprof_rows"] = [{"symbol": r[0], "calls": r[1], "avg_us": round(r[2], 2)} for r in rows]
     if pmc_pattern:
         e["traffic"] = pmc_traffic(k, pmc_pattern)
     return e

@@ -379,7 +379,8 @@ class PPO(BaseAgent):
             self._upload_idx(st, lambda out: np_rng.epoch_shuffles(M, E, out))
 
         pin = st.get("stats_pin")
-        if pin is not None:  # arrival marker in the LAST element the last update's loss kernel writes (c2 = a mean of squares: never -1)
+        if pin is not None:  # arrival markers: one element of EACH 16-byte granule of the last update's row (critic and c2: means of squares, never -1)
+            pin.np[st["n_upd"] - 1, 2] = -1.0
             pin.np[st["n_upd"] - 1, 7] = -1.0
         graphable = (self.use_graph and not ops._PROF["on"] and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
                      and (self.grad_sync is None or (self.graph_with_collective and getattr(self.grad_sync, "capturable", True))))
@@ -464,7 +465,7 @@ class PPO(BaseAgent):
 
     def _await_mapped_stats(self, a, n_upd):
         """Wait until the last loss kernel's row has landed in the mapped host buffer (BaseAgent._await_marks)."""
-        self._await_marks(a, ((n_upd - 1) * 8 + 7,), "PPO.learn()")
+        self._await_marks(a, ((n_upd - 1) * 8 + 2, (n_upd - 1) * 8 + 7), "PPO.learn()")  # jh_ppo.hip: jh_ppo_stats_row
         return a.astype(np.float64)
 
     def learning_rate_decay(self, step, optimizers=None, mode="cosine"):

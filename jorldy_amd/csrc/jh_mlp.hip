@@ -465,8 +465,28 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
                                                       float* __restrict__ norm_out, const float* __restrict__ part,
                                                       int tiles_m, int64_t n_head) {
   __shared__ float s_red[16];
+  // round 5: the first pass's parameter / moment / gradient rows are fetched BEFORE the norm prologue (they do not depend on it):
+  // the prologue's partial sums, slab sums and block reduction used to stand in front of these fetches as one more dependent
+  // round trip per launch (tools/isa_chain.py).  The grid (kNormBlocks x 256 threads x 4 floats) covers all but a few rows in the
+  // first pass; later passes fetch in the loop as before.  Same arithmetic, same bits.
+  const int64_t n4 = n >> 2;  // the buckets are 16-byte aligned: 16-byte accesses + <= 3 trailing elements
+  float4 *p4 = reinterpret_cast<float4*>(p), *g4 = reinterpret_cast<float4*>(g), *m4 = reinterpret_cast<float4*>(m), *v4 = reinterpret_cast<float4*>(v);
+  const int64_t i_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i_fc = i_first < n4 ? i_first : 0;
+  const float4 pp0 = p4[i_fc], mm0 = m4[i_fc], vv0 = v4[i_fc], gg0 = g4[i_fc];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  bool partials_added = false;
+  // the partial sums of squares, called once BEHIND the slab fetches below: issued in front of them, the first use of a partial is a
+  // wait for everything older in the queue, i.e. a round trip before the 48 slab fetches even start.  Two per thread together
+  // (a plain loop fetched, waited and added once per pass); same order of additions
+  auto add_partials = [&]() {
+    const int ia = threadIdx.x, ib = threadIdx.x + 256;
+    const float pa = partial[ia < n_partial ? ia : 0], pb = partial[ib < n_partial ? ib : 0];
+    acc += ia < n_partial ? pa : 0.f;
+    acc += ib < n_partial ? pb : 0.f;
+    for (int i = threadIdx.x + 512; i < n_partial; i += 256) acc += partial[i];
+    partials_added = true;
+  };
   float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t h4 = n_head >> 2;
   if (FUSED) {
@@ -484,6 +504,7 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
 #pragma unroll
         for (int tu = 0; tu < TU; ++tu) w[ju][tu] = part4[(size_t)(tu < tiles_m ? tu : tiles_m - 1) * h4 + ic];
       }
+      if (!partials_added) add_partials();
 #pragma unroll
       for (int ju = 0; ju < JU; ++ju) {
         const int64_t i = threadIdx.x + 256 * (j0 + ju);
@@ -498,6 +519,7 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
       }
     }
   }
+  if (!partials_added) add_partials();
   const float total = sqrtf(jh_block_reduce(acc, s_red, JhAdd(), 0.f));
   const float bc1 = hyper[5], bc2s = hyper[6];
   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total + 1e-6), clamped to 1
@@ -517,11 +539,10 @@ __global__ void __launch_bounds__(256) jh_adam_kernel(int64_t n, float* __restri
     const float denom = sqrtf(vi) / bc2s + eps;
     pi = pi - step_size * (mi / denom);
   };
-  const int64_t n4 = n >> 2;  // the buckets are 16-byte aligned: 16-byte accesses + <= 3 trailing elements
-  float4 *p4 = reinterpret_cast<float4*>(p), *g4 = reinterpret_cast<float4*>(g), *m4 = reinterpret_cast<float4*>(m), *v4 = reinterpret_cast<float4*>(v);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float4 pp = p4[i], mm = m4[i], vv = v4[i];
-    float4 gg = (FUSED && i < h4) ? mine : g4[i];  // h4 <= gridDim.x * 256 (host): a head element is met in the first pass only
+  for (int64_t i = i_first; i < n4; i += (int64_t)gridDim.x * 256) {
+    const bool first = i == i_first;
+    float4 pp = first ? pp0 : p4[i], mm = first ? mm0 : m4[i], vv = first ? vv0 : v4[i];
+    float4 gg = (FUSED && i < h4) ? mine : (first ? gg0 : g4[i]);  // h4 <= gridDim.x * 256 (host): a head element is met in the first pass only
     upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
     p4[i] = pp; g4[i] = gg; m4[i] = mm; v4[i] = vv;
   }

@@ -447,16 +447,33 @@ struct PpoArgs {
   float* critic_sums;
 };
 
+// The per-row inputs of the loss that do not depend on the heads, fetched apart from their use: the single-workgroup kernel issues
+// them BEFORE it sums the partial heads (they used to follow the partial sums and a barrier as two more dependent round trips).
+struct RowIn {
+  int64_t r;
+  float adv, ret, vold;
+  float action, logp_old;  // discrete policies only (continuous ones read A of each in the loop)
+};
+template <bool CONT>
+__device__ __forceinline__ RowIn ppo_row_load(const PpoArgs<CONT>& a, int i) {
+  RowIn in;
+  in.r = a.idx ? a.idx[i] : (int64_t)i;
+  in.adv = a.adv[in.r]; in.ret = a.ret[in.r]; in.vold = a.value_old[in.r];
+  in.action = 0.f; in.logp_old = 0.f;
+  if (!CONT) { in.action = a.action[in.r]; in.logp_old = a.logp_old[in.r]; }
+  return in;
+}
+
 // z0 / z1: this row's head-0 / head-1 vectors (global memory or the LDS staging), v: value prediction
 template <bool CONT>
-__device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, const float* z0, const float* z1, float v,
+__device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, const RowIn& in, const float* z0, const float* z1, float v,
                                             RowCommon& rc, float& ent_row, float& minp_row, DiscRow& dr, int& act_k) {
-  const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
-  const float adv = a.adv[r], ret = a.ret[r], vold = a.value_old[r];
+  const int64_t r = in.r;
+  const float adv = in.adv, ret = in.ret, vold = in.vold;
   if (!CONT) {
     const float* z = z0;
     dr = disc_prepare(z, a.A);
-    int ak = (int)a.action[r];
+    int ak = (int)in.action;
     ak = ak < 0 ? 0 : (ak >= a.A ? a.A - 1 : ak);
     act_k = ak;
     float ent = 0.f, logp = 0.f;
@@ -468,7 +485,7 @@ __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, int i, const
       if (k == ak) logp = lg;
     }
     ent_row = -ent;  // Categorical.entropy
-    rc = row_common(logp - a.logp_old[r], adv, v, vold, ret, a.eps);
+    rc = row_common(logp - in.logp_old, adv, v, vold, ret, a.eps);
     minp_row = expf(logp);
   } else {
     double lsum = 0.0, ent = 0.0;
@@ -549,6 +566,31 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
   }
 }
 
+// One statistics row [8] = two 16-byte granules {loss, actor, critic, entropy} | {max_ratio, min_prob, c1, c2}.  The host may be
+// spinning on the row in device-mapped memory (the last update of a learn(), core/agent/ppo.py: _await_mapped_stats): it waits for
+// ONE element of EACH granule to change -- critic [2] and c2 [7], means of squares, never the -1 the host arms them with -- and each
+// granule is one 16-byte store, which lands whole (MI355X_MICROARCH.md, hand-off granules).  Rounds 1-4 wrote eight scalars with a
+// __threadfence_system() in front of [7]: an L2 write-back + invalidate (~2-3.5 us) on the critical path of EVERY minibatch's loss
+// launch, for a host that only ever waits on the last one.  A row that is not 16-byte aligned (public API, any pointer) keeps that form.
+// (noinline: inlined next to the 16-byte form, hipcc merged the two tails into dwordx4 + dwordx3 + dword stores -- a torn granule)
+__device__ __attribute__((noinline)) void jh_ppo_stats_row_unaligned(float* stats, float loss, float actor, float critic, float entropy, float max_ratio,
+                                                                     float min_prob, float c1, float c2) {
+  stats[0] = loss; stats[1] = actor; stats[2] = critic; stats[3] = entropy; stats[4] = max_ratio; stats[5] = min_prob; stats[6] = c1;
+  __threadfence_system();
+  stats[7] = c2;
+}
+__device__ __forceinline__ void jh_ppo_stats_row(float* stats, float loss, float actor, float critic, float entropy, float max_ratio, float min_prob,
+                                                 float c1, float c2) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  if ((reinterpret_cast<uintptr_t>(stats) & 15) == 0) {
+    const f32x4 ga = {loss, actor, critic, entropy}, gb = {max_ratio, min_prob, c1, c2};
+    // exactly ONE 16-byte store per granule, whatever the optimizer thinks of its neighbours
+    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(stats), "v"(ga), "v"(gb) : "memory");
+  } else {
+    jh_ppo_stats_row_unaligned(stats, loss, actor, critic, entropy, max_ratio, min_prob, c1, c2);
+  }
+}
+
 __device__ __forceinline__ void ppo_finish_stats(float s_smin, float s_e1, float s_e2, float s_ent, float max_ratio,
                                                  float min_prob, int B, int ent_count, float vf, float ent, float& w1,
                                                  float& w2, float* stats) {
@@ -558,17 +600,7 @@ __device__ __forceinline__ void ppo_finish_stats(float s_smin, float s_e1, float
   w1 = c1 > c2 ? 1.f : (c1 == c2 ? 0.5f : 0.f);
   w2 = 1.f - w1;
   const float entropy_loss = -(s_ent / (float)ent_count);
-  if (stats) {
-    stats[0] = actor + vf * critic + ent * entropy_loss;  // ppo.py:158-162
-    stats[1] = actor;
-    stats[2] = critic;
-    stats[3] = entropy_loss;
-    stats[4] = max_ratio;
-    stats[5] = min_prob;
-    stats[6] = c1;
-    __threadfence_system();  // the host waits for [7] of the last update's row (mapped host memory): payload first
-    stats[7] = c2;
-  }
+  if (stats) jh_ppo_stats_row(stats, actor + vf * critic + ent * entropy_loss /* ppo.py:158-162 */, actor, critic, entropy_loss, max_ratio, min_prob, c1, c2);
 }
 
 // {sum, sum, sum, sum, max, min} over the workgroup (<= 16 waves)
@@ -599,43 +631,48 @@ __device__ __forceinline__ void ppo_block_reduce6(float (&v)[6], float (*red)[6]
 
 // B <= 1024: one workgroup does forward, the 6 block reductions and backward with the row terms
 // still in registers (one launch per minibatch instead of two).
-template <bool CONT>
-__global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
+// MAXT: the launch's thread limit (256-row minibatches get the 512-VGPR budget: all 32 tiles of a 512-wide net in flight at once)
+template <bool CONT, int MAXT>
+__global__ void __launch_bounds__(MAXT) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   __shared__ float s_red6[16][6];
-  if (a.hyper_advance && threadIdx.x == blockDim.x - 1) jh_adam_advance(a.hyper_advance);  // (not wave 0: it owns the final reductions)
   extern __shared__ __attribute__((aligned(16))) float s_z[];  // [B][8] when the heads come as partials
   const int i = threadIdx.x;
   const bool on = i < a.B;
   const float *z0 = nullptr, *z1 = nullptr;
   float vpred = 0.f;
+  // first in the queue (round 5), the partial heads behind them.  Unconditional (threads beyond B re-read row 0): behind `if (on)` the
+  // block ends in copies of the fetched values = a wait before the partial heads are even requested
+  const RowIn rin = ppo_row_load<CONT>(a, on ? i : 0);
   if (a.hpart) {
     if (on) {
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const bool wide = a.hp_ld == 8;
-      if (!wide) {  // <= 4 head outputs (CartPole: 2 logits + value): 16 tiles' float4 per round trip, sums in tile order
-        for (int t0 = 0; t0 < a.hp_tiles; t0 += 16) {
-          float4 q0[16];
+      if (!wide) {  // <= 4 head outputs (CartPole: 2 logits + value): TU tiles' float4 per round trip, sums in tile order
+        constexpr int TU = MAXT <= 256 ? 32 : 16;
+        for (int t0 = 0; t0 < a.hp_tiles; t0 += TU) {
+          float4 q0[TU];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
+          for (int u = 0; u < TU; ++u) {
             const int t = t0 + u < a.hp_tiles ? t0 + u : a.hp_tiles - 1;
             q0[u] = *reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * 4);
           }
 #pragma unroll
-          for (int u = 0; u < 16; ++u)
+          for (int u = 0; u < TU; ++u)
             if (t0 + u < a.hp_tiles) { z[0] += q0[u].x; z[1] += q0[u].y; z[2] += q0[u].z; z[3] += q0[u].w; }
         }
       } else {
-        for (int t0 = 0; t0 < a.hp_tiles; t0 += 8) {  // tile order: deterministic; 16 loads in flight per batch
-          float4 q0[8], q1[8];
+        constexpr int TU = MAXT <= 256 ? 16 : 8;
+        for (int t0 = 0; t0 < a.hp_tiles; t0 += TU) {  // tile order: deterministic; 2 TU loads in flight per batch
+          float4 q0[TU], q1[TU];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < TU; ++u) {
             const int t = t0 + u < a.hp_tiles ? t0 + u : a.hp_tiles - 1;
             const float4* q = reinterpret_cast<const float4*>(a.hpart + ((size_t)t * a.hp_rows + i) * 8);
             q0[u] = q[0];
             q1[u] = q[1];
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < TU; ++u) {
             if (t0 + u < a.hp_tiles) {
               z[0] += q0[u].x; z[1] += q0[u].y; z[2] += q0[u].z; z[3] += q0[u].w;
               z[4] += q1[u].x; z[5] += q1[u].y; z[6] += q1[u].z; z[7] += q1[u].w;
@@ -660,7 +697,7 @@ __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
   DiscRow dr{};
   int act_k = 0;
   float ent_row = 0.f, minp = 3.4e38f;
-  if (on) ppo_row_fwd<CONT>(a, i, z0, z1, vpred, rc, ent_row, minp, dr, act_k);
+  if (on) ppo_row_fwd<CONT>(a, rin, z0, z1, vpred, rc, ent_row, minp, dr, act_k);
   const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
   const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
   // the six block reductions share one shuffle tree pass and ONE LDS exchange (same arithmetic order as six
@@ -672,6 +709,9 @@ __global__ void __launch_bounds__(1024) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
                    threadIdx.x == 0 ? a.stats : nullptr);
   if (a.critic_sums && threadIdx.x == 0) { a.critic_sums[0] = v6[1]; a.critic_sums[1] = v6[2]; }
   if (on) ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2);
+  // Adam's step counter + bias corrections (two double-precision pow: ~400 instructions) by the LAST wave, AFTER its rows: in front of
+  // the partial sums (rounds 2-4) that wave reached the barrier ~1 us behind the others, every minibatch (nobody reads hyper here)
+  if (a.hyper_advance && threadIdx.x == blockDim.x - 1) jh_adam_advance(a.hyper_advance);
 }
 
 // B > 1024: pass 1 writes per-block partials, pass 2 re-reduces them in every block (deterministic,
@@ -685,7 +725,7 @@ __global__ void __launch_bounds__(256) jh_ppo_fwd_kernel(PpoArgs<CONT> a) {
   DiscRow dr{};
   int act_k = 0;
   float ent_row = 0.f, minp = 3.4e38f;
-  if (on) ppo_row_fwd<CONT>(a, i, a.h0 + (size_t)i * a.A, CONT ? a.h1 + (size_t)i * a.A : nullptr, a.value_pred[i], rc, ent_row, minp, dr, act_k);
+  if (on) ppo_row_fwd<CONT>(a, ppo_row_load<CONT>(a, i), a.h0 + (size_t)i * a.A, CONT ? a.h1 + (size_t)i * a.A : nullptr, a.value_pred[i], rc, ent_row, minp, dr, act_k);
   const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
   const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
   const float s_smin = jh_block_reduce(on ? rc.smin : 0.f, s_red, JhAdd(), 0.f);
@@ -747,7 +787,7 @@ __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
   float ent_row, minp;
   const float* z0 = a.h0 + (size_t)i * a.A;
   const float* z1 = CONT ? a.h1 + (size_t)i * a.A : nullptr;
-  ppo_row_fwd<CONT>(a, i, z0, z1, a.value_pred[i], rc, ent_row, minp, dr, act_k);
+  ppo_row_fwd<CONT>(a, ppo_row_load<CONT>(a, i), z0, z1, a.value_pred[i], rc, ent_row, minp, dr, act_k);
   ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2);
 }
 
@@ -757,7 +797,8 @@ static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
     const int threads = ((a.B + 63) / 64) * 64;
     a.nb = 1;
     const size_t lds = a.hpart ? sizeof(float) * 8 * (size_t)a.B : 0;
-    JH_LAUNCH(jh_ppo_fused_kernel<CONT>, dim3(1), dim3(threads), lds, st, a);
+    if (threads <= 256) JH_LAUNCH((jh_ppo_fused_kernel<CONT, 256>), dim3(1), dim3(threads), lds, st, a);
+    else JH_LAUNCH((jh_ppo_fused_kernel<CONT, 1024>), dim3(1), dim3(threads), lds, st, a);
     JH_LAUNCH_CHECK();
     return JH_OK;
   }
@@ -818,7 +859,7 @@ JH_EXPORT int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const fl
 // ranks (one 8-byte all-reduce), B = rows per rank: c1 = sums[0] / B and c2 = sums[1] / B are then the means over the GLOBAL minibatch,
 // every rank takes the same branch, and after the gradient all-reduce the update equals one learner's on the concatenated batch.
 // stats_local: the loss kernel's row for this rank; stats_out gets it with the critic terms replaced by the global ones (written in the
-// order ppo_finish_stats uses: [7] last, behind a system fence -- it is the arrival marker of the mapped statistics).
+// form ppo_finish_stats uses, jh_ppo_stats_row: the arrival markers of the mapped statistics are its [2] and [7]).
 __global__ void __launch_bounds__(256) jh_ppo_critic_select_kernel(int B, const float* __restrict__ sums, float vf, float ent, float* __restrict__ gv, int ldv,
                                                                    const float* __restrict__ dv2, const float* __restrict__ stats_local,
                                                                    float* __restrict__ stats_out) {
@@ -828,15 +869,7 @@ __global__ void __launch_bounds__(256) jh_ppo_critic_select_kernel(int B, const 
   if (i < B) gv[(size_t)i * ldv] = w1 * gv[(size_t)i * ldv] + w2 * dv2[i];
   if (i == 0 && stats_out) {
     const float critic = fmaxf(c1, c2);
-    stats_out[0] = stats_local[1] + vf * critic + ent * stats_local[3];
-    stats_out[1] = stats_local[1];
-    stats_out[2] = critic;
-    stats_out[3] = stats_local[3];
-    stats_out[4] = stats_local[4];
-    stats_out[5] = stats_local[5];
-    stats_out[6] = c1;
-    __threadfence_system();
-    stats_out[7] = c2;
+    jh_ppo_stats_row(stats_out, stats_local[1] + vf * critic + ent * stats_local[3], stats_local[1], critic, stats_local[3], stats_local[4], stats_local[5], c1, c2);
   }
 }
 

@@ -63,9 +63,35 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
   const int m = m0 + r;
   const bool m_ok = m < g.M;
   const int mc = m_ok ? m : g.M - 1;
+  // ---- fetch order (round 5, read off the ISA with tools/isa_chain.py): as first compiled this prologue was SEVEN dependent
+  // L2 round trips in front of the first MFMA (row number -> observation, two W1 staging passes and two b1 passes each behind its
+  // own s_waitcnt vmcnt(0), bias / head columns, W2).  Now every independent fetch of the workgroup is in flight before the first
+  // wait: staging operands first (they are needed first and vmcnt retires in issue order), then the first batch of W2 rows and the
+  // epilogue operands; the staging data is written to LDS while W2 is still on its way.  Same arithmetic, same bits.
   float xr[8];
+  int64_t row = mc;
+  if (GEN && g.x_rows) row = g.x_rows[mc];
+  float* w1s = s_dyn + (size_t)wid * kper * (g.S + 1);
+  float* b1s = w1s + (size_t)kper * g.S;
+  const int kn = kend > kbeg ? kend - kbeg : 0;
+  constexpr int WB = 4;  // W1 float4s per lane and staging pass (H = 512: S = 4 needs 2, S = 8 needs 4); scalars, not an array: with
+                         // the scheduling barrier below an array stayed in scratch memory
+  float4 w1t0 = make_float4(0.f, 0.f, 0.f, 0.f), w1t1 = w1t0, w1t2 = w1t0, w1t3 = w1t0, b1t = w1t0;
+  const int n_el = kn * g.S;
+  const int wi0 = lane * 4 < n_el ? lane * 4 : 0, wi1 = (lane + 64) * 4 < n_el ? (lane + 64) * 4 : 0;
+  const int wi2 = (lane + 128) * 4 < n_el ? (lane + 128) * 4 : 0, wi3 = (lane + 192) * 4 < n_el ? (lane + 192) * 4 : 0;
+  const int bi0 = 4 * lane < kn ? 4 * lane : 0;
+  if (GEN && SV > 0) {  // (unconditional, clamped addresses: an empty wave -- H < 64 -- re-reads element 0)
+    const int kb0 = kn > 0 ? kbeg : 0;
+    const float* src = g.W1 + (size_t)kb0 * g.S;
+    w1t0 = *reinterpret_cast<const float4*>(src + wi0);
+    w1t1 = *reinterpret_cast<const float4*>(src + wi1);
+    w1t2 = *reinterpret_cast<const float4*>(src + wi2);
+    w1t3 = *reinterpret_cast<const float4*>(src + wi3);
+    b1t = *reinterpret_cast<const float4*>(g.b1 + kb0 + bi0);
+    __builtin_amdgcn_sched_barrier(0);  // keep them FIRST in the queue (the machine scheduler moved them behind the W2 rows)
+  }
   if (GEN) {
-    const int64_t row = g.x_rows ? g.x_rows[mc] : (int64_t)mc;
     if (SV > 0) {
 #pragma unroll
       for (int q = 0; q < SV; ++q) {
@@ -77,37 +103,58 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
       for (int s = 0; s < 8; ++s) xr[s] = s < g.S ? g.x[row * g.S + s] : 0.f;
     }
   }
-  float* w1s = s_dyn + (size_t)wid * kper * (g.S + 1);
-  float* b1s = w1s + (size_t)kper * g.S;
-  if (GEN && kend > kbeg) {
-    const int n_el = (kend - kbeg) * g.S;
-    const float* src = g.W1 + (size_t)kbeg * g.S;
-    if (SV > 0) {
-      for (int i = lane * 4; i < n_el; i += 256) *reinterpret_cast<float4*>(w1s + i) = *reinterpret_cast<const float4*>(src + i);
-    } else {
-      for (int i = lane; i < n_el; i += 64) w1s[i] = src[i];
-    }
-    for (int i = lane; i < kend - kbeg; i += 64) b1s[i] = g.b1[kbeg + i];
-    // wave-local hand-off: this wave's own ds_writes are ordered before its ds_reads
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // first batch of weight rows + the epilogue operands (bias, head weight columns): in flight behind the staging fetches
+  float4 bw[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int kb = kbeg + 16 * u + 4 * kq;
+    const int kc = kb < kend ? kb : (kbeg < K ? kbeg : 0);
+    bw[u] = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * K + kc);
   }
-  // epilogue operands (bias, head weight columns) fetched NOW: behind the split-K barrier they would be one more
-  // dependent L2 round trip on the critical path
   const float b2 = g.b2[n];
   float whv[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) whv[o] = o < g.n_out ? g.wh[o][n] : 0.f;
+  if (GEN) {
+    if (SV > 0) {
+      // UNCONDITIONAL stores: a lane beyond the slice fetched element 0 and rewrites it with the same bits -- behind an `if` LLVM
+      // sinks each fetch into its store's block and the staging is four serial round trips again
+      *reinterpret_cast<float4*>(w1s + wi0) = w1t0;
+      *reinterpret_cast<float4*>(w1s + wi1) = w1t1;
+      *reinterpret_cast<float4*>(w1s + wi2) = w1t2;
+      *reinterpret_cast<float4*>(w1s + wi3) = w1t3;
+      for (int i = (lane + 64 * WB) * 4; i < n_el; i += 256) *reinterpret_cast<float4*>(w1s + i) = *reinterpret_cast<const float4*>(g.W1 + (size_t)kbeg * g.S + i);  // wider nets
+      *reinterpret_cast<float4*>(b1s + bi0) = b1t;
+      for (int i = 4 * (lane + 64); i < kn; i += 256) *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(g.b1 + kbeg + i);
+    } else {
+      const float* src = g.W1 + (size_t)kbeg * g.S;
+      for (int i = lane; i < n_el; i += 64) w1s[i] = src[i];
+      for (int i = lane; i < kn; i += 64) b1s[i] = g.b1[kbeg + i];
+    }
+    // wave-local hand-off: this wave's own ds_writes are ordered before its ds_reads
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool st_h1 = GEN && g.h1_out && tn == 0;
   for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
-    float4 bw[U], av[U];
+    float4 av[U], bwn[U];
+    if (!GEN) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {  // every weight load of the batch in flight first
-      const int kb = k0 + 16 * u + 4 * kq;
-      const int kc = kb < kend ? kb : kbeg;
-      bw[u] = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * K + kc);
-      if (!GEN) av[u] = *reinterpret_cast<const float4*>(g.h1_in + (size_t)mc * K + kc);
+      for (int u = 0; u < U; ++u) {
+        const int kb = k0 + 16 * u + 4 * kq;
+        const int kc = kb < kend ? kb : kbeg;
+        av[u] = *reinterpret_cast<const float4*>(g.h1_in + (size_t)mc * K + kc);
+      }
+    }
+    const bool more = k0 + 16 * U < kend;
+    if (more) {  // the next batch's weight rows travel while this one is consumed
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int kb = k0 + 16 * U + 16 * u + 4 * kq;
+        const int kc = kb < kend ? kb : kbeg;
+        bwn[u] = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * K + kc);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -147,6 +194,10 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bw[u].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bw[u].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bw[u].w, acc, 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) bw[u] = bwn[u];
     }
   }
   // in-workgroup split-K combine, fixed wave order
@@ -242,19 +293,30 @@ __device__ __forceinline__ float pmb_wave_sum(float v) {
 
 // ---- role: dh1 = relu'(h1) * (dh2 W2) for a 16-row x 32-column tile, reduced on the spot against the
 // observation rows into partial dW1 / db1 (dh1 never reaches HBM)
-template <int NO, int U>
+template <int NO, int U, bool ROWS>
 __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s_acc)[4][64][4], float* s_wh) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
   const int H = g.H, tiles_n = H / 32;
   const int tm = blk / tiles_n, tn = blk - tm * tiles_n;
   const int m0 = tm * 16, i0 = tn * 32;
-  for (int q = threadIdx.x; q < NO * H; q += 256) {  // head weight rows -> LDS (rows >= n_out: zeros)
-    const int j = q / H, k = q - j * H;
-    s_wh[q] = j < g.n_out ? g.wh[j][k] : 0.f;
-  }
+  // ---- fetch order (round 5, tools/isa_chain.py): the head weight rows used to be staged by a loop that indexed the kernel
+  // argument array g.wh[j] DYNAMICALLY -- hipcc fetched the pointer from the kernarg segment with a vector load, waited, fetched
+  // the weight, waited, wrote it: sixteen serial round trips in front of the barrier every workgroup of this role sits behind, and
+  // the main loop's forty fetches only started after it.  Now: one static 16-byte fetch per head row and thread, the gradient row,
+  // wave 0's epilogue operands and the first batch of h2 / W2 rows are ALL issued before the first wait; the head rows (oldest in
+  // the queue) go to LDS while the rest travels.
   const int m = m0 + r;
   const bool m_ok = m < g.B;
   const int mc = m_ok ? m : g.B - 1;
+  // (4-byte fetches: the head rows sit behind A-element biases in the flat bucket and are not 16-byte aligned in general)
+  constexpr int KW = 2;  // columns per thread and head row in the first pass (H <= 512)
+  const int wk0 = threadIdx.x < H ? threadIdx.x : 0, wk1 = threadIdx.x + 256 < H ? threadIdx.x + 256 : 0;
+  float whs[NO][KW];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    whs[j][0] = whs[j][1] = 0.f;
+    if (j < g.n_out) { whs[j][0] = g.wh[j][wk0]; whs[j][1] = g.wh[j][wk1]; }
+  }
   float gj[NO];
   {
     const float4 a = *reinterpret_cast<const float4*>(g.g_all + (size_t)mc * 8);
@@ -264,34 +326,42 @@ __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s
       gj[4] = b.x; gj[5] = b.y; gj[6] = b.z; gj[7] = b.w;
     }
   }
-  __syncthreads();
   const int kper = ((H + 63) / 64) * 16, kbeg = wid * kper;
   const int kend = kbeg + kper < H ? kbeg + kper : H;
-  // epilogue operands of wave 0 (relu'(h1) mask rows, observation row numbers) fetched before the main loop: behind
+  // epilogue operands of wave 0 (relu'(h1) mask rows, observation rows) fetched before the main loop: behind
   // the split-K barrier they would be dependent L2 round trips on the critical path
+  // (every wave fetches them, not only wave 0: behind `if (wid == 0)` the block ends in copies of the fetched values, i.e. in a
+  // wait for the whole queue in front of the batch below)
   float2 hmask[4];
   int64_t xrow[4];
-  if (wid == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int mm = m0 + kq * 4 + i;
-      const int mmc = mm < g.B ? mm : g.B - 1;
-      hmask[i] = *reinterpret_cast<const float2*>(g.h1 + (size_t)mmc * H + i0 + 2 * r);
-      xrow[i] = g.x_rows ? g.x_rows[mmc] : (int64_t)mmc;
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int mm = m0 + kq * 4 + i;
+    const int mmc = mm < g.B ? mm : g.B - 1;
+    hmask[i] = *reinterpret_cast<const float2*>(g.h1 + (size_t)mmc * H + i0 + 2 * r);
+    xrow[i] = ROWS ? g.x_rows[mmc] : (int64_t)mmc;  // (compile-time: a run-time select ends in copies = a wait for the queue)
   }
+  float4 h2v[U];
+  float2 bw[U][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // first batch (H = 512: the only one)
+    const int kb = kbeg + 16 * u + 4 * kq;
+    const int kc = kb < kend ? kb : (kbeg < H ? kbeg : 0);
+    h2v[u] = *reinterpret_cast<const float4*>(g.h2 + (size_t)mc * H + kc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bw[u][j] = *reinterpret_cast<const float2*>(g.W2 + (size_t)(kc + j) * H + i0 + 2 * r);
+  }
+  // UNCONDITIONAL stores (a thread beyond the row rewrites column 0 with the same bits): behind an `if` LLVM sinks the fetches into
+  // the store's block, i.e. behind the waits again
+#pragma unroll
+  for (int j = 0; j < NO; ++j) { s_wh[j * H + wk0] = whs[j][0]; s_wh[j * H + wk1] = whs[j][1]; }
+  for (int k = threadIdx.x + 256 * KW; k < H; k += 256) {  // H > 512
+#pragma unroll
+    for (int j = 0; j < NO; ++j) s_wh[j * H + k] = j < g.n_out ? g.wh[j][k] : 0.f;
+  }
+  __syncthreads();
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
-    float4 h2v[U];
-    float2 bw[U][4];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kb = k0 + 16 * u + 4 * kq;
-      const int kc = kb < kend ? kb : kbeg;
-      h2v[u] = *reinterpret_cast<const float4*>(g.h2 + (size_t)mc * H + kc);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bw[u][j] = *reinterpret_cast<const float2*>(g.W2 + (size_t)(kc + j) * H + i0 + 2 * r);
-    }
+  auto consume = [&](int k0, const float4 (&h2b)[U], const float2 (&bwb)[U][4]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kb = k0 + 16 * u + 4 * kq;
@@ -303,14 +373,39 @@ __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s
         const float4 w = *reinterpret_cast<const float4*>(s_wh + jj * H + kc);
         a[0] = fmaf(gj[jj], w.x, a[0]); a[1] = fmaf(gj[jj], w.y, a[1]); a[2] = fmaf(gj[jj], w.z, a[2]); a[3] = fmaf(gj[jj], w.w, a[3]);
       }
-      const float hq[4] = {h2v[u].x, h2v[u].y, h2v[u].z, h2v[u].w};
+      const float hq[4] = {h2b[u].x, h2b[u].y, h2b[u].z, h2b[u].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float aj = (ok && hq[j] > 0.f) ? a[j] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, bw[u][j].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, bw[u][j].y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, bwb[u][j].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, bwb[u][j].y, acc[1], 0, 0, 0);
       }
     }
+  };
+  if (kend > kbeg) consume(kbeg, h2v, bw);
+  for (int k0 = kbeg + 16 * U; k0 < kend; k0 += 16 * U) {  // H > 512: further batches, fetched at the loop top (their own registers:
+    float4 h2n[U];                                          // carrying the first batch's through the loop cost 90 VGPRs)
+    float2 bwn[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = k0 + 16 * u + 4 * kq;
+      const int kc = kb < kend ? kb : kbeg;
+      h2n[u] = *reinterpret_cast<const float4*>(g.h2 + (size_t)mc * H + kc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bwn[u][j] = *reinterpret_cast<const float2*>(g.W2 + (size_t)(kc + j) * H + i0 + 2 * r);
+    }
+    consume(k0, h2n, bwn);
+  }
+  // observation values of wave 0's epilogue rows (the first PX features), issued HERE: the batch registers are free again (earlier
+  // they lift the kernel over 168 VGPRs = three workgroups per CU = the whole grid resident at once), and the fetch overlaps the
+  // split-K exchange instead of following it
+  constexpr int PX = 8;
+  float xv[PX][4];
+  if (wid == 0) {
+#pragma unroll
+    for (int s = 0; s < PX; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[s][i] = s < g.S ? g.x[xrow[i] * g.S + s] : 0.f;
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -329,8 +424,7 @@ __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s
     v[1][i] = (mm < g.B && hh.y > 0.f) ? s1 : 0.f;
   }
   float* slab = g.part_w1 + (size_t)tm * ((size_t)H * g.S + H);
-  for (int s = 0; s < g.S; ++s) {
-    const float x0 = g.x[xrow[0] * g.S + s], x1 = g.x[xrow[1] * g.S + s], x2 = g.x[xrow[2] * g.S + s], x3 = g.x[xrow[3] * g.S + s];
+  auto dw1_feature = [&](int s, float x0, float x1, float x2, float x3) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       float p = 0.f;
@@ -339,7 +433,12 @@ __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s
       p += __shfl_xor(p, 32, 64);
       if (kq == 0) slab[(size_t)(i0 + 2 * r + t) * g.S + s] = p;
     }
-  }
+  };
+#pragma unroll
+  for (int s = 0; s < PX; ++s)
+    if (s < g.S) dw1_feature(s, xv[s][0], xv[s][1], xv[s][2], xv[s][3]);
+  for (int s = PX; s < g.S; ++s)  // wider observations (Hopper: S = 11)
+    dw1_feature(s, g.x[xrow[0] * g.S + s], g.x[xrow[1] * g.S + s], g.x[xrow[2] * g.S + s], g.x[xrow[3] * g.S + s]);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     float p = ((v[t][0] + v[t][1]) + v[t][2]) + v[t][3];
@@ -349,9 +448,15 @@ __device__ __forceinline__ void pmb_role_dh1(const PmbBwd& g, int blk, float (*s
   }
 }
 
-// ---- role: dW2[o][i] = sum_b dh2[b][o] h1[b][i] (32 x 32 tile, both operands 2-column interleaved), db2 = row sums
-template <int NO>
-__device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s_acc)[4][64][4], float (*s_rs)[2][64]) {
+// ---- role: dW2[o][i] = sum_b dh2[b][o] h1[b][i] (32 x 32 tile, both operands 2-column interleaved), db2 = row sums.
+// DWH (the workgroups of column tile 0, one per 32 h2 columns): also the head weight gradients dWh[j][k] = sum_b g[b][j] h2[b][k] of
+// those 32 columns (rows j < n_out of a 16 x 32 tile) and, in the first of them, dbh = column sums of g.  Round 4 ran them as a third
+// role of H/32 extra workgroups: 528 workgroups need three per CU resident at once (<= 168 VGPRs: no room to prefetch anything), and
+// its loop compiled into one fetch at a time (tools/isa_chain.py: 13 serial round trips, the longest chain of the launch).  The h2
+// columns and the gradient rows it needs are exactly what this role already holds in registers: two more MFMAs per step in 16 of the
+// 256 workgroups, same row split over the waves, same accumulation order -> the same bits as the separate role.
+template <int NO, bool DWH>
+__device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s_acc)[4][64][4], float (*s_rs)[2][64], float (*s_hacc)[2][64][4], float (*s_hrs)[64]) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
   const int H = g.H, tiles_n = H / 32;
   const int tm = blk / tiles_n, tn = blk - tm * tiles_n;
@@ -364,13 +469,15 @@ __device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s
   }
   const int kper = ((g.B + 15) / 16) * 4, kbeg = wid * kper;  // rows per wave, multiple of 4
   const int kend = kbeg + kper < g.B ? kbeg + kper : g.B;
-  f32x4 acc[2][2];
+  f32x4 acc[2][2], hacc[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float rs[2] = {0.f, 0.f};
-  constexpr int U = 8;
+    hacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float rs[2] = {0.f, 0.f}, hrs = 0.f;
+  constexpr int U = NO <= 4 ? 16 : 8;  // rows x 4 in flight per wave: 256-row minibatches are ONE batch of fetches (NO <= 4)
   for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
     float4 g0[U], g1[U];
     float2 h2v[U], h1v[U];
@@ -383,6 +490,9 @@ __device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s
       h2v[u] = *reinterpret_cast<const float2*>(g.h2 + (size_t)bc * H + o0 + 2 * r);
       h1v[u] = *reinterpret_cast<const float2*>(g.h1 + (size_t)bc * H + i0 + 2 * r);
     }
+    // the whole batch in flight before the first MFMA: without this fence the machine scheduler interleaves fetch and use in the
+    // DWH variant (register-pressure heuristic), one round trip per step -- what made the separate head-gradient role the longest chain
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = k0 + 4 * u + kq < kend;
@@ -393,6 +503,15 @@ __device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s
       for (int jj = 0; jj < NO; ++jj) {
         a0 = fmaf(gq[jj], whr[jj][0], a0);
         a1 = fmaf(gq[jj], whr[jj][1], a1);
+      }
+      if (DWH) {  // A[m = r][k = kq] = g[row of this lane][r]: picked BEFORE the relu mask below touches nothing of it
+        float gr = gq[0];
+#pragma unroll
+        for (int jj = 1; jj < NO; ++jj) gr = (r & 7) == jj ? gq[jj] : gr;
+        const float ah = (ok && r < g.n_out) ? gr : 0.f;
+        hrs += ah;
+        hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, h2v[u].x, hacc[0], 0, 0, 0);
+        hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, h2v[u].y, hacc[1], 0, 0, 0);
       }
       a0 = (ok && h2v[u].x > 0.f) ? a0 : 0.f;  // relu'(h2)
       a1 = (ok && h2v[u].y > 0.f) ? a1 : 0.f;
@@ -411,7 +530,12 @@ __device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s
 #pragma unroll
       for (int i = 0; i < 4; ++i) s_acc[wid][t * 2 + u][lane][i] = acc[t][u][i];
     s_rs[wid][t][lane] = rs[t];
+    if (DWH) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s_hacc[wid][t][lane][i] = hacc[t][i];
+    }
   }
+  if (DWH) s_hrs[wid][lane] = hrs;
   __syncthreads();
   if (wid != 0) return;
   float ssq = 0.f;
@@ -441,67 +565,33 @@ __device__ __forceinline__ void pmb_role_dw2(const PmbBwd& g, int blk, float (*s
     ssq = pmb_wave_sum(ssq);
     if (lane == 0) g.ssq_part[blk] = ssq;
   }
-}
-
-// ---- role: head weight gradients dWh[j][k] = sum_b g[b][j] h2[b][k] (rows j < n_out of a 16 x 32 tile), dbh = row sums
-__device__ __forceinline__ void pmb_role_dwh(const PmbBwd& g, int blk, float (*s_acc)[4][64][4], float (*s_rs)[2][64]) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
-  const int H = g.H, c0 = blk * 32;
-  const int kper = ((g.B + 15) / 16) * 4, kbeg = wid * kper;
-  const int kend = kbeg + kper < g.B ? kbeg + kper : g.B;
-  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-  float rs = 0.f;
-  constexpr int U = 8;
-  for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
-    float av[U];
-    float2 hv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = k0 + 4 * u + kq;
-      const int bc = b < kend ? b : g.B - 1;
-      av[u] = g.g_all[(size_t)bc * 8 + (r & 7)];
-      hv[u] = *reinterpret_cast<const float2*>(g.h2 + (size_t)bc * H + c0 + 2 * r);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float a = (k0 + 4 * u + kq < kend && r < g.n_out) ? av[u] : 0.f;
-      rs += a;
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, hv[u].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, hv[u].y, acc[1], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_acc[wid][t][lane][i] = acc[t][i];
-  s_rs[wid][0][lane] = rs;
-  __syncthreads();
-  if (wid != 0) return;
-  float ssq = 0.f;
+  if (!DWH) return;
+  // ---- head weight gradients of the columns o0 .. o0 + 31 (the former third role's epilogue, its own sum-of-squares slot)
+  float hsq = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int j = kq * 4 + i;
     if (j < g.n_out) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const float w = ((s_acc[0][t][lane][i] + s_acc[1][t][lane][i]) + s_acc[2][t][lane][i]) + s_acc[3][t][lane][i];
-        g.dwh[j][c0 + 2 * r + t] = w;
-        ssq = fmaf(w, w, ssq);
+        const float w = ((s_hacc[0][t][lane][i] + s_hacc[1][t][lane][i]) + s_hacc[2][t][lane][i]) + s_hacc[3][t][lane][i];
+        g.dwh[j][o0 + 2 * r + t] = w;
+        hsq = fmaf(w, w, hsq);
       }
     }
   }
-  if (blk == 0) {
-    float s = ((s_rs[0][0][lane] + s_rs[1][0][lane]) + s_rs[2][0][lane]) + s_rs[3][0][lane];
+  if (tm == 0) {
+    float s = ((s_hrs[0][lane] + s_hrs[1][lane]) + s_hrs[2][lane]) + s_hrs[3][lane];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     if (kq == 0 && r < g.n_out) {
       *g.dbh[r] = s;
-      ssq = fmaf(s, s, ssq);
+      hsq = fmaf(s, s, hsq);
     }
   }
   if (g.ssq_part) {
-    ssq = pmb_wave_sum(ssq);
-    if (lane == 0) g.ssq_part[g.n_dw2 + blk] = ssq;
+    hsq = pmb_wave_sum(hsq);
+    if (lane == 0) g.ssq_part[g.n_dw2 + tm] = hsq;
   }
 }
 
@@ -509,11 +599,18 @@ template <int NO, int U1>
 __global__ void __launch_bounds__(256) jh_pmb_bwd_kernel(PmbBwd g) {
   __shared__ float s_acc[4][4][64][4];
   __shared__ float s_rs[4][2][64];
+  __shared__ float s_hacc[4][2][64][4];
+  __shared__ float s_hrs[4][64];
   extern __shared__ __attribute__((aligned(16))) float s_wh[];  // [NO][H] (dh1 role)
   const int b = blockIdx.x;
-  if (b < g.n_dh1) pmb_role_dh1<NO, U1>(g, b, s_acc, s_wh);  // the longest chains first
-  else if (b < g.n_dh1 + g.n_dw2) pmb_role_dw2<NO>(g, b - g.n_dh1, s_acc, s_rs);
-  else pmb_role_dwh(g, b - g.n_dh1 - g.n_dw2, s_acc, s_rs);
+  if (b < g.n_dh1) {  // the longest chains first
+    if (g.x_rows) pmb_role_dh1<NO, U1, true>(g, b, s_acc, s_wh);
+    else pmb_role_dh1<NO, U1, false>(g, b, s_acc, s_wh);
+  } else if ((b - g.n_dh1) % (g.H / 32) == 0) {
+    pmb_role_dw2<NO, true>(g, b - g.n_dh1, s_acc, s_rs, s_hacc, s_hrs);
+  } else {
+    pmb_role_dw2<NO, false>(g, b - g.n_dh1, s_acc, s_rs, s_hacc, s_hrs);
+  }
 }
 
 // ============================================================================ 4. dW1 / db1 combine + global norm
@@ -606,7 +703,7 @@ int jh_pmb_backward(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx,
   const int t32 = n->H / 32;
   g.n_dh1 = ((B + 15) / 16) * t32;
   g.n_dw2 = t32 * t32;
-  const int grid = g.n_dh1 + g.n_dw2 + t32;
+  const int grid = g.n_dh1 + g.n_dw2;  // 512 workgroups at B = 256, H = 512: two per CU, all resident (<= 256 VGPRs)
   static const int u1 = getenv("JH_PMB_U1") ? atoi(getenv("JH_PMB_U1")) : 8;  // k-chunks of dh1 loaded ahead of the MFMAs
   const bool deep = u1 >= 8 && n->H >= 512;
   // flops: dW2 + dh1 (B x H x H each), head weight gradients, dW1 partials, dh2 generated twice

@@ -5,6 +5,7 @@ torch-CPU ops in the reference's tensor-op style (dense one-hot projection, thre
 with fresh factorised noise, per-sample priority write-back through the Python sum tree):
     network      core/network/rainbow.py:8-94 + head.py:21-61 (Nature CNN) + utils.py:55-107
     learn        core/agent/rainbow.py:154-253
+    act / interact_callback / process   core/agent/rainbow.py:140-152, 294-308, 255-283 (the single-mode loop of run_mode.py:68-80)
     PER          core/buffer/per_buffer.py:19-101  (oracle.jorldy_oracle.PEROracle)
 Used by bench.py to time the reference's learner on the bench box's host cores (`rainbow.cpu_reference`)
 and pinned against the reference's own run in tests/test_oracle_golden.py::test_rainbow_port_matches_reference.
@@ -83,6 +84,47 @@ class RainbowPort:
         self.dz = (v_max - v_min) / (num_support - 1)
         self.z = torch.linspace(v_min, v_max, num_support).view(1, -1)
         self.noise = None  # tests inject [3] dicts tag -> (eps_in, eps_out)
+        # single-mode loop state (rainbow.py:96-129): n-step window, stamps, beta annealing
+        from collections import deque
+
+        self.tmp_buffer = deque(maxlen=n_step)
+        self.start_train_step, self.learn_period, self.target_update_period = 0, 4, 10000
+        self.time_t = self.learn_period_stamp = self.target_update_stamp = self.num_learn = 0
+        self.beta_add = (1.0 - beta) / 30_000_000
+
+    @torch.no_grad()
+    def act(self, state, training=True):  # rainbow.py:140-152 (noisy forward B = 1, logits2Q, argmax)
+        if training and self.memory.size < max(self.B, self.start_train_step):
+            return {"action": np.random.randint(0, self.A, size=(state.shape[0], 1))}
+        _, q = self._pq(self.network(torch.as_tensor(state, dtype=torch.float32)))
+        return {"action": torch.argmax(q, -1, keepdim=True).numpy()}
+
+    def interact_callback(self, transition):  # rainbow.py:294-308
+        out = {}
+        self.tmp_buffer.append(transition)
+        if len(self.tmp_buffer) == self.n:
+            out["state"], out["action"], out["next_state"] = self.tmp_buffer[0]["state"], self.tmp_buffer[0]["action"], self.tmp_buffer[-1]["next_state"]
+            for key in self.tmp_buffer[0].keys():
+                if key not in ("state", "action", "next_state"):
+                    out[key] = np.stack([t[key] for t in self.tmp_buffer], axis=1)
+        return out
+
+    def process(self, transitions, step):  # rainbow.py:255-283
+        result = {}
+        delta_t = step - self.time_t
+        self.memory.store(transitions)
+        self.time_t = step
+        self.target_update_stamp += delta_t
+        self.learn_period_stamp += delta_t
+        self.beta = min(1.0, self.beta + self.beta_add * delta_t)
+        if self.learn_period_stamp >= self.learn_period and self.memory.buffer_counter >= self.B and self.time_t >= self.start_train_step:
+            result = self.learn()
+            self.num_learn += 1
+            self.learn_period_stamp -= self.learn_period
+        if self.num_learn > 0 and self.target_update_stamp >= self.target_update_period:
+            self.target_network.load_state_dict(self.network.state_dict())
+            self.target_update_stamp -= self.target_update_period
+        return result
 
     def _pq(self, logits):
         p = torch.exp(F.log_softmax(logits, dim=-1))
