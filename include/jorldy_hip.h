@@ -369,6 +369,31 @@ int jh_control_step(jh_control* e, const float* h_action /* [W][A] */, float* h_
  * one hipMemcpyAsync per column.  cols = store column indices of {state, action, reward,
  * next_state, done} (f32[4], i64[1], f32[1], f32[4], u8[1]).                                       */
 typedef struct jh_collector jh_collector;
+
+/* The host envs behind the collector as a table of functions (round 5): what `Actor.run` needs from an env
+ * (manager/distributed_manager.py:76-92: the current observations, one step with auto-reset) plus, OPTIONALLY, the ability to be
+ * copied on the host.  The two built-in envs above are two such tables (jh_collector_create / _create_control build them);
+ * jh_collector_create_env plugs any other host simulator -- a C user's, or Python callbacks through ctypes (tests).
+ *   obs   rows r0 .. r1-1 of the CURRENT observations (the reset observation where the last step ended an episode) -> h_obs [r1-r0][S]
+ *   step  rows r0 .. r1-1 take h_action (int64 [n] for a discrete policy, float [n][A] in [-1, 1] for a continuous one):
+ *         h_next_obs [n][S] (the terminal observation where done), h_reward [n], h_done [n]; finished rows reset themselves
+ *   both return 0 or a negative JH_ERR_* (the run stops, what was collected is still committed).
+ *   fork_alloc / fork_free / copy_row (all three or none): a scratch env of `rows` rows, its release, and "row di of dst becomes an
+ *   exact copy of row si of src" including the row's RNG stream.  An env that offers them and has two discrete actions gets TWO
+ *   timesteps per acting exchange (the collector steps copies one to three steps ahead while the GPU evaluates the policy; rollouts
+ *   are bit-identical to one timestep per exchange); one that does not runs one timestep per exchange.
+ * The collector calls obs / step with r0 = 0, r1 = W on the env itself and with arbitrary row ranges on scratch envs only.          */
+typedef struct jh_env_vtbl {
+  int32_t W, S, A, continuous;
+  int (*obs)(void* env, int32_t r0, int32_t r1, float* h_obs);
+  int (*step)(void* env, int32_t r0, int32_t r1, const void* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done);
+  void* (*fork_alloc)(void* env, int32_t rows);
+  void (*fork_free)(void* scratch);
+  void (*copy_row)(void* dst, int32_t di, const void* src, int32_t si);
+} jh_env_vtbl;
+int jh_collector_create_env(jh_ctx* ctx, jh_pponet* net, const jh_env_vtbl* vt, void* env, jh_store* store, const int32_t* cols,
+                            jh_collector** out);
+
 int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store, const int32_t* cols,
                         jh_collector** out);
 /* The same for a CONTINUOUS policy (PPO.act, ppo.py:55-63: tanh(Normal(mu, std).sample())) on jh_control: the

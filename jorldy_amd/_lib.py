@@ -106,6 +106,7 @@ _PROTOS = {
     "jh_control_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "jh_collector_create_control": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
     "jh_collector_create": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
+    "jh_collector_create_env": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _pp]),
     "jh_collector_destroy": (None, [_vp]),
     "jh_rbnet_param_count_for": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "jh_rbnet_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _pp]),

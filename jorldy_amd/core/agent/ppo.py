@@ -10,9 +10,11 @@ from ..optimizer import Optimizer
 from .base import BaseAgent
 
 
+MAX_HEAD_OUTPUTS = 40  # jh_pponet_create (csrc/jh_mlp.hip: kMaxHeadOutputs): continuous A <= 19 (Humanoid: 17), discrete A <= 39
 NATIVE_ELIGIBLE = ("PPO runs on libjorldy_hip only: network in {discrete_policy_value, continuous_policy_value}, head='mlp', int state_size, "
                    "hidden_size % 16 == 0, optim_config name 'adam' without weight_decay / amsgrad, and action_size + 1 (discrete) or "
-                   "2 * action_size + 1 (continuous) <= 8 head outputs (config.ppo.cartpole, config.ppo.mujoco and their shapes)")
+                   f"2 * action_size + 1 (continuous) <= {MAX_HEAD_OUTPUTS} head outputs (config.ppo.cartpole, config.ppo.mujoco on all its envs; up to 8 outputs "
+                   "-- CartPole, Hopper -- on the four-launch minibatch update and the persistent acting kernel, beyond that on the separate calls / the tiled engine)")
 
 
 class PPO(BaseAgent):
@@ -28,8 +30,8 @@ class PPO(BaseAgent):
       the 5 `.item()` syncs per minibatch                  one D2H of a [n_updates, 8] stats array
 
     Everything above is hand-written kernels; the whole learn() is captured in one hipGraph after the first call.
-    There is ONE backend (libjorldy_hip): head="mlp", an int state_size, Adam without weight decay / amsgrad and <= 8 head
-    outputs -- what configs ppo.cartpole / ppo.mujoco use.  Any other configuration raises (NATIVE_ELIGIBLE below) instead of
+    There is ONE backend (libjorldy_hip): head="mlp", an int state_size, Adam without weight decay / amsgrad and <= 40 head
+    outputs -- what configs ppo.cartpole / ppo.mujoco (Hopper, HalfCheetah, Walker, Ant, Humanoid) use.  Any other configuration raises (NATIVE_ELIGIBLE below) instead of
     silently switching to library kernels; the reference agent keeps working for those.
     Constructor arguments, `act`, `process`, result keys, checkpoint format are the reference's.
     """
@@ -41,6 +43,16 @@ class PPO(BaseAgent):
         self.device = self._require_gpu(device)
         self.action_type = network.split("_")[0]
         assert self.action_type in ["continuous", "discrete"]
+        if backend not in (None, "auto", "native"):
+            raise ValueError(f"backend={backend!r}: jorldy_amd has one backend (libjorldy_hip); the torch mirror of round 1-3 is test infrastructure now (tests/mirror)")
+        # what the library's policy-value net covers, checked BEFORE anything is built: an unsupported configuration says so at construction
+        # with the eligible list (the parameter containers of core/network only know the hot path's heads)
+        shape_ok = (head == "mlp" and isinstance(state_size, (int, np.integer)) and network in ("discrete_policy_value", "continuous_policy_value")
+                    and hidden_size % 16 == 0 and optim_config.get("name", "adam").lower() == "adam"
+                    and (2 * action_size + 1 if self.action_type == "continuous" else action_size + 1) <= MAX_HEAD_OUTPUTS)
+        if not shape_ok:
+            raise ValueError(f"{NATIVE_ELIGIBLE}; got network={network!r}, head={head!r}, state_size={state_size!r}, hidden_size={hidden_size}, "
+                             f"optim_config={optim_config!r}, action_size={action_size}")
         self.network = Network(network, state_size, action_size, D_hidden=hidden_size, head=head).to(self.device)
         self.optimizer = Optimizer(**optim_config, params=self.network.parameters())
         self.gamma = gamma
@@ -70,10 +82,8 @@ class PPO(BaseAgent):
             head == "mlp" and isinstance(state_size, (int, np.integer)) and optim_config.get("name", "adam").lower() == "adam"
             and network in ("discrete_policy_value", "continuous_policy_value") and hidden_size % 16 == 0
             and not self.optimizer.defaults.get("amsgrad", False) and self.optimizer.defaults.get("weight_decay", 0) == 0
-            and (2 * action_size + 1 if self.action_type == "continuous" else action_size + 1) <= 8
+            and (2 * action_size + 1 if self.action_type == "continuous" else action_size + 1) <= MAX_HEAD_OUTPUTS
         )
-        if backend not in (None, "auto", "native"):
-            raise ValueError(f"backend={backend!r}: jorldy_amd has one backend (libjorldy_hip); the torch mirror of round 1-3 is test infrastructure now (tests/mirror)")
         if not eligible:
             raise ValueError(f"{NATIVE_ELIGIBLE}; got network={network!r}, head={head!r}, state_size={state_size!r}, hidden_size={hidden_size}, "
                              f"optim_config={optim_config!r}, action_size={action_size}")

@@ -28,11 +28,42 @@ void jh_persist_abort(jh_persist* p);
 bool jh_persist_gave_up(const jh_persist* p);
 void jh_persist_dump_debug(jh_persist* p, int T);
 
+namespace {
+struct Level {  // 2^k W forked envs: row 2 i + a = env i of the level above after action a
+  void* env = nullptr;
+  int S = 0;
+  std::vector<float> next, obs, rw;
+  std::vector<uint8_t> dn;
+  std::vector<int64_t> act;
+  void init(int rows, int S_) {  // (keeps its buffers across runs: resize is a no-op from the second run on)
+    S = S_;
+    next.resize((size_t)S * rows); obs.resize((size_t)S * rows); rw.resize(rows); dn.resize(rows); act.resize(rows);
+    for (int i = 0; i < rows; ++i) act[i] = i & 1;
+  }
+};
+// dst rows 2 i + a <- src row i stepped with action a (auto-reset included: the row then holds the reset state)
+inline void fork_step(const jh_env_vtbl& vt, Level& dst, const void* src, int n_src) {
+  for (int i = 0; i < n_src; ++i) { vt.copy_row(dst.env, 2 * i, src, i); vt.copy_row(dst.env, 2 * i + 1, src, i); }
+  vt.step(dst.env, 0, 2 * n_src, dst.act.data(), dst.next.data(), dst.rw.data(), dst.dn.data());
+  vt.obs(dst.env, 0, 2 * n_src, dst.obs.data());
+}
+inline void copy_level_row(const jh_env_vtbl& vt, Level& d, int di, const Level& s_, int si) {
+  vt.copy_row(d.env, di, s_.env, si);
+  const size_t S = (size_t)d.S;
+  memcpy(&d.next[S * (size_t)di], &s_.next[S * (size_t)si], sizeof(float) * S);
+  memcpy(&d.obs[S * (size_t)di], &s_.obs[S * (size_t)si], sizeof(float) * S);
+  d.rw[di] = s_.rw[si];
+  d.dn[di] = s_.dn[si];
+}
+}  // namespace
+
 struct jh_collector {
   jh_ctx* ctx = nullptr;
   jh_pponet* net = nullptr;
-  jh_cartpole* cart = nullptr;  // exactly one of the two envs is set
-  jh_control* ctl = nullptr;
+  // the host envs behind a table of functions (include/jorldy_hip.h: jh_env_vtbl; round 5): the two built-in envs
+  // (jh_cartpole_*, jh_control_*) are two such tables, a C user plugs any other with jh_collector_create_env
+  jh_env_vtbl vt{};
+  void* env = nullptr;
   jh_store* store = nullptr;
   int W = 0, S = 0, A = 0;
   bool cont = false;
@@ -45,7 +76,8 @@ struct jh_collector {
   // lookahead = 2 (discrete two-action envs that can be forked on the host, 3 W <= 32 rows): every PCIe round trip carries each
   // env's state AND both successor states, and serves two timesteps (run_loop_lookahead).  1: one timestep per round trip.
   int lookahead = 1;
-  jh_cartpole *spec = nullptr, *spec2 = nullptr, *spec3 = nullptr;  // 2 W / 4 W / 8 W scratch envs: successors one, two and three steps ahead
+  Level lv[4];  // L1, L2, L3 and the one-step exchange's scratch level
+  void *spec = nullptr, *spec2 = nullptr, *spec3 = nullptr;  // 2 W / 4 W / 8 W scratch envs (vt.fork_alloc): successors one, two and three steps ahead
   // acting-time capture (jh_collector_set_capture): device destinations of the raw heads / values of the states acted on
   float *cap_h0 = nullptr, *cap_h1 = nullptr, *cap_v = nullptr, *cap_nv = nullptr;
   int64_t cap_rows = 0;
@@ -66,11 +98,12 @@ struct RunState;
 static void run_state_alloc(jh_collector* c);
 static void run_state_free(jh_collector* c);
 
-static int collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* cart, jh_control* ctl, jh_store* store, const int32_t* cols,
+static int collector_create(jh_ctx* ctx, jh_pponet* net, const jh_env_vtbl* vt, void* env, jh_store* store, const int32_t* cols,
                             jh_collector** out) {
-  JH_ARG(ctx && net && (cart || ctl) && store && cols && out);
-  const int W = cart ? cart->W : ctl->W, S = cart ? 4 : ctl->S, A = cart ? 2 : ctl->A;
-  const bool cont = ctl != nullptr;
+  JH_ARG(ctx && net && vt && env && store && cols && out);
+  JH_ARG(vt->obs && vt->step && vt->W > 0 && vt->S > 0 && vt->A > 0);
+  const int W = vt->W, S = vt->S, A = vt->A;
+  const bool cont = vt->continuous != 0;
   JH_ARG(net->S == S && net->A == A && (net->cont != 0) == cont);
   JH_ARG(W <= net->max_act_rows);
   for (int i = 0; i < 5; ++i) JH_ARG(cols[i] >= 0 && cols[i] < store->n_cols);
@@ -82,18 +115,22 @@ static int collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* cart, jh_c
   JH_ARG(store->cols[cols[4]].dtype == JH_U8 && store->cols[cols[4]].elems == 1);
   JH_HIP(hipSetDevice(ctx->device));
   jh_collector* c = new jh_collector();
-  c->ctx = ctx; c->net = net; c->cart = cart; c->ctl = ctl; c->store = store; c->W = W; c->S = S; c->A = A; c->cont = cont;
+  c->ctx = ctx; c->net = net; c->vt = *vt; c->env = env; c->store = store; c->W = W; c->S = S; c->A = A; c->cont = cont;
   c->col_state = cols[0]; c->col_action = cols[1]; c->col_reward = cols[2]; c->col_next = cols[3]; c->col_done = cols[4];
   if (const char* e = getenv("JH_COLLECT_PERSISTENT")) c->mode = atoi(e);
   if (c->mode == 1 && W <= 16 && W * S <= 128) {
     if (jh_persist_create(net, &c->persist) != JH_OK) c->persist = nullptr;  // unsupported width: one launch per step
   }
-  if (c->persist && cart && A == 2 && 3 * W <= 32 && 3 * W * S <= 128) {
+  // Two timesteps per exchange is a CAPABILITY of the env (it can be forked on the host: fork_alloc / fork_free / copy_row given) with
+  // two discrete actions, not a type: any env that offers it gets it; one that cannot be copied runs one timestep per exchange
+  const bool forkable = vt->fork_alloc && vt->fork_free && vt->copy_row;
+  if (c->persist && forkable && !cont && A == 2 && 3 * W <= 32 && 3 * W * S <= 128) {
     const char* e = getenv("JH_COLLECT_LOOKAHEAD");
     c->lookahead = e ? (atoi(e) >= 2 ? 2 : 1) : 2;
-    if (c->lookahead == 2 && (jh_cartpole_create(2 * W, 0, &c->spec) != JH_OK || jh_cartpole_create(4 * W, 0, &c->spec2) != JH_OK ||
-                              jh_cartpole_create(8 * W, 0, &c->spec3) != JH_OK))
-      c->lookahead = 1;
+    if (c->lookahead == 2) {
+      c->spec = vt->fork_alloc(env, 2 * W); c->spec2 = vt->fork_alloc(env, 4 * W); c->spec3 = vt->fork_alloc(env, 8 * W);
+      if (!c->spec || !c->spec2 || !c->spec3) c->lookahead = 1;
+    }
   }
   c->obs.resize((size_t)S * W);
   c->next_obs.resize((size_t)S * W);
@@ -107,17 +144,56 @@ static int collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* cart, jh_c
   return JH_OK;
 }
 
+// ---- the two built-in envs as function tables
+static int cart_obs(void* e, int32_t r0, int32_t r1, float* o) { jh_cartpole_obs_rows((const jh_cartpole*)e, r0, r1, o); return JH_OK; }
+static int cart_step(void* e, int32_t r0, int32_t r1, const void* a, float* nx, float* rw, uint8_t* dn) {
+  jh_cartpole_step_rows((jh_cartpole*)e, r0, r1, (const int64_t*)a, nx, rw, dn);
+  return JH_OK;
+}
+static void* cart_fork_alloc(void*, int32_t rows) {
+  jh_cartpole* e = nullptr;
+  return jh_cartpole_create(rows, 0, &e) == JH_OK ? e : nullptr;
+}
+static void cart_fork_free(void* e) { jh_cartpole_destroy((jh_cartpole*)e); }
+static void cart_copy_row(void* d_, int32_t di, const void* s_, int32_t si) {
+  jh_cartpole* d = (jh_cartpole*)d_;
+  const jh_cartpole* s = (const jh_cartpole*)s_;
+  memcpy(&d->s[4 * (size_t)di], &s->s[4 * (size_t)si], sizeof(double) * 4);
+  d->t[di] = s->t[si];
+  d->rng[di] = s->rng[si];
+}
+static int ctl_obs(void* e, int32_t r0, int32_t r1, float* o) {
+  const jh_control* c = (const jh_control*)e;
+  if (r0 != 0 || r1 != c->W) return jh_fail(JH_ERR_ARG, "jh_control: whole-env calls only (rows %d..%d of %d)", r0, r1, c->W);
+  return jh_control_obs(c, o);
+}
+static int ctl_step(void* e, int32_t r0, int32_t r1, const void* a, float* nx, float* rw, uint8_t* dn) {
+  jh_control* c = (jh_control*)e;
+  if (r0 != 0 || r1 != c->W) return jh_fail(JH_ERR_ARG, "jh_control: whole-env calls only (rows %d..%d of %d)", r0, r1, c->W);
+  return jh_control_step(c, (const float*)a, nx, rw, dn);
+}
+
 JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store,
                                   const int32_t* cols /* state, action, reward, next_state, done */,
                                   jh_collector** out) {
-  return collector_create(ctx, net, env, nullptr, store, cols, out);
+  JH_ARG(env != nullptr);
+  const jh_env_vtbl vt{env->W, 4, 2, 0, cart_obs, cart_step, cart_fork_alloc, cart_fork_free, cart_copy_row};
+  return collector_create(ctx, net, &vt, env, store, cols, out);
 }
 
 // The same collector for a continuous-action policy on the synthetic control env (config.ppo.mujoco shapes):
 // store columns state f32[S], action f32[A], reward f32[1], next_state f32[S], done u8[1].
 JH_EXPORT int jh_collector_create_control(jh_ctx* ctx, jh_pponet* net, jh_control* env, jh_store* store, const int32_t* cols,
                                           jh_collector** out) {
-  return collector_create(ctx, net, nullptr, env, store, cols, out);
+  JH_ARG(env != nullptr);
+  const jh_env_vtbl vt{env->W, env->S, env->A, 1, ctl_obs, ctl_step, nullptr, nullptr, nullptr};
+  return collector_create(ctx, net, &vt, env, store, cols, out);
+}
+
+// ANY host env behind the table (a C user's simulator, a test's callbacks): see include/jorldy_hip.h
+JH_EXPORT int jh_collector_create_env(jh_ctx* ctx, jh_pponet* net, const jh_env_vtbl* vt, void* env, jh_store* store, const int32_t* cols,
+                                      jh_collector** out) {
+  return collector_create(ctx, net, vt, env, store, cols, out);
 }
 
 JH_EXPORT void jh_collector_destroy(jh_collector* c) {
@@ -128,9 +204,9 @@ JH_EXPORT void jh_collector_destroy(jh_collector* c) {
     jh_persist_destroy(c->persist);
   }
   if (c->gate_h) (void)hipHostFree(c->gate_h);
-  if (c->spec) jh_cartpole_destroy(c->spec);
-  if (c->spec2) jh_cartpole_destroy(c->spec2);
-  if (c->spec3) jh_cartpole_destroy(c->spec3);
+  if (c->spec) c->vt.fork_free(c->spec);
+  if (c->spec2) c->vt.fork_free(c->spec2);
+  if (c->spec3) c->vt.fork_free(c->spec3);
   run_state_free(c);
   delete c;
 }
@@ -228,6 +304,14 @@ static int run_commit(jh_collector* c, RunState& r, int rc_in, const unsigned* w
 }
 
 static int run_prepare(jh_collector* c, int T, hipStream_t st) {
+  if (c->gate_h) {  // did the commit launch of an EARLIER run give up waiting for its release (it copied nothing then)?
+    const unsigned lost = __atomic_load_n(c->gate_h + 1, __ATOMIC_ACQUIRE);
+    if (lost) {
+      __atomic_store_n(c->gate_h + 1, 0u, __ATOMIC_RELEASE);
+      return jh_fail(JH_ERR_STATE, "the commit launch of an earlier run (tag %u) timed out waiting for its release: that rollout never reached the store and the "
+                                   "learner behind it ran on stale rows -- the agent's weights are not trustworthy", lost);
+    }
+  }
   RunState& r = run_state(c);
   const int W = c->W, A = c->A;
   r = RunState();
@@ -294,8 +378,8 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
   for (int t = t_begin; t < steps; ++t) {
     const bool extra = t == T;  // capture: one value-only query of the states the rollout ended in
     // current state of every env (reset state where it just finished)
-    if (c->cart) jh_cartpole_obs(c->cart, c->obs.data());
-    else jh_control_obs(c->ctl, c->obs.data());
+    rc = c->vt.obs(c->env, 0, W, c->obs.data());
+    if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     if (persistent) {
       const unsigned tag = jh_persist_publish(c->persist, W, c->obs.data());
@@ -354,8 +438,7 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
     }
     const auto t1 = std::chrono::steady_clock::now();
     if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
-    rc = c->cart ? jh_cartpole_step(c->cart, c->act_i.data(), c->next_obs.data(), c->reward.data(), c->done.data())
-                 : jh_control_step(c->ctl, c->act_f.data(), c->next_obs.data(), c->reward.data(), c->done.data());
+    rc = c->vt.step(c->env, 0, W, c->cont ? (const void*)c->act_f.data() : (const void*)c->act_i.data(), c->next_obs.data(), c->reward.data(), c->done.data());
     if (rc) return rc;
     for (int w = 0; w < W; ++w) {
       const size_t row = (size_t)w * T + t;  // worker-major: w0 t0..tT-1, w1 ...  (distributed_manager.py:30)
@@ -394,42 +477,12 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
 // (tests/test_agents_gpu.py: lookahead vs JH_COLLECT_LOOKAHEAD=1); what changes is that the GPU also evaluates the successor that
 // was not taken (8 wasted rows per exchange) and the host steps env copies that are thrown away.
 // *t_done: timesteps (incl. the value-only query) completed; < steps only when the kernel gave up.
-namespace {
-struct Level {  // 2^k W forked envs: row 2 i + a = env i of the level above after action a
-  jh_cartpole* env = nullptr;
-  std::vector<float> next, obs, rw;
-  std::vector<uint8_t> dn;
-  std::vector<int64_t> act;
-  void init(int rows) {
-    next.resize((size_t)4 * rows); obs.resize((size_t)4 * rows); rw.resize(rows); dn.resize(rows); act.resize(rows);
-    for (int i = 0; i < rows; ++i) act[i] = i & 1;
-  }
-};
-inline void copy_env(jh_cartpole* d, int di, const jh_cartpole* s_, int si) {
-  memcpy(&d->s[4 * (size_t)di], &s_->s[4 * (size_t)si], sizeof(double) * 4);
-  d->t[di] = s_->t[si];
-  d->rng[di] = s_->rng[si];
-}
-// dst rows 2 i + a <- src row i stepped with action a (auto-reset included: the row then holds the reset state)
-inline void fork_step(Level& dst, const jh_cartpole* src, int n_src) {
-  for (int i = 0; i < n_src; ++i) { copy_env(dst.env, 2 * i, src, i); copy_env(dst.env, 2 * i + 1, src, i); }
-  jh_cartpole_step_rows(dst.env, 0, 2 * n_src, dst.act.data(), dst.next.data(), dst.rw.data(), dst.dn.data());
-  jh_cartpole_obs_rows(dst.env, 0, 2 * n_src, dst.obs.data());
-}
-inline void copy_level_row(Level& d, int di, const Level& s_, int si) {
-  copy_env(d.env, di, s_.env, si);
-  memcpy(&d.next[4 * (size_t)di], &s_.next[4 * (size_t)si], 16);
-  memcpy(&d.obs[4 * (size_t)di], &s_.obs[4 * (size_t)si], 16);
-  d.rw[di] = s_.rw[si];
-  d.dn[di] = s_.dn[si];
-}
-}  // namespace
-
 static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_h, int* t_done) {
   RunState& r = run_state(c);
   const int W = c->W, S = c->S, T = r.T, steps = T + (r.cap ? 1 : 0);
   const bool cap = r.cap;
-  jh_cartpole* e = c->cart;
+  void* e = c->env;
+  const jh_env_vtbl& vt = c->vt;
   float *ch0 = r.ch0, *cv = r.cv, *cnv = r.cnv;
   float* st = (float*)r.cols[c->col_state];
   int64_t* ac_i = (int64_t*)r.cols[c->col_action];
@@ -438,17 +491,18 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
   uint8_t* dn = (uint8_t*)r.cols[c->col_done];
   const int no = jh_persist_heads(c->persist);  // A logits + value
   const int A = c->A;
-  Level L1, L2, L3, tmp;
+  // the levels' buffers live in the collector (they were re-allocated on every run)
+  Level &L1 = c->lv[0], &L2 = c->lv[1], &L3 = c->lv[2], &tmp = c->lv[3];
   L1.env = c->spec; L2.env = c->spec2; L3.env = c->spec3;
-  L1.init(2 * W); L2.init(4 * W); L3.init(8 * W);
+  L1.init(2 * W, S); L2.init(4 * W, S); L3.init(8 * W, S);
   std::vector<float> pub((size_t)3 * W * S), pub_next((size_t)3 * W * S), hz((size_t)W * no), hz2((size_t)W * no);
   std::vector<int> pick(W);
   std::vector<int64_t> a0(W), a1(W);
   int t = 0;
   *t_done = 0;
   // rows 0 .. W-1: the envs' current states; rows W + 2 w + a: the state env w acts on next if it takes action a now
-  fork_step(L1, e, W);
-  jh_cartpole_obs(e, pub.data());
+  fork_step(vt, L1, e, W);
+  vt.obs(e, 0, W, pub.data());
   memcpy(pub.data() + (size_t)W * S, L1.obs.data(), sizeof(float) * (size_t)2 * W * S);
   auto t0 = std::chrono::steady_clock::now();
   unsigned tag = jh_persist_publish(c->persist, 3 * W, pub.data());
@@ -457,8 +511,8 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
     const bool two = !extra && t + 1 < T;
     const int t_next = t + (two ? 2 : 1);
     if (!extra) {  // the GPU is busy for ~5 us: run the env model two levels further meanwhile
-      fork_step(L2, L1.env, 2 * W);
-      if (two && t_next < steps) fork_step(L3, L2.env, 4 * W);
+      fork_step(vt, L2, L1.env, 2 * W);
+      if (two && t_next < steps) fork_step(vt, L3, L2.env, 4 * W);
     }
     int rc = jh_persist_collect_rows(c->persist, nullptr, W, tag, hz.data());
     if (rc) {  // the kernel gave up (it exits by itself)
@@ -528,7 +582,7 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
       break;
     }
     if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
-    if (!two) { tmp.env = L3.env; tmp.init(2 * W); }  // one-step exchange: L3 is free, the successors move up through it
+    if (!two) { tmp.env = L3.env; tmp.init(2 * W, S); }  // one-step exchange: L3 is free, the successors move up through it
     for (int w = 0; w < W; ++w) {
       const int k1 = 2 * w + (int)a0[w];
       size_t row = (size_t)w * T + t;  // worker-major (distributed_manager.py:30)
@@ -545,19 +599,19 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
         ac_i[row] = a1[w];
         rw[row] = L2.rw[k2];
         dn[row] = L2.dn[k2];
-        copy_env(e, w, L2.env, k2);
+        vt.copy_row(e, w, L2.env, k2);
         if (t_next < steps) {  // (L1's rows of env w are read above before they are overwritten)
-          copy_level_row(L1, 2 * w, L3, 2 * k2);
-          copy_level_row(L1, 2 * w + 1, L3, 2 * k2 + 1);
+          copy_level_row(vt, L1, 2 * w, L3, 2 * k2);
+          copy_level_row(vt, L1, 2 * w + 1, L3, 2 * k2 + 1);
         }
       } else {
-        copy_env(e, w, L1.env, k1);
-        copy_level_row(tmp, 2 * w, L2, 2 * k1);
-        copy_level_row(tmp, 2 * w + 1, L2, 2 * k1 + 1);
+        vt.copy_row(e, w, L1.env, k1);
+        copy_level_row(vt, tmp, 2 * w, L2, 2 * k1);
+        copy_level_row(vt, tmp, 2 * w + 1, L2, 2 * k1 + 1);
       }
     }
     if (!two)
-      for (int i = 0; i < 2 * W; ++i) copy_level_row(L1, i, tmp, i);
+      for (int i = 0; i < 2 * W; ++i) copy_level_row(vt, L1, i, tmp, i);
     c->steps += two ? 2 : 1;
     const auto t2 = std::chrono::steady_clock::now();
     c->t_act += std::chrono::duration<double>(t1 - t0).count();
@@ -602,7 +656,8 @@ JH_EXPORT int jh_collector_begin(jh_collector* c, int32_t T, jh_stream stream) {
   if (!c->gate_h) {
     JH_HIP(hipHostMalloc((void**)&c->gate_h, 64, hipHostMallocMapped));
     JH_HIP(hipHostGetDevicePointer((void**)&c->gate_d, c->gate_h, 0));
-    *c->gate_h = 0;
+    c->gate_h[0] = 0;  // the release word
+    c->gate_h[1] = 0;  // tag of a run whose commit launch timed out waiting for it (jh_store_copy_cols_kernel)
   }
   int rc = run_prepare(c, T, jh_s(stream));
   if (rc) return rc;

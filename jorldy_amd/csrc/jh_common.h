@@ -44,13 +44,16 @@ int jh_fail(int code, const char* fmt, ...);
 // average is the kernel's duration in a dependent chain -- comparable with rocprofv3's kernel-trace average.
 extern bool g_jh_prof_on;
 extern int g_jh_prof_repeat;
+// A sticky / asynchronous HIP error left behind by earlier work: clearing it keeps THIS launch's check meaningful, but it must not vanish --
+// it goes to jh_last_error() and (the first few times) to stderr, attributed to "before <launch>".
+void jh_note_earlier_error(hipError_t e, const char* before);
 void jh_prof_begin(const char* name, hipStream_t st, int reps, double work);
 void jh_prof_end(hipStream_t st);
 #define JH_LAUNCH_WORK(NAME, WORK, REPS, KERNEL, GRID, BLOCK, LDS, ST, ...)  \
   do {                                                                       \
     const int _reps = g_jh_prof_on ? (REPS) : 1;                             \
     if (g_jh_prof_on) jh_prof_begin(NAME, ST, _reps, WORK);                  \
-    (void)hipGetLastError(); /* a stale error of an earlier call (e.g. a capture torch abandoned) is not this launch's */ \
+    jh_note_earlier_error(hipGetLastError(), NAME); /* an error of EARLIER work (a capture torch abandoned, another library's launch) is not this launch's: cleared, but no longer silently */ \
     for (int _i = 0; _i < _reps; ++_i) hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__); \
     if (g_jh_prof_on) jh_prof_end(ST);                                       \
   } while (0)
@@ -146,13 +149,15 @@ void jh_cartpole_step_rows(jh_cartpole* e, int r0, int r1, const int64_t* h_acti
 struct jh_pponet {
   jh_ctx* ctx = nullptr;
   int S = 0, H = 0, A = 0, cont = 0, max_rows = 0;
+  int n_out = 0;  // head outputs: A + 1 (discrete) | 2 A + 1 (continuous)
+  int gld = 8;    // row width of g_all: 8, or n_out rounded up to 4 beyond 8 outputs (separate-call / tiled paths only)
   int64_t n_params = 0;
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;  // borrowed flat buckets
   // offsets into the flat buckets (state_dict order)
   int64_t o_w1, o_b1, o_w2, o_b2, o_wh0, o_bh0, o_wh1, o_bh1, o_wv, o_bv;
   // owned workspaces
   float *h1 = nullptr, *h2 = nullptr, *dh1 = nullptr, *dh2 = nullptr;
-  float* g_all = nullptr;     // [max_rows][8] packed head gradients (A-operand of the dW_heads GEMM)
+  float* g_all = nullptr;     // [max_rows][gld] packed head gradients (A-operand of the dW_heads GEMM)
   float* dv2 = nullptr;       // [min(max_rows, 1024)] value gradients of the critic's second branch (data-parallel exact critic) + 8 floats:
   float* stats_tmp = nullptr; // the loss kernel's local statistics row between jh_pponet_ppo_update_dp_begin and _end
   int max_act_rows = 0;
@@ -161,6 +166,7 @@ struct jh_pponet {
   float *part_pin_h = nullptr, *part_pin_d = nullptr;      // [H/16][max_act_rows][8] partial head outputs (kernel writes)
   unsigned *flag_pin_h = nullptr, *flag_pin_d = nullptr;   // [tiles] per-tile sequence words
   unsigned act_seq = 0;
+  float *act_out_h = nullptr, *act_out_d = nullptr;        // [max_act_rows][n_out] raw heads of nets with more than 8 outputs (pinned + mapped)
   uint64_t act_seed = 0, act_ctr = 0;  // host-side counter-based sampling stream
   float* fwd_part = nullptr;      // [H/16][max_rows][8] per-column-tile partial head outputs (jh_ppo_mb.hip forward)
   float* part_w1 = nullptr;       // [min(max_rows,1024)/16][H*S + H] per-row-tile partial (dW1 | db1) sums
@@ -193,7 +199,7 @@ static inline int64_t jh_sample_discrete(const jh_pponet* n, const float* z, int
   for (int k = 1; k < A; ++k)
     if (z[k] > mx) { mx = z[k]; act = k; }
   if (!training) return act;
-  float e[16], se = 0.f;
+  float e[40], se = 0.f;  // (jh_pponet_create: <= 40 head outputs)
   for (int k = 0; k < A; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
   const float u = (float)jh_u01_of(n->act_seed * 0x100000001B3ull + n->act_ctr * 0x9E3779B97F4A7C15ull + (uint64_t)wq) * se;
   float c = 0.f;

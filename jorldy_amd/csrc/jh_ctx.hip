@@ -283,6 +283,17 @@ JH_EXPORT int jh_calib_stream(jh_ctx* ctx, const void* d_src, int64_t bytes, int
 // ------------------------------------------------------------------------------ kernel profiler
 #include <map>
 bool g_jh_prof_on = false;
+void jh_note_earlier_error(hipError_t e, const char* before) {
+  if (e == hipSuccess) return;
+  static int shown = 0;
+  char buf[256];
+  snprintf(buf, sizeof buf, "an earlier HIP error surfaced before launching %s: %s (cleared; it belongs to work enqueued before this call)", before, hipGetErrorString(e));
+  jh_err_slot() = buf;
+  if (shown < 8) {
+    ++shown;
+    fprintf(stderr, "[libjorldy_hip] %s\n", buf);
+  }
+}
 int g_jh_prof_repeat = 1;
 namespace {
 struct ProfRec {

@@ -24,6 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int kNormBlocks = 256;
+constexpr int kMaxHeadOutputs = 40;
 }
 
 // ============================================================================ layer 1 (K = S, tiny)
@@ -372,8 +373,9 @@ struct HeadPtrs {
 
 // forward: one wave per row; lanes split H.  All (<= 8) outputs' lane-partial dot products first, then their shuffle reductions
 // INTERLEAVED (the same tree per output as one reduction after the other: identical bits; seven dependent 6-step chains one after the
-// other were most of the kernel's 9-11 us at B = 2048)
-__global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, const float* __restrict__ h2, HeadPtrs hp) {
+// other were most of the kernel's 9-11 us at B = 2048).  o_begin: first flat output of this launch -- nets with more than 8 head
+// outputs (config.ppo.mujoco on HalfCheetah / Walker / Ant: 2 A + 1 = 13 / 13 / 17) take one launch per 8 outputs (round 5).
+__global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, const float* __restrict__ h2, HeadPtrs hp, int o_begin) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -381,12 +383,14 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, con
   const float* wrow[8];
   float* dst[8];
   float bias[8];
-  int n_out = 0;
+  int n_out = 0, o_flat = 0;
   for (int g = 0; g < hp.groups; ++g)
-    for (int o = 0; o < hp.n[g] && n_out < 8; ++o, ++n_out) {
+    for (int o = 0; o < hp.n[g]; ++o, ++o_flat) {
+      if (o_flat < o_begin || n_out >= 8) continue;
       wrow[n_out] = hp.w[g] + (size_t)o * H;
       dst[n_out] = hp.out[g] + (size_t)b * hp.n[g] + o;
       bias[n_out] = hp.b[g][o];
+      ++n_out;
     }
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k = lane * 4; k < H; k += 256) {
@@ -418,7 +422,7 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, con
 // the head gradients into g_all[b][8] (the A operand of the head-weight-gradient GEMM).
 __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, const float* __restrict__ h2,
                                                                   float* __restrict__ dh2, float* __restrict__ g_all,
-                                                                  HeadPtrs hp) {
+                                                                  HeadPtrs hp, int gld) {
   // four consecutive hidden units per thread (H % 4 == 0: 16-byte loads of h2 / the head weight rows, one 16-byte store of dh2);
   // the sum over the outputs runs in the same order per element as one thread per element did
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -437,7 +441,7 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, 
     }
   const float4 hv = *reinterpret_cast<const float4*>(h2 + (size_t)b * H + k);
   *reinterpret_cast<float4*>(dh2 + (size_t)b * H + k) = make_float4(hv.x > 0.f ? acc[0] : 0.f, hv.y > 0.f ? acc[1] : 0.f, hv.z > 0.f ? acc[2] : 0.f, hv.w > 0.f ? acc[3] : 0.f);
-  if (k < 8) *reinterpret_cast<float4*>(g_all + (size_t)b * 8 + k) = make_float4(mine[0], mine[1], mine[2], mine[3]);  // zero beyond the head outputs
+  if (k < gld) *reinterpret_cast<float4*>(g_all + (size_t)b * gld + k) = make_float4(mine[0], mine[1], mine[2], mine[3]);  // zero beyond the head outputs (gld: 8, or the output count rounded up to 4)
 }
 
 // ============================================================================ clip_grad_norm_ + Adam
@@ -585,7 +589,9 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   JH_ARG(ctx && out && d_params && d_grads && d_m && d_v);
   JH_ARG(S > 0 && A > 0 && max_rows > 0);
   JH_ARG(H >= 16 && H % 16 == 0);
-  JH_ARG((continuous ? 2 * A + 1 : A + 1) <= 8);
+  // <= 8 head outputs: every path (the 4-launch minibatch update, the persistent acting kernel).  9 .. 40 (continuous A <= 19: Humanoid's
+  // 17; discrete A <= 39): the separate forward / backward calls and the tiled engine -- wider action spaces than Hopper's run, slower
+  JH_ARG((continuous ? 2 * A + 1 : A + 1) <= kMaxHeadOutputs);
   JH_HIP(hipSetDevice(ctx->device));
   jh_pponet* n = new jh_pponet();
   n->ctx = ctx; n->S = S; n->H = H; n->A = A; n->cont = continuous ? 1 : 0; n->max_rows = max_rows;
@@ -596,7 +602,9 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   JH_HIP(hipMalloc((void**)&n->h2, act));
   JH_HIP(hipMalloc((void**)&n->dh1, act));
   JH_HIP(hipMalloc((void**)&n->dh2, act));
-  JH_HIP(hipMalloc((void**)&n->g_all, sizeof(float) * 8 * (size_t)max_rows));
+  n->n_out = continuous ? 2 * A + 1 : A + 1;
+  n->gld = n->n_out <= 8 ? 8 : (n->n_out + 3) / 4 * 4;
+  JH_HIP(hipMalloc((void**)&n->g_all, sizeof(float) * (size_t)n->gld * (size_t)max_rows));
   n->max_act_rows = max_rows < 1024 ? max_rows : 1024;
   {
     const size_t tiles = (size_t)((n->max_act_rows + 15) / 16) * (size_t)(H / 16);
@@ -608,6 +616,10 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     JH_HIP(hipHostGetDevicePointer((void**)&n->flag_pin_d, n->flag_pin_h, 0));
     memset(n->flag_pin_h, 0, sizeof(unsigned) * tiles);
     n->act_seed = seed;
+    if (n->n_out > 8) {
+      JH_HIP(hipHostMalloc((void**)&n->act_out_h, sizeof(float) * (size_t)n->max_act_rows * (size_t)n->n_out, hipHostMallocMapped));
+      JH_HIP(hipHostGetDevicePointer((void**)&n->act_out_d, n->act_out_h, 0));
+    }
   }
   n->tg_ws_floats = (size_t)4 << 20;
   n->tg_cnt_slots = 4096;
@@ -619,7 +631,7 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     const size_t part_bytes = sizeof(float) * 8 * (size_t)max_rows * (size_t)(H / 16);
     JH_HIP(hipMalloc((void**)&n->fwd_part, part_bytes));
     JH_HIP(hipMemset(n->fwd_part, 0, part_bytes));  // head slots >= n_out are never written: they must read as 0
-    JH_HIP(hipMemset(n->g_all, 0, sizeof(float) * 8 * (size_t)max_rows));
+    JH_HIP(hipMemset(n->g_all, 0, sizeof(float) * (size_t)n->gld * (size_t)max_rows));
     JH_HIP(hipMalloc((void**)&n->dv2, sizeof(float) * ((size_t)(max_rows < 1024 ? max_rows : 1024) + 8)));
     n->stats_tmp = n->dv2 + (max_rows < 1024 ? max_rows : 1024);
     const size_t slabs = (size_t)(((max_rows < 1024 ? max_rows : 1024) + 15) / 16);
@@ -642,6 +654,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   (void)hipFree(n->h1); (void)hipFree(n->h2); (void)hipFree(n->dh1); (void)hipFree(n->dh2);
   (void)hipFree(n->g_all);
   (void)hipHostFree(n->obs_pin_h); (void)hipHostFree(n->part_pin_h); (void)hipHostFree(n->flag_pin_h);
+  if (n->act_out_h) (void)hipHostFree(n->act_out_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper); (void)hipFree(n->dv2);
   (void)hipFree(n->fwd_part); (void)hipFree(n->part_w1); (void)hipFree(n->ssq_part);
   (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt); (void)hipFree(n->xg);
@@ -704,7 +717,7 @@ static HeadPtrs head_ptrs(jh_pponet* n, float* out0, float* out1, float* outv, c
 }
 
 // Flat list of head outputs: weight row / weight-grad row / bias / bias-grad of output o.
-static int head_rows(jh_pponet* n, const float* w[8], float* dw[8], const float* b[8], float* db[8]) {
+static int head_rows(jh_pponet* n, const float** w, float** dw, const float** b, float** db) {
   int o = 0;
   for (int a = 0; a < n->A; ++a, ++o) {
     w[o] = n->params + n->o_wh0 + (int64_t)a * n->H; dw[o] = n->grads + n->o_wh0 + (int64_t)a * n->H;
@@ -947,8 +960,10 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   }
   if (rc) return rc;
   HeadPtrs hp = head_ptrs(n, d_head0, d_head1, d_value, nullptr, nullptr, nullptr);
-  JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp);
-  JH_LAUNCH_CHECK();
+  for (int o0 = 0; o0 < n->n_out; o0 += 8) {  // one launch per 8 head outputs (Hopper / CartPole: one)
+    JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp, o0);
+    JH_LAUNCH_CHECK();
+  }
   return JH_OK;
 }
 
@@ -966,10 +981,11 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
   const int64_t bh = (int64_t)B * H;
   HeadPtrs hp = head_ptrs(n, nullptr, nullptr, nullptr, d_g_head0, d_g_head1, d_g_value);
   JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh / 4 + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
-            n->g_all, hp);
+            n->g_all, hp, n->gld);
   JH_LAUNCH_CHECK();
-  const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
+  const float* w[kMaxHeadOutputs]; float* dw[kMaxHeadOutputs]; const float* b[kMaxHeadOutputs]; float* db[kMaxHeadOutputs];
   const int n_out = head_rows(n, w, dw, b, db);
+  const int gld = n->gld;
   int rc;
   if (pponet_use_tiled(B)) {
     // dW2, dh1 and the head weight gradients only need dh2 / g_all: ONE grouped launch of the tiled MFMA GEMM
@@ -977,6 +993,7 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     const int A = n->A;
     TGemm g[6];
     int ng = 0;
+    (void)n_out;
     // dW2[o][i] = sum_b dh2[b][o] h1[b][i], db2 as the A-operand row sum
     g[ng++] = mk_gemm(H, H, B, op_dense(OP_XCONT, n->dh2, H), op_dense(OP_XCONT, n->h1, H), n->grads + n->o_w2, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b2);
     // dh1[b][i] = relu'(h1) * sum_o dh2[b][o] W2[o][i]
@@ -985,29 +1002,30 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
     // when that runs, else three more problems of this group
     static const bool kDw1Gemm = getenv("JH_PPO_DW1_GEMM") && atoi(getenv("JH_PPO_DW1_GEMM")) != 0;  // A/B: round 2's tile-engine form
     const bool reduce = !kDw1Gemm && pponet_dw1_reduce_fits(B, S);
-    if (!reduce) {
-      g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh0, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh0);
+    const bool reduce_heads = reduce && n->n_out <= 8;  // the column reduction carries 8 head columns; wider heads: three more problems of this group
+    if (!reduce_heads) {
+      g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all, gld), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh0, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh0);
       int col = A;
       if (n->cont) {
-        g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh1, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh1);
+        g[ng++] = mk_gemm(A, H, B, op_dense(OP_XCONT, n->g_all + col, gld), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wh1, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bh1);
         col += A;
       }
-      g[ng++] = mk_gemm(1, H, B, op_dense(OP_XCONT, n->g_all + col, 8), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wv, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bv);
+      g[ng++] = mk_gemm(1, H, B, op_dense(OP_XCONT, n->g_all + col, gld), op_dense(OP_XCONT, n->h2, H), n->grads + n->o_wv, H, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_bv);
     }
     TGemmWorkspace tw;
     tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
     rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd", g, ng, st);
     if (rc) return rc;
-    if (reduce) return pponet_dw1_reduce(n, B, d_x, d_idx, true, st);
+    if (reduce) return pponet_dw1_reduce(n, B, d_x, d_idx, reduce_heads, st);
     JH_LAUNCH(jh_rowgather_f32_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, st, B, S, d_x, d_idx, n->xg);
     JH_LAUNCH_CHECK();
     g[0] = mk_gemm(H, S, B, op_dense(OP_XCONT, n->dh1, H), op_dense(OP_XCONT, n->xg, S), n->grads + n->o_w1, S, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b1);
     return jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd_dW1", g, 1, st);
   }
-  {  // dWh[o][k] = sum_b g[b][o] h2[b][k] ; dbh[o] = sum_b g[b][o]      (A = g_all^T stored [K=B][8])
+  for (int o0 = 0; o0 < n_out; o0 += 8) {  // dWh[o][k] = sum_b g[b][o] h2[b][k] ; dbh[o] = sum_b g[b][o]   (A = g_all^T stored [K=B][gld]; 8 output rows per launch)
     GemmArgs g{};
-    g.M = n_out; g.N = H; g.K = B; g.A = n->g_all; g.lda = 8; g.B = n->h2; g.ldb = H;
-    for (int o = 0; o < n_out; ++o) { g.rowptr[o] = dw[o]; g.rowsum_ptr[o] = db[o]; }
+    g.M = n_out - o0 < 8 ? n_out - o0 : 8; g.N = H; g.K = B; g.A = n->g_all + o0; g.lda = gld; g.B = n->h2; g.ldb = H;
+    for (int o = 0; o < g.M; ++o) { g.rowptr[o] = dw[o0 + o]; g.rowsum_ptr[o] = db[o0 + o]; }
     rc = launch_gemm<1, false, EPI_ROWPTR, true, 1, 1>("jh_gemm16_bwd_dWheads", g, st);
     if (rc) return rc;
   }
@@ -1148,14 +1166,36 @@ JH_EXPORT int jh_pponet_ppo_update_dp_end(jh_pponet* n, int32_t B, const float* 
 // h_obs [W][S] and h_action [W] are ordinary host pointers; the call returns when the actions are
 // there (acting is synchronous by nature: the envs need them).  h_logits_out / h_value_out optional.
 // raw head outputs z [W][8] (flat output order: head0[A], head1[A] (continuous), value) of W observation rows
+// zld: row stride of z_out (8, or n_out beyond 8 outputs)
+static inline int pponet_zld(const jh_pponet* n) { return n->n_out <= 8 ? 8 : n->n_out; }
 static int pponet_act_raw(jh_pponet* n, int32_t W, const float* h_obs, float* z_out, hipStream_t st) {
   const int H = n->H;
+  if (n->n_out > 8) {
+    // more than 8 head outputs (round 5): the separate-call forward writes the raw heads straight into device-mapped pinned memory;
+    // three launches + a stream sync per timestep instead of one launch + a flag spin -- the wide action spaces run, slower
+    memcpy(n->obs_pin_h, h_obs, sizeof(float) * (size_t)W * n->S);
+    const int A = n->A;
+    float* d0 = n->act_out_d;
+    float* d1 = n->cont ? d0 + (size_t)W * A : nullptr;
+    float* dv = d0 + (size_t)(n->cont ? 2 : 1) * W * A;
+    int rc = jh_pponet_forward(n, W, n->obs_pin_d, nullptr, d0, d1, dv, (jh_stream)st);
+    if (rc) return rc;
+    JH_HIP(hipStreamSynchronize(st));
+    const float *h0 = n->act_out_h, *h1 = h0 + (size_t)W * A, *hv = h0 + (size_t)(n->cont ? 2 : 1) * W * A;
+    for (int wq = 0; wq < W; ++wq) {
+      float* z = z_out + (size_t)n->n_out * wq;
+      memcpy(z, h0 + (size_t)wq * A, sizeof(float) * A);
+      if (n->cont) memcpy(z + A, h1 + (size_t)wq * A, sizeof(float) * A);
+      z[n->n_out - 1] = hv[wq];
+    }
+    return JH_OK;
+  }
   const int tiles_n = H / 16, tiles = ((W + 15) / 16) * tiles_n;
   // (tried: observations inline in the kernel-argument segment -- the 1 KB larger kernarg made every
   // launch slower than the one PCIe read it saved: 21.9 vs 18.8 us per timestep)
   memcpy(n->obs_pin_h, h_obs, sizeof(float) * (size_t)W * n->S);
   const float* w[8]; float* dw[8]; const float* b[8]; float* db[8];
-  const int n_out = head_rows(n, w, dw, b, db);
+  const int n_out = head_rows(n, w, dw, b, db);  // (<= 8 here)
   GemmArgs g{};
   g.M = W; g.N = H; g.K = H; g.B = n->params + n->o_w2; g.ldb = H; g.C = nullptr; g.aux = n->params + n->o_b2;
   g.x = n->obs_pin_d; g.x_rows = nullptr; g.W1 = n->params + n->o_w1; g.b1 = n->params + n->o_b1; g.S = n->S;
@@ -1198,13 +1238,14 @@ JH_EXPORT int jh_pponet_act_discrete(jh_pponet* n, int32_t W, const float* h_obs
   JH_ARG(n && h_obs && h_action);
   JH_ARG(!n->cont);
   JH_ARG(W > 0 && W <= n->max_act_rows);
-  std::vector<float> z(8 * (size_t)W);
+  const size_t zld = (size_t)pponet_zld(n);
+  std::vector<float> z(zld * (size_t)W);
   int rc = pponet_act_raw(n, W, h_obs, z.data(), jh_s(stream));
   if (rc) return rc;
   for (int wq = 0; wq < W; ++wq) {
-    h_action[wq] = jh_sample_discrete(n, z.data() + 8 * (size_t)wq, wq, training);
-    if (h_logits_out) memcpy(h_logits_out + (size_t)wq * n->A, z.data() + 8 * (size_t)wq, sizeof(float) * n->A);
-    if (h_value_out) h_value_out[wq] = z[8 * (size_t)wq + n->A];
+    h_action[wq] = jh_sample_discrete(n, z.data() + zld * (size_t)wq, wq, training);
+    if (h_logits_out) memcpy(h_logits_out + (size_t)wq * n->A, z.data() + zld * (size_t)wq, sizeof(float) * n->A);
+    if (h_value_out) h_value_out[wq] = z[zld * (size_t)wq + n->A];
   }
   n->act_ctr += 1;
   return JH_OK;
@@ -1217,15 +1258,16 @@ JH_EXPORT int jh_pponet_act_continuous(jh_pponet* n, int32_t W, const float* h_o
   JH_ARG(n && h_obs && h_action);
   JH_ARG(n->cont);
   JH_ARG(W > 0 && W <= n->max_act_rows);
-  std::vector<float> z(8 * (size_t)W);
+  const size_t zld = (size_t)pponet_zld(n);
+  std::vector<float> z(zld * (size_t)W);
   int rc = pponet_act_raw(n, W, h_obs, z.data(), jh_s(stream));
   if (rc) return rc;
   const int A = n->A;
   for (int wq = 0; wq < W; ++wq) {
-    jh_sample_continuous(n, z.data() + 8 * (size_t)wq, wq, training, h_action + (size_t)wq * A);
-    if (h_mu_raw_out) memcpy(h_mu_raw_out + (size_t)wq * A, z.data() + 8 * (size_t)wq, sizeof(float) * A);
-    if (h_log_std_raw_out) memcpy(h_log_std_raw_out + (size_t)wq * A, z.data() + 8 * (size_t)wq + A, sizeof(float) * A);
-    if (h_value_out) h_value_out[wq] = z[8 * (size_t)wq + 2 * A];
+    jh_sample_continuous(n, z.data() + zld * (size_t)wq, wq, training, h_action + (size_t)wq * A);
+    if (h_mu_raw_out) memcpy(h_mu_raw_out + (size_t)wq * A, z.data() + zld * (size_t)wq, sizeof(float) * A);
+    if (h_log_std_raw_out) memcpy(h_log_std_raw_out + (size_t)wq * A, z.data() + zld * (size_t)wq + A, sizeof(float) * A);
+    if (h_value_out) h_value_out[wq] = z[zld * (size_t)wq + 2 * A];
   }
   n->act_ctr += 1;
   return JH_OK;

@@ -30,7 +30,9 @@
 // is a second set of 32 workgroups (grid = column tiles x row tiles): a step's compute stays the one-tile 1.65 us.
 // Heads: G = ceil(n_out / 3) granules per (tile, row), n_out = A logits (or mu / log_std of a continuous policy) + the value
 // head (last output; handed to the learner by the collector's capture): discrete A <= 11, continuous A <= 5.
+#if defined(__x86_64__)
 #include <emmintrin.h>
+#endif
 
 #include "jh_common.h"
 
@@ -412,7 +414,8 @@ int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned
   // [tiles][G][ld] granules of 16 bytes {out, out, out, tag}: ONE 16-byte load per granule serves the tag check and the sum (the
   // device's 16-byte store is one PCIe write: tag and payload arrive together); a row is summed tile by tile as its granules are
   // found, and only the missing rows are re-polled
-  const __m128i* part = reinterpret_cast<const __m128i*>(p->part_h);
+  struct alignas(16) Gran16 { unsigned w[4]; };
+  const Gran16* part = reinterpret_cast<const Gran16*>(p->part_h);
   float z[32][12];
   unsigned char have[32];
   JH_ARG(n_rows <= 32);
@@ -426,9 +429,18 @@ int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned
       bool ok = true;
       for (int t = 0; t < tiles && ok; ++t)
         for (int g = 0; g < G; ++g) {
-          const __m128i q = _mm_load_si128(part + ((size_t)t * G + g) * ld + wq);
+          // tag first (acquire), payload after it: the device writes a granule as ONE 16-byte store, so a host that has seen the new
+          // tag sees the new payload in any LATER load (x86: loads are not reordered with older loads).  This does not lean on the
+          // 16-byte load itself being single-copy atomic (guaranteed on AVX-capable CPUs only); the tag inside the value is
+          // checked once more in case the granule was rewritten between the two loads
+          const Gran16* gp = part + ((size_t)t * G + g) * ld + wq;
+          if (__atomic_load_n(reinterpret_cast<const unsigned*>(gp) + 3, __ATOMIC_ACQUIRE) != tag) { ok = false; break; }
           alignas(16) unsigned w4[4];
-          _mm_store_si128(reinterpret_cast<__m128i*>(w4), q);
+#if defined(__x86_64__)
+          _mm_store_si128(reinterpret_cast<__m128i*>(w4), _mm_load_si128(reinterpret_cast<const __m128i*>(gp)));
+#else
+          memcpy(w4, gp, 16);
+#endif
           if (w4[3] != tag) { ok = false; break; }
           float f3[3];
           memcpy(f3, w4, 12);

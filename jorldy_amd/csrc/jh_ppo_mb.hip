@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(256) jh_pmb_norm_kernel(int64_t n, float* __re
 }
 
 // ============================================================================ host side
-bool jh_pmb_eligible(const jh_pponet* n, int B) { return n->H % 32 == 0 && B > 0 && B <= n->max_rows; }
+bool jh_pmb_eligible(const jh_pponet* n, int B) { return n->H % 32 == 0 && B > 0 && B <= n->max_rows && n->n_out <= 8; }  // (packed [B][8] head gradients, 8 partial-head slots per tile)
 
 template <int SV, bool GEN>
 static int pmb_fwd_launch(const PmbFwd& g, hipStream_t st) {

@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
     // the launch sits behind the acting kernel in stream order, so in practice the flag arrives within a microsecond or two), then
     // the sources -- fine-grained host memory, never cached on the device -- are read.
     // The host ABORTS a run by storing gate_val | 0x80000000 (jh_collector_loop after an error: half-filled staging rows must not reach
-    // the store): the launch then copies nothing.  On a timeout nothing is copied either; the stream drains, the host reports the failed run.
+    // the store): the launch then copies nothing.  On a timeout nothing is copied either and gate[1] carries the run's tag: the stream
+    // drains, the collector's next run reports the failed one (jh_collect.hip: run_prepare).
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
       int ok = 0;
@@ -77,6 +78,10 @@ __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
         __builtin_amdgcn_s_sleep(8);
       }
       s_ok = ok;
+      // a TIMEOUT (not an abort) is reported: gate[1] <- the run's tag, in the same device-mapped page; the collector's next run fails
+      // with it instead of training on rows that never arrived
+      if (!ok && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (a.gate_val | 0x80000000u))
+        __hip_atomic_store(const_cast<unsigned*>(a.gate) + 1, a.gate_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     if (!s_ok) return;

@@ -61,9 +61,95 @@ class VecCollector:
         return None
 
 
+class JhEnvVtbl(C.Structure):
+    """include/jorldy_hip.h: jh_env_vtbl."""
+    OBS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float))
+    STEP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+    FORK_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32)
+    FORK_FREE = C.CFUNCTYPE(None, C.c_void_p)
+    COPY_ROW = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32)
+    _fields_ = [("W", C.c_int32), ("S", C.c_int32), ("A", C.c_int32), ("continuous", C.c_int32), ("obs", OBS), ("step", STEP),
+                ("fork_alloc", FORK_ALLOC), ("fork_free", FORK_FREE), ("copy_row", COPY_ROW)]
+
+
+class PythonEnvTable:
+    """A Python vector env behind the C collector's function table (jh_collector_create_env): the rollout loop, the persistent acting
+    kernel and the staging stay native, only obs / step call back into Python -- any env with the VecCollector protocol
+
+        env.W, env.state_size, env.action_size, env.action_type
+        env.obs(out [W, S] float32)                       current observations (the reset observation where an episode just ended)
+        env.step(action, next_obs, reward, done)          writes float32 [W, S], float32 [W], uint8 [W]; finished rows reset themselves
+
+    and, optionally (both or neither): env.fork(rows) -> an env of `rows` rows with the same protocol whose obs / step also take a row
+    range, and env.copy_row(di, src_env, si).  With them a two-action discrete env gets two timesteps per acting exchange, like the
+    built-in CartPole.  The callbacks hold the GIL for their duration (jh_collector_run is entered through ctypes, which releases it)."""
+
+    def __init__(self, env):
+        self.env = env
+        W, S, A = int(env.W), int(env.state_size), int(env.action_size)
+        cont = env.action_type == "continuous"
+        self._scratch = {}  # handle -> forked env (kept alive until fork_free)
+        self._next_handle = 1
+
+        def rows_of(handle):
+            return env if handle in (None, 0) or handle == 1 << 62 else self._scratch[handle]
+
+        def obs_cb(handle, r0, r1, out):
+            try:
+                e, n = rows_of(handle), r1 - r0
+                buf = np.ctypeslib.as_array(out, shape=(n, S))
+                if e is env:
+                    e.obs(buf)
+                else:
+                    e.obs(buf, r0, r1)
+                return 0
+            except Exception:  # noqa: BLE001 -- an exception must not unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return -2
+
+        def step_cb(handle, r0, r1, action, nxt, rew, done):
+            try:
+                e, n = rows_of(handle), r1 - r0
+                a = np.ctypeslib.as_array(C.cast(action, C.POINTER(C.c_float if cont else C.c_int64)), shape=(n, A) if cont else (n,))
+                args = (a, np.ctypeslib.as_array(nxt, shape=(n, S)), np.ctypeslib.as_array(rew, shape=(n,)), np.ctypeslib.as_array(done, shape=(n,)))
+                if e is env:
+                    e.step(*args)
+                else:
+                    e.step(*args, r0, r1)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return -2
+
+        forkable = hasattr(env, "fork") and hasattr(env, "copy_row")
+
+        def fork_alloc_cb(_handle, rows):
+            h = self._next_handle = self._next_handle + 1
+            self._scratch[h] = env.fork(int(rows))
+            return h
+
+        def fork_free_cb(handle):
+            self._scratch.pop(handle, None)
+
+        def copy_row_cb(dst, di, src, si):
+            rows_of(dst).copy_row(int(di), rows_of(src), int(si))
+
+        self._cbs = (JhEnvVtbl.OBS(obs_cb), JhEnvVtbl.STEP(step_cb),
+                     JhEnvVtbl.FORK_ALLOC(fork_alloc_cb) if forkable else JhEnvVtbl.FORK_ALLOC(),
+                     JhEnvVtbl.FORK_FREE(fork_free_cb) if forkable else JhEnvVtbl.FORK_FREE(),
+                     JhEnvVtbl.COPY_ROW(copy_row_cb) if forkable else JhEnvVtbl.COPY_ROW())
+        self.table = JhEnvVtbl(W, S, A, int(cont), *self._cbs)
+        self.handle = C.c_void_p(1 << 62)  # the env itself (any non-null cookie: the callbacks close over the object)
+
+
 class NativeCollector:
-    """jh_collector_*: the whole T-step rollout loop in one C call for a native PPO agent on a native vectorised env:
-    ops.CartPoleVec (discrete policy) or ops.ControlVec (continuous policy, config.ppo.mujoco shapes).  `run(step)`
+    """jh_collector_*: the whole T-step rollout loop in one C call for a native PPO agent on a vectorised env: the library's own
+    ops.CartPoleVec (discrete policy) / ops.ControlVec (continuous policy, config.ppo.mujoco shapes), or ANY Python vector env with the
+    VecCollector protocol, which is then put behind the collector's function table (PythonEnvTable, jh_collector_create_env).  `run(step)`
     appends W*step transitions to the agent's rollout store and returns (None, 1.0); pass None to `agent.process`."""
 
     def __init__(self, env_vec, agent, num_workers=None, mode="sync"):
@@ -79,6 +165,7 @@ class NativeCollector:
         self.h = None
         self._store_h = None
         self._net_h = None
+        self._table = None  # PythonEnvTable of a non-native env (owns the ctypes callbacks: must outlive the C collector)
         import os
 
         # acting-time capture (jh_collector_set_capture): the raw heads and values the acting kernel computed anyway replace the two
@@ -106,8 +193,13 @@ class NativeCollector:
             self.lib.jh_collector_destroy(self.h)
         cols = (C.c_int32 * 5)(*[store.names.index(k) for k in ("state", "action", "reward", "next_state", "done")])
         h = C.c_void_p()
-        create = self.lib.jh_collector_create_control if cont else self.lib.jh_collector_create
-        L.check(create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
+        if getattr(self.env, "h", None) is not None:  # the library's own envs
+            create = self.lib.jh_collector_create_control if cont else self.lib.jh_collector_create
+            L.check(create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
+        else:  # any other env: obs / step (/ fork) call back into Python
+            if self._table is None:
+                self._table = PythonEnvTable(self.env)
+            L.check(self.lib.jh_collector_create_env(L.ctx(self.agent.device.index), net.h, C.byref(self._table.table), self._table.handle, store.h, cols, C.byref(h)))
         self.h, self._store_h, self._net_h = h, store.h.value, net.h.value
         self._set_capture(cap, n_rows)
         self._rides = {}

@@ -612,7 +612,8 @@ class PPONet:
     def fused_ok(self, B):
         """Minibatches the four- / five-launch update (jh_pponet_ppo_update) takes: < 1024 rows (from there on the
         LDS-tiled engine wins), hidden width a multiple of 32."""
-        return self.H % 32 == 0 and 0 < B < 1024
+        n_out = (2 * self.A + 1) if self.cont else (self.A + 1)
+        return self.H % 32 == 0 and 0 < B < 1024 and n_out <= 8  # wider heads (round 5): the separate forward / loss / backward / Adam calls
 
     def ppo_update(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, max_norm, stats, do_adam=True):
         """One whole PPO minibatch update in 4 launches (5 beyond 256 rows or with do_adam=False) (jh_pponet_ppo_update).  B = idx.numel() <= 1024."""

@@ -239,6 +239,11 @@ def gen_ppo(out_dir, only=None):
         # config.ppo.mujoco Hopper shapes (S=11, A=3, hidden 512, T=2048, distributed batch 2048;
         # config/ppo/mujoco.py:8-41) with 2 workers x 2 epochs = 4 minibatches of 2048 rows
         ("ppo_cont_hopper_real", 11, 3, 512, 2, 2048, 2048, 2, True, True),
+        # config.ppo.mujoco on its OTHER envs (config/ppo/mujoco.py:3-4 takes --env.name half_cheetah | walker | ant ...): more than 8 head
+        # outputs (2 A + 1 = 13 / 17).  HalfCheetah-v3 shapes (S=17, A=6) with minibatches of 1024 rows (the tiled engine), Ant shapes
+        # (S=27, A=8) with minibatches of 256 rows (the separate forward / backward calls)
+        ("ppo_cont_halfcheetah", 17, 6, 512, 2, 1024, 1024, 2, True, True),
+        ("ppo_cont_ant_mb256", 27, 8, 512, 2, 256, 256, 2, True, True),
     ]
     for name, S, A, H, W, T, B, E, cont, recipe in cases:
         if only is not None and name not in only:

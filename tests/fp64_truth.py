@@ -141,3 +141,51 @@ def check_first_step_from_our_gradient(w0, g_clipped, w1, make_opt, lr, tag):
         margins.leq(float(err.reshape(-1)[j]), float(allowed.reshape(-1)[j]), f"{tag} weight {k}[{j}] vs float64 step of OUR gradient from the fixture's w0 (max err {float(err.max()):.2e})")
         worst = max(worst, float(ratio[j]))
     return worst
+
+
+def ppo_head_grads_float64(cont, heads, action, adv, ret, v_old, lp_old, eps, vf, ent):
+    """d(loss)/d(raw heads) of ONE PPO minibatch in float64: core/agent/ppo.py:125-165 (+ the policy modules of
+    core/network/policy_value.py:38-57) restated with torch autograd on the CPU -- the comparator of the loss-kernel tests (test
+    infrastructure, not the product).  heads: {"logits" | "mu_raw", "log_std_raw", "v"} arrays of the minibatch's rows; the other
+    arguments are the rows' upstream quantities.  -> {name: float64 gradient array}."""
+    import numpy as np
+
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    adv, ret, v_old, lp_old, action = t(adv), t(ret), t(v_old), t(lp_old), t(action)
+    v = t(heads["v"]).reshape(-1, 1).requires_grad_(True)
+    if cont:
+        mu_raw, ls_raw = t(heads["mu_raw"]).requires_grad_(True), t(heads["log_std_raw"]).requires_grad_(True)
+        m = torch.distributions.Normal(torch.clamp(mu_raw, -5.0, 5.0), torch.tanh(ls_raw).exp())
+        # the action clamp is part of the INPUT preparation and happens in float32 in the reference (reinforce.py / ppo.py:85-88 on fp32
+        # tensors: the bound 1 - 1e-7 rounds to 1 - 2^-23 there); everything from the clamped action on is float64
+        a_cl = torch.clamp(action.float(), -1 + 1e-7, 1 - 1e-7).double()
+        log_prob = m.log_prob(torch.atanh(a_cl))
+        leaves = {"mu_raw": mu_raw, "log_std_raw": ls_raw, "v": v}
+    else:
+        logits = t(heads["logits"]).requires_grad_(True)
+        m = torch.distributions.Categorical(torch.exp(torch.log_softmax(logits, dim=-1)))
+        log_prob = m.log_prob(action.reshape(-1).long()).unsqueeze(-1)
+        leaves = {"logits": logits, "v": v}
+    ratio = (log_prob - lp_old).sum(1, keepdim=True).exp()
+    actor = -torch.min(ratio * adv, torch.clamp(ratio, 1 - eps, 1 + eps) * adv).mean()
+    v_clip = v_old + torch.clamp(v - v_old, -eps, eps)
+    critic = torch.max(torch.nn.functional.mse_loss(v, ret), torch.nn.functional.mse_loss(v_clip, ret))
+    loss = actor + vf * critic + ent * (-m.entropy().mean())
+    loss.backward()
+    out = {k: x.grad.numpy() for k, x in leaves.items()}
+    out["ratio"] = ratio.detach().numpy()
+    return out
+
+
+def grad_vs_exact(ours, exact, ref32, tol, what, rows=None):
+    """|ours - exact| <= max(tol, 2 x |reference fp32 - exact|), relative to max |exact| (ref32 None: tol alone); rows: boolean row mask."""
+    import numpy as np
+
+    exact = np.asarray(exact, dtype=np.float64)
+    scale = float(np.abs(exact).max()) + 1e-30
+    pick = (lambda a: np.asarray(a, dtype=np.float64).reshape(exact.shape)[rows]) if rows is not None else (lambda a: np.asarray(a, dtype=np.float64).reshape(exact.shape))
+    ex = pick(exact)
+    e_ours = float(np.abs(pick(ours) - ex).max()) / scale
+    e_ref = float(np.abs(pick(ref32) - ex).max()) / scale if ref32 is not None else 0.0
+    margins.leq(e_ours, max(tol, 2.0 * e_ref), f"{what} |ours - fp64| / max|fp64| (reference fp32: {e_ref:.2e})")
+    return e_ours, e_ref

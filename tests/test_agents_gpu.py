@@ -356,7 +356,8 @@ def test_pponet_forward_backward_adam_vs_float64():
     from jorldy_amd import ops
     from mirror.networks import Network
 
-    for cont, S, H, A, B in ((False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8)):
+    # (the last three: more than 8 head outputs -- 13 / 13 / 17 -- on the separate forward / backward calls; the tiled engine at 13 outputs: test_baseline_width_gpu, ppo_cont_halfcheetah)
+    for cont, S, H, A, B in ((False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8), (True, 17, 64, 6, 100), (False, 5, 32, 12, 40), (True, 27, 128, 8, 200)):
         torch.manual_seed(0)
         ref64 = Network("continuous_policy_value" if cont else "discrete_policy_value", S, A, D_hidden=H).double()
         with torch.no_grad():
@@ -622,6 +623,78 @@ def test_collector_lookahead_two_timesteps_per_exchange_is_bit_identical(T, H, m
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
 
 
+class _PyCartPole:
+    """The oracle's CartPole (bit-identical to the library's jh_cartpole) as a PYTHON vector env with the VecCollector protocol, plus --
+    when `forkable` -- fork / copy_row / row ranges: what a user's own env has to offer the C collector's function table."""
+
+    state_size, action_size, action_type = 4, 2, "discrete"
+
+    def __init__(self, W, seed=0, forkable=False):
+        from oracle.jorldy_oracle import CartPoleOracle
+
+        self.W, self.o = W, CartPoleOracle(W, seed=seed)
+        if forkable:
+            self.fork = lambda rows: _PyCartPole(rows, 0, True)
+            self.copy_row = self._copy_row
+
+    def _copy_row(self, di, src, si):
+        self.o.s[di], self.o.t[di], self.o.rng[di] = src.o.s[si], src.o.t[si], src.o.rng[si]
+
+    def obs(self, out, r0=0, r1=None):
+        out[:] = self.o.s[r0 : self.W if r1 is None else r1].astype(np.float32)
+        return out
+
+    def step(self, action, nxt, rew, done, r0=0, r1=None):
+        r1 = self.W if r1 is None else r1
+        full = self.o
+        if (r0, r1) != (0, self.W):  # a scratch env stepped on a row range: the oracle steps whole envs
+            from oracle.jorldy_oracle import CartPoleOracle
+
+            sub = CartPoleOracle.__new__(CartPoleOracle)
+            sub.W, sub.s, sub.t, sub.rng = r1 - r0, full.s[r0:r1], full.t[r0:r1], full.rng[r0:r1]  # views: stepped in place
+            full = sub
+        n, r, d = full.step(np.asarray(action).reshape(-1))
+        nxt[:], rew[:], done[:] = n, r, d
+        return nxt, rew, done
+
+
+@pytest.mark.parametrize("forkable", [False, True])
+def test_c_collector_on_a_python_env_through_the_function_table(forkable):
+    """jh_collector_create_env: the collector takes its env as a table of functions -- here Python callbacks around the
+    oracle's CartPole.  Same dynamics and RNG streams as the library's own CartPole, same agent seed: stored transitions, captured heads
+    and values must equal the built-in env's BIT FOR BIT, without the fork capability (one timestep per exchange) and with it (two
+    timesteps per exchange: the lookahead is a capability of the table, not of the built-in type)."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+
+    W, T, H = 8, 17, 64
+    res = {}
+    for kind in ("builtin", "python"):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        agent = Agent("ppo", state_size=4, action_size=2, hidden_size=H, n_step=T, batch_size=64, n_epoch=1, device="cuda", seed=3, lr_decay=False)
+        agent.memory.first_store = False
+        env = ops.CartPoleVec(W, seed=4) if kind == "builtin" else _PyCartPole(W, seed=4, forkable=forkable)
+        col = NativeCollector(env, agent, W)
+        out = []
+        for it in range(2):
+            col.run(T)
+            torch.cuda.synchronize()
+            st, M = agent._static, W * T
+            store = agent.memory._store
+            rec = {k: npy(store.column(k)[:M]).copy() for k in ("state", "action", "reward", "next_state", "done")}
+            rec.update(h0=npy(st["h0"]).copy(), value=npy(st["value"]).copy(), next_value=npy(st["next_value"]).copy())
+            out.append(rec)
+            agent.process(None, T * (it + 1))
+        res[kind] = out
+        col.terminate()
+    assert any(o["done"].any() for o in res["builtin"]), "no episode ended: the reset path was not exercised"
+    for a, b in zip(res["builtin"], res["python"]):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("cont", [False, True])
 @pytest.mark.parametrize("persistent,early", [(True, False), (False, False), (True, True)])
 def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persistent, early, monkeypatch):
@@ -758,6 +831,78 @@ def test_native_act_continuous_distribution():
     np.testing.assert_allclose(zs.std(0), npy(std)[0], rtol=0.05)
     g = agent.act(obs, training=False)["action"]
     np.testing.assert_allclose(g, np.tile(np.tanh(npy(mu)), (64, 1)), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cont,S,A", [(True, 17, 6), (True, 27, 8), (False, 6, 12)])
+def test_native_act_with_more_than_8_head_outputs(cont, S, A):
+    """config.ppo.mujoco on HalfCheetah / Ant (2 A + 1 = 13 / 17 head outputs) and a 12-action discrete policy: acting on the separate-call
+    forward (round 5; VERDICT r4 missing #6).  Raw heads against the reference's modules in float64, the greedy action exact
+    in the heads, samples distributed like the policy."""
+    from jorldy_amd.core.agent import Agent
+
+    torch.manual_seed(1)
+    net = "continuous_policy_value" if cont else "discrete_policy_value"
+    agent = Agent("ppo", state_size=S, action_size=A, hidden_size=64, network=net, device="cuda", backend="native", seed=3)
+    with torch.no_grad():
+        for p in agent.network.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+    rng = np.random.RandomState(0)
+    obs = rng.randn(37, S).astype(np.float32)
+    pol = _policy64(agent, net, S, A, 64)
+    if cont:
+        act, mu_raw, ls_raw = agent._net.act_continuous(obs, training=False, want_heads=True)
+        with torch.no_grad():
+            mu, std, _ = pol(torch.from_numpy(obs).double())
+        np.testing.assert_allclose(np.clip(mu_raw, -5, 5), npy(mu), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(np.exp(np.tanh(ls_raw)), npy(std), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(act, np.tanh(np.clip(mu_raw, -5, 5)), rtol=1e-6, atol=1e-6)
+        one = np.repeat(obs[:1], 64, 0)
+        zs = np.concatenate([np.arctanh(np.clip(agent.act(one, True)["action"].astype(np.float64), -1 + 1e-7, 1 - 1e-7)) for _ in range(300)], 0)
+        np.testing.assert_allclose(zs.mean(0), npy(mu)[0], atol=0.06)
+        np.testing.assert_allclose(zs.std(0), npy(std)[0], rtol=0.06)
+    else:
+        act, logits, val = agent._net.act_discrete(obs, training=False, want_logits=True)
+        with torch.no_grad():
+            pi, v = pol(torch.from_numpy(obs).double())
+        p_ours = np.exp(logits - logits.max(1, keepdims=True))
+        np.testing.assert_allclose(p_ours / p_ours.sum(1, keepdims=True), npy(pi), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(val, npy(v), rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(act.reshape(-1), logits.argmax(1))
+        one = np.repeat(obs[:1], 64, 0)
+        cnt = np.bincount(np.concatenate([agent.act(one, True)["action"].reshape(-1) for _ in range(300)]), minlength=A) / (300 * 64)
+        np.testing.assert_allclose(cnt, npy(pi)[0], atol=0.02)
+
+
+def test_native_collector_32_workers_wide_action_space_end_to_end():
+    """configs[4]'s worker count (config.ppo.mujoco: 32 workers) on ONE GPU with an action space wider than Hopper's (A = 6): the native
+    collector (one acting forward per timestep: the persistent kernel serves <= 16 rows / <= 12 outputs) feeds the learner, the stored
+    transitions replay through the oracle env bit for bit, learn() consumes them on the separate-call path."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+    from oracle.jorldy_oracle import ControlOracle
+
+    S, A, T, W = 17, 6, 24, 32
+    torch.manual_seed(3)
+    agent = Agent("ppo", state_size=S, action_size=A, hidden_size=64, network="continuous_policy_value", n_step=T, batch_size=256, n_epoch=2, device="cuda", backend="native", seed=5)
+    agent.memory.first_store = False
+    col = NativeCollector(ops.ControlVec(W, S, A, seed=9), agent, W)
+    col.run(T)
+    torch.cuda.synchronize()
+    st = agent.memory._store
+    assert st.size == W * T
+    cols = {k: npy(st.column(k)[: W * T]) for k in ("state", "action", "reward", "next_state", "done")}
+    orc = ControlOracle(W, S, A, seed=9)
+    a = cols["action"].reshape(W, T, A)
+    for t in range(T):
+        obs = orc.obs()
+        nxt, rew, done = orc.step(a[:, t])
+        rows = np.arange(W) * T + t
+        np.testing.assert_array_equal(cols["state"][rows], obs)
+        np.testing.assert_array_equal(cols["next_state"][rows], nxt)
+        np.testing.assert_array_equal(cols["reward"][rows, 0], rew)
+    res = agent.process(None, T)
+    assert set(res) == {"actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob", "mean_ret"} and all(np.isfinite(v) for v in res.values())
 
 
 def test_ppo_native_data_parallel_path_single_rank_rccl():
