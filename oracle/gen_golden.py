@@ -242,10 +242,18 @@ def gen_ppo(out_dir, only=None):
         # config.ppo.mujoco on its OTHER envs (config/ppo/mujoco.py:3-4 takes --env.name half_cheetah | walker | ant ...): more than 8 head
         # outputs (2 A + 1 = 13 / 17).  HalfCheetah-v3 shapes (S=17, A=6) with minibatches of 1024 rows (the tiled engine), Ant shapes
         # (S=27, A=8) with minibatches of 256 rows (the separate forward / backward calls)
-        ("ppo_cont_halfcheetah", 17, 6, 512, 2, 1024, 1024, 2, True, True),
-        ("ppo_cont_ant_mb256", 27, 8, 512, 2, 256, 256, 2, True, True),
+        # (11th element = the rollout seed, CHOSEN so that no ReLU pre-activation of any forward pass of this learn() lies within 3e-7
+        # of zero -- `relu_margin` in the fixture: two correct fp32 evaluations of a 512-term dot product differ by ~1e-7, and a unit whose
+        # pre-activation is that close to zero is on in one and off in the other: with seed 5 exactly ONE of HalfCheetah's 8 M ReLU
+        # decisions (row 297, unit 344 of minibatch 0: -3.2e-7 in float64, +6.0e-8 in torch's fp32) moved the trunk gradients by 1e-3 of
+        # their largest entry -- a property of the input, not of either implementation.  Among seeds 5..16 HalfCheetah's best margin is 3.7e-7
+        # (seed 15), Ant's 3.2e-6 (seed 5).  JH_GEN_ROLLOUT_SEED overrides for the search.)
+        ("ppo_cont_halfcheetah", 17, 6, 512, 2, 1024, 1024, 2, True, True, 15),
+        ("ppo_cont_ant_mb256", 27, 8, 512, 2, 256, 256, 2, True, True, 5),
     ]
-    for name, S, A, H, W, T, B, E, cont, recipe in cases:
+    for case in cases:
+        name, S, A, H, W, T, B, E, cont, recipe = case[:10]
+        rollout_seed = int(os.environ.get("JH_GEN_ROLLOUT_SEED", case[10])) if len(case) > 10 else 5
         if only is not None and name not in only:
             continue
         torch.manual_seed(11)
@@ -280,7 +288,7 @@ def gen_ppo(out_dir, only=None):
                     p.add_(0.05 * torch.randn_like(p))
         sd0 = sd_to_np(agent.network.state_dict())
 
-        rng = np.random.RandomState(5)
+        rng = np.random.RandomState(rollout_seed)
         M = W * T
         trs = synth.ppo_rollout(rng, M, S, A, cont, clamp_every=0 if recipe else 17)
         agent.memory.first_store = False
@@ -303,6 +311,13 @@ def gen_ppo(out_dir, only=None):
         else:
             hooks.append(agent.network.pi.register_forward_hook(mk_hook("logits")))
         hooks.append(agent.network.v.register_forward_hook(mk_hook("v")))
+        relu_margin = [np.inf]
+        if len(case) > 10:  # smallest |pre-activation| over every forward pass of this learn() (both hidden layers)
+            def margin_hook(mod, inp, outp):
+                relu_margin[0] = min(relu_margin[0], float(outp.detach().abs().min()))
+
+            hooks.append(agent.network.head.l.register_forward_hook(margin_hook))
+            hooks.append(agent.network.l.register_forward_hook(margin_hook))
 
         markers = {
             "gae_done": ("mean_ret = ret.mean().item()", ["value", "next_value", "delta", "adv", "ret", "log_prob_old", "reward", "done"]),
@@ -347,7 +362,9 @@ def gen_ppo(out_dir, only=None):
         if recipe:
             # inputs: synth.ppo_rollout(RandomState(5), M, S, A, cont); weights: synth.ppo_recipe
             out["recipe_seed"] = np.asarray(RECIPE_SEED)
-            out["rollout_seed"] = np.asarray(5)
+            out["rollout_seed"] = np.asarray(rollout_seed)
+            if len(case) > 10:
+                out["relu_margin"] = np.asarray(relu_margin[0])
             for k in ("state", "reward", "action"):
                 out[f"in_{k}_check"] = synth.row_checksum(np.concatenate([t[k] for t in trs], 0).astype(np.float32))[:: max(1, M // 64)]
             flat("sd0_thin/", {k: th(v) for k, v in sd0.items()}, out)
@@ -374,7 +391,7 @@ def gen_ppo(out_dir, only=None):
             out[f"result/{k}"] = np.asarray(v)
         out["lr_after"] = np.asarray(agent.optimizer.param_groups[0]["lr"])
         np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **out)
-        print(name, {k: float(v) for k, v in result.items()})
+        print(name, {k: float(v) for k, v in result.items()}, ("relu_margin %.3g (rollout seed %d)" % (relu_margin[0], rollout_seed)) if len(case) > 10 else "")
 
 
 # ----------------------------------------------------------------------------

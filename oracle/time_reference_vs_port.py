@@ -4,7 +4,7 @@
 bench.py's `cpu_baseline` times oracle/ppo_port.py (kind "port") because the reference tree does not exist on the GPU box.
 This script shows what that stands for: PPO.learn of the unmodified reference (config.ppo.cartpole: 1024 transitions, 3 epochs x 4
 minibatches of 256, hidden 512) and PPOPort.process on the same transitions, same torch thread count, alternating; and
-Rainbow.learn (config.rainbow.atari shapes) vs RainbowPort.learn.  -> JSON (committed as profiles/r03_cpu_reference_vs_port.json).
+Rainbow.learn (config.rainbow.atari shapes) vs RainbowPort.learn.  and DQN.learn (config.dqn.cartpole) vs DQNPort.learn.  -> JSON (committed as profiles/r05_cpu_reference_vs_port.json; round 3's: r03_...).
 
     python oracle/time_reference_vs_port.py [--threads 8] [--iters 10]
 """
@@ -91,6 +91,30 @@ def main():
                 t_port.append(t2 - t1)
         out["rainbow_atari_learn_B32"] = {"reference_ms": float(np.median(t_ref)) * 1e3, "port_ms": float(np.median(t_port)) * 1e3,
                                           "port_over_reference": float(np.median(t_port) / np.median(t_ref))}
+        # DQN at config.dqn.cartpole (BASELINE configs[0]): one learn() of the reference vs oracle/dqn_port.py on the same 256 stored transitions
+        from core.agent.dqn import DQN
+
+        from oracle.dqn_port import DQNPort
+
+        dq = DQN(state_size=4, action_size=2, hidden_size=512, optim_config={"name": "adam", "lr": 1e-4}, gamma=0.99, buffer_size=50000, batch_size=32,
+                 start_train_step=0, target_update_period=500, run_step=100000, device="cpu")
+        dq.memory.first_store = False
+        dp = DQNPort(4, 2, 512, lr=1e-4, batch_size=32, start_train_step=0)
+        rows = [synth.raw_transition(rng, 4, 2) for _ in range(256)]
+        dq.memory.store([dict(r) for r in rows])
+        dp.memory.store([dict(r) for r in rows])
+        t_ref, t_port = [], []
+        for it in range(20 * args.iters + 20):
+            t0 = time.perf_counter()
+            dq.learn()
+            t1 = time.perf_counter()
+            dp.learn()
+            t2 = time.perf_counter()
+            if it >= 20:
+                t_ref.append(t1 - t0)
+                t_port.append(t2 - t1)
+        out["dqn_cartpole_learn_B32"] = {"reference_ms": float(np.median(t_ref)) * 1e3, "port_ms": float(np.median(t_port)) * 1e3,
+                                         "port_over_reference": float(np.median(t_port) / np.median(t_ref))}
         out["threads"], out["host"] = args.threads, f"{os.cpu_count()} logical cores (build container)"
         out["note"] = "same process, same torch thread count, alternating calls, medians; the port is what bench.py's cpu_baseline times on the GPU box"
         print(json.dumps(out, indent=1))
