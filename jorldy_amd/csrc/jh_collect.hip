@@ -500,6 +500,14 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
   std::vector<int64_t> a0(W), a1(W);
   int t = 0;
   *t_done = 0;
+  // JH_COLLECT_DEBUG=1: where the host's time per exchange goes (ns, summed over the run, printed every 16th run): fork = stepping the
+  // speculative copies, wait = polling for the root rows' heads, sample = both samplings + the chosen successors' heads,
+  // publish = assembling and publishing the next exchange, book = transitions / captured heads / moving the envs on
+  static const bool dbg = getenv("JH_COLLECT_DEBUG") != nullptr;
+  double d_fork = 0, d_wait = 0, d_sample = 0, d_publish = 0, d_book = 0;
+  int n_ex = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   // rows 0 .. W-1: the envs' current states; rows W + 2 w + a: the state env w acts on next if it takes action a now
   fork_step(vt, L1, e, W);
   vt.obs(e, 0, W, pub.data());
@@ -510,11 +518,14 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
     const bool extra = t == T;
     const bool two = !extra && t + 1 < T;
     const int t_next = t + (two ? 2 : 1);
+    const auto q0 = dbg ? now() : std::chrono::steady_clock::time_point();
     if (!extra) {  // the GPU is busy for ~5 us: run the env model two levels further meanwhile
       fork_step(vt, L2, L1.env, 2 * W);
       if (two && t_next < steps) fork_step(vt, L3, L2.env, 4 * W);
     }
+    const auto q1 = dbg ? now() : q0;
     int rc = jh_persist_collect_rows(c->persist, nullptr, W, tag, hz.data());
+    const auto q2 = dbg ? now() : q0;
     if (rc) {  // the kernel gave up (it exits by itself)
       jh_persist_abort(c->persist);
       if (r.early)
@@ -538,6 +549,7 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
       }
     }
     const auto t1 = std::chrono::steady_clock::now();
+    if (dbg) { d_fork += secs(q0, q1); d_wait += secs(q1, q2); d_sample += secs(q2, t1); ++n_ex; }
     // ---- the next exchange first: its rows are already computed; everything else happens while the GPU works on it
     unsigned tag_next = 0;
     auto t0_next = t1;
@@ -556,6 +568,8 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
       t0_next = std::chrono::steady_clock::now();
       tag_next = jh_persist_publish(c->persist, 3 * W, pub_next.data());
     }
+    const auto q3 = dbg ? now() : t1;
+    if (dbg) d_publish += secs(t1, q3);
     // ---- bookkeeping of this exchange: captured heads / values, transitions, the envs move on
     if (cap) {
       for (int w = 0; w < W; ++w) {
@@ -614,6 +628,7 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
       for (int i = 0; i < 2 * W; ++i) copy_level_row(vt, L1, i, tmp, i);
     c->steps += two ? 2 : 1;
     const auto t2 = std::chrono::steady_clock::now();
+    if (dbg) d_book += secs(q3, t2);
     c->t_act += std::chrono::duration<double>(t1 - t0).count();
     c->t_env += std::chrono::duration<double>(t2 - t1).count();
     t = t_next;
@@ -622,6 +637,9 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
     pub.swap(pub_next);
   }
   *t_done = t;
+  if (dbg && n_ex > 0 && (c->runs % 16) == 15)
+    fprintf(stderr, "[jh_collect] host us per exchange (%d exchanges): fork %.2f  wait %.2f  sample %.2f  publish %.2f  book %.2f\n", n_ex, d_fork / n_ex * 1e6,
+            d_wait / n_ex * 1e6, d_sample / n_ex * 1e6, d_publish / n_ex * 1e6, d_book / n_ex * 1e6);
   if (getenv("JH_PERSIST_DEBUG") && (c->runs % 16) == 15) jh_persist_dump_debug(c->persist, collector_steps(c, T));
   return JH_OK;
 }

@@ -76,3 +76,72 @@ def test_ppo_cartpole_learning_curve_tracks_the_reference_cpu_path():
     assert g_end > 4 * g_start and c_end > 4 * c_start  # both learn
     # within noise of each other at the end of the budget (seed-to-seed spread of PPO on CartPole is large)
     assert 0.5 * c_end <= g_end <= 2.0 * c_end
+
+
+# ----------------------------------------------------------------------------- a VALUE agent ("one algorithm, port not reference")
+DQN_STEPS, DQN_RUN_STEP, DQN_CHUNK = 12000, 15000, 1000
+
+
+def _dqn_curve(make_agent, make_env, step_env, seed):
+    """Single-mode loop of run_mode.py:68-91 for DQN_STEPS steps; -> mean episode length per DQN_CHUNK steps."""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    agent = make_agent()
+    env, state = make_env(seed)
+    out, lens, ep = [], [], 0
+    for step in range(1, DQN_STEPS + 1):
+        a = agent.act(state, True)
+        nxt, rew, done, state_next = step_env(env, a["action"])
+        tr = {"state": state, "next_state": nxt, "reward": rew, "done": done}
+        tr.update(a)
+        agent.process([tr], step)
+        state = state_next
+        ep += 1
+        if bool(done[0, 0]):
+            lens.append(ep)
+            ep = 0
+        if step % DQN_CHUNK == 0:
+            out.append(float(np.mean(lens)) if lens else float(ep))
+            lens = []
+    return out
+
+
+def test_dqn_cartpole_learning_curve_tracks_the_reference_cpu_path():
+    """config.dqn.cartpole (hidden 512, B = 32, Adam 1e-4, target update every 500, learning from step 2000, epsilon 1 -> 0.01 over the first
+    20 % of a 15 000-step schedule) trained for 12 000 env steps in the reference's single-mode loop: the HIP agent on the library's CartPole,
+    the reference's CPU path (oracle/dqn_port.py, pinned to the reference's learn() by the dqn_h512 fixture) on the oracle's bit-identical
+    CartPole.  Both must learn (random play: ~22 steps per episode) and end within a factor 2 of each other."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from oracle.dqn_port import DQNPort
+    from oracle.dqn_port import make_env as port_env
+
+    cfg = dict(gamma=0.99, epsilon_init=1.0, epsilon_min=0.01, explore_ratio=0.2, buffer_size=50000, batch_size=32, start_train_step=2000, target_update_period=500)
+
+    def gpu_env(seed):
+        env = ops.CartPoleVec(1, seed=1000 + seed)
+        return env, env.obs().copy()
+
+    def gpu_step(env, action):
+        nxt, rew, done = env.step(action)
+        return nxt.copy(), rew.reshape(1, 1).astype(np.float64), done.reshape(1, 1).astype(bool), env.obs().copy()
+
+    def cpu_step(env, action):
+        nxt, rew, done = env.step(np.asarray(action).reshape(-1))
+        return nxt.astype(np.float32), rew.reshape(1, 1).astype(np.float64), done.reshape(1, 1), env.obs().astype(np.float32)
+
+    gpu_agent = lambda: Agent("dqn", state_size=4, action_size=2, hidden_size=512, network="discrete_q_network", optim_config={"name": "adam", "lr": 1e-4},
+                              lr_decay=True, run_step=DQN_RUN_STEP, device="cuda", **cfg)
+    cpu_agent = lambda: DQNPort(4, 2, 512, lr=1e-4, run_step=DQN_RUN_STEP, **cfg)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    gpu = [_dqn_curve(gpu_agent, gpu_env, gpu_step, s) for s in (1, 2, 3)]
+    cpu = [_dqn_curve(cpu_agent, lambda s: port_env(1000 + s), cpu_step, s) for s in (1, 2)]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/learning_curve_dqn.json", "w") as f:
+        json.dump({"steps": DQN_STEPS, "chunk": DQN_CHUNK, "metric": "mean episode length per 1000 env steps (max 500)", "hip": gpu, "reference_cpu_port": cpu}, f)
+    g_start, g_end = np.mean([np.mean(c[:2]) for c in gpu]), np.mean([np.mean(c[-4:]) for c in gpu])
+    c_start, c_end = np.mean([np.mean(c[:2]) for c in cpu]), np.mean([np.mean(c[-4:]) for c in cpu])
+    print(f"DQN episode length: HIP {g_start:.1f} -> {g_end:.1f}, reference CPU port {c_start:.1f} -> {c_end:.1f}")
+    assert g_start < 40 and c_start < 40  # random policy: ~22 steps
+    assert g_end > 4 * g_start and c_end > 4 * c_start  # both learn
+    assert 0.5 * c_end <= g_end <= 2.0 * c_end
