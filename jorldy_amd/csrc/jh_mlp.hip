@@ -36,7 +36,7 @@ constexpr int kL1Rows = 16;
 __global__ void __launch_bounds__(256) jh_mlp_l1_kernel(int B, int S, int H, const float* __restrict__ x,
                                                         const int64_t* __restrict__ idx, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, float* __restrict__ h1) {
-  __shared__ float sx[kL1Rows][16];
+  __shared__ __attribute__((aligned(16))) float sx[kL1Rows][16];
   const int jb = (H + 255) / 256;  // column blocks of 256 hidden units
   const int rb = blockIdx.x / jb, j = (blockIdx.x - rb * jb) * 256 + threadIdx.x;
   const int b0 = rb * kL1Rows, nb = b0 + kL1Rows < B ? kL1Rows : B - b0;
@@ -57,16 +57,29 @@ __global__ void __launch_bounds__(256) jh_mlp_l1_kernel(int B, int S, int H, con
   const float bias = b1[jc];
   __syncthreads();
   if (j >= H) return;
+  // Every fetch above has LANDED before the row loop (round 5, tools/isa_chain.py): left pending, hipcc's wait for the bias sat
+  // INSIDE the loop as s_waitcnt vmcnt(0) -- which also waits for the previous row's STORE: sixteen stores, each acknowledged before
+  // the next was issued (14.5 us per launch for 4 MB of h1 at B = 2048; the builtin clears the compiler's own scoreboard).
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
+  if (lds_rows) {  // (its own loop: with the S > 16 branch's fetches in the same loop body hipcc keeps a vmcnt(0) in front of every store)
+    for (int rr = 0; rr < nb; ++rr) {
+      // the row as four 16-byte LDS reads, all 16 taps unconditionally: columns >= S hold 0 in sx AND in w, and fmaf(0, 0, acc) == acc
+      // (acc is never -0: it starts at +0), so the chain over s < S is unchanged
+      const float4* xr = reinterpret_cast<const float4*>(&sx[rr][0]);
+      const float4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
+      const float xs[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+      float acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = fmaf(xs[s], w[s], acc);
+      acc += bias;
+      h1[(size_t)(b0 + rr) * H + j] = acc > 0.f ? acc : 0.f;
+    }
+    return;
+  }
   for (int rr = 0; rr < nb; ++rr) {
     float acc = 0.f;
-    if (lds_rows) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        if (s < S) acc = fmaf(sx[rr][s], w[s], acc);
-    } else {
-      const int64_t r = idx ? idx[b0 + rr] : (int64_t)(b0 + rr);
-      for (int s = 0; s < S; ++s) acc = fmaf(x[r * S + s], W1[(size_t)j * S + s], acc);
-    }
+    const int64_t r = idx ? idx[b0 + rr] : (int64_t)(b0 + rr);
+    for (int s = 0; s < S; ++s) acc = fmaf(x[r * S + s], W1[(size_t)j * S + s], acc);
     acc += bias;
     h1[(size_t)(b0 + rr) * H + j] = acc > 0.f ? acc : 0.f;
   }
@@ -371,39 +384,40 @@ struct HeadPtrs {
   int groups;
 };
 
+// Up to 8 head outputs of one launch as FLAT arrays with static indices (round 5): built on the host.  The grouped form (HeadPtrs walked
+// by a run-time loop inside the kernel) put the pointers into a dynamically indexed array, and hipcc fetched weight row after weight row
+// behind its own s_waitcnt vmcnt(0): 14 serial L2 round trips per row at H = 512 (11.3 us per launch at B = 2048).
+struct HeadFlat {
+  const float* w[8];   // weight row of output o ([H]); outputs >= n: a valid row (fetched, ignored)
+  const float* b[8];   // its bias
+  float* out[8];       // element of row 0 of its output tensor
+  const float* g[8];   // backward: element of row 0 of its upstream gradient
+  int ld[8];           // row stride of that tensor (A, A, 1)
+  int n;
+};
 // forward: one wave per row; lanes split H.  All (<= 8) outputs' lane-partial dot products first, then their shuffle reductions
-// INTERLEAVED (the same tree per output as one reduction after the other: identical bits; seven dependent 6-step chains one after the
-// other were most of the kernel's 9-11 us at B = 2048).  o_begin: first flat output of this launch -- nets with more than 8 head
-// outputs (config.ppo.mujoco on HalfCheetah / Walker / Ant: 2 A + 1 = 13 / 13 / 17) take one launch per 8 outputs (round 5).
-__global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, const float* __restrict__ h2, HeadPtrs hp, int o_begin) {
+// INTERLEAVED (the same tree per output as one reduction after the other: identical bits).  Nets with more than 8 head outputs
+// (config.ppo.mujoco on HalfCheetah / Walker / Ant: 2 A + 1 = 13 / 13 / 17) take one launch per 8 outputs.
+__global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, const float* __restrict__ h2, HeadFlat hf) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const float* hr = h2 + (size_t)b * H;
-  const float* wrow[8];
-  float* dst[8];
-  float bias[8];
-  int n_out = 0, o_flat = 0;
-  for (int g = 0; g < hp.groups; ++g)
-    for (int o = 0; o < hp.n[g]; ++o, ++o_flat) {
-      if (o_flat < o_begin || n_out >= 8) continue;
-      wrow[n_out] = hp.w[g] + (size_t)o * H;
-      dst[n_out] = hp.out[g] + (size_t)b * hp.n[g] + o;
-      bias[n_out] = hp.b[g][o];
-      ++n_out;
-    }
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bias[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) bias[o] = *hf.b[o];  // with the weight rows, not one by one between the stores
   for (int k = lane * 4; k < H; k += 256) {
     const float4 hv = *reinterpret_cast<const float4*>(hr + k);
+    float4 wv[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) wv[o] = *reinterpret_cast<const float4*>(hf.w[o] + k);  // all eight in flight (rows >= n: row 0 again)
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      if (o < n_out) {
-        const float4 wv = *reinterpret_cast<const float4*>(wrow[o] + k);
-        acc[o] = fmaf(hv.x, wv.x, acc[o]);
-        acc[o] = fmaf(hv.y, wv.y, acc[o]);
-        acc[o] = fmaf(hv.z, wv.z, acc[o]);
-        acc[o] = fmaf(hv.w, wv.w, acc[o]);
-      }
+      acc[o] = fmaf(hv.x, wv[o].x, acc[o]);
+      acc[o] = fmaf(hv.y, wv[o].y, acc[o]);
+      acc[o] = fmaf(hv.z, wv[o].z, acc[o]);
+      acc[o] = fmaf(hv.w, wv[o].w, acc[o]);
     }
   }
 #pragma unroll
@@ -414,34 +428,55 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, con
   if (lane == 0) {
 #pragma unroll
     for (int o = 0; o < 8; ++o)
-      if (o < n_out) *dst[o] = acc[o] + bias[o];
+      if (o < hf.n) hf.out[o][(size_t)b * hf.ld[o]] = acc[o] + bias[o];
   }
 }
 
-// backward: dh2[b][k] = relu'(h2[b][k]) * sum_o g[b][o] * Wh[o][k]; lanes k < 8 of each row also pack
-// the head gradients into g_all[b][8] (the A operand of the head-weight-gradient GEMM).
+// backward: dh2[b][k] = relu'(h2[b][k]) * sum_o g[b][o] * Wh[o][k]; the first gld / 4 threads of each row also pack the head gradients
+// into g_all[b][gld] (the A operand of the head-weight-gradient GEMM).  Four consecutive hidden units per thread (H % 4 == 0); the sum over
+// the outputs runs in output order per element (an fmaf chain, carried through `acc_io` from one launch of 8 outputs to the next).
+// first: this launch holds outputs o0 .. o0 + n - 1 and is the first (the chain starts at 0); last: it applies relu' and stores dh2
+// (earlier launches store the raw partial chain).  Round 5: flat descriptors with static indices -- the grouped form fetched
+// (gradient, weight row) pair after pair behind s_waitcnt vmcnt(0) (7 serial round trips per thread at Hopper's 7 outputs).
 __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, const float* __restrict__ h2,
                                                                   float* __restrict__ dh2, float* __restrict__ g_all,
-                                                                  HeadPtrs hp, int gld) {
-  // four consecutive hidden units per thread (H % 4 == 0: 16-byte loads of h2 / the head weight rows, one 16-byte store of dh2);
-  // the sum over the outputs runs in the same order per element as one thread per element did
+                                                                  HeadFlat hf, int gld, int o0, int first, int last) {
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int h4 = H >> 2;
   if (i4 >= (int64_t)B * h4) return;
   const int b = (int)(i4 / h4), k = 4 * (int)(i4 - (int64_t)b * h4);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  float mine[4] = {0.f, 0.f, 0.f, 0.f};
-  int o_flat = 0;
-  for (int g = 0; g < hp.groups; ++g)
-    for (int o = 0; o < hp.n[g]; ++o, ++o_flat) {
-      const float gv = hp.g[g][(size_t)b * hp.n[g] + o];
-      const float4 w = *reinterpret_cast<const float4*>(hp.w[g] + (size_t)o * H + k);
-      acc[0] = fmaf(gv, w.x, acc[0]); acc[1] = fmaf(gv, w.y, acc[1]); acc[2] = fmaf(gv, w.z, acc[2]); acc[3] = fmaf(gv, w.w, acc[3]);
-      if (o_flat >= k && o_flat < k + 4) mine[o_flat - k] = gv;
-    }
+  float gv[8];
+  float4 w[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {  // all fetches in flight (outputs >= n: output 0 again, ignored)
+    gv[o] = hf.g[o][(size_t)b * hf.ld[o]];
+    w[o] = *reinterpret_cast<const float4*>(hf.w[o] + k);
+  }
+  float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dh2 + (size_t)b * H + k);
   const float4 hv = *reinterpret_cast<const float4*>(h2 + (size_t)b * H + k);
-  *reinterpret_cast<float4*>(dh2 + (size_t)b * H + k) = make_float4(hv.x > 0.f ? acc[0] : 0.f, hv.y > 0.f ? acc[1] : 0.f, hv.z > 0.f ? acc[2] : 0.f, hv.w > 0.f ? acc[3] : 0.f);
-  if (k < gld) *reinterpret_cast<float4*>(g_all + (size_t)b * gld + k) = make_float4(mine[0], mine[1], mine[2], mine[3]);  // zero beyond the head outputs (gld: 8, or the output count rounded up to 4)
+  float mine[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (o < hf.n) {
+      acc.x = fmaf(gv[o], w[o].x, acc.x); acc.y = fmaf(gv[o], w[o].y, acc.y); acc.z = fmaf(gv[o], w[o].z, acc.z); acc.w = fmaf(gv[o], w[o].w, acc.w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[j] = (o0 + o == k + j) ? gv[o] : mine[j];
+    }
+  }
+  if (last) acc = make_float4(hv.x > 0.f ? acc.x : 0.f, hv.y > 0.f ? acc.y : 0.f, hv.z > 0.f ? acc.z : 0.f, hv.w > 0.f ? acc.w : 0.f);
+  *reinterpret_cast<float4*>(dh2 + (size_t)b * H + k) = acc;
+  // this launch's outputs that fall into the thread's four packed columns (the columns beyond the head outputs stay 0: the first launch
+  // writes all of the row's gld columns, later launches only the ones they own)
+  if (k < gld) {
+    float* dst = g_all + (size_t)b * gld + k;
+    if (first) {
+      *reinterpret_cast<float4*>(dst) = make_float4(mine[0], mine[1], mine[2], mine[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k + j >= o0 && k + j < o0 + hf.n) dst[j] = mine[j];
+    }
+  }
 }
 
 // ============================================================================ clip_grad_norm_ + Adam
@@ -450,7 +485,20 @@ __global__ void __launch_bounds__(256) jh_gradnorm_kernel(int64_t n, const float
                                                           float* __restrict__ partial, float* __restrict__ hyper) {
   __shared__ float s_red[16];
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+  // eight grid-stride elements per round, all fetched before the first fmaf (round 5: one fetch per s_waitcnt vmcnt(0) before --
+  // five serial round trips for Hopper's 272 391 parameters); the order of the chain is unchanged
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 8 * stride) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * stride;
+      v[u] = g[i < n ? i : i0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * stride < n) acc = fmaf(v[u], v[u], acc);
+  }
   acc = jh_block_reduce(acc, s_red, JhAdd(), 0.f);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
   if (blockIdx.x == 0 && threadIdx.x == 0) jh_adam_advance(hyper);  // nobody reads hyper in this kernel
@@ -716,6 +764,27 @@ static HeadPtrs head_ptrs(jh_pponet* n, float* out0, float* out1, float* outv, c
   return hp;
 }
 
+// Outputs o0 .. o0 + 7 of the net's heads (flat output order: head0[A], head1[A] (continuous), value) as the kernels' HeadFlat.
+static HeadFlat head_flat(jh_pponet* n, const HeadPtrs& hp, int o0) {
+  HeadFlat hf{};
+  int o_flat = 0, k = 0;
+  for (int g = 0; g < hp.groups; ++g)
+    for (int o = 0; o < hp.n[g]; ++o, ++o_flat) {
+      if (o_flat < o0 || k >= 8) continue;
+      hf.w[k] = hp.w[g] + (size_t)o * n->H;
+      hf.b[k] = hp.b[g] + o;
+      hf.out[k] = hp.out[g] ? hp.out[g] + o : nullptr;
+      hf.g[k] = hp.g[g] ? hp.g[g] + o : nullptr;
+      hf.ld[k] = hp.n[g];
+      ++k;
+    }
+  hf.n = k;
+  for (; k < 8; ++k) {  // unused slots: valid addresses (fetched unconditionally, ignored)
+    hf.w[k] = hf.w[0]; hf.b[k] = hf.b[0]; hf.out[k] = hf.out[0]; hf.g[k] = hf.g[0]; hf.ld[k] = hf.ld[0];
+  }
+  return hf;
+}
+
 // Flat list of head outputs: weight row / weight-grad row / bias / bias-grad of output o.
 static int head_rows(jh_pponet* n, const float** w, float** dw, const float** b, float** db) {
   int o = 0;
@@ -846,7 +915,17 @@ __global__ void __launch_bounds__(256) jh_ppo_dw1_combine_kernel(int H, int S, i
     __shared__ float s_b[32][8];
     const int o = threadIdx.x & 7, rl = threadIdx.x >> 3;
     float v = 0.f;
-    for (int b = rl; b < hg.B; b += 32) v += hg.g8[(size_t)b * 8 + o];
+    for (int b0 = rl; b0 < hg.B; b0 += 32 * 8) {  // eight fetches in flight (one per wait before: 64 serial round trips at B = 2048 -- this workgroup WAS the launch's 9.6 us); same order of additions
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 32 * u;
+        q[u] = hg.g8[(size_t)(b < hg.B ? b : b0) * 8 + o];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + 32 * u < hg.B) v += q[u];
+    }
     s_b[rl][o] = v;
     __syncthreads();
     if (threadIdx.x < 8 && threadIdx.x < hg.n_out) {
@@ -961,7 +1040,7 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
   if (rc) return rc;
   HeadPtrs hp = head_ptrs(n, d_head0, d_head1, d_value, nullptr, nullptr, nullptr);
   for (int o0 = 0; o0 < n->n_out; o0 += 8) {  // one launch per 8 head outputs (Hopper / CartPole: one)
-    JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, hp, o0);
+    JH_LAUNCH(jh_mlp_heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, n->h2, head_flat(n, hp, o0));
     JH_LAUNCH_CHECK();
   }
   return JH_OK;
@@ -980,9 +1059,11 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
   const int H = n->H, S = n->S;
   const int64_t bh = (int64_t)B * H;
   HeadPtrs hp = head_ptrs(n, nullptr, nullptr, nullptr, d_g_head0, d_g_head1, d_g_value);
-  JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh / 4 + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
-            n->g_all, hp, n->gld);
-  JH_LAUNCH_CHECK();
+  for (int o0 = 0; o0 < n->n_out; o0 += 8) {  // the chain over the outputs continues from launch to launch (dh2 holds it in between)
+    JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh / 4 + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
+              n->g_all, head_flat(n, hp, o0), n->gld, o0, o0 == 0 ? 1 : 0, o0 + 8 >= n->n_out ? 1 : 0);
+    JH_LAUNCH_CHECK();
+  }
   const float* w[kMaxHeadOutputs]; float* dw[kMaxHeadOutputs]; const float* b[kMaxHeadOutputs]; float* db[kMaxHeadOutputs];
   const int n_out = head_rows(n, w, dw, b, db);
   const int gld = n->gld;
