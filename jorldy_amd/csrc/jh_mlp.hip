@@ -844,43 +844,83 @@ __global__ void __launch_bounds__(256) jh_ppo_dw1_partial_kernel(int B, int H, i
   const int z = blockIdx.y, b0 = z * rows_per;
   int nb = B - b0;
   if (nb > rows_per) nb = rows_per;
-  for (int i = threadIdx.x; i < nb * SP; i += 256) {
-    const int r = i / SP, q = i - r * SP;
-    s_x[i] = q < S ? x[(idx ? idx[b0 + r] : (int64_t)(b0 + r)) * S + q] : 0.f;
+  // Fetch order (round 5; the launch was a chain of ~12 dependent round trips: three staging passes of idx -> x, two of g8, then one
+  // per round of four rows): this thread's first SIXTEEN rows of dh1 / h2 (two rounds of eight: every row of a 64-row slab) are
+  // requested first -- they depend on nothing --, then the slab's row indices, its observation rows and its head-gradient rows, each as one
+  // batch.  Addresses past the end are clamped and the values dropped (a conditional load is sunk behind its use = serial again).
+  constexpr int RU = 8;
+  const int hc = h < H ? h : H - 1;
+  const float* h2c = heads ? h2 : dh1;
+  auto fetch = [&](int r0, float (&g)[RU], float (&a2)[RU]) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = r0 + 4 * u;
+      const int rc = r < nb ? r : nb - 1;
+      g[u] = dh1[(size_t)(b0 + rc) * H + hc];
+      a2[u] = h2c[(size_t)(b0 + rc) * H + hc];
+    }
+  };
+  float gA[RU], aA[RU], gB[RU], aB[RU];
+  fetch(rl, gA, aA);
+  fetch(rl + 4 * RU, gB, aB);
+  float* dummy = s_acc + threadIdx.x;  // not in use before the barrier
+  const float4* g4 = (const float4*)((heads ? g8 : dh1) + (size_t)b0 * 8);  // [nb][8] contiguous, 32-byte rows
+  const int ng = heads ? nb * 2 : 0;
+  const float4 g_first = g4[(int)threadIdx.x < ng ? threadIdx.x : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    constexpr int SU = 4;
+    const int nx = nb * SP;
+    for (int i0 = threadIdx.x; i0 < nx; i0 += 256 * SU) {
+      int64_t row[SU];
+      int qq[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + 256 * u;
+        const int ic = i < nx ? i : nx - 1;
+        const int r = ic / SP;
+        qq[u] = ic - r * SP;
+        row[u] = idx ? idx[b0 + r] : (int64_t)(b0 + r);
+      }
+      float v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) v[u] = x[row[u] * S + (qq[u] < S ? qq[u] : S - 1)];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + 256 * u;
+        *(i < nx ? s_x + i : dummy) = qq[u] < S ? v[u] : 0.f;
+      }
+    }
+    *((int)threadIdx.x < ng ? (float4*)s_g + threadIdx.x : (float4*)s_acc + threadIdx.x) = g_first;
+    for (int i = threadIdx.x + 256; i < ng; i += 256) ((float4*)s_g)[i] = g4[i];
   }
-  if (heads)
-    for (int i = threadIdx.x; i < nb * 8; i += 256) s_g[i] = g8[(size_t)b0 * 8 + i];
   __syncthreads();
   float acc[NA];
 #pragma unroll
   for (int q = 0; q < NA; ++q) acc[q] = 0.f;
+  // the FMA order per accumulator is this thread's rows in ascending order, as before
+  auto consume = [&](int r0, const float (&g)[RU], const float (&a2)[RU]) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = r0 + 4 * u;
+      if (r >= nb) break;
+      const float* xr = s_x + (size_t)r * SP;
+#pragma unroll
+      for (int q = 0; q < SP; ++q) acc[q] = fmaf(g[u], xr[q], acc[q]);
+      acc[SP] += g[u];
+      if (heads) {
+        const float* gr = s_g + (size_t)r * 8;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[SP + 1 + o] = fmaf(a2[u], gr[o], acc[SP + 1 + o]);
+      }
+    }
+  };
   if (h < H) {
-    // four of this thread's rows per round, their dh1 / h2 loads issued before the first FMA (one row per round left the thread waiting
-    // for a dependent HBM round trip sixteen times: 14-16 us at B = 2048 for 8 MB of reads); the FMA order per accumulator is unchanged
-    constexpr int RU = 4;
-    for (int r0 = rl; r0 < nb; r0 += 4 * RU) {
-      float g[RU], a2[RU];
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const int r = r0 + 4 * u;
-        const int rc = r < nb ? r : nb - 1;
-        g[u] = dh1[(size_t)(b0 + rc) * H + h];
-        a2[u] = heads ? h2[(size_t)(b0 + rc) * H + h] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const int r = r0 + 4 * u;
-        if (r >= nb) break;
-        const float* xr = s_x + (size_t)r * SP;
-#pragma unroll
-        for (int q = 0; q < SP; ++q) acc[q] = fmaf(g[u], xr[q], acc[q]);
-        acc[SP] += g[u];
-        if (heads) {
-          const float* gr = s_g + (size_t)r * 8;
-#pragma unroll
-          for (int o = 0; o < 8; ++o) acc[SP + 1 + o] = fmaf(a2[u], gr[o], acc[SP + 1 + o]);
-        }
-      }
+    for (int r0 = rl; r0 < nb; r0 += 8 * RU) {
+      consume(r0, gA, aA);
+      if (r0 + 8 * RU < nb) fetch(r0 + 8 * RU, gA, aA);
+      consume(r0 + 4 * RU, gB, aB);
+      if (r0 + 12 * RU < nb) fetch(r0 + 12 * RU, gB, aB);
     }
   }
   float* mine = s_acc + ((size_t)rl * 64 + hl) * NA;

@@ -464,10 +464,29 @@ __device__ __forceinline__ RowIn ppo_row_load(const PpoArgs<CONT>& a, int i) {
   return in;
 }
 
+// The continuous policy's per-dimension inputs of one row -- head outputs, action, log pi_old -- for the first kContCache dimensions,
+// fetched in ONE batch (the multi-workgroup kernels: the row loop read four values per dimension, waited, ran ~470 double-precision
+// instructions and only then asked for the next dimension's four).  Dimensions past A re-read dimension A-1 (never used).
+struct ContPre {
+  float z0[kContCache], z1[kContCache], act[kContCache], lpo[kContCache];
+};
+template <bool CONT>
+__device__ __forceinline__ ContPre ppo_cont_prefetch(const PpoArgs<CONT>& a, const float* z0, const float* z1, int64_t r) {
+  ContPre c;
+#pragma unroll
+  for (int k = 0; k < kContCache; ++k) {
+    const int kk = k < a.A ? k : a.A - 1;
+    c.z0[k] = z0[kk]; c.z1[k] = z1[kk]; c.act[k] = a.action[r * a.A + kk]; c.lpo[k] = a.logp_old[r * a.A + kk];
+  }
+  return c;
+}
+
 // z0 / z1: this row's head-0 / head-1 vectors (global memory or the LDS staging), v: value prediction
+// pre: optional (continuous policies), the first kContCache dimensions' inputs already in registers
 template <bool CONT>
 __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, const RowIn& in, const float* z0, const float* z1, float v,
-                                            RowCommon& rc, float& ent_row, float& minp_row, DiscRow& dr, int& act_k) {
+                                            RowCommon& rc, float& ent_row, float& minp_row, DiscRow& dr, int& act_k,
+                                            const ContPre* pre = nullptr) {
   const int64_t r = in.r;
   const float adv = in.adv, ret = in.ret, vold = in.vold;
   if (!CONT) {
@@ -490,12 +509,22 @@ __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, const RowIn&
   } else {
     double lsum = 0.0, ent = 0.0;
     float minp = 3.4e38f;
-    for (int k = 0; k < a.A; ++k) {
-      const NormalD n = normal_terms(z0[k], z1[k], a.action[r * a.A + k]);
-      if (k < kContCache) dr.n[k] = n;
-      lsum += n.lp - (double)a.logp_old[r * a.A + k];
+    auto dim = [&](const NormalD& n, float lpo) {
+      lsum += n.lp - (double)lpo;
       ent += 0.5 + 0.91893853320467274178 + n.th;  // Normal.entropy = 1/2 + log sqrt(2 pi) + log(std), log(std) = tanh(log_std_raw)
       minp = fminf(minp, (float)exp(n.lp));
+    };
+    int k0 = 0;
+    if (pre) {  // same terms, same order; the unrolled form keeps dr.n[] in registers under static indices
+#pragma unroll
+      for (int k = 0; k < kContCache; ++k)
+        if (k < a.A) { dr.n[k] = normal_terms(pre->z0[k], pre->z1[k], pre->act[k]); dim(dr.n[k], pre->lpo[k]); }
+      k0 = kContCache;
+    }
+    for (int k = k0; k < a.A; ++k) {
+      const NormalD n = normal_terms(z0[k], z1[k], a.action[r * a.A + k]);
+      if (k < kContCache) dr.n[k] = n;
+      dim(n, a.logp_old[r * a.A + k]);
     }
     ent_row = (float)ent;  // summed over dims; the mean is over B*A elements (ppo.py:156)
     rc = row_common((float)lsum, adv, v, vold, ret, a.eps);
@@ -505,7 +534,8 @@ __device__ __forceinline__ void ppo_row_fwd(const PpoArgs<CONT>& a, const RowIn&
 
 template <bool CONT>
 __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const float* z0, const float* z1,
-                                            const RowCommon& rc, const DiscRow& dr, int act_k, float w1, float w2) {
+                                            const RowCommon& rc, const DiscRow& dr, int act_k, float w1, float w2,
+                                            const ContPre* pre = nullptr) {
   const float invB = 1.f / (float)a.B;
   const float d_ratio = -invB * (rc.g1 * rc.adv + (rc.in_clip ? rc.g2 * rc.adv : 0.f));
   const float d_logp = d_ratio * rc.ratio;
@@ -553,15 +583,25 @@ __device__ __forceinline__ void ppo_row_bwd(const PpoArgs<CONT>& a, int i, const
     const int64_t r = a.idx ? a.idx[i] : (int64_t)i;
     const double ce = -(double)a.ent / (double)(a.B * a.A);  // d(ent_coef * -mean(H)) / d log(std)
     const double dlp = (double)d_logp;
-    for (int k = 0; k < a.A; ++k) {
-      const float mr = z0[k], lr = z1[k];
-      const NormalD n = k < kContCache ? dr.n[k] : normal_terms(mr, lr, a.action[r * a.A + k]);  // (the forward half evaluated them: ~10 double transcendentals per dimension)
+    auto dim = [&](int k, float mr, const NormalD& n) {
       const double var = n.std * n.std, dm = n.z - n.mu;
       const double d_mu = dlp * dm / var;
       // d/d(std): d_logp ((dm^2 - var) / (var std)) + ce / std; then std' = std (1 - th^2) through exp(tanh(.))
       const double d_std = dlp * ((dm * dm - var) / (var * n.std)) + ce / n.std;
       a.g0[(size_t)i * a.ldg + k] = (mr >= -5.f && mr <= 5.f) ? (float)d_mu : 0.f;
       a.g1[(size_t)i * a.ldg + k] = (float)(d_std * n.std * (1.0 - n.th * n.th));
+    };
+    int k0 = 0;
+    if (pre) {
+#pragma unroll
+      for (int k = 0; k < kContCache; ++k)
+        if (k < a.A) dim(k, pre->z0[k], dr.n[k]);
+      k0 = kContCache;
+    }
+    for (int k = k0; k < a.A; ++k) {
+      const float mr = z0[k], lr = z1[k];
+      const NormalD n = k < kContCache ? dr.n[k] : normal_terms(mr, lr, a.action[r * a.A + k]);  // (the forward half evaluated them: ~10 double transcendentals per dimension)
+      dim(k, mr, n);
     }
   }
 }
@@ -715,28 +755,34 @@ __global__ void __launch_bounds__(MAXT) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
 }
 
 // B > 1024: pass 1 writes per-block partials, pass 2 re-reduces them in every block (deterministic,
-// no atomics) and recomputes the cheap row terms instead of spilling them to HBM.
+// no atomics) and recomputes the row terms instead of spilling them to HBM.
+// Fetch order (round 5, both passes): rows past B work on row B-1 and drop the result, so that every load is unconditional and the
+// compiler can batch them -- row index, then {adv, ret, value_old, value prediction, the policy's inputs} in one round trip; the six
+// block reductions share one LDS exchange (12 barriers -> 1; same arithmetic order, see ppo_block_reduce6).
 template <bool CONT>
 __global__ void __launch_bounds__(256) jh_ppo_fwd_kernel(PpoArgs<CONT> a) {
-  __shared__ float s_red[16];
+  __shared__ float s_red6[16][6];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool on = i < a.B;
+  const int ic = on ? i : a.B - 1;
   RowCommon rc{};
   DiscRow dr{};
   int act_k = 0;
   float ent_row = 0.f, minp = 3.4e38f;
-  if (on) ppo_row_fwd<CONT>(a, ppo_row_load<CONT>(a, i), a.h0 + (size_t)i * a.A, CONT ? a.h1 + (size_t)i * a.A : nullptr, a.value_pred[i], rc, ent_row, minp, dr, act_k);
+  const float* z0 = a.h0 + (size_t)ic * a.A;
+  const float* z1 = CONT ? a.h1 + (size_t)ic * a.A : nullptr;
+  const RowIn rin = ppo_row_load<CONT>(a, ic);
+  const float vpred = a.value_pred[ic];
+  ContPre pre;
+  if (CONT) pre = ppo_cont_prefetch<CONT>(a, z0, z1, rin.r);
+  ppo_row_fwd<CONT>(a, rin, z0, z1, vpred, rc, ent_row, minp, dr, act_k, CONT ? &pre : nullptr);
   const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
   const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
-  const float s_smin = jh_block_reduce(on ? rc.smin : 0.f, s_red, JhAdd(), 0.f);
-  const float s_e1 = jh_block_reduce(e1, s_red, JhAdd(), 0.f);
-  const float s_e2 = jh_block_reduce(e2, s_red, JhAdd(), 0.f);
-  const float s_ent = jh_block_reduce(on ? ent_row : 0.f, s_red, JhAdd(), 0.f);
-  const float mx = jh_block_reduce(on ? rc.ratio : -3.4e38f, s_red, JhMax(), -3.4e38f);
-  const float mn = jh_block_reduce(on ? minp : 3.4e38f, s_red, JhMin(), 3.4e38f);
+  float v6[6] = {on ? rc.smin : 0.f, e1, e2, on ? ent_row : 0.f, on ? rc.ratio : -3.4e38f, on ? minp : 3.4e38f};
+  ppo_block_reduce6(v6, s_red6);
   if (threadIdx.x == 0) {
     float* p = a.partial + (size_t)blockIdx.x * PPO_NPART;
-    p[0] = s_smin; p[1] = s_e1; p[2] = s_e2; p[3] = s_ent; p[4] = mx; p[5] = mn;
+    p[0] = v6[0]; p[1] = v6[1]; p[2] = v6[2]; p[3] = v6[3]; p[4] = v6[4]; p[5] = v6[5];
   }
 }
 
@@ -766,29 +812,62 @@ __global__ void __launch_bounds__(256) jh_ppo_totals_kernel(const float* __restr
   if (threadIdx.x == 0) { totals[0] = t0; totals[1] = t1; totals[2] = t2; totals[3] = t3; totals[4] = t4; totals[5] = t5; }
 }
 
+// nb <= 64 partials fit one wave: every wave reduces them by itself with the shuffle tree wave 0 of ppo_reduce_partials would run
+// (lane b holds 0 + partial b, the other lanes the identity), and the block-level combine of that form adds the other waves'
+// identities -- 0.f + tree, which is what is returned here: bit-identical, without the LDS exchange and its 12 barriers.
+__device__ __forceinline__ void ppo_reduce_partials_wave(const float* __restrict__ partial, int nb, float (&t)[6]) {
+  const int lane = threadIdx.x & 63;
+  const float* p = partial + (size_t)(lane < nb ? lane : 0) * PPO_NPART;
+  float q[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) q[k] = p[k];
+  const bool mine = lane < nb;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = mine ? 0.f + q[k] : 0.f;
+  t[4] = mine ? fmaxf(-3.4e38f, q[4]) : -3.4e38f;
+  t[5] = mine ? fminf(3.4e38f, q[5]) : 3.4e38f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] += __shfl_xor(t[k], o, 64);
+    t[4] = fmaxf(t[4], __shfl_xor(t[4], o, 64));
+    t[5] = fminf(t[5], __shfl_xor(t[5], o, 64));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = 0.f + t[k];
+  t[4] = fmaxf(-3.4e38f, t[4]);
+  t[5] = fminf(3.4e38f, t[5]);
+}
+
 template <bool CONT>
 __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
-  __shared__ float s_red[16];
-  float t0, t1, t2, t3, t4, t5;
+  // the row's inputs first: they do not depend on the totals (see jh_ppo_fwd_kernel for the clamped row)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < a.B;
+  const int ic = on ? i : a.B - 1;
+  const float* z0 = a.h0 + (size_t)ic * a.A;
+  const float* z1 = CONT ? a.h1 + (size_t)ic * a.A : nullptr;
+  const RowIn rin = ppo_row_load<CONT>(a, ic);
+  const float vpred = a.value_pred[ic];
+  ContPre pre;
+  if (CONT) pre = ppo_cont_prefetch<CONT>(a, z0, z1, rin.r);
+  float t[6];
   if (a.totals) {
-    t0 = a.totals[0]; t1 = a.totals[1]; t2 = a.totals[2]; t3 = a.totals[3]; t4 = a.totals[4]; t5 = a.totals[5];
-  } else {
-    ppo_reduce_partials(a.partial, a.nb, s_red, t0, t1, t2, t3, t4, t5);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = a.totals[k];
+  } else {  // ppo_launch: more than 64 partials always come reduced (a.totals)
+    ppo_reduce_partials_wave(a.partial, a.nb, t);
   }
   float w1, w2;
-  ppo_finish_stats(t0, t1, t2, t3, t4, t5, a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
+  ppo_finish_stats(t[0], t[1], t[2], t[3], t[4], t[5], a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2,
                    (blockIdx.x == 0 && threadIdx.x == 0) ? a.stats : nullptr);
-  if (a.critic_sums && blockIdx.x == 0 && threadIdx.x == 0) { a.critic_sums[0] = t1; a.critic_sums[1] = t2; }
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.B) return;
+  if (a.critic_sums && blockIdx.x == 0 && threadIdx.x == 0) { a.critic_sums[0] = t[1]; a.critic_sums[1] = t[2]; }
   RowCommon rc;
   DiscRow dr{};
   int act_k = 0;
   float ent_row, minp;
-  const float* z0 = a.h0 + (size_t)i * a.A;
-  const float* z1 = CONT ? a.h1 + (size_t)i * a.A : nullptr;
-  ppo_row_fwd<CONT>(a, ppo_row_load<CONT>(a, i), z0, z1, a.value_pred[i], rc, ent_row, minp, dr, act_k);
-  ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2);
+  ppo_row_fwd<CONT>(a, rin, z0, z1, vpred, rc, ent_row, minp, dr, act_k, CONT ? &pre : nullptr);
+  if (on) ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2, CONT ? &pre : nullptr);
 }
 
 template <bool CONT>
