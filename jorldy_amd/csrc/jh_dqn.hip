@@ -188,15 +188,34 @@ __device__ __forceinline__ float atom_softmax(const float* __restrict__ row, int
 
 // Dueling combine of one (set, sample): this lane's share of mean_a xa[b][a][k] (the sum runs over a in order, like
 // jh_rb_duel_fwd_kernel), and one action's logits (xa - mean) + xv, written to the set's logits as a side effect.
-__device__ __forceinline__ void duel_mean(const C51Duel& d, int set, int b, int A, int K, int lane, float mean[4]) {
-  const float* xa = d.xa[set] + (size_t)b * d.ld_a;
+// All three sets at once, four actions per round: 12 fetches in flight (round 5; one fetch per wait before: 3 sets x A dependent
+// round trips in front of the first softmax).  Addresses are clamped (atom K - 1, action A - 1) and the surplus dropped; the sums
+// run over a in ascending order as before.
+__device__ __forceinline__ void duel_mean3(const C51Duel& d, int b, int A, int K, int lane, float (&mean0)[4], float (&mean1)[4], float (&mean2)[4]) {
+  const float* xa0 = d.xa[0] + (size_t)b * d.ld_a;
+  const float* xa1 = d.xa[1] + (size_t)b * d.ld_a;
+  const float* xa2 = d.xa[2] + (size_t)b * d.ld_a;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int k = lane + 64 * s;
-    float sum = 0.f;
-    if (k < K)
-      for (int a = 0; a < A; ++a) sum += xa[a * K + k];
-    mean[s] = sum / (float)A;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (64 * s < K) {  // wave-uniform
+      const int kc = k < K ? k : K - 1;
+      for (int a0 = 0; a0 < A; a0 += 4) {
+        float v0[4], v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int o = (a0 + u < A ? a0 + u : A - 1) * K + kc;
+          v0[u] = xa0[o]; v1[u] = xa1[o]; v2[u] = xa2[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (a0 + u < A) { s0 += v0[u]; s1 += v1[u]; s2 += v2[u]; }
+      }
+    }
+    mean0[s] = (k < K ? s0 : 0.f) / (float)A;
+    mean1[s] = (k < K ? s1 : 0.f) / (float)A;
+    mean2[s] = (k < K ? s2 : 0.f) / (float)A;
   }
 }
 // one action's row: the loads (issued with the mean's loads, in front of any store), then combine + store
@@ -400,13 +419,14 @@ __global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a, C51Duel d)
   act = act < 0 ? 0 : (act >= a.A ? a.A - 1 : act);
   // what wave 0 needs after the barrier, requested now so that it arrives under the softmaxes instead of as three more dependent round
   // trips: the n-step rewards / dones (lane i holds step i) and this lane's share of the batch's IS weights (summed in the old order)
+  // (round 5: every wave fetches them, unconditionally and from clamped addresses -- inside `if (wid == 0)` the block ended in a wait,
+  // and so did the row loads inside `if (wid < A)` below: three dependent round trips where one batch does)
   const bool pre = a.n <= 64;
-  float pre_r = 0.f, pre_d = 0.f, pre_ws = 0.f;
-  if (wid == 0) {
-    if (pre && lane < a.n) { pre_r = a.reward[(size_t)b * a.n + lane]; pre_d = a.done[(size_t)b * a.n + lane]; }
-    if (a.flags & JH_C51_PER)
-      for (int i = lane; i < a.B; i += 64) pre_ws += a.weights[i];
-  }
+  const bool per = (a.flags & JH_C51_PER) != 0;
+  const int ln = lane < a.n ? lane : a.n - 1;
+  const float ld_r = a.reward[(size_t)b * a.n + ln], ld_d = a.done[(size_t)b * a.n + ln];
+  const float* wp = per ? a.weights : a.reward;
+  const float ld_w0 = wp[(per && lane < a.B) ? lane : 0], ld_w1 = wp[(per && lane + 64 < a.B) ? lane + 64 : 0];
   // ---- phase 1: online softmaxes (stats + the taken action's distribution) and the selector's Q, actions strided over waves
   float maxq = -3.4e38f, maxl = -3.4e38f, minl = 3.4e38f;
   const float* sel = (a.flags & JH_C51_DOUBLE) ? a.next_logit : a.target_logit;
@@ -415,11 +435,17 @@ __global__ void __launch_bounds__(256) jh_c51_block_kernel(C51Args a, C51Duel d)
   float ra[3][4], rv[3][4];
   if (DUEL) {
     // this wave's first row of the three sets and everything the means need: one batch of loads, one wait
-    if (wid < a.A)
-      for (int j = 0; j < 3; ++j) duel_row_load(d, j, b, wid, K, lane, ra[j], rv[j]);
-    duel_mean(d, 0, b, a.A, K, lane, mean0);
-    duel_mean(d, 1, b, a.A, K, lane, mean1);
-    duel_mean(d, 2, b, a.A, K, lane, mean2);
+    const int aw = wid < a.A ? wid : a.A - 1;
+    for (int j = 0; j < 3; ++j) duel_row_load(d, j, b, aw, K, lane, ra[j], rv[j]);
+    duel_mean3(d, b, a.A, K, lane, mean0, mean1, mean2);
+  }
+  const float pre_r = (pre && lane < a.n) ? ld_r : 0.f, pre_d = (pre && lane < a.n) ? ld_d : 0.f;
+  float pre_ws = 0.f;
+  if (per) {
+    if (lane < a.B) pre_ws += ld_w0;
+    if (lane + 64 < a.B) pre_ws += ld_w1;
+    if (wid == 0)
+      for (int i = lane + 128; i < a.B; i += 64) pre_ws += a.weights[i];
   }
   for (int aa = wid; aa < a.A; aa += 4) {
     float p[4], rmx, rmn, q, q2, p2[4];

@@ -116,25 +116,54 @@ __global__ void __launch_bounds__(256) jh_per_climb_kernel(double* __restrict__ 
 // one lane per sample: descent + importance weight (unnormalised) + per-block partials
 __global__ void __launch_bounds__(256) jh_per_sample_kernel(const double* __restrict__ tree, int64_t first_leaf,
                                                             int64_t B, int64_t n_uniform,
-                                                            const int64_t* __restrict__ uni_slot,
-                                                            const double* __restrict__ u, int64_t counter, double usp,
+                                                            const int64_t* uni_slot,  // (no __restrict__ on these two: a restrict-qualified
+                                                            const double* u,          //  fetch is free to sink below the barrier, behind the staging)
+                                                            int64_t counter, double usp,
                                                             double beta, int64_t* __restrict__ idx_out,
                                                             double* __restrict__ prio_ws, double* __restrict__ w_ws,
                                                             double* __restrict__ partial, int fuse_norm,
                                                             double* __restrict__ w64, float* __restrict__ w32,
                                                             double* __restrict__ stats) {
   __shared__ double s_red[16];
-  const double root = tree[0];
+  // The top ten levels of the tree (nodes 0 .. 1022, 8 KB) go to LDS in ONE batch of fetches, together with the root and this
+  // thread's first draw (device-mapped host memory: a PCIe read): the descent is a chain of dependent reads, 20 levels at N = 2^20,
+  // and its first ten now cost an LDS read each instead of an L2 round trip (round 5; 10.3 us at B = 32 before).  Same values, same
+  // comparisons: the indices are the reference's bit for bit.
+  constexpr int NC = 1023;
+  __shared__ double s_top[NC + 1];
+  const int64_t tree_size = 2 * first_leaf + 1;
+  const int64_t b_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool first_draws = b_first < B && b_first >= n_uniform;
+  const double u_first = u[first_draws ? b_first - n_uniform : 0];
+  const int64_t slot_first = uni_slot[(b_first < B && b_first < n_uniform) ? b_first : 0];
+  {
+    double tv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = threadIdx.x + 256 * q;
+      tv[q] = tree[i < tree_size ? i : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_top[threadIdx.x + 256 * q] = tv[q];
+  }
+  __syncthreads();
+  const double root = s_top[0];
   const double uniform_probs = 1.0 / (double)counter;
   double my_w = 0.0, my_p = 0.0;
-  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+  for (int64_t b = b_first; b < B; b += (int64_t)gridDim.x * 256) {
     int64_t index;
     if (b < n_uniform) {
-      index = uni_slot[b] + first_leaf;  // per_buffer.py:75-78
+      index = (b == b_first ? slot_first : uni_slot[b]) + first_leaf;  // per_buffer.py:75-78
     } else {
-      double num = u[b - n_uniform] * root;  // per_buffer.py:81
+      double num = (b == b_first ? u_first : u[b - n_uniform]) * root;  // per_buffer.py:81
       index = 0;
-      while (index < first_leaf) {  // per_buffer.py:56-68
+      while (index < first_leaf && 2 * index + 1 < NC) {  // per_buffer.py:56-68, levels held in LDS
+        const int64_t left = 2 * index + 1;
+        const double l = s_top[left];
+        if (num <= l) index = left;
+        else { num -= l; index = left + 1; }
+      }
+      while (index < first_leaf) {
         const int64_t left = 2 * index + 1;
         const double l = tree[left];
         if (num <= l) index = left;

@@ -151,30 +151,41 @@ __global__ void __launch_bounds__(256) jh_rb_duel_bwd_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------- col2im (+ relu')
 // d(act)[(b, y, x)][c] = relu'(act) * sum over the taps (ky, kx) that read this pixel of d(col)[(b, oy, ox)][(ky, kx, c)]
+// Round 5: the taps that can reach a pixel are ky = y % S + S t, kx = x % S + S u (all others fail `yy % S`): (KH / S) (KW / S) of
+// them -- 4 for conv2's 4 x 4 stride 2, 9 for conv3's 3 x 3 stride 1 --, fetched as ONE batch from clamped addresses and added in
+// ascending (ky, kx) order where valid.  The loop over all KH KW taps with `continue` compiled to one fetch per wait: up to nine
+// dependent round trips per pixel (tools/isa_chain.py), 7-10 us per launch at B = 32.
+template <int KH, int KW, int S>
 __global__ void __launch_bounds__(256) jh_rb_col2im_kernel(const float* __restrict__ dcol, const float* __restrict__ act, float* __restrict__ dact,
-                                                           int n_pix, int C, int H, int W, int OH, int OW, int KH, int KW, int S) {
+                                                           int n_pix, int C, int H, int W, int OH, int OW) {
+  constexpr int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
   const int c4 = C / 4;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)n_pix * c4) return;
   const int pix = (int)(i / c4), c = 4 * (int)(i - (int64_t)pix * c4);
   const int x = pix % W, t = pix / W, y = t % H, b = t / H;
   const int Kp = KH * KW * C;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int ky = 0; ky < KH; ++ky) {
-    const int yy = y - ky;
-    if (yy < 0 || yy % S) continue;
-    const int oy = yy / S;
-    if (oy >= OH) continue;
-    for (int kx = 0; kx < KW; ++kx) {
-      const int xx = x - kx;
-      if (xx < 0 || xx % S) continue;
-      const int ox = xx / S;
-      if (ox >= OW) continue;
-      const float4 v = *reinterpret_cast<const float4*>(dcol + ((size_t)(b * OH + oy) * OW + ox) * Kp + (ky * KW + kx) * C + c);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  const float4 a = *reinterpret_cast<const float4*>(act + (size_t)pix * C + c);
+  float4 v[TY][TX];
+  bool ok[TY][TX];
+#pragma unroll
+  for (int ty = 0; ty < TY; ++ty) {
+    const int ky = y % S + S * ty, yy = y - ky, oy = yy / S;  // yy % S == 0 by construction
+    const bool oky = ky < KH && yy >= 0 && oy < OH;
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx) {
+      const int kx = x % S + S * tx, xx = x - kx, ox = xx / S;
+      ok[ty][tx] = oky && kx < KW && xx >= 0 && ox < OW;
+      const int oyc = ok[ty][tx] ? oy : 0, oxc = ok[ty][tx] ? ox : 0, kc = ok[ty][tx] ? ky * KW + kx : 0;
+      v[ty][tx] = *reinterpret_cast<const float4*>(dcol + ((size_t)(b * OH + oyc) * OW + oxc) * Kp + kc * C + c);
     }
   }
-  const float4 a = *reinterpret_cast<const float4*>(act + (size_t)pix * C + c);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx)
+      if (ok[ty][tx]) { acc.x += v[ty][tx].x; acc.y += v[ty][tx].y; acc.z += v[ty][tx].z; acc.w += v[ty][tx].w; }
   acc.x = a.x > 0.f ? acc.x : 0.f; acc.y = a.y > 0.f ? acc.y : 0.f; acc.z = a.z > 0.f ? acc.z : 0.f; acc.w = a.w > 0.f ? acc.w : 0.f;
   *reinterpret_cast<float4*>(dact + (size_t)pix * C + c) = acc;
 }
@@ -207,31 +218,49 @@ __global__ void __launch_bounds__(256) jh_rb_conv1_fwd_kernel(C1Fwd a) {
   const C1Job& J = a.j[(a.nj > 1 && (int)blockIdx.x >= a.j[1].wg_begin) ? 1 : 0];
   const int local = blockIdx.x - J.wg_begin;
   const int img = local / a.wgs_per_img, part = local - img * a.wgs_per_img;
-  for (int i = t; i < 32 * (K / 4); i += 256) {
-    const int oc = i / (K / 4), k4 = i - oc * (K / 4);
-    *reinterpret_cast<float4*>(&sW[oc * LDW + 4 * k4]) = *reinterpret_cast<const float4*>(J.W + (size_t)oc * K + 4 * k4);
-  }
-  __syncthreads();
-  const float bias0 = J.bias[r], bias1 = J.bias[16 + r];
+  // Fetch order (round 5, tools/isa_chain.py): the weight staging was 8 passes compiled as 5 + 1 + 1 + 1 fetches per wait, the bias
+  // followed the barrier, a tile's 16 frame dwords came as two batches of 8 and the next tile's only after the last MFMA of this one
+  // -- about ten dependent round trips for a launch with 0.2 us of matrix work.  Now: the first tile's frame dwords, the bias and all
+  // weight passes are ONE batch in front of the barrier, and tile i + 1 is fetched in front of tile i's MFMAs.
   const int t0 = part * a.tiles_per_wg;
   int t1 = t0 + a.tiles_per_wg;
   if (t1 > a.tiles_per_img) t1 = a.tiles_per_img;
   const uint8_t* frame = J.x + (size_t)img * CIN * a.H * a.W;
   float* out = J.out + (size_t)img * a.P * 32;
-  for (int tile = t0 + wid; tile < t1; tile += 4) {
+  auto fetch_tile = [&](int tile, uint32_t (&xw)[NS]) {  // a tile past the end re-reads the last pixel (never used)
     const int p = tile * 16 + r, pc = p < a.P ? p : a.P - 1;
     const int oy = (int)(((float)pc + 0.5f) * a.inv_ow), ox = pc - oy * a.OW;
     const uint8_t* base = frame + (size_t)(4 * oy) * a.W + 4 * ox;
-    uint32_t xw[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int q = 4 * s + kq, c = q >> 4, ky = (q >> 1) & 7, h = q & 1;
       xw[s] = *reinterpret_cast<const uint32_t*>(base + (size_t)(c * a.H + ky) * a.W + 4 * h);
     }
+  };
+  uint32_t xw[NS], xn[NS];
+  fetch_tile(t0 + wid, xw);
+  const float bias0 = J.bias[r], bias1 = J.bias[16 + r];
+  {
+    constexpr int NP = 32 * (K / 4) / 256;  // 8 passes for 4 input planes
+    static_assert(32 * (K / 4) % 256 == 0, "whole passes");
+    float4 wv[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = t + 256 * u, oc = i / (K / 4), k4 = i - oc * (K / 4);
+      wv[u] = *reinterpret_cast<const float4*>(J.W + (size_t)oc * K + 4 * k4);
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = t + 256 * u, oc = i / (K / 4), k4 = i - oc * (K / 4);
+      *reinterpret_cast<float4*>(&sW[oc * LDW + 4 * k4]) = wv[u];
+    }
+  }
+  __syncthreads();
+  auto run_tile = [&](int tile, const uint32_t (&xv)[NS]) {
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float af[4] = {u8_unit(xw[s] & 255u), u8_unit((xw[s] >> 8) & 255u), u8_unit((xw[s] >> 16) & 255u), u8_unit(xw[s] >> 24)};
+      const float af[4] = {u8_unit(xv[s] & 255u), u8_unit((xv[s] >> 8) & 255u), u8_unit((xv[s] >> 16) & 255u), u8_unit(xv[s] >> 24)};
       const float4 w0 = *reinterpret_cast<const float4*>(&sW[r * LDW + 4 * (4 * s + kq)]);
       const float4 w1 = *reinterpret_cast<const float4*>(&sW[(16 + r) * LDW + 4 * (4 * s + kq)]);
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], w0.x, acc[0], 0, 0, 0);
@@ -252,6 +281,16 @@ __global__ void __launch_bounds__(256) jh_rb_conv1_fwd_kernel(C1Fwd a) {
         out[(size_t)m * 32 + 16 + r] = v1 > 0.f ? v1 : 0.f;
       }
     }
+  };
+  // two tiles per turn, registers ping-pong (no copies: a copy of a fetched value is a wait)
+  for (int tile = t0 + wid; tile < t1; tile += 8) {
+    fetch_tile(tile + 4, xn);
+    __builtin_amdgcn_sched_barrier(0);
+    run_tile(tile, xw);
+    if (tile + 4 >= t1) break;
+    fetch_tile(tile + 8, xw);
+    __builtin_amdgcn_sched_barrier(0);
+    run_tile(tile + 4, xn);
   }
 }
 
@@ -920,7 +959,7 @@ static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t
       ns.params[j] = jobs[j].P; ns.noise[j] = jobs[j].noise; ns.weff[j] = n->weff + (size_t)j * d.set_stride;
     }
     int64_t blocks = (n->n_noisy + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 4096) blocks = 4096;  // one element per thread at the configs' widths (a thread's pass is three dependent fetches: 1024 blocks walked 2.5 passes)
     JH_LAUNCH(jh_rb_noise_kernel, dim3((unsigned)blocks, nj), dim3(256), 0, st, d, ns, n->n_noisy);
     JH_LAUNCH_CHECK();
   }
@@ -991,7 +1030,7 @@ JH_EXPORT int jh_rbnet_prepare_noise(jh_rbnet* n, const float* d_noise, jh_strea
   const float* P[3] = {n->params, n->params, n->target};
   for (int j = 0; j < 3; ++j) { ns.params[j] = P[j]; ns.noise[j] = d_noise + j * L; ns.weff[j] = n->weff + (size_t)j * d.set_stride; }
   int64_t blocks = (n->n_noisy + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 4096) blocks = 4096;  // one element per thread at the configs' widths (a thread's pass is three dependent fetches: 1024 blocks walked 2.5 passes)
   JH_LAUNCH(jh_rb_noise_kernel, dim3((unsigned)blocks, 3), dim3(256), 0, jh_s(stream), d, ns, n->n_noisy);
   JH_LAUNCH_CHECK();
   n->prepared_noise = d_noise;
@@ -1089,7 +1128,7 @@ JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dty
 
 static int rb_noisy_grad(jh_rbnet* n, hipStream_t st) {
   int64_t blocks = (n->n_noisy + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 4096) blocks = 4096;  // one element per thread at the configs' widths (a thread's pass is three dependent fetches: 1024 blocks walked 2.5 passes)
   JH_LAUNCH(jh_rb_noisy_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n->nd, n->last_noise, n->grads, n->n_noisy);
   JH_LAUNCH_CHECK();
   return JH_OK;
@@ -1195,8 +1234,8 @@ static int rb_backward(jh_rbnet* n, const float* d_g, bool defer, jh_stream stre
   if (rc) return rc;
   {
     const int n_pix = B * n->P2;
-    JH_LAUNCH(jh_rb_col2im_kernel, dim3((unsigned)(((int64_t)n_pix * 16 + 255) / 256)), dim3(256), 0, st, n->dcol, n->act2[0], n->dact2, n_pix, 64, n->c3.H,
-              n->c3.W, n->c3.OH, n->c3.OW, 3, 3, 1);
+    JH_LAUNCH((jh_rb_col2im_kernel<3, 3, 1>), dim3((unsigned)(((int64_t)n_pix * 16 + 255) / 256)), dim3(256), 0, st, n->dcol, n->act2[0], n->dact2, n_pix, 64,
+              n->c3.H, n->c3.W, n->c3.OH, n->c3.OW);
     JH_LAUNCH_CHECK();
   }
   g[0] = mk_gemm(64, 512, B * n->P2, op_dense(OP_XCONT, n->dact2, 64), op_conv(OP_NHWC_X, n->act1[0], 0, n->c2), G + n->seg_off[SEG_W2], 512, TEPI_NONE, nullptr,
@@ -1206,8 +1245,8 @@ static int rb_backward(jh_rbnet* n, const float* d_g, bool defer, jh_stream stre
   if (rc) return rc;
   {
     const int n_pix = B * n->P1;
-    JH_LAUNCH(jh_rb_col2im_kernel, dim3((unsigned)(((int64_t)n_pix * 8 + 255) / 256)), dim3(256), 0, st, n->dcol, n->act1[0], n->dact1, n_pix, 32, n->c2.H,
-              n->c2.W, n->c2.OH, n->c2.OW, 4, 4, 2);
+    JH_LAUNCH((jh_rb_col2im_kernel<4, 4, 2>), dim3((unsigned)(((int64_t)n_pix * 8 + 255) / 256)), dim3(256), 0, st, n->dcol, n->act1[0], n->dact1, n_pix, 32,
+              n->c2.H, n->c2.W, n->c2.OH, n->c2.OW);
     JH_LAUNCH_CHECK();
   }
   // uint8 frames in the head's own geometry: the dedicated K-parallel kernel (above); anything else is a GEMM like the other layers

@@ -93,6 +93,9 @@ __global__ void __launch_bounds__(256) jh_store_copy_cols_kernel(CopyCols a) {
   const int64_t first = a.first[c], total = a.total[c];
   const bool vec = ((((uintptr_t)src | (uintptr_t)d0 | (uintptr_t)d1) & 15) == 0) && ((first & 15) == 0);
   const int64_t nv = vec ? total >> 4 : 0;
+  // (one 16-byte piece per thread for every commit below 8 MB per column -- see the grid in store_append_kernel: the sources are
+  // device-mapped HOST memory for every collector / single-transition commit, and with 64 bytes per thread this loop was four PCIe
+  // round trips in series, 6-9 us per commit; round 5)
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
     const int64_t o = i << 4;
     const uint4 v = *reinterpret_cast<const uint4*>(src + o);
@@ -125,7 +128,7 @@ static int store_append_kernel(jh_store* s, int64_t n, const void* const* cols, 
     a.total[c] = (int64_t)(rb * (size_t)n);
     if (rb * (size_t)n > most) most = rb * (size_t)n;
   }
-  unsigned gx = (unsigned)((most + 16383) / 16384);  // 64 bytes per thread and pass
+  unsigned gx = (unsigned)((most + 4095) / 4096);  // 16 bytes per thread: one round for every commit below 8 MB per column
   if (gx < 1) gx = 1;
   if (gx > 2048) gx = 2048;
   JH_LAUNCH(jh_store_copy_cols_kernel, dim3(gx, (unsigned)(s->n_cols + n_extra)), dim3(256), 0, st, a);

@@ -2,6 +2,8 @@
 // convolutions, linear layers, data / weight gradients) and the PPO net's backward GEMMs.  See jh_tgemm.h.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "jh_tgemm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,15 +38,73 @@ __device__ __noinline__ float4 op_fetch4_slow(Opnd o, int x, int k, int X, int K
 struct TileCtx {
   int z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn;
 };
+// The epilogue's operands of this lane's output elements -- bias, activation mask, NoisyNet noise -- fetched as ONE batch right
+// behind the MFMA loop, in front of the split-K hand-off whose own round trips they fly under (round 5).  In the store loop they sat
+// inside `if (m < M && n < N)`: fetch, wait, store per element, up to 16 elements x 3 operands in series behind the last MFMA of a
+// 13-22 us launch (tools/isa_chain.py).  Every fetch is unconditional from a clamped element; an epilogue that does not use an
+// operand reads the output matrix itself (valid memory, value dropped), so that there is no branch in between.  Split-K workgroups
+// that turn out not to be the last arriver fetched them for nothing (a few hundred bytes).  (Fetched BEFORE the MFMA loop they cost
+// 36 VGPRs across it: the 512-row launches lost a resident workgroup per CU and 5-15 % -- profiles/r05_ab_tgemm_fetch_order.txt.)
+// The activation mask (data gradients) and the noise factors (NoisyNet weight gradients) never meet in one problem: they share the
+// slots x[] (36 -> 18 registers for a 64 x 64 tile; with both, the LDS-DMA kernel crossed 128 VGPRs = one resident workgroup less per CU).
+//   mask:  x[(i TN + j) 4 + q]                                      noise:  x[i 4 + q] = e_out of row m,  x[TM 4 + s TN + j] = e_in of column n, set s
+template <int TM, int TN>
+struct EpiPre {
+  static constexpr int NX = (TM * TN * 4 > TM * 4 + 2 * TN) ? TM * TN * 4 : TM * 4 + 2 * TN;
+  float bias[TN], x[NX];
+};
+template <int TM, int TN>
+__device__ __forceinline__ EpiPre<TM, TN> tgemm_epi_prefetch(const TGemm& g, const TileCtx& c) {
+  EpiPre<TM, TN> e;
+  constexpr int NX = EpiPre<TM, TN>::NX;
+  const bool has_bias = g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU, has_mask = g.epi == TEPI_MASK, has_c2 = g.C2 != nullptr;
+  const float* bias_p = has_bias ? g.bias : g.C;
+  const float* aux_p = has_mask ? g.aux : g.C;
+  const int lda = has_mask ? g.ldaux : g.ldc;
+  const float* n1 = has_c2 ? g.nz_n : g.C;
+  const float* n2 = (has_c2 && g.nz_n2) ? g.nz_n2 : n1;
+  const float* m1 = has_c2 ? g.nz_m : g.C;
+  const float* m2 = (has_c2 && g.nz_m2) ? g.nz_m2 : m1;
+  int nc[TN], mc[TM][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = c.n0 + c.wn * 16 * TN + 16 * j + c.r;
+    nc[j] = n < g.N ? n : g.N - 1;
+    e.bias[j] = bias_p[nc[j]];
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = c.m0 + c.wm * 16 * TM + 16 * i + 4 * c.kq + q;
+      mc[i][q] = m < g.M ? m : g.M - 1;
+    }
+#pragma unroll
+  for (int s = 0; s < NX; ++s) {
+    // the slot's address under either meaning (static indices after unrolling; a slot without a meaning re-reads slot 0's element)
+    const int sa = s < TM * TN * 4 ? s : 0;
+    const float* pa = aux_p + (size_t)mc[sa / (4 * TN)][sa % 4] * lda + nc[(sa / 4) % TN];
+    const float* pn;
+    if (s < TM * 4) pn = (mc[s / 4][s % 4] >= g.nz_split ? m2 : m1) + mc[s / 4][s % 4];
+    else if (s < TM * 4 + TN) pn = n1 + nc[s - TM * 4];
+    else if (s < TM * 4 + 2 * TN) pn = n2 + nc[s - TM * 4 - TN];
+    else pn = m1 + mc[0][0];
+    e.x[s] = *(has_c2 ? pn : pa);
+  }
+  return e;
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f32x4 (&acc)[TM][TN], float (&rs)[TM], bool want_rs, int* s_last_p) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
+  const EpiPre<TM, TN> ep = tgemm_epi_prefetch<TM, TN>(g, c);
+  asm volatile("" ::: "memory");  // issued here, not sunk to the stores
   const int z = c.z, tiles = c.tiles, tile = c.tile, m0 = c.m0, n0 = c.n0, t = c.t, lane = c.lane, wid = c.wid, r = c.r, kq = c.kq, wm = c.wm, wn = c.wn;
   int& s_last = *s_last_p;
-  auto epilogue = [&](float v, int m, int n) -> float {
-    if (g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU) v += g.bias[n];
+  auto epilogue = [&](float v, float bias, float aux) -> float {
+    if (g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU) v += bias;
     if (g.epi == TEPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-    if (g.epi == TEPI_MASK) v = g.aux[(size_t)m * g.ldaux + n] > 0.f ? v : 0.f;
+    if (g.epi == TEPI_MASK) v = aux > 0.f ? v : 0.f;
     return v;
   };
 
@@ -148,11 +208,11 @@ __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f
       for (int q = 0; q < 4; ++q) {  // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
         const int m = m0 + wm * 16 * TM + 16 * i + 4 * kq + q;
         if (m < g.M && n < g.N) {
-          const float v = epilogue(acc[i][j][q], m, n);
+          const float v = epilogue(acc[i][j][q], ep.bias[j], ep.x[(i * TN + j) * 4 + q]);
           g.C[(size_t)m * g.ldc + n] = v;
           if (g.C2) {  // d(sig) = d(mu) * eps, eps = f(e_in[n]) * f(e_out[m]) (jh_rb_noisy_grad_kernel's expression)
             const bool second = m >= g.nz_split;
-            g.C2[(size_t)m * g.ldc + n] = v * (jh_noise_f((second ? g.nz_n2 : g.nz_n)[n]) * jh_noise_f((second ? g.nz_m2 : g.nz_m)[m]));
+            g.C2[(size_t)m * g.ldc + n] = v * (jh_noise_f(second ? ep.x[TM * 4 + TN + j] : ep.x[TM * 4 + j]) * jh_noise_f(ep.x[i * 4 + q]));
           }
         }
       }
@@ -193,7 +253,7 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
     if (i < batch.n && (int)blockIdx.x >= batch.p[i].wg_begin) pi = i;
-  const TGemm& g = batch.p[pi];
+  const TGemm g = batch.p[pi];  // a COPY: the whole descriptor in one batch of scalar loads (through a reference, every field was its own dependent s_load + wait)
   const int tiles = g.tiles_m * g.tiles_n;
   const int local = blockIdx.x - g.wg_begin;
   const int z = local / tiles, tile = local - z * tiles;
@@ -214,30 +274,49 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   int a_x[TM], a_k[TM], a_off[TM], b_x[TN], b_k[TN], b_off[TN];
   // im2col operands: the offset term that follows k (taps for k-fast, pixels for x-fast) is staged in LDS for
   // this split's whole k range; the term that follows x is fixed per slot and sits in a register.
-  if (a_conv) {
-    const int* ktab = a_kfast ? g.a.tap_tab : g.a.pix_tab;
-    for (int i = t; i < kend - kbeg; i += 256) sTabA[i] = ktab[kbeg + i];
+  // (round 5: one batch of kTabMax / 256 fetches from clamped addresses, unconditional stores -- see jh_tgemm_dma_kernel)
+  if (a_conv || b_conv) {  // an operand without a table stages the other one's (never read)
+    const int* ta = a_conv ? (a_kfast ? g.a.tap_tab : g.a.pix_tab) : (b_kfast ? g.b.tap_tab : g.b.pix_tab);
+    const int* tb = b_conv ? (b_kfast ? g.b.tap_tab : g.b.pix_tab) : ta;
+    const int tn = kend - kbeg;
+    int tva[kTabMax / 256], tvb[kTabMax / 256];
+#pragma unroll
+    for (int u = 0; u < kTabMax / 256; ++u) {
+      const int i = kbeg + (t + 256 * u < tn ? t + 256 * u : 0);
+      tva[u] = ta[i];
+      tvb[u] = tb[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kTabMax / 256; ++u) {
+      sTabA[t + 256 * u] = tva[u];
+      sTabB[t + 256 * u] = tvb[u];
+    }
   }
-  if (b_conv) {
-    const int* ktab = b_kfast ? g.b.tap_tab : g.b.pix_tab;
-    for (int i = t; i < kend - kbeg; i += 256) sTabB[i] = ktab[kbeg + i];
-  }
+  // the im2col lookups are issued unconditionally, all of them before the first use (a dense operand reads element 0 of its own
+  // matrix and drops it): inside `conv ? tab[xc] : ...` each was a fetch + wait in a basic block of its own (round 5)
+  int a_xc[TM], b_xc[TN], a_look[TM], b_look[TN];
+  const int* a_xt = a_conv ? (a_kfast ? g.a.pix_tab : g.a.tap_tab) : (const int*)g.a.p;
+  const int* b_xt = b_conv ? (b_kfast ? g.b.pix_tab : g.b.tap_tab) : (const int*)g.b.p;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int e = t + 256 * i;
     a_x[i] = a_kfast ? m0 + (e >> 3) : m0 + 4 * (e % (BM / 4));
     a_k[i] = a_kfast ? 4 * (e & 7) : e / (BM / 4);
-    const int xc = a_kfast ? (a_x[i] < g.M ? a_x[i] : g.M - 1) : (a_x[i] + 3 < g.M ? a_x[i] : (g.M >= 4 ? g.M - 4 : 0));
-    a_off[i] = a_conv ? (a_kfast ? g.a.pix_tab : g.a.tap_tab)[xc] : (a_kfast ? xc * g.a.ld : xc);
+    a_xc[i] = a_kfast ? (a_x[i] < g.M ? a_x[i] : g.M - 1) : (a_x[i] + 3 < g.M ? a_x[i] : (g.M >= 4 ? g.M - 4 : 0));
+    a_look[i] = a_xt[a_conv ? a_xc[i] : 0];
   }
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int e = t + 256 * i;
     b_x[i] = b_kfast ? n0 + (e >> 3) : n0 + 4 * (e % (BN / 4));
     b_k[i] = b_kfast ? 4 * (e & 7) : e / (BN / 4);
-    const int xc = b_kfast ? (b_x[i] < g.N ? b_x[i] : g.N - 1) : (b_x[i] + 3 < g.N ? b_x[i] : (g.N >= 4 ? g.N - 4 : 0));
-    b_off[i] = b_conv ? (b_kfast ? g.b.pix_tab : g.b.tap_tab)[xc] : (b_kfast ? xc * g.b.ld : xc);
+    b_xc[i] = b_kfast ? (b_x[i] < g.N ? b_x[i] : g.N - 1) : (b_x[i] + 3 < g.N ? b_x[i] : (g.N >= 4 ? g.N - 4 : 0));
+    b_look[i] = b_xt[b_conv ? b_xc[i] : 0];
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_off[i] = a_conv ? a_look[i] : (a_kfast ? a_xc[i] * g.a.ld : a_xc[i]);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) b_off[i] = b_conv ? b_look[i] : (b_kfast ? b_xc[i] * g.b.ld : b_xc[i]);
   if (a_conv || b_conv) __syncthreads();
 
   // one piece: (operand, fast?, conv?, kfast?, x, in-tile k, slot offset, LDS table, extent X) at chunk k0
@@ -268,6 +347,39 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
     for (int i = 0; i < TM; ++i) fetch(g.a, a_fast, a_conv, a_kfast, a_x[i], a_k[i], a_off[i], sTabA, g.M, k0, ra[i]);
 #pragma unroll
     for (int i = 0; i < TN; ++i) fetch(g.b, b_fast, b_conv, b_kfast, b_x[i], b_k[i], b_off[i], sTabB, g.N, k0, rb[i]);
+  };
+  // Round 5, the streamlined fetch for launches whose operands are both fp32 in 16-byte pieces (dense either way, NHWC im2col): the
+  // addresses are SELECTED (no branch per mode), the TM + TN loads of a chunk are issued back to back, and the in-range selects are
+  // applied when the registers go to LDS one iteration later.  Through fetch() every piece was a basic block of its own that ended
+  // in the select on the loaded value: fetch A, wait, fetch B, wait -- in front of the chunk's MFMAs, so two dependent L2 round trips
+  // per chunk and nothing in flight under the matrix cores (tools/isa_chain.py).
+  const bool all_fast = a_fast && b_fast && g.a.mode <= OP_NHWC_X && g.b.mode <= OP_NHWC_X;
+  bool oka[TM], okb[TN];
+  auto gload_fast = [&](int k0) {
+    auto piece = [&](const Opnd& o, bool conv, bool kfast, int x, int kin, int off, const int* tab, int X, float (&v)[4], bool& ok) {
+      const int k = k0 + kin;
+      const int last = kfast ? kend - 4 : kend - 1;  // clamped: the load itself is always in bounds
+      const int kc = k < last ? k : last;
+      ok = (kfast ? x < X : x + 3 < X) && k < kend;
+      const int tv = tab[conv ? kc - kbeg : 0];
+      const size_t e = conv ? (size_t)((ptrdiff_t)off + tv) : (kfast ? (size_t)off + kc : (size_t)kc * o.ld + off);
+      const float4 q = *reinterpret_cast<const float4*>((const float*)o.p + e);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) piece(g.a, a_conv, a_kfast, a_x[i], a_k[i], a_off[i], sTabA, g.M, ra[i], oka[i]);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) piece(g.b, b_conv, b_kfast, b_x[i], b_k[i], b_off[i], sTabB, g.N, rb[i], okb[i]);
+  };
+  auto mask_fast = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[i][j] = oka[i] ? ra[i][j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rb[i][j] = okb[i] ? rb[i][j] : 0.f;
   };
   auto sstore = [&]() {
 #pragma unroll
@@ -302,13 +414,17 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   for (int i = 0; i < TM; ++i) rs[i] = 0.f;
   const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
 
+  const TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
   // tile i: registers -> LDS, refill the registers with tile i + 1 (its HBM loads fly under the MFMAs of tile i)
-  if (kbeg < kend) gload(kbeg);
+  auto mainloop = [&](auto fast_tag) {
+  constexpr bool FAST = decltype(fast_tag)::value;
+  if (kbeg < kend) { if constexpr (FAST) gload_fast(kbeg); else gload(kbeg); }
 #pragma unroll 1
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if constexpr (FAST) mask_fast();
     sstore();
     __syncthreads();
-    if (k0 + BK < kend) gload(k0 + BK);
+    if (k0 + BK < kend) { if constexpr (FAST) gload_fast(k0 + BK); else gload(k0 + BK); }
 #pragma unroll
     for (int kb = 0; kb < BK; kb += 16) {
       float a[TM][4], b[TN][4];
@@ -333,6 +449,8 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
     }
     __syncthreads();
   }
+  };
+  if (all_fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
   if (want_rs && wn == 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -341,7 +459,6 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
     }
   }
 
-  TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
   tgemm_finish<TM, TN>(g, tc, acc, rs, want_rs, &s_last);
 }
 
@@ -386,25 +503,45 @@ struct DmaOp {
   size_t step;          // dense: floats from one chunk to the next
   const int* tab;       // im2col: the LDS table (taps for k-contiguous, pixels for x-contiguous), else nullptr
 };
-__device__ __forceinline__ DmaOp tgemm_dma_operand(const Opnd& o, int X, int x0, int kbeg, const int* tab, int wid, int lane) {
+// Two phases so that the im2col offset lookups of BOTH operands (and the table staging) are in flight together: phase 1 computes the
+// pieces' coordinates and ISSUES the lookups -- unconditionally: a dense operand reads element 0 of its own matrix and drops it; a
+// lookup inside `conv ? tab[xc] : ...` is a fetch + wait in its own basic block, four of them in series per launch (round 5) --,
+// phase 2 builds the addresses.
+struct DmaLook {
+  int xc[2], kin[2], look[2];
+};
+__device__ __forceinline__ DmaLook tgemm_dma_look(const Opnd& o, int X, int x0, int wid, int lane) {
+  DmaLook l;
+  const bool xfast = o.mode & 1, conv = o.mode >= OP_NHWC_K;
+  const int* xt = conv ? (xfast ? o.tap_tab : o.pix_tab) : (const int*)o.p;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = (i * 4 + wid) * 64 + lane;
+    if (!xfast) {
+      const int row = p >> 3, kb = 4 * ((p & 7) ^ ((row >> 1) & 7));
+      const int x = x0 + row;
+      l.xc[i] = x < X ? x : X - 1;  // rows beyond the matrix fetch a valid row: their results are never stored
+      l.kin[i] = kb;
+    } else {
+      const int kk = p >> 4, xb = (p & 15) ^ (((kk >> 2) & 3) << 2);
+      const int x = x0 + 4 * xb;
+      l.xc[i] = x + 3 < X ? x : X - 4;  // X % 4 == 0: a piece is wholly inside or wholly outside
+      l.kin[i] = kk;
+    }
+    l.look[i] = xt[conv ? l.xc[i] : 0];
+  }
+  return l;
+}
+__device__ __forceinline__ DmaOp tgemm_dma_operand(const Opnd& o, const DmaLook& l, int kbeg, const int* tab) {
   DmaOp d;
   const bool xfast = o.mode & 1, conv = o.mode >= OP_NHWC_K;
   d.tab = conv ? tab : nullptr;
   d.step = xfast ? (size_t)32 * o.ld : 32;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int p = (i * 4 + wid) * 64 + lane;
-    if (!xfast) {
-      const int row = p >> 3, kb = 4 * ((p & 7) ^ ((row >> 1) & 7));
-      const int x = x0 + row, xc = x < X ? x : X - 1;  // rows beyond the matrix fetch a valid row: their results are never stored
-      d.kin[i] = kb;
-      d.src[i] = (const float*)o.p + (conv ? (size_t)o.pix_tab[xc] : (size_t)xc * o.ld + kbeg + kb);
-    } else {
-      const int kk = p >> 4, xb = (p & 15) ^ (((kk >> 2) & 3) << 2);
-      const int x = x0 + 4 * xb, xc = x + 3 < X ? x : X - 4;  // X % 4 == 0: a piece is wholly inside or wholly outside
-      d.kin[i] = kk;
-      d.src[i] = (const float*)o.p + (conv ? (size_t)o.tap_tab[xc] : (size_t)(kbeg + kk) * o.ld + xc);
-    }
+    d.kin[i] = l.kin[i];
+    if (!xfast) d.src[i] = (const float*)o.p + (conv ? (size_t)l.look[i] : (size_t)l.xc[i] * o.ld + kbeg + l.kin[i]);
+    else d.src[i] = (const float*)o.p + (conv ? (size_t)l.look[i] : (size_t)(kbeg + l.kin[i]) * o.ld + l.xc[i]);
   }
   return d;
 }
@@ -503,7 +640,7 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
     if (i < batch.n && (int)blockIdx.x >= batch.p[i].wg_begin) pi = i;
-  const TGemm& g = batch.p[pi];
+  const TGemm g = batch.p[pi];  // a COPY: the whole descriptor in one batch of scalar loads (through a reference, every field was its own dependent s_load + wait)
   const int tiles = g.tiles_m * g.tiles_n;
   const int local = blockIdx.x - g.wg_begin;
   const int z = local / tiles, tile = local - z * tiles;
@@ -518,16 +655,22 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
   const bool a_conv = g.a.mode >= OP_NHWC_K, b_conv = g.b.mode >= OP_NHWC_K;
   // im2col operands: the offset term that follows k (taps for k-contiguous, pixels for x-contiguous) is staged in LDS for this
   // split's whole k range, as in the staged kernel
-  if (a_conv) {
-    const int* ktab = a_x ? g.a.pix_tab : g.a.tap_tab;
-    for (int i = t; i < kend - kbeg; i += 256) sTab[i] = ktab[kbeg + i];
+  // (round 5: all kTabMax / 256 passes fetched as ONE batch from clamped addresses and stored unconditionally -- entries past the
+  // split's range are never read.  The plain loop compiled to fetch, wait, store per pass: up to four dependent round trips in front
+  // of the first operand fetch of a launch that lasts 13-22 us.)
+  const DmaLook la = tgemm_dma_look(g.a, g.M, m0, wid, lane);
+  const DmaLook lb = tgemm_dma_look(g.b, g.N, n0, wid, lane);
+  if (a_conv || b_conv) {
+    const int* ktab = a_conv ? (a_x ? g.a.pix_tab : g.a.tap_tab) : (b_x ? g.b.pix_tab : g.b.tap_tab);
+    const int tn = kend - kbeg;
+    int tv[kTabMax / 256];
+#pragma unroll
+    for (int u = 0; u < kTabMax / 256; ++u) tv[u] = ktab[kbeg + (t + 256 * u < tn ? t + 256 * u : 0)];
+#pragma unroll
+    for (int u = 0; u < kTabMax / 256; ++u) sTab[t + 256 * u] = tv[u];
   }
-  if (b_conv) {
-    const int* ktab = b_x ? g.b.pix_tab : g.b.tap_tab;
-    for (int i = t; i < kend - kbeg; i += 256) sTab[i] = ktab[kbeg + i];
-  }
-  const DmaOp da = tgemm_dma_operand(g.a, g.M, m0, kbeg, sTab, wid, lane);
-  const DmaOp db = tgemm_dma_operand(g.b, g.N, n0, kbeg, sTab, wid, lane);
+  const DmaOp da = tgemm_dma_operand(g.a, la, kbeg, sTab);
+  const DmaOp db = tgemm_dma_operand(g.b, lb, kbeg, sTab);
   if (a_conv || b_conv) __syncthreads();
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -537,6 +680,7 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
   float rs[TM] = {0.f, 0.f};
   const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
   const int nc = (kend - kbeg) / BK;
+  const TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
 #define JH_DMA_LOOP(AX, BX, RS) tgemm_dma_mainloop<AX, BX, RS>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs)
   if (want_rs && wn == 0) {  // wave-uniform
     if (a_x) { if (b_x) JH_DMA_LOOP(true, true, true); else JH_DMA_LOOP(true, false, true); }
@@ -553,7 +697,6 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
       rs[i] += __shfl_xor(rs[i], 32, 64);
     }
   }
-  TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
   tgemm_finish<TM, TN>(g, tc, acc, rs, want_rs, &s_last);
 }
 
