@@ -959,7 +959,7 @@ static int rb_heads(jh_rbnet* n, const HeadJob* jobs, int nj, int B, hipStream_t
       ns.params[j] = jobs[j].P; ns.noise[j] = jobs[j].noise; ns.weff[j] = n->weff + (size_t)j * d.set_stride;
     }
     int64_t blocks = (n->n_noisy + 255) / 256;
-    if (blocks > 4096) blocks = 4096;  // one element per thread at the configs' widths (a thread's pass is three dependent fetches: 1024 blocks walked 2.5 passes)
+    if (blocks > 1024) blocks = 1024;  // (4096 blocks -- one element per thread -- measured 2.6 us SLOWER at Rainbow's 655 k noisy weights x 3 sets, round 5)
     JH_LAUNCH(jh_rb_noise_kernel, dim3((unsigned)blocks, nj), dim3(256), 0, st, d, ns, n->n_noisy);
     JH_LAUNCH_CHECK();
   }
@@ -1030,7 +1030,7 @@ JH_EXPORT int jh_rbnet_prepare_noise(jh_rbnet* n, const float* d_noise, jh_strea
   const float* P[3] = {n->params, n->params, n->target};
   for (int j = 0; j < 3; ++j) { ns.params[j] = P[j]; ns.noise[j] = d_noise + j * L; ns.weff[j] = n->weff + (size_t)j * d.set_stride; }
   int64_t blocks = (n->n_noisy + 255) / 256;
-  if (blocks > 4096) blocks = 4096;  // one element per thread at the configs' widths (a thread's pass is three dependent fetches: 1024 blocks walked 2.5 passes)
+  if (blocks > 1024) blocks = 1024;  // (4096 blocks -- one element per thread -- measured 2.6 us SLOWER at Rainbow's 655 k noisy weights x 3 sets, round 5)
   JH_LAUNCH(jh_rb_noise_kernel, dim3((unsigned)blocks, 3), dim3(256), 0, jh_s(stream), d, ns, n->n_noisy);
   JH_LAUNCH_CHECK();
   n->prepared_noise = d_noise;
@@ -1128,7 +1128,7 @@ JH_EXPORT int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dty
 
 static int rb_noisy_grad(jh_rbnet* n, hipStream_t st) {
   int64_t blocks = (n->n_noisy + 255) / 256;
-  if (blocks > 4096) blocks = 4096;  // one element per thread at the configs' widths (a thread's pass is three dependent fetches: 1024 blocks walked 2.5 passes)
+  if (blocks > 1024) blocks = 1024;  // (4096 blocks -- one element per thread -- measured 2.6 us SLOWER at Rainbow's 655 k noisy weights x 3 sets, round 5)
   JH_LAUNCH(jh_rb_noisy_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n->nd, n->last_noise, n->grads, n->n_noisy);
   JH_LAUNCH_CHECK();
   return JH_OK;

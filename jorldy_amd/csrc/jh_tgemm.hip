@@ -94,11 +94,18 @@ __device__ __forceinline__ EpiPre<TM, TN> tgemm_epi_prefetch(const TGemm& g, con
   return e;
 }
 
-template <int TM, int TN>
+// EPI = false: the kernel variant for groups of plain products (data gradients into the im2col buffer: K = 64, thousands of
+// workgroups; the convolutions' weight gradients), chosen by the host per launch: no fetches and none of their address arithmetic.
+// Unconditional, they cost conv2 / conv3's backward groups 7-9 % at B = 512; behind a run-time branch, the values join the common
+// tail through copies = a wait for the fetches in front of the split-K hand-off (profiles/r05_ab_tgemm_fetch_order.txt).
+template <int TM, int TN, bool EPI>
 __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f32x4 (&acc)[TM][TN], float (&rs)[TM], bool want_rs, int* s_last_p) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
-  const EpiPre<TM, TN> ep = tgemm_epi_prefetch<TM, TN>(g, c);
-  asm volatile("" ::: "memory");  // issued here, not sunk to the stores
+  EpiPre<TM, TN> ep;  // (!EPI: never read -- the host launches that variant only for groups without epilogue operands)
+  if constexpr (EPI) {
+    ep = tgemm_epi_prefetch<TM, TN>(g, c);
+    asm volatile("" ::: "memory");  // issued here, not sunk to the stores
+  }
   const int z = c.z, tiles = c.tiles, tile = c.tile, m0 = c.m0, n0 = c.n0, t = c.t, lane = c.lane, wid = c.wid, r = c.r, kq = c.kq, wm = c.wm, wn = c.wn;
   int& s_last = *s_last_p;
   auto epilogue = [&](float v, float bias, float aux) -> float {
@@ -242,7 +249,7 @@ constexpr int kTabMax = 1024;  // k-range of one split that an im2col operand ca
 // TAG: one kernel SYMBOL per call site (conv1_fwd, stream2_bwd, ...), so that rocprofv3's kernel trace and PMC passes
 // attribute time and traffic per layer instead of to three shared `jh_tgemm_kernel<TM,TN>` symbols; the
 // body does not depend on it.
-template <int TM, int TN, int TAG>
+template <int TM, int TN, int TAG, bool EPI = true>
 __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = 36;
   __shared__ __attribute__((aligned(16))) float sA[BM * LD];
@@ -459,7 +466,7 @@ __global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
     }
   }
 
-  tgemm_finish<TM, TN>(g, tc, acc, rs, want_rs, &s_last);
+  tgemm_finish<TM, TN, EPI>(g, tc, acc, rs, want_rs, &s_last);
 }
 
 // ---- the same 64 x 64 tile with its operands DMA-ed straight from global memory into LDS (global_load_lds_dwordx4: 16 bytes per lane,
@@ -554,7 +561,8 @@ __device__ __forceinline__ void tgemm_dma_issue(const DmaOp& d, int c, unsigned 
 
 // RS: this wave accumulates the row sums of A (bias gradients).  A template parameter, not a run-time flag: as a flag hipcc computes
 // the sums in every wave and selects (36 VALU instructions per chunk next to 32 MFMAs: the forward launches lost 8 % to it).
-template <bool AX, bool BX, bool RS>
+// NB: LDS buffers per operand = chunks in flight + 1 (NB; 4 for the 2048-row PPO launches, which have the CU to themselves)
+template <bool AX, bool BX, bool RS, int NB>
 __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float* sB, const DmaOp& da, const DmaOp& db, int nc, int wid, int r, int kq, int wm,
                                                    int wn, f32x4 (&acc)[2][2], float (&rs)[2]) {
   constexpr int TM = 2, TN = 2, BK = 32, TILE = 64 * BK;
@@ -573,22 +581,22 @@ __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float*
   }
   // (the compiler's own loads so far -- tables, operand descriptors -- must not be counted by the vmcnt arithmetic below)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int c = 0; c < kDmaBufs - 1 && c < nc; ++c) {
+  for (int c = 0; c < NB - 1 && c < nc; ++c) {
     tgemm_dma_issue(da, c, ldsA + (unsigned)c * (TILE * 4));
     tgemm_dma_issue(db, c, ldsB + (unsigned)c * (TILE * 4));
   }
-  int buf = 0, nbuf = kDmaBufs - 1;  // buffer of chunk c, buffer of chunk c + kDmaBufs - 1 (the one chunk c - 1 just left)
+  int buf = 0, nbuf = NB - 1;  // buffer of chunk c, buffer of chunk c + NB - 1 (the one chunk c - 1 just left)
 #pragma unroll 1
   for (int c = 0; c < nc; ++c) {
     // this wave's pieces of chunk c have landed once at most the chunks issued after it (4 loads each) are outstanding
-    const int after = nc - 1 - c < kDmaBufs - 2 ? nc - 1 - c : kDmaBufs - 2;
-    if (kDmaBufs >= 4 && after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kDmaBufs >= 3 && after >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int after = nc - 1 - c < NB - 2 ? nc - 1 - c : NB - 2;
+    if (NB >= 4 && after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (NB >= 3 && after >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // ... and everybody else's; every wave is done with chunk c - 1, so its buffer may be refilled
-    if (c + kDmaBufs - 1 < nc) {
-      tgemm_dma_issue(da, c + kDmaBufs - 1, ldsA + (unsigned)nbuf * (TILE * 4));
-      tgemm_dma_issue(db, c + kDmaBufs - 1, ldsB + (unsigned)nbuf * (TILE * 4));
+    if (c + NB - 1 < nc) {
+      tgemm_dma_issue(da, c + NB - 1, ldsA + (unsigned)nbuf * (TILE * 4));
+      tgemm_dma_issue(db, c + NB - 1, ldsB + (unsigned)nbuf * (TILE * 4));
     }
     const float* A = sA + buf * TILE;
     const float* B = sB + buf * TILE;
@@ -624,16 +632,16 @@ __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float*
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][cc], b[j][cc], acc[i][j], 0, 0, 0);
     }
-    buf = buf + 1 == kDmaBufs ? 0 : buf + 1;
-    nbuf = nbuf + 1 == kDmaBufs ? 0 : nbuf + 1;
+    buf = buf + 1 == NB ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NB ? 0 : nbuf + 1;
   }
 }
 
-template <int TAG>
+template <int TAG, bool EPI = true, int NB = kDmaBufs>
 __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) {
   constexpr int TM = 2, TN = 2, BM = 64, BN = 64, BK = 32;
-  __shared__ __attribute__((aligned(16))) float sA[kDmaBufs * BM * BK];
-  __shared__ __attribute__((aligned(16))) float sB[kDmaBufs * BN * BK];
+  __shared__ __attribute__((aligned(16))) float sA[NB * BM * BK];
+  __shared__ __attribute__((aligned(16))) float sB[NB * BN * BK];
   __shared__ int sTab[kTabMax];  // at most one operand of a problem is an im2col view; 48 + 4 KB lets three workgroups share a CU
   __shared__ int s_last;
   int pi = 0;
@@ -681,7 +689,7 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
   const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
   const int nc = (kend - kbeg) / BK;
   const TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
-#define JH_DMA_LOOP(AX, BX, RS) tgemm_dma_mainloop<AX, BX, RS>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs)
+#define JH_DMA_LOOP(AX, BX, RS) tgemm_dma_mainloop<AX, BX, RS, NB>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs)
   if (want_rs && wn == 0) {  // wave-uniform
     if (a_x) { if (b_x) JH_DMA_LOOP(true, true, true); else JH_DMA_LOOP(true, false, true); }
     else { if (b_x) JH_DMA_LOOP(false, true, true); else JH_DMA_LOOP(false, false, true); }
@@ -697,7 +705,7 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
       rs[i] += __shfl_xor(rs[i], 32, 64);
     }
   }
-  tgemm_finish<TM, TN>(g, tc, acc, rs, want_rs, &s_last);
+  tgemm_finish<TM, TN, EPI>(g, tc, acc, rs, want_rs, &s_last);
 }
 
 }  // namespace
@@ -832,6 +840,34 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
                        // rewritten, arrival counters return to zero)
   for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * (double)probs[i].K;
   const int tag = tgemm_tag_of(name);
+  // groups without epilogue operands at the call sites that have such groups: the variant without the operand fetches (tgemm_finish)
+  bool plain = true;
+  for (int i = 0; i < n; ++i) plain = plain && probs[i].epi == TEPI_NONE && probs[i].C2 == nullptr;
+#define JH_TGEMM_PLAIN_TAGS(X) X(dense, 0) X(conv3_bwd, 12) X(conv2_bwd, 13) X(conv1_bwd, 14) X(ppo_bwd_dW1, 17)
+  if (plain && use_dma) {
+#define JH_TGEMM_DMA_PLAIN(NAME, ID) \
+  case ID: JH_LAUNCH_IDEM(name, flops, (jh_tgemm_dma_kernel<ID, false>), grid, dim3(256), 0, st, batch); JH_LAUNCH_CHECK(); return JH_OK;
+    switch (tag) {
+      JH_TGEMM_PLAIN_TAGS(JH_TGEMM_DMA_PLAIN)
+      default: break;
+    }
+#undef JH_TGEMM_DMA_PLAIN
+  } else if (plain) {
+#define JH_TGEMM_PLAIN(NAME, ID)                                                                                                 \
+  case ID:                                                                                                                      \
+    if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2, ID, false>), grid, dim3(256), 0, st, batch);      \
+    else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2, ID, false>), grid, dim3(256), 0, st, batch); \
+    else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1, ID, false>), grid, dim3(256), 0, st, batch); \
+    else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1, ID, false>), grid, dim3(256), 0, st, batch);                         \
+    JH_LAUNCH_CHECK();                                                                                                          \
+    return JH_OK;
+    switch (tag) {
+      JH_TGEMM_PLAIN_TAGS(JH_TGEMM_PLAIN)
+      default: break;
+    }
+#undef JH_TGEMM_PLAIN
+  }
+#undef JH_TGEMM_PLAIN_TAGS
   if (use_dma) {
 #define JH_TGEMM_DMA_CASE(NAME, ID) \
   case ID: JH_LAUNCH_IDEM(name, flops, (jh_tgemm_dma_kernel<ID>), grid, dim3(256), 0, st, batch); break;
