@@ -80,7 +80,9 @@ class DQN(NativeValueNetMixin, BaseAgent):
             batch_size = state[0].shape[0] if isinstance(state, list) else state.shape[0]
             action = np.random.randint(0, self.action_size, size=(batch_size, 1))
         else:
-            action = torch.argmax(self.network(self.as_tensor(state)), -1, keepdim=True).cpu().numpy()
+            action = self._act_greedy(state)
+            if action is None:
+                action = torch.argmax(self.network(self.as_tensor(state)), -1, keepdim=True).cpu().numpy()
         return {"action": action}
 
     # ------------------------------------------------------------------------------------------

@@ -119,6 +119,51 @@ class NativeValueNetMixin:
             return torch.as_tensor(x, device=self.device)
         return super().as_tensor(x)
 
+    @torch.no_grad()
+    def _act_greedy(self, state, is_train=False):
+        """The network branch of act() (dqn.py:100-115, rainbow.py:140-152) without torch in the loop: observations -> pinned slab -> one
+        async H2D -> forward of the live online network -> jh_value_act (Q from the outputs, first-maximum argmax) writing the actions
+        into device-mapped memory -> the host waits for their arrival (jh_host_wait_words).  The generic form -- as_tensor (a pageable,
+        synchronous copy), five torch kernels for logits2Q + argmax, `.cpu()` -- was most of a single-mode env step.
+        Rainbow in training mode draws its noise exactly as NativeNet.__call__ does (torch.randn on the device: the same stream of
+        draws).  -> int64 [N, 1]; None when this form does not apply (list-valued states, more rows than the network's batch)."""
+        net = getattr(self, "_net", None)
+        if net is None or isinstance(state, list):
+            return None
+        x = np.asarray(state)
+        N = int(x.shape[0])
+        if N < 1 or N > net.maxB:
+            return None
+        # [rows, actions, atoms] as the agent reads the outputs (C51 keeps its A x K outputs in a plain q-network: c51.py:27-31)
+        A, K = int(self.action_size), int(getattr(self, "num_support", 1))
+        if A * K != net.A * net.K:
+            return None
+        u8 = bool(net.cnn and x.dtype == np.uint8)
+        key = (N, tuple(x.shape[1:]), u8)
+        a = self.__dict__.get("_actbuf")
+        if a is None or a["key"] != key:
+            dt = torch.uint8 if u8 else torch.float32
+            am, qm = ops.PinnedBuffer((N,), np.int64, self.device.index), ops.PinnedBuffer((N,), np.float32, self.device.index)
+            a = dict(key=key, x_pin=torch.empty((N,) + tuple(x.shape[1:]), dtype=dt, pin_memory=True), x_dev=torch.empty((N,) + tuple(x.shape[1:]), dtype=dt, device=self.device),
+                     logits=torch.empty(N, net.A, net.K, dtype=torch.float32, device=self.device), am=am, qm=qm,  # (viewed [N, A, K] for the act kernel)
+                     act_dev=ops._wrap_device(am.dev_ptr.value, (N,), torch.int64, self.device, owner=am),
+                     q_dev=ops._wrap_device(qm.dev_ptr.value, (N,), torch.float32, self.device, owner=qm), words=am.np.view(np.uint32),
+                     marks=np.arange(0, 2 * N, 2, dtype=np.int32))  # low words of the int64 actions
+            self._actbuf = a
+        np.copyto(a["x_pin"].numpy(), x, casting="same_kind")
+        a["x_dev"].copy_(a["x_pin"], non_blocking=True)
+        nz = torch.randn(net.noise_len, device=net.device) if (net.kind == "rainbow" and is_train) else None
+        net.forward(a["x_dev"], 0, nz, out=a["logits"])
+        a["am"].np[:] = -1  # arrival marks (actions are >= 0)
+        ops.value_act(a["logits"].view(N, A, K), float(getattr(self, "v_min", 0.0)), float(getattr(self, "v_max", 0.0)), out=(a["act_dev"], a["q_dev"]))
+        from ... import _lib as L
+
+        if L.load().jh_host_wait_words(L.ptr(a["words"]), L.ptr(a["marks"]), N, 0xFFFFFFFF, 5.0) != 0:
+            torch.cuda.current_stream(self.device).synchronize()
+            if (a["am"].np < 0).any():
+                raise RuntimeError("act(): the actions never arrived (failed launch?)")
+        return a["am"].np.reshape(N, 1).copy()
+
     def _set_native_hyper(self, d, steps):
         if self._opt_name == "adam":
             self._net.set_hyper(d["lr"], d["betas"][0], d["betas"][1], d["eps"], steps)

@@ -37,8 +37,10 @@ class C51(DQN):
             batch_size = state[0].shape[0] if isinstance(state, list) else state.shape[0]
             action = np.random.randint(0, self.action_size, size=(batch_size, 1))
         else:
-            _, q_action = self.logits2Q(self.network(self.as_tensor(state)))
-            action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
+            action = self._act_greedy(state)
+            if action is None:
+                _, q_action = self.logits2Q(self.network(self.as_tensor(state)))
+                action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
         return {"action": action}
 
     def _learn_body(self, st):
@@ -127,8 +129,10 @@ class Rainbow(DQN):
             batch_size = state[0].shape[0] if isinstance(state, list) else state.shape[0]
             action = np.random.randint(0, self.action_size, size=(batch_size, 1))
         else:
-            _, q_action = self.logits2Q(self.network(self.as_tensor(state), training))
-            action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
+            action = self._act_greedy(state, training)
+            if action is None:
+                _, q_action = self.logits2Q(self.network(self.as_tensor(state), training))
+                action = torch.argmax(q_action, -1, keepdim=True).cpu().numpy()
         return {"action": action}
 
     def _draw(self, st):

@@ -876,7 +876,10 @@ static int rb_trunk(jh_rbnet* n, const TrunkJob* jobs, int nj, int x_u8, hipStre
       for (int j = 0; j < nj; ++j) imgs += jobs[j].rows;
       a.nj = nj; a.H = c1.H; a.W = c1.W; a.OW = c1.OW; a.P = n->P1; a.inv_ow = 1.0f / (float)c1.OW;
       a.tiles_per_img = (n->P1 + 15) / 16;
-      a.wgs_per_img = imgs >= 512 ? 1 : (imgs >= 192 ? 2 : (imgs >= 64 ? 3 : 6));  // >= 256 workgroups once there are 43 frames
+      // >= 256 workgroups once there are 43 frames.  64-191 frames (learn() at B = 32: 96 frames x 25 tiles): ONE tile per wave.  With three
+      // workgroups per frame (288 on 256 CUs, waves of 3 | 2 | 2 | 2 tiles) the 32 CUs that got two workgroups ran six tiles on one SIMD
+      // while the chip-wide average is 2.3: the launch lasted as long as those (round 5: a tile is 128 MFMAs = 1.7 us of one SIMD)
+      a.wgs_per_img = imgs >= 512 ? 1 : (imgs >= 192 ? 2 : (imgs >= 64 ? (a.tiles_per_img + 3) / 4 : 6));
       a.tiles_per_wg = (a.tiles_per_img + a.wgs_per_img - 1) / a.wgs_per_img;
       a.wgs_per_img = (a.tiles_per_img + a.tiles_per_wg - 1) / a.tiles_per_wg;
       int wgs = 0;

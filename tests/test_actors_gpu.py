@@ -50,6 +50,56 @@ def test_value_act_matches_the_cpu_restatement(N, A, K):
 
 
 @pytest.mark.parametrize("name,extra,S", [
+    ("rainbow", dict(head="cnn", n_step=3, num_support=21, v_min=-1, v_max=10), (4, 44, 52)),
+    ("c51", dict(head="mlp", num_support=21, v_min=-1, v_max=10), 6),
+    ("dqn", dict(), 6),
+    ("double", dict(head="cnn"), (4, 44, 52)),
+])
+def test_native_act_branch_equals_the_generic_one(name, extra, S):
+    """act()'s network branch through pinned slab -> forward -> jh_value_act -> device-mapped actions (NativeValueNetMixin._act_greedy)
+    against the reference's expression evaluated with torch ops on the same forward (dqn.py:100-115, c51.py:50-66, rainbow.py:140-152):
+    the same actions, row by row and for whole batches; Rainbow in training mode consumes the same torch.randn draws in the same order."""
+    from jorldy_amd.core.agent import Agent
+
+    torch.manual_seed(3)
+    np.random.seed(3)
+    A = 5
+    agent = Agent(name, state_size=S, action_size=A, hidden_size=32, batch_size=8, buffer_size=64, start_train_step=0, device="cuda", **extra)
+    with torch.no_grad():
+        agent._net.params.add_(0.05 * torch.randn_like(agent._net.params))
+    agent.epsilon = agent.epsilon_eval = 0.0
+    if name == "rainbow":
+        agent.memory.buffer_counter = 10 ** 6  # past the warm-up branch of Rainbow.act
+    rng = np.random.RandomState(4)
+
+    def generic(x, training):
+        if name == "rainbow":
+            lg = agent.network(agent.as_tensor(x), training)
+        else:
+            lg = agent.network(agent.as_tensor(x))
+        q = agent.logits2Q(lg)[1] if hasattr(agent, "logits2Q") else lg
+        top2 = torch.topk(q.double(), 2, dim=-1).values
+        clear = ((top2[:, 0] - top2[:, 1]) > 1e-5 * (1.0 + top2[:, 0].abs())).cpu().numpy()
+        return torch.argmax(q, -1, keepdim=True).cpu().numpy(), clear
+
+    n_clear = 0
+    for N in (1, 3, 8):
+        for training in (False, True):
+            x = rng.randint(0, 256, size=(N,) + S).astype(np.uint8) if isinstance(S, tuple) else rng.randn(N, S).astype(np.float32)
+            torch.manual_seed(100 + N)
+            want, clear = generic(x, training)
+            torch.manual_seed(100 + N)
+            got = agent.act(x, training)["action"]
+            assert got.shape == (N, 1) and got.dtype == np.int64
+            assert np.array_equal(got[clear], want[clear]), (N, training, got.ravel(), want.ravel())
+            n_clear += int(clear.sum())
+            torch.manual_seed(100 + N)
+            assert np.array_equal(agent._act_greedy(x, training), got)  # and it IS the branch act() took
+    assert n_clear >= 20
+    assert agent._act_greedy(np.zeros((agent._net.maxB + 1,) + (S if isinstance(S, tuple) else (S,)), np.uint8 if isinstance(S, tuple) else np.float32)) is None
+
+
+@pytest.mark.parametrize("name,extra,S", [
     ("ape_x", dict(network="dueling", head="cnn", n_step=3, num_workers=8), (4, 44, 52)),
     ("rainbow", dict(head="cnn", n_step=3, num_support=21, v_min=-1, v_max=10), (4, 44, 52)),
     ("dqn", dict(), 6),
