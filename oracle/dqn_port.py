@@ -28,6 +28,11 @@ class QNet(torch.nn.Module):
         self.head.l = torch.nn.Linear(S, H)
         self.l = torch.nn.Linear(H, H)
         self.q = torch.nn.Linear(H, A)
+        # head.py:14, q_network.py:13-14: orthogonal_init(layer) for head.l and l (gain sqrt(2)), orthogonal_init(q, "linear") (gain 1);
+        # zero biases (utils.py:110-124) -- what a run from scratch starts from
+        for layer, g in ((self.head.l, torch.nn.init.calculate_gain("relu")), (self.l, torch.nn.init.calculate_gain("relu")), (self.q, torch.nn.init.calculate_gain("linear"))):
+            torch.nn.init.orthogonal_(layer.weight.data, g)
+            torch.nn.init.zeros_(layer.bias.data)
 
     def forward(self, x):
         return self.q(F.relu(self.l(F.relu(self.head.l(x)))))

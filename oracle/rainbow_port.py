@@ -48,6 +48,12 @@ class RainbowNet(torch.nn.Module):
             d = lambda n, k, s: (n - k) // s + 1
             feat = 64 * d(d(d(h, 8, 4), 4, 2), 3, 1) * d(d(d(w, 8, 4), 4, 2), 3, 1)
         self.l = torch.nn.Linear(feat, H)
+        # head.py:14,43 / rainbow.py:33: orthogonal_init(layer) = orthogonal weights with gain sqrt(2), zero biases (utils.py:110-124) --
+        # what a run FROM SCRATCH starts from (the learn() fixtures load the reference's weights; the learning-curve tests do not)
+        gain = torch.nn.init.calculate_gain("relu")
+        for layer in list(self.head.children()) + [self.l]:
+            torch.nn.init.orthogonal_(layer.weight.data, gain)
+            torch.nn.init.zeros_(layer.bias.data)
         for tag, shape in (("a1", (H, H)), ("v1", (H, H)), ("a2", (H, K * A)), ("v2", (H, K))):
             bound = 1.0 / shape[0] ** 0.5
             for nm, val in (("mu_w", torch.empty(shape).uniform_(-bound, bound)), ("sig_w", torch.full(shape, 0.5 * bound)),

@@ -145,3 +145,101 @@ def test_dqn_cartpole_learning_curve_tracks_the_reference_cpu_path():
     assert g_start < 40 and c_start < 40  # random policy: ~22 steps
     assert g_end > 4 * g_start and c_end > 4 * c_start  # both learn
     assert 0.5 * c_end <= g_end <= 2.0 * c_end
+
+
+# ----------------------------------------------------------------------------- a value agent on an IMAGE task ("a value-agent curve on a small synthetic image task")
+class CueFrames:
+    """A synthetic image task for the CNN value agents (there is no Atari in the image): one-step episodes of (4, 44, 52) uint8 frames --
+    uniform noise in [0, 60) with one 8 x 8 block of 110 somewhere in one of the four quadrants, the same on all four planes; reward 1
+    for the action that names the quadrant, else 0.  Random play: 0.25.  Host-side numpy; both sides of the test use this class."""
+
+    def __init__(self, seed, shape=(4, 44, 52)):
+        self.rng, self.shape = np.random.RandomState(seed), shape
+        self._new()
+
+    def _new(self):
+        c, h, w = self.shape
+        self.quadrant = int(self.rng.randint(4))
+        f = self.rng.randint(0, 60, size=self.shape).astype(np.uint8)
+        x0 = (2 if self.quadrant % 2 == 0 else w // 2 + 2) + int(self.rng.randint(0, w // 2 - 12))
+        y0 = (2 if self.quadrant // 2 == 0 else h // 2 + 2) + int(self.rng.randint(0, h // 2 - 12))
+        f[:, y0 : y0 + 8, x0 : x0 + 8] = 110
+        self.frame = f[None]
+
+    def obs(self):
+        return self.frame
+
+    def step(self, action):
+        r = 1.0 if int(np.asarray(action).reshape(-1)[0]) == self.quadrant else 0.0
+        self._new()
+        return self.frame, np.array([[r]], np.float64), np.array([[True]])
+
+
+RB_STEPS, RB_CHUNK = 4000, 250
+
+
+def _rainbow_curve(agent, seed):
+    """The single-mode loop of run_mode.py:68-80 with Rainbow's n-step window (rainbow.py:294-308): mean reward per RB_CHUNK env steps."""
+    env = CueFrames(seed)
+    state, rs, out = env.obs(), [], []
+    for step in range(1, RB_STEPS + 1):
+        a = agent.act(state, True)
+        nxt, rew, done = env.step(a["action"])
+        tr = {"state": state, "next_state": nxt, "reward": rew, "done": done}
+        tr.update(a)
+        tr = agent.interact_callback(tr)
+        if tr:
+            agent.process([tr], step)
+        state = env.obs()
+        rs.append(float(rew[0, 0]))
+        if step % RB_CHUNK == 0:
+            out.append(float(np.mean(rs)))
+            rs = []
+    return out
+
+
+def test_rainbow_image_task_learning_curve_tracks_the_reference_cpu_path():
+    """Rainbow (noisy dueling categorical net on the Nature-CNN head, 3-step returns, PER) on CueFrames for 4 000 env steps in the
+    reference's single-mode loop: the HIP agent (uint8 frames -> conv1 on the MFMA, learn() as one hipGraph, act() through jh_value_act)
+    against the reference's CPU path (oracle/rainbow_port.py, pinned to the reference's learn() by the rainbow_cnn fixtures), same env
+    class, same hyper-parameters.  Both must learn (random play 0.25) and end within noise of each other."""
+    from jorldy_amd.core.agent import Agent
+    from oracle.rainbow_port import RainbowPort
+
+    S, A = (4, 44, 52), 4
+    hp = dict(hidden_size=128, gamma=0.99, buffer_size=4096, batch_size=32, n_step=3, alpha=0.5, beta=0.4, uniform_sample_prob=1e-3, v_min=-1.0, v_max=2.0, num_support=21)
+
+    def gpu(seed):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        agent = Agent("rainbow", state_size=S, action_size=A, head="cnn", optim_config={"name": "adam", "lr": 2.5e-4}, start_train_step=200, learn_period=4,
+                      target_update_period=400, lr_decay=False, run_step=30_000_000, device="cuda", **hp)
+        return _rainbow_curve(agent, seed)
+
+    def cpu(seed):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        agent = RainbowPort(S, A, lr=2.5e-4, **hp)
+        agent.start_train_step, agent.learn_period, agent.target_update_period = 200, 4, 400
+        return _rainbow_curve(agent, seed)
+
+    g = [gpu(s) for s in (1, 2, 3)]
+    c = [cpu(s) for s in (1, 2)]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/learning_curve_rainbow_image.json", "w") as f:
+        json.dump({"env": "CueFrames (4, 44, 52) uint8, 4 actions, one-step episodes", "steps": RB_STEPS, "metric": f"mean reward per {RB_CHUNK} env steps (random play 0.25)",
+                   "hip": g, "reference_cpu_port": c}, f)
+    g_start, g_end = np.mean([np.mean(x[:2]) for x in g]), np.mean([np.mean(x[-2:]) for x in g])
+    c_start, c_end = np.mean([np.mean(x[:2]) for x in c]), np.mean([np.mean(x[-2:]) for x in c])
+    print(f"mean reward: HIP {g_start:.2f} -> {g_end:.2f}, reference CPU port {c_start:.2f} -> {c_end:.2f}")
+    assert g_start < 0.45 and c_start < 0.45  # random play: 0.25
+    assert g_end > 0.9 and c_end > 0.9  # both solve it
+    assert abs(g_end - c_end) < 0.1
+    # ... and at the same pace: the first chunk with mean reward >= 0.9 (chunks of 250 env steps).  (This is the assertion that found the CPU
+    # port starting from torch's default initialisation instead of the reference's orthogonal one: it then needed 3 250 steps, the
+    # HIP agent -- whose weights come from the reference's own init -- 1 500.  With the port fixed both take 1 250-1 500.)
+    first = lambda x: next((i for i, v in enumerate(x) if v >= 0.9), len(x))
+    g_first, c_first = np.mean([first(x) for x in g]), np.mean([first(x) for x in c])
+    print(f"first chunk at >= 0.9: HIP {g_first:.1f}, reference CPU port {c_first:.1f}")
+    assert abs(g_first - c_first) <= 2.5
