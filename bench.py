@@ -611,8 +611,8 @@ def hopper_leg(rank, world, local_rank, dist, iters):
     """BASELINE.json configs[4] (config.ppo.mujoco Hopper-v3 shapes: S=11, A=3 continuous, 32 workers x 2048 steps, distributed batch 2048,
     10 epochs; "8 x MI355X data-parallel learners").  The config is split over the ranks (strong scaling: 32 / N workers and 2048 / N
     minibatch rows per GPU, one all-reduce of the flat gradient per minibatch).  N = 1: the learner side on 65 536 synthetic transitions
-    (the persistent acting kernel serves <= 16 env rows per GPU; MuJoCo itself is not installable); N >= 2: end to end with the native
-    collector on the synthetic control env."""
+    (MuJoCo itself is not installable) + the whole loop end to end beside it; N >= 2: end to end with the native collector on the
+    synthetic control env."""
     W, B = max(1, 32 // world), max(1, 2048 // world)
     e2e = W <= 16
     r = _tool("bench_hopper").hopper_leg(iters=iters, warmup=4, workers=W, batch=B, e2e=e2e, dist=dist if world > 1 else None, device=f"cuda:{local_rank}")
@@ -621,13 +621,13 @@ def hopper_leg(rank, world, local_rank, dist, iters):
              config={"workload": r.pop("workload"), "parallelism": f"dp{world}", "workers_per_gpu": W, "batch_per_gpu": B}, roofline=_dominant_mfma(r["lib_kernels"], note), **r)
     if not e2e and world == 1:
         # configs[4] END TO END on one GPU (VERDICT r4 missing #5): all 32 workers of the config on the native collector + the synthetic control env.
-        # 32 rows x 11 observations are beyond the persistent acting kernel's 128 observation granules, so acting is one forward launch per
-        # timestep here (jh_pponet_act_continuous: ~20 us x 2048 timesteps per iteration beside the 41 ms learner) -- slower than the learner
-        # alone, but the whole loop, measured
+        # Round 5: the persistent acting kernel takes up to 512 observation granules per exchange (32 rows x 11 observations = 352: three poll
+        # instructions per poll, two row tiles), so acting is ONE launch per 2048-step rollout here too; a timestep is the exchange (~12-23 us:
+        # 48 KB of partial heads come back per step) + the host's 32 env steps (~10.7 us)
         try:
             ee = _tool("bench_hopper").hopper_leg(iters=max(1, min(2, iters)), warmup=4, workers=W, batch=B, e2e=True, dist=None, device=f"cuda:{local_rank}")
             r["end_to_end"] = {"env_transitions_per_s": ee["env_transitions_per_s_end_to_end"], "ms_per_iteration": ee["ms_per_iteration"], "collector": ee["collector"],
-                               "workload": ee["workload"], "acting": "one acting forward per timestep for the 32 rows (W x S = 352 observation values > the persistent kernel's 128)"}
+                               "workload": ee["workload"], "acting": "persistent acting kernel, one launch per rollout: 32 rows x 11 observations = 352 granules per exchange (three poll instructions per poll, two row tiles)"}
         except Exception as e:
             r["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
     return r
@@ -905,7 +905,12 @@ def main():
                 e["rocprof_symbol_avg_us"], e["live_symbol_avg_us"], e["symbol_traffic_mixed"] = sym_avg, mix, sym_traffic
         # dominant = most GPU time per learn() among the minibatch kernels (launches per learn x average)
         per_learn = {k: (12 if k != "jh_pmb_fwd_nograd" else 1) * e["avg_us"] for k, e in entries.items()}
-        dom = max(per_learn, key=per_learn.get)
+        # (since round 5 the forward and the backward launch last the same to within their run-to-run noise -- 10.0 vs 9.9 us --, so "most
+        # time" alone flips between them from run to run, and with it the reported fraction by a factor of two (136 vs 272 MFLOP per launch).
+        # Launches within 5 % of the longest count as tied; among those the one with the most work per launch is reported, the others sit in
+        # `roofline_kernels`)
+        top = max(per_learn.values())
+        dom = max((k for k in per_learn if per_learn[k] >= 0.95 * top), key=lambda k: entries[k]["flops_per_launch"])
         out["roofline"] = dict(entries[dom])
         out["roofline"]["note"] = ("latency-bound BASELINE shape (minibatch 256 x hidden 512: 0.13-0.27 GFLOP per launch against a ~4.5 us "
                                    "launch floor); jh_act_persist_kernel is reported under `acting`, not here: its time is PCIe round trips")

@@ -416,7 +416,7 @@ int jh_collector_set_capture(jh_collector* c, float* d_h0, float* d_h1, float* d
  *                       row count advances here: the caller may enqueue the rollout's consumer (the learner's launches) on `stream` now.
  *   jh_collector_loop   the T-step host loop (Actor.run, manager/distributed_manager.py:76-92); its last act releases the flag.
  * The consumer then starts the instant the rollout ends instead of after the host has returned and launched it.  Needs the persistent
- * acting kernel (W <= 16, W * S <= 128) and a one-launch commit (<= 512 KB of rows), else the pair behaves exactly like jh_collector_run.
+ * acting kernel (W <= 32, W * S <= 512) and a one-launch commit (<= 512 KB of rows), else the pair behaves exactly like jh_collector_run.
  * A stalled environment (no observations for ~0.2 s) is an ERROR in this form (work is queued behind the acting kernel, the per-step
  * fallback of jh_collector_run cannot run); the flag is released regardless so that the stream drains.                              */
 int jh_collector_begin(jh_collector* c, int32_t T, jh_stream stream);

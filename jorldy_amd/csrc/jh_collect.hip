@@ -118,7 +118,7 @@ static int collector_create(jh_ctx* ctx, jh_pponet* net, const jh_env_vtbl* vt, 
   c->ctx = ctx; c->net = net; c->vt = *vt; c->env = env; c->store = store; c->W = W; c->S = S; c->A = A; c->cont = cont;
   c->col_state = cols[0]; c->col_action = cols[1]; c->col_reward = cols[2]; c->col_next = cols[3]; c->col_done = cols[4];
   if (const char* e = getenv("JH_COLLECT_PERSISTENT")) c->mode = atoi(e);
-  if (c->mode == 1 && W <= 16 && W * S <= 128) {
+  if (c->mode == 1 && W <= 32 && W * S <= 512) {  // jh_persist.hip: two row tiles of 16, up to four poll instructions of 128 observation granules
     if (jh_persist_create(net, &c->persist) != JH_OK) c->persist = nullptr;  // unsupported width: one launch per step
   }
   // Two timesteps per exchange is a CAPABILITY of the env (it can be forked on the host: fork_alloc / fork_free / copy_row given) with
@@ -405,7 +405,7 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
       }
     }
     if (!persistent) {
-      if (r.early) return jh_fail(JH_ERR_STATE, "jh_collector_begin needs the persistent acting kernel (W <= 16, W * S <= 128, JH_COLLECT_PERSISTENT != 0)");
+      if (r.early) return jh_fail(JH_ERR_STATE, "jh_collector_begin needs the persistent acting kernel (W <= 32, W * S <= 512, JH_COLLECT_PERSISTENT != 0)");
       // (the per-step launch samples even for the value-only query; its actions are not used)
       rc = c->cont ? jh_pponet_act_continuous(c->net, W, c->obs.data(), c->act_f.data(), lg.data(), lg.data() + (size_t)W * A, val.data(), training, stream)
                    : jh_pponet_act_discrete(c->net, W, c->obs.data(), c->act_i.data(), lg.data(), val.data(), training, stream);
@@ -670,7 +670,7 @@ JH_EXPORT int jh_collector_run(jh_collector* c, int32_t T, int32_t training, jh_
 JH_EXPORT int jh_collector_begin(jh_collector* c, int32_t T, jh_stream stream) {
   JH_ARG(c != nullptr && T > 0);
   if (run_state(c).active) return jh_fail(JH_ERR_STATE, "jh_collector_begin twice without jh_collector_loop");
-  if (!c->persist) return jh_fail(JH_ERR_STATE, "jh_collector_begin needs the persistent acting kernel (W <= 16, W * S <= 128, JH_COLLECT_PERSISTENT != 0)");
+  if (!c->persist) return jh_fail(JH_ERR_STATE, "jh_collector_begin needs the persistent acting kernel (W <= 32, W * S <= 512, JH_COLLECT_PERSISTENT != 0)");
   if (!c->gate_h) {
     JH_HIP(hipHostMalloc((void**)&c->gate_h, 64, hipHostMallocMapped));
     JH_HIP(hipHostGetDevicePointer((void**)&c->gate_d, c->gate_h, 0));

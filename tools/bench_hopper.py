@@ -120,9 +120,12 @@ def main():
     ap.add_argument("--workers", type=int, default=32)
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--e2e", action="store_true", help="per-GPU share of configs[4] with the native collector on the synthetic control env (4 workers, minibatch 256)")
+    ap.add_argument("--e2e-full", action="store_true", help="configs[4] end to end on ONE GPU: all 32 workers on the native collector, minibatch 2048")
     args = ap.parse_args()
     if args.e2e:
         args.workers, args.batch = 4, 256
+    if args.e2e_full:
+        args.e2e = True
     print(json.dumps(hopper_leg(args.iters, args.warmup, args.workers, args.batch, args.e2e)))
 
 
