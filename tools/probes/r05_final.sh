@@ -15,7 +15,7 @@ try:
 except Exception as e:
     print("parse failed", e)
 PY
-timeout 600 tools/profile_bench.sh r05_bench --steps 60 --warmup 10 --no-cpu-baseline --no-apex --no-rainbow --no-hopper --no-dqn --no-variants > gpurun_out/r05_profile_bench.log 2>&1; tail -12 gpurun_out/r05_profile_bench.log | cut -c1-150
-timeout 400 tools/profile_cmd.sh r05_rainbow python tools/bench_rainbow.py --updates 300 > gpurun_out/r05_profile_rainbow.log 2>&1; tail -14 gpurun_out/r05_profile_rainbow.log | cut -c1-150
-timeout 400 tools/profile_cmd.sh r05_apex python tools/bench_apex.py --updates 100 > gpurun_out/r05_profile_apex.log 2>&1; tail -14 gpurun_out/r05_profile_apex.log | cut -c1-150
-timeout 300 tools/profile_cmd.sh r05_hopper python tools/bench_hopper.py --iters 3 > gpurun_out/r05_profile_hopper.log 2>&1; tail -14 gpurun_out/r05_profile_hopper.log | cut -c1-150
+
+
+
+
