@@ -673,8 +673,8 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
   n->tg_cnt_slots = 4096;
   JH_HIP(hipMalloc((void**)&n->xg, sizeof(float) * (size_t)max_rows * (size_t)S));
   JH_HIP(hipMalloc((void**)&n->tg_ws, sizeof(float) * n->tg_ws_floats));
-  JH_HIP(hipMalloc((void**)&n->tg_cnt, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
-  JH_HIP(hipMemset(n->tg_cnt, 0, sizeof(unsigned) * (size_t)n->tg_cnt_slots));
+  JH_HIP(hipMalloc((void**)&n->tg_cnt, sizeof(unsigned) * (size_t)n->tg_cnt_slots * kTgemmCntStride));
+  JH_HIP(hipMemset(n->tg_cnt, 0, sizeof(unsigned) * (size_t)n->tg_cnt_slots * kTgemmCntStride));
   {
     const size_t part_bytes = sizeof(float) * 8 * (size_t)max_rows * (size_t)(H / 16);
     JH_HIP(hipMalloc((void**)&n->fwd_part, part_bytes));

@@ -579,10 +579,21 @@ __global__ void __launch_bounds__(256) jh_rb_optim_kernel(int64_t n, float* __re
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk == gridDim.x - 1) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      hyper[JH_HY_STEP] = t_new;
+    // "the last workgroup to finish stores the new step" as a TWO-LEVEL ticket (round 5): eight counters on separate cache lines, one
+    // per residue of blockIdx mod 8, and one on top of them.  Device-scope atomics on ONE address retire at ~9-15 ns apiece, and the
+    // workgroups of this launch finish together: with a single counter the launch grew by that much per workgroup (22.5 us at 512
+    // workgroups, 30.5 at 1024, 48 at 3072 for the same 3 M parameters -- profiles/r05_optim_grid_sweep.txt), i.e. its tail WAS the queue.
+    const unsigned k = blockIdx.x & 7u;
+    const unsigned nk = (gridDim.x - k + 7u) >> 3;  // workgroups with this residue
+    const unsigned tk = __hip_atomic_fetch_add(ticket + 32u * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == nk - 1) {
+      __hip_atomic_store(ticket + 32u * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+      const unsigned top = __hip_atomic_fetch_add(ticket + 256u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (top == groups - 1) {
+        __hip_atomic_store(ticket + 256u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hyper[JH_HY_STEP] = t_new;
+      }
     }
   }
 }
@@ -743,7 +754,7 @@ JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t kind, int32_t head_cnn, int32
   auto A4 = [&](float** p, size_t floats, bool zero = true) { if (!rc) rc = rb_alloc(n, (void**)p, floats * sizeof(float), zero); };
   A4(&n->hyper, JH_HY_FLOATS);
   A4(&n->norm_partial, 256);
-  if (!rc) rc = rb_alloc(n, (void**)&n->ticket, 16, true);
+  if (!rc) rc = rb_alloc(n, (void**)&n->ticket, 2048, true);  // jh_rb_optim_kernel: eight counters 128 bytes apart + the one on top of them
   A4(&n->weff, 3 * (size_t)d.set_stride);
   for (int s = 0; s < 2; ++s) {
     const size_t rows = s == 0 ? 2 * B : B;
@@ -794,7 +805,7 @@ JH_EXPORT int jh_rbnet_create(jh_ctx* ctx, int32_t kind, int32_t head_cnn, int32
   n->ws_floats = (size_t)8 << 20;  // 32 MB of split-K partials
   A4(&n->ws, n->ws_floats, false);
   n->cnt_slots = 8192;
-  if (!rc) rc = rb_alloc(n, (void**)&n->cnt, sizeof(unsigned) * n->cnt_slots, true);
+  if (!rc) rc = rb_alloc(n, (void**)&n->cnt, sizeof(unsigned) * (size_t)n->cnt_slots * kTgemmCntStride, true);
   if (rc) {
     for (void* p : n->owned) (void)hipFree(p);
     delete n;

@@ -42,6 +42,9 @@ struct TGemm {
   unsigned* cnt;       // [tiles] arrival counters (zero between launches)
 };
 constexpr int kMaxGroup = 6;
+// A tile's split-K arrival counter has a 128-byte line to itself (round 5): device-scope atomics retire one after the other per line, and
+// the counters of a launch's tiles used to sit in two or three lines that ALL of its workgroups hit within the same microsecond.
+constexpr int kTgemmCntStride = 32;
 struct TGemmBatch {
   TGemm p[kMaxGroup];
   int n;
@@ -88,7 +91,7 @@ struct TGemmWorkspace {
   float* ws = nullptr;
   size_t ws_floats = 0;
   unsigned* cnt = nullptr;
-  int cnt_slots = 0;
+  int cnt_slots = 0;   // arrival counters, kTgemmCntStride words apart (allocate cnt_slots * kTgemmCntStride words)
 };
 // The call sites of the engine: launch name "jh_tgemm_<NAME>" <-> kernel symbol jh_tgemm_kernel<TM, TN, ID> (what rocprofv3 sees;
 // tools/rocprof_tgemm_names.py maps the IDs back).  A launch under a name that is not listed here is refused.

@@ -140,9 +140,9 @@ __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-      const unsigned old = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(g.cnt + (size_t)tile * kTgemmCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = old == (unsigned)g.splitk - 1;
-      if (s_last) __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (s_last) __hip_atomic_store(g.cnt + (size_t)tile * kTgemmCntStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last) return;
@@ -820,7 +820,7 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
     probs[i].splitk = s;
     if (s > 1) {
       probs[i].ws = net_w.ws + ws_used;
-      probs[i].cnt = net_w.cnt + cnt_used;
+      probs[i].cnt = net_w.cnt + (size_t)cnt_used * kTgemmCntStride;
       ws_used += (size_t)s * tiles * pstride;
       cnt_used += tiles;
     }
@@ -919,8 +919,8 @@ JH_EXPORT int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const
     w.ws_floats = (size_t)4 << 20;
     w.cnt_slots = 4096;
     JH_HIP(hipMalloc((void**)&w.ws, sizeof(float) * w.ws_floats));
-    JH_HIP(hipMalloc((void**)&w.cnt, sizeof(unsigned) * (size_t)w.cnt_slots));
-    JH_HIP(hipMemset(w.cnt, 0, sizeof(unsigned) * (size_t)w.cnt_slots));
+    JH_HIP(hipMalloc((void**)&w.cnt, sizeof(unsigned) * (size_t)w.cnt_slots * kTgemmCntStride));
+    JH_HIP(hipMemset(w.cnt, 0, sizeof(unsigned) * (size_t)w.cnt_slots * kTgemmCntStride));
   }
   TGemm g = mk_gemm(M, N, K, op_dense(a_kcont ? OP_KCONT : OP_XCONT, d_a, lda), op_dense(b_kcont ? OP_KCONT : OP_XCONT, d_b, ldb), d_c, ldc, epi, d_bias, d_aux, ldaux,
                     d_rowsum);
@@ -939,8 +939,8 @@ JH_EXPORT int jh_tgemm_dense_group(jh_ctx* ctx, int32_t n, int32_t M, int32_t N,
     w.ws_floats = (size_t)4 << 20;
     w.cnt_slots = 4096;
     JH_HIP(hipMalloc((void**)&w.ws, sizeof(float) * w.ws_floats));
-    JH_HIP(hipMalloc((void**)&w.cnt, sizeof(unsigned) * (size_t)w.cnt_slots));
-    JH_HIP(hipMemset(w.cnt, 0, sizeof(unsigned) * (size_t)w.cnt_slots));
+    JH_HIP(hipMalloc((void**)&w.cnt, sizeof(unsigned) * (size_t)w.cnt_slots * kTgemmCntStride));
+    JH_HIP(hipMemset(w.cnt, 0, sizeof(unsigned) * (size_t)w.cnt_slots * kTgemmCntStride));
   }
   TGemm g[kMaxGroup];
   for (int j = 0; j < n; ++j) g[j] = mk_gemm(M, N, K, op_dense(OP_KCONT, d_a[j], K), op_dense(OP_KCONT, d_b[j], K), d_c[j], N, TEPI_NONE);
