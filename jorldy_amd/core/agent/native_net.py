@@ -7,6 +7,7 @@ import os
 import numpy as np
 import torch
 
+from ... import _lib as L
 from ... import ops
 from ..optimizer import Optimizer
 
@@ -156,8 +157,6 @@ class NativeValueNetMixin:
         net.forward(a["x_dev"], 0, nz, out=a["logits"])
         a["am"].np[:] = -1  # arrival marks (actions are >= 0)
         ops.value_act(a["logits"].view(N, A, K), float(getattr(self, "v_min", 0.0)), float(getattr(self, "v_max", 0.0)), out=(a["act_dev"], a["q_dev"]))
-        from ... import _lib as L
-
         if L.load().jh_host_wait_words(L.ptr(a["words"]), L.ptr(a["marks"]), N, 0xFFFFFFFF, 5.0) != 0:
             torch.cuda.current_stream(self.device).synchronize()
             if (a["am"].np < 0).any():
