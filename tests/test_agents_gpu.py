@@ -767,12 +767,13 @@ def test_collector_capture_equals_the_learners_own_no_grad_passes(cont, persiste
 
 
 @pytest.mark.parametrize("persistent", [True, False])
-@pytest.mark.parametrize("H,W", [(64, 5), (512, 8), (512, 32), (128, 19)])
+@pytest.mark.parametrize("H,W", [(64, 5), (512, 8), (512, 32), (128, 19), (256, 16)])
 def test_native_collector_continuous_policy_on_control_env(H, W, persistent, monkeypatch):
     """jh_collector_create_control / jh_collector_run (config.ppo.mujoco shapes: S = 11, A = 3, continuous): the stored
     worker-major transitions replayed through the oracle env reproduce states / rewards / dones bit for bit; the stored
     actions are tanh-squashed samples of the policy (persistent acting kernel with W1 in LDS for S > 8 and 88
-    observation granules -- 352 for the config's 32 workers, three poll instructions per poll and two row tiles; 209 for 19 --, or
+    observation granules -- 352 for the config's 32 workers, three poll instructions per poll and two row tiles; 209 for 19; 176 for the
+    16 workers per GPU of a two-GPU run: two instructions, one row tile --, or
     one launch per timestep); the learner consumes the rollout."""
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
