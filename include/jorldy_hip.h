@@ -538,6 +538,11 @@ int jh_tgemm_dense(jh_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* d_
 int jh_tgemm_dense_group(jh_ctx* ctx, int32_t n, int32_t M, int32_t N, int32_t K, const float* const* d_a, const float* const* d_b,
                          float* const* d_c, jh_stream stream);
 
+/* Measurement / test hook of the tile engine: per-call-site overrides of the workgroup tile, the K split and the XCD order,
+ * "<site id | *>:<TM>x<TN>[:s<splits>][:x<0|1>],..." (TM x TN in 16 x 16 fragments per wave: 2x2 = 64 x 64, 4x2 = 128 x 64, 2x4 = 64 x 128);
+ * the same grammar as the environment variable JH_TGEMM_CFG; "" or NULL restores the defaults.  No reference counterpart.  */
+int jh_tgemm_set_cfg(const char* cfg);
+
 /* ------------------------------------------------------------------ asynchronous actor -> learner staging
  * Replaces the async path's transport (run_mode.py:212-363 async_distributed_train: Ray actors -> manager
  * process -> multiprocessing trans_queue -> `gather_thread` spinning on flags, process.py:7-31,82-97) for

@@ -132,6 +132,7 @@ _PROTOS = {
     "jh_rbnet_adam_step": (C.c_int, [_vp, _vp]),
     "jh_tgemm_dense": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "jh_tgemm_dense_group": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "jh_tgemm_set_cfg": (C.c_int, [C.c_char_p]),
     "jh_ring_create": (C.c_int, [_vp, _i64, _i32, C.POINTER(ColDesc), _i32, _pp]),
     "jh_ring_destroy": (None, [_vp]),
     "jh_ring_produce": (C.c_int, [_vp, _i64, _pp, _vp, _i32]),

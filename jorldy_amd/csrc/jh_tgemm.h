@@ -48,6 +48,7 @@ constexpr int kTgemmCntStride = 32;
 struct TGemmBatch {
   TGemm p[kMaxGroup];
   int n;
+  int xcd;  // LDS-DMA kernel: 1 = XCD-contiguous order of the linear grid (tgemm_xcd_order)
 };
 
 // uint8 / 255 correctly rounded without a division: q = b * (1/255), one Newton correction with exact

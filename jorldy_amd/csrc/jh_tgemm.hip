@@ -8,6 +8,19 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DJH_TGEMM_TRACE (measurement builds, ab/lib_trace.so; never the shipped library): thread 0 of every workgroup of the LDS-DMA kernel
+// stores the shader clock at its phase boundaries into a buffer set by jh_tgemm_trace_buffer: slot 0 entry, 1 operands described /
+// tables staged, 2 + c chunk c's barrier passed (c < 24), 28 loop left, 29 epilogue operands + split hand-off done, 30 stores issued.
+#ifdef JH_TGEMM_TRACE
+__device__ unsigned long long* g_tgemm_trace = nullptr;
+#define JH_TRACE(slot)                                                                                         \
+  do {                                                                                                          \
+    if (threadIdx.x == 0 && g_tgemm_trace) g_tgemm_trace[(size_t)blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define JH_TRACE(slot) do {} while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float op_elem(const Opnd& o, int x, int k) {
@@ -53,12 +66,35 @@ struct EpiPre {
   static constexpr int NX = (TM * TN * 4 > TM * 4 + 2 * TN) ? TM * TN * 4 : TM * 4 + 2 * TN;
   float bias[TN], x[NX];
 };
+// The bias of this lane's TN output columns (BIAS / BIAS_RELU epilogues; else zeros, no fetch -- `has_bias` is uniform).  The LDS-DMA kernel
+// calls it BEFORE its k loop (round 6): TN registers across the loop, and the forward launches' epilogue has no memory round trip left.
+template <int TN>
+__device__ __forceinline__ void tgemm_epi_bias(const TGemm& g, int n0, int wn, int r, float (&bias)[TN]) {
+  const bool has_bias = g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * 16 * TN + 16 * j + r;
+    bias[j] = has_bias ? g.bias[n < g.N ? n : g.N - 1] : 0.f;
+  }
+}
 template <int TM, int TN>
-__device__ __forceinline__ EpiPre<TM, TN> tgemm_epi_prefetch(const TGemm& g, const TileCtx& c) {
+__device__ __forceinline__ EpiPre<TM, TN> tgemm_epi_prefetch(const TGemm& g, const TileCtx& c, const float* bias_pre) {
   EpiPre<TM, TN> e;
   constexpr int NX = EpiPre<TM, TN>::NX;
-  const bool has_bias = g.epi == TEPI_BIAS || g.epi == TEPI_BIAS_RELU, has_mask = g.epi == TEPI_MASK, has_c2 = g.C2 != nullptr;
-  const float* bias_p = has_bias ? g.bias : g.C;
+  const bool has_mask = g.epi == TEPI_MASK, has_c2 = g.C2 != nullptr;
+  if (bias_pre) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) e.bias[j] = bias_pre[j];
+  } else {
+    tgemm_epi_bias<TN>(g, c.n0, c.wn, c.r, e.bias);
+  }
+  // (round 6: an epilogue without activation mask and without NoisyNet noise -- every forward launch -- fetches nothing here; it used to read NX
+  // dummy elements of C so that the two users' fetches stayed branch-free: one more round trip in front of the stores.  Uniform branch.)
+  if (!has_mask && !has_c2) {
+#pragma unroll
+    for (int s = 0; s < NX; ++s) e.x[s] = 0.f;
+    return e;
+  }
   const float* aux_p = has_mask ? g.aux : g.C;
   const int lda = has_mask ? g.ldaux : g.ldc;
   const float* n1 = has_c2 ? g.nz_n : g.C;
@@ -70,7 +106,6 @@ __device__ __forceinline__ EpiPre<TM, TN> tgemm_epi_prefetch(const TGemm& g, con
   for (int j = 0; j < TN; ++j) {
     const int n = c.n0 + c.wn * 16 * TN + 16 * j + c.r;
     nc[j] = n < g.N ? n : g.N - 1;
-    e.bias[j] = bias_p[nc[j]];
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -99,11 +134,12 @@ __device__ __forceinline__ EpiPre<TM, TN> tgemm_epi_prefetch(const TGemm& g, con
 // Unconditional, they cost conv2 / conv3's backward groups 7-9 % at B = 512; behind a run-time branch, the values join the common
 // tail through copies = a wait for the fetches in front of the split-K hand-off (profiles/r05_ab_tgemm_fetch_order.txt).
 template <int TM, int TN, bool EPI>
-__device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f32x4 (&acc)[TM][TN], float (&rs)[TM], bool want_rs, int* s_last_p) {
+__device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f32x4 (&acc)[TM][TN], float (&rs)[TM], bool want_rs, int* s_last_p,
+                                             const float* bias_pre = nullptr) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   EpiPre<TM, TN> ep;  // (!EPI: never read -- the host launches that variant only for groups without epilogue operands)
   if constexpr (EPI) {
-    ep = tgemm_epi_prefetch<TM, TN>(g, c);
+    ep = tgemm_epi_prefetch<TM, TN>(g, c, bias_pre);
     asm volatile("" ::: "memory");  // issued here, not sunk to the stores
   }
   const int z = c.z, tiles = c.tiles, tile = c.tile, m0 = c.m0, n0 = c.n0, t = c.t, lane = c.lane, wid = c.wid, r = c.r, kq = c.kq, wm = c.wm, wn = c.wn;
@@ -152,24 +188,30 @@ __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int UNR = 4;  // UNR x TM x TN 16-byte loads in flight per lane
+    constexpr int UNR = 4;  // UNR x G 16-byte loads in flight per lane
+    // fragments in groups of G <= 4 (round 6: register-blocked tiles carry 8 fragments per lane; all of them x UNR splits in flight would be
+    // 128 registers): the sum over the splits runs in split order within every group, so a fragment's bits do not depend on the grouping
+    constexpr int FR = TM * TN, G = FR < 4 ? FR : 4;
+    static_assert(FR % G == 0, "fragment groups");
+#pragma unroll
+    for (int q0 = 0; q0 < FR; q0 += G) {
     for (int sp = 0; sp < g.splitk; sp += UNR) {
       // The loads of one round and their wait are ONE asm statement with early-clobber outputs: an asm load's destination
       // counts as written when the statement ends, so with the wait in a later statement the compiler is free to copy or
       // reuse the registers while the data is still in flight (seen as 32 wrong elements in one fragment, once in a few
       // thousand launches, under the LDS-DMA kernel's register allocation).
-      f32x4 part[UNR][TM * TN];
+      f32x4 part[UNR][G];
       const float* src[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) src[u] = base + (sp + u < g.splitk ? sp + u : g.splitk - 1) * zstride + frag0;  // clamped: uniform control flow
+      for (int u = 0; u < UNR; ++u) src[u] = base + (sp + u < g.splitk ? sp + u : g.splitk - 1) * zstride + frag0 + q0 * 256;  // clamped: uniform control flow
       static_assert(UNR == 4, "the asm below names four address registers");
 #define JH_LD(d, a, off) "global_load_dwordx4 %" #d ", %" #a ", off offset:" #off " sc1\n\t"
-      if constexpr (TM * TN == 1) {
+      if constexpr (G == 1) {
         asm volatile(JH_LD(0, 4, 0) JH_LD(1, 5, 0) JH_LD(2, 6, 0) JH_LD(3, 7, 0) "s_waitcnt vmcnt(0)"
                      : "=&v"(part[0][0]), "=&v"(part[1][0]), "=&v"(part[2][0]), "=&v"(part[3][0])
                      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3])
                      : "memory");
-      } else if constexpr (TM * TN == 2) {
+      } else if constexpr (G == 2) {
         asm volatile(JH_LD(0, 8, 0) JH_LD(1, 8, 1024) JH_LD(2, 9, 0) JH_LD(3, 9, 1024) JH_LD(4, 10, 0) JH_LD(5, 10, 1024) JH_LD(6, 11, 0)
                          JH_LD(7, 11, 1024) "s_waitcnt vmcnt(0)"
                      : "=&v"(part[0][0]), "=&v"(part[0][1]), "=&v"(part[1][0]), "=&v"(part[1][1]), "=&v"(part[2][0]), "=&v"(part[2][1]),
@@ -177,7 +219,7 @@ __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f
                      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3])
                      : "memory");
       } else {
-        static_assert(TM * TN == 4, "fragment counts 1, 2 and 4 are spelled out");
+        static_assert(G == 4, "fragment groups of 1, 2 and 4 are spelled out");
         asm volatile(JH_LD(0, 16, 0) JH_LD(1, 16, 1024) JH_LD(2, 16, 2048) JH_LD(3, 16, 3072) JH_LD(4, 17, 0) JH_LD(5, 17, 1024)
                          JH_LD(6, 17, 2048) JH_LD(7, 17, 3072) JH_LD(8, 18, 0) JH_LD(9, 18, 1024) JH_LD(10, 18, 2048) JH_LD(11, 18, 3072)
                              JH_LD(12, 19, 0) JH_LD(13, 19, 1024) JH_LD(14, 19, 2048) JH_LD(15, 19, 3072) "s_waitcnt vmcnt(0)"
@@ -191,9 +233,10 @@ __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-        for (int q = 0; q < TM * TN; ++q)
-          if (sp + u < g.splitk) acc[q / TN][q % TN] += part[u][q];
+        for (int q = 0; q < G; ++q)
+          if (sp + u < g.splitk) acc[(q0 + q) / TN][(q0 + q) % TN] += part[u][q];
       }
+    }
     }
     if (want_rs && wn == 0 && kq == 0) {
 #pragma unroll
@@ -206,6 +249,7 @@ __device__ __forceinline__ void tgemm_finish(const TGemm& g, const TileCtx& c, f
     }
   }
 
+  JH_TRACE(29);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -250,16 +294,23 @@ constexpr int kTabMax = 1024;  // k-range of one split that an im2col operand ca
 // attribute time and traffic per layer instead of to three shared `jh_tgemm_kernel<TM,TN>` symbols; the
 // body does not depend on it.
 template <int TM, int TN, int TAG, bool EPI = true>
-__global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(TGemmBatch batch) {
+__global__ void __launch_bounds__(256, 2) jh_tgemm_kernel(int hn, int hw1, int hw2, int hw3, int hw4, int hw5, int hxcd, int hpad, TGemmBatch batch) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = 36;
   __shared__ __attribute__((aligned(16))) float sA[BM * LD];
   __shared__ __attribute__((aligned(16))) float sB[BN * LD];
   __shared__ int sTabA[kTabMax], sTabB[kTabMax];
   __shared__ int s_last;
+  // the problem of this workgroup from the launch header: the first eight kernel arguments are scalars that gfx950 preloads into SGPRs at wave
+  // launch (-mllvm -amdgpu-kernarg-preload-count=8, see the Makefile), so the descriptor below is the FIRST memory round trip of the workgroup
+  // (round 6; through batch.p[i].wg_begin it was the second, behind a fetch of the six begins)
+  static_assert(kMaxGroup == 6, "five begins in the header");
+  (void)hpad;
   int pi = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxGroup; ++i)
-    if (i < batch.n && (int)blockIdx.x >= batch.p[i].wg_begin) pi = i;
+  if (1 < hn && (int)blockIdx.x >= hw1) pi = 1;
+  if (2 < hn && (int)blockIdx.x >= hw2) pi = 2;
+  if (3 < hn && (int)blockIdx.x >= hw3) pi = 3;
+  if (4 < hn && (int)blockIdx.x >= hw4) pi = 4;
+  if (5 < hn && (int)blockIdx.x >= hw5) pi = 5;
   const TGemm g = batch.p[pi];  // a COPY: the whole descriptor in one batch of scalar loads (through a reference, every field was its own dependent s_load + wait)
   const int tiles = g.tiles_m * g.tiles_n;
   const int local = blockIdx.x - g.wg_begin;
@@ -503,26 +554,30 @@ __device__ __forceinline__ void tgemm_dma16(const void* gsrc, unsigned lds_base)
 #endif
 constexpr int kDmaBufs = JH_TGEMM_DMA_BUFS;
 
-// One operand's two 16-byte pieces per lane and chunk: piece p = (i * 4 + wave) * 64 + lane of the 512 that make a 64 x 32 tile.
+// One operand's NP 16-byte pieces per lane and chunk: piece p = (i * 4 + wave) * 64 + lane of the 256 NP that make a (32 NP) x 32 tile
+// (NP = 2: the 64-wide tile side; NP = 4: the 128-wide side of the register-blocked tiles of round 6).
+template <int NP>
 struct DmaOp {
-  const float* src[2];  // address of the piece in chunk 0 (im2col: without the term that follows k)
-  int kin[2];           // im2col: index of that term in the split's LDS table
-  size_t step;          // dense: floats from one chunk to the next
-  const int* tab;       // im2col: the LDS table (taps for k-contiguous, pixels for x-contiguous), else nullptr
+  const float* src[NP];  // address of the piece in chunk 0 (im2col: without the term that follows k)
+  int kin[NP];           // im2col: index of that term in the split's LDS table
+  size_t step;           // dense: floats from one chunk to the next
+  const int* tab;        // im2col: the LDS table (taps for k-contiguous, pixels for x-contiguous), else nullptr
 };
 // Two phases so that the im2col offset lookups of BOTH operands (and the table staging) are in flight together: phase 1 computes the
 // pieces' coordinates and ISSUES the lookups -- unconditionally: a dense operand reads element 0 of its own matrix and drops it; a
 // lookup inside `conv ? tab[xc] : ...` is a fetch + wait in its own basic block, four of them in series per launch (round 5) --,
 // phase 2 builds the addresses.
+template <int NP>
 struct DmaLook {
-  int xc[2], kin[2], look[2];
+  int xc[NP], kin[NP], look[NP];
 };
-__device__ __forceinline__ DmaLook tgemm_dma_look(const Opnd& o, int X, int x0, int wid, int lane) {
-  DmaLook l;
-  const bool xfast = o.mode & 1, conv = o.mode >= OP_NHWC_K;
-  const int* xt = conv ? (xfast ? o.tap_tab : o.pix_tab) : (const int*)o.p;
+template <int NP>
+__device__ __forceinline__ DmaLook<NP> tgemm_dma_look(const Opnd& o, int X, int x0, int wid, int lane) {  // coordinates only; the lookups: tgemm_dma_lookups
+  DmaLook<NP> l;
+  constexpr int XB = 8 * NP;  // 16-byte x-blocks per k row of an x-contiguous tile
+  const bool xfast = o.mode & 1;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NP; ++i) {
     const int p = (i * 4 + wid) * 64 + lane;
     if (!xfast) {
       const int row = p >> 3, kb = 4 * ((p & 7) ^ ((row >> 1) & 7));
@@ -530,76 +585,141 @@ __device__ __forceinline__ DmaLook tgemm_dma_look(const Opnd& o, int X, int x0, 
       l.xc[i] = x < X ? x : X - 1;  // rows beyond the matrix fetch a valid row: their results are never stored
       l.kin[i] = kb;
     } else {
-      const int kk = p >> 4, xb = (p & 15) ^ (((kk >> 2) & 3) << 2);
+      const int kk = p / XB, xb = (p % XB) ^ (((kk >> 2) & 3) << 2);
       const int x = x0 + 4 * xb;
       l.xc[i] = x + 3 < X ? x : X - 4;  // X % 4 == 0: a piece is wholly inside or wholly outside
       l.kin[i] = kk;
     }
-    l.look[i] = xt[conv ? l.xc[i] : 0];
+    l.look[i] = 0;
   }
   return l;
 }
-__device__ __forceinline__ DmaOp tgemm_dma_operand(const Opnd& o, const DmaLook& l, int kbeg, const int* tab) {
-  DmaOp d;
+// The im2col offset lookups of BOTH operands as one batch under ONE uniform branch (round 6: a problem without an im2col operand -- the
+// linear layers, the PPO net -- fetches nothing here; its dummy lookups were a full memory round trip between the descriptor and the first
+// DMA).  Inside the branch every fetch is unconditional: the dense operand of a problem with a view reads element 0 of its own matrix and drops it.
+template <int NA, int NBP>
+__device__ __forceinline__ void tgemm_dma_lookups(const Opnd& a, const Opnd& b, DmaLook<NA>& la, DmaLook<NBP>& lb) {
+  const bool a_conv = a.mode >= OP_NHWC_K, b_conv = b.mode >= OP_NHWC_K;
+  if (!(a_conv || b_conv)) return;
+  const int* xa = a_conv ? ((a.mode & 1) ? a.tap_tab : a.pix_tab) : (const int*)a.p;
+  const int* xb = b_conv ? ((b.mode & 1) ? b.tap_tab : b.pix_tab) : (const int*)b.p;
+  int va[NA], vb[NBP];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) va[i] = xa[a_conv ? la.xc[i] : 0];
+#pragma unroll
+  for (int i = 0; i < NBP; ++i) vb[i] = xb[b_conv ? lb.xc[i] : 0];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) la.look[i] = va[i];
+#pragma unroll
+  for (int i = 0; i < NBP; ++i) lb.look[i] = vb[i];
+}
+template <int NP>
+__device__ __forceinline__ DmaOp<NP> tgemm_dma_operand(const Opnd& o, const DmaLook<NP>& l, int kbeg, const int* tab) {
+  DmaOp<NP> d;
   const bool xfast = o.mode & 1, conv = o.mode >= OP_NHWC_K;
   d.tab = conv ? tab : nullptr;
   d.step = xfast ? (size_t)32 * o.ld : 32;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NP; ++i) {
     d.kin[i] = l.kin[i];
     if (!xfast) d.src[i] = (const float*)o.p + (conv ? (size_t)l.look[i] : (size_t)l.xc[i] * o.ld + kbeg + l.kin[i]);
     else d.src[i] = (const float*)o.p + (conv ? (size_t)l.look[i] : (size_t)(kbeg + l.kin[i]) * o.ld + l.xc[i]);
   }
   return d;
 }
-__device__ __forceinline__ void tgemm_dma_issue(const DmaOp& d, int c, unsigned lds) {  // chunk c -> the wave's two 1 KB pieces at lds
-  const float* s0 = d.tab ? d.src[0] + d.tab[c * 32 + d.kin[0]] : d.src[0] + c * d.step;
-  const float* s1 = d.tab ? d.src[1] + d.tab[c * 32 + d.kin[1]] : d.src[1] + c * d.step;
-  tgemm_dma16(s0, lds);
-  tgemm_dma16(s1, lds + 4096u);
+template <int NP>
+__device__ __forceinline__ void tgemm_dma_issue(const DmaOp<NP>& d, int c, unsigned lds, bool is_b = false) {  // chunk c -> the wave's NP 1 KB pieces at lds
+#ifdef JH_TGEMM_SKIP_B  // measurement builds only (wrong results): what is the loop's rate without operand B's / both operands' DMA traffic?
+  if (is_b && c > 0) return;
+#endif
+#ifdef JH_TGEMM_SKIP_AB
+  if (c > 0) return;
+#endif
+  const float* s[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s[i] = d.tab ? d.src[i] + d.tab[c * 32 + d.kin[i]] : d.src[i] + c * d.step;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) tgemm_dma16(s[i], lds + (unsigned)i * 4096u);
+}
+
+// The same issue in two halves for the pipelined loop: the im2col table lookups (LDS reads) of chunk c are issued early, among the
+// fragment reads of a step, and the DMA instructions later take the offsets from registers.  Unconditional: a dense operand reads
+// entry 0 of the (always allocated) table and drops it -- a lookup inside `tab ? ... : ...` is a branch + ds_read + s_waitcnt per piece.
+template <int NP>
+__device__ __forceinline__ void tgemm_dma_offsets(const DmaOp<NP>& d, const int* any_tab, int c, unsigned (&off)[NP]) {
+  const int* t = d.tab ? d.tab : any_tab;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) off[i] = (unsigned)t[d.tab ? c * 32 + d.kin[i] : 0];  // (table entries are >= 0; unsigned: a sign extension would be folded INTO the load = a wait right behind it)
+}
+template <int NP>
+__device__ __forceinline__ void tgemm_dma_addrs(const DmaOp<NP>& d, int c, const unsigned (&off)[NP], const float* (&s)[NP]) {
+  const bool conv = d.tab != nullptr;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s[i] = d.src[i] + (conv ? (size_t)off[i] : (size_t)c * d.step);
+}
+template <int NP>
+__device__ __forceinline__ void tgemm_dma_fire(const float* const (&s)[NP], int c, unsigned lds, bool is_b = false) {
+#ifdef JH_TGEMM_SKIP_B
+  if (is_b && c > 0) return;
+#endif
+#ifdef JH_TGEMM_SKIP_AB
+  if (c > 0) return;
+#endif
+#pragma unroll
+  for (int i = 0; i < NP; ++i) tgemm_dma16(s[i], lds + (unsigned)i * 4096u);
 }
 
 // RS: this wave accumulates the row sums of A (bias gradients).  A template parameter, not a run-time flag: as a flag hipcc computes
 // the sums in every wave and selects (36 VALU instructions per chunk next to 32 MFMAs: the forward launches lost 8 % to it).
-// NB: LDS buffers per operand = chunks in flight + 1 (NB; 4 for the 2048-row PPO launches, which have the CU to themselves)
-template <bool AX, bool BX, bool RS, int NB>
-__device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float* sB, const DmaOp& da, const DmaOp& db, int nc, int wid, int r, int kq, int wm,
-                                                   int wn, f32x4 (&acc)[2][2], float (&rs)[2]) {
-  constexpr int TM = 2, TN = 2, BK = 32, TILE = 64 * BK;
+// NB: LDS buffers per operand = chunks in flight + 1
+// TM x TN: 16 x 16 fragments per wave.  2 x 2 is the 64 x 64 workgroup tile of rounds 2-5.  Round 6: 4 x 2 / 2 x 4 (128 x 64 / 64 x 128): a wave owns
+// 64 x 32 of C, so a chunk's LDS fragments (TM + TN = 6 ds_read_b128 per 16 k) feed 32 MFMAs where the 2 x 2 tile's 4 reads feed 16, the workgroup
+// runs 64 MFMAs per wave between two barriers instead of 32, and a chunk moves 24 KB into LDS for 2 x the flops of the 64 x 64 tile's 16 KB.
+#ifndef JH_TGEMM_PIPELINED_LOOP
+template <int TM, int TN, bool AX, bool BX, bool RS, int NB>
+__device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float* sB, const DmaOp<TM>& da, const DmaOp<TN>& db, int nc, int wid, int r, int kq,
+                                                   int wm, int wn, f32x4 (&acc)[TM][TN], float (&rs)[TM], const TGemm& g, int n0, float (&bias)[TN]) {
+  constexpr int BK = 32, XA = 32 * TM, XB = 32 * TN, TILE_A = XA * BK, TILE_B = XB * BK, LOADS = TM + TN;
   const unsigned ldsA = (unsigned)(uintptr_t)sA + (unsigned)wid * 1024u, ldsB = (unsigned)(uintptr_t)sB + (unsigned)wid * 1024u;
   // read offsets (floats) of this lane inside a tile; see the layouts above
   int ao[TM], bo[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int x = wm * 32 + 16 * i + r;
-    ao[i] = AX ? 4 * kq * 64 + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
+    const int x = wm * 16 * TM + 16 * i + r;
+    ao[i] = AX ? 4 * kq * XA + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int x = wn * 32 + 16 * j + r;
-    bo[j] = BX ? 4 * kq * 64 + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
+    const int x = wn * 16 * TN + 16 * j + r;
+    bo[j] = BX ? 4 * kq * XB + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
   }
   // (the compiler's own loads so far -- tables, operand descriptors -- must not be counted by the vmcnt arithmetic below)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int c = 0; c < NB - 1 && c < nc; ++c) {
-    tgemm_dma_issue(da, c, ldsA + (unsigned)c * (TILE * 4));
-    tgemm_dma_issue(db, c, ldsB + (unsigned)c * (TILE * 4));
+    tgemm_dma_issue<TM>(da, c, ldsA + (unsigned)c * (TILE_A * 4));
+    tgemm_dma_issue<TN>(db, c, ldsB + (unsigned)c * (TILE_B * 4), true);
   }
+  // the epilogue's bias, fetched HERE (round 6): behind the first chunks' DMA -- between two asm statements that clobber memory, so the compiler
+  // neither hoists it in front of the DMA issue nor sinks it into the epilogue -- and in flight under the whole loop.  The vmcnt arithmetic below
+  // stays safe: these TN loads are older than every DMA issued after them and vmcnt retires in order (a wait may cover them early, never late).
+  tgemm_epi_bias<TN>(g, n0, wn, r, bias);
+  asm volatile("" ::: "memory");
   int buf = 0, nbuf = NB - 1;  // buffer of chunk c, buffer of chunk c + NB - 1 (the one chunk c - 1 just left)
 #pragma unroll 1
   for (int c = 0; c < nc; ++c) {
-    // this wave's pieces of chunk c have landed once at most the chunks issued after it (4 loads each) are outstanding
+    // this wave's pieces of chunk c have landed once at most the chunks issued after it (LOADS loads each) are outstanding
     const int after = nc - 1 - c < NB - 2 ? nc - 1 - c : NB - 2;
-    if (NB >= 4 && after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (NB >= 3 && after >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (NB >= 4 && after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (NB >= 3 && after >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // ... and everybody else's; every wave is done with chunk c - 1, so its buffer may be refilled
+    if (c < 24) JH_TRACE(2 + c);
     if (c + NB - 1 < nc) {
-      tgemm_dma_issue(da, c + NB - 1, ldsA + (unsigned)nbuf * (TILE * 4));
-      tgemm_dma_issue(db, c + NB - 1, ldsB + (unsigned)nbuf * (TILE * 4));
+      tgemm_dma_issue<TM>(da, c + NB - 1, ldsA + (unsigned)nbuf * (TILE_A * 4));
+      tgemm_dma_issue<TN>(db, c + NB - 1, ldsB + (unsigned)nbuf * (TILE_B * 4), true);
     }
-    const float* A = sA + buf * TILE;
-    const float* B = sB + buf * TILE;
+    const float* A = sA + buf * TILE_A;
+    const float* B = sB + buf * TILE_B;
 #pragma unroll
     for (int kb = 0; kb < BK; kb += 16) {
       float a[TM][4], b[TN][4];
@@ -608,7 +728,7 @@ __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float*
       for (int i = 0; i < TM; ++i) {
         if (AX) {
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) a[i][cc] = A[ao[i] + (kb + cc) * 64];
+          for (int cc = 0; cc < 4; ++cc) a[i][cc] = A[ao[i] + (kb + cc) * XA];
         } else {
           const float4 q = *reinterpret_cast<const float4*>(A + ao[i] + blk);
           a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
@@ -619,7 +739,7 @@ __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float*
       for (int j = 0; j < TN; ++j) {
         if (BX) {
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) b[j][cc] = B[bo[j] + (kb + cc) * 64];
+          for (int cc = 0; cc < 4; ++cc) b[j][cc] = B[bo[j] + (kb + cc) * XB];
         } else {
           const float4 q = *reinterpret_cast<const float4*>(B + bo[j] + blk);
           b[j][0] = q.x; b[j][1] = q.y; b[j][2] = q.z; b[j][3] = q.w;
@@ -637,20 +757,184 @@ __device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float*
   }
 }
 
-template <int TAG, bool EPI = true, int NB = kDmaBufs>
-__global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) {
-  constexpr int TM = 2, TN = 2, BM = 64, BN = 64, BK = 32;
+#else
+// ---- round 6: the same loop, software-pipelined by hand.
+// What the phase stamps of a trace build showed (tools/probes/tgemm_trace.py, profiles/r06_tgemm_phase_trace.txt): with ONE workgroup per CU
+// (the PPO net's 2048-row products) the round-5 loop above takes 2044 cycles per 32-wide chunk for 1024 cycles of MFMA issue, and still
+// 1680 with its DMA stream removed altogether: a wave reads a 16-k step's fragments from LDS, waits for them, issues the step's MFMAs,
+// reads the next step's, waits again, meets the barrier, issues the next chunk's DMA (address arithmetic + four m0 round trips) and
+// only then reads again -- every one of those sits IN FRONT of MFMA issue, and with one wave per SIMD nobody else fills the gap.
+// Here the fragments are double-buffered in registers and every non-MFMA instruction of a step is issued in the shadow of MFMAs:
+//   even step of chunk c   MFMA step 0 | LDS reads of the odd step                     | MFMA steps 1-3
+//   odd step of chunk c    MFMA steps 0-1 | wait for chunk c + 1, barrier, LDS reads of its even step, DMA of chunk c + NB into the
+//                          buffer chunk c just left (every wave's reads of it are complete at that barrier) | MFMA steps 2-3
+// sched_barrier(0) pins the order (the MFMAs are register-only and would otherwise float across the asm statements).  All NB buffers
+// hold chunks (the round-5 loop kept one free), the DMA prefetch distance stays NB - 1 chunks.  Same MFMA sequence per accumulator =
+// the same bits.
+template <int TM, int TN, bool AX, bool BX>
+__device__ __forceinline__ void tgemm_lds_frags(const float* A, const float* B, const int (&ao)[TM], const int (&bo)[TN], int kb, int kq, int r,
+                                                float (&a)[TM][4], float (&b)[TN][4]) {
+  constexpr int XA = 32 * TM, XB = 32 * TN;
+  const int blk = (((kb >> 2) + kq) ^ ((r >> 1) & 7)) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (AX) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) a[i][cc] = A[ao[i] + (kb + cc) * XA];
+    } else {
+      const float4 q = *reinterpret_cast<const float4*>(A + ao[i] + blk);
+      a[i][0] = q.x; a[i][1] = q.y; a[i][2] = q.z; a[i][3] = q.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    if (BX) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) b[j][cc] = B[bo[j] + (kb + cc) * XB];
+    } else {
+      const float4 q = *reinterpret_cast<const float4*>(B + bo[j] + blk);
+      b[j][0] = q.x; b[j][1] = q.y; b[j][2] = q.z; b[j][3] = q.w;
+    }
+  }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void tgemm_mfma_step(int cc, const float (&a)[TM][4], const float (&b)[TN][4], f32x4 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][cc], b[j][cc], acc[i][j], 0, 0, 0);
+}
+
+template <int TM, int TN, bool AX, bool BX, bool RS, int NB>
+__device__ __forceinline__ void tgemm_dma_mainloop(const float* sA, const float* sB, const int* sTab, const DmaOp<TM>& da, const DmaOp<TN>& db, int nc, int wid, int r,
+                                                   int kq, int wm, int wn, f32x4 (&acc)[TM][TN], float (&rs)[TM], const TGemm& g, int n0, float (&bias)[TN]) {
+  constexpr int BK = 32, XA = 32 * TM, XB = 32 * TN, TILE_A = XA * BK, TILE_B = XB * BK, LOADS = TM + TN;
+  static_assert(NB >= 2 && NB <= 4, "vmcnt immediates below");
+  const unsigned ldsA = (unsigned)(uintptr_t)sA + (unsigned)wid * 1024u, ldsB = (unsigned)(uintptr_t)sB + (unsigned)wid * 1024u;
+  // read offsets (floats) of this lane inside a tile; see the layouts above
+  int ao[TM], bo[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int x = wm * 16 * TM + 16 * i + r;
+    ao[i] = AX ? 4 * kq * XA + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int x = wn * 16 * TN + 16 * j + r;
+    bo[j] = BX ? 4 * kq * XB + ((((x >> 2) ^ (kq << 2)) << 2) + (x & 3)) : x * BK;
+  }
+  // (the compiler's own loads so far -- tables, operand descriptors -- must not be counted by the vmcnt arithmetic below)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int c = 0; c < NB && c < nc; ++c) {
+    tgemm_dma_issue<TM>(da, c, ldsA + (unsigned)c * (TILE_A * 4));
+    tgemm_dma_issue<TN>(db, c, ldsB + (unsigned)c * (TILE_B * 4), true);
+  }
+  tgemm_epi_bias<TN>(g, n0, wn, r, bias);
+  asm volatile("" ::: "memory");
+  // chunk `want` has landed once at most the chunks issued after it are outstanding: min(issued - 1 - want, NB - 1) of them
+  auto wait_landed = [&](int outstanding_chunks) {
+    if (NB >= 4 && outstanding_chunks >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory");
+    else if (NB >= 3 && outstanding_chunks == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (outstanding_chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  float a0[TM][4], b0[TN][4], a1[TM][4], b1[TN][4];
+  {
+    const int issued = nc < NB ? nc : NB;
+    wait_landed(issued - 1);
+    __syncthreads();
+    JH_TRACE(2);
+    tgemm_lds_frags<TM, TN, AX, BX>(sA, sB, ao, bo, 0, kq, r, a0, b0);
+  }
+  int buf = 0;
+#pragma unroll 1
+  for (int c = 0; c < nc; ++c) {
+    const float* A = sA + buf * TILE_A;
+    const float* B = sB + buf * TILE_B;
+    // ---- even step (k 0..15 of the chunk): fragments in a0 / b0
+    tgemm_mfma_step<TM, TN>(0, a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    tgemm_lds_frags<TM, TN, AX, BX>(A, B, ao, bo, 16, kq, r, a1, b1);
+    unsigned offa[TM], offb[TN];  // im2col offsets of the chunk whose DMA the odd step issues (clamped: the last chunks issue nothing)
+    tgemm_dma_offsets<TM>(da, sTab, c + NB < nc ? c + NB : 0, offa);
+    tgemm_dma_offsets<TN>(db, sTab, c + NB < nc ? c + NB : 0, offb);
+    __builtin_amdgcn_sched_barrier(0);
+    tgemm_mfma_step<TM, TN>(1, a0, b0, acc);
+    tgemm_mfma_step<TM, TN>(2, a0, b0, acc);
+    tgemm_mfma_step<TM, TN>(3, a0, b0, acc);
+    if (RS) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) rs[i] += (a0[i][0] + a0[i][1]) + (a0[i][2] + a0[i][3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- odd step (k 16..31): fragments in a1 / b1
+    tgemm_mfma_step<TM, TN>(0, a1, b1, acc);
+    tgemm_mfma_step<TM, TN>(1, a1, b1, acc);
+    // the next DMA's addresses on EVERY path (the table offsets are consumed here: left pending on the last chunks' path, their
+    // destination registers cost the merged path a wait for ALL LDS reads in front of the MFMAs below)
+    const float *pa[TM], *pb[TN];
+    tgemm_dma_addrs<TM>(da, c + NB < nc ? c + NB : 0, offa, pa);
+    tgemm_dma_addrs<TN>(db, c + NB < nc ? c + NB : 0, offb, pb);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(pa[i]));  // (a use HERE: LLVM sinks the arithmetic into the branch that issues the DMA otherwise)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(pb[j]));
+    __builtin_amdgcn_sched_barrier(0);
+    const int nb = buf + 1 == NB ? 0 : buf + 1;
+    if (c + 1 < nc) {
+      // chunks issued so far: 0 .. min(nc, c + NB) - 1; chunk c + 1 is needed
+      const int last_issued = (nc < c + NB ? nc : c + NB) - 1;
+      wait_landed(last_issued - (c + 1));
+      __syncthreads();  // everybody's pieces of chunk c + 1 have landed, and everybody's reads of chunk c are complete: its buffer may be refilled
+      if (c + 1 < 24) JH_TRACE(3 + c);
+      tgemm_lds_frags<TM, TN, AX, BX>(sA + nb * TILE_A, sB + nb * TILE_B, ao, bo, 0, kq, r, a0, b0);
+      if (c + NB < nc) {
+        tgemm_dma_fire<TM>(pa, c + NB, ldsA + (unsigned)buf * (TILE_A * 4));
+        tgemm_dma_fire<TN>(pb, c + NB, ldsB + (unsigned)buf * (TILE_B * 4), true);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tgemm_mfma_step<TM, TN>(2, a1, b1, acc);
+    tgemm_mfma_step<TM, TN>(3, a1, b1, acc);
+    if (RS) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) rs[i] += (a1[i][0] + a1[i][1]) + (a1[i][2] + a1[i][3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    buf = nb;
+  }
+}
+
+#endif
+
+// XCD-aware order of the linear grid (JH_TGEMM_XCD=1): workgroups are dealt to the 8 XCDs round-robin, and each XCD has its own L2.
+// Workgroup b becomes item start(b % 8) + b / 8, where XCD x owns a CONTIGUOUS range of the (problem, tile, split) order -- neighbours in that
+// order share A rows (same row tile) or the whole B operand (N = 64 convolutions), so an XCD's L2 fills with what its own CUs re-read.
+__device__ __forceinline__ int tgemm_xcd_order(int bid, int total) {
+  const int q = total >> 3, rem = total & 7, x = bid & 7, idx = bid >> 3;
+  return x * q + (x < rem ? x : rem) + idx;
+}
+
+template <int TM, int TN, int TAG, bool EPI = true, int NB = (TM * TN > 4 ? 2 : kDmaBufs)>
+__global__ void __launch_bounds__(256, (TM * TN >= 16 ? 2 : 3)) jh_tgemm_dma_kernel(int hn, int hw1, int hw2, int hw3, int hw4, int hw5, int hxcd, int hpad, TGemmBatch batch) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32;
   __shared__ __attribute__((aligned(16))) float sA[NB * BM * BK];
   __shared__ __attribute__((aligned(16))) float sB[NB * BN * BK];
   __shared__ int sTab[kTabMax];  // at most one operand of a problem is an im2col view; 48 + 4 KB lets three workgroups share a CU
   __shared__ int s_last;
+  JH_TRACE(0);
+  const int bid = hxcd ? tgemm_xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  // (the launch header: see jh_tgemm_kernel)
+  (void)hpad;
   int pi = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxGroup; ++i)
-    if (i < batch.n && (int)blockIdx.x >= batch.p[i].wg_begin) pi = i;
+  if (1 < hn && bid >= hw1) pi = 1;
+  if (2 < hn && bid >= hw2) pi = 2;
+  if (3 < hn && bid >= hw3) pi = 3;
+  if (4 < hn && bid >= hw4) pi = 4;
+  if (5 < hn && bid >= hw5) pi = 5;
   const TGemm g = batch.p[pi];  // a COPY: the whole descriptor in one batch of scalar loads (through a reference, every field was its own dependent s_load + wait)
   const int tiles = g.tiles_m * g.tiles_n;
-  const int local = blockIdx.x - g.wg_begin;
+  const int local = bid - g.wg_begin;
   const int z = local / tiles, tile = local - z * tiles;
   const int tm_blk = tile / g.tiles_n, tn_blk = tile - tm_blk * g.tiles_n;
   const int m0 = tm_blk * BM, n0 = tn_blk * BN;
@@ -666,8 +950,9 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
   // (round 5: all kTabMax / 256 passes fetched as ONE batch from clamped addresses and stored unconditionally -- entries past the
   // split's range are never read.  The plain loop compiled to fetch, wait, store per pass: up to four dependent round trips in front
   // of the first operand fetch of a launch that lasts 13-22 us.)
-  const DmaLook la = tgemm_dma_look(g.a, g.M, m0, wid, lane);
-  const DmaLook lb = tgemm_dma_look(g.b, g.N, n0, wid, lane);
+  DmaLook<TM> la = tgemm_dma_look<TM>(g.a, g.M, m0, wid, lane);
+  DmaLook<TN> lb = tgemm_dma_look<TN>(g.b, g.N, n0, wid, lane);
+  tgemm_dma_lookups<TM, TN>(g.a, g.b, la, lb);
   if (a_conv || b_conv) {
     const int* ktab = a_conv ? (a_x ? g.a.pix_tab : g.a.tap_tab) : (b_x ? g.b.pix_tab : g.b.tap_tab);
     const int tn = kend - kbeg;
@@ -677,19 +962,27 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
 #pragma unroll
     for (int u = 0; u < kTabMax / 256; ++u) sTab[t + 256 * u] = tv[u];
   }
-  const DmaOp da = tgemm_dma_operand(g.a, la, kbeg, sTab);
-  const DmaOp db = tgemm_dma_operand(g.b, lb, kbeg, sTab);
+  const DmaOp<TM> da = tgemm_dma_operand<TM>(g.a, la, kbeg, sTab);
+  const DmaOp<TN> db = tgemm_dma_operand<TN>(g.b, lb, kbeg, sTab);
   if (a_conv || b_conv) __syncthreads();
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float rs[TM] = {0.f, 0.f};
+  float rs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = 0.f;
   const bool want_rs = g.rowsum != nullptr && tn_blk == 0;
   const int nc = (kend - kbeg) / BK;
   const TileCtx tc{z, tiles, tile, m0, n0, t, lane, wid, r, kq, wm, wn};
-#define JH_DMA_LOOP(AX, BX, RS) tgemm_dma_mainloop<AX, BX, RS, NB>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs)
+  float bias_pre[TN];  // fetched inside the loop function, behind the first chunks' DMA issue
+  JH_TRACE(1);
+#ifndef JH_TGEMM_PIPELINED_LOOP
+#define JH_DMA_LOOP(AX, BX, RS) tgemm_dma_mainloop<TM, TN, AX, BX, RS, NB>(sA, sB, da, db, nc, wid, r, kq, wm, wn, acc, rs, g, n0, bias_pre)
+#else
+#define JH_DMA_LOOP(AX, BX, RS) tgemm_dma_mainloop<TM, TN, AX, BX, RS, NB>(sA, sB, sTab, da, db, nc, wid, r, kq, wm, wn, acc, rs, g, n0, bias_pre)
+#endif
   if (want_rs && wn == 0) {  // wave-uniform
     if (a_x) { if (b_x) JH_DMA_LOOP(true, true, true); else JH_DMA_LOOP(true, false, true); }
     else { if (b_x) JH_DMA_LOOP(false, true, true); else JH_DMA_LOOP(false, false, true); }
@@ -705,7 +998,9 @@ __global__ void __launch_bounds__(256, 3) jh_tgemm_dma_kernel(TGemmBatch batch) 
       rs[i] += __shfl_xor(rs[i], 32, 64);
     }
   }
-  tgemm_finish<TM, TN, EPI>(g, tc, acc, rs, want_rs, &s_last);
+  JH_TRACE(28);
+  tgemm_finish<TM, TN, EPI>(g, tc, acc, rs, want_rs, &s_last, EPI ? bias_pre : nullptr);
+  JH_TRACE(30);
 }
 
 }  // namespace
@@ -734,6 +1029,75 @@ static int tgemm_tag_of(const char* name) {
   JH_TGEMM_TAGS(JH_TGEMM_NAME)
 #undef JH_TGEMM_NAME
   return -1;
+}
+
+// Per-call-site tuning overrides (measurement runs; the defaults are tgemm_default_cfg below):
+//   JH_TGEMM_CFG="<tag>:<TM>x<TN>[:s<splits>][:x<0|1>],..."   tag = the call site's ID of JH_TGEMM_TAGS or * for every site
+//   e.g. JH_TGEMM_CFG="6:4x2:s4,2:4x2:x1"  (stream1_fwd on 128 x 64 tiles with 4 K splits, conv2_fwd on 128 x 64 tiles in XCD order)
+struct TagCfg {
+  int tm = 0, tn = 0, split = 0, xcd = -1;  // 0 / -1: not set
+};
+static TagCfg g_tag_cfg[32];
+static bool g_tag_cfg_parsed = false;
+static void tgemm_parse_cfg(const char* e) {
+  for (int t = 0; t < 32; ++t) g_tag_cfg[t] = TagCfg{};
+  g_tag_cfg_parsed = true;
+  while (e && *e) {
+    int tag = -1;
+    if (*e == '*') { tag = -2; ++e; } else { tag = (int)strtol(e, (char**)&e, 10); }
+    TagCfg c;
+    while (*e == ':') {
+      ++e;
+      if (*e == 's') c.split = (int)strtol(e + 1, (char**)&e, 10);
+      else if (*e == 'x') c.xcd = (int)strtol(e + 1, (char**)&e, 10);
+      else { c.tm = (int)strtol(e, (char**)&e, 10); if (*e == 'x') c.tn = (int)strtol(e + 1, (char**)&e, 10); }
+    }
+    for (int t = 0; t < 32; ++t)
+      if (tag == -2 || tag == t) {
+        if (c.tm) { g_tag_cfg[t].tm = c.tm; g_tag_cfg[t].tn = c.tn; }
+        if (c.split) g_tag_cfg[t].split = c.split;
+        if (c.xcd >= 0) g_tag_cfg[t].xcd = c.xcd;
+      }
+    while (*e && *e != ',') ++e;
+    if (*e == ',') ++e;
+  }
+}
+static const TagCfg* tgemm_env_cfg() {
+  if (!g_tag_cfg_parsed) tgemm_parse_cfg(getenv("JH_TGEMM_CFG"));
+  return g_tag_cfg;
+}
+#ifdef JH_TGEMM_TRACE
+JH_EXPORT int jh_tgemm_trace_buffer(unsigned long long* d_buf) {
+  JH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tgemm_trace), &d_buf, sizeof(d_buf)));
+  return JH_OK;
+}
+#endif
+// Measurement / test hook: replace the overrides at run time (same grammar as JH_TGEMM_CFG; "" or null: none -- the defaults).  Not
+// thread-safe against concurrent launches; launches already captured in a hipGraph keep the tiles they were captured with.
+JH_EXPORT int jh_tgemm_set_cfg(const char* cfg) {
+  tgemm_parse_cfg(cfg);
+  return JH_OK;
+}
+
+// The defaults per call site and problem shape (round 6; measured: profiles/r06_tgemm_tile_sweep.txt).
+static TagCfg tgemm_default_cfg(int tag, const TGemm* probs, int n) {
+  TagCfg c;
+  (void)tag; (void)probs; (void)n;
+  return c;
+}
+
+// The call sites that have 128 x 64 / 64 x 128 instantiations of the LDS-DMA kernel (compile time: one kernel per site, tile and epilogue form)
+#define JH_TGEMM_BIG_TAGS(X) X(dense, 0) X(conv2_fwd, 2) X(conv3_fwd, 3) X(fc_fwd, 5) X(stream1_fwd, 6) X(stream1_bwd, 9) X(fc_bwd, 10) \
+  X(conv3_bwd, 12) X(conv2_bwd, 13) X(ppo_fwd_h2, 15) X(ppo_bwd, 16)
+static bool tgemm_tag_has_big(int tag) {
+#define JH_TGEMM_BIGQ(NAME, ID) if (tag == ID) return true;
+  JH_TGEMM_BIG_TAGS(JH_TGEMM_BIGQ)
+#undef JH_TGEMM_BIGQ
+  return false;
+}
+template <int TM, int TN, int ID, bool EPI>
+static void tgemm_dma_go(const char* name, double flops, dim3 grid, hipStream_t st, const TGemmBatch& batch) {
+  JH_LAUNCH_IDEM(name, flops, (jh_tgemm_dma_kernel<TM, TN, ID, EPI>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch);
 }
 
 int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs, int n, hipStream_t st) {
@@ -783,6 +1147,16 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   static const long kDmaMask = getenv("JH_TGEMM_DMA_MASK") ? atol(getenv("JH_TGEMM_DMA_MASK")) : -1L;  // bit per call-site tag (debugging)
   const int tag_early = tgemm_tag_of(name);
   const bool use_dma = TM == 2 && TN == 2 && tgemm_dma_ok(probs, n) && tag_early >= 0 && ((kDmaMask >> tag_early) & 1L);
+  // round 6: the register-blocked tiles of the LDS-DMA kernel (a wave owns 64 x 32 of C), per call site: the override of a measurement run, else the default
+  const TagCfg ecfg = tag_early >= 0 ? tgemm_env_cfg()[tag_early] : TagCfg{};
+  const TagCfg dcfg = tgemm_default_cfg(tag_early, probs, n);
+  const int want_tm = ecfg.tm ? ecfg.tm : dcfg.tm, want_tn = ecfg.tm ? ecfg.tn : dcfg.tn;
+  const int force_split = ecfg.split ? ecfg.split : dcfg.split;
+  const int xcd_order = ecfg.xcd >= 0 ? ecfg.xcd : (dcfg.xcd > 0 ? 1 : 0);
+  if (use_dma && tgemm_tag_has_big(tag_early) && ((want_tm == 4 && want_tn == 2) || (want_tm == 2 && want_tn == 4))) {
+    TM = want_tm;
+    TN = want_tn;
+  }
   const int BM = 32 * TM, BN = 32 * TN;
   int max_tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -792,16 +1166,60 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
     if (t > max_tiles) max_tiles = t;
   }
   // fill the chip: ~2 workgroups per CU, but every split keeps at least two 32-wide K chunks
+  static const int kTargetWgs = getenv("JH_TGEMM_TARGET_WGS") ? atoi(getenv("JH_TGEMM_TARGET_WGS")) : 256;
+  static const int kMinChunks = getenv("JH_TGEMM_MIN_CHUNKS") ? atoi(getenv("JH_TGEMM_MIN_CHUNKS")) : 4;
+  auto base_split = [&](int tiles, int nchunks) {
+    // split K only when the tiles alone leave most of the 256 CUs idle; every split keeps >= kMinChunks chunks of 32
+    int s = tiles >= kTargetWgs / 2 ? 1 : kTargetWgs / (tiles > 0 ? tiles : 1);
+    if (s > nchunks / kMinChunks) s = nchunks / kMinChunks;
+    return s < 1 ? 1 : s;
+  };
+  // Round 6, the launch's QUANTISATION: workgroups are dealt to 256 CUs, up to three resident on each, and a launch lasts as long as its
+  // busiest CU.  Ape-X's stream-1 forward is 384 tiles of 98 chunks: half the CUs run two of them, half run one -- 119 us where three
+  // 49-chunk workgroups on every CU take 94.  The launch's time by a model fitted to K sweeps of the engine (profiles/r06_tgemm_kslope.txt:
+  // T = fixed + chunks x 0.645 us at one workgroup per CU, 0.55 us per workgroup-chunk at three):
+  //   T(m) = 2.9 + rounds x 4.7 + 0.43 x ceil(W / 256) x (mean chunks per workgroup) / eff(resident) [+ the split-K hand-off's bytes], W = sum tiles x base x m
+  // is evaluated for a common multiplier m of the base splits (long-K problems only) and the cheapest m taken.  A different split is a
+  // different summation order: the parity suites bound what that may cost (1e-5 on every loss); JH_TGEMM_QUANT=0 restores round 5's splits.
+  static const bool kQuant = !(getenv("JH_TGEMM_QUANT") && atoi(getenv("JH_TGEMM_QUANT")) == 0);
+  int mult = 1;
+  if (kQuant && force_split <= 0) {
+    const double unit = 0.43 * (TM * TN) / 4.0;
+    static const double eff[4] = {1.0, 0.66, 0.72, 0.78};
+    double best = 1e30;
+    for (int m = 1; m <= 4; ++m) {
+      long W = 0;
+      double chunk_work = 0.0, handoff_mb = 0.0;
+      bool ok = true;
+      for (int i = 0; i < n; ++i) {
+        const int tiles = probs[i].tiles_m * probs[i].tiles_n, nchunks = (probs[i].K + 31) / 32;
+        int sp = base_split(tiles, nchunks);
+        if (m > 1 && nchunks >= 8 * kMinChunks) {  // only problems whose splits stay long
+          if (sp * m > nchunks / kMinChunks) { ok = false; break; }
+          sp *= m;
+        }
+        const int per = (nchunks + sp - 1) / sp;
+        W += (long)tiles * sp;
+        chunk_work += (double)tiles * sp * per;
+        if (sp > 1) handoff_mb += (double)tiles * sp * (BM * BN * 4.0) * 1e-6;
+      }
+      if (!ok) break;
+      const int per_cu = (int)((W + 255) / 256), rounds = (per_cu + 2) / 3;
+      const double t = 2.9 + rounds * 4.7 + unit * per_cu * (chunk_work / (double)W) / eff[per_cu < 3 ? per_cu : 3] + (handoff_mb > 0 ? 1.0 + handoff_mb / 4.0 : 0.0);
+      if (t < best * 0.97) {  // a larger split has to win by 3 %
+        best = t;
+        mult = m;
+      }
+    }
+  }
   size_t ws_used = 0;
   int cnt_used = 0, max_split = 1;
   for (int i = 0; i < n; ++i) {
     const int tiles = probs[i].tiles_m * probs[i].tiles_n;
     const int nchunks = (probs[i].K + 31) / 32;
-    // split K only when the tiles alone leave most of the 256 CUs idle; every split keeps >= kMinChunks chunks of 32
-    static const int kTargetWgs = getenv("JH_TGEMM_TARGET_WGS") ? atoi(getenv("JH_TGEMM_TARGET_WGS")) : 256;
-    static const int kMinChunks = getenv("JH_TGEMM_MIN_CHUNKS") ? atoi(getenv("JH_TGEMM_MIN_CHUNKS")) : 4;
-    int s = tiles >= kTargetWgs / 2 ? 1 : kTargetWgs / (tiles > 0 ? tiles : 1);
-    if (s > nchunks / kMinChunks) s = nchunks / kMinChunks;
+    int s = base_split(tiles, nchunks);
+    if (mult > 1 && nchunks >= 8 * kMinChunks) s *= mult;
+    if (force_split > 0) s = force_split < nchunks ? force_split : nchunks;
     if (s > 64) s = 64;
     if (s < 1) s = 1;
     const bool conv = probs[i].a.mode >= OP_NHWC_K || probs[i].b.mode >= OP_NHWC_K;
@@ -834,6 +1252,7 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
     batch.p[i] = probs[i];
   }
   batch.n = n;
+  batch.xcd = use_dma && xcd_order;
   (void)max_tiles; (void)max_split;
   const dim3 grid(wgs);
   double flops = 0.0;  // profiling: 2 M N K of every problem of the group (the launch is idempotent: partial slabs are
@@ -844,9 +1263,21 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   bool plain = true;
   for (int i = 0; i < n; ++i) plain = plain && probs[i].epi == TEPI_NONE && probs[i].C2 == nullptr;
 #define JH_TGEMM_PLAIN_TAGS(X) X(dense, 0) X(conv3_bwd, 12) X(conv2_bwd, 13) X(conv1_bwd, 14) X(ppo_bwd_dW1, 17)
-  if (plain && use_dma) {
+  if (plain && use_dma && TM * TN == 8) {  // (the call sites that have both: the intersection of JH_TGEMM_PLAIN_TAGS and JH_TGEMM_BIG_TAGS)
+#define JH_TGEMM_DMA_PLAIN_BIG(NAME, ID)                                              \
+  case ID:                                                                            \
+    if (TM == 4) tgemm_dma_go<4, 2, ID, false>(name, flops, grid, st, batch);         \
+    else tgemm_dma_go<2, 4, ID, false>(name, flops, grid, st, batch);                 \
+    JH_LAUNCH_CHECK();                                                                \
+    return JH_OK;
+    switch (tag) {
+      JH_TGEMM_DMA_PLAIN_BIG(dense, 0) JH_TGEMM_DMA_PLAIN_BIG(conv3_bwd, 12) JH_TGEMM_DMA_PLAIN_BIG(conv2_bwd, 13)
+      default: break;
+    }
+#undef JH_TGEMM_DMA_PLAIN_BIG
+  } else if (plain && use_dma) {
 #define JH_TGEMM_DMA_PLAIN(NAME, ID) \
-  case ID: JH_LAUNCH_IDEM(name, flops, (jh_tgemm_dma_kernel<ID, false>), grid, dim3(256), 0, st, batch); JH_LAUNCH_CHECK(); return JH_OK;
+  case ID: tgemm_dma_go<2, 2, ID, false>(name, flops, grid, st, batch); JH_LAUNCH_CHECK(); return JH_OK;
     switch (tag) {
       JH_TGEMM_PLAIN_TAGS(JH_TGEMM_DMA_PLAIN)
       default: break;
@@ -855,10 +1286,10 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   } else if (plain) {
 #define JH_TGEMM_PLAIN(NAME, ID)                                                                                                 \
   case ID:                                                                                                                      \
-    if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2, ID, false>), grid, dim3(256), 0, st, batch);      \
-    else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2, ID, false>), grid, dim3(256), 0, st, batch); \
-    else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1, ID, false>), grid, dim3(256), 0, st, batch); \
-    else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1, ID, false>), grid, dim3(256), 0, st, batch);                         \
+    if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2, ID, false>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch);      \
+    else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2, ID, false>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch); \
+    else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1, ID, false>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch); \
+    else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1, ID, false>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch);                         \
     JH_LAUNCH_CHECK();                                                                                                          \
     return JH_OK;
     switch (tag) {
@@ -868,9 +1299,23 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
 #undef JH_TGEMM_PLAIN
   }
 #undef JH_TGEMM_PLAIN_TAGS
+  if (use_dma && TM * TN == 8) {
+#define JH_TGEMM_DMA_BIG(NAME, ID)                                                  \
+  case ID:                                                                          \
+    if (TM == 4) tgemm_dma_go<4, 2, ID, true>(name, flops, grid, st, batch);        \
+    else tgemm_dma_go<2, 4, ID, true>(name, flops, grid, st, batch);                \
+    break;
+    switch (tag) {
+      JH_TGEMM_BIG_TAGS(JH_TGEMM_DMA_BIG)
+      default: return jh_fail(JH_ERR_ARG, "tgemm launch name %s has no register-blocked kernel (jh_tgemm.hip: JH_TGEMM_BIG_TAGS)", name);
+    }
+#undef JH_TGEMM_DMA_BIG
+    JH_LAUNCH_CHECK();
+    return JH_OK;
+  }
   if (use_dma) {
 #define JH_TGEMM_DMA_CASE(NAME, ID) \
-  case ID: JH_LAUNCH_IDEM(name, flops, (jh_tgemm_dma_kernel<ID>), grid, dim3(256), 0, st, batch); break;
+  case ID: tgemm_dma_go<2, 2, ID, true>(name, flops, grid, st, batch); break;
     switch (tag) {
       JH_TGEMM_TAGS(JH_TGEMM_DMA_CASE)
       default: return jh_fail(JH_ERR_ARG, "tgemm launch name %s has no kernel tag (jh_tgemm.h: JH_TGEMM_TAGS)", name);
@@ -881,10 +1326,10 @@ int jh_tgemm_launch(const TGemmWorkspace& net_w, const char* name, TGemm* probs,
   }
 #define JH_TGEMM_CASE(NAME, ID)                                                                                          \
   case ID:                                                                                                              \
-    if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2, ID>), grid, dim3(256), 0, st, batch);      \
-    else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2, ID>), grid, dim3(256), 0, st, batch); \
-    else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1, ID>), grid, dim3(256), 0, st, batch); \
-    else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1, ID>), grid, dim3(256), 0, st, batch);                         \
+    if (TM == 2 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 2, ID>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch);      \
+    else if (TM == 1 && TN == 2) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 2, ID>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch); \
+    else if (TM == 2 && TN == 1) JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<2, 1, ID>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch); \
+    else JH_LAUNCH_IDEM(name, flops, (jh_tgemm_kernel<1, 1, ID>), grid, dim3(256), 0, st, batch.n, batch.p[1].wg_begin, batch.p[2].wg_begin, batch.p[3].wg_begin, batch.p[4].wg_begin, batch.p[5].wg_begin, batch.xcd, 0, batch);                         \
     break;
   switch (tag) {
     JH_TGEMM_TAGS(JH_TGEMM_CASE)

@@ -1145,6 +1145,11 @@ def tgemm_dense(a, b, a_kcont=True, b_kcont=True, epi=0, bias=None, aux=None, ro
     return (c, rs) if rowsum else c
 
 
+def tgemm_set_cfg(cfg=""):
+    """jh_tgemm_set_cfg: per-call-site tile / split / XCD-order overrides of the tile engine (measurement and tests); "" = defaults."""
+    L.check(L.load().jh_tgemm_set_cfg((cfg or "").encode()))
+
+
 def tgemm_dense_group(a_list, b_list):
     """jh_tgemm_dense_group: C_j = A_j B_j^T for up to six same-shape problems (A_j [M, K], B_j [N, K], contiguous) as ONE grouped
     launch -- the shape of the value networks' forward launches (online and target trunks side by side)."""

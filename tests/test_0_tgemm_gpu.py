@@ -1,5 +1,6 @@
 """Unit tests of the tile-GEMM engine under every value-network layer (jh_tgemm_*: LDS-tiled fp32 MFMA, grouped launches, split-K
-hand-offs, the LDS-DMA operand path) against float64 matmuls.  Named test_0_* so that the driver's `pytest -x` reaches the engine
+hand-offs, the LDS-DMA operand path, the register-blocked 128 x 64 / 64 x 128 tiles of round 6) against float64 matmuls computed ON THE CPU
+(numpy; no GPU library is the truth of any test -- VERDICT r5 weak #2).  Named test_0_* so that the driver's `pytest -x` reaches the engine
 first: in round 3 one marginal assert in a network-level test hid these (VERDICT r3 #1c)."""
 import numpy as np
 import pytest
@@ -24,10 +25,24 @@ def test_tgemm_grouped_split_k_is_exact_launch_after_launch(n, M, N, K):
         Cs = ops.tgemm_dense_group(As, Bs)
         torch.cuda.synchronize()
         for a, b, c in zip(As, Bs, Cs):
-            want = a.double() @ b.double().t()
-            err = ((c.double() - want).abs() / want.abs().max())
-            assert not bool(torch.isnan(err).any())
+            want = a.cpu().numpy().astype(np.float64) @ b.cpu().numpy().astype(np.float64).T
+            err = np.abs(c.cpu().numpy().astype(np.float64) - want) / np.abs(want).max()
+            assert not bool(np.isnan(err).any())
             margins.lt(float(err.max()), 1e-5, f"grouped split-K n{n} M{M} N{N} K{K}")
+
+
+def _truth(a2, b2, epi, bias, aux):
+    """float64 on the CPU: (want, scale) for C = a2 [M, K] @ b2 [K, N] with the engine's epilogues; scale = max sum_k |a||b| (what fp32
+    accumulation error is relative to)."""
+    a64, b64 = a2.cpu().numpy().astype(np.float64), b2.cpu().numpy().astype(np.float64)
+    want = a64 @ b64
+    if epi in (1, 2):
+        want = want + bias.cpu().numpy().astype(np.float64)
+    if epi == 2:
+        want = np.maximum(want, 0.0)
+    if epi == 3:
+        want = np.where(aux.cpu().numpy() > 0, want, 0.0)
+    return want, float((np.abs(a64) @ np.abs(b64)).max()) + 1e-9, a64
 
 
 def test_tgemm_dense_random_shapes_modes_and_epilogues_match_torch():
@@ -54,30 +69,20 @@ def test_tgemm_dense_random_shapes_modes_and_epilogues_match_torch():
         epi = case % 4
         bias = torch.randn(N, device="cuda", generator=g) if epi in (1, 2) else None
         aux = torch.randn(M, N, device="cuda", generator=g) if epi == 3 else None
-        want = a2.double() @ b2.double()
-        if epi in (1, 2):
-            want = want + bias.double()
-        if epi == 2:
-            want = want.clamp_min(0)
-        if epi == 3:
-            want = torch.where(aux > 0, want, torch.zeros_like(want))
+        want, scale, a64 = _truth(a2, b2, epi, bias, aux)  # fp32 accumulation error scales with sum |a||b|
         got, rs = ops.tgemm_dense(a_v, b_v, a_kcont=a_kc, b_kcont=b_kc, epi=epi, bias=bias, aux=aux, rowsum=True, M=M, N=N, K=K)
-        scale = float(a2.abs().double().matmul(b2.abs().double()).max()) + 1e-9  # fp32 accumulation error scales with sum |a||b|
-        err = float((got.double() - want).abs().max()) / scale
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - want).max()) / scale
         margins.lt(err, 2e-6, f"tgemm case {case} M{M} N{N} K{K} a_kc{a_kc} b_kc{b_kc} epi{epi}")
-        rs_err = float((rs.double() - a2.double().sum(1)).abs().max()) / (float(a2.abs().double().sum(1).max()) + 1e-9)
+        rs_err = float(np.abs(rs.cpu().numpy().astype(np.float64) - a64.sum(1)).max()) / (float(np.abs(a64).sum(1).max()) + 1e-9)
         margins.lt(rs_err, 2e-6, f"rowsum case {case} M{M} N{N} K{K}")
 
 
-def test_tgemm_dense_lds_dma_shapes_all_layouts_match_torch():
-    """Problems the LDS-DMA kernel takes (K % 32 == 0, 16-byte pieces, x-contiguous extents % 4 == 0; tiles that are and are not
-    full, K ranges that do and do not split, one to three chunk buffers' worth of K) in all four dense layouts, with every epilogue
-    and the fused row sums."""
+def _dma_cases(seed, label, reps=3, every=1):
     import torch
     from jorldy_amd import ops
 
-    g = torch.Generator(device="cuda").manual_seed(1)
-    rng = np.random.RandomState(1)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rng = np.random.RandomState(seed)
     for case in range(64):
         a_kc, b_kc = bool(case & 1), bool(case & 2)
         M = int(rng.choice([64, 65, 100, 512, 777] if a_kc else [64, 68, 132, 512, 1000]))
@@ -86,6 +91,8 @@ def test_tgemm_dense_lds_dma_shapes_all_layouts_match_torch():
         pad = 4 * int(rng.randint(2))
         A = torch.randn((M, K + pad) if a_kc else (K, M + pad), device="cuda", generator=g)
         Bm = torch.randn((N, K + pad) if b_kc else (K, N + pad), device="cuda", generator=g)
+        if case % every:
+            continue
         a_v = A[:, :K] if a_kc else A[:, :M]
         b_v = Bm[:, :K] if b_kc else Bm[:, :N]
         a2 = a_v if a_kc else a_v.t()
@@ -93,17 +100,51 @@ def test_tgemm_dense_lds_dma_shapes_all_layouts_match_torch():
         epi = (case >> 2) % 4
         bias = torch.randn(N, device="cuda", generator=g) if epi in (1, 2) else None
         aux = torch.randn(M, N, device="cuda", generator=g) if epi == 3 else None
-        want = a2.double() @ b2.double()
-        if epi in (1, 2):
-            want = want + bias.double()
-        if epi == 2:
-            want = want.clamp_min(0)
-        if epi == 3:
-            want = torch.where(aux > 0, want, torch.zeros_like(want))
-        for rep in range(3):
+        want, scale, a64 = _truth(a2, b2, epi, bias, aux)
+        for rep in range(reps):
             got, rs = ops.tgemm_dense(a_v, b_v, a_kcont=a_kc, b_kcont=b_kc, epi=epi, bias=bias, aux=aux, rowsum=True, M=M, N=N, K=K)
-            scale = float(a2.abs().double().matmul(b2.abs().double()).max()) + 1e-9
-            err = float((got.double() - want).abs().max()) / scale
-            margins.lt(err, 2e-6, f"tgemm dma case {case} rep {rep} M{M} N{N} K{K} a_kc{a_kc} b_kc{b_kc} epi{epi}")
-            rs_err = float((rs.double() - a2.double().sum(1)).abs().max()) / (float(a2.abs().double().sum(1).max()) + 1e-9)
-            margins.lt(rs_err, 2e-6, f"rowsum dma case {case} M{M} N{N} K{K}")
+            err = float(np.abs(got.cpu().numpy().astype(np.float64) - want).max()) / scale
+            margins.lt(err, 2e-6, f"tgemm dma {label} case {case} rep {rep} M{M} N{N} K{K} a_kc{a_kc} b_kc{b_kc} epi{epi}")
+            rs_err = float(np.abs(rs.cpu().numpy().astype(np.float64) - a64.sum(1)).max()) / (float(np.abs(a64).sum(1).max()) + 1e-9)
+            margins.lt(rs_err, 2e-6, f"rowsum dma {label} case {case} M{M} N{N} K{K}")
+
+
+def test_tgemm_dense_lds_dma_shapes_all_layouts_match_torch():
+    """Problems the LDS-DMA kernel takes (K % 32 == 0, 16-byte pieces, x-contiguous extents % 4 == 0; tiles that are and are not
+    full, K ranges that do and do not split, one to three chunk buffers' worth of K) in all four dense layouts, with every epilogue
+    and the fused row sums."""
+    _dma_cases(1, "64x64")
+
+
+@pytest.mark.parametrize("cfg", ["0:4x2", "0:2x4", "0:4x2:s3:x1", "0:2x4:s2", "0:2x2:x1", "0:4x2:s1"])
+def test_tgemm_register_blocked_tiles_all_layouts(cfg):
+    """Round 6: the same problems on the 128 x 64 / 64 x 128 workgroup tiles (a wave owns 64 x 32 of C), with forced K splits (the
+    split-K hand-off in fragment groups) and in XCD-contiguous grid order -- every layout, epilogue and the fused row sums."""
+    from jorldy_amd import ops
+
+    ops.tgemm_set_cfg(cfg)
+    try:
+        _dma_cases(2, cfg, reps=2)
+    finally:
+        ops.tgemm_set_cfg("")
+
+
+def test_tgemm_tile_shape_does_not_change_the_bits_at_equal_splits():
+    """The K order of an output element is the loop over 32-wide chunks and MFMA steps, not the tile: at the same number of K splits
+    the 64 x 64, 128 x 64 and 64 x 128 tiles give IDENTICAL bits (what lets a call site change tiles without touching parity)."""
+    import torch
+    from jorldy_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for (M, N, K, akc, bkc) in [(512, 1024, 3136, True, True), (1024, 3136, 512, False, False), (2048, 512, 512, True, False), (640, 192, 1024, False, True)]:
+        A = torch.randn((M, K) if akc else (K, M), device="cuda", generator=g)
+        Bm = torch.randn((N, K) if bkc else (K, N), device="cuda", generator=g)
+        outs = []
+        for cfg in ("0:2x2:s2", "0:4x2:s2", "0:2x4:s2", "0:4x2:s2:x1"):
+            ops.tgemm_set_cfg(cfg)
+            try:
+                outs.append(ops.tgemm_dense(A, Bm, a_kcont=akc, b_kcont=bkc, M=M, N=N, K=K).clone())
+            finally:
+                ops.tgemm_set_cfg("")
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), (M, N, K)
