@@ -129,9 +129,13 @@ class NativeValueNetMixin:
         Rainbow in training mode draws its noise exactly as NativeNet.__call__ does (torch.randn on the device: the same stream of
         draws).  -> int64 [N, 1]; None when this form does not apply (list-valued states, more rows than the network's batch)."""
         net = getattr(self, "_net", None)
-        if net is None or isinstance(state, list):
+        # the reference's as_tensor (base.py:61-73) takes torch tensors and any dtype: only ndarrays that copy into the slab without a lossy
+        # cast come this way, everything else takes the generic path (ADVICE r5: a CUDA tensor or a float64 observation raised here)
+        if net is None or not isinstance(state, np.ndarray) or state.ndim < 2:
             return None
-        x = np.asarray(state)
+        x = state
+        if not (x.dtype == np.uint8 and net.cnn) and not np.can_cast(x.dtype, np.float32, casting="same_kind"):
+            return None
         N = int(x.shape[0])
         if N < 1 or N > net.maxB:
             return None

@@ -42,10 +42,13 @@ struct Level {  // 2^k W forked envs: row 2 i + a = env i of the level above aft
   }
 };
 // dst rows 2 i + a <- src row i stepped with action a (auto-reset included: the row then holds the reset state)
-inline void fork_step(const jh_env_vtbl& vt, Level& dst, const void* src, int n_src) {
+// -> the env table's first error (jh_env_vtbl: obs / step return a negative JH_ERR_* and the run stops -- ADVICE r5: the speculative
+// steps dropped it, and a failing user env kept feeding stale rows into the store)
+inline int fork_step(const jh_env_vtbl& vt, Level& dst, const void* src, int n_src) {
   for (int i = 0; i < n_src; ++i) { vt.copy_row(dst.env, 2 * i, src, i); vt.copy_row(dst.env, 2 * i + 1, src, i); }
-  vt.step(dst.env, 0, 2 * n_src, dst.act.data(), dst.next.data(), dst.rw.data(), dst.dn.data());
-  vt.obs(dst.env, 0, 2 * n_src, dst.obs.data());
+  int rc = vt.step(dst.env, 0, 2 * n_src, dst.act.data(), dst.next.data(), dst.rw.data(), dst.dn.data());
+  if (rc) return rc;
+  return vt.obs(dst.env, 0, 2 * n_src, dst.obs.data());
 }
 inline void copy_level_row(const jh_env_vtbl& vt, Level& d, int di, const Level& s_, int si) {
   vt.copy_row(d.env, di, s_.env, si);
@@ -279,7 +282,15 @@ static void run_state_alloc(jh_collector* c) { c->run = new RunState(); }
 static void run_state_free(jh_collector* c) { delete static_cast<RunState*>(c->run); c->run = nullptr; }
 
 static int run_commit(jh_collector* c, RunState& r, int rc_in, const unsigned* wait_flag, unsigned wait_val, hipStream_t st) {
-  // commit what was staged (keeps the store consistent) and hand the capture slab back
+  // commit what was staged (keeps the store consistent) and hand the capture slab back.  A run that FAILED (an env error, the acting
+  // kernel gone with work queued behind it) appends nothing: its staging rows are half written
+  if (rc_in != JH_OK && wait_flag == nullptr) {
+    (void)jh_store_stage_abort(c->store, st);
+    if (r.cap_slab) (void)jh_ctx_slab_release(c->ctx, r.cap_slab, st);
+    r.cap_slab = nullptr;
+    for (int q = 0; q < 2; ++q) { c->ride_src[q] = nullptr; c->ride_dst[q] = nullptr; c->ride_bytes[q] = 0; }
+    return rc_in;
+  }
   const int A = c->A;
   const int64_t n = r.n;
   const void* xs[6]; void* xd[6]; int64_t xb[6]; int k = 0;
@@ -379,7 +390,10 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
     const bool extra = t == T;  // capture: one value-only query of the states the rollout ended in
     // current state of every env (reset state where it just finished)
     rc = c->vt.obs(c->env, 0, W, c->obs.data());
-    if (rc) return rc;
+    if (rc) {
+      if (persistent) jh_persist_abort(c->persist);
+      return rc;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     if (persistent) {
       const unsigned tag = jh_persist_publish(c->persist, W, c->obs.data());
@@ -439,7 +453,10 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
     const auto t1 = std::chrono::steady_clock::now();
     if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
     rc = c->vt.step(c->env, 0, W, c->cont ? (const void*)c->act_f.data() : (const void*)c->act_i.data(), c->next_obs.data(), c->reward.data(), c->done.data());
-    if (rc) return rc;
+    if (rc) {
+      if (persistent) jh_persist_abort(c->persist);
+      return rc;
+    }
     for (int w = 0; w < W; ++w) {
       const size_t row = (size_t)w * T + t;  // worker-major: w0 t0..tT-1, w1 ...  (distributed_manager.py:30)
       memcpy(st + S * row, c->obs.data() + (size_t)S * w, sizeof(float) * S);
@@ -509,8 +526,15 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   // rows 0 .. W-1: the envs' current states; rows W + 2 w + a: the state env w acts on next if it takes action a now
-  fork_step(vt, L1, e, W);
-  vt.obs(e, 0, W, pub.data());
+  // an env error anywhere in this loop: stop the acting kernel (it would poll for ~0.2 s otherwise) and return the error -- the caller's
+  // commit carries the abort value, nothing of this run reaches the store
+  auto env_failed = [&](int rc_env) {
+    jh_persist_abort(c->persist);
+    return rc_env;
+  };
+  int rc_env = fork_step(vt, L1, e, W);
+  if (!rc_env) rc_env = vt.obs(e, 0, W, pub.data());
+  if (rc_env) return env_failed(rc_env);
   memcpy(pub.data() + (size_t)W * S, L1.obs.data(), sizeof(float) * (size_t)2 * W * S);
   auto t0 = std::chrono::steady_clock::now();
   unsigned tag = jh_persist_publish(c->persist, 3 * W, pub.data());
@@ -520,8 +544,9 @@ static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_
     const int t_next = t + (two ? 2 : 1);
     const auto q0 = dbg ? now() : std::chrono::steady_clock::time_point();
     if (!extra) {  // the GPU is busy for ~5 us: run the env model two levels further meanwhile
-      fork_step(vt, L2, L1.env, 2 * W);
-      if (two && t_next < steps) fork_step(vt, L3, L2.env, 4 * W);
+      rc_env = fork_step(vt, L2, L1.env, 2 * W);
+      if (!rc_env && two && t_next < steps) rc_env = fork_step(vt, L3, L2.env, 4 * W);
+      if (rc_env) return env_failed(rc_env);
     }
     const auto q1 = dbg ? now() : q0;
     int rc = jh_persist_collect_rows(c->persist, nullptr, W, tag, hz.data());

@@ -125,6 +125,7 @@ struct jh_store {
 int jh_store_append(jh_store* s, int64_t n, const void* const* cols, hipMemcpyKind kind, hipStream_t st);
 int jh_store_stage_commit_extra(jh_store* s, int n_extra, const void* const* x_src, void* const* x_dst, const int64_t* x_bytes, hipStream_t st);
 bool jh_store_commit_is_one_launch(const jh_store* s, int64_t n);
+int jh_store_stage_abort(jh_store* s, hipStream_t st);
 int jh_store_stage_commit_gated(jh_store* s, int n_extra, const void* const* x_src, void* const* x_dst, const int64_t* x_bytes, const unsigned* gate,
                                 unsigned gate_val, hipStream_t st);
 

@@ -477,6 +477,20 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, 
         if (k + j >= o0 && k + j < o0 + hf.n) dst[j] = mine[j];
     }
   }
+  // a row narrower than the packed gradient (hidden 16 / 32 under Ant's 20 or Humanoid's 36 columns: ADVICE r5): the row's last thread also
+  // packs the columns [H, gld) -- nobody's k reaches them, and they stayed at their memset 0 = silently zero head gradients
+  if (H < gld && k == H - 4) {
+    for (int kk = H; kk < gld; kk += 4) {
+      float* dst = g_all + (size_t)b * gld + kk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) v = (o < hf.n && o0 + o == kk + j) ? gv[o] : v;
+        if (first || (kk + j >= o0 && kk + j < o0 + hf.n)) dst[j] = v;
+      }
+    }
+  }
 }
 
 // ============================================================================ clip_grad_norm_ + Adam
@@ -1226,7 +1240,7 @@ JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, co
                                    int32_t do_adam, float* d_stats, jh_stream stream) {
   JH_ARG(n && d_x && d_action && d_adv && d_ret && d_value_old && d_logp_old);
   JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
-  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update needs hidden_size %% 32 == 0 (H = %d)", n->H);
+  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update needs hidden_size %% 32 == 0 and at most 8 head outputs (H = %d, %d outputs: A + 1 discrete, 2 A + 1 continuous)", n->H, n->n_out);
   hipStream_t st = jh_s(stream);
   int rc = pponet_forward_partials(n, B, d_x, d_idx, st);
   if (rc) return rc;
@@ -1256,7 +1270,7 @@ JH_EXPORT int jh_pponet_ppo_update_dp_begin(jh_pponet* n, int32_t B, const float
                                             float ent_coef, float* d_critic_sums, jh_stream stream) {
   JH_ARG(n && d_x && d_action && d_adv && d_ret && d_value_old && d_logp_old && d_critic_sums);
   JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
-  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update_dp_begin needs hidden_size %% 32 == 0 (H = %d)", n->H);
+  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update_dp_begin needs hidden_size %% 32 == 0 and at most 8 head outputs (H = %d, %d outputs: A + 1 discrete, 2 A + 1 continuous)", n->H, n->n_out);
   hipStream_t st = jh_s(stream);
   int rc = pponet_forward_partials(n, B, d_x, d_idx, st);
   if (rc) return rc;
@@ -1268,9 +1282,10 @@ JH_EXPORT int jh_pponet_ppo_update_dp_end(jh_pponet* n, int32_t B, const float* 
                                           float ent_coef, float* d_stats, jh_stream stream) {
   JH_ARG(n && d_x && d_critic_sums);
   JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
+  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update_dp_end needs hidden_size %% 32 == 0 and at most 8 head outputs (H = %d, %d outputs: A + 1 discrete, 2 A + 1 continuous)", n->H, n->n_out);
   hipStream_t st = jh_s(stream);
-  const int vcol = n->cont ? 2 * n->A : n->A;  // the value head's column of g_all [B][8]
-  int rc = jh_ppo_critic_select(B, d_critic_sums, vf_coef, ent_coef, n->g_all + vcol, 8, n->dv2, n->stats_tmp, d_stats, st);
+  const int vcol = n->cont ? 2 * n->A : n->A;  // the value head's column of g_all [B][gld]
+  int rc = jh_ppo_critic_select(B, d_critic_sums, vf_coef, ent_coef, n->g_all + vcol, n->gld, n->dv2, n->stats_tmp, d_stats, st);
   if (rc) return rc;
   rc = jh_pmb_backward(n, B, d_x, d_idx, pmb_heads(n), false, st);
   if (rc) return rc;

@@ -156,6 +156,15 @@ JH_EXPORT int jh_store_stage_begin(jh_store* s, int64_t n, void** h_cols_out) {
   return JH_OK;
 }
 
+// Drop what was staged: the slab goes back, the ring does not move (internal: a collector run that failed half way must not append its
+// half-written rows -- ADVICE r5).
+int jh_store_stage_abort(jh_store* s, hipStream_t st) {
+  if (!s || !s->staged) return JH_OK;
+  const int rc = jh_ctx_slab_release(s->ctx, s->staged, st);
+  s->staged = nullptr;
+  return rc;
+}
+
 JH_EXPORT int jh_store_stage_commit(jh_store* s, jh_stream stream) { return jh_store_stage_commit_extra(s, 0, nullptr, nullptr, nullptr, jh_s(stream)); }
 
 // The commit with n_extra (<= 4) plain device-visible -> device copies in the SAME launch (internal: the collector's captured

@@ -18,6 +18,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib as L
+from .. import ops
 
 
 class VecCollector:
@@ -90,12 +91,20 @@ class PythonEnvTable:
         cont = env.action_type == "continuous"
         self._scratch = {}  # handle -> forked env (kept alive until fork_free)
         self._next_handle = 1
+        # fork_alloc / fork_free / copy_row have no status in the C table: an exception inside them is recorded here and the NEXT obs / step
+        # callback returns it, which stops the run (ctypes prints and swallows an exception that leaves a callback, and a
+        # copy_row that failed silently left the env row stale -- rollouts that were no longer the env's)
+        self._sticky = [0]
+        sticky = self._sticky
 
         def rows_of(handle):
             return env if handle in (None, 0) or handle == 1 << 62 else self._scratch[handle]
 
         def obs_cb(handle, r0, r1, out):
             try:
+                if sticky[0]:
+                    rc, sticky[0] = sticky[0], 0
+                    return rc
                 e, n = rows_of(handle), r1 - r0
                 buf = np.ctypeslib.as_array(out, shape=(n, S))
                 if e is env:
@@ -111,6 +120,9 @@ class PythonEnvTable:
 
         def step_cb(handle, r0, r1, action, nxt, rew, done):
             try:
+                if sticky[0]:
+                    rc, sticky[0] = sticky[0], 0
+                    return rc
                 e, n = rows_of(handle), r1 - r0
                 a = np.ctypeslib.as_array(C.cast(action, C.POINTER(C.c_float if cont else C.c_int64)), shape=(n, A) if cont else (n,))
                 args = (a, np.ctypeslib.as_array(nxt, shape=(n, S)), np.ctypeslib.as_array(rew, shape=(n,)), np.ctypeslib.as_array(done, shape=(n,)))
@@ -127,16 +139,29 @@ class PythonEnvTable:
 
         forkable = hasattr(env, "fork") and hasattr(env, "copy_row")
 
+        def failed():
+            import traceback
+
+            traceback.print_exc()
+            sticky[0] = -2
+
         def fork_alloc_cb(_handle, rows):
-            h = self._next_handle = self._next_handle + 1
-            self._scratch[h] = env.fork(int(rows))
-            return h
+            try:
+                h = self._next_handle = self._next_handle + 1
+                self._scratch[h] = env.fork(int(rows))
+                return h
+            except Exception:  # noqa: BLE001
+                failed()
+                return None  # null handle: the collector runs this env one timestep per exchange
 
         def fork_free_cb(handle):
             self._scratch.pop(handle, None)
 
         def copy_row_cb(dst, di, src, si):
-            rows_of(dst).copy_row(int(di), rows_of(src), int(si))
+            try:
+                rows_of(dst).copy_row(int(di), rows_of(src), int(si))
+            except Exception:  # noqa: BLE001
+                failed()
 
         self._cbs = (JhEnvVtbl.OBS(obs_cb), JhEnvVtbl.STEP(step_cb),
                      JhEnvVtbl.FORK_ALLOC(fork_alloc_cb) if forkable else JhEnvVtbl.FORK_ALLOC(),
@@ -193,7 +218,7 @@ class NativeCollector:
             self.lib.jh_collector_destroy(self.h)
         cols = (C.c_int32 * 5)(*[store.names.index(k) for k in ("state", "action", "reward", "next_state", "done")])
         h = C.c_void_p()
-        if getattr(self.env, "h", None) is not None:  # the library's own envs
+        if isinstance(self.env, (ops.CartPoleVec, ops.ControlVec)):  # the library's own envs (by type: a Python env may have an attribute `h` of its own)
             create = self.lib.jh_collector_create_control if cont else self.lib.jh_collector_create
             L.check(create(L.ctx(self.agent.device.index), net.h, self.env.h, store.h, cols, C.byref(h)))
         else:  # any other env: obs / step (/ fork) call back into Python

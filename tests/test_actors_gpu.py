@@ -99,6 +99,27 @@ def test_native_act_branch_equals_the_generic_one(name, extra, S):
     assert agent._act_greedy(np.zeros((agent._net.maxB + 1,) + (S if isinstance(S, tuple) else (S,)), np.uint8 if isinstance(S, tuple) else np.float32)) is None
 
 
+def test_act_takes_what_the_references_as_tensor_takes():
+    """base.py:61-73 as_tensor accepts torch tensors (CPU or CUDA) and any numeric dtype: act() gives the float32-ndarray answer for a
+    float64 ndarray (native branch, down-cast into the slab), for CPU / CUDA tensors and for a list-of-arrays state (generic branch)
+    instead of raising inside the native branch."""
+    from jorldy_amd.core.agent import Agent
+
+    torch.manual_seed(5)
+    np.random.seed(5)
+    agent = Agent("dqn", state_size=6, action_size=5, hidden_size=32, batch_size=8, buffer_size=64, start_train_step=0, device="cuda")
+    with torch.no_grad():
+        agent._net.params.add_(0.05 * torch.randn_like(agent._net.params))
+    agent.epsilon = agent.epsilon_eval = 0.0
+    x = np.random.RandomState(6).randn(4, 6).astype(np.float32)
+    want = agent.act(x, False)["action"]
+    assert agent._act_greedy(x.astype(np.float64)) is not None and np.array_equal(agent.act(x.astype(np.float64), False)["action"], want)
+    for other in (torch.from_numpy(x), torch.from_numpy(x).cuda(), torch.from_numpy(x).double()):
+        assert agent._act_greedy(other) is None  # not the native branch ...
+        assert np.array_equal(agent.act(other, False)["action"], want)  # ... and the generic one answers
+    assert agent._act_greedy(x.astype(np.complex64)) is None
+
+
 @pytest.mark.parametrize("name,extra,S", [
     ("ape_x", dict(network="dueling", head="cnn", n_step=3, num_workers=8), (4, 44, 52)),
     ("rainbow", dict(head="cnn", n_step=3, num_support=21, v_min=-1, v_max=10), (4, 44, 52)),

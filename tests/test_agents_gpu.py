@@ -357,7 +357,10 @@ def test_pponet_forward_backward_adam_vs_float64():
     from mirror.networks import Network
 
     # (the last three: more than 8 head outputs -- 13 / 13 / 17 -- on the separate forward / backward calls; the tiled engine at 13 outputs: test_baseline_width_gpu, ppo_cont_halfcheetah)
-    for cont, S, H, A, B in ((False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8), (True, 17, 64, 6, 100), (False, 5, 32, 12, 40), (True, 27, 128, 8, 200)):
+    # the last two: a hidden row NARROWER than the packed head gradient (Humanoid's 35 outputs = 36 columns over hidden 32, 19 outputs = 20 columns
+    # over hidden 16): the columns beyond the row were never packed and their head gradients silently zero
+    for cont, S, H, A, B in ((False, 4, 512, 2, 256), (True, 11, 64, 3, 100), (False, 7, 32, 5, 8), (True, 17, 64, 6, 100), (False, 5, 32, 12, 40), (True, 27, 128, 8, 200),
+                             (True, 45, 32, 17, 64), (True, 9, 16, 9, 33)):
         torch.manual_seed(0)
         ref64 = Network("continuous_policy_value" if cont else "discrete_policy_value", S, A, D_hidden=H).double()
         with torch.no_grad():
@@ -693,6 +696,71 @@ def test_c_collector_on_a_python_env_through_the_function_table(forkable):
     for a, b in zip(res["builtin"], res["python"]):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("forkable,where", [(False, "step"), (True, "step"), (True, "copy_row")])
+def test_c_collector_stops_when_the_env_fails(forkable, where, capfd):
+    """jh_env_vtbl's contract: obs / step return a negative status and the run STOPS.  A Python env that raises in the middle of a rollout --
+    in step (one and two timesteps per exchange: the speculative steps of the lookahead dropped the status until round 6) or in copy_row
+    (no status in the table: recorded, returned by the next callback) -- makes run() raise, and the failed run appends NOTHING to the
+    rollout store (its staging rows are half written).  The collector is usable again afterwards."""
+    from jorldy_amd import _lib as L
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+
+    W, T = 8, 16
+    torch.manual_seed(1)
+    np.random.seed(1)
+    agent = Agent("ppo", state_size=4, action_size=2, hidden_size=64, n_step=T, batch_size=64, n_epoch=1, device="cuda", seed=3, lr_decay=False)
+    agent.memory.first_store = False
+    env = _PyCartPole(W, seed=4, forkable=forkable)
+    calls = {"n": 0, "armed": False}
+    inner = env.step if where == "step" else env.copy_row
+
+    def flaky(*a, **k):
+        calls["n"] += 1
+        if calls["armed"] and calls["n"] > 9:
+            raise RuntimeError("simulator fell over")
+        return inner(*a, **k)
+
+    if where == "step":
+        env.step = flaky
+        if forkable:
+            env.fork = lambda rows: _flaky_fork(rows, flaky_owner=calls)
+    else:
+        env.copy_row = flaky
+    col = NativeCollector(env, agent, W)
+    col.run(T)  # a healthy run first
+    agent.process(None, T)
+    torch.cuda.synchronize()
+    assert agent.memory.size == 0
+    calls["armed"], calls["n"] = True, 0
+    with pytest.raises(L.JhError):
+        col.run(T)
+    torch.cuda.synchronize()
+    assert agent.memory.size == 0, "a failed run appended rows"
+    assert "simulator fell over" in capfd.readouterr().err
+    calls["armed"] = False
+    col.run(T)  # and the collector still works
+    torch.cuda.synchronize()
+    assert agent.memory.size == W * T
+    col.terminate()
+
+
+def _flaky_fork(rows, flaky_owner):
+    """A forked scratch env whose step shares the failure switch of the env it was forked from."""
+    e = _PyCartPole(rows, 0, True)
+    inner = e.step
+
+    def step(*a, **k):
+        flaky_owner["n"] += 1
+        if flaky_owner["armed"] and flaky_owner["n"] > 9:
+            raise RuntimeError("simulator fell over")
+        return inner(*a, **k)
+
+    e.step = step
+    e.fork = lambda r: _flaky_fork(r, flaky_owner)
+    return e
 
 
 @pytest.mark.parametrize("W", [8, 32])
