@@ -640,6 +640,28 @@ int jh_comm_allreduce_mean_f32(jh_comm* m, float* d_bucket, int64_t n, jh_stream
 int jh_comm_broadcast(jh_comm* m, void* d_buf, int64_t bytes, int32_t root, jh_stream stream);
 int jh_comm_allgather_f64(jh_comm* m, const double* d_in, double* d_out, int64_t n, jh_stream stream);
 
+/* ---- the same collectives through peer pointers (round 6): every rank of ONE node maps its peers' arenas (hipIpc) and the gradient
+ * bucket's all-reduce is two one-hop exchanges -- reduce-scatter by reading slice `rank` of every peer's bucket, all-gather by reading the
+ * peers' reduced slices -- inside two launches of this library, no collective library's launch and no ring (csrc/jh_peer.hip).  Chosen with
+ * JH_DP_COLLECTIVE=peer; RCCL (jh_comm_*) stays the default.  No reference counterpart.
+ *   jh_peer_create   this rank's arena for buckets of up to max_floats floats
+ *   jh_peer_handle   its 64-byte hipIpcMemHandle_t; the caller ships all ranks' handles to every rank (any side channel)
+ *   jh_peer_connect  h_handles: nranks x 64 bytes in rank order (the own entry is ignored)
+ *   jh_peer_allreduce_mean_f32   in place, d_bucket[i] <- mean over ranks; every slice is summed in rank order by ONE rank: identical bits on
+ *                    all ranks.  Capturable (sequence numbers advance on the device).  d_bucket 16-byte aligned.
+ *   jh_peer_allreduce_small_f32  <= 16 floats, sum (mean != 0: mean) over ranks in rank order, one single-workgroup launch
+ *   jh_peer_status   bounded waits (~2 s) that gave up since creation, completed all-reduces                                        */
+#define JH_PEER_HANDLE_BYTES 64
+typedef struct jh_peer jh_peer;
+int jh_peer_create(jh_ctx* ctx, int32_t nranks, int32_t rank, int64_t max_floats, jh_peer** out);
+int jh_peer_handle(jh_peer* p, void* h_handle64);
+int jh_peer_connect(jh_peer* p, const void* h_handles);
+int jh_peer_allreduce_mean_f32(jh_peer* p, float* d_bucket, int64_t n, jh_stream stream);
+int jh_peer_allreduce_small_f32(jh_peer* p, float* d_vals, int32_t n, int32_t mean, jh_stream stream);
+int jh_peer_status(jh_peer* p, int32_t* timeouts, int64_t* completed);
+void jh_peer_destroy(jh_peer* p);
+
+
 #ifdef __cplusplus
 }
 #endif

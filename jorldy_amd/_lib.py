@@ -169,6 +169,13 @@ _PROTOS = {
     "jh_comm_allreduce_mean_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "jh_comm_broadcast": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "jh_comm_allgather_f64": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "jh_peer_create": (C.c_int, [_vp, _i32, _i32, _i64, _vp]),
+    "jh_peer_handle": (C.c_int, [_vp, _vp]),
+    "jh_peer_connect": (C.c_int, [_vp, _vp]),
+    "jh_peer_allreduce_mean_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "jh_peer_allreduce_small_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "jh_peer_status": (C.c_int, [_vp, _vp, _vp]),
+    "jh_peer_destroy": (None, [_vp]),
 }
 
 _lib = None

@@ -1,0 +1,305 @@
+// Peer-pointer collectives for the data-parallel learners of ONE node (round 6, VERDICT r5 #2b): the gradient bucket's
+// all-reduce without a collective library's launch -- every rank READS its peers' memory through hipIpc pointers over xGMI.
+//
+// The DP step's collectives are latency, not bytes: 1.07 MB (PPO) at 7 x ~153 GB/s is ~2 us of wire, but a ring all-reduce is 2 (N - 1)
+// dependent hops behind a collective launch, 25-40 us per minibatch at 8 ranks.  xGMI is point to point: a rank can read
+// all seven peers at once.  So, per all-reduce (two launches of this file, no ring):
+//   reduce-scatter   every rank copies its bucket into its ARENA (an IPC-exported, fine-grained allocation every peer has mapped), raises a
+//                    flag word IN EVERY PEER's arena (a remote 4-byte store: the waiter then polls its own memory), waits for the peers'
+//                    flags, reads slice `rank` of every peer's bucket -- N - 1 concurrent remote reads of n / N floats --, sums them in RANK
+//                    ORDER (one owner per slice: the same bits reach every rank, deterministic), scales by 1 / N and publishes the slice
+//   all-gather       waits for the peers' slice flags and reads the N - 1 remote slices into the caller's bucket
+// = two one-hop exchanges.  A third entry point exchanges <= 16 floats (the exact critic's {sum e1, sum e2}) through per-rank mailboxes in
+// one single-workgroup launch.  Sequence numbers live in device memory and advance inside the launches, so a captured hipGraph replays them.
+// Every wait is bounded (~2 s of the 100 MHz clock): a rank that never shows up makes the others count a timeout (jh_peer_status) and
+// carry on with whatever they read, instead of hanging the device.
+//
+// Flag protocol: flag words only grow (sequence numbers); `in` is single-buffered (a rank rewrites it only after its own all-gather of the
+// previous call, which waited for every peer's slice flag = every peer is done reading `in`), `out` is double-buffered by sequence parity (a
+// peer may still gather call k while this rank reduces call k + 1; call k + 2's reduce waits for every peer's `in` flag of k + 2, raised
+// after that peer's gather of k + 1).
+//
+// The reference has no counterpart (one learner, Ray fan-out only: manager/distributed_manager.py:26-31).  RCCL (jh_comm_*) stays the
+// default transport; this one is chosen with JH_DP_COLLECTIVE=peer and is exercised by two processes on ONE GPU (IPC handles open across
+// processes on the same device) in tests/test_dp_two_ranks_gpu.py -- a multi-GPU node has not measured it yet.
+#include "jh_common.h"
+
+namespace {
+constexpr int kMaxRanks = 16;
+constexpr int kSmallMax = 16;
+constexpr int kCtlBytes = 16384;
+// control block at the head of every arena (offsets in bytes); written by PEERS, polled by the owner
+constexpr int kOffFlagsIn = 0, kOffFlagsOut = 256, kOffFlagsSmall = 512, kOffSmallBox = 1024;  // small_box [2][kMaxRanks][kSmallMax] floats = 2 KB
+
+struct PeerArgs {
+  char* arena[kMaxRanks];  // every rank's arena as THIS process sees it (own: the allocation itself)
+  int nranks, rank;
+  int64_t n, slice;        // floats in the bucket, floats per slice (multiple of 4)
+  size_t off_in, off_out, out_stride;  // byte offsets of `in` and `out[2]` in an arena
+  unsigned* seq;       // [4] device-private: [0] completed all-reduces, [1] completed small exchanges
+  unsigned* arrive;    // [4] device-private arrival counters
+  unsigned* err;       // [1] bounded waits that gave up
+  float* bucket;
+};
+
+__device__ __forceinline__ unsigned ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// thread 0 of the workgroup waits until words[p] >= seq for every rank p (its own included); everybody leaves with an acquire
+__device__ __forceinline__ void wait_all(const unsigned* words, int nranks, unsigned seq, unsigned* err) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int p = 0; p < nranks; ++p) {
+      while ((int)(ld_sys(words + p) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s of the 100 MHz clock
+          atomicAdd(err, 1u);
+          p = nranks;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: what the peers wrote before their flag
+}
+
+// the LAST workgroup of the grid to get here (everybody's stores released first) runs `f` on its thread 0
+template <typename F>
+__device__ __forceinline__ void last_arriver(unsigned* counter, F f) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this workgroup's stores are visible to the peers
+    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      f();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) jh_peer_reduce_scatter_kernel(PeerArgs a) {
+  const unsigned seq = a.seq[0] + 1u;
+  const int t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+  char* mine = a.arena[a.rank];
+  // 1. bucket -> in (the tail beyond n is never read)
+  {
+    float* in = (float*)(mine + a.off_in);
+    const int64_t n4 = a.n >> 2;
+    for (int64_t i = t; i < n4; i += nt) reinterpret_cast<float4*>(in)[i] = reinterpret_cast<const float4*>(a.bucket)[i];
+    for (int64_t i = (n4 << 2) + t; i < a.n; i += nt) in[i] = a.bucket[i];
+  }
+  // 2. the whole bucket is in place: raise "in ready" in every arena
+  last_arriver(a.arrive + 0, [&] {
+    for (int p = 0; p < a.nranks; ++p) st_sys((unsigned*)(a.arena[p] + kOffFlagsIn) + a.rank, seq);
+  });
+  // 3. every peer's bucket is in place
+  wait_all((const unsigned*)(mine + kOffFlagsIn), a.nranks, seq, a.err);
+  // 4. my slice of everybody's bucket, summed in rank order, / N -> out[parity]
+  {
+    const int64_t lo = (int64_t)a.rank * a.slice;
+    int64_t cnt = a.n - lo;
+    cnt = cnt < 0 ? 0 : (cnt > a.slice ? a.slice : cnt);
+    float* out = (float*)(mine + a.off_out + (size_t)(seq & 1u) * a.out_stride);
+    const float inv = 1.0f / (float)a.nranks;
+    const int64_t c4 = cnt >> 2;
+    for (int64_t i = t; i < c4; i += nt) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p = 0; p < a.nranks; ++p) {
+        const float4 v = reinterpret_cast<const float4*>((const float*)(a.arena[p] + a.off_in) + lo)[i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      reinterpret_cast<float4*>(out)[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    }
+    for (int64_t i = (c4 << 2) + t; i < cnt; i += nt) {
+      float s = 0.f;
+      for (int p = 0; p < a.nranks; ++p) s += ((const float*)(a.arena[p] + a.off_in))[lo + i];
+      out[i] = s * inv;
+    }
+  }
+  // 5. the slice is published
+  last_arriver(a.arrive + 1, [&] {
+    for (int p = 0; p < a.nranks; ++p) st_sys((unsigned*)(a.arena[p] + kOffFlagsOut) + a.rank, seq);
+  });
+}
+
+__global__ void __launch_bounds__(256) jh_peer_all_gather_kernel(PeerArgs a) {
+  const unsigned seq = a.seq[0] + 1u;
+  const int t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+  wait_all((const unsigned*)(a.arena[a.rank] + kOffFlagsOut), a.nranks, seq, a.err);
+  for (int p = 0; p < a.nranks; ++p) {
+    const int64_t lo = (int64_t)p * a.slice;
+    int64_t cnt = a.n - lo;
+    cnt = cnt < 0 ? 0 : (cnt > a.slice ? a.slice : cnt);
+    const float* src = (const float*)(a.arena[p] + a.off_out + (size_t)(seq & 1u) * a.out_stride);
+    const int64_t c4 = cnt >> 2;
+    for (int64_t i = t; i < c4; i += nt) reinterpret_cast<float4*>(a.bucket + lo)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (int64_t i = (c4 << 2) + t; i < cnt; i += nt) a.bucket[lo + i] = src[i];
+  }
+  last_arriver(a.arrive + 2, [&] { a.seq[0] = seq; });
+}
+
+// <= 16 floats summed over the ranks (rank order), one workgroup: mailbox [parity][from][16] in every arena
+__global__ void __launch_bounds__(64) jh_peer_small_kernel(PeerArgs a, float* vals, int n, float scale) {
+  const unsigned seq = a.seq[1] + 1u;
+  const int t = threadIdx.x;
+  const size_t box = kOffSmallBox + (size_t)(seq & 1u) * kMaxRanks * kSmallMax * sizeof(float);
+  if (t < n) {
+    const float v = vals[t];
+    for (int p = 0; p < a.nranks; ++p)
+      __hip_atomic_store((float*)(a.arena[p] + box) + a.rank * kSmallMax + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    for (int p = 0; p < a.nranks; ++p) st_sys((unsigned*)(a.arena[p] + kOffFlagsSmall) + a.rank, seq);
+  }
+  wait_all((const unsigned*)(a.arena[a.rank] + kOffFlagsSmall), a.nranks, seq, a.err);
+  if (t < n) {
+    float s = 0.f;
+    for (int p = 0; p < a.nranks; ++p)
+      s += __hip_atomic_load((const float*)(a.arena[a.rank] + box) + p * kSmallMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    vals[t] = s * scale;
+  }
+  __syncthreads();
+  if (t == 0) a.seq[1] = seq;
+}
+}  // namespace
+
+struct jh_peer {
+  jh_ctx* ctx = nullptr;
+  int nranks = 0, rank = 0;
+  int64_t max_floats = 0, slice_max = 0;
+  size_t arena_bytes = 0, off_in = 0, off_out = 0, out_stride = 0;
+  char* arena = nullptr;            // own arena (exported)
+  char* peer[kMaxRanks] = {};       // opened peers (own: arena)
+  bool opened[kMaxRanks] = {};
+  unsigned* priv = nullptr;         // seq[4] | arrive[4] | err[4]
+  bool connected = false;
+};
+
+JH_EXPORT int jh_peer_create(jh_ctx* ctx, int32_t nranks, int32_t rank, int64_t max_floats, jh_peer** out) {
+  JH_ARG(ctx && out);
+  JH_ARG(nranks >= 1 && nranks <= kMaxRanks && rank >= 0 && rank < nranks && max_floats > 0);
+  JH_HIP(hipSetDevice(ctx->device));
+  jh_peer* p = new jh_peer();
+  p->ctx = ctx; p->nranks = nranks; p->rank = rank; p->max_floats = max_floats;
+  p->slice_max = ((max_floats + nranks - 1) / nranks + 3) / 4 * 4;
+  p->off_in = kCtlBytes;
+  p->off_out = p->off_in + (((size_t)max_floats * 4 + 255) & ~(size_t)255);
+  p->out_stride = ((size_t)p->slice_max * 4 + 255) & ~(size_t)255;
+  p->arena_bytes = p->off_out + 2 * p->out_stride;
+  // fine-grained device memory: stores go through to the fabric, peers' reads are not served from a stale L2 line (what RCCL's own
+  // buffers are); plain hipMalloc when the platform refuses (the fences of the kernels then carry the visibility alone)
+  void* mem = nullptr;
+  bool fine = hipExtMallocWithFlags(&mem, p->arena_bytes, hipDeviceMallocFinegrained) == hipSuccess;
+  if (fine) {  // ... and it must be exportable
+    hipIpcMemHandle_t probe;
+    if (hipIpcGetMemHandle(&probe, mem) != hipSuccess) {
+      (void)hipFree(mem);
+      fine = false;
+    }
+  }
+  if (!fine) {
+    (void)hipGetLastError();
+    mem = nullptr;
+    if (hipMalloc(&mem, p->arena_bytes) != hipSuccess) {
+      delete p;
+      return jh_fail(JH_ERR_NOMEM, "jh_peer_create: %zu bytes of arena", p->arena_bytes);
+    }
+  }
+  p->arena = (char*)mem;
+  p->peer[rank] = p->arena;
+  if (hipMemset(p->arena, 0, p->arena_bytes) != hipSuccess || hipMalloc((void**)&p->priv, 64) != hipSuccess || hipMemset(p->priv, 0, 64) != hipSuccess) {
+    (void)hipFree(p->arena);
+    delete p;
+    return jh_fail(JH_ERR_HIP, "jh_peer_create: arena initialisation failed");
+  }
+  JH_HIP(hipDeviceSynchronize());
+  p->connected = nranks == 1;
+  *out = p;
+  return JH_OK;
+}
+
+JH_EXPORT int jh_peer_handle(jh_peer* p, void* h_handle64) {
+  JH_ARG(p && h_handle64);
+  static_assert(sizeof(hipIpcMemHandle_t) == JH_PEER_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+  JH_HIP(hipSetDevice(p->ctx->device));
+  hipIpcMemHandle_t h;
+  JH_HIP(hipIpcGetMemHandle(&h, p->arena));
+  memcpy(h_handle64, &h, sizeof(h));
+  return JH_OK;
+}
+
+JH_EXPORT int jh_peer_connect(jh_peer* p, const void* h_handles) {
+  JH_ARG(p && h_handles);
+  JH_HIP(hipSetDevice(p->ctx->device));
+  for (int r = 0; r < p->nranks; ++r) {
+    if (r == p->rank || p->opened[r]) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)h_handles + (size_t)r * JH_PEER_HANDLE_BYTES, sizeof(h));
+    void* ptr = nullptr;
+    JH_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    p->peer[r] = (char*)ptr;
+    p->opened[r] = true;
+  }
+  p->connected = true;
+  return JH_OK;
+}
+
+static PeerArgs peer_args(jh_peer* p, float* bucket, int64_t n) {
+  PeerArgs a{};
+  for (int r = 0; r < p->nranks; ++r) a.arena[r] = p->peer[r];
+  a.nranks = p->nranks; a.rank = p->rank; a.n = n;
+  a.slice = ((n + p->nranks - 1) / p->nranks + 3) / 4 * 4;
+  a.off_in = p->off_in; a.off_out = p->off_out; a.out_stride = p->out_stride;
+  a.seq = p->priv; a.arrive = p->priv + 4; a.err = p->priv + 8;
+  a.bucket = bucket;
+  return a;
+}
+
+JH_EXPORT int jh_peer_allreduce_mean_f32(jh_peer* p, float* d_bucket, int64_t n, jh_stream stream) {
+  JH_ARG(p && d_bucket && n > 0 && n <= p->max_floats);
+  JH_ARG(((uintptr_t)d_bucket & 15) == 0);
+  if (!p->connected) return jh_fail(JH_ERR_STATE, "jh_peer_allreduce_mean_f32 before jh_peer_connect");
+  const PeerArgs a = peer_args(p, d_bucket, n);
+  // few workgroups: the launches are latency (flag hand-offs), the bytes a fraction of a MB per rank; and every workgroup of a launch
+  // must be resident at once (they meet in the arrival counters)
+  int g = (int)((n / 4 + 255) / 256);
+  g = g < 1 ? 1 : (g > 64 ? 64 : g);
+  JH_LAUNCH(jh_peer_reduce_scatter_kernel, dim3(g), dim3(256), 0, jh_s(stream), a);
+  JH_LAUNCH_CHECK();
+  JH_LAUNCH(jh_peer_all_gather_kernel, dim3(g), dim3(256), 0, jh_s(stream), a);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+JH_EXPORT int jh_peer_allreduce_small_f32(jh_peer* p, float* d_vals, int32_t n, int32_t mean, jh_stream stream) {
+  JH_ARG(p && d_vals && n > 0 && n <= kSmallMax);
+  if (!p->connected) return jh_fail(JH_ERR_STATE, "jh_peer_allreduce_small_f32 before jh_peer_connect");
+  const PeerArgs a = peer_args(p, nullptr, 0);
+  JH_LAUNCH(jh_peer_small_kernel, dim3(1), dim3(64), 0, jh_s(stream), a, d_vals, (int)n, mean ? 1.0f / (float)p->nranks : 1.0f);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+JH_EXPORT int jh_peer_status(jh_peer* p, int32_t* timeouts, int64_t* completed) {
+  JH_ARG(p != nullptr);
+  unsigned h[12];
+  JH_HIP(hipMemcpy(h, p->priv, sizeof(h), hipMemcpyDeviceToHost));
+  if (timeouts) *timeouts = (int32_t)h[8];
+  if (completed) *completed = (int64_t)h[0];
+  return JH_OK;
+}
+
+JH_EXPORT void jh_peer_destroy(jh_peer* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < p->nranks; ++r)
+    if (p->opened[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
+  if (p->arena) (void)hipFree(p->arena);
+  if (p->priv) (void)hipFree(p->priv);
+  delete p;
+}

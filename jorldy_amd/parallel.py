@@ -21,7 +21,12 @@ class Transport:
       "torch"  torch.distributed collectives on device tensors (backend nccl; JH_DP_COLLECTIVE=torch, or when the
                library's communicator cannot be created).  Capturable.
       "host"   backend gloo: device tensors are staged through host memory around the collective.  This is the
-               two-ranks-on-one-GPU test transport (RCCL refuses two ranks on one device); never capturable."""
+               two-ranks-on-one-GPU test transport (RCCL refuses two ranks on one device); never capturable.
+      "peer"   JH_DP_COLLECTIVE=peer (round 6): the gradient bucket's mean and the <= 16-float exchanges through peer pointers
+               (jh_peer_* of the C ABI: every rank reads its peers' arenas over xGMI, two one-hop exchanges inside the library's
+               own launches, no collective library's launch and no ring); the process group -- any backend -- is the side
+               channel for the 64-byte IPC handles and still carries broadcasts / the float64 all-gather.  One node only.
+               Capturable.  Works across two processes on ONE GPU too (the functional test of tests/test_dp_two_ranks_gpu.py)."""
 
     def __init__(self, dist, group=None, device=None):
         self.dist, self.group = dist, group
@@ -35,7 +40,70 @@ class Transport:
             # end on the same transport (a per-rank try/except left ranks on different transports / off-by-one collectives)
             if self._create_comm(torch.device(device)):
                 self.kind = "rccl"
+        self.base_kind = self.kind  # what broadcasts / the float64 all-gather travel on when the bucket goes through peer pointers
+        self.peer = None
+        self._want_peer = os.environ.get("JH_DP_COLLECTIVE", "rccl") == "peer" and device is not None and torch.device(device).type == "cuda"
+        self._device = torch.device(device) if device is not None else None
         self.capturable = self.kind in ("rccl", "torch")
+
+    def ensure_peer(self, max_floats):
+        """COLLECTIVE (every rank, same order): with JH_DP_COLLECTIVE=peer, create this rank's arena for buckets of up to max_floats floats,
+        exchange the IPC handles over the process group and map the peers.  All ranks end on the peer transport or none does."""
+        if not self._want_peer or (self.peer is not None and self._peer_floats >= max_floats):
+            return self.kind == "peer"
+        import ctypes as C
+
+        from . import _lib as L
+
+        lib = L.load()
+        h, ok, err = C.c_void_p(), 1, None
+        handle = torch.zeros(64, dtype=torch.uint8)
+        try:
+            L.check(lib.jh_peer_create(L.ctx(self._device.index), self.world, self.rank, int(max_floats), C.byref(h)))
+            L.check(lib.jh_peer_handle(h, L.ptr(handle)))
+        except Exception as e:  # noqa: BLE001
+            ok, err = 0, e
+        parts = [torch.zeros(65, dtype=torch.uint8) for _ in range(self.world)]
+        mine = torch.cat([handle, torch.tensor([ok], dtype=torch.uint8)])
+        if self.base_kind == "host":
+            self.dist.all_gather(parts, mine, group=self.group)
+        else:
+            dev_parts = [q.to(self._device) for q in parts]
+            self.dist.all_gather(dev_parts, mine.to(self._device), group=self.group)
+            parts = [q.cpu() for q in dev_parts]
+        all_ok = all(int(q[64]) == 1 for q in parts)
+        if all_ok:
+            try:
+                handles = torch.cat([q[:64] for q in parts]).contiguous()
+                L.check(lib.jh_peer_connect(h, L.ptr(handles)))
+            except Exception as e:  # noqa: BLE001
+                all_ok, err = False, e
+        flag = torch.tensor([1 if all_ok else 0], dtype=torch.int32)
+        if self.base_kind == "host":
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        else:
+            f = flag.to(self._device)
+            self.dist.all_reduce(f, op=self.dist.ReduceOp.MIN, group=self.group)
+            flag = f.cpu()
+        if int(flag.item()) == 0:
+            if h:
+                lib.jh_peer_destroy(h)
+            print(f"[jorldy_amd] rank {self.rank}: peer-pointer transport unavailable ({type(err).__name__ if err else 'another rank failed'}: {err}); ALL ranks stay on {self.kind!r}")
+            self._want_peer = False
+            return False
+        if self.peer is not None:
+            lib.jh_peer_destroy(self.peer)
+        self.peer, self._peer_floats, self._lib, self._L = h, int(max_floats), lib, L
+        self.kind, self.capturable = "peer", True
+        return True
+
+    def peer_status(self):
+        """-> (bounded waits that gave up, completed all-reduces) of the peer transport."""
+        import ctypes as C
+
+        t, c = C.c_int32(), C.c_int64()
+        self._L.check(self._lib.jh_peer_status(self.peer, C.byref(t), C.byref(c)))
+        return t.value, c.value
 
     def _create_comm(self, device):
         """-> True when EVERY rank holds a working jh_comm communicator; otherwise nothing is left behind on any rank.
@@ -91,15 +159,27 @@ class Transport:
             if self.comm is not None:
                 self._lib.jh_comm_destroy(self.comm)
                 self.comm = None
+            if getattr(self, "peer", None) is not None:
+                self._lib.jh_peer_destroy(self.peer)
+                self.peer = None
         except Exception:
             pass
 
     # ---- the three collectives the learners need ----------------------------------------------------
     def mean_(self, flat):
         """flat (fp32, contiguous) <- mean over ranks, in place."""
-        if self.kind == "rccl":
+        if self.kind == "peer" and flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous():
+            n = int(flat.numel())
+            if n <= 16:
+                self._L.check(self._lib.jh_peer_allreduce_small_f32(self.peer, self._L.ptr(flat), n, 1, self._L.stream_ptr()))
+                return flat
+            if n <= self._peer_floats and flat.data_ptr() % 16 == 0:
+                self._L.check(self._lib.jh_peer_allreduce_mean_f32(self.peer, self._L.ptr(flat), n, self._L.stream_ptr()))
+                return flat
+        kind = self.base_kind if self.kind == "peer" else self.kind
+        if kind == "rccl":
             self._L.check(self._lib.jh_comm_allreduce_mean_f32(self.comm, self._L.ptr(flat), int(flat.numel()), self._L.stream_ptr()))
-        elif self.kind == "torch" or not flat.is_cuda:
+        elif kind == "torch" or not flat.is_cuda:
             self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
             flat.div_(self.world)
         else:
@@ -109,11 +189,12 @@ class Transport:
         return flat
 
     def broadcast_(self, t, src=0):
-        if self.kind == "rccl" and t.is_contiguous():
+        kind = self.base_kind if self.kind == "peer" else self.kind
+        if kind == "rccl" and t.is_contiguous():
             self._L.check(self._lib.jh_comm_broadcast(self.comm, self._L.ptr(t), int(t.numel() * t.element_size()), int(src), self._L.stream_ptr()))
             return t
         gsrc = self.dist.get_global_rank(self.group, src) if self.group is not None else src
-        if self.kind != "host" or not t.is_cuda:
+        if kind != "host" or not t.is_cuda:
             self.dist.broadcast(t, src=gsrc, group=self.group)
         else:
             h = t.cpu()
@@ -123,9 +204,10 @@ class Transport:
 
     def all_gather_f64_(self, out, loc):
         """out [world * n] <- the ranks' loc [n] (float64) in rank order."""
-        if self.kind == "rccl":
+        kind = self.base_kind if self.kind == "peer" else self.kind
+        if kind == "rccl":
             self._L.check(self._lib.jh_comm_allgather_f64(self.comm, self._L.ptr(loc), self._L.ptr(out), int(loc.numel()), self._L.stream_ptr()))
-        elif self.kind == "torch" or not loc.is_cuda:
+        elif kind == "torch" or not loc.is_cuda:
             self.dist.all_gather_into_tensor(out, loc, group=self.group)
         else:
             h = torch.empty(out.shape, dtype=out.dtype)
@@ -240,6 +322,7 @@ def attach_data_parallel(agent, dist, group=None):
     device = getattr(agent, "device", None)
     assert net is not None, "attach_data_parallel needs a jorldy_amd agent (its network lives in libjorldy_hip's flat buckets)"
     transport = Transport(dist, group, device)
+    transport.ensure_peer(int(net.grads.numel()))  # JH_DP_COLLECTIVE=peer: arenas + IPC handles (a collective step; no-op otherwise)
     sync = BucketSync(dist, group, transport)  # ops.PPONet / ops.RainbowNet: the gradient already IS one flat bucket
     sync.broadcast(net.params, net.m, net.v, *([net.target] if hasattr(net, "target") else []))  # identical start (ncclBroadcast only at init/load)
     mem = getattr(agent, "memory", None)

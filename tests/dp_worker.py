@@ -1,6 +1,8 @@
 """One rank of the two-ranks-on-one-GPU data-parallel tests (tests/test_dp_two_ranks_gpu.py).  Not a test module.
 
-usage: python tests/dp_worker.py <mode: ppo|rainbow> <rank> <world> <port> <out.npz> [gloo|nccl]
+usage: python tests/dp_worker.py <mode: ppo|rainbow|apex|peer_unit> <rank> <world> <port> <out.npz> [gloo|nccl]
+JH_DP_COLLECTIVE=peer in the environment: the gradient bucket and the critic sums travel through peer pointers (jh_peer_*, hipIpc handles
+opened across the two processes on the one GPU) instead of the host-staged gloo all-reduce, captured inside the learn() graph.
 nccl (= RCCL): rank r on GPU r -- the form the N-GPU bench runs; needs >= world GPUs (the driver's 8-GPU node).
 RCCL refuses two ranks on one device, gloo does not: the process group is gloo, the gradient bucket is staged through
 host memory around the all-reduce (jorldy_amd.parallel.Transport kind "host"); everything else -- the native agents'
@@ -58,6 +60,24 @@ def rainbow_agent(B, N, **kw):
     return agent
 
 
+def apex_agent(B, N, **kw):
+    """Ape-X (core/agent/ape_x.py) at a small MLP width: dueling network, n-step double-Q, PER with actor-side priorities, centered RMSprop,
+    gradient clipping -- the learner of config.ape_x.atari, one per rank, each with its own replay shard (north_star: "one learner per GPU
+    with RCCL all-reduce of gradients")."""
+    from jorldy_amd.core.agent import Agent
+
+    c = RB_CFG
+    agent = Agent("ape_x", state_size=c["S"], action_size=c["A"], hidden_size=c["H"], network="dueling", head="mlp",
+                  optim_config={"name": "rmsprop", "eps": 1.5e-7, "lr": 1e-3, "centered": True}, gamma=0.99, buffer_size=N, batch_size=B, clip_grad_norm=40.0,
+                  start_train_step=0, target_update_period=10000, run_step=100000, n_step=c["n_step"], alpha=0.6, beta=0.4, uniform_sample_prob=0.05,
+                  num_workers=4, device="cuda", **kw)
+    shapes = {k: v.shape for k, v in agent.network.state_dict().items()}
+    agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, 87).items()})
+    agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in synth.recipe_state_dict(shapes, 88).items()})
+    agent.memory.first_store = False
+    return agent
+
+
 def rainbow_shard(rank):
     """This rank's replay shard: rows + priorities (slot order)."""
     c = RB_CFG
@@ -81,10 +101,56 @@ def main():
     torch.cuda.set_device(rank if rccl else 0)
     kw = {"device_id": torch.device("cuda", rank)} if rccl else {}
     dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
-    kinds = ("rccl", "torch") if rccl else ("host",)
+    peer = os.environ.get("JH_DP_COLLECTIVE") == "peer"
+    kinds = ("peer",) if peer else (("rccl", "torch") if rccl else ("host",))
     res = {}
     try:
-        if mode == "ppo":
+        if mode == "peer_unit":
+            # jh_peer_* by themselves: buckets of awkward lengths (not multiples of 4 / of the rank count), many calls in a row (flag and
+            # buffer reuse), eager and replayed from a hipGraph; the small exchange in between
+            from jorldy_amd.parallel import Transport
+
+            tr = Transport(dist, None, torch.device("cuda", 0))
+            assert tr.ensure_peer(300_000) and tr.kind == "peer" and tr.capturable
+            g = torch.Generator().manual_seed(7)  # the SAME stream on both ranks: each knows the other's data
+            means, smalls = [], []
+            for n in (266_755, 17, 4096, 300_000, 33):
+                for it in range(3):
+                    both = torch.randn(world, n, generator=g)
+                    mine = both[rank].cuda()
+                    tr.mean_(mine)
+                    want = both[0]
+                    for r in range(1, world):
+                        want = want + both[r]  # rank order, fp32
+                    want = want * (1.0 / world)
+                    means.append(float((mine.cpu() - want).abs().max()))
+                    sm = torch.randn(world, 5, generator=g)
+                    v = sm[rank].cuda()
+                    tr._L.check(tr._lib.jh_peer_allreduce_small_f32(tr.peer, tr._L.ptr(v), 5, 0, tr._L.stream_ptr()))
+                    smalls.append(float((v.cpu() - sm.sum(0)).abs().max()))
+            # ... and from a captured graph: sequence numbers advance on the device
+            buf = torch.zeros(70_001, device="cuda")
+            gr = torch.cuda.CUDAGraph()
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):
+                tr.mean_(buf)  # warm
+                torch.cuda.synchronize()
+                with torch.cuda.graph(gr, stream=s_):
+                    tr.mean_(buf)
+            torch.cuda.synchronize()
+            graph_err = []
+            for it in range(6):
+                both = torch.randn(world, 70_001, generator=g)
+                buf.copy_(both[rank])
+                gr.replay()
+                torch.cuda.synchronize()
+                want = (both[0] + both[1]) * 0.5 if world == 2 else both.sum(0) / world
+                graph_err.append(float((buf.cpu() - want).abs().max()))
+            timeouts, done = tr.peer_status()
+            res = dict(means=np.asarray(means), smalls=np.asarray(smalls), graph_err=np.asarray(graph_err), timeouts=timeouts, done=done)
+            sync = type("S", (), {"transport": tr})()
+        elif mode == "ppo":
             c = PPO_CFG
             agent = ppo_agent(c["W"], c["B"])
             if rank == 1:  # attach must overwrite rank 1's weights with rank 0's
@@ -92,7 +158,7 @@ def main():
                     for p in agent.network.parameters():
                         p.add_(0.01)
             sync = attach_data_parallel(agent, dist)
-            assert sync.transport.kind in kinds and (rccl or not agent.graph_with_collective)
+            assert sync.transport.kind in kinds and (rccl or peer or not agent.graph_with_collective) and (not peer or agent.graph_with_collective)
             agent._predraw = None  # keep this learn()'s index lists in st["idx"] (no lists of a next learn() drawn ahead)
             np.random.seed(200 + rank)
             result = agent.process(ppo_rows(rank), c["T"])
@@ -100,10 +166,11 @@ def main():
             n_upd = c["E"] * (c["W"] * c["T"] // c["B"])
             perms = agent._static["idx"].cpu().numpy().reshape(c["E"], c["W"] * c["T"])  # the epochs' index lists this rank drew (np.random, seed 200 + rank)
             res = dict(params=agent._net.params.cpu().numpy(), perms=perms, stats=np.asarray(agent._static["stats_pin"].np[: n_upd + 1]).copy(),
-                       grads=agent._net.grads.cpu().numpy(), n_upd=n_upd, **{f"result_{k}": v for k, v in result.items()})
+                       grads=agent._net.grads.cpu().numpy(), n_upd=n_upd, graphed=int(agent._graph is not None),
+                       peer_timeouts=(sync.transport.peer_status()[0] if peer else 0), **{f"result_{k}": v for k, v in result.items()})
         else:
             c = RB_CFG
-            agent = rainbow_agent(c["B"], c["N"], use_graph=False)
+            agent = (apex_agent if mode == "apex" else rainbow_agent)(c["B"], c["N"], use_graph=peer)
             cols, prio = rainbow_shard(rank)
             agent.memory.store_soa(cols, priorities=prio)
             N = c["N"]
@@ -119,7 +186,8 @@ def main():
             torch.cuda.synchronize()
             st = agent._static
             res = dict(params=agent._net.params.cpu().numpy(), target=agent._net.target.cpu().numpy(), idx=st["idx"].cpu().numpy(), w=st["w"].cpu().numpy(),
-                       tree_before=tree_before, count_before=count_before, beta=agent.beta, usp=agent.uniform_sample_prob, losses=np.asarray(losses), N=N)
+                       tree_before=tree_before, count_before=count_before, beta=agent.beta, usp=agent.uniform_sample_prob, losses=np.asarray(losses), N=N,
+                       tree_after=agent.memory.sum_tree.copy(), peer_timeouts=(sync.transport.peer_status()[0] if peer else 0))
         dist.barrier()
     finally:
         dist.destroy_process_group()
