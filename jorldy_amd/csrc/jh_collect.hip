@@ -74,6 +74,8 @@ struct jh_collector {
   std::vector<float> obs, next_obs, reward, heads, act_f;
   std::vector<int64_t> act_i;
   std::vector<uint8_t> done;
+  double dbg_publish = 0.0, dbg_wait = 0.0;  // JH_COLLECT_DEBUG
+  long dbg_n = 0;
   jh_persist* persist = nullptr;  // null: one launch per timestep
   int mode = 1;                   // 1: persistent acting kernel (default), 0: launch per step (JH_COLLECT_PERSISTENT=0)
   // lookahead = 2 (discrete two-action envs that can be forked on the host, 3 W <= 32 rows): every PCIe round trip carries each
@@ -396,8 +398,17 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
     }
     const auto t0 = std::chrono::steady_clock::now();
     if (persistent) {
+      static const bool dbg1 = getenv("JH_COLLECT_DEBUG") != nullptr;
+      const auto d0 = dbg1 ? std::chrono::steady_clock::now() : t0;
       const unsigned tag = jh_persist_publish(c->persist, W, c->obs.data());
+      const auto d1 = dbg1 ? std::chrono::steady_clock::now() : t0;
       rc = jh_persist_collect(c->persist, W, tag, c->heads.data());
+      if (dbg1) {  // JH_COLLECT_DEBUG=1: publish / wait + read of an exchange, summed per collector (printed every 16th run below)
+        const auto d2 = std::chrono::steady_clock::now();
+        c->dbg_publish += std::chrono::duration<double>(d1 - d0).count();
+        c->dbg_wait += std::chrono::duration<double>(d2 - d1).count();
+        c->dbg_n += 1;
+      }
       if (rc) {  // the kernel gave up (it exits by itself)
         jh_persist_abort(c->persist);
         if (r.early)  // the commit launch and the learner are already queued behind it on this stream: no per-step launches possible
@@ -472,6 +483,12 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
     c->steps += 1;
   }
   if (persistent && getenv("JH_PERSIST_DEBUG") && (c->runs % 16) == 15) jh_persist_dump_debug(c->persist, T);
+  if (c->dbg_n > 0 && (c->runs % 4) == 3) {
+    fprintf(stderr, "[jh_collect] one timestep per exchange, per step: publish %.2f us, wait + read of the heads %.2f us (sampling + bookkeeping + env step: the rest of act / env)\n",
+            c->dbg_publish / c->dbg_n * 1e6, c->dbg_wait / c->dbg_n * 1e6);
+    c->dbg_publish = c->dbg_wait = 0.0;
+    c->dbg_n = 0;
+  }
   return JH_OK;
 }
 

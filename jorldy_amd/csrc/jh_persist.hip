@@ -52,6 +52,7 @@ struct PersistArgs {
   unsigned long long* dbg;             // optional [T][8]: per-step timestamps of workgroup 0 (diagnostics)
   int period;                          // spacing of the polls in flight, wall_clock64 ticks (10 ns)
   unsigned long long* mbox;            // device memory [64] granules: relay of the observations (null: every workgroup polls the host)
+  float4* dpart;                       // device memory [row tiles][G][16 rows][tiles] granules, or null: round 6, the partial heads are summed ON THE DEVICE
 };
 
 // One poll: lanes 0..n16-1 of the calling wave each fetch 16 bytes (two granules) of the observation area
@@ -306,10 +307,62 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
       const int g = lane >> 4, row = lane & 15;
       if (g < p.G && 16 * rt + row < p.W) {
         const f32x4 gq = (f32x4){s_out[row][3 * g], s_out[row][3 * g + 1], s_out[row][3 * g + 2], __uint_as_float(tag)};
-        float4* dst = p.part + ((size_t)tile * p.G + g) * p.rows_ld + 16 * rt + row;
-        // write-through system-scope 16-byte store (a plain store lingers in L2 for milliseconds); hipcc does not
-        // track asm stores: the s_nop keeps the data registers intact until the store has read them (CDNA guide §5.7)
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
+        // write-through 16-byte store (a plain store lingers in L2 for milliseconds); hipcc does not track asm stores: the s_nop keeps
+        // the data registers intact until the store has read them (CDNA guide §5.7).  Host memory, or -- round 6 -- the device-side
+        // mailbox of this (row tile, g, row): the column tiles' granules side by side for the reducing wave below
+        if (p.dpart) {
+          float4* dst = p.dpart + ((size_t)(rt * p.G + g) * 16 + row) * tiles_n + tile;
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
+        } else {
+          float4* dst = p.part + ((size_t)tile * p.G + g) * p.rows_ld + 16 * rt + row;
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
+        }
+      }
+    }
+    // ---- round 6: the column tiles' partial heads are summed on the DEVICE.  With every workgroup answering the host
+    // itself, a step of config.ppo.mujoco's 32 workers x 7 outputs sent 32 tiles x 3 granules x 32 rows = 48 KB over PCIe and the host
+    // read and added them (18.7 us per exchange).  Now wave 1 of column tile 0 -- idle from here to the next step -- collects the 32 tiles'
+    // granules of its (g, row) from the device mailbox (agent-coherent 16-byte loads, the granule's tag is its flag), adds them IN TILE
+    // ORDER (the host's order: the same bits) and sends ONE granule per (row, g) to the host, into tile 0's slots.
+    if (p.dpart && tile == 0 && wid == 1) {
+      const int g = lane >> 4, row = lane & 15;
+      if (g < p.G && 16 * rt + row < p.W) {
+        const float4* src = p.dpart + ((size_t)(rt * p.G + g) * 16 + row) * tiles_n;
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        bool ok = true;
+        for (int t0 = 0; t0 < tiles_n && ok; t0 += 8) {
+          f32x4 q[8];
+          const bool hi = t0 + 4 < tiles_n;       // tiles_n = 4 (hidden 64): the second four loads re-read the first four and are dropped
+          const float4* a0 = src + t0;
+          const float4* a1 = hi ? a0 + 4 : a0;
+          long spin = 0;
+          for (;;) {
+            // the loads of one round and their wait are ONE asm statement (early-clobber outputs: see jh_tgemm.hip's split-K reduce)
+            asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+                         "global_load_dwordx4 %3, %8, off offset:48 sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
+                         "global_load_dwordx4 %6, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                         : "v"(a0), "v"(a1)
+                         : "memory");
+            bool all = true, newer = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const unsigned seen = __float_as_uint(q[j][3]);
+              all = all && seen == tag;
+              newer = newer || (int)(seen - tag) > 0;  // a later step's granule: this step's answer is no longer wanted (nobody waits for it)
+            }
+            if (all) break;
+            if (newer || ++spin > 2000000L || ((spin & 1023) == 1023 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { ok = false; break; }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (ok && (j < 4 || hi)) { z0 += q[j][0]; z1 += q[j][1]; z2 += q[j][2]; }
+        }
+        if (ok) {
+          const f32x4 gq = (f32x4){z0, z1, z2, __uint_as_float(tag)};
+          float4* dst = p.part + (size_t)g * p.rows_ld + 16 * rt + row;
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
+        }
       }
     }
     // no end-of-step barrier: s_x / s_acc alternate by step parity, s_h2 / s_out belong to wave 0
@@ -332,6 +385,8 @@ struct jh_persist {
   int rows_ld = 16;  // rows per (tile, g) block of `part` in the running kernel: 16 RT
   unsigned long long *dbg_h = nullptr, *dbg_d = nullptr;
   unsigned long long* mbox = nullptr;  // device: relay of the observation granules
+  float4* dpart = nullptr;             // device: the column tiles' partial heads, summed by a wave of the kernel (round 6)
+  bool reduced = false;                // the running kernel answers with ONE granule per (row, g) in tile 0's slots
   int rows_published = 0;              // rows of the last jh_persist_publish (a two-timestep exchange carries more rows than its first read asks for)
 };
 
@@ -360,6 +415,8 @@ int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
   JH_HIP(hipMalloc((void**)&p->mbox, sizeof(unsigned long long) * kPersistMaxGranules));
   JH_HIP(hipMemset(p->mbox, 0, sizeof(unsigned long long) * kPersistMaxGranules));
+  JH_HIP(hipMalloc((void**)&p->dpart, sizeof(float4) * 2 * 4 * 16 * (size_t)p->tiles));
+  JH_HIP(hipMemset(p->dpart, 0, sizeof(float4) * 2 * 4 * 16 * (size_t)p->tiles));
   memset(p->gran_h, 0, sizeof(unsigned long long) * kPersistMaxGranules);
   memset(p->flag_h, 0, sizeof(unsigned) * 16);
   if (getenv("JH_PERSIST_DEBUG")) {
@@ -379,6 +436,7 @@ void jh_persist_destroy(jh_persist* p) {
   (void)hipHostFree(p->part_h);
   (void)hipHostFree(p->flag_h);
   (void)hipFree(p->mbox);
+  (void)hipFree(p->dpart);
   if (p->dbg_d) (void)hipFree(p->dbg_d);
   free(p->dbg_h);
   delete p;
@@ -418,6 +476,12 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.period = depth > 1 ? period : 0;
   static const int relay = getenv("JH_PERSIST_RELAY") ? atoi(getenv("JH_PERSIST_RELAY")) : 1;
   a.mbox = relay ? p->mbox : nullptr;
+  // device-side sum of the partial heads: JH_PERSIST_REDUCE = 1 always | 0 never | unset: when a step's answer is more than one granule per
+  // (tile, row) or has two row tiles (config.ppo.mujoco: 48 KB per step otherwise); config.ppo.cartpole's 24 rows x 1 granule stay on the
+  // direct path (measured: profiles/r06_ab_persist_device_reduce.txt)
+  static const int reduce = getenv("JH_PERSIST_REDUCE") ? atoi(getenv("JH_PERSIST_REDUCE")) : -1;
+  p->reduced = reduce == 1 || (reduce < 0 && (p->G > 1 || W > 16));
+  a.dpart = p->reduced ? p->dpart : nullptr;
   a.max_polls = 600000;  // x (>= 0.3 us per consumed poll) = >= 0.2 s without observations -> give up
   p->flag_h[0] = 0;
   const int nch = n->H / 64;
@@ -455,7 +519,7 @@ unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs) {
 // Wait until every tile's granules of the listed rows (rows == NULL: rows 0 .. n_rows-1) carry `tag`, then sum the per-tile partials
 // in tile order: h_heads [n_rows][n_out] raw head outputs (logits | mu_raw, log_std_raw; value last).  JH_ERR_STATE if the kernel gave up.
 int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned tag, float* h_heads) {
-  const int n_out = p->n_out, G = p->G, ld = p->rows_ld, tiles = p->tiles;
+  const int n_out = p->n_out, G = p->G, ld = p->rows_ld, tiles = p->reduced ? 1 : p->tiles;  // (reduced: the device summed the tiles; tile 0's slots hold the answer)
   volatile unsigned* abort_w = p->flag_h;
   // [tiles][G][ld] granules of 16 bytes {out, out, out, tag}: ONE 16-byte load per granule serves the tag check and the sum (the
   // device's 16-byte store is one PCIe write: tag and payload arrive together); a row is summed tile by tile as its granules are
