@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
   __shared__ float s_b2[16], s_hb[12];
   __shared__ __attribute__((aligned(16))) float s_out[16][12];
   __shared__ int s_go[2];
+  __shared__ __attribute__((aligned(16))) f32x4 s_red[32][64];  // device-side sum of the partial heads: [column tile][(g, row) lane] granules (32 KB)
   const int H = p.H, S = p.S;
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: an SGPR
   // grid = (H / 16 column tiles) x (row tiles of 16): workgroup (tile, rt) owns rows 16 rt .. 16 rt + 15 of column tile `tile`.
@@ -320,50 +321,62 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
       }
     }
     // ---- round 6: the column tiles' partial heads are summed on the DEVICE.  With every workgroup answering the host
-    // itself, a step of config.ppo.mujoco's 32 workers x 7 outputs sent 32 tiles x 3 granules x 32 rows = 48 KB over PCIe and the host
-    // read and added them (18.7 us per exchange).  Now wave 1 of column tile 0 -- idle from here to the next step -- collects the 32 tiles'
-    // granules of its (g, row) from the device mailbox (agent-coherent 16-byte loads, the granule's tag is its flag), adds them IN TILE
-    // ORDER (the host's order: the same bits) and sends ONE granule per (row, g) to the host, into tile 0's slots.
-    if (p.dpart && tile == 0 && wid == 1) {
+    // itself, a step of config.ppo.mujoco's 32 workers x 7 outputs sends 32 tiles x 3 granules x 32 rows = 48 KB over PCIe and the host
+    // gathers and adds them (14 us from publication to the last granule read).  Here column tile 0's workgroup -- idle from now to the next
+    // step -- collects the tiles' granules from the device mailbox: its four waves each fetch a quarter of the tiles for every (g, row)
+    // lane (agent-coherent 16-byte loads, all of a wave's in flight together; the granule's tag is its flag) into LDS, then ONE wave adds
+    // them IN TILE ORDER (the host's order: the same bits) and sends one granule per (row, g) to the host, into tile 0's slots.
+    if (p.dpart && tile == 0) {
       const int g = lane >> 4, row = lane & 15;
-      if (g < p.G && 16 * rt + row < p.W) {
-        const float4* src = p.dpart + ((size_t)(rt * p.G + g) * 16 + row) * tiles_n;
-        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        bool ok = true;
-        for (int t0 = 0; t0 < tiles_n && ok; t0 += 8) {
-          f32x4 q[8];
-          const bool hi = t0 + 4 < tiles_n;       // tiles_n = 4 (hidden 64): the second four loads re-read the first four and are dropped
-          const float4* a0 = src + t0;
-          const float4* a1 = hi ? a0 + 4 : a0;
-          long spin = 0;
-          for (;;) {
-            // the loads of one round and their wait are ONE asm statement (early-clobber outputs: see jh_tgemm.hip's split-K reduce)
-            asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
-                         "global_load_dwordx4 %3, %8, off offset:48 sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
-                         "global_load_dwordx4 %6, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
-                         : "v"(a0), "v"(a1)
-                         : "memory");
-            bool all = true, newer = false;
+      const bool mine = g < p.G && 16 * rt + row < p.W;
+      const int per = tiles_n / 4;  // tiles per wave: 1, 2, 4, 8 (hidden 64 .. 512)
+      bool ok = true;
+      if (mine) {
+        const float4* src = p.dpart + ((size_t)(rt * p.G + g) * 16 + row) * tiles_n + wid * per;
+        f32x4 q[8];
+        long spin = 0;
+        for (;;) {
+          // the loads of one round and their wait are ONE asm statement (early-clobber outputs: see jh_tgemm.hip's split-K reduce); a wave
+          // with fewer than 8 tiles re-reads its last one (clamped offsets) and drops the copies
+          const float4* a1 = per > 4 ? src + 4 : src;
+          asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+                       "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %12, off offset:16 sc1\n\t"
+                       "global_load_dwordx4 %6, %12, off offset:32 sc1\n\tglobal_load_dwordx4 %7, %12, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                       : "v"(src), "v"(src + (per > 1 ? 1 : 0)), "v"(src + (per > 2 ? 2 : 0)), "v"(src + (per > 2 ? 3 : 0)), "v"(a1)
+                       : "memory");
+          bool all = true, newer = false;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const unsigned seen = __float_as_uint(q[j][3]);
+          for (int j = 0; j < 8; ++j) {
+            const unsigned seen = __float_as_uint(q[j][3]);
+            if (j < per) {  // (the clamped re-reads beyond this wave's tiles are somebody else's granules: not waited for)
               all = all && seen == tag;
               newer = newer || (int)(seen - tag) > 0;  // a later step's granule: this step's answer is no longer wanted (nobody waits for it)
             }
-            if (all) break;
-            if (newer || ++spin > 2000000L || ((spin & 1023) == 1023 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { ok = false; break; }
           }
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (ok && (j < 4 || hi)) { z0 += q[j][0]; z1 += q[j][1]; z2 += q[j][2]; }
+          if (all) break;
+          if (newer || ++spin > 2000000L || ((spin & 1023) == 1023 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { ok = false; break; }
         }
-        if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < per) s_red[wid * per + j][lane] = ok ? q[j] : (f32x4){0.f, 0.f, 0.f, __uint_as_float(tag + 0x40000000u)};  // (a tag no step carries: the row is dropped below)
+      }
+      __syncthreads();  // (uniform: every wave of this workgroup is here)
+      if (wid == 1 && mine) {
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        bool good = true;
+        for (int tt = 0; tt < tiles_n; ++tt) {
+          const f32x4 v = s_red[tt][lane];
+          good = good && __float_as_uint(v[3]) == tag;
+          z0 += v[0]; z1 += v[1]; z2 += v[2];
+        }
+        if (good) {
           const f32x4 gq = (f32x4){z0, z1, z2, __uint_as_float(tag)};
           float4* dst = p.part + (size_t)g * p.rows_ld + 16 * rt + row;
           asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(gq) : "memory");
         }
       }
+      // (s_red is rewritten one step later, behind the next step's barriers: the summing wave is long done)
     }
     // no end-of-step barrier: s_x / s_acc alternate by step parity, s_h2 / s_out belong to wave 0
     if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[(t - 1) * 8 + 4] = wall_clock64(); p.dbg[(t - 1) * 8 + 5] = __builtin_readcyclecounter(); }
@@ -415,8 +428,8 @@ int jh_persist_create(jh_pponet* n, jh_persist** out) {
   JH_HIP(hipHostGetDevicePointer((void**)&p->flag_d, p->flag_h, 0));
   JH_HIP(hipMalloc((void**)&p->mbox, sizeof(unsigned long long) * kPersistMaxGranules));
   JH_HIP(hipMemset(p->mbox, 0, sizeof(unsigned long long) * kPersistMaxGranules));
-  JH_HIP(hipMalloc((void**)&p->dpart, sizeof(float4) * 2 * 4 * 16 * (size_t)p->tiles));
-  JH_HIP(hipMemset(p->dpart, 0, sizeof(float4) * 2 * 4 * 16 * (size_t)p->tiles));
+  JH_HIP(hipMalloc((void**)&p->dpart, sizeof(float4) * (2 * 4 * 16 * (size_t)p->tiles + 8)));  // (+ 8: a wave with fewer than 8 tiles reads a few granules past its last one and drops them)
+  JH_HIP(hipMemset(p->dpart, 0, sizeof(float4) * (2 * 4 * 16 * (size_t)p->tiles + 8)));
   memset(p->gran_h, 0, sizeof(unsigned long long) * kPersistMaxGranules);
   memset(p->flag_h, 0, sizeof(unsigned) * 16);
   if (getenv("JH_PERSIST_DEBUG")) {
@@ -476,11 +489,12 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   a.period = depth > 1 ? period : 0;
   static const int relay = getenv("JH_PERSIST_RELAY") ? atoi(getenv("JH_PERSIST_RELAY")) : 1;
   a.mbox = relay ? p->mbox : nullptr;
-  // device-side sum of the partial heads: JH_PERSIST_REDUCE = 1 always | 0 never | unset: when a step's answer is more than one granule per
-  // (tile, row) or has two row tiles (config.ppo.mujoco: 48 KB per step otherwise); config.ppo.cartpole's 24 rows x 1 granule stay on the
-  // direct path (measured: profiles/r06_ab_persist_device_reduce.txt)
-  static const int reduce = getenv("JH_PERSIST_REDUCE") ? atoi(getenv("JH_PERSIST_REDUCE")) : -1;
-  p->reduced = reduce == 1 || (reduce < 0 && (p->G > 1 || W > 16));
+  // device-side sum of the partial heads: JH_PERSIST_REDUCE=1.  OFF by default: measured (profiles/r06_ab_persist_device_reduce.txt), the
+  // on-device hand-off -- write-through granules of 64 workgroups on 8 XCDs, fetched agent-coherently by one workgroup -- costs 3.2 us
+  // per step, more than the host's gather of the 48 KB it replaces (config.ppo.mujoco, 32 workers: publication-to-heads 15.2 us direct,
+  // 15.8 us reduced; 8 workers: 6.9 vs 8.4 us).  The cross-XCD visibility of a store is the price, not the bytes.
+  const int reduce = getenv("JH_PERSIST_REDUCE") ? atoi(getenv("JH_PERSIST_REDUCE")) : 0;  // (read per launch: the test below switches it)
+  p->reduced = reduce == 1;
   a.dpart = p->reduced ? p->dpart : nullptr;
   a.max_polls = 600000;  // x (>= 0.3 us per consumed poll) = >= 0.2 s without observations -> give up
   p->flag_h[0] = 0;

@@ -703,6 +703,44 @@ def test_c_collector_on_a_python_env_through_the_function_table(forkable):
             assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("cont,W,H", [(True, 32, 512), (True, 8, 64), (False, 8, 128)])
+def test_persistent_kernel_device_side_sum_of_the_partial_heads_is_bit_identical(cont, W, H, monkeypatch):
+    """JH_PERSIST_REDUCE=1 (round 6): the column tiles' partial heads are fetched and added IN TILE ORDER by one workgroup of the acting
+    kernel instead of by the host -- the same additions in the same order: stored transitions, captured heads / values bit-identical to the
+    direct path, at config.ppo.mujoco's 32 workers x 7 outputs (two row tiles, three granules), at one tile per wave (hidden 64) and for
+    a discrete policy's two-timestep exchanges (24 rows)."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+
+    T, S, A = 12, 11 if cont else 4, 3 if cont else 2
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("JH_PERSIST_REDUCE", mode)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        agent = Agent("ppo", state_size=S, action_size=A, hidden_size=H, network="continuous_policy_value" if cont else "discrete_policy_value", n_step=T, batch_size=64,
+                      n_epoch=1, device="cuda", seed=3, lr_decay=False, num_workers=W)
+        agent.memory.first_store = False
+        env = ops.ControlVec(W, S, A, seed=4) if cont else ops.CartPoleVec(W, seed=4)
+        col = NativeCollector(env, agent, W)
+        out = []
+        for it in range(2):
+            col.run(T)
+            torch.cuda.synchronize()
+            st, M = agent._static, W * T
+            store = agent.memory._store
+            rec = {k: npy(store.column(k)[:M]).copy() for k in ("state", "action", "reward", "next_state", "done")}
+            rec.update(h0=npy(st["h0"]).copy(), value=npy(st["value"]).copy(), next_value=npy(st["next_value"]).copy())
+            out.append(rec)
+            agent.process(None, T * (it + 1))
+        res[mode] = out
+        col.terminate()
+    for a, b in zip(res["0"], res["1"]):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("forkable,where", [(False, "step"), (True, "step"), (True, "copy_row")])
 def test_c_collector_stops_when_the_env_fails(forkable, where, capfd):
     """jh_env_vtbl's contract: obs / step return a negative status and the run STOPS.  A Python env that raises in the middle of a rollout --
