@@ -24,7 +24,9 @@ struct PerDeltaArgs {
   int prio_dt, mode;
   int64_t tree_size, first_leaf;
   double* delta_out;   // [B] for the climb
+  int climb_depth;     // > 0 (round 6): B <= kPerSmall items -- the climb runs in THIS launch (jh_per_climb_small), over depths 0 .. climb_depth - 1
 };
+constexpr int kPerSmall = 64;  // write-backs / pushes of up to this many items: leaves and climb in ONE launch
 
 // In-LDS bitonic sort of n (power of two, <= kPerChunk) 64-bit keys by 256 threads.  Keys are
 // (node << 12 | batch position): equal nodes become one contiguous run ordered by batch position,
@@ -49,6 +51,57 @@ __device__ __forceinline__ int jh_pow2_ge(int n) {
   int p = 1;
   while (p < n) p <<= 1;
   return p;
+}
+
+// Round 6: the climb of a SMALL batch (B <= 64: Rainbow's write-back of 32, a step's stores) inside the launch that wrote the leaves --
+// one launch instead of two on the learn() chain.  Same arithmetic as jh_per_climb_kernel: for every depth, every node hit
+// by the batch gets its deltas added in ascending batch order, float64, one rounding per add.  A WAVE per depth (different depths never
+// share a node): the 64 lanes hold (node << 12 | batch position) keys, sorted with shuffles (no barriers), the head lane of a run of equal
+// nodes adds the run.  Called by all 256 threads of the workgroup right behind jh_per_delta_body's leaf phase.
+__device__ __forceinline__ int jh_node_depth(long long i) { return 63 - __clzll((unsigned long long)(i + 1)); }
+__device__ __forceinline__ void jh_per_climb_small(const PerDeltaArgs& a, int B) {
+  __shared__ double s_dl[kPerSmall];
+  __shared__ unsigned long long s_k[4][64];
+  __shared__ double s_sd[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();  // delta_out is written (and the callers' LDS is free)
+  if (threadIdx.x < B) s_dl[threadIdx.x] = a.delta_out[threadIdx.x];
+  __syncthreads();
+  long long ix = 0;
+  int dep = 0;
+  if (lane < B) {
+    ix = a.idx ? a.idx[lane] : a.push_start + lane;
+    ix = ix < a.first_leaf ? a.first_leaf : (ix >= a.tree_size ? a.tree_size - 1 : ix);
+    dep = jh_node_depth(ix);
+  }
+  for (int d = wid; d < a.climb_depth; d += 4) {
+    unsigned long long key = ~0ull;
+    if (lane < B && dep > d) key = ((unsigned long long)(((ix + 1) >> (dep - d)) - 1) << 12) | (unsigned long long)lane;
+    // bitonic sort of the wave's 64 keys, ascending
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const unsigned long long other = __shfl_xor(key, j, 64);
+        const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
+        key = keep_min ? (key < other ? key : other) : (key > other ? key : other);
+      }
+    }
+    s_k[wid][lane] = key;
+    s_sd[wid][lane] = key == ~0ull ? 0.0 : s_dl[(int)(key & 4095ull)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (key != ~0ull) {
+      const unsigned long long node = key >> 12;
+      if (lane == 0 || (s_k[wid][lane - 1] >> 12) != node) {  // head of this node's run
+        double v = a.tree[node];
+        for (int j = lane; j < 64 && (s_k[wid][j] >> 12) == node; ++j) v += s_sd[wid][j];
+        a.tree[node] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next depth of this wave rewrites s_k / s_sd)
+  }
 }
 
 // One workgroup of 256 threads: delta_out[i] = new_i - (what the reference would find in the leaf at that moment), leaves
@@ -95,6 +148,7 @@ __device__ __forceinline__ void jh_per_delta_body(const PerDeltaArgs& a, int B, 
   }
   const double m = jh_block_reduce(my_max, s_red, JhMax(), 0.0);
   if (threadIdx.x == 0) *a.maxp = m;  // max(max_priority, new...) per_buffer.py:48
+  if (a.climb_depth > 0) jh_per_climb_small(a, B);
 }
 
 struct jh_per;

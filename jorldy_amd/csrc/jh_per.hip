@@ -292,11 +292,22 @@ static int per_climb(jh_per* p, int B, const int64_t* d_idx, int64_t push_start,
   return JH_OK;
 }
 
+// leaves and climb in one launch (jh_fused.h: jh_per_climb_small)?  JH_PER_FUSED_CLIMB=1; OFF by default: measured on Rainbow's loop
+// (profiles/r06_ab_per_fused_climb.txt: 3 638-3 768 updates/s with the two launches, 3 610-3 623 fused) it buys nothing -- the write-back
+// runs on a side stream beside the backward, and five serial rounds of four depth-waves are no shorter than twenty depth-workgroups
+bool jh_per_small(const jh_per* p, int B) {
+  static const bool on = getenv("JH_PER_FUSED_CLIMB") && atoi(getenv("JH_PER_FUSED_CLIMB")) == 1;
+  return on && B <= kPerSmall && p->depth_max > 0;
+}
+
 static int per_apply(jh_per* p, int B, const int64_t* d_idx, int64_t push_start, const void* prio, int prio_dt, int mode,
                      hipStream_t st) {
-  JH_LAUNCH(jh_per_delta_kernel, dim3(1), dim3(256), 0, st, per_delta_args(p, d_idx, push_start, prio, prio_dt, mode), B);
+  PerDeltaArgs a = per_delta_args(p, d_idx, push_start, prio, prio_dt, mode);
+  const bool small = jh_per_small(p, B);
+  a.climb_depth = small ? p->depth_max : 0;
+  JH_LAUNCH(jh_per_delta_kernel, dim3(1), dim3(256), 0, st, a, B);
   JH_LAUNCH_CHECK();
-  return per_climb(p, B, d_idx, push_start, mode, st);
+  return small ? JH_OK : per_climb(p, B, d_idx, push_start, mode, st);
 }
 
 // the two halves for a caller that folds the leaf write-back into a kernel of its own (jh_fused.h)
@@ -304,9 +315,10 @@ int jh_per_delta_args(jh_per* p, int B, const int64_t* d_idx, const void* d_prio
   JH_ARG(p && d_idx && d_prio && out);
   JH_ARG(B > 0 && B <= kChunk && (prio_dt == JH_F32 || prio_dt == JH_F64));
   *out = per_delta_args(p, d_idx, 0, d_prio, prio_dt, 0);
+  out->climb_depth = jh_per_small(p, B) ? p->depth_max : 0;  // small batches: the caller's launch climbs too, jh_per_climb below is a no-op
   return JH_OK;
 }
-int jh_per_climb(jh_per* p, int B, const int64_t* d_idx, hipStream_t st) { return per_climb(p, B, d_idx, 0, 0, st); }
+int jh_per_climb(jh_per* p, int B, const int64_t* d_idx, hipStream_t st) { return jh_per_small(p, B) ? JH_OK : per_climb(p, B, d_idx, 0, 0, st); }
 
 JH_EXPORT int jh_per_push(jh_per* p, int64_t n, const double* h_prio, jh_stream stream) {
   JH_ARG(p != nullptr && n >= 0);

@@ -44,6 +44,14 @@ def hopper_leg(iters=10, warmup=4, workers=32, batch=2048, e2e=False, dist=None,
     rng = np.random.RandomState(rank)
     cols = {"state": rng.randn(M, S).astype(np.float32), "action": np.tanh(rng.randn(M, A)).astype(np.float32), "reward": rng.randn(M, 1).astype(np.float32),
             "next_state": rng.randn(M, S).astype(np.float32), "done": (rng.rand(M, 1) < 1e-3)}
+    # the learner-side leg uploads this rollout every iteration: from PINNED host memory (round 6; pageable, the 7 MB copy was 0.4-5 ms by box -- VERDICT r5 weak #11)
+    if not e2e:
+        pinned = {}
+        for k, v in cols.items():
+            t = torch.empty(v.shape, dtype=torch.from_numpy(v).dtype, pin_memory=True)
+            t.numpy()[...] = v
+            pinned[k] = t  # keeps the allocation alive
+            cols[k] = t.numpy()
     step = 0
     collector = None
     if e2e:
@@ -107,7 +115,7 @@ def hopper_leg(iters=10, warmup=4, workers=32, batch=2048, e2e=False, dist=None,
                     f"minibatch {B}/GPU, 10 epochs" + (", native collector on the synthetic control env" if collector is not None else ", learner side only (rollout rows uploaded)"),
         "n_gpus": world, "backend": agent.backend, "learn_in_hipgraph": bool(agent._graph is not None),
         "ms_per_iteration": dt * 1e3, "learner_transitions_per_s": world * M / dt, "learner_updates_per_s": n_upd / dt, "minibatch_updates_per_iteration": n_upd,
-        "host_to_device_MB_per_iteration": sum(v.nbytes for v in cols.values()) / 1e6,
+        "host_to_device_MB_per_iteration": sum(v.nbytes for v in cols.values()) / 1e6, "rollout_upload_from": "pinned host memory" if not e2e else None,
         "collector": (dict(kind="NativeCollector on jh_control (synthetic stand-in for MuJoCo Hopper)", **cstats) if collector is not None else None),
         "env_transitions_per_s_end_to_end": (world * M / dt if collector is not None else None),
         "last_result": {k: float(v) for k, v in r.items()}, "lib_kernels": kern}
