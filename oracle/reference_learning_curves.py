@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2])
     ap.add_argument("--skip", nargs="*", default=[])
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_learning_curve_reference_vs_port.json"))
+    ap.add_argument("--fixtures", action="store_true", help="instead: the reference's curves for the two tasks that have NO port (continuous PPO on the control env, Ape-X on "
+                                                            "CartPole) -> tests/golden/curves_reference_r06.json, what tests/test_learning_curve_gpu.py holds the HIP agents against")
     args = ap.parse_args()
     import torch
 
@@ -57,6 +59,23 @@ def main():
         from core.agent.rainbow import Rainbow
 
         W, T, ITERS, RUN_STEP = LC.W, LC.T, LC.ITERS, LC.RUN_STEP
+        if args.fixtures:
+            from core.agent.ape_x import ApeX
+
+            fx = {"generator": "oracle/reference_learning_curves.py --fixtures (the unmodified reference agents, CPU, scratch copy)", "seeds": args.seeds}
+            t0 = time.time()
+            mk = lambda: PPO(state_size=LC.CTL["S"], action_size=LC.CTL["A"], device="cpu", **LC.ctl_agent_kwargs())
+            fx["ppo_control"] = {"config": LC.CTL, "metric": "mean reward per transition, per iteration", "reference": [LC.ctl_curve_host(mk, s) for s in args.seeds]}
+            print("ppo control done", round(time.time() - t0, 1), [round(float(np.mean(c[-5:])), 3) for c in fx["ppo_control"]["reference"]], flush=True)
+            t0 = time.time()
+            mk = lambda: ApeX(state_size=4, action_size=2, device="cpu", **LC.apex_agent_kwargs())
+            fx["apex_cartpole"] = {"config": LC.APEX, "metric": f"mean episode length per {LC.APEX['chunk']} env steps", "reference": [LC.apex_curve(mk, s, host_env=True) for s in args.seeds]}
+            print("apex done", round(time.time() - t0, 1), [round(float(np.mean(c[-3:])), 1) for c in fx["apex_cartpole"]["reference"]], flush=True)
+            os.chdir(cwd)
+            with open(os.path.join(ROOT, "tests", "golden", "curves_reference_r06.json"), "w") as f:
+                json.dump(fx, f)
+            print("wrote tests/golden/curves_reference_r06.json")
+            return
         if "ppo" not in args.skip:
             def ref_ppo_curve(seed):
                 np.random.seed(seed)

@@ -199,7 +199,8 @@ def test_bench_two_ranks_on_one_gpu_plumbing(tmp_path, launcher, strong):
     env = dict(os.environ, JH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    args = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-rainbow", "--no-roofline", "--no-cpu-baseline", "--hopper-iters", "1"] + (["--strong"] if strong else [])
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-rainbow", "--no-roofline", "--no-cpu-baseline", "--hopper-iters", "1",
+            "--apex-actors", "16", "--apex-updates", "240", "--apex-buffer", "200000", "--apex-prefill", "4000"] + (["--strong"] if strong else [])
     if launcher == "torchrun":
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "bench.py")] + args
@@ -212,5 +213,8 @@ def test_bench_two_ranks_on_one_gpu_plumbing(tmp_path, launcher, strong):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == ("strong" if strong else "weak") and out["config"]["workers_per_gpu"] == (4 if strong else 8) and out["config"]["batch_size"] == (128 if strong else 256)
     assert out["value"] > 0 and np.isfinite(out["last_result"]["critic_loss"]) and list(out)[-1] == "legs"
+    ax = out["apex"]  # round 6: configs[3] as one learner + its actors + its replay shard per rank, gradients averaged per learn()
+    assert "error" not in ax, ax
+    assert ax["n_gpus"] == 2 and ax["value"] > 0 and ax["learner_updates_per_s"] > 0 and np.isfinite(ax["rank0"]["last_result"]["loss"])
     hp = out["hopper"]  # configs[4] strong-scaled over the two ranks: 16 workers and 1024 minibatch rows each, collector + DP learners
     assert hp["n_gpus"] == 2 and hp["config"]["workers_per_gpu"] == 16 and hp["config"]["batch_per_gpu"] == 1024 and hp["value"] > 0

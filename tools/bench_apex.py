@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--buffer", type=int, default=2_000_000, help="PER slots (config.ape_x.atari: buffer_size 2e6; frame mode: ~21 GB of de-duplicated 84x84 planes "
                                                                     "in HBM, plain rows would be 113 GB of uint8 stacks -- both fit the 288 GB)")
@@ -37,19 +37,36 @@ def main():
                                                            "forward is rebuilt in HBM from the plane pool; 7 KB instead of 28 KB per env step over PCIe)")
     ap.add_argument("--device-feed", action="store_true", help="--e2e: the actors' stacks stay in HBM (DeviceActorFeed: plane pool + n-step assembly + "
                                                                 "actor-side priorities on the acting stream) instead of VecNStepApeX + the pinned staging ring")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    print(json.dumps(run(parse())))
+
+
+def run(args, dist=None):
+    """One measurement -> dict.  dist: an initialised torch.distributed with world size > 1 -> ONE LEARNER PER GPU (north_star: "Ape-X-style many-actor /
+    one-learner re-expressed as one learner per GPU with RCCL all-reduce"): every rank runs this function on its own device with its own actors, its own
+    replay shard and sum tree; the learners' gradient buckets are averaged per learn() (attach_data_parallel), the IS weights are those of the one
+    logical buffer over all shards.  Every rank runs the same number of learner iterations (the all-reduce is a rendezvous)."""
     from jorldy_amd import ops
     from jorldy_amd.core.agent import Agent
 
-    torch.manual_seed(0)
-    np.random.seed(0)
+    torch.manual_seed(0)  # (identical initial weights on every rank; attach_data_parallel broadcasts rank 0's anyway)
+    np.random.seed(dist.get_rank() if dist is not None else 0)
     N, B, n, chunk_rows, filled = args.buffer, args.batch, 3, 100, min(args.prefill, 16384)  # (host-synthesised rows: 115 MB of randint per 2048)
     agent = Agent("ape_x", state_size=[4, 84, 84], action_size=6, hidden_size=512, network="dueling", head="cnn",
                   optim_config={"name": "rmsprop", "eps": 1.5e-7, "lr": 2.5e-4 / 4, "centered": True}, gamma=0.99, buffer_size=N, batch_size=B,
                   clip_grad_norm=40.0, start_train_step=0, target_update_period=2500, run_step=30_000_000, n_step=n, alpha=0.6, beta=0.4,
                   uniform_sample_prob=1e-3, num_workers=64, device="cuda")
     agent.memory.first_store = False
-    rng = np.random.RandomState(0)
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    if dist is not None and world > 1:
+        from jorldy_amd.parallel import attach_data_parallel
+
+        attach_data_parallel(agent, dist)
+    rng = np.random.RandomState(rank)
     if args.device_feed:
         assert args.e2e > 0, "--device-feed is a mode of --e2e"
         filled = 0  # the feed owns the (empty) buffer's row format: the actors fill it
@@ -182,17 +199,29 @@ def main():
             time.sleep(0.0005)
         filled = int(agent.memory.buffer_counter)
         prefill_s = time.perf_counter() - t_fill
+
+    def fence():  # one learner per GPU: the timed region is bracketed by a barrier on every rank, its length is the slowest rank's
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
     for _ in range(args.warmup):
         iteration()
-    torch.cuda.synchronize()
+    fence()
     if args.e2e > 0:
         tick0, tact0, thost0 = counters["ticks"], counters["t_act"], counters["t_host"]
     n0 = agent.num_transitions
     t0 = time.perf_counter()
     for _ in range(args.updates):
         r = iteration()
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     if args.e2e > 0:
         ticks = counters["ticks"] - tick0
         e2e_stats = {"actors": args.e2e, "actor_ticks_per_s": ticks / dt, "env_steps_per_s": ticks * args.e2e / dt,
@@ -230,7 +259,16 @@ def main():
     # group; the dedicated conv1 kernels likewise); v = (launches, total ms, total flops)
     kern = {k: {"avg_us": round(v[1] / v[0] * 1e3, 2), **({"TFLOP/s": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "frac_of_157.3_f32_mfma_peak": round(v[2] / (v[1] * 1e-3) / 157.3e12, 3)} if v[2] > 0 else {})}
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    totals = None
+    if world > 1:  # whole-job aggregates: every rank's actors' env steps and ingested transitions over the slowest rank's time
+        mine = torch.tensor([float((e2e_stats or {}).get("env_steps_per_s", 0.0)) * dt, float(agent.num_transitions - n0)], dtype=torch.float64,
+                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        totals = {"n_gpus": world, "env_steps_per_s": float(mine[0]) / dt, "ingested_transitions_per_s": float(mine[1]) / dt, "learner_updates_per_s": args.updates / dt,
+                  "sampled_transitions_per_s": world * B * args.updates / dt, "parallelism": f"dp{world}: one learner + {args.e2e} actors + one replay shard per GPU, "
+                  "gradient bucket averaged per learn(), IS weights of the one logical buffer"}
     out = {
+        "whole_job": totals,
         "workload": f"config.ape_x.atari pong-shaped (BASELINE.json configs[3]), synthetic uint8 (4,84,84), A=6, B={B}, n=3, dueling CNN, centered RMSprop, clip 40, "
                     f"PER N={N} ({filled} filled)",
         "timed_s": dt,
@@ -246,7 +284,7 @@ def main():
         "last_result": {k: float(v) for k, v in r.items()},
         "lib_kernels": kern,
     }
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":
