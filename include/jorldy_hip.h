@@ -323,6 +323,11 @@ int jh_pponet_ppo_update_dp_begin(jh_pponet* n, int32_t B, const float* d_x, con
                                   float ent_coef, float* d_critic_sums, jh_stream stream);
 int jh_pponet_ppo_update_dp_end(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_critic_sums, float vf_coef,
                                 float ent_coef, float* d_stats, jh_stream stream);
+/* jh_pponet_ppo_update_dp_end with the ranks' exchange of the critic sums folded into its first launch (jh_peer_*, B <= 256 rows per rank):
+ * d_critic_sums = this rank's sums on entry, the ranks' mean on exit.  Declared behind jh_peer below (forward declaration here).  */
+struct jh_peer;
+int jh_pponet_ppo_update_dp_end_peer(jh_pponet* n, struct jh_peer* peer, int32_t B, const float* d_x, const int64_t* d_idx, float* d_critic_sums,
+                                     float vf_coef, float ent_coef, float* d_stats, jh_stream stream);
 /* Device address of the optimizer's hyper block (float[8]: lr, beta1, beta2, eps, step, ...), e.g. as the destination of a
  * jh_collector_set_ride_along copy that delivers the next decayed learning rate (base.py:93-111) without a copy of its own. */
 void* jh_pponet_hyper_ptr(jh_pponet* n);

@@ -98,6 +98,7 @@ _PROTOS = {
     "jh_ppo_critic_select_rows": (C.c_int, [_vp, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_ppo_update_dp_begin": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp]),
     "jh_pponet_ppo_update_dp_end": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "jh_pponet_ppo_update_dp_end_peer": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp]),
     "jh_pponet_act_discrete": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jh_pponet_act_continuous": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jh_control_create": (C.c_int, [_i32, _i32, _i32, C.c_uint64, _pp]),

@@ -313,7 +313,8 @@ class PPO(BaseAgent):
                     o0, o1 = e * M + offset, e * M + min(offset + B, M)
                     if exact:  # critic = max(mean(e1), mean(e2)) over the GLOBAL minibatch: 8 more bytes on the wire, before the backward
                         net.ppo_update_dp(xs[o0:o1], None, acts[o0:o1], advs[o0:o1], rets[o0:o1], vals[o0:o1], lps[o0:o1], self.epsilon_clip, self.vf_coef,
-                                          self.ent_coef, st["stats"][k], self.grad_sync.reduce_flat, st["critic_sums"][k])
+                                          self.ent_coef, st["stats"][k], self.grad_sync.reduce_flat, st["critic_sums"][k],
+                                          peer=getattr(getattr(self.grad_sync, "transport", None), "peer", None))
                     else:
                         net.ppo_update(xs[o0:o1], None, acts[o0:o1], advs[o0:o1], rets[o0:o1], vals[o0:o1], lps[o0:o1], self.epsilon_clip, self.vf_coef,
                                        self.ent_coef, self.clip_grad_norm, st["stats"][k], do_adam=self.grad_sync is None)

@@ -1226,8 +1226,9 @@ int jh_ppo_loss_from_partials(jh_ctx* ctx, int continuous, int B, int A, const f
                               const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
                               const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
                               float* d_g_all, float* d_stats, float* d_hyper_advance, float* d_defer_dv2, float* d_critic_sums, hipStream_t st);
-int jh_ppo_critic_select(int B, const float* d_sums, float vf, float ent, float* d_gv, int ldv, const float* d_dv2, const float* d_stats_local,
-                         float* d_stats_out, hipStream_t st);
+struct jh_peer;
+int jh_ppo_critic_select(int B, float* d_sums, float vf, float ent, float* d_gv, int ldv, const float* d_dv2, const float* d_stats_local,
+                         float* d_stats_out, hipStream_t st, jh_peer* peer);
 
 // One PPO minibatch update (ppo.py:122-169) in FOUR launches when the (dW1 | db1) slabs are small enough for Adam's
 // prologue to sum them in every workgroup (B <= 256 rows, CartPole / Hopper widths), else five (jh_ppo_mb.hip): forward into partial heads,
@@ -1278,18 +1279,32 @@ JH_EXPORT int jh_pponet_ppo_update_dp_begin(jh_pponet* n, int32_t B, const float
                                    d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, n->g_all, n->stats_tmp, nullptr, n->dv2, d_critic_sums, st);
 }
 
-JH_EXPORT int jh_pponet_ppo_update_dp_end(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_critic_sums, float vf_coef,
-                                          float ent_coef, float* d_stats, jh_stream stream) {
+static int pponet_dp_end(jh_pponet* n, jh_peer* peer, int32_t B, const float* d_x, const int64_t* d_idx, float* d_critic_sums, float vf_coef, float ent_coef,
+                         float* d_stats, jh_stream stream, const char* who) {
   JH_ARG(n && d_x && d_critic_sums);
   JH_ARG(B > 0 && B <= 1024 && B <= n->max_rows);
-  if (!jh_pmb_eligible(n, B)) return jh_fail(JH_ERR_ARG, "jh_pponet_ppo_update_dp_end needs hidden_size %% 32 == 0 and at most 8 head outputs (H = %d, %d outputs: A + 1 discrete, 2 A + 1 continuous)", n->H, n->n_out);
+  if (!jh_pmb_eligible(n, B))
+    return jh_fail(JH_ERR_ARG, "%s needs hidden_size %% 32 == 0 and at most 8 head outputs (H = %d, %d outputs: A + 1 discrete, 2 A + 1 continuous)", who, n->H, n->n_out);
   hipStream_t st = jh_s(stream);
   const int vcol = n->cont ? 2 * n->A : n->A;  // the value head's column of g_all [B][gld]
-  int rc = jh_ppo_critic_select(B, d_critic_sums, vf_coef, ent_coef, n->g_all + vcol, n->gld, n->dv2, n->stats_tmp, d_stats, st);
+  int rc = jh_ppo_critic_select(B, d_critic_sums, vf_coef, ent_coef, n->g_all + vcol, n->gld, n->dv2, n->stats_tmp, d_stats, st, peer);
   if (rc) return rc;
   rc = jh_pmb_backward(n, B, d_x, d_idx, pmb_heads(n), false, st);
   if (rc) return rc;
   return jh_pmb_finalize(n, B, false, st);
+}
+
+JH_EXPORT int jh_pponet_ppo_update_dp_end(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_critic_sums, float vf_coef,
+                                          float ent_coef, float* d_stats, jh_stream stream) {
+  return pponet_dp_end(n, nullptr, B, d_x, d_idx, const_cast<float*>(d_critic_sums), vf_coef, ent_coef, d_stats, stream, "jh_pponet_ppo_update_dp_end");
+}
+
+// The same second half with the ranks' exchange of {sum e1, sum e2} INSIDE its first launch (round 6; peer-pointer transport, B <= 256 rows per rank):
+// d_critic_sums holds THIS rank's sums on entry and the ranks' mean on exit -- no collective launch between jh_pponet_ppo_update_dp_begin and here.
+JH_EXPORT int jh_pponet_ppo_update_dp_end_peer(jh_pponet* n, jh_peer* peer, int32_t B, const float* d_x, const int64_t* d_idx, float* d_critic_sums, float vf_coef,
+                                               float ent_coef, float* d_stats, jh_stream stream) {
+  JH_ARG(peer != nullptr);
+  return pponet_dp_end(n, peer, B, d_x, d_idx, d_critic_sums, vf_coef, ent_coef, d_stats, stream, "jh_pponet_ppo_update_dp_end_peer");
 }
 
 // Batched acting for W envs (PPO.act, ppo.py:55-69, discrete): ONE launch + host finish.

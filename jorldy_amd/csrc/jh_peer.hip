@@ -22,58 +22,19 @@
 // The reference has no counterpart (one learner, Ray fan-out only: manager/distributed_manager.py:26-31).  RCCL (jh_comm_*) stays the
 // default transport; this one is chosen with JH_DP_COLLECTIVE=peer and is exercised by two processes on ONE GPU (IPC handles open across
 // processes on the same device) in tests/test_dp_two_ranks_gpu.py -- a multi-GPU node has not measured it yet.
-#include "jh_common.h"
+#include "jh_peer.h"
 
 namespace {
-constexpr int kMaxRanks = 16;
-constexpr int kSmallMax = 16;
-constexpr int kCtlBytes = 16384;
-// control block at the head of every arena (offsets in bytes); written by PEERS, polled by the owner
-constexpr int kOffFlagsIn = 0, kOffFlagsOut = 256, kOffFlagsSmall = 512, kOffSmallBox = 1024;  // small_box [2][kMaxRanks][kSmallMax] floats = 2 KB
-
-struct PeerArgs {
-  char* arena[kMaxRanks];  // every rank's arena as THIS process sees it (own: the allocation itself)
-  int nranks, rank;
-  int64_t n, slice;        // floats in the bucket, floats per slice (multiple of 4)
-  size_t off_in, off_out, out_stride;  // byte offsets of `in` and `out[2]` in an arena
-  unsigned* seq;       // [4] device-private: [0] completed all-reduces, [1] completed small exchanges
-  unsigned* arrive;    // [4] device-private arrival counters
-  unsigned* err;       // [1] bounded waits that gave up
-  float* bucket;
-};
-
-__device__ __forceinline__ unsigned ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-// thread 0 of the workgroup waits until words[p] >= seq for every rank p (its own included); everybody leaves with an acquire
-__device__ __forceinline__ void wait_all(const unsigned* words, int nranks, unsigned seq, unsigned* err) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (int p = 0; p < nranks; ++p) {
-      while ((int)(ld_sys(words + p) - seq) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s of the 100 MHz clock
-          atomicAdd(err, 1u);
-          p = nranks;
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: what the peers wrote before their flag
-}
-
-// the LAST workgroup of the grid to get here (everybody's stores released first) runs `f` on its thread 0
+// the LAST workgroup of the grid to get here runs `f` on its thread 0.  Everybody's arena stores are system-scope write-through stores: a thread waits
+// for its own (s_waitcnt vmcnt(0)) before the barrier, the arrival counter orders the workgroups -- no fence (see jh_peer_wait_all).
 template <typename F>
 __device__ __forceinline__ void last_arriver(unsigned* counter, F f) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this workgroup's stores are visible to the peers
-    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
       __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
       f();
     }
   }
@@ -83,87 +44,75 @@ __global__ void __launch_bounds__(256) jh_peer_reduce_scatter_kernel(PeerArgs a)
   const unsigned seq = a.seq[0] + 1u;
   const int t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
   char* mine = a.arena[a.rank];
-  // 1. bucket -> in (the tail beyond n is never read)
+  // 1. bucket -> in, write-through (the tail beyond n is never read); pairs of floats: n is padded to an even count by the reader's clamp below
   {
     float* in = (float*)(mine + a.off_in);
-    const int64_t n4 = a.n >> 2;
-    for (int64_t i = t; i < n4; i += nt) reinterpret_cast<float4*>(in)[i] = reinterpret_cast<const float4*>(a.bucket)[i];
-    for (int64_t i = (n4 << 2) + t; i < a.n; i += nt) in[i] = a.bucket[i];
+    const int64_t n2 = a.n >> 1;
+    for (int64_t i = t; i < n2; i += nt) {
+      const float2 v = reinterpret_cast<const float2*>(a.bucket)[i];
+      jh_st_f2_sys(in + 2 * i, v.x, v.y);
+    }
+    if ((a.n & 1) && t == 0) jh_st_f2_sys(in + a.n - 1, a.bucket[a.n - 1], 0.f);  // (8-byte aligned: n - 1 is even)
   }
   // 2. the whole bucket is in place: raise "in ready" in every arena
   last_arriver(a.arrive + 0, [&] {
-    for (int p = 0; p < a.nranks; ++p) st_sys((unsigned*)(a.arena[p] + kOffFlagsIn) + a.rank, seq);
+    for (int p = 0; p < a.nranks; ++p) jh_st_sys((unsigned*)(a.arena[p] + kPeerOffFlagsIn) + a.rank, seq);
   });
   // 3. every peer's bucket is in place
-  wait_all((const unsigned*)(mine + kOffFlagsIn), a.nranks, seq, a.err);
+  jh_peer_wait_all((const unsigned*)(mine + kPeerOffFlagsIn), a.nranks, seq, a.err);
   // 4. my slice of everybody's bucket, summed in rank order, / N -> out[parity]
   {
-    const int64_t lo = (int64_t)a.rank * a.slice;
+    const int64_t lo = (int64_t)a.rank * a.slice;  // a multiple of 4
     int64_t cnt = a.n - lo;
     cnt = cnt < 0 ? 0 : (cnt > a.slice ? a.slice : cnt);
     float* out = (float*)(mine + a.off_out + (size_t)(seq & 1u) * a.out_stride);
     const float inv = 1.0f / (float)a.nranks;
-    const int64_t c4 = cnt >> 2;
-    for (int64_t i = t; i < c4; i += nt) {
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t c2 = (cnt + 1) >> 1;  // pairs; an odd tail reads the zero written behind element n - 1
+    for (int64_t i = t; i < c2; i += nt) {
+      float s0 = 0.f, s1 = 0.f;
       for (int p = 0; p < a.nranks; ++p) {
-        const float4 v = reinterpret_cast<const float4*>((const float*)(a.arena[p] + a.off_in) + lo)[i];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        float v0, v1;
+        jh_ld_f2_sys((const float*)(a.arena[p] + a.off_in) + lo + 2 * i, v0, v1);
+        s0 += v0; s1 += v1;
       }
-      reinterpret_cast<float4*>(out)[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
-    }
-    for (int64_t i = (c4 << 2) + t; i < cnt; i += nt) {
-      float s = 0.f;
-      for (int p = 0; p < a.nranks; ++p) s += ((const float*)(a.arena[p] + a.off_in))[lo + i];
-      out[i] = s * inv;
+      jh_st_f2_sys(out + 2 * i, s0 * inv, s1 * inv);
     }
   }
   // 5. the slice is published
   last_arriver(a.arrive + 1, [&] {
-    for (int p = 0; p < a.nranks; ++p) st_sys((unsigned*)(a.arena[p] + kOffFlagsOut) + a.rank, seq);
+    for (int p = 0; p < a.nranks; ++p) jh_st_sys((unsigned*)(a.arena[p] + kPeerOffFlagsOut) + a.rank, seq);
   });
 }
 
 __global__ void __launch_bounds__(256) jh_peer_all_gather_kernel(PeerArgs a) {
   const unsigned seq = a.seq[0] + 1u;
   const int t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
-  wait_all((const unsigned*)(a.arena[a.rank] + kOffFlagsOut), a.nranks, seq, a.err);
+  jh_peer_wait_all((const unsigned*)(a.arena[a.rank] + kPeerOffFlagsOut), a.nranks, seq, a.err);
   for (int p = 0; p < a.nranks; ++p) {
     const int64_t lo = (int64_t)p * a.slice;
     int64_t cnt = a.n - lo;
     cnt = cnt < 0 ? 0 : (cnt > a.slice ? a.slice : cnt);
     const float* src = (const float*)(a.arena[p] + a.off_out + (size_t)(seq & 1u) * a.out_stride);
-    const int64_t c4 = cnt >> 2;
-    for (int64_t i = t; i < c4; i += nt) reinterpret_cast<float4*>(a.bucket + lo)[i] = reinterpret_cast<const float4*>(src)[i];
-    for (int64_t i = (c4 << 2) + t; i < cnt; i += nt) a.bucket[lo + i] = src[i];
+    const int64_t c2 = cnt >> 1;
+    for (int64_t i = t; i < c2; i += nt) {
+      float v0, v1;
+      jh_ld_f2_sys(src + 2 * i, v0, v1);
+      reinterpret_cast<float2*>(a.bucket + lo)[i] = make_float2(v0, v1);
+    }
+    if ((cnt & 1) && t == 0) {
+      float v0, v1;
+      jh_ld_f2_sys(src + cnt - 1, v0, v1);
+      a.bucket[lo + cnt - 1] = v0;
+    }
   }
   last_arriver(a.arrive + 2, [&] { a.seq[0] = seq; });
 }
 
 // <= 16 floats summed over the ranks (rank order), one workgroup: mailbox [parity][from][16] in every arena
 __global__ void __launch_bounds__(64) jh_peer_small_kernel(PeerArgs a, float* vals, int n, float scale) {
-  const unsigned seq = a.seq[1] + 1u;
   const int t = threadIdx.x;
-  const size_t box = kOffSmallBox + (size_t)(seq & 1u) * kMaxRanks * kSmallMax * sizeof(float);
-  if (t < n) {
-    const float v = vals[t];
-    for (int p = 0; p < a.nranks; ++p)
-      __hip_atomic_store((float*)(a.arena[p] + box) + a.rank * kSmallMax + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __syncthreads();
-  if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    for (int p = 0; p < a.nranks; ++p) st_sys((unsigned*)(a.arena[p] + kOffFlagsSmall) + a.rank, seq);
-  }
-  wait_all((const unsigned*)(a.arena[a.rank] + kOffFlagsSmall), a.nranks, seq, a.err);
-  if (t < n) {
-    float s = 0.f;
-    for (int p = 0; p < a.nranks; ++p)
-      s += __hip_atomic_load((const float*)(a.arena[a.rank] + box) + p * kSmallMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    vals[t] = s * scale;
-  }
-  __syncthreads();
-  if (t == 0) a.seq[1] = seq;
+  const float r = jh_peer_small_exchange(a, t < n ? vals[t] : 0.f, n, scale);
+  if (t < n) vals[t] = r;
 }
 }  // namespace
 
@@ -173,20 +122,20 @@ struct jh_peer {
   int64_t max_floats = 0, slice_max = 0;
   size_t arena_bytes = 0, off_in = 0, off_out = 0, out_stride = 0;
   char* arena = nullptr;            // own arena (exported)
-  char* peer[kMaxRanks] = {};       // opened peers (own: arena)
-  bool opened[kMaxRanks] = {};
+  char* peer[kPeerMaxRanks] = {};       // opened peers (own: arena)
+  bool opened[kPeerMaxRanks] = {};
   unsigned* priv = nullptr;         // seq[4] | arrive[4] | err[4]
   bool connected = false;
 };
 
 JH_EXPORT int jh_peer_create(jh_ctx* ctx, int32_t nranks, int32_t rank, int64_t max_floats, jh_peer** out) {
   JH_ARG(ctx && out);
-  JH_ARG(nranks >= 1 && nranks <= kMaxRanks && rank >= 0 && rank < nranks && max_floats > 0);
+  JH_ARG(nranks >= 1 && nranks <= kPeerMaxRanks && rank >= 0 && rank < nranks && max_floats > 0);
   JH_HIP(hipSetDevice(ctx->device));
   jh_peer* p = new jh_peer();
   p->ctx = ctx; p->nranks = nranks; p->rank = rank; p->max_floats = max_floats;
   p->slice_max = ((max_floats + nranks - 1) / nranks + 3) / 4 * 4;
-  p->off_in = kCtlBytes;
+  p->off_in = kPeerCtlBytes;
   p->off_out = p->off_in + (((size_t)max_floats * 4 + 255) & ~(size_t)255);
   p->out_stride = ((size_t)p->slice_max * 4 + 255) & ~(size_t)255;
   p->arena_bytes = p->off_out + 2 * p->out_stride;
@@ -263,6 +212,7 @@ JH_EXPORT int jh_peer_allreduce_mean_f32(jh_peer* p, float* d_bucket, int64_t n,
   JH_ARG(p && d_bucket && n > 0 && n <= p->max_floats);
   JH_ARG(((uintptr_t)d_bucket & 15) == 0);
   if (!p->connected) return jh_fail(JH_ERR_STATE, "jh_peer_allreduce_mean_f32 before jh_peer_connect");
+  if (p->nranks == 1) return JH_OK;  // the mean over one rank
   const PeerArgs a = peer_args(p, d_bucket, n);
   // few workgroups: the launches are latency (flag hand-offs), the bytes a fraction of a MB per rank; and every workgroup of a launch
   // must be resident at once (they meet in the arrival counters)
@@ -276,11 +226,18 @@ JH_EXPORT int jh_peer_allreduce_mean_f32(jh_peer* p, float* d_bucket, int64_t n,
 }
 
 JH_EXPORT int jh_peer_allreduce_small_f32(jh_peer* p, float* d_vals, int32_t n, int32_t mean, jh_stream stream) {
-  JH_ARG(p && d_vals && n > 0 && n <= kSmallMax);
+  JH_ARG(p && d_vals && n > 0 && n <= kPeerSmallMax);
   if (!p->connected) return jh_fail(JH_ERR_STATE, "jh_peer_allreduce_small_f32 before jh_peer_connect");
   const PeerArgs a = peer_args(p, nullptr, 0);
   JH_LAUNCH(jh_peer_small_kernel, dim3(1), dim3(64), 0, jh_s(stream), a, d_vals, (int)n, mean ? 1.0f / (float)p->nranks : 1.0f);
   JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+int jh_peer_args_for(jh_peer* p, PeerArgs* out) {
+  JH_ARG(p && out);
+  if (!p->connected) return jh_fail(JH_ERR_STATE, "peer communicator used before jh_peer_connect");
+  *out = peer_args(p, nullptr, 0);
   return JH_OK;
 }
 

@@ -6,6 +6,7 @@
 // loads, wave-shuffle scans/reductions, no GEMM.  Compiled with -ffp-contract=off so products and
 // sums round separately like the torch ops they replace.
 #include "jh_common.h"
+#include "jh_peer.h"
 
 // ============================================================================ GAE
 // One wave (64 lanes) per rollout row.  The recurrence adv[t] = delta[t] + c[t]*adv[t+1],
@@ -939,10 +940,24 @@ JH_EXPORT int jh_ppo_loss_continuous(jh_ctx* ctx, int32_t B, int32_t A, const fl
 // every rank takes the same branch, and after the gradient all-reduce the update equals one learner's on the concatenated batch.
 // stats_local: the loss kernel's row for this rank; stats_out gets it with the critic terms replaced by the global ones (written in the
 // form ppo_finish_stats uses, jh_ppo_stats_row: the arrival markers of the mapped statistics are its [2] and [7]).
-__global__ void __launch_bounds__(256) jh_ppo_critic_select_kernel(int B, const float* __restrict__ sums, float vf, float ent, float* __restrict__ gv, int ldv,
+// pa.nranks > 1 (round 6, peer-pointer transport): the ranks' sums meet INSIDE this launch (jh_peer_small_exchange: mailboxes in the peers' arenas,
+// one workgroup, so B <= 256) -- the separate 8-byte all-reduce launch between the loss and the backward is gone; `sums` then holds THIS rank's
+// sums on entry and the ranks' mean on exit.
+__global__ void __launch_bounds__(256) jh_ppo_critic_select_kernel(int B, float* __restrict__ sums, float vf, float ent, float* __restrict__ gv, int ldv,
                                                                    const float* __restrict__ dv2, const float* __restrict__ stats_local,
-                                                                   float* __restrict__ stats_out) {
-  const float c1 = sums[0] / (float)B, c2 = sums[1] / (float)B;
+                                                                   float* __restrict__ stats_out, PeerArgs pa) {
+  float c1, c2;
+  if (pa.nranks > 1) {
+    __shared__ float s_mean[2];
+    const float m = jh_peer_small_exchange(pa, threadIdx.x < 2 ? sums[threadIdx.x] : 0.f, 2, 1.0f / (float)pa.nranks);
+    if (threadIdx.x < 2) { s_mean[threadIdx.x] = m; sums[threadIdx.x] = m; }
+    __syncthreads();
+    c1 = s_mean[0] / (float)B;
+    c2 = s_mean[1] / (float)B;
+  } else {
+    c1 = sums[0] / (float)B;
+    c2 = sums[1] / (float)B;
+  }
   const float w1 = c1 > c2 ? 1.f : (c1 == c2 ? 0.5f : 0.f), w2 = 1.f - w1;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < B) gv[(size_t)i * ldv] = w1 * gv[(size_t)i * ldv] + w2 * dv2[i];
@@ -952,9 +967,15 @@ __global__ void __launch_bounds__(256) jh_ppo_critic_select_kernel(int B, const 
   }
 }
 
-int jh_ppo_critic_select(int B, const float* d_sums, float vf, float ent, float* d_gv, int ldv, const float* d_dv2, const float* d_stats_local,
-                         float* d_stats_out, hipStream_t st) {
-  JH_LAUNCH(jh_ppo_critic_select_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, d_sums, vf, ent, d_gv, ldv, d_dv2, d_stats_local, d_stats_out);
+int jh_ppo_critic_select(int B, float* d_sums, float vf, float ent, float* d_gv, int ldv, const float* d_dv2, const float* d_stats_local,
+                         float* d_stats_out, hipStream_t st, jh_peer* peer) {
+  PeerArgs pa{};
+  if (peer) {
+    if (B > 256) return jh_fail(JH_ERR_ARG, "the critic select with the ranks' exchange inside is one workgroup: B <= 256 (got %d)", B);
+    const int rc = jh_peer_args_for(peer, &pa);
+    if (rc) return rc;
+  }
+  JH_LAUNCH(jh_ppo_critic_select_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, d_sums, vf, ent, d_gv, ldv, d_dv2, d_stats_local, d_stats_out, pa);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
@@ -988,7 +1009,7 @@ JH_EXPORT int jh_ppo_loss_deferred(jh_ctx* ctx, int32_t continuous, int32_t B, i
 JH_EXPORT int jh_ppo_critic_select_rows(jh_ctx* ctx, int32_t B, const float* d_critic_sums, float vf_coef, float ent_coef, float* d_grad_value,
                                         const float* d_dv2, const float* d_stats_local, float* d_stats, jh_stream stream) {
   JH_ARG(ctx && B > 0 && d_critic_sums && d_grad_value && d_dv2 && d_stats_local);
-  return jh_ppo_critic_select(B, d_critic_sums, vf_coef, ent_coef, d_grad_value, 1, d_dv2, d_stats_local, d_stats, jh_s(stream));
+  return jh_ppo_critic_select(B, const_cast<float*>(d_critic_sums), vf_coef, ent_coef, d_grad_value, 1, d_dv2, d_stats_local, d_stats, jh_s(stream), nullptr);
 }
 
 // Internal entry (jh_mlp.hip): same losses with the heads given as encoder partial sums (jh_pmb_fwd_kernel) and

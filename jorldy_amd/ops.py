@@ -622,7 +622,7 @@ class PPONet:
                                               L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
                                               float(max_norm if max_norm else 0.0), int(bool(do_adam)), L.ptr(stats), L.stream_ptr()))
 
-    def ppo_update_dp(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, stats, reduce_mean, critic_sums):
+    def ppo_update_dp(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, stats, reduce_mean, critic_sums, peer=None):
         """The minibatch update for data-parallel learners with the reference's critic exactly (jh_pponet_ppo_update_dp_begin / _end around
         an 8-byte all-reduce): reduce_mean(t) all-reduces a small fp32 device tensor to its mean over the ranks, in place, on the current
         stream.  Leaves a complete gradient bucket; the caller reduces it and calls adam_step."""
@@ -630,6 +630,9 @@ class PPONet:
         L.check(self.lib.jh_pponet_ppo_update_dp_begin(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
                                                        L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
                                                        L.ptr(critic_sums), L.stream_ptr()))
+        if peer is not None and B <= 256:  # peer-pointer transport: the ranks' sums meet inside the second half's first launch
+            L.check(self.lib.jh_pponet_ppo_update_dp_end_peer(self.h, peer, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(critic_sums), float(vf_coef), float(ent_coef), L.ptr(stats), L.stream_ptr()))
+            return
         reduce_mean(critic_sums)
         L.check(self.lib.jh_pponet_ppo_update_dp_end(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(critic_sums), float(vf_coef), float(ent_coef), L.ptr(stats), L.stream_ptr()))
 
