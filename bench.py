@@ -404,8 +404,9 @@ def _kmatch(key, name):
     import re
 
     if key.startswith("jh_tgemm_") and key[len("jh_tgemm_"):] in TGEMM_TAGS:
-        tag = TGEMM_TAGS.index(key[len("jh_tgemm_"):])  # staged kernel <TM, TN, TAG> or LDS-DMA kernel <TAG>
-        return re.search(r"jh_tgemm_kernel<\d+, ?\d+, ?%d>|jh_tgemm_dma_kernel<%d>" % (tag, tag), name) is not None
+        tag = TGEMM_TAGS.index(key[len("jh_tgemm_"):])
+        # staged kernel <TM, TN, TAG[, EPI]>; LDS-DMA kernel <TM, TN, TAG, EPI, NB> (round 6) or <TAG, EPI, NB> (rounds 3-5's summaries)
+        return re.search(r"jh_tgemm_kernel<\d+, ?\d+, ?%d[,>]|jh_tgemm_dma_kernel<\d+, ?\d+, ?%d, ?(true|false)|jh_tgemm_dma_kernel<%d, ?(true|false)" % (tag, tag, tag), name) is not None
     return key in name
 
 

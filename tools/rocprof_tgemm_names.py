@@ -2,7 +2,7 @@
 """Put the call-site names back on the grouped GEMM engine's kernels in a rocprofv3 --kernel-trace --stats summary.
 
 The engine's kernels are instantiated once per call site (csrc/jh_tgemm.h: JH_TGEMM_TAGS), so rocprofv3 sees
-`jh_tgemm_kernel<TM, TN, ID>` (register-staged operands) and `jh_tgemm_dma_kernel<ID>` (LDS-DMA operands); this prints the
+`jh_tgemm_kernel<TM, TN, ID, EPI>` (register-staged operands) and `jh_tgemm_dma_kernel<TM, TN, ID, EPI, NB>` (LDS-DMA operands; `<ID, EPI, NB>` in the summaries of rounds 3-5); this prints the
 CSV with `jh_tgemm_<site>[TMxTN|dma]` in their place:  python tools/rocprof_tgemm_names.py profiles/r03_bench_kernel_stats.csv
 """
 import csv
@@ -22,10 +22,13 @@ def tags():
 
 def rename(name, t=None):
     t = t or tags()
-    m = re.search(r"jh_tgemm_kernel<(\d+), ?(\d+), ?(\d+)>", name)
+    m = re.search(r"jh_tgemm_kernel<(\d+), ?(\d+), ?(\d+)[,>]", name)
     if m:
         return f"jh_tgemm_{t.get(int(m.group(3)), m.group(3))}[{32 * int(m.group(1))}x{32 * int(m.group(2))}]"
-    m = re.search(r"jh_tgemm_dma_kernel<(\d+)>", name)
+    m = re.search(r"jh_tgemm_dma_kernel<(\d+), ?(\d+), ?(\d+), ?(?:true|false)", name)  # round 6: <TM, TN, TAG, EPI, NB>
+    if m:
+        return f"jh_tgemm_{t.get(int(m.group(3)), m.group(3))}[dma {32 * int(m.group(1))}x{32 * int(m.group(2))}]"
+    m = re.search(r"jh_tgemm_dma_kernel<(\d+)[,>]", name)  # rounds 3-5: <TAG, EPI, NB>
     if m:
         return f"jh_tgemm_{t.get(int(m.group(1)), m.group(1))}[dma]"
     return name
