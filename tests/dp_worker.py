@@ -147,8 +147,29 @@ def main():
                 torch.cuda.synchronize()
                 want = (both[0] + both[1]) * 0.5 if world == 2 else both.sum(0) / world
                 graph_err.append(float((buf.cpu() - want).abs().max()))
+            # how long one all-reduce of the PPO bucket takes through this transport with both ranks on this ONE device (no xGMI in it: the software
+            # floor of the two launches, their flag hand-offs and write-through copies); 200 back-to-back calls between two events
+            bucket = torch.randn(266_755, device="cuda")
+            for _ in range(20):
+                tr.mean_(bucket)
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                tr.mean_(bucket)
+            e1.record()
+            torch.cuda.synchronize()
+            us_per_allreduce = e0.elapsed_time(e1) * 1e3 / 200
+            small = torch.randn(2, device="cuda")
+            e0.record()
+            for _ in range(200):
+                tr.mean_(small)
+            e1.record()
+            torch.cuda.synchronize()
+            us_per_small = e0.elapsed_time(e1) * 1e3 / 200
             timeouts, done = tr.peer_status()
-            res = dict(means=np.asarray(means), smalls=np.asarray(smalls), graph_err=np.asarray(graph_err), timeouts=timeouts, done=done)
+            res = dict(means=np.asarray(means), smalls=np.asarray(smalls), graph_err=np.asarray(graph_err), timeouts=timeouts, done=done,
+                       us_per_allreduce=us_per_allreduce, us_per_small=us_per_small)
             sync = type("S", (), {"transport": tr})()
         elif mode == "ppo":
             c = PPO_CFG

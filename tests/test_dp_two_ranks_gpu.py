@@ -74,6 +74,7 @@ def test_peer_pointer_collectives_two_processes_one_gpu(tmp_path):
         assert float(r["means"].max()) == 0.0, r["means"]       # the same additions in the same order: bit-exact
         assert float(r["smalls"].max()) <= 1e-6, r["smalls"]
         assert float(r["graph_err"].max()) == 0.0, r["graph_err"]
+    print(f"peer all-reduce of 266 755 floats, two ranks on one GPU: {float(r0['us_per_allreduce']):.1f} us per call; 2-float exchange: {float(r0['us_per_small']):.1f} us")
 
 
 def test_ppo_native_two_ranks_through_peer_pointers(tmp_path, monkeypatch):
