@@ -925,6 +925,46 @@ def main():
         out["repeats"] = {"n": len(chunk_ms), "steps_each": [m1 - m0 for m0, m1 in zip([0] + marks[:-1], marks)], "ms_per_step": [round(v, 4) for v in chunk_ms],
                           "median_ms_per_step": med, "min_ms_per_step": min(chunk_ms), "max_ms_per_step": max(chunk_ms), "median_value": world * W * T / (med * 1e-3),
                           "note": "consecutive chunks of the ONE timed region (rank 0 host clock); `value` is the whole region"}
+    variants = {}
+
+    def emit():
+        # the secondary legs' headline numbers once more, compact and LAST on the line: a truncated tail still carries them
+        leg = lambda k, f: (out.get(k) or {}).get(f)
+        cpu_v = out["cpu_baseline"]["value"] if out.get("cpu_baseline") else None
+        var = lambda k: (variants.get(k) or {}).get("env_transitions_per_s")
+        out["legs"] = {"ppo_env_transitions_s": out["value"], "ppo_ms_per_step": ms_per_step, "ppo_x_cpu_baseline": (out["value"] / cpu_v) if cpu_v else None,
+                       # the same step with ONE timestep per acting exchange (no speculative copies of the built-in CartPole: what any non-forkable env gets)
+                       # and through the generic Python collector (agent.act / env.step per timestep: any Python env)
+                       "ppo_no_lookahead_env_transitions_s": var("one_timestep_per_exchange"),
+                       "ppo_x_cpu_baseline_no_lookahead": (var("one_timestep_per_exchange") / cpu_v) if (cpu_v and var("one_timestep_per_exchange")) else None,
+                       "ppo_python_collector_env_transitions_s": var("python_collector"),
+                       "ppo_x_cpu_baseline_python_collector": (var("python_collector") / cpu_v) if (cpu_v and var("python_collector")) else None,
+                       "dqn_env_steps_s": leg("dqn", "value"), "dqn_x_cpu_reference": leg("dqn", "x_cpu_reference"),
+                       "rainbow_env_steps_s_measured": ((out.get("rainbow") or {}).get("single_mode") or {}).get("env_steps_per_s"),
+                       "rainbow_updates_s": leg("rainbow", "value"), "apex_env_steps_s": leg("apex", "value"), "apex_updates_s": leg("apex", "learner_updates_per_s"),
+                       "hopper_transitions_s": leg("hopper", "value"), "hopper_end_to_end_env_transitions_s": ((out.get("hopper") or {}).get("end_to_end") or {}).get("env_transitions_per_s"),
+                       "hopper_x_cpu_reference": (leg("hopper", "value") / out["hopper"]["cpu_reference"]["value"]) if (out.get("hopper") or {}).get("cpu_reference", {}).get("value") else None}
+        print(json.dumps(out))
+
+    def guard(seconds, key, text):
+        """N > 1 only: the legs after the timed region have never run on separate GPUs (no multi-GPU box in five rounds); one that hangs must not take the
+        line -- the scaling measurement the driver came for -- with it.  After `seconds` rank 0 prints the line with what it has and every rank leaves."""
+        import threading
+
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(seconds):
+                if rank == 0:
+                    out[key] = {"error": text}
+                    emit()
+                    sys.stdout.flush()
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        return done
+
+    legs_done = guard(float(os.environ.get("JH_BENCH_LEGS_TIMEOUT", "1500")), "legs_error", "a leg after the timed region did not finish in time; the line is printed with what had finished") if world > 1 else None
     act_us = None
     if hasattr(collector, "stats"):
         st = collector.stats()
@@ -990,7 +1030,6 @@ def main():
                          "timesteps_per_exchange": 2 if os.environ.get("JH_COLLECT_LOOKAHEAD", "2") != "1" else 1,
                          "bound": "PCIe round trip per EXCHANGE (host envs between two crossings); one exchange carries every env's state and both successor states "
                                   "and serves two timesteps (jh_collect.hip run_loop_lookahead); in-kernel compute ~1.6 us of an exchange (JH_PERSIST_DEBUG=1)"}
-    variants = {}
     if rank == 0 and world == 1 and not args.no_variants and not args.python_collector:
         # the headline number again with the CartPole-only speculation off, and through the generic Python collector (missing #7)
         variants["one_timestep_per_exchange"] = ppo_variant(rank, local_rank, W, T, 40, 8, lookahead=1)
@@ -1009,12 +1048,6 @@ def main():
             out["dqn"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_apex:
         out["apex"] = apex_leg(args.apex_actors, args.apex_updates, args.apex_buffer, args.apex_prefill)
-    elif world > 1 and not args.no_apex:
-        # round 6 (VERDICT r5 missing #2): configs[3] as ONE LEARNER PER GPU -- every rank runs the end-to-end Ape-X loop in process with its own actors, replay
-        # shard and sum tree; the learners' gradient buckets are averaged per learn() over the ranks' transport
-        ap_out = apex_leg_dp(dist, rank, world, args.apex_actors, args.apex_updates if world == 1 else max(200, args.apex_updates // 6), args.apex_buffer, args.apex_prefill)
-        if rank == 0:
-            out["apex"] = ap_out
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_iters, W, T)
         if "hopper" in out:  # CPU work last: nothing on the GPU legs' host side shares the cores with it
@@ -1022,24 +1055,19 @@ def main():
                 out["hopper"]["cpu_reference"] = hopper_cpu_reference(epochs=10 if args.cpu_baseline_iters >= 3 else 1)
             except Exception as e:
                 out["hopper"]["cpu_reference"] = {"error": f"{type(e).__name__}: {e}"}
+    if world > 1 and not args.no_apex:
+        # round 6 (VERDICT r5 missing #2): configs[3] as ONE LEARNER PER GPU -- every rank runs the end-to-end Ape-X loop in process with its own actors, replay
+        # shard and sum tree; the learners' gradient buckets are averaged per learn() over the ranks' transport.  It is the LAST thing of an N > 1 run and sits
+        # under a watchdog: this path has never run on separate GPUs, and a leg that hangs must not take the line -- the scaling measurement -- with it
+        done = guard(float(os.environ.get("JH_APEX_DP_TIMEOUT", "300")), "apex", "the one-learner-per-GPU Ape-X leg did not finish in time; the line is printed without it")
+        ap_out = apex_leg_dp(dist, rank, world, args.apex_actors, max(200, args.apex_updates // 6), args.apex_buffer, args.apex_prefill)
+        done.set()
+        if rank == 0:
+            out["apex"] = ap_out
+    if legs_done is not None:
+        legs_done.set()
     if rank == 0:
-        # the secondary legs' headline numbers once more, compact and LAST on the line: a truncated tail still carries them
-        leg = lambda k, f: (out.get(k) or {}).get(f)
-        cpu_v = out["cpu_baseline"]["value"] if out.get("cpu_baseline") else None
-        var = lambda k: (variants.get(k) or {}).get("env_transitions_per_s")
-        out["legs"] = {"ppo_env_transitions_s": out["value"], "ppo_ms_per_step": ms_per_step, "ppo_x_cpu_baseline": (out["value"] / cpu_v) if cpu_v else None,
-                       # the same step with ONE timestep per acting exchange (no speculative copies of the built-in CartPole: what any non-forkable env gets)
-                       # and through the generic Python collector (agent.act / env.step per timestep: any Python env)
-                       "ppo_no_lookahead_env_transitions_s": var("one_timestep_per_exchange"),
-                       "ppo_x_cpu_baseline_no_lookahead": (var("one_timestep_per_exchange") / cpu_v) if (cpu_v and var("one_timestep_per_exchange")) else None,
-                       "ppo_python_collector_env_transitions_s": var("python_collector"),
-                       "ppo_x_cpu_baseline_python_collector": (var("python_collector") / cpu_v) if (cpu_v and var("python_collector")) else None,
-                       "dqn_env_steps_s": leg("dqn", "value"), "dqn_x_cpu_reference": leg("dqn", "x_cpu_reference"),
-                       "rainbow_env_steps_s_measured": ((out.get("rainbow") or {}).get("single_mode") or {}).get("env_steps_per_s"),
-                       "rainbow_updates_s": leg("rainbow", "value"), "apex_env_steps_s": leg("apex", "value"), "apex_updates_s": leg("apex", "learner_updates_per_s"),
-                       "hopper_transitions_s": leg("hopper", "value"), "hopper_end_to_end_env_transitions_s": ((out.get("hopper") or {}).get("end_to_end") or {}).get("env_transitions_per_s"),
-                       "hopper_x_cpu_reference": (leg("hopper", "value") / out["hopper"]["cpu_reference"]["value"]) if (out.get("hopper") or {}).get("cpu_reference", {}).get("value") else None}
-        print(json.dumps(out))
+        emit()
     if dist is not None:
         dist.destroy_process_group()
 
