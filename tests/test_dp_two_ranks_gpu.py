@@ -219,3 +219,21 @@ def test_bench_two_ranks_on_one_gpu_plumbing(tmp_path, launcher, strong):
     assert ax["n_gpus"] == 2 and ax["value"] > 0 and ax["learner_updates_per_s"] > 0 and np.isfinite(ax["rank0"]["last_result"]["loss"])
     hp = out["hopper"]  # configs[4] strong-scaled over the two ranks: 16 workers and 1024 minibatch rows each, collector + DP learners
     assert hp["n_gpus"] == 2 and hp["config"]["workers_per_gpu"] == 16 and hp["config"]["batch_per_gpu"] == 1024 and hp["value"] > 0
+
+
+def test_bench_two_ranks_prints_the_line_when_a_late_leg_hangs():
+    """The N > 1 legs after the timed region sit under watchdogs (no multi-GPU box has ever run them): with the Ape-X leg's time limit set to a
+    fraction of what it needs, rank 0 still prints the ONE line -- the timed PPO measurement intact, the leg an error entry -- and the job ends with rc 0."""
+    import json
+
+    env = dict(os.environ, JH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", JH_APEX_DP_TIMEOUT="0.5")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-rainbow", "--no-hopper", "--no-roofline", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "did not finish in time" in out["apex"]["error"] and out["legs"]["ppo_env_transitions_s"] == out["value"]
