@@ -225,6 +225,24 @@ int jh_ppo_loss_deferred(jh_ctx* ctx, int32_t continuous, int32_t B, int32_t A, 
 int jh_ppo_critic_select_rows(jh_ctx* ctx, int32_t B, const float* d_critic_sums, float vf_coef, float ent_coef, float* d_grad_value,
                               const float* d_dv2, const float* d_stats_local, float* d_stats, jh_stream stream);
 
+/* The same losses for a network whose LAST LAYER stacks the heads (the policy-value net on the CNN head as jh_rbnet runs it: policy_value.py:8-22 with
+ * head.py:21-61 under it; rows of the last layer = pi [A] | v, or mu [A] | log_std [A] | v): d_heads float32[B][ld] = (head0 [A] | head1 [A] (continuous) |
+ * value | padding), gradient back in the same layout (d_grad_heads float32[B][ld], padding columns untouched).  d_dv2 float32[B] + d_critic_sums float32[2]
+ * both non-NULL: the deferred critic of jh_ppo_loss_deferred (d_stats is then the LOCAL row; finish with jh_ppo_critic_select_strided on the value column,
+ * ldv = ld).  Replaces ppo.py:122-165 for config.ppo.atari / ppo.procgen.                                                                               */
+int jh_ppo_loss_packed(jh_ctx* ctx, int32_t continuous, int32_t B, int32_t A, const float* d_heads, int32_t ld, const int64_t* d_idx, const float* d_action,
+                       const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef,
+                       float ent_coef, float* d_grad_heads, float* d_dv2, float* d_critic_sums, float* d_stats, jh_stream stream);
+int jh_ppo_critic_select_strided(jh_ctx* ctx, int32_t B, const float* d_critic_sums, float vf_coef, float ent_coef, float* d_grad_value, int32_t ldv,
+                                 const float* d_dv2, const float* d_stats_local, float* d_stats, jh_stream stream);
+/* d_packed float32[rows][ld] -> d_h0 [rows][A], d_h1 [rows][A] (NULL: one head), d_value [rows]: what jh_logp_* / jh_gae read (ppo.py:83-94, once per learn()) */
+int jh_heads_unpack(jh_ctx* ctx, int64_t rows, int32_t A, const float* d_packed, int32_t ld, float* d_h0, float* d_h1, float* d_value, jh_stream stream);
+/* PPO.act, discrete policy, heads already on the device (ppo.py:63-69): action[w] = Categorical(softmax(d_heads[w][0..A))).sample() by inverse CDF on the
+ * counter-based stream (seed, counter = timestep, w) -- the stream of jh_pponet_act_discrete's host-side sampler --, or the first maximum when !training.
+ * d_action int64[W]: device or device-mapped host memory.                                                                                                */
+int jh_policy_act_discrete(jh_ctx* ctx, int32_t W, int32_t A, const float* d_heads, int32_t ld, uint64_t seed, uint64_t counter, int32_t training,
+                           int64_t* d_action, jh_stream stream);
+
 /* ------------------------------------------------------------------ TD losses (DQN family)
  * One kernel for dqn.py:128-141, double.py:28-39, multistep.py:41-50, per.py:54-74,
  * ape_x.py:96-116.  flags: */
@@ -492,6 +510,9 @@ int jh_rbnet_sync_target(jh_rbnet* n, jh_stream stream);
  * which 0 online / 1 target, d_noise one noise set or NULL (kind 0: is_train = False) -> logits [rows][A][K] */
 int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int32_t x_dtype, int32_t rows, const float* d_noise,
                      float* d_logits, jh_stream stream);
+/* An on-policy learner's forward (ppo.py:127-135 on the CNN head): network(x) of the online parameters for B <= max_batch rows, activations kept for
+ * jh_rbnet_backward (which then takes d(loss)/d(outputs) [B][A][K] of these rows).  Kinds 1 and 2 (no noise).                                  */
+int jh_rbnet_forward_keep(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, float* d_logits, jh_stream stream);
 /* The three forwards of learn(): d_x = [state; next_state] (2B rows), d_noise three noise sets (kind 0, else
  * NULL) -> d_logits [3][B][A][K] = online(state), online(next_state), target(next_state)                */
 int jh_rbnet_learn_forward(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, const float* d_noise, float* d_logits,

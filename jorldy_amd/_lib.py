@@ -95,6 +95,10 @@ _PROTOS = {
     "jh_pponet_adam_step": (C.c_int, [_vp, _f32, _vp, _vp]),
     "jh_pponet_ppo_update": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "jh_ppo_loss_deferred": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "jh_ppo_loss_packed": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "jh_ppo_critic_select_strided": (C.c_int, [_vp, _i32, _vp, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "jh_heads_unpack": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "jh_policy_act_discrete": (C.c_int, [_vp, _i32, _i32, _vp, _i32, C.c_uint64, C.c_uint64, _i32, _vp, _vp]),
     "jh_ppo_critic_select_rows": (C.c_int, [_vp, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_ppo_update_dp_begin": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp]),
     "jh_pponet_ppo_update_dp_end": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
@@ -121,6 +125,7 @@ _PROTOS = {
     "jh_rbnet_set_lr": (C.c_int, [_vp, _f64, _vp]),
     "jh_rbnet_sync_target": (C.c_int, [_vp, _vp]),
     "jh_rbnet_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "jh_rbnet_forward_keep": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "jh_rbnet_learn_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "jh_rbnet_prepare_noise": (C.c_int, [_vp, _vp, _vp]),
     "jh_rbnet_learn_trunk": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),

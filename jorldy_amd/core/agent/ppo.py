@@ -14,7 +14,8 @@ MAX_HEAD_OUTPUTS = 40  # jh_pponet_create (csrc/jh_mlp.hip: kMaxHeadOutputs): co
 NATIVE_ELIGIBLE = ("PPO runs on libjorldy_hip only: network in {discrete_policy_value, continuous_policy_value}, head='mlp', int state_size, "
                    "hidden_size % 16 == 0, optim_config name 'adam' without weight_decay / amsgrad, and action_size + 1 (discrete) or "
                    f"2 * action_size + 1 (continuous) <= {MAX_HEAD_OUTPUTS} head outputs (config.ppo.cartpole, config.ppo.mujoco on all its envs; up to 8 outputs "
-                   "-- CartPole, Hopper -- on the four-launch minibatch update and the persistent acting kernel, beyond that on the separate calls / the tiled engine)")
+                   "-- CartPole, Hopper -- on the four-launch minibatch update and the persistent acting kernel, beyond that on the separate calls / the tiled engine); "
+                   "head='cnn' with a (C, H, W) state_size and network 'discrete_policy_value' runs on the convolutional engine (core/agent/ppo_cnn.py: config.ppo.atari, ppo.procgen)")
 
 
 class PPO(BaseAgent):
@@ -35,6 +36,14 @@ class PPO(BaseAgent):
     silently switching to library kernels; the reference agent keeps working for those.
     Constructor arguments, `act`, `process`, result keys, checkpoint format are the reference's.
     """
+
+    def __new__(cls, *args, **kwargs):
+        # head="cnn" (config.ppo.atari / ppo.procgen): the same agent on the convolutional engine (ppo_cnn.PPOConv, a subclass: its __init__ runs)
+        if cls is PPO and kwargs.get("head", args[4] if len(args) > 4 else "mlp") == "cnn":
+            from .ppo_cnn import PPOConv
+
+            return object.__new__(PPOConv)
+        return object.__new__(cls)
 
     def __init__(self, state_size, action_size, hidden_size=512, network="discrete_policy_value", head="mlp",
                  optim_config={"name": "adam"}, gamma=0.99, use_standardization=True, run_step=1e6, lr_decay=True,

@@ -428,6 +428,7 @@ struct PpoArgs {
   float* g1;  // unused   | d log_std_raw
   float* gv;  // d value_pred
   int ldg, ldv;  // row strides of g0 / g1 and of gv (A and 1; 8 and 8 when all three are packed into [B][8])
+  int ldh, ldvp; // row strides of h0 / h1 and of value_pred (0: A and 1; jh_ppo_loss_packed: the row width of one [B][ld] output matrix)
   float* partial;
   float* stats;
   int nb;
@@ -730,9 +731,9 @@ __global__ void __launch_bounds__(MAXT) jh_ppo_fused_kernel(PpoArgs<CONT> a) {
     z1 = z0 + a.A;
     if (on) vpred = z0[CONT ? 2 * a.A : a.A];
   } else if (on) {
-    z0 = a.h0 + (size_t)i * a.A;
-    z1 = CONT ? a.h1 + (size_t)i * a.A : nullptr;
-    vpred = a.value_pred[i];
+    z0 = a.h0 + (size_t)i * a.ldh;
+    z1 = CONT ? a.h1 + (size_t)i * a.ldh : nullptr;
+    vpred = a.value_pred[(size_t)i * a.ldvp];
   }
   RowCommon rc{};
   DiscRow dr{};
@@ -770,10 +771,10 @@ __global__ void __launch_bounds__(256) jh_ppo_fwd_kernel(PpoArgs<CONT> a) {
   DiscRow dr{};
   int act_k = 0;
   float ent_row = 0.f, minp = 3.4e38f;
-  const float* z0 = a.h0 + (size_t)ic * a.A;
-  const float* z1 = CONT ? a.h1 + (size_t)ic * a.A : nullptr;
+  const float* z0 = a.h0 + (size_t)ic * a.ldh;
+  const float* z1 = CONT ? a.h1 + (size_t)ic * a.ldh : nullptr;
   const RowIn rin = ppo_row_load<CONT>(a, ic);
-  const float vpred = a.value_pred[ic];
+  const float vpred = a.value_pred[(size_t)ic * a.ldvp];
   ContPre pre;
   if (CONT) pre = ppo_cont_prefetch<CONT>(a, z0, z1, rin.r);
   ppo_row_fwd<CONT>(a, rin, z0, z1, vpred, rc, ent_row, minp, dr, act_k, CONT ? &pre : nullptr);
@@ -846,10 +847,10 @@ __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool on = i < a.B;
   const int ic = on ? i : a.B - 1;
-  const float* z0 = a.h0 + (size_t)ic * a.A;
-  const float* z1 = CONT ? a.h1 + (size_t)ic * a.A : nullptr;
+  const float* z0 = a.h0 + (size_t)ic * a.ldh;
+  const float* z1 = CONT ? a.h1 + (size_t)ic * a.ldh : nullptr;
   const RowIn rin = ppo_row_load<CONT>(a, ic);
-  const float vpred = a.value_pred[ic];
+  const float vpred = a.value_pred[(size_t)ic * a.ldvp];
   ContPre pre;
   if (CONT) pre = ppo_cont_prefetch<CONT>(a, z0, z1, rin.r);
   float t[6];
@@ -873,6 +874,8 @@ __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
 
 template <bool CONT>
 static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
+  if (a.ldh == 0) a.ldh = a.A;
+  if (a.ldvp == 0) a.ldvp = 1;
   if (a.B <= 1024) {
     const int threads = ((a.B + 63) / 64) * 64;
     a.nb = 1;
@@ -1006,10 +1009,107 @@ JH_EXPORT int jh_ppo_loss_deferred(jh_ctx* ctx, int32_t continuous, int32_t B, i
   return ppo_launch<false>(ctx, a, jh_s(stream));
 }
 
+// The heads in ONE row-major matrix, as a network whose last layer stacks them leaves them (jh_rbnet kind q with A + 1 | 2 A + 1 output rows: the policy-
+// value net on the CNN head, policy_value.py:8-22 | 38-57): d_heads [B][ld] = (head0 [A] | head1 [A] (continuous) | value | padding), and the gradient goes back
+// in the same layout (d_grad_heads [B][ld]; padding columns are not written).  d_dv2 / d_critic_sums / non-null: the deferred critic of jh_ppo_loss_deferred.
+JH_EXPORT int jh_ppo_loss_packed(jh_ctx* ctx, int32_t continuous, int32_t B, int32_t A, const float* d_heads, int32_t ld, const int64_t* d_idx,
+                                 const float* d_action, const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old,
+                                 float eps_clip, float vf_coef, float ent_coef, float* d_grad_heads, float* d_dv2, float* d_critic_sums, float* d_stats,
+                                 jh_stream stream) {
+  JH_ARG(ctx && d_heads && d_action && d_adv && d_ret && d_value_old && d_logp_old && d_grad_heads);
+  JH_ARG(B > 0 && A > 0 && ld >= (continuous ? 2 * A + 1 : A + 1) && (!d_dv2 == !d_critic_sums));
+  const int nv = continuous ? 2 * A : A;
+  if (continuous) {
+    PpoArgs<true> a{};
+    a.B = B; a.A = A; a.h0 = d_heads; a.h1 = d_heads + A; a.value_pred = d_heads + nv; a.ldh = ld; a.ldvp = ld; a.idx = d_idx;
+    a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+    a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_heads; a.g1 = d_grad_heads + A; a.gv = d_grad_heads + nv;
+    a.ldg = ld; a.ldv = ld; a.stats = d_stats; a.defer_dv2 = d_dv2; a.critic_sums = d_critic_sums;
+    return ppo_launch<true>(ctx, a, jh_s(stream));
+  }
+  PpoArgs<false> a{};
+  a.B = B; a.A = A; a.h0 = d_heads; a.h1 = nullptr; a.value_pred = d_heads + nv; a.ldh = ld; a.ldvp = ld; a.idx = d_idx;
+  a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+  a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_grad_heads; a.g1 = nullptr; a.gv = d_grad_heads + nv;
+  a.ldg = ld; a.ldv = ld; a.stats = d_stats; a.defer_dv2 = d_dv2; a.critic_sums = d_critic_sums;
+  return ppo_launch<false>(ctx, a, jh_s(stream));
+}
+
+// ... and apart again for the kernels that want them apart (log pi_old, GAE: once per learn() over the whole rollout): d_h0 [rows][A], d_h1 [rows][A] or null,
+// d_value [rows].
+__global__ void __launch_bounds__(256) jh_heads_unpack_kernel(int64_t rows, int A, int n_heads, const float* __restrict__ packed, int ld, float* __restrict__ h0,
+                                                              float* __restrict__ h1, float* __restrict__ value) {
+  const int w = n_heads * A + 1;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * w) return;
+  const int64_t r = i / w;
+  const int c = (int)(i - r * w);
+  const float x = packed[r * ld + c];
+  if (c < A) h0[r * A + c] = x;
+  else if (c < n_heads * A) h1[r * A + (c - A)] = x;
+  else value[r] = x;
+}
+JH_EXPORT int jh_heads_unpack(jh_ctx* ctx, int64_t rows, int32_t A, const float* d_packed, int32_t ld, float* d_h0, float* d_h1, float* d_value, jh_stream stream) {
+  JH_ARG(ctx && d_packed && d_h0 && d_value && rows > 0 && A > 0);
+  const int n_heads = d_h1 ? 2 : 1;
+  JH_ARG(ld >= n_heads * A + 1);
+  const int64_t tot = rows * (n_heads * A + 1);
+  JH_LAUNCH(jh_heads_unpack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, jh_s(stream), rows, A, n_heads, d_packed, ld, d_h0, d_h1, d_value);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
+// PPO.act for a discrete policy whose heads are already on the device (ppo.py:63-69): Categorical(softmax(z)).sample() by inverse CDF on the SAME
+// counter-based stream as the host-side sampler of the MLP policy (jh_common.h: jh_sample_discrete; key = seed, timestep counter, row), argmax (first
+// maximum, torch.argmax) when !training.  One thread per row; d_action [W] int64 (device or device-mapped host memory).
+__device__ __forceinline__ static uint64_t jh_mix64_dev(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(64) jh_policy_act_discrete_kernel(int W, int A, const float* __restrict__ heads, int ld, uint64_t seed, uint64_t ctr, int training,
+                                                                    int64_t* __restrict__ action) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= W) return;
+  const float* z = heads + (size_t)w * ld;
+  int act = 0;
+  float mx = z[0];
+  for (int k = 1; k < A; ++k)
+    if (z[k] > mx) { mx = z[k]; act = k; }
+  if (training) {
+    float se = 0.f;
+    for (int k = 0; k < A; ++k) se += expf(z[k] - mx);
+    const double u01 = (double)(jh_mix64_dev(seed * 0x100000001B3ull + ctr * 0x9E3779B97F4A7C15ull + (uint64_t)w) >> 11) * (1.0 / 9007199254740992.0);
+    const float u = (float)u01 * se;
+    float c = 0.f;
+    act = A - 1;
+    for (int k = 0; k < A; ++k) {
+      c += expf(z[k] - mx);
+      if (u < c) { act = k; break; }
+    }
+  }
+  action[w] = act;
+}
+JH_EXPORT int jh_policy_act_discrete(jh_ctx* ctx, int32_t W, int32_t A, const float* d_heads, int32_t ld, uint64_t seed, uint64_t counter, int32_t training,
+                                     int64_t* d_action, jh_stream stream) {
+  JH_ARG(ctx && d_heads && d_action && W > 0 && A > 0 && ld >= A);
+  JH_LAUNCH(jh_policy_act_discrete_kernel, dim3((W + 63) / 64), dim3(64), 0, jh_s(stream), W, A, d_heads, ld, seed, counter, training, d_action);
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
 JH_EXPORT int jh_ppo_critic_select_rows(jh_ctx* ctx, int32_t B, const float* d_critic_sums, float vf_coef, float ent_coef, float* d_grad_value,
                                         const float* d_dv2, const float* d_stats_local, float* d_stats, jh_stream stream) {
   JH_ARG(ctx && B > 0 && d_critic_sums && d_grad_value && d_dv2 && d_stats_local);
   return jh_ppo_critic_select(B, const_cast<float*>(d_critic_sums), vf_coef, ent_coef, d_grad_value, 1, d_dv2, d_stats_local, d_stats, jh_s(stream), nullptr);
+}
+
+// ... for a gradient that sits in a packed [B][ld] matrix (jh_ppo_loss_packed): d_grad_value = its value column, ldv = ld
+JH_EXPORT int jh_ppo_critic_select_strided(jh_ctx* ctx, int32_t B, const float* d_critic_sums, float vf_coef, float ent_coef, float* d_grad_value, int32_t ldv,
+                                           const float* d_dv2, const float* d_stats_local, float* d_stats, jh_stream stream) {
+  JH_ARG(ctx && B > 0 && ldv > 0 && d_critic_sums && d_grad_value && d_dv2 && d_stats_local);
+  return jh_ppo_critic_select(B, const_cast<float*>(d_critic_sums), vf_coef, ent_coef, d_grad_value, ldv, d_dv2, d_stats_local, d_stats, jh_s(stream), nullptr);
 }
 
 // Internal entry (jh_mlp.hip): same losses with the heads given as encoder partial sums (jh_pmb_fwd_kernel) and

@@ -1026,6 +1026,18 @@ JH_EXPORT int jh_rbnet_forward(jh_rbnet* n, int32_t which, const void* d_x, int3
   return rb_heads(n, &hj, 1, rows, st);
 }
 
+// The forward of an on-policy learner (PPO on the CNN head, ppo.py:127-135): network(x) of the online parameters for B <= max_batch rows with every
+// activation kept for jh_rbnet_backward (which then takes d(loss)/d(outputs) [B][A][K] of THESE rows).  Networks without noise only (q, dueling).
+JH_EXPORT int jh_rbnet_forward_keep(jh_rbnet* n, const void* d_x, int32_t x_dtype, int32_t B, float* d_logits, jh_stream stream) {
+  JH_ARG(n && d_x && d_logits);
+  if (n->noisy) return jh_fail(JH_ERR_ARG, "jh_rbnet_forward_keep: a noisy network's learn() is jh_rbnet_learn_forward");
+  int rc = jh_rbnet_forward(n, 0, d_x, x_dtype, B, nullptr, d_logits, stream);
+  if (rc) return rc;
+  n->last_x = d_x; n->last_x_u8 = x_dtype == JH_U8; n->last_B = B;
+  n->last_noise = nullptr; n->raw_heads = 0; n->dx_ready = 0;
+  return JH_OK;
+}
+
 // The three forwards of Rainbow.learn (agent/rainbow.py:160-186) in one pass:
 //   d_x = [state (B rows); next_state (B rows)]  (one contiguous batch of 2B observations)
 //   logits[0] = online(state; noise 0)   logits[1] = online(next_state; noise 1)   logits[2] = target(next_state; noise 2)

@@ -518,6 +518,45 @@ def ppo_loss_dp(head0, head1, value_pred, idx, action, adv, ret, value_old, logp
     return (g0, g1, g_v.view(-1, 1)) if cont else (g0, g_v.view(-1, 1))
 
 
+def ppo_loss_packed(heads, A, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, grad_out, stats, continuous=False, reduce_mean=None, work=None):
+    """The PPO losses (ppo.py:122-165) on a network whose last layer stacks the heads (jh_ppo_loss_packed): heads float32 [B, ld] = (head0 [A] | head1 [A]
+    (continuous) | value | padding), grad_out the same shape -- d(loss)/d(heads), padding columns untouched (keep them zero).  idx None: the per-row
+    inputs are already the minibatch's rows.  reduce_mean + work (>= B + 16 floats): data-parallel learners, the critic branch of the GLOBAL minibatch
+    (ppo_loss_dp's scheme)."""
+    lib = L.load()
+    assert heads.dtype == torch.float32 and heads.is_contiguous() and grad_out.is_contiguous() and grad_out.shape == heads.shape
+    B, ld = int(heads.shape[0]), int(heads.shape[1])
+    ctx = L.ctx(_dev(heads))
+    act = _f32(action) if continuous else _f32(action).reshape(-1)
+    lpo = _f32(logp_old) if continuous else _f32(logp_old).reshape(-1)
+    dv2 = sums = local = None
+    if reduce_mean is not None:
+        dv2, sums, local = work[:B], work[B : B + 2], work[B + 8 : B + 16]
+    L.check(lib.jh_ppo_loss_packed(ctx, int(bool(continuous)), B, int(A), L.ptr(heads), ld, L.ptr(idx), L.ptr(act), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
+                                   L.ptr(_f32(value_old).reshape(-1)), L.ptr(lpo), float(eps_clip), float(vf_coef), float(ent_coef), L.ptr(grad_out), L.ptr(dv2), L.ptr(sums),
+                                   L.ptr(local if reduce_mean is not None else stats), L.stream_ptr()))
+    if reduce_mean is not None:
+        reduce_mean(sums)
+        nv = (2 * A if continuous else A)
+        gv = grad_out.view(-1)[nv:]  # the value column, row stride ld
+        L.check(lib.jh_ppo_critic_select_strided(ctx, B, L.ptr(sums), float(vf_coef), float(ent_coef), L.ptr(gv), ld, L.ptr(dv2), L.ptr(local), L.ptr(stats), L.stream_ptr()))
+    return grad_out
+
+
+def heads_unpack(packed, A, h0, h1, value):
+    """packed [rows, ld] -> h0 [rows, A], h1 [rows, A] (or None), value [rows]: the layout jh_logp_* / jh_gae read."""
+    assert packed.is_contiguous() and h0.is_contiguous() and value.is_contiguous() and (h1 is None or h1.is_contiguous())
+    L.check(L.load().jh_heads_unpack(L.ctx(_dev(packed)), int(packed.shape[0]), int(A), L.ptr(packed), int(packed.shape[1]), L.ptr(h0), L.ptr(h1), L.ptr(value), L.stream_ptr()))
+
+
+def policy_act_discrete(heads, A, seed, counter, training, out):
+    """ppo.py:63-69 on device-resident heads [W, ld]: out int64 [W] (device / device-mapped) <- sampled (training) or greedy actions."""
+    assert heads.is_contiguous() and out.dtype == torch.int64
+    L.check(L.load().jh_policy_act_discrete(L.ctx(_dev(heads)), int(heads.shape[0]), int(A), L.ptr(heads), int(heads.shape[1]), int(seed) & (2**64 - 1), int(counter) & (2**64 - 1),
+                                            int(bool(training)), L.ptr(out), L.stream_ptr()))
+    return out
+
+
 # ============================================================================= native policy-value MLP
 class PinnedBuffer:
     """Pinned host memory mapped into the device address space (jh_pinned_alloc): `.np` is the host
@@ -847,7 +886,7 @@ class RainbowNet:
 
     _SEG = ("w1", "b1", "w2", "b2", "w3", "b3", "wl", "bl", "mu_av1", "sig_av1", "mub_av1", "sigb_av1", "mu_a2", "sig_a2", "mub_a2", "sigb_a2",
             "mu_v2", "sig_v2", "mub_v2", "sigb_v2")
-    _KIND = {"rainbow": 0, "dueling": 1, "q": 2}
+    _KIND = {"rainbow": 0, "dueling": 1, "q": 2, "pv": 2}  # "pv": the discrete policy-value net (policy_value.py:8-22) = head -> l -> (pi | v) stacked into ONE last layer of A + 1 rows
 
     def __init__(self, state_size, action_size, num_support, hidden, head, max_batch, device, kind="rainbow", noise_type="factorized"):
         self.lib = L.load()
@@ -860,6 +899,8 @@ class RainbowNet:
         else:
             self.Cin, self.Hin, self.Win = int(state_size), 0, 0
         self.H, self.A, self.K, self.maxB = int(hidden), int(action_size), int(num_support), int(max_batch)
+        if kind == "pv":
+            self.n_actions, self.A = self.A, self.A + 1  # the library sees a q-network with one more output row: the value head
         kid = self._KIND[kind]
         self.noise_type = noise_type
         if kind == "rainbow" and noise_type == "independent":
@@ -933,6 +974,11 @@ class RainbowNet:
             out += [("l1_a.weight", self._feat_cols(av1[:H])), ("l1_a.bias", bav1[:H]), ("l1_v.weight", self._feat_cols(av1[H:])), ("l1_v.bias", bav1[H:]),
                     ("l2_a.weight", self._v(bucket, "mu_a2")), ("l2_a.bias", self._v(bucket, "mub_a2").view(-1)),
                     ("l2_v.weight", self._v(bucket, "mu_v2")), ("l2_v.bias", self._v(bucket, "mub_v2").view(-1))]
+        elif self.kind == "pv":
+            w, b, n = self._v(bucket, "mu_a2"), self._v(bucket, "mub_a2").view(-1), self.n_actions
+            out += head
+            out += [("l.weight", self._feat_cols(self._v(bucket, "wl"))), ("l.bias", self._v(bucket, "bl").view(-1)),
+                    ("pi.weight", w[:n]), ("pi.bias", b[:n]), ("v.weight", w[n:]), ("v.bias", b[n:])]
         else:
             out += head
             out += [("l.weight", self._feat_cols(self._v(bucket, "wl"))), ("l.bias", self._v(bucket, "bl").view(-1)),
@@ -988,6 +1034,12 @@ class RainbowNet:
         if out is None:
             out = torch.empty(rows, self.A, self.K, dtype=torch.float32, device=self.device)
         L.check(self.lib.jh_rbnet_forward(self.h, int(which), L.ptr(x), self._xdt(x), rows, L.ptr(noise), L.ptr(out), L.stream_ptr()))
+        return out
+
+    def forward_keep(self, x, out):
+        """network(x) of the online parameters with the activations kept for `backward` (an on-policy learner's forward: jh_rbnet_forward_keep)."""
+        assert x.is_contiguous() and out.is_contiguous() and x.device == self.device
+        L.check(self.lib.jh_rbnet_forward_keep(self.h, L.ptr(x), self._xdt(x), int(x.shape[0]), L.ptr(out), L.stream_ptr()))
         return out
 
     def learn_forward(self, x_all, B, noise, out):

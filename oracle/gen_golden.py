@@ -250,6 +250,10 @@ def gen_ppo(out_dir, only=None):
         # (seed 15), Ant's 3.2e-6 (seed 5).  JH_GEN_ROLLOUT_SEED overrides for the search.)
         ("ppo_cont_halfcheetah", 17, 6, 512, 2, 1024, 1024, 2, True, True, 15),
         ("ppo_cont_ant_mb256", 27, 8, 512, 2, 256, 256, 2, True, True, 5),
+        # round 6: PPO on the CNN head (policy_value.py:8-22 over head.py:21-61).  A small image, and config.ppo.atari's shapes exactly
+        # ((4, 84, 84) uint8 frames, hidden 512, minibatch 32, lr 2.5e-4; config/ppo/atari.py:16-36) with A = 6 (Pong) on a 2 x 32 rollout
+        ("ppo_disc_cnn_small", (4, 44, 52), 4, 64, 2, 16, 16, 2, False, True),
+        ("ppo_disc_atari", (4, 84, 84), 6, 512, 2, 32, 32, 2, False, True),
     ]
     for case in cases:
         name, S, A, H, W, T, B, E, cont, recipe = case[:10]
@@ -259,10 +263,11 @@ def gen_ppo(out_dir, only=None):
         torch.manual_seed(11)
         np.random.seed(11)
         agent = PPO(
-            state_size=S,
+            state_size=list(S) if isinstance(S, tuple) else S,
             action_size=A,
             hidden_size=H,
             network="continuous_policy_value" if cont else "discrete_policy_value",
+            head="cnn" if isinstance(S, tuple) else "mlp",
             optim_config={"name": "adam", "lr": 2.5e-4},
             batch_size=B,
             n_step=T,
@@ -290,7 +295,7 @@ def gen_ppo(out_dir, only=None):
 
         rng = np.random.RandomState(rollout_seed)
         M = W * T
-        trs = synth.ppo_rollout(rng, M, S, A, cont, clamp_every=0 if recipe else 17)
+        trs = synth.ppo_image_rollout(rng, M, S, A) if isinstance(S, tuple) else synth.ppo_rollout(rng, M, S, A, cont, clamp_every=0 if recipe else 17)
         agent.memory.first_store = False
 
         # capture pre-softmax / pre-clamp head outputs with grads
@@ -355,7 +360,9 @@ def gen_ppo(out_dir, only=None):
         assert result, "learn did not run"
 
         out = {}
-        out["cfg"] = np.asarray([S, A, H, W, T, B, E, int(cont)])
+        out["cfg"] = np.asarray([0 if isinstance(S, tuple) else S, A, H, W, T, B, E, int(cont)])
+        if isinstance(S, tuple):
+            out["state_shape"] = np.asarray(S)
         out["hyper"] = np.asarray([0.99, 0.95, 0.1, 1.0, 0.01, 1.0, 2.5e-4])  # gamma, lambda, eps, vf, ent, clip, lr
         out["np_seed"] = np.asarray(21)
         th = synth.thin if recipe else (lambda a: a)

@@ -18,23 +18,36 @@ from .jorldy_oracle import CartPoleOracle, RolloutOracle
 
 
 class _PolicyValue(torch.nn.Module):
-    """discrete/continuous policy-value MLP with the reference's parameter names
-    (core/network/policy_value.py:8-57, head.py:6-18)."""
+    """discrete/continuous policy-value net with the reference's parameter names (core/network/policy_value.py:8-57) on the MLP head
+    (head.py:6-18; S an int) or the CNN head (head.py:21-61; S = (C, H, W), frames divided by 255 in the head)."""
 
     def __init__(self, S, A, H, continuous):
         super().__init__()
         self.continuous = continuous
         self.head = torch.nn.Module()
-        self.head.l = torch.nn.Linear(S, H)
-        self.l = torch.nn.Linear(H, H)
+        self.cnn = not isinstance(S, (int, np.integer))
+        gain = torch.nn.init.calculate_gain("relu")
+        if self.cnn:
+            self.head.conv1 = torch.nn.Conv2d(S[0], 32, kernel_size=8, stride=4)
+            self.head.conv2 = torch.nn.Conv2d(32, 64, kernel_size=4, stride=2)
+            self.head.conv3 = torch.nn.Conv2d(64, 64, kernel_size=3, stride=1)
+            d = [((S[1] - 8) // 4 + 1), ((S[2] - 8) // 4 + 1)]
+            d = [(v - 4) // 2 + 1 for v in d]
+            d = [v - 3 + 1 for v in d]
+            for conv in (self.head.conv1, self.head.conv2, self.head.conv3):
+                torch.nn.init.orthogonal_(conv.weight.data, gain)
+                torch.nn.init.zeros_(conv.bias.data)
+            self.l = torch.nn.Linear(64 * d[0] * d[1], H)
+        else:
+            self.head.l = torch.nn.Linear(S, H)
+            self.l = torch.nn.Linear(H, H)
         if continuous:
             self.mu = torch.nn.Linear(H, A)
             self.log_std = torch.nn.Linear(H, A)
         else:
             self.pi = torch.nn.Linear(H, A)
         self.v = torch.nn.Linear(H, 1)
-        gain = torch.nn.init.calculate_gain("relu")
-        for lin, g in ((self.head.l, gain), (self.l, gain), (self.v, 1.0)):
+        for lin, g in (((self.head.l, gain),) if not self.cnn else ()) + ((self.l, gain), (self.v, 1.0)):
             torch.nn.init.orthogonal_(lin.weight.data, g)
             torch.nn.init.zeros_(lin.bias.data)
         if continuous:
@@ -47,7 +60,12 @@ class _PolicyValue(torch.nn.Module):
             torch.nn.init.zeros_(self.pi.bias.data)
 
     def forward(self, x):
-        x = F.relu(self.l(F.relu(self.head.l(x))))
+        if self.cnn:
+            x = x / 255.0
+            x = F.relu(self.head.conv3(F.relu(self.head.conv2(F.relu(self.head.conv1(x))))))
+            x = F.relu(self.l(x.view(x.size(0), -1)))
+        else:
+            x = F.relu(self.l(F.relu(self.head.l(x))))
         if self.continuous:
             return torch.clamp(self.mu(x), -5.0, 5.0), torch.tanh(self.log_std(x)).exp(), self.v(x)
         return torch.exp(F.log_softmax(self.pi(x), dim=-1)), self.v(x)

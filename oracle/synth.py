@@ -103,6 +103,20 @@ def ppo_rollout(rng, M, S, A, cont, clamp_every=17):
     return trs
 
 
+def ppo_image_rollout(rng, M, S, A):
+    """M synthetic PPO transitions on uint8 frames of shape S = (C, H, W) (core/env/atari.py:147-149 hands frames over as uint8), discrete actions."""
+    trs = []
+    for _ in range(M):
+        trs.append({
+            "state": rng.randint(0, 256, size=(1,) + tuple(S)).astype(np.uint8),
+            "next_state": rng.randint(0, 256, size=(1,) + tuple(S)).astype(np.uint8),
+            "reward": rng.randn(1, 1) * 0.5,
+            "done": np.asarray([[rng.rand() < 0.05]]),
+            "action": rng.randint(0, A, size=(1, 1)),
+        })
+    return trs
+
+
 def row_checksum(a):
     """int64 byte sum + a position-weighted sum per leading row: pins regenerated frames to the fixture."""
     b = np.ascontiguousarray(a).reshape(a.shape[0], -1).view(np.uint8).astype(np.int64)

@@ -1,0 +1,241 @@
+"""PPO on the CNN head (config.ppo.atari / ppo.procgen: policy_value.py:8-22 over head.py:21-61) against runs of the unmodified reference:
+
+  ppo_disc_cnn_small   (4, 44, 52) uint8 frames, A = 4, hidden 64, 2 x 16 rows, minibatch 16, 2 epochs
+  ppo_disc_atari       config.ppo.atari's shapes exactly: (4, 84, 84) uint8 frames, hidden 512, minibatch 32, lr 2.5e-4; A = 6 (Pong), 2 x 32 rows, 2 epochs
+
+Frames and initial weights are regenerated from seeds (oracle/synth.py: the values the generator wrote into the reference agent) and pinned by the
+fixture's checksums / strided samples.  Tolerances: north_star's 1e-5 -- values, log-probs, GAE, heads and the loss scalars of EVERY update
+(|ours - ref| / (1 + |ref|)); gradients relative to the tensor's largest entry."""
+import os
+
+import numpy as np
+
+import margins
+import pytest
+import torch
+
+from oracle import synth
+from tests.util import load, npy
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["ppo_disc_cnn_small", "ppo_disc_atari"]
+
+
+def _thin_cmp(ours, z, prefix, scale_of=None, tol=1e-5, what=""):
+    for k, v in ours.items():
+        ref = z[prefix + k]
+        got = synth.thin(np.asarray(v))
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        scale = float(scale_of(k)) if scale_of else float(np.abs(ref).max())
+        margins.leq(float(np.abs(got - ref).max()) / (scale + 1e-30), tol, f"{what} {k}: max |diff| / the tensor's largest entry")
+
+
+def _agent(z, **kw):
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.core.agent.ppo_cnn import PPOConv
+
+    _, A, H, W, T, B, E, cont = [int(x) for x in z["cfg"]]
+    S = tuple(int(v) for v in z["state_shape"])
+    gamma, lam, eps, vf, ent, clip, lr = z["hyper"]
+    agent = Agent("ppo", state_size=list(S), action_size=A, hidden_size=H, network="discrete_policy_value", head="cnn", optim_config={"name": "adam", "lr": lr},
+                  batch_size=B, n_step=T, n_epoch=E, _lambda=lam, epsilon_clip=eps, vf_coef=vf, ent_coef=ent, clip_grad_norm=clip, gamma=gamma, run_step=100000,
+                  num_workers=W, device="cuda", **kw)
+    assert isinstance(agent, PPOConv) and agent.backend == "native"
+    rec = synth.ppo_recipe({k: v.shape for k, v in agent.network.state_dict().items()}, int(z["recipe_seed"]))
+    assert list(rec) == [k[9:] for k in z.files if k.startswith("sd0_thin/")]  # the reference's state_dict keys, in its order
+    agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in rec.items()})
+    _thin_cmp({k: npy(v) for k, v in agent.network.state_dict().items()}, z, "sd0_thin/", tol=0.0, what="initial weights")
+    M = W * T
+    trs = synth.ppo_image_rollout(np.random.RandomState(int(z["rollout_seed"])), M, S, A)
+    cols = {k: np.concatenate([t[k] for t in trs], 0) for k in ("state", "next_state", "reward", "done", "action")}
+    for k in ("state", "reward", "action"):
+        assert np.array_equal(synth.row_checksum(cols[k].astype(np.float32))[:: max(1, M // 64)], z[f"in_{k}_check"]), k
+    agent.memory.first_store = False
+    return agent, cols, (S, A, H, W, T, B, E), float(lr)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_ppo_cnn_first_minibatch_step_by_step(name):
+    """ppo.py:83-165 through the C ABI, one step at a time against the reference's intermediates: the no-grad passes (values, log pi_old), GAE, minibatch 0's
+    forward (kept), the packed loss (statistics + head gradients), the backward into the flat gradient bucket."""
+    from jorldy_amd import ops
+
+    z = load(name)
+    agent, cols, (S, A, H, W, T, B, E), lr = _agent(z, use_graph=False)
+    gamma, lam, eps, vf, ent, clip, _ = [float(v) for v in z["hyper"]]
+    net, M = agent._net, W * T
+    assert net.kind == "pv" and net.n_actions == A and net.A == A + 1
+    u8 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    x_all = torch.cat([u8(cols["state"]), u8(cols["next_state"])], 0)
+    assert x_all.dtype == torch.uint8
+    packed = torch.empty(2 * M, A + 1, device="cuda")
+    for o in range(0, 2 * M, net.maxB):
+        net.forward(x_all[o : o + net.maxB], 0, None, out=packed[o : o + net.maxB])
+    h0, v = torch.empty(2 * M, A, device="cuda"), torch.empty(2 * M, device="cuda")
+    ops.heads_unpack(packed, A, h0, None, v)
+    np.testing.assert_array_equal(npy(h0), npy(packed[:, :A]))
+    np.testing.assert_array_equal(npy(v), npy(packed[:, A]))
+    np.testing.assert_allclose(npy(v[:M]).reshape(-1, 1), z["gae/value"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(npy(v[M:]).reshape(-1, 1), z["gae/next_value"], rtol=1e-5, atol=1e-5)
+    action, reward, done = f32(cols["action"]), f32(cols["reward"]), f32(cols["done"])
+    logp_old = ops.logp_discrete(h0[:M], action)
+    np.testing.assert_allclose(npy(logp_old), z["gae/log_prob_old"], rtol=1e-5, atol=1e-5)
+    adv, ret = ops.gae(reward, done, v[:M], v[M:], T, gamma, lam, True)
+    np.testing.assert_allclose(npy(adv), z["gae/adv"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(npy(ret), z["gae/ret"], rtol=1e-5, atol=1e-5)
+    # minibatch 0 with the reference's own values upstream (isolates this step)
+    idx = torch.from_numpy(z["mb0/idx"].astype(np.int64)).cuda()
+    b = int(idx.numel())
+    x_mb = x_all[:M][idx].contiguous()
+    heads, grad = torch.empty(b, A + 1, device="cuda"), torch.zeros(b, A + 1, device="cuda")
+    net.forward_keep(x_mb, heads)
+    np.testing.assert_allclose(npy(heads[:, :A]), z["mb0/head/logits"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(npy(heads[:, A:]), z["mb0/head/v"], rtol=1e-5, atol=1e-5)
+    adv_r, ret_r, v_r, lp_r = f32(z["gae/adv"]), f32(z["gae/ret"]), f32(z["gae/value"]), f32(z["gae/log_prob_old"])
+    stats = torch.zeros(8, device="cuda")
+    ops.ppo_loss_packed(heads, A, idx, action, adv_r, ret_r, v_r, lp_r, eps, vf, ent, grad, stats)
+    s = npy(stats)
+    for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")):
+        np.testing.assert_allclose(s[j], z[f"mb0/{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
+    # the packed loss against the separate-heads entry point on the same inputs: the same kernel with other strides -> the same bits
+    g_z, g_v, st2 = ops.ppo_loss_discrete(heads[:, :A].contiguous(), heads[:, A].contiguous(), idx, action, adv_r, ret_r, v_r, lp_r, eps, vf, ent)
+    np.testing.assert_array_equal(npy(grad[:, :A]), npy(g_z))
+    np.testing.assert_array_equal(npy(grad[:, A:]), npy(g_v))
+    np.testing.assert_array_equal(npy(stats), npy(st2))
+    for tag, g in (("logits", grad[:, :A]), ("v", grad[:, A:])):
+        ref = z[f"mb0/head/d_{tag}"]
+        margins.leq(float(np.abs(npy(g).reshape(ref.shape) - ref).max()) / float(np.abs(ref).max()), 1e-5, f"{name}: d(loss)/d({tag}) of minibatch 0 vs the reference's")
+    net.backward(grad)
+    torch.cuda.synchronize()
+    grads = net.export_state(net.grads)
+    _thin_cmp({k: npy(g) for k, g in grads.items()}, z, "mb0/grad_raw/", scale_of=lambda k: z[f"mb0/grad_raw_absmax/{k}"], tol=1e-5, what=f"{name}: d(loss)/d")
+    norm = float(np.sqrt(sum(float((npy(g).astype(np.float64) ** 2).sum()) for g in grads.values())))
+    np.testing.assert_allclose(norm, float(z["mb0/grad_raw_norm"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("graph", [False, True])
+def test_ppo_cnn_learn_matches_reference(name, graph):
+    """One process() = one learn() of the reference (E epochs x M / B minibatch updates with clip_grad_norm_ + Adam), eager and as ONE hipGraph."""
+    z = load(name)
+    agent, cols, (S, A, H, W, T, B, E), lr = _agent(z, use_graph=graph)
+    n_upd = int(z["n_minibatch"])
+    sd0 = {k: v.clone() for k, v in agent.network.state_dict().items()}
+    for rep in range(3 if graph else 1):  # graph: eager warm-up, capture + replay, replay
+        agent.network.load_state_dict(sd0)
+        agent._net.m.zero_()
+        agent._net.v.zero_()
+        agent._adam_steps = 0
+        agent._net.set_hyper(lr, 0.9, 0.999, 1e-8, 0)
+        agent._lr_now = lr
+        agent.time_t, agent.learn_stamp = 0, 0
+        np.random.seed(int(z["np_seed"]))
+        result = agent.process(cols, T)
+        assert agent.memory.size == 0
+        if graph and rep >= 1:
+            assert agent._graph is not None
+        s = npy(agent._stats[:n_upd]).astype(np.float64)
+        for i in range(n_upd):
+            e = max(abs(s[i, j] - float(z[f"mb{i}/{k}"])) / (1.0 + abs(float(z[f"mb{i}/{k}"]))) for j, k in enumerate(("loss", "actor_loss", "critic_loss", "entropy_loss")))
+            margins.leq(e, 1e-5, f"{name} {'graph' if graph else 'eager'} rep {rep} update {i}: loss scalars vs the reference's")
+        for k in ("actor_loss", "critic_loss", "entropy_loss", "mean_ret"):
+            np.testing.assert_allclose(result[k], z[f"result/{k}"], rtol=2e-5, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(result["max_ratio"], z["result/max_ratio"], rtol=1e-3)
+        np.testing.assert_allclose(agent._lr_now, z["lr_after"], rtol=1e-12)
+        last = n_upd - 1
+        grads = {k: npy(g) for k, g in agent._net.export_state(agent._net.grads).items()}  # the bucket holds the last minibatch's CLIPPED gradient
+        _thin_cmp(grads, z, f"mb{last}/grad_clip/", scale_of=lambda k: z[f"mb{last}/grad_raw_absmax/{k}"], tol=2e-4, what="last clipped gradient")
+        tot = bad = 0
+        worst = 0.0
+        for k, v in agent.network.state_dict().items():
+            d = np.abs(synth.thin(npy(v)) - z[f"sd1_thin/{k}"])
+            tot += d.size
+            bad += int((d > 2e-5).sum())
+            worst = max(worst, float(d.max()))
+        margins.leq(bad / tot, 0.005, "fraction of weights further than 2e-5 from the reference's")
+        margins.leq(worst, 2.1 * lr * n_upd, "worst weight difference vs the possible travel")
+
+
+def test_ppo_cnn_act_samples_the_policy_and_is_greedy_in_eval():
+    """ppo.py:55-69: training -> Categorical(pi) (frequencies over many timesteps match pi of the network's own forward), eval -> argmax; uint8 and float frames."""
+    from jorldy_amd.core.agent import Agent
+
+    torch.manual_seed(0)
+    S, A, N = (4, 44, 52), 5, 6
+    agent = Agent("ppo", state_size=list(S), action_size=A, hidden_size=64, network="discrete_policy_value", head="cnn", batch_size=16, n_step=8, device="cuda", seed=3)
+    sd = agent.network.state_dict()
+    sd["pi.weight"] = sd["pi.weight"] * 60.0  # (policy gain 0.01: make pi visibly non-uniform)
+    agent.network.load_state_dict(sd)
+    frames = np.random.RandomState(0).randint(0, 256, size=(N,) + S).astype(np.uint8)
+    pi, v = agent.network(torch.from_numpy(frames).cuda())
+    pi = npy(pi).astype(np.float64)
+    assert pi.shape == (N, A) and v.shape == (N, 1) and np.allclose(pi.sum(1), 1.0, atol=1e-5) and (pi.max(1) - pi.min(1)).min() > 0.02
+    greedy = agent.act(frames, training=False)["action"]
+    assert greedy.shape == (N, 1) and greedy.dtype == np.int64 and np.array_equal(greedy[:, 0], pi.argmax(1))
+    assert np.array_equal(agent.act(frames.astype(np.float32), training=False)["action"], greedy)  # float frames: the same values through the fp32 operand fetch
+    n = 4000
+    counts = np.zeros((N, A))
+    for _ in range(n):
+        a = agent.act(frames, training=True)["action"]
+        counts[np.arange(N), a[:, 0]] += 1
+    # binomial: |freq - p| <= 5 sigma
+    sig = np.sqrt(pi * (1 - pi) / n)
+    assert (np.abs(counts / n - pi) <= 5 * sig + 1e-3).all(), (counts / n, pi)
+    # the stream is keyed by (seed, timestep, row): a second agent with the same seed and weights replays the same actions
+    other = Agent("ppo", state_size=list(S), action_size=A, hidden_size=64, network="discrete_policy_value", head="cnn", batch_size=16, n_step=8, device="cuda", seed=3)
+    other.network.load_state_dict(agent.network.state_dict())
+    agent._act_ctr = other._act_ctr = 17
+    assert np.array_equal(agent.act(frames)["action"], other.act(frames)["action"])
+
+
+def test_ppo_cnn_checkpoint_in_the_references_format(tmp_path):
+    """save() writes {"network": state_dict, "optimizer": Adam state_dict} with the reference's keys (reinforce.py:128-136); load() resumes weights, moments,
+    step count and learning rate: two agents -- one that learned twice, one that learned, was saved, reloaded into a FRESH agent and learned again -- agree bit for bit."""
+    from jorldy_amd.core.agent import Agent
+
+    S, A, W, T = (4, 44, 52), 4, 2, 8
+    mk = lambda: Agent("ppo", state_size=list(S), action_size=A, hidden_size=64, network="discrete_policy_value", head="cnn", batch_size=8, n_step=T, n_epoch=2,
+                       optim_config={"name": "adam", "lr": 1e-3}, num_workers=W, run_step=1000, device="cuda", use_graph=False)
+    rng = np.random.RandomState(1)
+
+    def rollout():
+        trs = synth.ppo_image_rollout(rng, W * T, S, A)
+        return {k: np.concatenate([t[k] for t in trs], 0) for k in ("state", "next_state", "reward", "done", "action")}
+
+    r1, r2 = rollout(), rollout()
+    torch.manual_seed(5)
+    a = mk()
+    sd0 = {k: v.clone() for k, v in a.network.state_dict().items()}
+    np.random.seed(9)
+    a.process(r1, T)
+    a.save(str(tmp_path))
+    ck = torch.load(os.path.join(str(tmp_path), "ckpt"), map_location="cpu", weights_only=False)
+    assert list(ck["network"]) == ["head.conv1.weight", "head.conv1.bias", "head.conv2.weight", "head.conv2.bias", "head.conv3.weight", "head.conv3.bias",
+                                   "l.weight", "l.bias", "pi.weight", "pi.bias", "v.weight", "v.bias"]
+    assert tuple(ck["network"]["head.conv2.weight"].shape) == (64, 32, 4, 4) and tuple(ck["network"]["pi.weight"].shape) == (A, 64) and tuple(ck["network"]["v.weight"].shape) == (1, 64)
+    assert len(ck["optimizer"]["state"]) == 12 and float(ck["optimizer"]["state"][0]["step"]) == 4.0  # 2 epochs x 2 minibatches
+    np.random.seed(10)
+    res_a = a.process(r2, 2 * T)
+    b = mk()
+    b.load(str(tmp_path))
+    b.time_t, b.learn_stamp = T, 0
+    assert b._adam_steps == 4 and b._lr_now == pytest.approx(ck["optimizer"]["param_groups"][0]["lr"])
+    np.random.seed(10)
+    res_b = b.process(r2, 2 * T)
+    assert res_a == res_b
+    for (k, va), vb in zip(a.network.state_dict().items(), b.network.state_dict().values()):
+        assert torch.equal(va, vb), k
+    assert not torch.equal(sd0["l.weight"], a.network.state_dict()["l.weight"])
+
+
+def test_ppo_cnn_refuses_what_the_engine_does_not_cover():
+    from jorldy_amd.core.agent import Agent
+
+    with pytest.raises(ValueError, match="CNN head"):
+        Agent("ppo", state_size=[4, 84, 84], action_size=3, network="continuous_policy_value", head="cnn", device="cuda")
+    with pytest.raises(ValueError, match="CNN head"):
+        Agent("ppo", state_size=[4, 84, 84], action_size=3, head="cnn", optim_config={"name": "sgd", "lr": 1e-3}, device="cuda")
+    with pytest.raises(ValueError, match="CNN head"):
+        Agent("ppo", state_size=[4, 30, 84], action_size=3, head="cnn", device="cuda")
