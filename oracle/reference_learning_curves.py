@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2])
     ap.add_argument("--skip", nargs="*", default=[])
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_learning_curve_reference_vs_port.json"))
+    ap.add_argument("--ppo-cnn", action="store_true", help="instead: the reference's PPO on the CNN head (config.ppo.atari's agent) on the CueFrames image task -> "
+                                                           "tests/golden/curves_reference_r06_ppo_cnn.json")
     ap.add_argument("--fixtures", action="store_true", help="instead: the reference's curves for the two tasks that have NO port (continuous PPO on the control env, Ape-X on "
                                                             "CartPole) -> tests/golden/curves_reference_r06.json, what tests/test_learning_curve_gpu.py holds the HIP agents against")
     args = ap.parse_args()
@@ -59,6 +61,18 @@ def main():
         from core.agent.rainbow import Rainbow
 
         W, T, ITERS, RUN_STEP = LC.W, LC.T, LC.ITERS, LC.RUN_STEP
+        if args.ppo_cnn:
+            t0 = time.time()
+            mk = lambda: PPO(device="cpu", **LC.pcn_agent_kwargs())
+            fx = {"generator": "oracle/reference_learning_curves.py --ppo-cnn (the unmodified reference agent, CPU, scratch copy)", "seeds": args.seeds,
+                  "ppo_cueframes": {"config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in LC.PCN.items()}, "metric": "mean reward per transition, per iteration (random play 0.25)",
+                                    "reference": [LC.pcn_curve_host(mk, s) for s in args.seeds]}}
+            print("ppo cnn done", round(time.time() - t0, 1), [[round(float(np.mean(c[:3])), 3), round(float(np.mean(c[-5:])), 3)] for c in fx["ppo_cueframes"]["reference"]], flush=True)
+            os.chdir(cwd)
+            with open(os.path.join(ROOT, "tests", "golden", "curves_reference_r06_ppo_cnn.json"), "w") as f:
+                json.dump(fx, f)
+            print("wrote tests/golden/curves_reference_r06_ppo_cnn.json")
+            return
         if args.fixtures:
             from core.agent.ape_x import ApeX
 

@@ -1,6 +1,6 @@
 """One rank of the two-ranks-on-one-GPU data-parallel tests (tests/test_dp_two_ranks_gpu.py).  Not a test module.
 
-usage: python tests/dp_worker.py <mode: ppo|rainbow|apex|peer_unit> <rank> <world> <port> <out.npz> [gloo|nccl]
+usage: python tests/dp_worker.py <mode: ppo|ppo_cnn|rainbow|apex|peer_unit> <rank> <world> <port> <out.npz> [gloo|nccl]
 JH_DP_COLLECTIVE=peer in the environment: the gradient bucket and the critic sums travel through peer pointers (jh_peer_*, hipIpc handles
 opened across the two processes on the one GPU) instead of the host-staged gloo all-reduce, captured inside the learn() graph.
 nccl (= RCCL): rank r on GPU r -- the form the N-GPU bench runs; needs >= world GPUs (the driver's 8-GPU node).
@@ -43,6 +43,29 @@ def ppo_agent(W, B, **kw):
 def ppo_rows(rank):
     c = PPO_CFG
     trs = synth.ppo_rollout(np.random.RandomState(50 + rank), c["W"] * c["T"], c["S"], c["A"], False, clamp_every=0)
+    return {k: np.concatenate([t[k] for t in trs], 0) for k in ("state", "next_state", "reward", "done", "action")}
+
+
+# PPO on the CNN head (round 6): a small image, minibatches of 8 rows per rank, a learning rate large enough for the value clamp to become active
+PPO_CNN_CFG = dict(S=(4, 44, 52), A=4, H=64, W=2, T=16, B=8, E=3, lr=2e-3, seed=20260930)
+
+
+def ppo_cnn_agent(W, B, **kw):
+    from jorldy_amd.core.agent import Agent
+
+    c = PPO_CNN_CFG
+    agent = Agent("ppo", state_size=list(c["S"]), action_size=c["A"], hidden_size=c["H"], network="discrete_policy_value", head="cnn", optim_config={"name": "adam", "lr": c["lr"]},
+                  batch_size=B, n_step=c["T"], n_epoch=c["E"], _lambda=0.95, epsilon_clip=0.1, vf_coef=1.0, ent_coef=0.01, clip_grad_norm=1.0, gamma=0.99,
+                  run_step=100000, num_workers=W, device="cuda", lr_decay=False, **kw)
+    rec = synth.ppo_recipe({k: v.shape for k, v in agent.network.state_dict().items()}, c["seed"])
+    agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in rec.items()})
+    agent.memory.first_store = False
+    return agent
+
+
+def ppo_cnn_rows(rank):
+    c = PPO_CNN_CFG
+    trs = synth.ppo_image_rollout(np.random.RandomState(70 + rank), c["W"] * c["T"], c["S"], c["A"])
     return {k: np.concatenate([t[k] for t in trs], 0) for k in ("state", "next_state", "reward", "done", "action")}
 
 
@@ -189,6 +212,24 @@ def main():
             res = dict(params=agent._net.params.cpu().numpy(), perms=perms, stats=np.asarray(agent._static["stats_pin"].np[: n_upd + 1]).copy(),
                        grads=agent._net.grads.cpu().numpy(), n_upd=n_upd, graphed=int(agent._graph is not None),
                        peer_timeouts=(sync.transport.peer_status()[0] if peer else 0), **{f"result_{k}": v for k, v in result.items()})
+        elif mode == "ppo_cnn":
+            c = PPO_CNN_CFG
+            agent = ppo_cnn_agent(c["W"], c["B"], use_graph=peer)
+            if rank == 1:  # attach must overwrite rank 1's weights with rank 0's
+                agent._net.params.add_(0.01)
+            sync = attach_data_parallel(agent, dist)
+            assert sync.transport.kind in kinds
+            results = []
+            for it in range(3 if peer else 1):  # peer: eager, capture + replay, replay -- the collectives inside the learn() graph
+                if it:
+                    agent.time_t = agent.learn_stamp = 0
+                np.random.seed(200 + rank)
+                results.append(agent.process(ppo_cnn_rows(rank), c["T"]))
+            torch.cuda.synchronize()
+            M = c["W"] * c["T"]
+            n_upd = c["E"] * (M // c["B"])
+            res = dict(params=agent._net.params.cpu().numpy(), perms=agent._static["idx"].cpu().numpy().reshape(c["E"], M), stats=agent._static["stats"].cpu().numpy(),
+                       grads=agent._net.grads.cpu().numpy(), n_upd=n_upd, graphed=int(agent._graph is not None), peer_timeouts=(sync.transport.peer_status()[0] if peer else 0))
         else:
             c = RB_CFG
             agent = (apex_agent if mode == "apex" else rainbow_agent)(c["B"], c["N"], use_graph=peer)

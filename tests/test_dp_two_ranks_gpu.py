@@ -161,6 +161,55 @@ def _check_ppo_two_ranks(ranks, monkeypatch):
     margins.leq(float(d.max()), 2.1 * lr * n_upd, "worst weight difference vs travel")
 
 
+@pytest.mark.parametrize("env", [None, PEER])
+def test_ppo_on_the_cnn_head_two_ranks_equal_one_learner_on_the_concatenated_batch(tmp_path, monkeypatch, env):
+    """PPO on the convolutional engine (core/agent/ppo_cnn.py) as data-parallel learners: jh_ppo_loss_packed with the deferred critic -> the ranks' {sum e1, sum e2}
+    -> jh_ppo_critic_select_strided -> backward -> gradient bucket mean -> clip + Adam.  Both ranks end with identical weights, and they are the weights of ONE
+    learner on the two ranks' rows with the two ranks' minibatches side by side.  env PEER: everything through peer pointers, inside the learn() graph (three
+    process() calls of the same rollout -- eager, capture + replay, replay; the weights move on, the LAST call's statistics are compared)."""
+    ranks = _run_ranks("ppo_cnn", tmp_path, extra_env=env)
+    r0, r1 = ranks
+    assert np.array_equal(r0["params"], r1["params"]), "ranks diverged"
+    assert np.array_equal(r0["grads"], r1["grads"])
+    if env:
+        assert int(r0["peer_timeouts"]) == 0 and int(r1["peer_timeouts"]) == 0 and int(r0["graphed"]) == 1
+    c = W.PPO_CNN_CFG
+    M, B, E, n_upd = c["W"] * c["T"], c["B"], c["E"], int(r0["n_upd"])
+    agent = W.ppo_cnn_agent(2 * c["W"], 2 * B, use_graph=False)
+    rows = [W.ppo_cnn_rows(0), W.ppo_cnn_rows(1)]
+    cols = {k: np.concatenate([rows[0][k], rows[1][k]], 0) for k in rows[0]}
+    perms = []
+    for e in range(E):
+        p0, p1 = r0["perms"][e], r1["perms"][e]
+        perms.append(np.concatenate([np.concatenate([p0[o:o + B], M + p1[o:o + B]]) for o in range(0, M, B)]))
+    from jorldy_amd import np_rng
+
+    def fixed_lists(M_, E_, out):
+        out.reshape(-1)[:] = np.concatenate(perms)
+        return out
+
+    monkeypatch.setattr(np_rng, "epoch_shuffles", fixed_lists)
+    for _ in range(3 if env else 1):  # the ranks ran the same rollout that many times (eager, capture + replay, replay)
+        agent.time_t = agent.learn_stamp = 0
+        agent.process(cols, c["T"])
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    s1 = npy(agent._static["stats"]).astype(np.float64)
+    s_dp = 0.5 * (r0["stats"].astype(np.float64) + r1["stats"].astype(np.float64))
+    np.testing.assert_array_equal(r0["stats"][:n_upd, 6:8], r1["stats"][:n_upd, 6:8])  # the same global c1 / c2 on both ranks, bit for bit
+    gap = np.abs(s1[:n_upd, 6] - s1[:n_upd, 7]) / np.maximum(s1[:n_upd, 6], 1e-12)
+    assert (gap > 1e-4).sum() >= 2, f"the value clamp never became active (relative |c1 - c2| per update: {gap})"
+    tol = dict(rtol=2e-5, atol=1e-6) if not env else dict(rtol=2e-4, atol=1e-5)  # third learn() of two fp32 trajectories
+    for j in (6, 7):
+        np.testing.assert_allclose(s1[:n_upd, j], r0["stats"][:n_upd, j], err_msg="global c1 / c2 vs one learner", **tol)
+    for j, name in ((1, "actor_loss"), (2, "critic_loss"), (3, "entropy_loss")):
+        np.testing.assert_allclose(s1[:n_upd, j], s_dp[:n_upd, j], err_msg=name, **tol)
+    d = np.abs(npy(agent._net.params) - r0["params"])
+    n_all = n_upd * (3 if env else 1)
+    margins.lt(float((d > 1e-5).mean()), 0.01, f"fraction of weights > 1e-5 apart (max {d.max():.2e})")
+    margins.leq(float(d.max()), 2.1 * c["lr"] * n_all, "worst weight difference vs travel")
+
+
 @pytest.mark.parametrize("mode,env", [("rainbow", None), ("rainbow", PEER), ("apex", None), ("apex", PEER)])
 def test_value_learners_two_ranks_identical_weights_and_single_tree_is_weights(tmp_path, mode, env):
     """Rainbow and -- round 6, north_star's "Ape-X re-expressed as one learner per GPU" -- the Ape-X learner (dueling net, n-step double-Q,
