@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--apex-prefill", type=int, default=50_000, help="config.ape_x.atari start_train_step: transitions in the buffer before the first learn()")
     ap.add_argument("--no-hopper", action="store_true", help="skip the PPO Hopper-shaped (configs[4]) leg")
     ap.add_argument("--hopper-iters", type=int, default=3)
+    ap.add_argument("--no-ppo-atari", action="store_true", help="skip the config.ppo.atari learner leg (PPO on the CNN head; rank 0 of a 1-GPU run only)")
     ap.add_argument("--no-dqn", action="store_true", help="skip the DQN (configs[0]) single-mode leg")
     ap.add_argument("--dqn-steps", type=int, default=3000)
     ap.add_argument("--no-variants", action="store_true", help="skip the PPO side runs (one timestep per exchange; Python collector)")
@@ -675,6 +676,22 @@ def hopper_leg(rank, world, local_rank, dist, iters):
     return r
 
 
+def ppo_atari_leg(cpu):
+    """config.ppo.atari's shapes (outside BASELINE's five configs; VERDICT r5 missing #5): PPO on the Nature-CNN head, learner side (tools/bench_ppo_atari.py)."""
+    mod = _tool("bench_ppo_atari")
+    r = mod.ppo_atari_leg(iters=6, warmup=3)
+    out = dict(metric="learner transitions/s (PPO, config.ppo.atari shapes)", value=r["learner_transitions_per_s"], unit="transitions/s", n_gpus=1, dtype="f32", data="synthetic",
+               config={"workload": r.pop("workload")},
+               roofline=_dominant_mfma(r["lib_kernels"], "minibatch of 32 frames: every launch is latency-bound (2.2 GFLOP per update over ~20 launches)", "r*_ppo_atari_kernel_stats.csv", "r*_ppo_atari_pmc.json"), **r)
+    if cpu:
+        try:
+            out["cpu_reference"] = mod.cpu_reference()
+            out["x_cpu_reference"] = out["value"] / out["cpu_reference"]["value"]
+        except Exception as e:  # noqa: BLE001
+            out["cpu_reference"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def apex_leg(actors, updates, buffer=2_000_000, prefill=50_000):
     """BASELINE.json configs[3] (config.ape_x.atari pong shapes, `actors` host actors -> 1 learner GPU) end to end in a child process:
     batched acting on the GPU, device-resident frame / n-step feed (frame mode), learner at B = 512 with centered RMSprop, clip 40, PER with
@@ -942,6 +959,7 @@ def main():
                        "dqn_env_steps_s": leg("dqn", "value"), "dqn_x_cpu_reference": leg("dqn", "x_cpu_reference"),
                        "rainbow_env_steps_s_measured": ((out.get("rainbow") or {}).get("single_mode") or {}).get("env_steps_per_s"),
                        "rainbow_updates_s": leg("rainbow", "value"), "apex_env_steps_s": leg("apex", "value"), "apex_updates_s": leg("apex", "learner_updates_per_s"),
+                       "ppo_atari_learner_transitions_s": leg("ppo_atari", "value"), "ppo_atari_updates_s": leg("ppo_atari", "learner_updates_per_s"), "ppo_atari_x_cpu_reference": leg("ppo_atari", "x_cpu_reference"),
                        "hopper_transitions_s": leg("hopper", "value"), "hopper_end_to_end_env_transitions_s": ((out.get("hopper") or {}).get("end_to_end") or {}).get("env_transitions_per_s"),
                        "hopper_x_cpu_reference": (leg("hopper", "value") / out["hopper"]["cpu_reference"]["value"]) if (out.get("hopper") or {}).get("cpu_reference", {}).get("value") else None}
         print(json.dumps(out))
@@ -1046,6 +1064,11 @@ def main():
             out["dqn"] = dqn_leg(local_rank, args.dqn_steps, not args.no_cpu_baseline)
         except Exception as e:
             out["dqn"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.no_ppo_atari:
+        try:
+            out["ppo_atari"] = ppo_atari_leg(not args.no_cpu_baseline)
+        except Exception as e:  # noqa: BLE001
+            out["ppo_atari"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_apex:
         out["apex"] = apex_leg(args.apex_actors, args.apex_updates, args.apex_buffer, args.apex_prefill)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -73,3 +73,8 @@ def test_bench_emits_one_contract_json_line():
     hc = hp["cpu_reference"]
     assert "error" not in hc, hc
     assert hc["kind"] == "port" and hc["unit"] == hp["unit"] and hc["value"] > 0 and abs(lg["hopper_x_cpu_reference"] - hp["value"] / hc["value"]) < 1e-6 * lg["hopper_x_cpu_reference"]
+    # config.ppo.atari's learner (PPO on the CNN head, round 6) with its CPU port beside it
+    pa = d["ppo_atari"]
+    assert "error" not in pa, pa
+    assert pa["agent"] == "PPOConv" and pa["learn_in_hipgraph"] and pa["value"] > 0 and pa["minibatch_updates_per_iteration"] == 96 and 0 < pa["roofline"]["frac"] < 1
+    assert pa["cpu_reference"]["value"] > 0 and abs(lg["ppo_atari_x_cpu_reference"] - pa["value"] / pa["cpu_reference"]["value"]) < 1e-6 * lg["ppo_atari_x_cpu_reference"]
