@@ -21,6 +21,8 @@ SUPPORTED = [
     ("config.ppo.mujoco humanoid", "ppo", dict(state_size=376, action_size=17, network="continuous_policy_value")),
     ("config.ppo.pong_mlagent", "ppo", dict(state_size=8, action_size=3, network="discrete_policy_value")),
     ("config.ppo.hopper_mlagent", "ppo", dict(state_size=19, action_size=3, network="continuous_policy_value")),
+    ("config.ppo.atari (head cnn, round 6)", "ppo", dict(state_size=(4, 84, 84), action_size=6, network="discrete_policy_value", head="cnn")),
+    ("config.ppo.procgen (head cnn, round 6)", "ppo", dict(state_size=(3, 64, 64), action_size=15, network="discrete_policy_value", head="cnn")),
     ("config.dqn.cartpole", "dqn", dict(state_size=4, action_size=2)),
     ("config.dqn.atari", "dqn", dict(state_size=(4, 84, 84), action_size=6, head="cnn")),
     ("config.dqn.procgen", "dqn", dict(state_size=(3, 64, 64), action_size=15, head="cnn")),
@@ -35,7 +37,8 @@ SUPPORTED = [
 
 # (label, agent, kwargs, fragment of the message) -- raises ValueError when constructed
 UNSUPPORTED = [
-    ("config.ppo.atari / procgen / super_mario_bros (head cnn)", "ppo", dict(state_size=(4, 84, 84), action_size=6, network="discrete_policy_value", head="cnn"), "head='mlp'"),
+    ("ppo on the cnn head with a continuous policy", "ppo", dict(state_size=(4, 84, 84), action_size=3, network="continuous_policy_value", head="cnn"), "CNN head"),
+    ("ppo on the cnn head with RMSprop", "ppo", dict(state_size=(4, 84, 84), action_size=3, network="discrete_policy_value", head="cnn", optim_config={"name": "rmsprop", "lr": 1e-3}), "CNN head"),
     ("config.ppo.drone_delivery_mlagent (head multi, list-valued state)", "ppo", dict(state_size=[(6, 64, 84), 95], action_size=3, network="continuous_policy_value", head="multi"), "head='mlp'"),
     ("ppo with an optimizer other than Adam", "ppo", dict(state_size=4, action_size=2, optim_config={"name": "rmsprop", "lr": 1e-3}), "optim_config name 'adam'"),
     ("ppo with Adam weight decay", "ppo", dict(state_size=4, action_size=2, optim_config={"name": "adam", "lr": 1e-3, "weight_decay": 1e-2}), "weight_decay"),
