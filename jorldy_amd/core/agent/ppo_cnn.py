@@ -174,6 +174,8 @@ class PPOConv(NativeValueNetMixin, PPO):
         if self._static is None or self._static["M"] != M:
             self._static, self._graphs = self._alloc_static(M), {}
         st = self._static
+        if st.get("store") is not self.memory._store:  # the rollout store was replaced (it grows by doubling): a captured graph holds the old one's addresses
+            st["store"], self._graphs, self._graph = self.memory._store, {}, None
         graphable = (self.use_graph and not ops._PROF["on"] and not ops._PROF["lib"] and not getattr(self, "_graph_failed", False)
                      and (self.grad_sync is None or (self.graph_with_collective and getattr(self.grad_sync, "capturable", True))))
         if graphable and "learn" not in self._graphs and getattr(self, "_warm", False):
