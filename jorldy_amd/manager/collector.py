@@ -28,7 +28,7 @@ class VecCollector:
         self.agent = agent
         self.num_workers = env_vec.W if num_workers is None else num_workers
         assert self.num_workers == env_vec.W
-        self.state = self.env.obs()  # (W, S) float32
+        self.state = self.env.obs()  # (W, S) float32 -- or (W, C, H, W) frames in the env's own dtype (uint8 for the image envs: they stay uint8 up to the first convolution)
         from ..parallel import pin_to_gpu_node
 
         dev = getattr(agent, "device", None)
@@ -37,13 +37,13 @@ class VecCollector:
     def run(self, step=1):
         """-> (SoA dict in worker-major order, completed_ratio) like DistributedManager.run (:26-31)."""
         assert step > 0
-        W, S = self.state.shape
-        st = np.empty((W, step, S), np.float32)
-        ns = np.empty((W, step, S), np.float32)
+        W, S, odt = self.state.shape[0], tuple(self.state.shape[1:]), self.state.dtype
+        st = np.empty((W, step) + S, odt)
+        ns = np.empty((W, step) + S, odt)
         rw = np.empty((W, step, 1), np.float32)
         dn = np.empty((W, step, 1), np.uint8)
         ac = None
-        nxt, r, d = np.empty((W, S), np.float32), np.empty(W, np.float32), np.empty(W, np.uint8)
+        nxt, r, d = np.empty((W,) + S, odt), np.empty(W, np.float32), np.empty(W, np.uint8)
         for t in range(step):  # Actor.run, distributed_manager.py:76-92, for all workers at once
             action = self.agent.act(self.state, training=True)["action"]  # (W, 1) or (W, A)
             if ac is None:

@@ -239,3 +239,52 @@ def test_ppo_cnn_refuses_what_the_engine_does_not_cover():
         Agent("ppo", state_size=[4, 84, 84], action_size=3, head="cnn", optim_config={"name": "sgd", "lr": 1e-3}, device="cuda")
     with pytest.raises(ValueError, match="CNN head"):
         Agent("ppo", state_size=[4, 30, 84], action_size=3, head="cnn", device="cuda")
+
+
+class _CueFramesVec:
+    """W copies of the CueFrames task (tests/test_learning_curve_gpu.py) behind the VecCollector protocol: obs(out) / step(action, next_obs, reward, done) on
+    uint8 (W, 4, 44, 52) frames; every episode is one step long, a finished row shows its next frame."""
+
+    def __init__(self, W, seed):
+        from tests.test_learning_curve_gpu import CueFrames
+
+        self.W, self.envs = W, [CueFrames(1000 * seed + w) for w in range(W)]
+        self.state_size, self.action_size, self.action_type = (4, 44, 52), 4, "discrete"
+
+    def obs(self, out=None):
+        out = np.empty((self.W, 4, 44, 52), np.uint8) if out is None else out
+        for w, e in enumerate(self.envs):
+            out[w] = e.obs()[0]
+        return out
+
+    def step(self, action, next_obs, reward, done):
+        for w, e in enumerate(self.envs):
+            nxt, r, d = e.step(action[w])
+            next_obs[w], reward[w], done[w] = nxt[0], r[0, 0], d[0, 0]
+
+
+def test_ppo_cnn_through_the_vectorised_sync_collector_learns_the_image_task():
+    """DistributedManager + Actors in sync mode (distributed_manager.py:26-92) for an IMAGE env: `VecCollector` (one batched act() per timestep for all workers, frames
+    kept uint8, transitions in the reference's worker-major order) driving PPO on the CNN head -- the whole drop-in loop of run_mode.py:180-186."""
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import VecCollector
+
+    torch.manual_seed(4)
+    np.random.seed(4)
+    W, T = 8, 32
+    agent = Agent("ppo", state_size=[4, 44, 52], action_size=4, hidden_size=128, network="discrete_policy_value", head="cnn", optim_config={"name": "adam", "lr": 5e-4},
+                  batch_size=32, n_step=T, n_epoch=3, run_step=W * T * 60, num_workers=W, device="cuda", seed=4)
+    agent.memory.first_store = False
+    col = VecCollector(_CueFramesVec(W, 4), agent)
+    curve, step = [], 0
+    for _ in range(20):
+        trs, ratio = col.run(T)
+        assert trs["state"].dtype == np.uint8 and trs["state"].shape == (W * T, 4, 44, 52) and trs["action"].shape == (W * T, 1) and ratio == 1.0
+        # worker-major order: row w * T + t is worker w's t-th step, and its next_state is that worker's next observation (one-step episodes: the next frame)
+        assert np.array_equal(trs["next_state"][: T - 1], trs["state"][1:T])
+        curve.append(float(trs["reward"].mean()))
+        step += T
+        result = agent.process(trs, step)
+        assert set(result) == {"actor_loss", "critic_loss", "entropy_loss", "max_ratio", "min_prob", "mean_ret"}
+    assert agent.memory._store.column("state").dtype == torch.uint8
+    assert np.mean(curve[:3]) < 0.4 and np.mean(curve[-3:]) > 0.85, curve
