@@ -330,6 +330,13 @@ int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, const int64_
                          const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old,
                          float eps_clip, float vf_coef, float ent_coef, float max_norm, int32_t do_adam, float* d_stats,
                          jh_stream stream);
+/* The minibatch update of ppo.py:122-169 for ANY number of rows up to max_rows (config.ppo.mujoco: 2048-row minibatches) in one call: forward, the loss --
+ * forward and backward in ONE launch whatever B (both critic branches' value gradients are kept per row, the last workgroup to arrive reduces the
+ * partials and leaves the branch weights; the backward's first kernel forms the value gradient) --, backward, [clip_grad_norm_ + Adam unless
+ * do_adam == 0].  Bit-identical to jh_pponet_forward -> jh_ppo_loss_discrete / _continuous -> jh_pponet_backward -> jh_pponet_adam_step, one launch less. */
+int jh_pponet_ppo_update_rows(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action, const float* d_adv, const float* d_ret,
+                              const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef, float max_norm,
+                              int32_t do_adam, float* d_stats, jh_stream stream);
 /* jh_pponet_ppo_update for DATA-PARALLEL learners with the reference's critic exactly: core/agent/ppo.py:147-154 takes
  * max(mean(e1), mean(e2)) over the WHOLE minibatch -- a max of two means, so with the minibatch sharded over ranks the branch is
  * only known after {sum e1, sum e2} have been reduced.  _begin: forward + loss of this rank's B rows; d_critic_sums float32[2] <- this

@@ -94,6 +94,7 @@ _PROTOS = {
     "jh_pponet_backward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_pponet_adam_step": (C.c_int, [_vp, _f32, _vp, _vp]),
     "jh_pponet_ppo_update": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
+    "jh_pponet_ppo_update_rows": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "jh_ppo_loss_deferred": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jh_ppo_loss_packed": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "jh_ppo_critic_select_strided": (C.c_int, [_vp, _i32, _vp, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -335,10 +335,21 @@ class PPO(BaseAgent):
         exact = self.grad_sync is not None and self.dp_exact_critic
         if exact and "dp_work" not in st:
             st["dp_work"] = torch.zeros(st["n_upd"], B + 16, dtype=torch.float32, device=self.device)
+        # round 6: one call per update with the loss in ONE launch whatever the minibatch size (jh_pponet_ppo_update_rows); JH_PPO_ONEPASS=0 keeps the
+        # separate forward / two-pass loss / backward / Adam calls (A/B switch, bit-identical)
+        onepass = not exact and os.environ.get("JH_PPO_ONEPASS", "1") == "1"
         for e in range(self.n_epoch):
             for offset in range(0, M, B):
                 b = min(B, M - offset)
                 idx = st["idx"][e * M + offset : e * M + offset + b]
+                if onepass:
+                    net.ppo_update_rows(tr["state"], idx, tr["action"], adv, ret, st["value"], logp_old, self.epsilon_clip, self.vf_coef, self.ent_coef, self.clip_grad_norm,
+                                        st["stats"][k], do_adam=self.grad_sync is None)
+                    if self.grad_sync is not None:
+                        self.grad_sync.reduce_flat(net.grads)
+                        net.adam_step(self.clip_grad_norm)
+                    k += 1
+                    continue
                 if cont:
                     mu, ls, vp = net.forward(tr["state"], idx=idx, out=(st["mb_h0"][:b], st["mb_h1"][:b], st["mb_v"][:b]))
                     if exact:

@@ -174,6 +174,8 @@ struct jh_pponet {
   float* ssq_part = nullptr;      // [(H/32)^2 + H/32] sums of squares of the gradient tiles written by jh_pmb_bwd's workgroups
   float* norm_partial = nullptr;  // [kNormBlocks]
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
+  float* upd_ws = nullptr;    // jh_pponet_ppo_update_rows: raw heads, their gradients, the second critic branch, loss partials, {w1, w2}, ticket
+  size_t upd_floats = 0;
   float* xg = nullptr;        // [max_rows][S] gathered observation rows (B operand of dW1 on the tiled engine)
   float* tg_ws = nullptr;
   size_t tg_ws_floats = 0;

@@ -440,7 +440,8 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, con
 // (gradient, weight row) pair after pair behind s_waitcnt vmcnt(0) (7 serial round trips per thread at Hopper's 7 outputs).
 __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, const float* __restrict__ h2,
                                                                   float* __restrict__ dh2, float* __restrict__ g_all,
-                                                                  HeadFlat hf, int gld, int o0, int first, int last) {
+                                                                  HeadFlat hf, int gld, int o0, int first, int last,
+                                                                  const float* __restrict__ dv2, const float* __restrict__ mix, int ov) {
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int h4 = H >> 2;
   if (i4 >= (int64_t)B * h4) return;
@@ -451,6 +452,12 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, 
   for (int o = 0; o < 8; ++o) {  // all fetches in flight (outputs >= n: output 0 again, ignored)
     gv[o] = hf.g[o][(size_t)b * hf.ld[o]];
     w[o] = *reinterpret_cast<const float4*>(hf.w[o] + k);
+  }
+  if (dv2) {  // the one-launch loss (jh_ppo_onepass_kernel) left both critic branches' value gradients and the branch weights: slot `ov` is the value head
+    const float w1 = mix[0], w2 = mix[1], g2 = dv2[b];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o == ov) gv[o] = w1 * gv[o] + w2 * g2;  // jh_ppo_critic_select_kernel's expression
   }
   float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dh2 + (size_t)b * H + k);
   const float4 hv = *reinterpret_cast<const float4*>(h2 + (size_t)b * H + k);
@@ -700,6 +707,12 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     JH_HIP(hipMalloc((void**)&n->part_w1, sizeof(float) * slabs * ((size_t)H * S + H + 8 * (size_t)H)));
     JH_HIP(hipMalloc((void**)&n->ssq_part, sizeof(float) * ((size_t)(H / 32) * (H / 32) + H / 32 + 1)));
   }
+  {  // jh_pponet_ppo_update_rows: raw heads + their gradients as separate arrays ([max_rows][A] x 2 x 2, [max_rows] x 3), the loss's partials, {w1, w2}, a ticket
+    const size_t rows = (size_t)max_rows, per = 4 * (size_t)A + 3;
+    n->upd_floats = rows * per + 8 * ((rows + 255) / 256) + 16;
+    JH_HIP(hipMalloc((void**)&n->upd_ws, sizeof(float) * n->upd_floats));
+    JH_HIP(hipMemset(n->upd_ws, 0, sizeof(float) * n->upd_floats));
+  }
   JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * JH_HY_FLOATS));
   float hy[JH_HY_FLOATS];
@@ -719,7 +732,7 @@ JH_EXPORT void jh_pponet_destroy(jh_pponet* n) {
   if (n->act_out_h) (void)hipHostFree(n->act_out_h);
   (void)hipFree(n->norm_partial); (void)hipFree(n->hyper); (void)hipFree(n->dv2);
   (void)hipFree(n->fwd_part); (void)hipFree(n->part_w1); (void)hipFree(n->ssq_part);
-  (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt); (void)hipFree(n->xg);
+  (void)hipFree(n->tg_ws); (void)hipFree(n->tg_cnt); (void)hipFree(n->xg); (void)hipFree(n->upd_ws);
   delete n;
 }
 
@@ -1103,19 +1116,27 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
 // Backward of the LAST forward (same B, x, idx) given d(loss)/d(raw heads) as separate arrays: overwrites the
 // flat gradient bucket.  (The PPO agent's minibatches of < kTiledRows rows go through jh_pponet_ppo_update
 // instead, where the head gradients never leave the packed [B][8] form.)
+static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0, const float* d_g_head1,
+                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st);
 JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx,
                                  const float* d_g_head0, const float* d_g_head1, const float* d_g_value,
                                  jh_stream stream) {
   JH_ARG(n && d_x && d_g_head0 && d_g_value);
   JH_ARG(B > 0 && B <= n->max_rows);
   JH_ARG(!n->cont || d_g_head1);
-  hipStream_t st = jh_s(stream);
+  return pponet_backward(n, B, d_x, d_idx, d_g_head0, d_g_head1, d_g_value, nullptr, nullptr, jh_s(stream));
+}
+// d_dv2 / d_mix (both or neither): the value gradient is w1 d_g_value + w2 d_dv2 with {w1, w2} = d_mix, formed by the first kernel
+static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0, const float* d_g_head1,
+                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st) {
   const int H = n->H, S = n->S;
   const int64_t bh = (int64_t)B * H;
   HeadPtrs hp = head_ptrs(n, nullptr, nullptr, nullptr, d_g_head0, d_g_head1, d_g_value);
   for (int o0 = 0; o0 < n->n_out; o0 += 8) {  // the chain over the outputs continues from launch to launch (dh2 holds it in between)
+    const int ov = n->n_out - 1 - o0;  // the value head is the last output
     JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh / 4 + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
-              n->g_all, head_flat(n, hp, o0), n->gld, o0, o0 == 0 ? 1 : 0, o0 + 8 >= n->n_out ? 1 : 0);
+              n->g_all, head_flat(n, hp, o0), n->gld, o0, o0 == 0 ? 1 : 0, o0 + 8 >= n->n_out ? 1 : 0,
+              (d_dv2 && ov >= 0 && ov < 8) ? d_dv2 : nullptr, d_mix, ov);
     JH_LAUNCH_CHECK();
   }
   const float* w[kMaxHeadOutputs]; float* dw[kMaxHeadOutputs]; const float* b[kMaxHeadOutputs]; float* db[kMaxHeadOutputs];
@@ -1255,6 +1276,45 @@ JH_EXPORT int jh_pponet_ppo_update(jh_pponet* n, int32_t B, const float* d_x, co
   rc = jh_pmb_finalize(n, B, do_adam != 0, st);
   if (rc) return rc;
   return do_adam ? pponet_adam(n, max_norm, nullptr, st) : JH_OK;
+}
+
+// The same update for minibatches of ANY size up to max_rows -- what config.ppo.mujoco's 2048-row minibatches take (round 6) -- in one call:
+//   forward (layer 1, layer 2 on the tile engine or the fused latency kernel, heads)            jh_pponet_forward
+//   loss, forward AND backward, in ONE launch whatever B (jh_ppo_onepass_kernel: both critic branches' value gradients + {w1, w2})
+//   backward (its first kernel forms the value gradient from the two branches), clip + Adam     jh_pponet_backward, jh_pponet_adam_step
+// Bit-identical to the separate calls (jh_pponet_forward -> jh_ppo_loss_* -> jh_pponet_backward -> jh_pponet_adam_step): the partials are reduced
+// in the same order, and w1 g1 + w2 g2 with w in {0, 1/2, 1} is what the two-pass kernels evaluate (tested).  One launch less per update.
+int jh_ppo_loss_onepass(int continuous, int B, int A, const float* d_head0, const float* d_head1, const float* d_value_pred, const int64_t* d_idx,
+                        const float* d_action, const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip,
+                        float vf_coef, float ent_coef, float* d_g0, float* d_g1, float* d_gv, float* d_dv2, float* d_mix, unsigned* d_ticket, float* d_partial,
+                        float* d_stats, hipStream_t st);
+JH_EXPORT int jh_pponet_ppo_update_rows(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_action, const float* d_adv,
+                                        const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip, float vf_coef, float ent_coef,
+                                        float max_norm, int32_t do_adam, float* d_stats, jh_stream stream) {
+  JH_ARG(n && d_x && d_action && d_adv && d_ret && d_value_old && d_logp_old);
+  JH_ARG(B > 0 && B <= n->max_rows);
+  const size_t rows = (size_t)n->max_rows, A = (size_t)n->A;
+  float* ws = n->upd_ws;
+  float *h0 = ws, *h1 = h0 + rows * A, *hv = h1 + rows * A, *g0 = hv + rows, *g1 = g0 + rows * A, *gv = g1 + rows * A, *dv2 = gv + rows;
+  float* partial = dv2 + rows;
+  float* mix = partial + 8 * ((rows + 255) / 256);
+  unsigned* ticket = reinterpret_cast<unsigned*>(mix + 8);
+  int rc = jh_pponet_forward(n, B, d_x, d_idx, h0, n->cont ? h1 : nullptr, hv, stream);
+  if (rc) return rc;
+  hipStream_t st = jh_s(stream);
+  if (B <= 1024) {  // one workgroup holds the whole minibatch: the fused forward + backward loss kernel IS one launch (and reduces in its own order)
+    rc = n->cont ? jh_ppo_loss_continuous(n->ctx, B, n->A, h0, h1, hv, d_idx, d_action, d_adv, d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, g0, g1, gv, d_stats, stream)
+                 : jh_ppo_loss_discrete(n->ctx, B, n->A, h0, hv, d_idx, d_action, d_adv, d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, g0, gv, d_stats, stream);
+    if (rc) return rc;
+    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, nullptr, nullptr, st);
+  } else {
+    rc = jh_ppo_loss_onepass(n->cont, B, n->A, h0, n->cont ? h1 : nullptr, hv, d_idx, d_action, d_adv, d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef,
+                             g0, n->cont ? g1 : nullptr, gv, dv2, mix, ticket, partial, d_stats, st);
+    if (rc) return rc;
+    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, dv2, mix, st);
+  }
+  if (rc || !do_adam) return rc;
+  return jh_pponet_adam_step(n, max_norm, nullptr, stream);
 }
 
 // ---- the same update for DATA-PARALLEL learners with the reference's exact critic.  The critic of ppo.py:147-154 is

@@ -872,6 +872,130 @@ __global__ void __launch_bounds__(256) jh_ppo_bwd_kernel(PpoArgs<CONT> a) {
   if (on) ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, w1, w2, CONT ? &pre : nullptr);
 }
 
+// ONE launch for B > 1024 rows (round 6): the two passes above exist because the critic's branch -- max(mean(e1), mean(e2)), ppo.py:147-154 -- is
+// known only after the whole minibatch has been reduced.  But nothing else of the backward half depends on the totals: the policy / entropy gradients are
+// per-row, and the value gradient is one of two per-row candidates.  So every workgroup runs forward AND backward for its rows while they are in registers
+// (the deferred form of the data-parallel learners: gv = branch 1's value gradient, defer_dv2 = branch 2's), leaves its six partials, and the LAST
+// workgroup to arrive reduces them -- in the order the second pass used, so the totals, the statistics row and the branch weights are bit-identical -- and
+// writes mix = {w1, w2}.  Whoever consumes the value gradient applies gv = w1 gv + w2 dv2 (the backward's first kernel, jh_mlp.hip: heads_bwd_dh).
+// Partials travel as agent-scope (write-through) atomics like the tile engine's split-K hand-off: no fence, no L2 flush on eight XCDs.
+template <bool CONT>
+__global__ void __launch_bounds__(256) jh_ppo_onepass_kernel(PpoArgs<CONT> a, unsigned* __restrict__ ticket, float* __restrict__ mix) {
+  __shared__ float s_red6[16][6];
+  __shared__ float s_red[16];
+  __shared__ int s_last;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < a.B;
+  const int ic = on ? i : a.B - 1;
+  RowCommon rc{};
+  DiscRow dr{};
+  int act_k = 0;
+  float ent_row = 0.f, minp = 3.4e38f;
+  const float* z0 = a.h0 + (size_t)ic * a.ldh;
+  const float* z1 = CONT ? a.h1 + (size_t)ic * a.ldh : nullptr;
+  const RowIn rin = ppo_row_load<CONT>(a, ic);
+  const float vpred = a.value_pred[(size_t)ic * a.ldvp];
+  ContPre pre;
+  if (CONT) pre = ppo_cont_prefetch<CONT>(a, z0, z1, rin.r);
+  ppo_row_fwd<CONT>(a, rin, z0, z1, vpred, rc, ent_row, minp, dr, act_k, CONT ? &pre : nullptr);
+  const float e1 = on ? (rc.v - rc.ret) * (rc.v - rc.ret) : 0.f;
+  const float e2 = on ? (rc.vclip - rc.ret) * (rc.vclip - rc.ret) : 0.f;
+  float v6[6] = {on ? rc.smin : 0.f, e1, e2, on ? ent_row : 0.f, on ? rc.ratio : -3.4e38f, on ? minp : 3.4e38f};
+  ppo_block_reduce6(v6, s_red6);
+  if (threadIdx.x < PPO_NPART && threadIdx.x < 6) {
+    float mine = v6[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) mine = threadIdx.x == k ? v6[k] : mine;
+    __hip_atomic_store(a.partial + (size_t)blockIdx.x * PPO_NPART + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (on) ppo_row_bwd<CONT>(a, i, z0, z1, rc, dr, act_k, 0.f, 0.f, CONT ? &pre : nullptr);  // a.defer_dv2: both branches, no weights
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have completed before its workgroup takes a ticket
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == gridDim.x - 1;
+    if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the second pass's reduction over the partials, fetched agent-coherently: nb <= 64 the wave form, else the block form (ppo_launch gave
+  // the second pass `totals` from jh_ppo_totals_kernel = ppo_reduce_partials there)
+  float t[6];
+  const int nb = (int)gridDim.x;
+  if (nb <= 64) {
+    const int lane = threadIdx.x & 63;
+    const float* p = a.partial + (size_t)(lane < nb ? lane : 0) * PPO_NPART;
+    float q[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool mine = lane < nb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = mine ? 0.f + q[k] : 0.f;
+    t[4] = mine ? fmaxf(-3.4e38f, q[4]) : -3.4e38f;
+    t[5] = mine ? fminf(3.4e38f, q[5]) : 3.4e38f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] += __shfl_xor(t[k], o, 64);
+      t[4] = fmaxf(t[4], __shfl_xor(t[4], o, 64));
+      t[5] = fminf(t[5], __shfl_xor(t[5], o, 64));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = 0.f + t[k];
+    t[4] = fmaxf(-3.4e38f, t[4]);
+    t[5] = fminf(3.4e38f, t[5]);
+  } else {
+    t[0] = t[1] = t[2] = t[3] = 0.f; t[4] = -3.4e38f; t[5] = 3.4e38f;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+      const float* p = a.partial + (size_t)b * PPO_NPART;
+      float q[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) q[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t[0] += q[0]; t[1] += q[1]; t[2] += q[2]; t[3] += q[3];
+      t[4] = fmaxf(t[4], q[4]); t[5] = fminf(t[5], q[5]);
+    }
+    t[0] = jh_block_reduce(t[0], s_red, JhAdd(), 0.f);
+    t[1] = jh_block_reduce(t[1], s_red, JhAdd(), 0.f);
+    t[2] = jh_block_reduce(t[2], s_red, JhAdd(), 0.f);
+    t[3] = jh_block_reduce(t[3], s_red, JhAdd(), 0.f);
+    t[4] = jh_block_reduce(t[4], s_red, JhMax(), -3.4e38f);
+    t[5] = jh_block_reduce(t[5], s_red, JhMin(), 3.4e38f);
+  }
+  if (threadIdx.x == 0) {
+    float w1, w2;
+    ppo_finish_stats(t[0], t[1], t[2], t[3], t[4], t[5], a.B, CONT ? a.B * a.A : a.B, a.vf, a.ent, w1, w2, a.stats);
+    mix[0] = w1; mix[1] = w2;
+    if (a.critic_sums) { a.critic_sums[0] = t[1]; a.critic_sums[1] = t[2]; }
+  }
+}
+
+// Internal entry (jh_mlp.hip: jh_pponet_ppo_update_rows): heads and gradients as separate arrays, d_dv2 [B] + d_mix [2] + d_ticket (one zeroed word, left zero)
+// + d_partial (>= 8 floats per 256 rows) from the caller.
+int jh_ppo_loss_onepass(int continuous, int B, int A, const float* d_head0, const float* d_head1, const float* d_value_pred, const int64_t* d_idx,
+                        const float* d_action, const float* d_adv, const float* d_ret, const float* d_value_old, const float* d_logp_old, float eps_clip,
+                        float vf_coef, float ent_coef, float* d_g0, float* d_g1, float* d_gv, float* d_dv2, float* d_mix, unsigned* d_ticket, float* d_partial,
+                        float* d_stats, hipStream_t st) {
+  JH_ARG(B > 0 && A > 0 && d_head0 && d_value_pred && d_g0 && d_gv && d_dv2 && d_mix && d_ticket && d_partial);
+  const int nb = (B + 255) / 256;
+  if (continuous) {
+    PpoArgs<true> a{};
+    a.B = B; a.A = A; a.h0 = d_head0; a.h1 = d_head1; a.value_pred = d_value_pred; a.ldh = A; a.ldvp = 1; a.idx = d_idx;
+    a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+    a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_g0; a.g1 = d_g1; a.gv = d_gv; a.ldg = A; a.ldv = 1;
+    a.stats = d_stats; a.defer_dv2 = d_dv2; a.partial = d_partial; a.nb = nb;
+    JH_LAUNCH(jh_ppo_onepass_kernel<true>, dim3(nb), dim3(256), 0, st, a, d_ticket, d_mix);
+  } else {
+    PpoArgs<false> a{};
+    a.B = B; a.A = A; a.h0 = d_head0; a.h1 = nullptr; a.value_pred = d_value_pred; a.ldh = A; a.ldvp = 1; a.idx = d_idx;
+    a.action = d_action; a.adv = d_adv; a.ret = d_ret; a.value_old = d_value_old; a.logp_old = d_logp_old;
+    a.eps = eps_clip; a.vf = vf_coef; a.ent = ent_coef; a.g0 = d_g0; a.g1 = nullptr; a.gv = d_gv; a.ldg = A; a.ldv = 1;
+    a.stats = d_stats; a.defer_dv2 = d_dv2; a.partial = d_partial; a.nb = nb;
+    JH_LAUNCH(jh_ppo_onepass_kernel<false>, dim3(nb), dim3(256), 0, st, a, d_ticket, d_mix);
+  }
+  JH_LAUNCH_CHECK();
+  return JH_OK;
+}
+
 template <bool CONT>
 static int ppo_launch(jh_ctx* ctx, PpoArgs<CONT>& a, hipStream_t st) {
   if (a.ldh == 0) a.ldh = a.A;

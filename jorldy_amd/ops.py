@@ -661,6 +661,14 @@ class PPONet:
                                               L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
                                               float(max_norm if max_norm else 0.0), int(bool(do_adam)), L.ptr(stats), L.stream_ptr()))
 
+    def ppo_update_rows(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, max_norm, stats, do_adam=True):
+        """The same update for any B <= max_rows in one call (jh_pponet_ppo_update_rows): forward, the loss forward + backward in ONE launch, backward,
+        [clip + Adam].  What minibatches of >= 1024 rows / nets with more than 8 head outputs take; bit-identical to forward -> ppo_loss_* -> backward -> adam_step."""
+        B = int(idx.numel()) if idx is not None else int(x.shape[0])
+        L.check(self.lib.jh_pponet_ppo_update_rows(self.h, B, L.ptr(_f32(x)), L.ptr(idx), L.ptr(_f32(action)), L.ptr(_f32(adv).reshape(-1)), L.ptr(_f32(ret).reshape(-1)),
+                                                   L.ptr(_f32(value_old).reshape(-1)), L.ptr(_f32(logp_old)), float(eps_clip), float(vf_coef), float(ent_coef),
+                                                   float(max_norm if max_norm else 0.0), int(bool(do_adam)), L.ptr(stats), L.stream_ptr()))
+
     def ppo_update_dp(self, x, idx, action, adv, ret, value_old, logp_old, eps_clip, vf_coef, ent_coef, stats, reduce_mean, critic_sums, peer=None):
         """The minibatch update for data-parallel learners with the reference's critic exactly (jh_pponet_ppo_update_dp_begin / _end around
         an 8-byte all-reduce): reduce_mean(t) all-reduces a small fp32 device tensor to its mean over the ranks, in place, on the current

@@ -227,6 +227,8 @@ def _check_every_adam_step(agent, lr, name, M):
     # the four-launch update steps inside ppo_update; the separate-call path (minibatches >= 1024 rows, more than 8 head outputs) in adam_step
     if agent.fused_update and net.fused_ok(agent.batch_size):
         net.ppo_update = wrap(net.ppo_update)
+    elif os.environ.get("JH_PPO_ONEPASS", "1") == "1":
+        net.ppo_update_rows = wrap(net.ppo_update_rows)  # round 6: one call per update (the loss in one launch); Adam steps inside it
     else:
         net.adam_step = wrap(net.adam_step)
     return seen
@@ -280,6 +282,26 @@ def test_ppo_learn_at_baseline_width(name, graph):
             worst = max(worst, float(d.max()))
         margins.leq(bad / tot, 0.005, "fraction of weights off")
         margins.leq(worst, 2.1 * lr * n_upd, "worst weight difference vs travel")
+
+
+@pytest.mark.parametrize("name", ["ppo_cont_hopper_real", "ppo_cont_halfcheetah", "ppo_cont_ant_mb256"])
+def test_ppo_one_launch_loss_update_is_bit_identical_to_the_separate_calls(name, monkeypatch):
+    """jh_pponet_ppo_update_rows (round 6: the loss forward + backward in ONE launch for any minibatch size -- every workgroup keeps both critic branches' value
+    gradients, the last one to arrive reduces the partials, the backward's first kernel mixes) against the path it replaces (jh_pponet_forward -> the two-pass
+    jh_ppo_fwd / jh_ppo_bwd kernels -> jh_pponet_backward -> jh_pponet_adam_step): the same statistics of every update and the same weights and moments after a
+    whole learn(), bit for bit -- 2048-row minibatches (8 workgroups), 1024 rows with 13 head outputs (the value head in the second heads launch), 256 rows with 17."""
+    z = load(name)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("JH_PPO_ONEPASS", mode)
+        agent, cols, (S, A, H, W, T, B, E, cont), lr = _ppo_agent(z, use_graph=False)
+        np.random.seed(int(z["np_seed"]))
+        agent.process(cols, T)
+        torch.cuda.synchronize()
+        n_upd = int(z["n_minibatch"])
+        out[mode] = (npy(agent._stats[:n_upd]).copy(), npy(agent._net.params).copy(), npy(agent._net.m).copy(), npy(agent._net.v).copy(), npy(agent._net.grads).copy())
+    for a, b, what in zip(out["0"], out["1"], ("statistics of every update", "weights", "exp_avg", "exp_avg_sq", "last clipped gradient")):
+        assert np.array_equal(a, b), f"{name}: {what} differ between the separate calls and the one-launch loss (max |diff| {np.abs(a - b).max():.3e})"
 
 
 def test_rainbow_learn_at_atari_shapes():
