@@ -172,7 +172,8 @@ struct jh_pponet {
   float* fwd_part = nullptr;      // [H/16][max_rows][8] per-column-tile partial head outputs (jh_ppo_mb.hip forward)
   float* part_w1 = nullptr;       // [min(max_rows,1024)/16][H*S + H] per-row-tile partial (dW1 | db1) sums
   float* ssq_part = nullptr;      // [(H/32)^2 + H/32] sums of squares of the gradient tiles written by jh_pmb_bwd's workgroups
-  float* norm_partial = nullptr;  // [kNormBlocks]
+  float* norm_partial = nullptr;  // [kNormSlots]
+  int norm_slots = 0;             // > 0: the last backward left the global norm's sums of squares in norm_partial[0 .. norm_slots) (jh_mlp.hip: NormJob)
   float* hyper = nullptr;         // device: {lr, beta1, beta2, eps, step, bc1, bc2_sqrt, _}
   float* upd_ws = nullptr;    // jh_pponet_ppo_update_rows: raw heads, their gradients, the second critic branch, loss partials, {w1, w2}, ticket
   size_t upd_floats = 0;

@@ -24,6 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int kNormBlocks = 256;
+constexpr int kNormSlots = kNormBlocks + 256;  // norm_partial: the norm kernel's 256 sums, or the folded form's (jh_ppo_dw1_partial_kernel: NormJob)
 constexpr int kMaxHeadOutputs = 40;
 }
 
@@ -713,7 +714,7 @@ JH_EXPORT int jh_pponet_create(jh_ctx* ctx, int32_t S, int32_t H, int32_t A, int
     JH_HIP(hipMalloc((void**)&n->upd_ws, sizeof(float) * n->upd_floats));
     JH_HIP(hipMemset(n->upd_ws, 0, sizeof(float) * n->upd_floats));
   }
-  JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormBlocks));
+  JH_HIP(hipMalloc((void**)&n->norm_partial, sizeof(float) * kNormSlots));
   JH_HIP(hipMalloc((void**)&n->hyper, sizeof(float) * JH_HY_FLOATS));
   float hy[JH_HY_FLOATS];
   jh_hyper_fill(hy, 1e-3, 0.9, 0.999, 1e-8, 0.0);
@@ -856,11 +857,40 @@ __global__ void __launch_bounds__(256) jh_rowgather_f32_kernel(int B, int S, con
 //           rows sit in LDS; every thread walks its rows with one coalesced dh1 (+ h2) load + S (+ 8) FMAs, the 4 row lanes combine
 //           through LDS -> partial[z][h][S + 1 (+ 8)]
 //   pass 2  out[h][s] = sum_z partial[z][h][s] in slab order (deterministic); head bias gradients = column sums of g_all (last workgroup)
+// Round 6: the launch also carries the sum of squares of the part of the gradient bucket that is ALREADY complete when it starts (dW2 | db2 [| head weights]
+// from the grouped GEMM before it) as kNormFoldBlocks more workgroups (blockIdx.y >= y0): the global norm of clip_grad_norm_ then needs no launch of its
+// own -- the rest of the bucket's squares come out of the combine kernel below, which forms those elements anyway.  Same loop as jh_gradnorm_kernel.
+constexpr int kNormFoldY = 8;  // x gridDim.x (= H / 64) workgroups
+struct NormJob {
+  const float* g;   // null: no norm job in this launch
+  int64_t n;
+  float* partial;   // [kNormFoldY * gridDim.x]
+  int y0;
+};
 template <int SP>
 __global__ void __launch_bounds__(256) jh_ppo_dw1_partial_kernel(int B, int H, int S, int rows_per, const float* __restrict__ dh1, const float* __restrict__ x,
                                                                  const int64_t* __restrict__ idx, float* __restrict__ partial, const float* __restrict__ h2,
-                                                                 const float* __restrict__ g8) {
+                                                                 const float* __restrict__ g8, NormJob nj) {
   extern __shared__ float s_dyn[];
+  if (nj.g && (int)blockIdx.y >= nj.y0) {
+    const int id = ((int)blockIdx.y - nj.y0) * (int)gridDim.x + (int)blockIdx.x, nblk = kNormFoldY * (int)gridDim.x;
+    float acc = 0.f;
+    const int64_t stride = (int64_t)nblk * 256;
+    for (int64_t i0 = (int64_t)id * 256 + threadIdx.x; i0 < nj.n; i0 += 8 * stride) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + u * stride;
+        v[u] = nj.g[i < nj.n ? i : i0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * stride < nj.n) acc = fmaf(v[u], v[u], acc);
+    }
+    acc = jh_block_reduce(acc, s_dyn, JhAdd(), 0.f);
+    if (threadIdx.x == 0) nj.partial[id] = acc;  // (idempotent: the profiler may repeat this launch; the step counter advances in the combine kernel)
+    return;
+  }
   const bool heads = h2 != nullptr;
   constexpr int NA = SP + 1 + 8;                               // accumulators per thread: S taps | row sum | 8 head columns
   float* s_x = s_dyn;                                          // [rows_per][SP]
@@ -974,8 +1004,11 @@ struct HeadGradOut {
   const float* g8;  // [B][8] packed head gradients (bias gradients = its column sums)
   int n_out, B;
 };
+// ssq (optional) [gridDim.x]: the sum of squares of what this workgroup wrote (see NormJob above)
 __global__ void __launch_bounds__(256) jh_ppo_dw1_combine_kernel(int H, int S, int slabs, const float* __restrict__ partial, float* __restrict__ dW1,
-                                                                 float* __restrict__ db1, HeadGradOut hg) {
+                                                                 float* __restrict__ db1, HeadGradOut hg, float* __restrict__ ssq, float* __restrict__ hyper_advance) {
+  __shared__ float s_ssq[16];
+  if (hyper_advance && blockIdx.x == 0 && threadIdx.x == 0) jh_adam_advance(hyper_advance);  // what jh_gradnorm_kernel does when it runs: nobody reads hyper in this launch
   const int PS = S + 1 + (hg.n_out > 0 ? 8 : 0);
   const int n_main = (H * PS + 255) / 256;
   if ((int)blockIdx.x >= n_main) {  // head bias gradients: 8 columns x 32 row lanes, combined in lane order
@@ -995,22 +1028,36 @@ __global__ void __launch_bounds__(256) jh_ppo_dw1_combine_kernel(int H, int S, i
     }
     s_b[rl][o] = v;
     __syncthreads();
+    float sq = 0.f;
     if (threadIdx.x < 8 && threadIdx.x < hg.n_out) {
       float t = s_b[0][threadIdx.x];
       for (int k = 1; k < 32; ++k) t += s_b[k][threadIdx.x];
       *hg.db[threadIdx.x] = t;
+      sq = t * t;
+    }
+    if (ssq) {
+      sq = jh_block_reduce(sq, s_ssq, JhAdd(), 0.f);
+      if (threadIdx.x == 0) ssq[blockIdx.x] = sq;
     }
     return;
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * PS) return;
   float v = 0.f;
+  bool wrote = false;
+  if (i < H * PS) {
 #pragma unroll 8
-  for (int z = 0; z < slabs; ++z) v += partial[(size_t)z * H * PS + i];
-  const int h = i / PS, q = i - h * PS;
-  if (q < S) dW1[(size_t)h * S + q] = v;
-  else if (q == S) db1[h] = v;
-  else if (q - S - 1 < hg.n_out) hg.dw[q - S - 1][h] = v;
+    for (int z = 0; z < slabs; ++z) v += partial[(size_t)z * H * PS + i];
+    const int h = i / PS, q = i - h * PS;
+    wrote = true;
+    if (q < S) dW1[(size_t)h * S + q] = v;
+    else if (q == S) db1[h] = v;
+    else if (q - S - 1 < hg.n_out) hg.dw[q - S - 1][h] = v;
+    else wrote = false;
+  }
+  if (ssq) {
+    const float sq = jh_block_reduce(wrote ? v * v : 0.f, s_ssq, JhAdd(), 0.f);
+    if (threadIdx.x == 0) ssq[blockIdx.x] = sq;
+  }
 }
 
 // slabs / rows per slab / dynamic LDS bytes of the column reduction for B rows (part_w1 holds 64 slabs of H * (S + 1 + 8) floats)
@@ -1027,11 +1074,18 @@ static size_t pponet_dw1_plan(int B, int S, int* slabs_out, int* rows_per_out) {
 // the reduction keeps a slab's observation and head-gradient rows in LDS: beyond ~24 k rows the tile engine takes over again
 static bool pponet_dw1_reduce_fits(int B, int S) { return S <= 16 && pponet_dw1_plan(B, S, nullptr, nullptr) <= 60 * 1024; }
 
-static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, bool heads, hipStream_t st) {
+// with_norm: the two launches also leave the global norm's sums of squares in n->norm_partial[0 .. n->norm_slots) (NormJob above): the caller goes straight
+// to pponet_adam.  Only for a bucket nobody reduces in between (no data-parallel hook).
+static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, bool heads, hipStream_t st, bool with_norm = false) {
   const int H = n->H, S = n->S;
   int slabs, rows_per;
   const size_t lds = pponet_dw1_plan(B, S, &slabs, &rows_per);
-  const dim3 grid((unsigned)((H + 63) / 64), (unsigned)slabs);
+  const dim3 grid((unsigned)((H + 63) / 64), (unsigned)(slabs + (with_norm ? kNormFoldY : 0)));
+  NormJob nj{};
+  const int n_rest = kNormFoldY * (int)grid.x;
+  if (with_norm) {  // what the grouped GEMM wrote: dW2 | db2, and the head weights / biases too when the column reduction does not carry them
+    nj.g = n->grads + n->o_w2; nj.n = (heads ? n->o_wh0 : n->n_params) - n->o_w2; nj.partial = n->norm_partial; nj.y0 = slabs;
+  }
   const int sp = (S + 3) / 4 * 4;
   if (lds > 60 * 1024) return jh_fail(JH_ERR_ARG, "dW1 reduction: %zu bytes of LDS for %d rows per slab", lds, rows_per);
   HeadGradOut hg{};
@@ -1043,16 +1097,19 @@ static int pponet_dw1_reduce(jh_pponet* n, int B, const float* d_x, const int64_
     h2 = n->h2;
   }
   const double flops = 2.0 * B * (double)H * (S + 1 + (heads ? hg.n_out : 0));
-  if (sp == 4) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<4>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
-  else if (sp == 8) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<8>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
-  else if (sp == 12) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<12>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
-  else if (sp == 16) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<16>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8);
+  if (sp == 4) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<4>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8, nj);
+  else if (sp == 8) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<8>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8, nj);
+  else if (sp == 12) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<12>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8, nj);
+  else if (sp == 16) JH_LAUNCH_IDEM("jh_ppo_dw1_partial", flops, jh_ppo_dw1_partial_kernel<16>, grid, dim3(256), lds, st, B, H, S, rows_per, (const float*)n->dh1, d_x, d_idx, n->part_w1, h2, hg.g8, nj);
   else return jh_fail(JH_ERR_ARG, "dW1 reduction: observation width %d", S);
   JH_LAUNCH_CHECK();
   const int PS = S + 1 + (heads ? 8 : 0);
-  JH_LAUNCH(jh_ppo_dw1_combine_kernel, dim3((unsigned)((H * PS + 255) / 256 + (heads ? 1 : 0))), dim3(256), 0, st, H, S, slabs, (const float*)n->part_w1, n->grads + n->o_w1,
-            n->grads + n->o_b1, hg);
+  const int n_comb = (H * PS + 255) / 256 + (heads ? 1 : 0);
+  if (with_norm && n_rest + n_comb > kNormSlots) return jh_fail(JH_ERR_ARG, "dW1 reduction: %d norm slots", n_rest + n_comb);
+  JH_LAUNCH(jh_ppo_dw1_combine_kernel, dim3((unsigned)n_comb), dim3(256), 0, st, H, S, slabs, (const float*)n->part_w1, n->grads + n->o_w1,
+            n->grads + n->o_b1, hg, with_norm ? n->norm_partial + n_rest : nullptr, with_norm ? n->hyper : nullptr);
   JH_LAUNCH_CHECK();
+  n->norm_slots = with_norm ? n_rest + n_comb : 0;
   return JH_OK;
 }
 
@@ -1117,7 +1174,7 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
 // flat gradient bucket.  (The PPO agent's minibatches of < kTiledRows rows go through jh_pponet_ppo_update
 // instead, where the head gradients never leave the packed [B][8] form.)
 static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0, const float* d_g_head1,
-                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st);
+                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st, bool with_norm = false);
 JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx,
                                  const float* d_g_head0, const float* d_g_head1, const float* d_g_value,
                                  jh_stream stream) {
@@ -1128,8 +1185,9 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
 }
 // d_dv2 / d_mix (both or neither): the value gradient is w1 d_g_value + w2 d_dv2 with {w1, w2} = d_mix, formed by the first kernel
 static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0, const float* d_g_head1,
-                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st) {
+                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st, bool with_norm) {
   const int H = n->H, S = n->S;
+  n->norm_slots = 0;
   const int64_t bh = (int64_t)B * H;
   HeadPtrs hp = head_ptrs(n, nullptr, nullptr, nullptr, d_g_head0, d_g_head1, d_g_value);
   for (int o0 = 0; o0 < n->n_out; o0 += 8) {  // the chain over the outputs continues from launch to launch (dh2 holds it in between)
@@ -1172,7 +1230,7 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
     tw.ws = n->tg_ws; tw.ws_floats = n->tg_ws_floats; tw.cnt = n->tg_cnt; tw.cnt_slots = n->tg_cnt_slots;
     rc = jh_tgemm_launch(tw, "jh_tgemm_ppo_bwd", g, ng, st);
     if (rc) return rc;
-    if (reduce) return pponet_dw1_reduce(n, B, d_x, d_idx, reduce_heads, st);
+    if (reduce) return pponet_dw1_reduce(n, B, d_x, d_idx, reduce_heads, st, with_norm);
     JH_LAUNCH(jh_rowgather_f32_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, st, B, S, d_x, d_idx, n->xg);
     JH_LAUNCH_CHECK();
     g[0] = mk_gemm(H, S, B, op_dense(OP_XCONT, n->dh1, H), op_dense(OP_XCONT, n->xg, S), n->grads + n->o_w1, S, TEPI_NONE, nullptr, nullptr, 0, n->grads + n->o_b1);
@@ -1209,9 +1267,9 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
   return JH_OK;
 }
 
-static int pponet_adam(jh_pponet* n, float max_norm, float* d_norm_out, hipStream_t st) {
+static int pponet_adam(jh_pponet* n, float max_norm, float* d_norm_out, hipStream_t st, int n_partial = kNormBlocks) {
   JH_LAUNCH(jh_adam_kernel<false>, dim3(kNormBlocks), dim3(256), 0, st, n->n_params, n->params, n->grads, n->m, n->v,
-            n->norm_partial, kNormBlocks, n->hyper, max_norm, d_norm_out, (const float*)nullptr, 0, (int64_t)0);
+            n->norm_partial, n_partial, n->hyper, max_norm, d_norm_out, (const float*)nullptr, 0, (int64_t)0);
   JH_LAUNCH_CHECK();
   return JH_OK;
 }
@@ -1302,18 +1360,21 @@ JH_EXPORT int jh_pponet_ppo_update_rows(jh_pponet* n, int32_t B, const float* d_
   int rc = jh_pponet_forward(n, B, d_x, d_idx, h0, n->cont ? h1 : nullptr, hv, stream);
   if (rc) return rc;
   hipStream_t st = jh_s(stream);
+  // clip_grad_norm_'s sums of squares ride in the dW1 launches when this call also steps (nobody reduces the bucket in between); JH_PPO_NORM_FOLD=0: the norm kernel
+  const bool fold = do_adam && max_norm > 0.f && !(getenv("JH_PPO_NORM_FOLD") && atoi(getenv("JH_PPO_NORM_FOLD")) == 0);
   if (B <= 1024) {  // one workgroup holds the whole minibatch: the fused forward + backward loss kernel IS one launch (and reduces in its own order)
     rc = n->cont ? jh_ppo_loss_continuous(n->ctx, B, n->A, h0, h1, hv, d_idx, d_action, d_adv, d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, g0, g1, gv, d_stats, stream)
                  : jh_ppo_loss_discrete(n->ctx, B, n->A, h0, hv, d_idx, d_action, d_adv, d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef, g0, gv, d_stats, stream);
     if (rc) return rc;
-    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, nullptr, nullptr, st);
+    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, nullptr, nullptr, st, fold);
   } else {
     rc = jh_ppo_loss_onepass(n->cont, B, n->A, h0, n->cont ? h1 : nullptr, hv, d_idx, d_action, d_adv, d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef,
                              g0, n->cont ? g1 : nullptr, gv, dv2, mix, ticket, partial, d_stats, st);
     if (rc) return rc;
-    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, dv2, mix, st);
+    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, dv2, mix, st, fold);
   }
   if (rc || !do_adam) return rc;
+  if (n->norm_slots > 0) return pponet_adam(n, max_norm, nullptr, st, n->norm_slots);  // the backward's last two launches left the norm's sums of squares behind
   return jh_pponet_adam_step(n, max_norm, nullptr, stream);
 }
 

@@ -292,6 +292,7 @@ def test_ppo_one_launch_loss_update_is_bit_identical_to_the_separate_calls(name,
     whole learn(), bit for bit -- 2048-row minibatches (8 workgroups), 1024 rows with 13 head outputs (the value head in the second heads launch), 256 rows with 17."""
     z = load(name)
     out = {}
+    monkeypatch.setenv("JH_PPO_NORM_FOLD", "0")  # (the folded norm sums the squares in another order: its own test below)
     for mode in ("0", "1"):
         monkeypatch.setenv("JH_PPO_ONEPASS", mode)
         agent, cols, (S, A, H, W, T, B, E, cont), lr = _ppo_agent(z, use_graph=False)
@@ -302,6 +303,29 @@ def test_ppo_one_launch_loss_update_is_bit_identical_to_the_separate_calls(name,
         out[mode] = (npy(agent._stats[:n_upd]).copy(), npy(agent._net.params).copy(), npy(agent._net.m).copy(), npy(agent._net.v).copy(), npy(agent._net.grads).copy())
     for a, b, what in zip(out["0"], out["1"], ("statistics of every update", "weights", "exp_avg", "exp_avg_sq", "last clipped gradient")):
         assert np.array_equal(a, b), f"{name}: {what} differ between the separate calls and the one-launch loss (max |diff| {np.abs(a - b).max():.3e})"
+
+
+@pytest.mark.parametrize("name", ["ppo_cont_hopper_real", "ppo_cont_halfcheetah"])
+def test_ppo_norm_folded_into_the_dw1_launches_equals_the_norm_kernel(name, monkeypatch):
+    """clip_grad_norm_'s sum of squares without a launch of its own (round 6): the part of the bucket the grouped GEMM wrote is squared by extra workgroups of
+    the dW1 column reduction's first launch, the rest by the combine kernel that forms those elements.  Another order of the same additions: the clip
+    coefficient agrees to fp32 rounding, and so does a whole learn() -- statistics of every update to 1e-6, weights to 1e-7 + a millionth of a step."""
+    z = load(name)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("JH_PPO_NORM_FOLD", mode)
+        agent, cols, (S, A, H, W, T, B, E, cont), lr = _ppo_agent(z, use_graph=False)
+        np.random.seed(int(z["np_seed"]))
+        agent.process(cols, T)
+        torch.cuda.synchronize()
+        n_upd = int(z["n_minibatch"])
+        out[mode] = (npy(agent._stats[:n_upd]).astype(np.float64), npy(agent._net.params).astype(np.float64), npy(agent._net.grads).astype(np.float64))
+    s0, w0, g0 = out["0"]
+    s1, w1, g1 = out["1"]
+    assert not np.array_equal(g0, g1) or np.array_equal(w0, w1)  # (the clipped gradient carries the coefficient: usually a few ulps apart)
+    margins.leq(float(np.abs(s0 - s1).max() / (1.0 + np.abs(s0).max())), 1e-6, f"{name}: statistics, folded norm vs norm kernel")
+    margins.leq(float(np.abs(g0 - g1).max() / np.abs(g0).max()), 1e-6, f"{name}: last clipped gradient, folded norm vs norm kernel")
+    margins.leq(float(np.abs(w0 - w1).max()), 1e-7 + 1e-2 * lr, f"{name}: weights after a learn(), folded norm vs norm kernel")
 
 
 def test_rainbow_learn_at_atari_shapes():
