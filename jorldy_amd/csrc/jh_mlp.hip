@@ -19,6 +19,7 @@
 //     sums, so they cost no extra pass.
 #include "jh_ppo_mb.h"
 #include "jh_tgemm.h"
+#include "jh_ppo_finish.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_fwd_kernel(int B, int H, con
 __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, const float* __restrict__ h2,
                                                                   float* __restrict__ dh2, float* __restrict__ g_all,
                                                                   HeadFlat hf, int gld, int o0, int first, int last,
-                                                                  const float* __restrict__ dv2, const float* __restrict__ mix, int ov) {
+                                                                  const float* __restrict__ dv2, const float* __restrict__ mix, int ov, PpoFinish fin) {
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int h4 = H >> 2;
   if (i4 >= (int64_t)B * h4) return;
@@ -454,8 +455,16 @@ __global__ void __launch_bounds__(256) jh_mlp_heads_bwd_dh_kernel(int B, int H, 
     gv[o] = hf.g[o][(size_t)b * hf.ld[o]];
     w[o] = *reinterpret_cast<const float4*>(hf.w[o] + k);
   }
-  if (dv2) {  // the one-launch loss (jh_ppo_onepass_kernel) left both critic branches' value gradients and the branch weights: slot `ov` is the value head
-    const float w1 = mix[0], w2 = mix[1], g2 = dv2[b];
+  if (dv2) {  // the one-launch loss (jh_ppo_onepass_kernel) left both critic branches' value gradients: slot `ov` is the value head
+    float w1, w2;
+    const float g2 = dv2[b];
+    if (fin.partial) {  // ... and its workgroups' partials (nb <= 64): every wave reduces them in the two-pass order (the same bits everywhere), workgroup 0 writes the statistics
+      float t[6];
+      ppo_reduce_partials_wave(fin.partial, fin.nb, t);
+      ppo_finish_stats(t[0], t[1], t[2], t[3], t[4], t[5], fin.B, fin.ent_count, fin.vf, fin.ent, w1, w2, (blockIdx.x == 0 && threadIdx.x == 0) ? fin.stats : nullptr);
+    } else {
+      w1 = mix[0]; w2 = mix[1];
+    }
 #pragma unroll
     for (int o = 0; o < 8; ++o)
       if (o == ov) gv[o] = w1 * gv[o] + w2 * g2;  // jh_ppo_critic_select_kernel's expression
@@ -1174,7 +1183,7 @@ JH_EXPORT int jh_pponet_forward(jh_pponet* n, int32_t B, const float* d_x, const
 // flat gradient bucket.  (The PPO agent's minibatches of < kTiledRows rows go through jh_pponet_ppo_update
 // instead, where the head gradients never leave the packed [B][8] form.)
 static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0, const float* d_g_head1,
-                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st, bool with_norm = false);
+                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st, bool with_norm = false, const PpoFinish* fin = nullptr);
 JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx,
                                  const float* d_g_head0, const float* d_g_head1, const float* d_g_value,
                                  jh_stream stream) {
@@ -1185,7 +1194,7 @@ JH_EXPORT int jh_pponet_backward(jh_pponet* n, int32_t B, const float* d_x, cons
 }
 // d_dv2 / d_mix (both or neither): the value gradient is w1 d_g_value + w2 d_dv2 with {w1, w2} = d_mix, formed by the first kernel
 static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int64_t* d_idx, const float* d_g_head0, const float* d_g_head1,
-                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st, bool with_norm) {
+                           const float* d_g_value, const float* d_dv2, const float* d_mix, hipStream_t st, bool with_norm, const PpoFinish* fin) {
   const int H = n->H, S = n->S;
   n->norm_slots = 0;
   const int64_t bh = (int64_t)B * H;
@@ -1194,7 +1203,7 @@ static int pponet_backward(jh_pponet* n, int32_t B, const float* d_x, const int6
     const int ov = n->n_out - 1 - o0;  // the value head is the last output
     JH_LAUNCH(jh_mlp_heads_bwd_dh_kernel, dim3((unsigned)((bh / 4 + 255) / 256)), dim3(256), 0, st, B, H, n->h2, n->dh2,
               n->g_all, head_flat(n, hp, o0), n->gld, o0, o0 == 0 ? 1 : 0, o0 + 8 >= n->n_out ? 1 : 0,
-              (d_dv2 && ov >= 0 && ov < 8) ? d_dv2 : nullptr, d_mix, ov);
+              (d_dv2 && ov >= 0 && ov < 8) ? d_dv2 : nullptr, d_mix, ov, fin ? *fin : PpoFinish{});
     JH_LAUNCH_CHECK();
   }
   const float* w[kMaxHeadOutputs]; float* dw[kMaxHeadOutputs]; const float* b[kMaxHeadOutputs]; float* db[kMaxHeadOutputs];
@@ -1368,10 +1377,17 @@ JH_EXPORT int jh_pponet_ppo_update_rows(jh_pponet* n, int32_t B, const float* d_
     if (rc) return rc;
     rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, nullptr, nullptr, st, fold);
   } else {
+    // up to 64 loss workgroups (16 384 rows): the backward's first kernel reduces their partials itself (no ticket, no tail in the loss launch) and writes the
+    // statistics; beyond, the loss launch's last workgroup does (every workgroup of the consumer re-reducing thousands of partials would cost more).  The
+    // value head sits in the consumer's LAST launch of 8 outputs.
+    const int nb = (B + 255) / 256;
+    const bool by_consumer = nb <= 64 && !(getenv("JH_PPO_LOSS_TICKET") && atoi(getenv("JH_PPO_LOSS_TICKET")) != 0);
     rc = jh_ppo_loss_onepass(n->cont, B, n->A, h0, n->cont ? h1 : nullptr, hv, d_idx, d_action, d_adv, d_ret, d_value_old, d_logp_old, eps_clip, vf_coef, ent_coef,
-                             g0, n->cont ? g1 : nullptr, gv, dv2, mix, ticket, partial, d_stats, st);
+                             g0, n->cont ? g1 : nullptr, gv, dv2, mix, by_consumer ? nullptr : ticket, partial, by_consumer ? nullptr : d_stats, st);
     if (rc) return rc;
-    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, dv2, mix, st, fold);
+    PpoFinish fin{};
+    if (by_consumer) { fin.partial = partial; fin.nb = nb; fin.B = B; fin.ent_count = n->cont ? B * n->A : B; fin.vf = vf_coef; fin.ent = ent_coef; fin.stats = d_stats; }
+    rc = pponet_backward(n, B, d_x, d_idx, g0, n->cont ? g1 : nullptr, gv, dv2, mix, st, fold, by_consumer ? &fin : nullptr);
   }
   if (rc || !do_adam) return rc;
   if (n->norm_slots > 0) return pponet_adam(n, max_norm, nullptr, st, n->norm_slots);  // the backward's last two launches left the norm's sums of squares behind
