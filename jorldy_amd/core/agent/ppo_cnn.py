@@ -91,6 +91,8 @@ class PPOConv(NativeValueNetMixin, PPO):
     def act(self, state, training=True):
         if isinstance(state, list):
             raise NotImplementedError("PPO: list-valued (multimodal) observations are outside the native policy-value net")
+        if torch.is_tensor(state):  # the reference's as_tensor (base.py:61-73) takes tensors too
+            state = state.detach().cpu().numpy()
         x = np.asarray(state)
         if x.dtype != np.uint8:
             x = x.astype(np.float32, copy=False)

@@ -175,6 +175,8 @@ def test_ppo_cnn_act_samples_the_policy_and_is_greedy_in_eval():
     greedy = agent.act(frames, training=False)["action"]
     assert greedy.shape == (N, 1) and greedy.dtype == np.int64 and np.array_equal(greedy[:, 0], pi.argmax(1))
     assert np.array_equal(agent.act(frames.astype(np.float32), training=False)["action"], greedy)  # float frames: the same values through the fp32 operand fetch
+    assert np.array_equal(agent.act(torch.from_numpy(frames).cuda(), training=False)["action"], greedy)  # ... and what else the reference's as_tensor takes: tensors, float64
+    assert np.array_equal(agent.act(frames.astype(np.float64), training=False)["action"], greedy)
     n = 4000
     counts = np.zeros((N, A))
     for _ in range(n):
