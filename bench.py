@@ -673,6 +673,13 @@ def hopper_leg(rank, world, local_rank, dist, iters):
                                "workload": ee["workload"], "acting": "persistent acting kernel, one launch per rollout: 32 rows x 11 observations = 352 granules per exchange (three poll instructions per poll, two row tiles)"}
         except Exception as e:
             r["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+        # ... and what ONE of the config's eight GPUs runs (4 workers, 256 minibatch rows per GPU: the layout `--gpus 8` measures), end to end on this GPU
+        try:
+            sh = _tool("bench_hopper").hopper_leg(iters=max(2, min(6, 2 * iters)), warmup=4, workers=4, batch=256, e2e=True, dist=None, device=f"cuda:{local_rank}")
+            r["per_gpu_share_of_8"] = {"env_transitions_per_s": sh["env_transitions_per_s_end_to_end"], "ms_per_iteration": sh["ms_per_iteration"], "collector": sh["collector"],
+                                       "workload": sh["workload"], "note": "one rank of the 8-GPU data-parallel layout WITHOUT its gradient all-reduce (measured on one GPU); x 8 = the aggregate before the collective's cost (DESIGN 7)"}
+        except Exception as e:
+            r["per_gpu_share_of_8"] = {"error": f"{type(e).__name__}: {e}"}
     return r
 
 
@@ -961,6 +968,7 @@ def main():
                        "rainbow_updates_s": leg("rainbow", "value"), "apex_env_steps_s": leg("apex", "value"), "apex_updates_s": leg("apex", "learner_updates_per_s"),
                        "ppo_atari_learner_transitions_s": leg("ppo_atari", "value"), "ppo_atari_updates_s": leg("ppo_atari", "learner_updates_per_s"), "ppo_atari_x_cpu_reference": leg("ppo_atari", "x_cpu_reference"),
                        "hopper_transitions_s": leg("hopper", "value"), "hopper_end_to_end_env_transitions_s": ((out.get("hopper") or {}).get("end_to_end") or {}).get("env_transitions_per_s"),
+                       "hopper_per_gpu_share_of_8_env_transitions_s": ((out.get("hopper") or {}).get("per_gpu_share_of_8") or {}).get("env_transitions_per_s"),
                        "hopper_x_cpu_reference": (leg("hopper", "value") / out["hopper"]["cpu_reference"]["value"]) if (out.get("hopper") or {}).get("cpu_reference", {}).get("value") else None}
         print(json.dumps(out))
 

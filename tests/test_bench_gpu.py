@@ -78,3 +78,7 @@ def test_bench_emits_one_contract_json_line():
     assert "error" not in pa, pa
     assert pa["agent"] == "PPOConv" and pa["learn_in_hipgraph"] and pa["value"] > 0 and pa["minibatch_updates_per_iteration"] == 96 and 0 < pa["roofline"]["frac"] < 1
     assert pa["cpu_reference"]["value"] > 0 and abs(lg["ppo_atari_x_cpu_reference"] - pa["value"] / pa["cpu_reference"]["value"]) < 1e-6 * lg["ppo_atari_x_cpu_reference"]
+    # configs[4] is an 8-GPU layout: one rank's share (4 workers, minibatch 256) measured end to end on this GPU rides on the line too
+    sh = hp["per_gpu_share_of_8"]
+    assert "error" not in sh, sh
+    assert sh["env_transitions_per_s"] > 0 and "W=4" in sh["workload"] and lg["hopper_per_gpu_share_of_8_env_transitions_s"] == sh["env_transitions_per_s"]
