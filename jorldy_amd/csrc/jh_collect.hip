@@ -19,8 +19,11 @@
 struct jh_persist;
 int jh_persist_create(jh_pponet* n, jh_persist** out);
 void jh_persist_destroy(jh_persist* p);
-int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st);
+int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st, int split = 0);
 unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs);
+unsigned jh_persist_seq(const jh_persist* p);
+void jh_persist_publish_rows(jh_persist* p, int r0, int r1, const float* h_obs, unsigned tag);
+int jh_persist_collect_range(jh_persist* p, int r0, int n_rows, unsigned tag, float* h_heads);
 int jh_persist_collect(jh_persist* p, int W, unsigned tag, float* h_heads);
 int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned tag, float* h_heads);
 int jh_persist_heads(const jh_persist* p);
@@ -81,6 +84,9 @@ struct jh_collector {
   // lookahead = 2 (discrete two-action envs that can be forked on the host, 3 W <= 32 rows): every PCIe round trip carries each
   // env's state AND both successor states, and serves two timesteps (run_loop_lookahead).  1: one timestep per round trip.
   int lookahead = 1;
+  // round 6: 32 rows of an env that steps row ranges (the built-in envs) are exchanged as two INDEPENDENT halves of 16 (run_loop_split): one half's round
+  // trip through the acting kernel runs under the other half's sampling, env steps and bookkeeping.  JH_COLLECT_SPLIT=0: one exchange of 32 rows.
+  bool split = false;
   Level lv[4];  // L1, L2, L3 and the one-step exchange's scratch level
   void *spec = nullptr, *spec2 = nullptr, *spec3 = nullptr;  // 2 W / 4 W / 8 W scratch envs (vt.fork_alloc): successors one, two and three steps ahead
   // acting-time capture (jh_collector_set_capture): device destinations of the raw heads / values of the states acted on
@@ -102,6 +108,9 @@ struct jh_collector {
 struct RunState;
 static void run_state_alloc(jh_collector* c);
 static void run_state_free(jh_collector* c);
+
+static int cart_obs(void* e, int32_t r0, int32_t r1, float* o);
+static int ctl_obs(void* e, int32_t r0, int32_t r1, float* o);
 
 static int collector_create(jh_ctx* ctx, jh_pponet* net, const jh_env_vtbl* vt, void* env, jh_store* store, const int32_t* cols,
                             jh_collector** out) {
@@ -137,6 +146,12 @@ static int collector_create(jh_ctx* ctx, jh_pponet* net, const jh_env_vtbl* vt, 
       if (!c->spec || !c->spec2 || !c->spec3) c->lookahead = 1;
     }
   }
+  // two independent halves per timestep: 32 rows, one timestep per exchange, an env that steps row ranges of ITSELF (the vtbl's contract promises that for
+  // scratch envs only: the built-in envs do)
+  {
+    const char* e = getenv("JH_COLLECT_SPLIT");
+    c->split = c->persist && c->lookahead != 2 && W == 32 && (vt->obs == cart_obs || vt->obs == ctl_obs) && !(e && atoi(e) == 0);
+  }
   c->obs.resize((size_t)S * W);
   c->next_obs.resize((size_t)S * W);
   c->act_i.resize(W);
@@ -169,13 +184,15 @@ static void cart_copy_row(void* d_, int32_t di, const void* s_, int32_t si) {
 }
 static int ctl_obs(void* e, int32_t r0, int32_t r1, float* o) {
   const jh_control* c = (const jh_control*)e;
-  if (r0 != 0 || r1 != c->W) return jh_fail(JH_ERR_ARG, "jh_control: whole-env calls only (rows %d..%d of %d)", r0, r1, c->W);
-  return jh_control_obs(c, o);
+  if (r0 < 0 || r1 > c->W || r0 >= r1) return jh_fail(JH_ERR_ARG, "jh_control: rows %d..%d of %d", r0, r1, c->W);
+  jh_control_obs_rows(c, r0, r1, o);
+  return JH_OK;
 }
 static int ctl_step(void* e, int32_t r0, int32_t r1, const void* a, float* nx, float* rw, uint8_t* dn) {
   jh_control* c = (jh_control*)e;
-  if (r0 != 0 || r1 != c->W) return jh_fail(JH_ERR_ARG, "jh_control: whole-env calls only (rows %d..%d of %d)", r0, r1, c->W);
-  return jh_control_step(c, (const float*)a, nx, rw, dn);
+  if (r0 < 0 || r1 > c->W || r0 >= r1) return jh_fail(JH_ERR_ARG, "jh_control: rows %d..%d of %d", r0, r1, c->W);
+  jh_control_step_rows(c, r0, r1, (const float*)a, nx, rw, dn);
+  return JH_OK;
 }
 
 JH_EXPORT int jh_collector_create(jh_ctx* ctx, jh_pponet* net, jh_cartpole* env, jh_store* store,
@@ -261,7 +278,7 @@ JH_EXPORT int jh_collector_prelaunch(jh_collector* c, int32_t T, jh_stream strea
   JH_ARG(c != nullptr && T > 0);
   if (!c->persist || c->prelaunched_T) return JH_OK;
   const int steps = collector_steps(c, T);
-  int rc = jh_persist_begin(c->persist, collector_rows(c), steps, jh_s(stream));
+  int rc = jh_persist_begin(c->persist, collector_rows(c), steps, jh_s(stream), c->split);
   if (rc == JH_OK) c->prelaunched_T = steps;
   return rc;
 }
@@ -353,7 +370,7 @@ static int run_prepare(jh_collector* c, int T, hipStream_t st) {
         jh_persist_abort(c->persist);
         (void)hipStreamSynchronize(st);
       }
-      rc = jh_persist_begin(c->persist, collector_rows(c), r.steps, st);
+      rc = jh_persist_begin(c->persist, collector_rows(c), r.steps, st, c->split);
       if (rc) r.persistent = false;
     }
   }
@@ -362,6 +379,7 @@ static int run_prepare(jh_collector* c, int T, hipStream_t st) {
 }
 
 static int run_loop_lookahead(jh_collector* c, int training, hipStream_t stream_h, int* t_done);
+static int run_loop_split(jh_collector* c, int training, hipStream_t stream_h, int* t_done);
 
 // The host loop.  Returns the first error; the caller commits either way.
 static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
@@ -374,6 +392,10 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
     if (rc_la != JH_OK || t_begin >= steps) return rc_la;
     // the acting kernel gave up in the middle of the run: finish the remaining timesteps with one launch per step (below)
     r.persistent = false;
+  } else if (r.persistent && c->split) {
+    const int rc_sp = run_loop_split(c, training, stream_h, &t_begin);
+    if (rc_sp != JH_OK || t_begin >= steps) return rc_sp;
+    r.persistent = false;  // (the same)
   }
   jh_stream stream = (jh_stream)stream_h;
   int rc = JH_OK;
@@ -492,6 +514,109 @@ static int run_loop(jh_collector* c, int training, hipStream_t stream_h) {
   return JH_OK;
 }
 
+
+// ---- split: the 32 rows of a timestep as two INDEPENDENT exchanges of 16 (round 6).
+// One timestep of config.ppo.mujoco's 32 workers was exchange (19.4 us: publication, PCIe polling, 3.9 us of kernel, 48 KB of partial heads back, the host's
+// sampling) + env steps and bookkeeping (11 us), one after the other.  The acting kernel's two row tiles are two sets of workgroups that never talk to each
+// other, so with tags per row tile (jh_persist.hip: PersistArgs::split) the host runs them out of phase: while half A's observations are on their way through
+// the kernel, the host samples, steps and stores half B, publishes B's next observations, and only then comes back for A's heads.  Nothing is speculated: the
+// same rows go through the same arithmetic (a row's position inside its tile is unchanged), the sampling stream is keyed by (seed, timestep, row), every env
+// row advances on its own state -- the rollout, the captured heads / values and every stored transition are bit-identical to the one-exchange path (tested).
+// *t_done: timesteps completed (incl. the value-only query); < steps only when the kernel gave up (the caller finishes with one launch per step).
+static int run_loop_split(jh_collector* c, int training, hipStream_t stream_h, int* t_done) {
+  RunState& r = run_state(c);
+  const int W = c->W, S = c->S, A = c->A, T = r.T, steps = T + (r.cap ? 1 : 0), HR = 16;
+  const bool cap = r.cap;
+  float *ch0 = r.ch0, *ch1 = r.ch1, *cv = r.cv, *cnv = r.cnv;
+  float* st = (float*)r.cols[c->col_state];
+  int64_t* ac_i = (int64_t*)r.cols[c->col_action];
+  float* ac_f = (float*)r.cols[c->col_action];
+  float* rw = (float*)r.cols[c->col_reward];
+  float* ns = (float*)r.cols[c->col_next];
+  uint8_t* dn = (uint8_t*)r.cols[c->col_done];
+  const int no = jh_persist_heads(c->persist);
+  const unsigned base = jh_persist_seq(c->persist);  // the kernel's tags are base + 1 .. base + steps, for each half on its own
+  bool dead = false;  // the kernel gave up while half 1 of a timestep was owed: that half is finished by hand, then the per-step path takes over
+  *t_done = 0;
+  int rc = c->vt.obs(c->env, 0, W, c->obs.data());
+  if (rc) { jh_persist_abort(c->persist); return rc; }
+  for (int h = 0; h < 2; ++h) jh_persist_publish_rows(c->persist, h * HR, (h + 1) * HR, c->obs.data(), base + 1);
+  for (int t = 0; t < steps; ++t) {
+    const bool extra = t == T;  // capture: one value-only query of the states the rollout ended in
+    for (int h = 0; h < 2; ++h) {
+      const int r0 = h * HR, r1 = r0 + HR;
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = jh_persist_collect_range(c->persist, r0, HR, base + (unsigned)t + 1, c->heads.data() + (size_t)r0 * no);
+      if (rc) {  // the kernel gave up (it exits by itself)
+        jh_persist_abort(c->persist);
+        if (r.early)
+          return jh_fail(JH_ERR_STATE, "the persistent acting kernel gave up at step %d of a run whose commit was enqueued ahead (jh_collector_begin): "
+                                       "no observations for ~0.2 s; use jh_collector_run for environments that may stall", t);
+        JH_HIP(hipStreamSynchronize(stream_h));
+        if (h == 0) { *t_done = t; return JH_OK; }  // both halves stand at step t: the per-step path takes over from here
+        // half 1 of step t is still owed (half 0 has moved on): its raw heads from one launch over its 16 rows, sampled below with the rows' own stream keys
+        std::vector<float> mu((size_t)HR * A), ls((size_t)HR * A), vv(HR);
+        std::vector<float> af((size_t)HR * A);
+        std::vector<int64_t> ai(HR);
+        const uint64_t ctr = c->net->act_ctr;
+        rc = c->cont ? jh_pponet_act_continuous(c->net, HR, c->obs.data() + (size_t)r0 * S, af.data(), mu.data(), ls.data(), vv.data(), 0, (jh_stream)stream_h)
+                     : jh_pponet_act_discrete(c->net, HR, c->obs.data() + (size_t)r0 * S, ai.data(), mu.data(), vv.data(), 0, (jh_stream)stream_h);
+        if (rc) return rc;
+        c->net->act_ctr = ctr;  // (the launch counted a sampling step; this timestep's count comes below)
+        dead = true;
+        for (int k = 0; k < HR; ++k) {
+          float* hz = c->heads.data() + (size_t)(r0 + k) * no;
+          memcpy(hz, mu.data() + (size_t)k * A, sizeof(float) * A);
+          if (c->cont) memcpy(hz + A, ls.data() + (size_t)k * A, sizeof(float) * A);
+          hz[no - 1] = vv[k];
+        }
+      }
+      for (int w = r0; w < r1; ++w) {
+        const float* hz = c->heads.data() + (size_t)w * no;
+        if (!extra) {
+          if (c->cont) jh_sample_continuous(c->net, hz, w, training, c->act_f.data() + (size_t)w * A);
+          else c->act_i[w] = jh_sample_discrete(c->net, hz, w, training);
+        }
+        if (cap) {
+          const float val = hz[no - 1];
+          if (t > 0) cnv[(size_t)w * T + (t - 1)] = val;  // V(next_state_{t-1}) = V(state_t)  (masked by done_{t-1} in GAE)
+          if (!extra) {
+            const size_t row = (size_t)w * T + t;
+            cv[row] = val;
+            memcpy(ch0 + row * A, hz, sizeof(float) * A);
+            if (c->cont) memcpy(ch1 + row * A, hz + A, sizeof(float) * A);
+          }
+        }
+      }
+      if (h == 1 && !extra) c->net->act_ctr += 1;  // one sampling step per TIMESTEP: both halves drew under the same counter
+      const auto t1 = std::chrono::steady_clock::now();
+      c->t_act += std::chrono::duration<double>(t1 - t0).count();
+      if (extra) { c->t_extra += std::chrono::duration<double>(t1 - t0).count(); continue; }
+      if (t == 0) c->t_first += std::chrono::duration<double>(t1 - t0).count();
+      rc = c->vt.step(c->env, r0, r1, c->cont ? (const void*)c->act_f.data() : (const void*)c->act_i.data(), c->next_obs.data(), c->reward.data(), c->done.data());
+      if (rc) { jh_persist_abort(c->persist); return rc; }
+      for (int w = r0; w < r1; ++w) {
+        const size_t row = (size_t)w * T + t;  // worker-major: w0 t0..tT-1, w1 ...  (distributed_manager.py:30)
+        memcpy(st + S * row, c->obs.data() + (size_t)S * w, sizeof(float) * S);
+        memcpy(ns + S * row, c->next_obs.data() + (size_t)S * w, sizeof(float) * S);
+        if (c->cont) memcpy(ac_f + A * row, c->act_f.data() + (size_t)A * w, sizeof(float) * A);
+        else ac_i[row] = c->act_i[w];
+        rw[row] = c->reward[w];
+        dn[row] = c->done[w];
+      }
+      if (t + 1 < steps && !dead) {  // this half's next observations (the reset state where an episode just ended) go out NOW: their round trip runs under the other half's work
+        rc = c->vt.obs(c->env, r0, r1, c->obs.data());
+        if (rc) { jh_persist_abort(c->persist); return rc; }
+        jh_persist_publish_rows(c->persist, r0, r1, c->obs.data(), base + (unsigned)t + 2);
+      }
+      c->t_env += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    }
+    if (!extra) c->steps += 1;
+    *t_done = t + 1;
+    if (dead) return JH_OK;
+  }
+  return JH_OK;
+}
 
 // ---- lookahead = 2: two timesteps per exchange with the acting kernel.
 // An acting step is latency: the host's observations cross PCIe (the GPU polls host memory: ~1.7 us), are relayed on the chip, go

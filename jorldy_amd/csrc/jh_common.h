@@ -146,6 +146,9 @@ struct jh_control {
 
 void jh_cartpole_obs_rows(const jh_cartpole* e, int r0, int r1, float* h_obs);
 void jh_cartpole_step_rows(jh_cartpole* e, int r0, int r1, const int64_t* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done);
+struct jh_control;
+void jh_control_obs_rows(const jh_control* e, int r0, int r1, float* h_obs);
+void jh_control_step_rows(jh_control* e, int r0, int r1, const float* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done);
 
 struct jh_pponet {
   jh_ctx* ctx = nullptr;

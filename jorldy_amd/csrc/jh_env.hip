@@ -123,15 +123,24 @@ JH_EXPORT void jh_control_destroy(jh_control* e) { delete e; }
 
 JH_EXPORT int jh_control_obs(const jh_control* e, float* h_obs) {
   JH_ARG(e && h_obs);
-  for (size_t i = 0; i < (size_t)e->S * e->W; ++i) h_obs[i] = (float)e->s[i];
+  jh_control_obs_rows(e, 0, e->W, h_obs);
   return JH_OK;
+}
+// rows r0 .. r1-1 of the full arrays (absolute row indexing, like jh_cartpole_*_rows): the collector steps the two halves of a 32-row env apart
+void jh_control_obs_rows(const jh_control* e, int r0, int r1, float* h_obs) {
+  for (size_t i = (size_t)e->S * r0; i < (size_t)e->S * r1; ++i) h_obs[i] = (float)e->s[i];
 }
 
 JH_EXPORT int jh_control_step(jh_control* e, const float* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done) {
   JH_ARG(e && h_action && h_next_obs && h_reward && h_done);
+  jh_control_step_rows(e, 0, e->W, h_action, h_next_obs, h_reward, h_done);
+  return JH_OK;
+}
+
+void jh_control_step_rows(jh_control* e, int r0, int r1, const float* h_action, float* h_next_obs, float* h_reward, uint8_t* h_done) {
   const int S = e->S, A = e->A;
   double nxt[64];
-  for (int w = 0; w < e->W; ++w) {
+  for (int w = r0; w < r1; ++w) {
     double* s = &e->s[(size_t)S * w];
     const float* a = h_action + (size_t)A * w;
     double a2 = 0.0;
@@ -149,5 +158,4 @@ JH_EXPORT int jh_control_step(jh_control* e, const float* h_action, float* h_nex
     h_reward[w] = (float)(s[0] + 0.1 - 0.001 * a2);
     if (d) reset_control(e, w);
   }
-  return JH_OK;
 }

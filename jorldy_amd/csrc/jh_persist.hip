@@ -53,6 +53,8 @@ struct PersistArgs {
   int period;                          // spacing of the polls in flight, wall_clock64 ticks (10 ns)
   unsigned long long* mbox;            // device memory [64] granules: relay of the observations (null: every workgroup polls the host)
   float4* dpart;                       // device memory [row tiles][G][16 rows][tiles] granules, or null: round 6, the partial heads are summed ON THE DEVICE
+  int split;                           // round 6: the two row tiles are exchanged INDEPENDENTLY (W = 32): a workgroup waits for, polls and relays only ITS row tile's
+                                       // observation granules, so the host can publish one half's step t + 1 while the other half's step t is still in flight
 };
 
 // One poll: lanes 0..n16-1 of the calling wave each fetch 16 bytes (two granules) of the observation area
@@ -123,9 +125,12 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
   for (int i = threadIdx.x; i < D * 128 * PI; i += 256) (&s_ring[0][0])[i] = 0ull;
   __syncthreads();
 
-  const int n_gran = p.W * S;            // <= 128 PI: lane l owns granules l + 64 j
+  // the window of observation granules this workgroup waits for: all of them, or (split) its row tile's rows -- S x 16 x 8 bytes = a multiple of 16
+  const int g0 = p.split ? rt * 16 * S : 0;
+  const int n_gran = p.split ? (p.W - 16 * rt < 16 ? p.W - 16 * rt : 16) * S : p.W * S;  // <= 128 PI: lane l owns granules g0 + l + 64 j
   const int n16 = (n_gran + 1) >> 1;     // 16-byte pieces per poll (two granules each); instruction q fetches pieces 64 q .. 64 q + 63
-  const char* my_src = reinterpret_cast<const char*>(p.obs_gran) + 16 * (lane < n16 ? lane : 0);
+  const char* my_src = reinterpret_cast<const char*>(p.obs_gran + g0) + 16 * (lane < n16 ? lane : 0);
+  const bool poller = !p.mbox || (p.split ? tile == 0 : blockIdx.x == 0);  // polls the HOST (and relays to its row tile / to everybody)
   unsigned long long next_issue = 0;
   int slot = 0;  // ring slot of the OLDEST poll in flight (wave 0)
   const unsigned ring_lane = (unsigned)(uintptr_t)&s_ring[0][0] + 8u * (unsigned)lane;  // LDS byte address of this lane's granule in slot 0
@@ -134,7 +139,7 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
   // also waits for the polls in flight and the previous step's PCIe store (measured: +2.4 us per step).  The
   // builtin (unlike an asm wait) clears the compiler's own scoreboard.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
-  if (wid == 0 && (!p.mbox || blockIdx.x == 0)) {
+  if (wid == 0 && poller) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -152,7 +157,7 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
     // workgroups poll that.  32 workgroups x 256 bytes of PCIe reads in flight queue behind each other on the
     // link's non-posted request tags (measured: every extra poll in flight per workgroup ADDS microseconds);
     // one poller sees the bare PCIe round trip, and the fan-out is an on-chip hand-off (~1 us).
-    if (wid == 0 && p.mbox && blockIdx.x != 0) {
+    if (wid == 0 && !poller) {
       bool ok = false;
       for (long spin = 0; spin < p.max_polls * 4; ++spin) {
         unsigned long long gq[NJ];
@@ -160,14 +165,14 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int g = 64 * j + lane;
-          gq[j] = (j == 0 || 64 * j < n_gran) ? __hip_atomic_load(p.mbox + (g < n_gran ? g : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          gq[j] = (j == 0 || 64 * j < n_gran) ? __hip_atomic_load(p.mbox + g0 + (g < n_gran ? g : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
           mine = mine && (g >= n_gran || (unsigned)(gq[j] >> 32) == tag);
         }
         if (__all(mine)) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int g = 64 * j + lane;
-            if (g < n_gran && (g / S) >> 4 == rt) s_x[par][(g / S) & 15][g % S] = __uint_as_float((unsigned)gq[j]);
+            const int g = 64 * j + lane, gg = g0 + g;
+            if (g < n_gran && (gg / S) >> 4 == rt) s_x[par][(gg / S) & 15][gg % S] = __uint_as_float((unsigned)gq[j]);
           }
           ok = true;
           break;
@@ -211,10 +216,10 @@ __global__ void __launch_bounds__(256, 1) jh_act_persist_kernel(PersistArgs p) {
         if (done) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int g = 64 * j + lane;
+            const int g = 64 * j + lane, gg = g0 + g;
             if (g < n_gran) {
-              if ((g / S) >> 4 == rt) s_x[par][(g / S) & 15][g % S] = __uint_as_float((unsigned)gq[j]);
-              if (p.mbox) __hip_atomic_store(p.mbox + g, gq[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: the granule is its own flag
+              if ((gg / S) >> 4 == rt) s_x[par][(gg / S) & 15][gg % S] = __uint_as_float((unsigned)gq[j]);
+              if (p.mbox) __hip_atomic_store(p.mbox + gg, gq[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: the granule is its own flag
             }
           }
         }
@@ -401,6 +406,7 @@ struct jh_persist {
   float4* dpart = nullptr;             // device: the column tiles' partial heads, summed by a wave of the kernel (round 6)
   bool reduced = false;                // the running kernel answers with ONE granule per (row, g) in tile 0's slots
   int rows_published = 0;              // rows of the last jh_persist_publish (a two-timestep exchange carries more rows than its first read asks for)
+  bool split = false;                  // the running kernel exchanges its two row tiles independently (jh_persist_publish_rows)
 };
 
 // heads needed to ACT: A logits (discrete) | A mu + A log_std (continuous) (ppo.py:55-69) -- plus the value head as the LAST
@@ -467,10 +473,12 @@ static void persist_launch(int depth, int pi, int grid, hipStream_t st, const Pe
 }
 
 // Launch the persistent kernel for T steps of W <= 32 rows (W * S <= 512 observation granules).
-int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
+// split: the two row tiles of a W = 32 exchange advance independently (tags per row tile; jh_persist_publish_rows / jh_persist_collect_rows).
+int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st, int split) {
   jh_pponet* n = p->net;
-  JH_ARG(W > 0 && W <= 32 && W * n->S <= kPersistMaxGranules && T > 0);
-  const int pi = ((W * n->S + 1) / 2 + 63) / 64;  // exactly the instructions that have a lane to fetch for (see the kernel)
+  JH_ARG(W > 0 && W <= 32 && W * n->S <= kPersistMaxGranules && T > 0 && (!split || W == 32));
+  const int win = split ? 16 * n->S : W * n->S;  // observation granules a workgroup polls
+  const int pi = ((win + 1) / 2 + 63) / 64;  // exactly the instructions that have a lane to fetch for (see the kernel)
   PersistArgs a{};
   a.W = W; a.S = n->S; a.H = n->H; a.T = T; a.G = p->G;
   a.W1 = n->params + n->o_w1; a.b1 = n->params + n->o_b1; a.W2 = n->params + n->o_w2; a.b2 = n->params + n->o_b2;
@@ -494,8 +502,10 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st) {
   // per step, more than the host's gather of the 48 KB it replaces (config.ppo.mujoco, 32 workers: publication-to-heads 15.2 us direct,
   // 15.8 us reduced; 8 workers: 6.9 vs 8.4 us).  The cross-XCD visibility of a store is the price, not the bytes.
   const int reduce = getenv("JH_PERSIST_REDUCE") ? atoi(getenv("JH_PERSIST_REDUCE")) : 0;  // (read per launch: the test below switches it)
-  p->reduced = reduce == 1;
+  p->reduced = reduce == 1 && !split;
   a.dpart = p->reduced ? p->dpart : nullptr;
+  a.split = split ? 1 : 0;
+  p->split = split != 0;
   a.max_polls = 600000;  // x (>= 0.3 us per consumed poll) = >= 0.2 s without observations -> give up
   p->flag_h[0] = 0;
   const int nch = n->H / 64;
@@ -530,9 +540,28 @@ unsigned jh_persist_publish(jh_persist* p, int W, const float* h_obs) {
   return tag;
 }
 
+// Split exchanges: publish rows r0 .. r1-1 (h_obs: the FULL [W][S] array) under `tag` = the persist's sequence number at jh_persist_begin + the step (1 ..).
+unsigned jh_persist_seq(const jh_persist* p) { return p->seq; }
+void jh_persist_publish_rows(jh_persist* p, int r0, int r1, const float* h_obs, unsigned tag) {
+  const int S = p->net->S;
+  if (r1 > p->rows_published) p->rows_published = r1;
+  for (int i = r0 * S; i < r1 * S; ++i) {
+    unsigned bits;
+    memcpy(&bits, h_obs + i, 4);
+    __atomic_store_n(p->gran_h + i, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELEASE);
+  }
+  if ((int)(tag - p->seq) > 0) p->seq = tag;
+}
+
 // Wait until every tile's granules of the listed rows (rows == NULL: rows 0 .. n_rows-1) carry `tag`, then sum the per-tile partials
 // in tile order: h_heads [n_rows][n_out] raw head outputs (logits | mu_raw, log_std_raw; value last).  JH_ERR_STATE if the kernel gave up.
+static int persist_collect(jh_persist* p, const int* rows, int n_rows, unsigned tag, float* h_heads, int r_first, bool block_order);
 int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned tag, float* h_heads) {
+  return persist_collect(p, rows, n_rows, tag, h_heads, 0, !rows && n_rows > 16);
+}
+// rows r0 .. r0 + n_rows - 1 in the blocks' storage order (a split exchange's half: 16 consecutive row granules per (tile, g) block)
+int jh_persist_collect_range(jh_persist* p, int r0, int n_rows, unsigned tag, float* h_heads) { return persist_collect(p, nullptr, n_rows, tag, h_heads, r0, true); }
+static int persist_collect(jh_persist* p, const int* rows, int n_rows, unsigned tag, float* h_heads, int r_first, bool block_order) {
   const int n_out = p->n_out, G = p->G, ld = p->rows_ld, tiles = p->reduced ? 1 : p->tiles;  // (reduced: the device summed the tiles; tile 0's slots hold the answer)
   volatile unsigned* abort_w = p->flag_h;
   // [tiles][G][ld] granules of 16 bytes {out, out, out, tag}: ONE 16-byte load per granule serves the tag check and the sum (the
@@ -543,7 +572,7 @@ int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned
   float z[32][12];
   unsigned char have[32];
   JH_ARG(n_rows <= 32);
-  if (!rows && n_rows > 16) {
+  if (block_order) {
     // All rows 0 .. n_rows-1 of a two-row-tile exchange (up to 16 rows keep the row-major walk below: for config.ppo.cartpole's 8
     // root rows the block order measured 1.4 % of the whole step SLOWER -- it waits block by block for rows the other order has
     // already summed): walk the
@@ -555,7 +584,7 @@ int jh_persist_collect_rows(jh_persist* p, const int* rows, int n_rows, unsigned
     long spins = 0;
     for (int t = 0; t < tiles; ++t)
       for (int g = 0; g < G; ++g) {
-        const Gran16* blk = part + ((size_t)t * G + g) * ld;
+        const Gran16* blk = part + ((size_t)t * G + g) * ld + r_first;
         for (;;) {  // every row's granule of this block carries the tag (tag first, acquire: see below)
           bool all = true;
           for (int k = 0; k < n_rows; ++k)

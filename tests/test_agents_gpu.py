@@ -741,6 +741,49 @@ def test_persistent_kernel_device_side_sum_of_the_partial_heads_is_bit_identical
             assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("cont,capture", [(True, True), (True, False), (False, True)])
+def test_collector_two_independent_halves_per_timestep_is_bit_identical(cont, capture, monkeypatch):
+    """Round 6: 32 workers are exchanged with the acting kernel as two independent halves of 16 (jh_collect.hip: run_loop_split -- half A's round trip runs under half
+    B's sampling, env steps and bookkeeping; tags per row tile in the kernel).  The same rows through the same arithmetic under the same sampling keys: the stored
+    transitions and the captured heads / values of two consecutive rollouts are bit-identical to the one-exchange-of-32 path (JH_COLLECT_SPLIT=0), for
+    config.ppo.mujoco's continuous policy and for a discrete one (CartPole, 32 workers: one timestep per exchange), with and without the acting-time capture."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+
+    W, T, S, A = 32, 24, 11 if cont else 4, 3 if cont else 2
+    if not capture:
+        monkeypatch.setenv("JH_COLLECT_CAPTURE", "0")
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("JH_COLLECT_SPLIT", mode)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        agent = Agent("ppo", state_size=S, action_size=A, hidden_size=512, network="continuous_policy_value" if cont else "discrete_policy_value", n_step=T, batch_size=256,
+                      n_epoch=1, device="cuda", seed=3, lr_decay=False, num_workers=W)
+        agent.memory.first_store = False
+        env = ops.ControlVec(W, S, A, seed=4) if cont else ops.CartPoleVec(W, seed=4)
+        col = NativeCollector(env, agent, W)
+        out = []
+        for it in range(3):
+            col.run(T)
+            torch.cuda.synchronize()
+            st, M = agent._static, W * T
+            store = agent.memory._store
+            rec = {k: npy(store.column(k)[:M]).copy() for k in ("state", "action", "reward", "next_state", "done")}
+            if capture:
+                rec.update(h0=npy(st["h0"]).copy(), value=npy(st["value"]).copy(), next_value=npy(st["next_value"]).copy())
+            out.append(rec)
+            agent.process(None, T * (it + 1))
+        res[mode] = (out, col.stats())
+        col.terminate()
+    for a, b in zip(res["0"][0], res["1"][0]):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    assert len({tuple(r["action"].reshape(-1)[:64]) for r in res["1"][0]}) == 3  # (three different rollouts, not one repeated)
+    print("acting host us per timestep: one exchange", res["0"][1]["act_us_per_step"] + res["0"][1]["env_us_per_step"], " two halves", res["1"][1]["act_us_per_step"] + res["1"][1]["env_us_per_step"])
+
+
 @pytest.mark.parametrize("forkable,where", [(False, "step"), (True, "step"), (True, "copy_row")])
 def test_c_collector_stops_when_the_env_fails(forkable, where, capfd):
     """jh_env_vtbl's contract: obs / step return a negative status and the run STOPS.  A Python env that raises in the middle of a rollout --
