@@ -670,7 +670,8 @@ def hopper_leg(rank, world, local_rank, dist, iters):
         try:
             ee = _tool("bench_hopper").hopper_leg(iters=max(1, min(2, iters)), warmup=4, workers=W, batch=B, e2e=True, dist=None, device=f"cuda:{local_rank}")
             r["end_to_end"] = {"env_transitions_per_s": ee["env_transitions_per_s_end_to_end"], "ms_per_iteration": ee["ms_per_iteration"], "collector": ee["collector"],
-                               "workload": ee["workload"], "acting": "persistent acting kernel, one launch per rollout: 32 rows x 11 observations = 352 granules per exchange (three poll instructions per poll, two row tiles)"}
+                               "workload": ee["workload"], "acting": "persistent acting kernel, one launch per rollout; round 6: the 32 rows go as two INDEPENDENT halves of 16 (176 observation granules each, tags per row tile): "
+                                         "one half's round trip runs under the other half's sampling, env steps and bookkeeping (JH_COLLECT_SPLIT=0: one exchange of 352 granules)"}
         except Exception as e:
             r["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
         # ... and what ONE of the config's eight GPUs runs (4 workers, 256 minibatch rows per GPU: the layout `--gpus 8` measures), end to end on this GPU
