@@ -501,8 +501,10 @@ int jh_persist_begin(jh_persist* p, int W, int T, hipStream_t st, int split) {
   // on-device hand-off -- write-through granules of 64 workgroups on 8 XCDs, fetched agent-coherently by one workgroup -- costs 3.2 us
   // per step, more than the host's gather of the 48 KB it replaces (config.ppo.mujoco, 32 workers: publication-to-heads 15.2 us direct,
   // 15.8 us reduced; 8 workers: 6.9 vs 8.4 us).  The cross-XCD visibility of a store is the price, not the bytes.
-  const int reduce = getenv("JH_PERSIST_REDUCE") ? atoi(getenv("JH_PERSIST_REDUCE")) : 0;  // (read per launch: the test below switches it)
-  p->reduced = reduce == 1 && !split;
+  // ... but ON by default for SPLIT exchanges (end of round 6): there the extra hand-off latency hides under the other half's host work, and what is left on the
+  // host's critical path -- reading 48 KB of partial heads per timestep (~4 us) -- shrinks to 1.5 KB: configs[4] end to end 0.79 -> 0.88 M env transitions/s.
+  const int reduce = getenv("JH_PERSIST_REDUCE") ? atoi(getenv("JH_PERSIST_REDUCE")) : (split ? 1 : 0);  // (read per launch: the tests switch it)
+  p->reduced = reduce == 1;
   a.dpart = p->reduced ? p->dpart : nullptr;
   a.split = split ? 1 : 0;
   p->split = split != 0;
