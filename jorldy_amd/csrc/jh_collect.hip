@@ -537,6 +537,10 @@ static int run_loop_split(jh_collector* c, int training, hipStream_t stream_h, i
   const int no = jh_persist_heads(c->persist);
   const unsigned base = jh_persist_seq(c->persist);  // the kernel's tags are base + 1 .. base + steps, for each half on its own
   bool dead = false;  // the kernel gave up while half 1 of a timestep was owed: that half is finished by hand, then the per-step path takes over
+  // test hook (tests/test_agents_gpu.py): JH_COLLECT_TEST_STALL="<timestep>,<half>" makes the host sit idle for 0.35 s in front of that half's read, which is what a
+  // stalled environment looks like to the acting kernel (it gives up after ~0.2 s without observations): exercises the hand-over to one launch per step
+  int stall_t = -1, stall_h = -1;
+  if (const char* e = getenv("JH_COLLECT_TEST_STALL")) (void)sscanf(e, "%d,%d", &stall_t, &stall_h);
   *t_done = 0;
   int rc = c->vt.obs(c->env, 0, W, c->obs.data());
   if (rc) { jh_persist_abort(c->persist); return rc; }
@@ -546,6 +550,10 @@ static int run_loop_split(jh_collector* c, int training, hipStream_t stream_h, i
     for (int h = 0; h < 2; ++h) {
       const int r0 = h * HR, r1 = r0 + HR;
       const auto t0 = std::chrono::steady_clock::now();
+      if (t == stall_t && h == stall_h) {
+        // (the OTHER half's workgroups are the ones starved: this half's observations are out already)
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.35) {}
+      }
       rc = jh_persist_collect_range(c->persist, r0, HR, base + (unsigned)t + 1, c->heads.data() + (size_t)r0 * no);
       if (rc) {  // the kernel gave up (it exits by itself)
         jh_persist_abort(c->persist);

@@ -784,6 +784,50 @@ def test_collector_two_independent_halves_per_timestep_is_bit_identical(cont, ca
     print("acting host us per timestep: one exchange", res["0"][1]["act_us_per_step"] + res["0"][1]["env_us_per_step"], " two halves", res["1"][1]["act_us_per_step"] + res["1"][1]["env_us_per_step"])
 
 
+@pytest.mark.parametrize("stall", ["5,0", "5,1"])
+def test_collector_two_halves_hands_over_to_one_launch_per_step_when_the_kernel_gives_up(stall, monkeypatch):
+    """A stalled environment (no observations for ~0.2 s) makes the persistent acting kernel give up; jh_collector_run then finishes the rollout with one launch per
+    timestep.  With the two halves out of phase the hand-over happens either with both halves at the same timestep (the stall sits in front of half 0's read) or with
+    half 1 of a timestep still owed (in front of half 1's: that half is finished from one launch over its 16 rows, sampled under its rows' own stream keys).  The
+    test hook JH_COLLECT_TEST_STALL idles the host for 0.35 s at that point.  The rollout completes, every worker's trajectory is continuous, the next run is normal."""
+    from jorldy_amd import ops
+    from jorldy_amd.core.agent import Agent
+    from jorldy_amd.manager import NativeCollector
+
+    W, T, S, A = 32, 16, 11, 3
+    torch.manual_seed(5)
+    np.random.seed(5)
+    agent = Agent("ppo", state_size=S, action_size=A, hidden_size=512, network="continuous_policy_value", n_step=T, batch_size=256, n_epoch=1, device="cuda", seed=3,
+                  lr_decay=False, num_workers=W)
+    agent.memory.first_store = False
+    col = NativeCollector(ops.ControlVec(W, S, A, seed=4), agent, W)
+    for it, env_stall in enumerate((None, stall, None)):
+        if env_stall is None:
+            monkeypatch.delenv("JH_COLLECT_TEST_STALL", raising=False)
+        else:
+            monkeypatch.setenv("JH_COLLECT_TEST_STALL", env_stall)
+        import time
+
+        t_run = time.perf_counter()
+        col.run(T)
+        torch.cuda.synchronize()
+        t_run = time.perf_counter() - t_run
+        # the hook ran (0.35 s), the dead kernel was noticed at once (its give-up word: no 40 M-spin wait), the rest took per-step launches; an undisturbed run is ~1 ms
+        assert (0.35 <= t_run < 2.0) if env_stall else t_run < 0.2, t_run
+        M = W * T
+        store = agent.memory._store
+        rec = {k: npy(store.column(k)[:M]).reshape(W, T, -1) for k in ("state", "action", "reward", "next_state", "done")}
+        assert all(np.isfinite(v).all() for v in rec.values()) and np.abs(rec["action"]).max() <= 1.0
+        cont = rec["done"][:, :-1, 0] == 0  # where the episode goes on, the next row starts where this one ended
+        assert np.array_equal(rec["next_state"][:, :-1][cont], rec["state"][:, 1:][cont])
+        assert len(np.unique(rec["action"].reshape(M, -1), axis=0)) > M // 2  # sampled, not a constant
+        st = agent._static
+        assert np.isfinite(npy(st["value"])).all() and np.isfinite(npy(st["next_value"])).all() and np.isfinite(npy(st["h0"])).all()
+        result = agent.process(None, T * (it + 1))
+        assert np.isfinite(result["actor_loss"]) and np.isfinite(result["critic_loss"])
+    col.terminate()
+
+
 @pytest.mark.parametrize("forkable,where", [(False, "step"), (True, "step"), (True, "copy_row")])
 def test_c_collector_stops_when_the_env_fails(forkable, where, capfd):
     """jh_env_vtbl's contract: obs / step return a negative status and the run STOPS.  A Python env that raises in the middle of a rollout --
