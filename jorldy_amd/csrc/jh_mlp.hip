@@ -1134,7 +1134,11 @@ static int pponet_l1(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx
 // minibatch update and of every no-grad pass.  Layer 1 is generated in registers for S <= 8.
 static int pponet_forward_partials(jh_pponet* n, int B, const float* d_x, const int64_t* d_idx, hipStream_t st) {
   const PmbHeads hd = pmb_heads(n);
-  if (n->S <= 8) return jh_pmb_forward(n, B, d_x, d_idx, hd, nullptr, true, st);
+  // layer 1 generated inside the forward kernel up to 8 observations.  JH_PMB_GEN16=1 (round 6, tried): up to 16, through scalar LDS reads of the W1 rows -- correct
+  // (the parity suites pass) and SLOWER at Hopper's S = 11: the forward launch goes from 15.5 to 31.4 us to save a 6.5 us layer-1 launch (36.8 vs 33.3 ms per iteration
+  // of configs[4]'s per-GPU share), so the separate launch stays
+  static const int gen_max = (getenv("JH_PMB_GEN16") && atoi(getenv("JH_PMB_GEN16")) == 1) ? 16 : 8;
+  if (n->S <= gen_max) return jh_pmb_forward(n, B, d_x, d_idx, hd, nullptr, true, st);
   int rc = pponet_l1(n, B, d_x, d_idx, st);
   if (rc) return rc;
   return jh_pmb_forward(n, B, d_x, d_idx, hd, n->h1, true, st);

@@ -46,9 +46,12 @@ struct PmbFwd {
   int part_rows, part_ld;
 };
 
-// SV: S == 4 * SV -> W1 rows / observations as float4 (SV = 1, 2); SV = 0: any S <= 8, scalar loads
+// SV: S == 4 * SV -> W1 rows / observations as float4 (SV = 1, 2); SV = 0: any S <= 8, scalar loads; SV = 3 (round 6): any S <= 16, scalar loads
+// (config.ppo.mujoco's Hopper, S = 11: layer 1 used to be a launch of its own in front of this one)
 template <int SV, bool GEN, int U>
 __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
+  constexpr bool VEC = SV == 1 || SV == 2;
+  constexpr int XS = SV == 3 ? 16 : 8;
   __shared__ float s_acc[4][64][4];
   // GEN: each wave stages the W1 rows + biases of ITS K quarter in LDS once ([kper][S] | [kper] per wave).  Read straight
   // from global memory, hipcc fetches them chunk by chunk behind an s_waitcnt vmcnt(0) each: eight serial L2 round
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
   // own s_waitcnt vmcnt(0), bias / head columns, W2).  Now every independent fetch of the workgroup is in flight before the first
   // wait: staging operands first (they are needed first and vmcnt retires in issue order), then the first batch of W2 rows and the
   // epilogue operands; the staging data is written to LDS while W2 is still on its way.  Same arithmetic, same bits.
-  float xr[8];
+  float xr[XS];
   int64_t row = mc;
   if (GEN && g.x_rows) row = g.x_rows[mc];
   float* w1s = s_dyn + (size_t)wid * kper * (g.S + 1);
@@ -81,7 +84,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
   const int wi0 = lane * 4 < n_el ? lane * 4 : 0, wi1 = (lane + 64) * 4 < n_el ? (lane + 64) * 4 : 0;
   const int wi2 = (lane + 128) * 4 < n_el ? (lane + 128) * 4 : 0, wi3 = (lane + 192) * 4 < n_el ? (lane + 192) * 4 : 0;
   const int bi0 = 4 * lane < kn ? 4 * lane : 0;
-  if (GEN && SV > 0) {  // (unconditional, clamped addresses: an empty wave -- H < 64 -- re-reads element 0)
+  if (GEN && VEC) {  // (unconditional, clamped addresses: an empty wave -- H < 64 -- re-reads element 0)
     const int kb0 = kn > 0 ? kbeg : 0;
     const float* src = g.W1 + (size_t)kb0 * g.S;
     w1t0 = *reinterpret_cast<const float4*>(src + wi0);
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
     __builtin_amdgcn_sched_barrier(0);  // keep them FIRST in the queue (the machine scheduler moved them behind the W2 rows)
   }
   if (GEN) {
-    if (SV > 0) {
+    if (VEC) {
 #pragma unroll
       for (int q = 0; q < SV; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(g.x + row * g.S + 4 * q);
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
       }
     } else {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) xr[s] = s < g.S ? g.x[row * g.S + s] : 0.f;
+      for (int s = 0; s < XS; ++s) xr[s] = s < g.S ? g.x[row * g.S + s] : 0.f;
     }
   }
   // first batch of weight rows + the epilogue operands (bias, head weight columns): in flight behind the staging fetches
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
 #pragma unroll
   for (int o = 0; o < 8; ++o) whv[o] = o < g.n_out ? g.wh[o][n] : 0.f;
   if (GEN) {
-    if (SV > 0) {
+    if (VEC) {
       // UNCONDITIONAL stores: a lane beyond the slice fetched element 0 and rewrites it with the same bits -- behind an `if` LLVM
       // sinks each fetch into its store's block and the staging is four serial round trips again
       *reinterpret_cast<float4*>(w1s + wi0) = w1t0;
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float t = 0.f;
-          if (SV > 0) {
+          if (VEC) {
 #pragma unroll
             for (int q = 0; q < SV; ++q) {
               const float4 w = *reinterpret_cast<const float4*>(w1s + (size_t)(kc - kbeg + j) * g.S + 4 * q);
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
             }
           } else {
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < XS; ++s)
               if (s < g.S) t = fmaf(xr[s], w1s[(size_t)(kc - kbeg + j) * g.S + s], t);
           }
           t += bj[j];
@@ -682,6 +685,7 @@ int jh_pmb_forward(jh_pponet* n, int M, const float* d_x, const int64_t* d_idx, 
   const bool al = (((uintptr_t)d_x) & 15) == 0 && (((uintptr_t)g.W1) & 15) == 0;
   if (n->S == 4 && al) return pmb_fwd_launch<1, true>(g, st);
   if (n->S == 8 && al) return pmb_fwd_launch<2, true>(g, st);
+  if (n->S > 8) return pmb_fwd_launch<3, true>(g, st);  // 9 .. 16 observations
   return pmb_fwd_launch<0, true>(g, st);
 }
 
