@@ -74,8 +74,10 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
   float xr[XS];
   int64_t row = mc;
   if (GEN && g.x_rows) row = g.x_rows[mc];
-  float* w1s = s_dyn + (size_t)wid * kper * (g.S + 1);
-  float* b1s = w1s + (size_t)kper * g.S;
+  // SV == 3: the staged W1 rows are padded to a multiple of four floats (zeros), so that the generation reads them as float4s like the S = 4 / 8 forms
+  const int ws = SV == 3 ? ((g.S + 3) & ~3) : g.S;  // row stride of the staged W1 rows
+  float* w1s = s_dyn + (size_t)wid * kper * (ws + 1);
+  float* b1s = w1s + (size_t)kper * ws;
   const int kn = kend > kbeg ? kend - kbeg : 0;
   constexpr int WB = 4;  // W1 float4s per lane and staging pass (H = 512: S = 4 needs 2, S = 8 needs 4); scalars, not an array: with
                          // the scheduling barrier below an array stayed in scratch memory
@@ -131,7 +133,18 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
       for (int i = 4 * (lane + 64); i < kn; i += 256) *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(g.b1 + kbeg + i);
     } else {
       const float* src = g.W1 + (size_t)kbeg * g.S;
-      for (int i = lane; i < n_el; i += 64) w1s[i] = src[i];
+      if (SV == 3) {
+        for (int i = lane; i < n_el; i += 64) {
+          const int rr = i / g.S, cc = i - rr * g.S;
+          w1s[rr * ws + cc] = src[i];
+        }
+        for (int i = lane; i < kn * (ws - g.S); i += 64) {
+          const int rr = i / (ws - g.S), cc = g.S + (i - rr * (ws - g.S));
+          w1s[rr * ws + cc] = 0.f;
+        }
+      } else {
+        for (int i = lane; i < n_el; i += 64) w1s[i] = src[i];
+      }
       for (int i = lane; i < kn; i += 64) b1s[i] = g.b1[kbeg + i];
     }
     // wave-local hand-off: this wave's own ds_writes are ordered before its ds_reads
@@ -177,6 +190,15 @@ __global__ void __launch_bounds__(256) jh_pmb_fwd_kernel(PmbFwd g) {
             for (int q = 0; q < SV; ++q) {
               const float4 w = *reinterpret_cast<const float4*>(w1s + (size_t)(kc - kbeg + j) * g.S + 4 * q);
               t = fmaf(xr[4 * q], w.x, t); t = fmaf(xr[4 * q + 1], w.y, t); t = fmaf(xr[4 * q + 2], w.z, t); t = fmaf(xr[4 * q + 3], w.w, t);
+            }
+          } else if (SV == 3) {
+            // (the pad columns hold 0 in xr AND in the staged row: fmaf(0, 0, t) == t, t is never -0 -- the chain over s < S is jh_mlp_l1_kernel's)
+#pragma unroll
+            for (int q = 0; q < XS / 4; ++q) {
+              if (4 * q < ws) {
+                const float4 w = *reinterpret_cast<const float4*>(w1s + (size_t)(kc - kbeg + j) * ws + 4 * q);
+                t = fmaf(xr[4 * q], w.x, t); t = fmaf(xr[4 * q + 1], w.y, t); t = fmaf(xr[4 * q + 2], w.z, t); t = fmaf(xr[4 * q + 3], w.w, t);
+              }
             }
           } else {
 #pragma unroll
@@ -665,7 +687,7 @@ static int pmb_fwd_launch(const PmbFwd& g, hipStream_t st) {
   // flops: layer 1 (generated) + the H x H contraction + the heads
   const double fl = 2.0 * g.M * (double)g.H * ((GEN ? g.S : 0) + g.H + g.n_out);
   const char* nm = g.M > 1024 ? "jh_pmb_fwd_nograd" : "jh_pmb_fwd";  // the no-grad pass over [state; next_state] vs a minibatch
-  const size_t lds = GEN ? sizeof(float) * 4 * (size_t)kper * (g.S + 1) : 0;
+  const size_t lds = GEN ? sizeof(float) * 4 * (size_t)kper * ((SV == 3 ? ((g.S + 3) & ~3) : g.S) + 1) : 0;
   if (kper > 64) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 8>), dim3(tiles), dim3(256), lds, st, g);
   else if (kper > 32) JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 4>), dim3(tiles), dim3(256), lds, st, g);
   else JH_LAUNCH_IDEM(nm, fl, (jh_pmb_fwd_kernel<SV, GEN, 2>), dim3(tiles), dim3(256), lds, st, g);
